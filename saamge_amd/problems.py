@@ -1,0 +1,285 @@
+"""Synthetic problem generators: the *inputs* of the hot path.
+
+These stand in for the MFEM-side problem setup of the reference (which is out of
+scope, SURVEY.md section 2 row "fem"): they produce exactly the arrays the reference
+hands to ``agg_create_partitioning_fine`` / ``ml_produce_data``
+(reference: amg/src/fem.cpp:687-717, amg/inc/fem.hpp:427-448,
+amg/test/mltest/mltest.cpp:481-621):
+
+* ``A``            global CSR stiffness matrix, essential rows/cols eliminated with
+                   the diagonal kept, explicit zeros left in place (``Finalize(0)``)
+* ``elem_to_dof``  NE x nde int32 (fixed number of dofs per element)
+* ``elmat``        NE x nde x nde fp64 raw (un-eliminated) element matrices
+* ``bdr``          ND int8 flags, bit 0x02 = on essential boundary
+                   (reference: amg/inc/aggregates.hpp:102-105)
+* ``b``            right-hand side with essential entries zeroed
+* ``partitions``   list of element->AE maps, one per coarsening
+
+Everything is numpy on the host; nothing here is timed by bench.py.
+"""
+import numpy as np
+import scipy.sparse as sp
+
+AGG_BETWEEN_AES_FLAG = 0x01
+AGG_ON_ESS_DOMAIN_BORDER_FLAG = 0x02
+AGG_ON_PROC_IFACE_FLAG = 0x04
+AGG_OWNED_FLAG = 0x08
+
+
+class Problem(object):
+    """Plain container of the hot-path inputs."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    @property
+    def ND(self):
+        return self.A.shape[0]
+
+    @property
+    def NE(self):
+        return self.elem_to_dof.shape[0]
+
+
+# --------------------------------------------------------------------------
+# 1-D building blocks
+# --------------------------------------------------------------------------
+def _lagrange_1d(order):
+    """1-D mass and stiffness matrices on [0,1] for equispaced Lagrange nodes."""
+    nodes = np.linspace(0.0, 1.0, order + 1)
+    # Gauss-Legendre with enough points to be exact for degree 2*order
+    xg, wg = np.polynomial.legendre.leggauss(order + 2)
+    xg = 0.5 * (xg + 1.0)
+    wg = 0.5 * wg
+    n = order + 1
+    phi = np.ones((n, xg.size))
+    dphi = np.zeros((n, xg.size))
+    for i in range(n):
+        for j in range(n):
+            if j != i:
+                phi[i] *= (xg - nodes[j]) / (nodes[i] - nodes[j])
+        for k in range(n):
+            if k == i:
+                continue
+            t = np.ones_like(xg) / (nodes[i] - nodes[k])
+            for j in range(n):
+                if j != i and j != k:
+                    t *= (xg - nodes[j]) / (nodes[i] - nodes[j])
+            dphi[i] += t
+    M = (phi * wg) @ phi.T
+    K = (dphi * wg) @ dphi.T
+    L = phi @ wg
+    return M, K, L
+
+
+def _assemble(ND, elem_to_dof, elmat):
+    """Sum element matrices in ascending element order (MFEM Assemble order)."""
+    NE, nde = elem_to_dof.shape
+    rows = np.repeat(elem_to_dof, nde, axis=1).ravel()
+    cols = np.tile(elem_to_dof, (1, nde)).ravel()
+    A = sp.coo_matrix((elmat.ravel(), (rows, cols)), shape=(ND, ND)).tocsr()
+    A.sort_indices()
+    return A
+
+
+def _eliminate(A, b, ess):
+    """EliminateEssentialBCFromDofs(ess, x=0, b, keep_diag=true) then Finalize(0):
+    zero rows/cols of essential dofs, keep the diagonal, keep explicit zeros
+    (reference: amg/inc/fem.hpp:438-448)."""
+    A = A.tocsr().copy()
+    ess = np.asarray(ess, dtype=bool)
+    row_of = np.repeat(np.arange(A.shape[0]), np.diff(A.indptr))
+    kill = (ess[row_of] | ess[A.indices]) & (row_of != A.indices)
+    A.data[kill] = 0.0
+    b = b.copy()
+    b[ess] = 0.0
+    return A, b
+
+
+# --------------------------------------------------------------------------
+# mltest.mesh fixture (reference: amg/test/mltest.mesh, mltest.cpp:196-295)
+# --------------------------------------------------------------------------
+MLTEST_PARTITION = np.array([0, 0, 1, 1, 0, 0, 2, 2, 3, 3, 3, 2], dtype=np.int32)
+MLTEST_COARSE_PARTITION = np.array([0, 0, 1, 1], dtype=np.int32)
+# 2-rank fixture: element -> rank and per-rank AE maps (mltest.cpp:230-241,279-286)
+MLTEST_RANK_OF_ELEM = np.array([0] * 6 + [1] * 6, dtype=np.int32)
+MLTEST_PARTITION_2RANKS = [np.array([0, 0, 1, 1, 0, 0], dtype=np.int32),
+                           np.array([0, 0, 1, 1, 1, 0], dtype=np.int32)]
+
+
+def checkerboard_coef(x, y, z=None):
+    """Reference: amg/test/mltest/mltest.cpp:156-175."""
+    d = 10.0
+    cx = np.ceil(x * d).astype(np.int64) & 1
+    cy = np.ceil(y * d).astype(np.int64) & 1
+    if z is None:
+        hi = cx == cy
+    else:
+        cz = np.ceil(z * d).astype(np.int64) & 1
+        hi = np.where(cz == 1, cx == cy, cx != cy)
+    return np.where(hi, 1e6, 1e0)
+
+
+def quad_mesh_problem(nx, ny, lx=1.0, ly=1.0, order=1, coef="checkerboard",
+                      ess_sides=("left",), partition=None):
+    """2-D tensor grid of rectangles with Q1/Q2 Lagrange elements.
+
+    Vertex numbering is row-major (x fastest), which is exactly mltest.mesh's
+    vertex numbering for nx=4, ny=3.  Element vertex order is MFEM's
+    counter-clockwise (v00, v10, v11, v01).  For order 2 the extra dofs are
+    numbered after the vertices: x-edges, y-edges, then element interiors
+    (MFEM's own edge numbering differs; the solver is invariant to it).
+    """
+    hx, hy = lx / nx, ly / ny
+    NE = nx * ny
+    ex, ey = np.meshgrid(np.arange(nx), np.arange(ny), indexing="xy")
+    ex = ex.ravel()
+    ey = ey.ravel()
+    nvx, nvy = nx + 1, ny + 1
+    vid = lambda i, j: j * nvx + i
+    M1, K1, L1 = _lagrange_1d(order)
+    if order == 1:
+        ND = nvx * nvy
+        elem_to_dof = np.stack([vid(ex, ey), vid(ex + 1, ey),
+                                vid(ex + 1, ey + 1), vid(ex, ey + 1)], axis=1)
+        # tensor index (ix, iy) of each local dof in MFEM order
+        loc = [(0, 0), (1, 0), (1, 1), (0, 1)]
+        xs = np.tile(np.arange(nvx) * hx, nvy)
+        ys = np.repeat(np.arange(nvy) * hy, nvx)
+    elif order == 2:
+        nV = nvx * nvy
+        nEx = nx * nvy          # horizontal edges
+        nEy = nvx * ny          # vertical edges
+        ND = nV + nEx + nEy + NE
+        xedge = lambda i, j: nV + j * nx + i
+        yedge = lambda i, j: nV + nEx + j * nvx + i
+        inter = nV + nEx + nEy + (ey * nx + ex)
+        elem_to_dof = np.stack([vid(ex, ey), vid(ex + 1, ey), vid(ex + 1, ey + 1),
+                                vid(ex, ey + 1), xedge(ex, ey), yedge(ex + 1, ey),
+                                xedge(ex, ey + 1), yedge(ex, ey), inter], axis=1)
+        loc = [(0, 0), (2, 0), (2, 2), (0, 2), (1, 0), (2, 1), (1, 2), (0, 1), (1, 1)]
+        xs = np.zeros(ND)
+        ys = np.zeros(ND)
+        for k, (ix, iy) in enumerate(loc):
+            xs[elem_to_dof[:, k]] = (ex + 0.5 * ix) * hx
+            ys[elem_to_dof[:, k]] = (ey + 0.5 * iy) * hy
+    else:
+        raise ValueError("order must be 1 or 2")
+    nde = len(loc)
+    n1 = order + 1
+    # reference element matrix in tensor ordering (ix fastest): K = Kx(x)My + Mx(x)Ky
+    Kt = (hy / hx) * np.kron(M1, K1) + (hx / hy) * np.kron(K1, M1)
+    Lt = hx * hy * np.kron(L1, L1)
+    perm = np.array([iy * n1 + ix for (ix, iy) in loc])
+    Kref = Kt[np.ix_(perm, perm)]
+    Lref = Lt[perm]
+    cx = (ex + 0.5) * hx
+    cy = (ey + 0.5) * hy
+    if coef == "checkerboard":
+        c = checkerboard_coef(cx, cy)
+    else:
+        c = np.full(NE, float(coef))
+    elmat = c[:, None, None] * Kref[None, :, :]
+    elem_to_dof = elem_to_dof.astype(np.int32)
+    A0 = _assemble(ND, elem_to_dof, elmat)
+    b0 = np.zeros(ND)
+    np.add.at(b0, elem_to_dof.ravel(), np.tile(Lref, NE))
+    eps = 1e-12
+    ess = np.zeros(ND, dtype=bool)
+    for s in ess_sides:
+        if s == "left":
+            ess |= xs < eps
+        elif s == "right":
+            ess |= xs > lx - eps
+        elif s == "bottom":
+            ess |= ys < eps
+        elif s == "top":
+            ess |= ys > ly - eps
+    A, b = _eliminate(A0, b0, ess)
+    bdr = np.where(ess, AGG_ON_ESS_DOMAIN_BORDER_FLAG, 0).astype(np.int8) | AGG_OWNED_FLAG
+    bdr = bdr.astype(np.int8)
+    return Problem(A=A, b=b, elem_to_dof=elem_to_dof, elmat=np.ascontiguousarray(elmat),
+                   bdr=bdr, ess=ess, partitions=partition, dims=(nx, ny), order=order,
+                   coords=np.stack([xs, ys], axis=1))
+
+
+def mltest_problem(order=1, levels=2):
+    """The reference's ctest fixture `mltest` / `mltest2` / `threelevel`
+    (amg/CMakeLists.txt:191-217): mltest.mesh (4x3 rectangles on the unit square;
+    the file's 0.333333333 vertex coordinates are taken as exact thirds),
+    checkerboard 1e6/1 coefficient sampled at element centres, essential boundary
+    = attribute 4 (x = 0), f = 1, hard-coded AE maps."""
+    parts = [MLTEST_PARTITION.copy()]
+    if levels >= 3:
+        parts.append(MLTEST_COARSE_PARTITION.copy())
+    return quad_mesh_problem(4, 3, order=order, coef="checkerboard",
+                             ess_sides=("left",), partition=parts)
+
+
+# --------------------------------------------------------------------------
+# structured 3-D hexahedral Poisson
+# --------------------------------------------------------------------------
+_HEX_LOC = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0),
+            (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)]
+
+
+def hex_element_matrix(h, K=(1.0, 1.0, 1.0)):
+    """Closed-form trilinear stiffness on an h[0] x h[1] x h[2] box, MFEM vertex order."""
+    M1, K1, _ = _lagrange_1d(1)
+    hx, hy, hz = h
+    Kt = (K[0] * (hy * hz / hx) * np.kron(M1, np.kron(M1, K1)) +
+          K[1] * (hx * hz / hy) * np.kron(M1, np.kron(K1, M1)) +
+          K[2] * (hx * hy / hz) * np.kron(K1, np.kron(M1, M1)))
+    perm = np.array([(iz * 2 + iy) * 2 + ix for (ix, iy, iz) in _HEX_LOC])
+    return Kt[np.ix_(perm, perm)]
+
+
+def block_partition(n, blk):
+    """element (x fastest) -> AE id for axis-aligned blocks of blk elements; AE ids x fastest."""
+    nx, ny, nz = n
+    bx, by, bz = blk
+    nbx, nby = -(-nx // bx), -(-ny // by)
+    ez, eyy, exx = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    part = ((ez // bz) * nby + (eyy // by)) * nbx + (exx // bx)
+    return part.ravel().astype(np.int32), (nbx, nby, -(-nz // bz))
+
+
+def poisson3d_problem(n, blk=(8, 8, 4), K=(1.0, 1.0, 1.0), coarse_blk=None,
+                      coef=None, with_elmat=True):
+    """Unit cube, n^3 (or n = (nx,ny,nz)) Q1 hexes, Dirichlet on all six faces
+    (diagonal kept), f = 1.  AE partition = blocks of `blk` elements; optional
+    further coarsenings = blocks of `coarse_blk` AEs (list of triples).
+    `coef`: None (constant 1) or "checkerboard"."""
+    if np.isscalar(n):
+        n = (int(n),) * 3
+    nx, ny, nz = n
+    h = (1.0 / nx, 1.0 / ny, 1.0 / nz)
+    nvx, nvy, nvz = nx + 1, ny + 1, nz + 1
+    ND = nvx * nvy * nvz
+    NE = nx * ny * nz
+    ez, ey, ex = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    ex, ey, ez = ex.ravel(), ey.ravel(), ez.ravel()
+    vid = lambda i, j, k: (k * nvy + j) * nvx + i
+    elem_to_dof = np.stack([vid(ex + a, ey + b_, ez + c) for (a, b_, c) in _HEX_LOC],
+                           axis=1).astype(np.int32)
+    Kref = hex_element_matrix(h, K)
+    if coef == "checkerboard":
+        c = checkerboard_coef((ex + 0.5) * h[0], (ey + 0.5) * h[1], (ez + 0.5) * h[2])
+    else:
+        c = np.ones(NE)
+    elmat = c[:, None, None] * Kref[None, :, :]
+    A0 = _assemble(ND, elem_to_dof, elmat)
+    b0 = np.zeros(ND)
+    np.add.at(b0, elem_to_dof.ravel(), h[0] * h[1] * h[2] / 8.0)
+    iz, iy, ix = np.meshgrid(np.arange(nvz), np.arange(nvy), np.arange(nvx), indexing="ij")
+    ess = ((ix == 0) | (ix == nx) | (iy == 0) | (iy == ny) | (iz == 0) | (iz == nz)).ravel()
+    A, b = _eliminate(A0, b0, ess)
+    bdr = (np.where(ess, AGG_ON_ESS_DOMAIN_BORDER_FLAG, 0) | AGG_OWNED_FLAG).astype(np.int8)
+    part0, nb = block_partition(n, blk)
+    parts = [part0]
+    for cb in (coarse_blk or []):
+        p, nb = block_partition(nb, cb)
+        parts.append(p)
+    return Problem(A=A, b=b, elem_to_dof=elem_to_dof,
+                   elmat=np.ascontiguousarray(elmat) if with_elmat else None,
+                   bdr=bdr, ess=ess, partitions=parts, dims=n, order=1, Kref=Kref, coefs=c)
