@@ -1,0 +1,127 @@
+/* saamge_amd -- C ABI of the MI355X-native SAAMGE hot path (setup + solve).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  Every
+ * entry point names the reference interface (LLNL/saamge, paths relative to amg/) it
+ * replaces.  Array arguments may be HOST or DEVICE pointers unless stated otherwise:
+ * device pointers are used in place (zero copy), host pointers are uploaded once.
+ * All indices are 32-bit like the reference's hypre/MFEM `int`; all reals are fp64.
+ *
+ * Return value: 0 on success, non-zero on failure (the reference aborts through
+ * SA_ASSERT -> MPI_Abort, inc/common.hpp:635-647; here the message is kept in
+ * saamge_amd_last_error()).  Not thread-safe (neither is the reference: global
+ * singletons, src/process.cpp:46-48); one hierarchy may be used from one thread at a time.
+ */
+#ifndef SAAMGE_AMD_H
+#define SAAMGE_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAAMGE_AMD_MAX_LEVELS 8
+
+/* agg_dof_status_t bit flags, inc/aggregates.hpp:102-105 */
+#define SAAMGE_AMD_BETWEEN_AES 0x01
+#define SAAMGE_AMD_ON_ESS_DOMAIN_BORDER 0x02
+#define SAAMGE_AMD_ON_PROC_IFACE 0x04
+#define SAAMGE_AMD_OWNED 0x08
+
+typedef struct saamge_amd_hierarchy saamge_amd_hierarchy; /* == ml_data_t, inc/ml.hpp:118-120 */
+
+/* == MultilevelParameters, inc/ml.hpp:59-114 (+ the hidden defaults of src/ml.cpp:64-67) */
+typedef struct saamge_amd_params {
+    int num_coarsenings;                      /* levels - 1 */
+    double theta[SAAMGE_AMD_MAX_LEVELS];      /* spectral tolerance per coarsening */
+    int nu_relax[SAAMGE_AMD_MAX_LEVELS];      /* smoother: SAS polynomial of degree 3 nu + 1 */
+    int nu_pro[SAAMGE_AMD_MAX_LEVELS];        /* prolongator smoothing degree (0 only, this round) */
+    int avoid_ess_bdr_dofs;                   /* src/ml.cpp:64, always true in the reference */
+    int testmesh;                             /* mltest fixture: ones-vector on AE 0, src/interp.cpp:510-524 */
+    int coarse_solver;                        /* 0 auto, 2 inner PCG on the coarsest operator */
+    double coarse_rtol;                       /* inner PCG tolerance on (B r, r), un-squared */
+    int coarse_max_iter;
+    long long workspace_bytes;                /* dense AE matrices are processed in chunks of this size */
+    int keep_debug;                           /* keep eigenpairs / singular values for inspection */
+} saamge_amd_params;
+
+void saamge_amd_params_default(saamge_amd_params *p);
+const char *saamge_amd_last_error(void);
+
+/* ml_produce_data (inc/ml.hpp:192-194, src/ml.cpp:379-472) on raw arrays:
+ *   A            n x n CSR, essential rows/cols eliminated with the diagonal kept
+ *                (== HypreParMatrix Ag / SparseMatrix Al of test/mltest/mltest.cpp:619-621)
+ *   elem_to_dof  NE x nde, elmat NE x nde x nde row-major raw element matrices
+ *                (== ElementMatrixProvider::GetMatrix, inc/elmat.hpp:53-78)
+ *   bdr_dofs     n flags (== fem_find_bdr_dofs, src/fem.cpp:87-140); may be NULL
+ *   partitions   partitions[k][e] = AE of level-k element e (level-k elements are the
+ *                level-(k-1) AEs); replaces METIS, exactly like the non-NULL
+ *                `partitioning` argument of agg_create_partitioning_fine
+ *                (inc/aggregates.hpp:385-390)
+ *   nparts       nparts[k] = number of AEs of coarsening k
+ *   stream       hipStream_t to run on (NULL = default stream)                          */
+int saamge_amd_ml_produce_data(int n, const int *rowptr, const int *col, const double *val,
+                               int NE, int nde, const int *elem_to_dof, const double *elmat,
+                               const signed char *bdr_dofs, const int *const *partitions,
+                               const int *nparts, const saamge_amd_params *params, void *stream,
+                               saamge_amd_hierarchy **out);
+/* ml_free_data, inc/ml.hpp:196 */
+void saamge_amd_ml_free_data(saamge_amd_hierarchy *h);
+
+/* VCycleSolver::Mult with iterative_mode = false (inc/solve.hpp:129-143,
+ * src/solve.cpp:309-323 -> tg_cycle_atb src/tg.cpp:91-132): x = B b */
+int saamge_amd_vcycle_mult(saamge_amd_hierarchy *h, const double *b, double *x);
+/* smpr_sym_poly on one level (inc/smpr.hpp:59-60, src/smpr.cpp:213-234): x += M^-1 (b - A x) */
+int saamge_amd_smoother(saamge_amd_hierarchy *h, int level, const double *b, double *x);
+/* Outer Krylov loop: MFEM CGSolver as driven by test/mltest/mltest.cpp:773-781
+ * (squared_tol = 1: stop when (B r,r) < max(rel_tol^2 (B r0,r0), abs_tol^2)) or
+ * kalchev_pcg, inc/mfem_addons.hpp:276 (squared_tol = 0).  hist (host, max_iter+1
+ * doubles, may be NULL) receives (B r_k, r_k).  zero_guess != 0 starts from x = 0. */
+int saamge_amd_pcg(saamge_amd_hierarchy *h, const double *b, double *x, double rel_tol,
+                   double abs_tol, int max_iter, int squared_tol, int zero_guess, int *iters,
+                   int *converged, double *hist);
+
+/* ---- inspection (ml_print_dims / tg_data_t field access, src/ml.cpp:296-355) ---- */
+int saamge_amd_num_levels(const saamge_amd_hierarchy *h); /* number of operators = coarsenings + 1 */
+/* info[0]=rows(A_l) [1]=nnz(A_l) [2]=nparts [3]=num_mises [4]=coarse dim [5]=nnz(P) [6]=nnz(Ac)
+ * [7]=total eigenvectors [8]=inner PCG iterations of the last coarsest solve */
+int saamge_amd_level_info(const saamge_amd_hierarchy *h, int level, long long info[16]);
+/* which: 0 A_l, 1 interp, 2 restr, 3 Ac (host output buffers sized from level_info) */
+int saamge_amd_get_csr(const saamge_amd_hierarchy *h, int level, int which, int *rowptr, int *col,
+                       double *val);
+/* which: 0 AE_to_dof, 1 dof_to_AE, 2 mis_to_dof, 3 mis_to_AE, 4 AE_to_mis, 5 elem_to_dof.
+ * Pass I = J = NULL to query sizes: *nrows, *nconn. */
+int saamge_amd_get_table(const saamge_amd_hierarchy *h, int level, int which, int *nrows,
+                         long long *nconn, int *I, int *J);
+/* per-dof MIS id (n), per-MIS kept vectors / SVD columns (num_mises), agg_flags (n) */
+int saamge_amd_get_mis(const saamge_amd_hierarchy *h, int level, int *mises, int *mis_k,
+                       int *mis_ncols, signed char *agg_flags);
+/* keep_debug only: eigenvector counts per AE (nparts), packed eigenvalues / eigenvectors
+ * (AE i: n_i x m_i column-major, AEs concatenated); sizes via level_info[7] and tables. */
+int saamge_amd_get_ae_eigens(const saamge_amd_hierarchy *h, int level, int *ae_m, double *evals,
+                             double *evecs, double *ae_D);
+/* keep_debug only: packed per-MIS singular values (sum of SVD input columns before dropping) and
+ * tentative blocks (MIS m: r_m x k_m column-major, concatenated). */
+int saamge_amd_get_mis_svd(const saamge_amd_hierarchy *h, int level, long long *sig_off,
+                           double *sig, double *U);
+
+/* ---- operator-level entry points (the same kernels, usable on their own) ---- */
+/* y = A x, hypre ParCSRMatrixMatvec as used by src/tg.cpp:115 */
+int saamge_amd_spmv(int nrows, int ncols, const int *rowptr, const int *col, const double *val,
+                    const double *x, double *y);
+/* xpacks_calc_lower_eigens_dense batched (src/xpacks.cpp:222-314) for A x = lambda D x with
+ * diagonal D: matrices packed column-major one after the other, D packed likewise.
+ * Outputs (host): m[i]; evals at offset sum_{j<i} n_j; evecs at offset sum_{j<i} n_j^2
+ * (first m[i] columns), D-orthonormal. */
+int saamge_amd_lower_eigens_batched(int count, const int *n, const double *A, const double *D,
+                                    double vl, double vu, int *m, double *evals, double *evecs);
+
+/* ---- per-kernel timing for bench.py's roofline leg (HIP events around every launch) ---- */
+void saamge_amd_profile_enable(int on);
+void saamge_amd_profile_reset(void);
+int saamge_amd_profile_count(void);
+int saamge_amd_profile_get(int i, char *name, int name_len, double *ms, long long *launches,
+                           double *bytes, double *flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,306 @@
+"""ctypes binding of include/saamge_amd.h -- the test/bench harness side of the C ABI.
+
+The product is ``libsaamge_amd.so`` (HIP, gfx950).  This module only marshals numpy
+arrays / raw device pointers through the C ABI; it contains no numerics and no CPU
+fallback: if the library is missing, import of the binding fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsaamge_amd.so")
+
+MAX_LEVELS = 8
+
+# every symbol include/saamge_amd.h declares
+SYMBOLS = [
+    "saamge_amd_params_default", "saamge_amd_last_error", "saamge_amd_ml_produce_data",
+    "saamge_amd_ml_free_data", "saamge_amd_vcycle_mult", "saamge_amd_smoother", "saamge_amd_pcg",
+    "saamge_amd_num_levels", "saamge_amd_level_info", "saamge_amd_get_csr", "saamge_amd_get_table",
+    "saamge_amd_get_mis", "saamge_amd_get_ae_eigens", "saamge_amd_get_mis_svd", "saamge_amd_spmv",
+    "saamge_amd_lower_eigens_batched", "saamge_amd_profile_enable", "saamge_amd_profile_reset",
+    "saamge_amd_profile_count", "saamge_amd_profile_get",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("num_coarsenings", C.c_int),
+        ("theta", C.c_double * MAX_LEVELS),
+        ("nu_relax", C.c_int * MAX_LEVELS),
+        ("nu_pro", C.c_int * MAX_LEVELS),
+        ("avoid_ess_bdr_dofs", C.c_int),
+        ("testmesh", C.c_int),
+        ("coarse_solver", C.c_int),
+        ("coarse_rtol", C.c_double),
+        ("coarse_max_iter", C.c_int),
+        ("workspace_bytes", C.c_longlong),
+        ("keep_debug", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("saamge_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; "
+                           "g.build()'` (hipcc, gfx950); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.saamge_amd_last_error.restype = C.c_char_p
+    lib.saamge_amd_num_levels.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError("saamge_amd: " + load().saamge_amd_last_error().decode())
+
+
+def _ptr(a):
+    """numpy array -> host pointer; int -> raw (device) pointer; None -> NULL."""
+    if a is None:
+        return C.c_void_p(0)
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if hasattr(a, "data_ptr"):  # torch tensor (device memory plumbing)
+        return C.c_void_p(a.data_ptr())
+    assert a.flags["C_CONTIGUOUS"]
+    return C.c_void_p(a.ctypes.data)
+
+
+def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, keep_debug=False,
+                   coarse_rtol=1e-14, workspace_bytes=None):
+    p = Params()
+    load().saamge_amd_params_default(C.byref(p))
+    p.num_coarsenings = num_coarsenings
+    for i in range(MAX_LEVELS):
+        p.theta[i] = theta
+        p.nu_relax[i] = nu_relax
+    p.testmesh = int(testmesh)
+    p.keep_debug = int(keep_debug)
+    p.coarse_rtol = coarse_rtol
+    if workspace_bytes is not None:
+        p.workspace_bytes = int(workspace_bytes)
+    return p
+
+
+class Hierarchy(object):
+    """Owner of a saamge_amd_hierarchy (== ml_data_t).  Mirrors the reference call
+    sequence: ml_produce_data -> VCycleSolver::Mult / CGSolver::Mult -> ml_free_data."""
+
+    def __init__(self, A_rowptr, A_col, A_val, n, elem_to_dof, elmat, bdr, partitions, nparts,
+                 params, NE, nde, stream=0):
+        lib = load()
+        self._keep = (A_rowptr, A_col, A_val, elem_to_dof, elmat, bdr, partitions)
+        parts = (C.c_void_p * len(partitions))(*[_ptr(p).value for p in partitions])
+        npa = (C.c_int * len(nparts))(*[int(x) for x in nparts])
+        h = C.c_void_p()
+        _check(lib.saamge_amd_ml_produce_data(
+            C.c_int(n), _ptr(A_rowptr), _ptr(A_col), _ptr(A_val), C.c_int(NE), C.c_int(nde),
+            _ptr(elem_to_dof), _ptr(elmat), _ptr(bdr), parts, npa, C.byref(params),
+            C.c_void_p(stream), C.byref(h)))
+        self.h = h
+        self.n = n
+        self.testmesh = bool(params.testmesh)
+
+    @classmethod
+    def from_problem(cls, prob, params, stream=0):
+        """Build from a saamge_amd.problems.Problem (host numpy arrays)."""
+        A = prob.A.tocsr()
+        rowptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
+        col = np.ascontiguousarray(A.indices, dtype=np.int32)
+        val = np.ascontiguousarray(A.data, dtype=np.float64)
+        e2d = np.ascontiguousarray(prob.elem_to_dof, dtype=np.int32)
+        elmat = np.ascontiguousarray(prob.elmat, dtype=np.float64)
+        bdr = np.ascontiguousarray(prob.bdr, dtype=np.int8)
+        parts = [np.ascontiguousarray(p, dtype=np.int32) for p in prob.partitions[:params.num_coarsenings]]
+        nparts = [int(p.max()) + 1 for p in parts]
+        return cls(rowptr, col, val, A.shape[0], e2d, elmat, bdr, parts, nparts, params,
+                   e2d.shape[0], e2d.shape[1], stream)
+
+    def close(self):
+        if self.h:
+            load().saamge_amd_ml_free_data(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- solve ----
+    def vcycle(self, b, x=None):
+        if x is None:
+            x = np.zeros_like(b)
+        _check(load().saamge_amd_vcycle_mult(self.h, _ptr(b), _ptr(x)))
+        return x
+
+    def smoother(self, level, b, x):
+        _check(load().saamge_amd_smoother(self.h, C.c_int(level), _ptr(b), _ptr(x)))
+        return x
+
+    def pcg(self, b, x=None, rel_tol=1e-6, abs_tol=0.0, max_iter=1000, squared_tol=True,
+            zero_guess=True):
+        if x is None:
+            x = np.zeros_like(b)
+        it = C.c_int(0)
+        conv = C.c_int(0)
+        hist = np.zeros(max_iter + 2)
+        _check(load().saamge_amd_pcg(self.h, _ptr(b), _ptr(x), C.c_double(rel_tol),
+                                     C.c_double(abs_tol), C.c_int(max_iter), C.c_int(int(squared_tol)),
+                                     C.c_int(int(zero_guess)), C.byref(it), C.byref(conv), _ptr(hist)))
+        return x, it.value, bool(conv.value), hist[:it.value + 1].copy()
+
+    # ---- inspection ----
+    @property
+    def num_levels(self):
+        return load().saamge_amd_num_levels(self.h)
+
+    def level_info(self, level):
+        info = (C.c_longlong * 16)()
+        _check(load().saamge_amd_level_info(self.h, C.c_int(level), info))
+        keys = ["n", "nnz", "nparts", "num_mises", "ncoarse", "nnzP", "nnzAc", "nvec",
+                "coarse_iters", "evecs_size", "sig_size", "U_size"]
+        return dict(zip(keys, [int(v) for v in info[:len(keys)]]))
+
+    def get_csr(self, level, which):
+        import scipy.sparse as sp
+        info = self.level_info(level)
+        which_id = {"A": 0, "P": 1, "R": 2, "Ac": 3}[which]
+        nrows, ncols, nnz = {
+            "A": (info["n"], info["n"], info["nnz"]),
+            "P": (info["n"], info["ncoarse"], info["nnzP"]),
+            "R": (info["ncoarse"], info["n"], info["nnzP"]),
+            "Ac": (info["ncoarse"], info["ncoarse"], info["nnzAc"]),
+        }[which]
+        rowptr = np.zeros(nrows + 1, dtype=np.int32)
+        col = np.zeros(nnz, dtype=np.int32)
+        val = np.zeros(nnz, dtype=np.float64)
+        _check(load().saamge_amd_get_csr(self.h, C.c_int(level), C.c_int(which_id), _ptr(rowptr),
+                                         _ptr(col), _ptr(val)))
+        return sp.csr_matrix((val, col, rowptr), shape=(nrows, ncols))
+
+    def get_table(self, level, name):
+        wid = {"AE_to_dof": 0, "dof_to_AE": 1, "mis_to_dof": 2, "mis_to_AE": 3, "AE_to_mis": 4,
+               "elem_to_dof": 5}[name]
+        nrows = C.c_int(0)
+        nconn = C.c_longlong(0)
+        _check(load().saamge_amd_get_table(self.h, C.c_int(level), C.c_int(wid), C.byref(nrows),
+                                           C.byref(nconn), None, None))
+        I = np.zeros(nrows.value + 1, dtype=np.int32)
+        J = np.zeros(nconn.value, dtype=np.int32)
+        _check(load().saamge_amd_get_table(self.h, C.c_int(level), C.c_int(wid), None, None,
+                                           _ptr(I), _ptr(J)))
+        return I, J
+
+    def get_mis(self, level):
+        info = self.level_info(level)
+        mises = np.zeros(info["n"], dtype=np.int32)
+        k = np.zeros(info["num_mises"], dtype=np.int32)
+        nc = np.zeros(info["num_mises"], dtype=np.int32)
+        flags = np.zeros(info["n"], dtype=np.int8)
+        _check(load().saamge_amd_get_mis(self.h, C.c_int(level), _ptr(mises), _ptr(k), _ptr(nc),
+                                         _ptr(flags)))
+        return mises, k, nc, flags
+
+    def get_ae_eigens(self, level):
+        """Returns (m, evals_list, evecs_list, D_list) per AE (needs keep_debug)."""
+        info = self.level_info(level)
+        I, _ = self.get_table(level, "AE_to_dof")
+        sizes = np.diff(I)
+        m = np.zeros(info["nparts"], dtype=np.int32)
+        _check(load().saamge_amd_get_ae_eigens(self.h, C.c_int(level), _ptr(m), None, None, None))
+        evecs = np.zeros(info["evecs_size"])
+        evals = np.zeros(max(int(m.sum()), 1))
+        D = np.zeros(int(sizes.sum()))
+        _check(load().saamge_amd_get_ae_eigens(self.h, C.c_int(level), _ptr(m), _ptr(evals),
+                                               _ptr(evecs), _ptr(D)))
+        ev, X, Ds = [], [], []
+        xo = eo = do = 0
+        for i, n in enumerate(sizes):
+            cnt = int(m[i])
+            X.append(evecs[xo:xo + n * cnt].reshape(cnt, n).T.copy())
+            xo += n * cnt
+            Ds.append(D[do:do + n].copy())
+            do += n
+            # eigenvalues exist only for computed pairs (not for the mltest fixture's ones-vector)
+            ne = cnt - 1 if (self.testmesh and level == 0 and i == 0) else cnt
+            ev.append(evals[eo:eo + ne].copy())
+            eo += ne
+        return m, ev, X, Ds
+
+    def get_mis_svd(self, level):
+        info = self.level_info(level)
+        nm = info["num_mises"]
+        off = np.zeros(nm + 1, dtype=np.int64)
+        sig = np.zeros(max(info["sig_size"], 1))
+        U = np.zeros(max(info["U_size"], 1))
+        _check(load().saamge_amd_get_mis_svd(self.h, C.c_int(level), _ptr(off), _ptr(sig), _ptr(U)))
+        return off, sig, U
+
+
+def spmv(A, x):
+    A = A.tocsr()
+    y = np.zeros(A.shape[0])
+    _check(load().saamge_amd_spmv(C.c_int(A.shape[0]), C.c_int(A.shape[1]),
+                                  _ptr(np.ascontiguousarray(A.indptr, dtype=np.int32)),
+                                  _ptr(np.ascontiguousarray(A.indices, dtype=np.int32)),
+                                  _ptr(np.ascontiguousarray(A.data, dtype=np.float64)),
+                                  _ptr(np.ascontiguousarray(x, dtype=np.float64)), _ptr(y)))
+    return y
+
+
+def lower_eigens_batched(mats, diags, vl, vu):
+    """mats: list of symmetric (n_i, n_i) arrays; diags: list of positive (n_i,) arrays."""
+    count = len(mats)
+    n = np.array([m.shape[0] for m in mats], dtype=np.int32)
+    A = np.concatenate([np.asfortranarray(m).ravel(order="F") for m in mats])
+    D = np.concatenate([np.asarray(d, dtype=np.float64) for d in diags])
+    m_out = np.zeros(count, dtype=np.int32)
+    evals = np.zeros(int(n.sum()))
+    evecs = np.zeros(int((n.astype(np.int64) ** 2).sum()))
+    _check(load().saamge_amd_lower_eigens_batched(C.c_int(count), _ptr(n), _ptr(A), _ptr(D),
+                                                  C.c_double(vl), C.c_double(vu), _ptr(m_out),
+                                                  _ptr(evals), _ptr(evecs)))
+    out = []
+    vo = 0
+    mo = 0
+    for i in range(count):
+        ni, mi = int(n[i]), int(m_out[i])
+        out.append((evals[vo:vo + mi].copy(), evecs[mo:mo + ni * mi].reshape(mi, ni).T.copy()))
+        vo += ni
+        mo += ni * ni
+    return out
+
+
+def profile(enable=True):
+    load().saamge_amd_profile_enable(C.c_int(int(enable)))
+
+
+def profile_reset():
+    load().saamge_amd_profile_reset()
+
+
+def profile_stats():
+    lib = load()
+    out = []
+    for i in range(lib.saamge_amd_profile_count()):
+        name = C.create_string_buffer(64)
+        ms = C.c_double()
+        launches = C.c_longlong()
+        by = C.c_double()
+        fl = C.c_double()
+        lib.saamge_amd_profile_get(C.c_int(i), name, C.c_int(64), C.byref(ms), C.byref(launches),
+                                   C.byref(by), C.byref(fl))
+        out.append(dict(name=name.value.decode(), ms=ms.value, launches=launches.value,
+                        bytes=by.value, flops=fl.value))
+    return out

@@ -1,0 +1,34 @@
+// Batched agglomerate (AE) matrix assembly, weighted-l1 scaling, coarse element matrices.
+#pragma once
+#include "common.h"
+#include "eig.h"
+#include "topology.h"
+
+namespace saamge_amd {
+
+// Packed element matrices of one level: element e is a dense nd_e x nd_e block
+// (nd_e = elem_to_dof row size) stored row-major at val[off[e]].
+struct DevElmats {
+    DBuf<int64_t> off;  // [NE+1]
+    DBuf<double> val;
+};
+
+// Dense AE matrices for the AEs [ae0, ae0+count) into batch.W (column-major, ld = n_i).
+//   fine level  (A != null): agg_build_AE_stiffm_with_global, amg/src/aggregates.cpp:855-945
+//   coarse level (A == null): agg_build_AE_stiffm (plain sum), amg/src/aggregates.cpp:959-1086
+void ae_assemble(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevElmats &el,
+                 int ae0, EigBatch &batch);
+
+// D_ii = sum_j |a_ij| sqrt(a_ii/a_jj)  (amg/src/mbox.cpp:913-949);  batch.dis = D^-1/2 and
+// W <- D^-1/2 W D^-1/2 in place.  Dout (optional, packed like batch.d) receives D.
+void ae_scale(hipStream_t s, EigBatch &batch, double *Dout);
+
+// Coarse element matrices E_e = P_loc^T A_e P_loc for AEs [ae0, ae0+count)
+// (ElementMatrixParallelCoarse::GetMatrix, amg/src/elmat.cpp:105-195).  batch.W must hold
+// the *unscaled* AE matrices.  Output row-major at out[out_off[e]], k_e x k_e.
+void coarse_elmats(hipStream_t s, const DevRelations &rel, int ae0, const EigBatch &batch,
+                   const int *mis_k, const int64_t *mis_u_off, const double *mis_u,
+                   const int *ae_mis_colbase, const int64_t *out_off, double *out,
+                   double *scratch, const int64_t *scratch_off);
+
+}  // namespace saamge_amd

@@ -1,0 +1,369 @@
+// extern "C" boundary (include/saamge_amd.h).  Exceptions stop here.
+#include "../../include/saamge_amd.h"
+
+#include <string>
+
+#include "hierarchy.h"
+
+using namespace saamge_amd;
+
+struct saamge_amd_hierarchy {
+    Hierarchy *H;
+};
+
+static std::string g_last_error;
+
+#define SA_API_BEGIN try {
+#define SA_API_END                                   \
+    }                                                \
+    catch (const Error &e) {                         \
+        g_last_error = e.what();                     \
+        return e.code ? e.code : 1;                  \
+    }                                                \
+    catch (const std::exception &e) {                \
+        g_last_error = e.what();                     \
+        return 1;                                    \
+    }                                                \
+    return 0;
+
+extern "C" {
+
+const char *saamge_amd_last_error(void) { return g_last_error.c_str(); }
+
+void saamge_amd_params_default(saamge_amd_params *p) {
+    // defaults of test/mltest/mltest.cpp:332-419
+    p->num_coarsenings = 1;
+    for (int i = 0; i < SAAMGE_AMD_MAX_LEVELS; ++i) {
+        p->theta[i] = 0.003;
+        p->nu_relax[i] = 3;
+        p->nu_pro[i] = 0;
+    }
+    p->avoid_ess_bdr_dofs = 1;
+    p->testmesh = 0;
+    p->coarse_solver = 0;
+    p->coarse_rtol = 1e-14;
+    p->coarse_max_iter = 2000;
+    p->workspace_bytes = (long long)8 << 30;
+    p->keep_debug = 0;
+}
+
+int saamge_amd_ml_produce_data(int n, const int *rowptr, const int *col, const double *val,
+                               int NE, int nde, const int *elem_to_dof, const double *elmat,
+                               const signed char *bdr_dofs, const int *const *partitions,
+                               const int *nparts, const saamge_amd_params *params, void *stream,
+                               saamge_amd_hierarchy **out) {
+    SA_API_BEGIN
+    SA_REQUIRE(out && params && rowptr && col && val && elem_to_dof && elmat && partitions && nparts,
+               "null argument");
+    Params p;
+    p.num_coarsenings = params->num_coarsenings;
+    SA_REQUIRE(p.num_coarsenings >= 1 && p.num_coarsenings < MAX_LEVELS, "bad num_coarsenings");
+    for (int i = 0; i < MAX_LEVELS; ++i) {
+        p.theta[i] = params->theta[i];
+        p.nu_relax[i] = params->nu_relax[i];
+        p.nu_pro[i] = params->nu_pro[i];
+    }
+    p.avoid_ess_bdr_dofs = params->avoid_ess_bdr_dofs;
+    p.testmesh = params->testmesh;
+    p.coarse_solver = params->coarse_solver;
+    p.coarse_rtol = params->coarse_rtol;
+    p.coarse_max_iter = params->coarse_max_iter;
+    p.workspace_bytes = (size_t)params->workspace_bytes;
+    p.keep_debug = params->keep_debug;
+    Hierarchy *H = hierarchy_create(n, rowptr, col, val, NE, nde, elem_to_dof, elmat, bdr_dofs,
+                                    partitions, nparts, p, (hipStream_t)stream);
+    *out = new saamge_amd_hierarchy{H};
+    SA_API_END
+}
+
+void saamge_amd_ml_free_data(saamge_amd_hierarchy *h) {
+    if (!h) return;
+    delete h->H;
+    delete h;
+}
+
+// stage a host vector on the device when needed
+struct VecIn {
+    DBuf<double> buf;
+    const double *p;
+    VecIn(const double *src, size_t n, hipStream_t s) {
+        if (is_device_ptr(src)) p = src;
+        else { buf.assign(src, n, s); p = buf.p; }
+    }
+};
+struct VecOut {
+    DBuf<double> buf;
+    double *p, *host = nullptr;
+    size_t n;
+    hipStream_t s;
+    VecOut(double *dst, size_t n_, hipStream_t s_, bool load) : n(n_), s(s_) {
+        if (is_device_ptr(dst)) p = dst;
+        else {
+            host = dst;
+            if (load) buf.assign(dst, n, s); else buf.alloc(n);
+            p = buf.p;
+        }
+    }
+    void finish() {
+        if (host && n) SA_HIP_CHECK(hipMemcpyAsync(host, p, 8 * n, hipMemcpyDeviceToHost, s));
+        SA_HIP_CHECK(hipStreamSynchronize(s));
+    }
+};
+
+int saamge_amd_vcycle_mult(saamge_amd_hierarchy *h, const double *b, double *x) {
+    SA_API_BEGIN
+    SA_REQUIRE(h && b && x, "null argument");
+    Hierarchy &H = *h->H;
+    const size_t n = (size_t)H.levels[0]->A.nrows;
+    VecIn vb(b, n, H.stream);
+    VecOut vx(x, n, H.stream, false);
+    vcycle_apply(H, 0, vb.p, vx.p);
+    vx.finish();
+    SA_API_END
+}
+
+int saamge_amd_smoother(saamge_amd_hierarchy *h, int level, const double *b, double *x) {
+    SA_API_BEGIN
+    SA_REQUIRE(h && b && x, "null argument");
+    Hierarchy &H = *h->H;
+    SA_REQUIRE(level >= 0 && level < (int)H.levels.size(), "bad level");
+    const size_t n = (size_t)H.levels[level]->A.nrows;
+    VecIn vb(b, n, H.stream);
+    VecOut vx(x, n, H.stream, true);
+    smoother_apply(H, level, vb.p, vx.p);
+    vx.finish();
+    SA_API_END
+}
+
+int saamge_amd_pcg(saamge_amd_hierarchy *h, const double *b, double *x, double rel_tol,
+                   double abs_tol, int max_iter, int squared_tol, int zero_guess, int *iters,
+                   int *converged, double *hist) {
+    SA_API_BEGIN
+    SA_REQUIRE(h && b && x && iters, "null argument");
+    Hierarchy &H = *h->H;
+    const size_t n = (size_t)H.levels[0]->A.nrows;
+    VecIn vb(b, n, H.stream);
+    VecOut vx(x, n, H.stream, !zero_guess);
+    int conv = 0;
+    *iters = pcg_solve(H, vb.p, vx.p, rel_tol, abs_tol, max_iter, squared_tol, zero_guess, &conv, hist);
+    if (converged) *converged = conv;
+    vx.finish();
+    SA_API_END
+}
+
+int saamge_amd_num_levels(const saamge_amd_hierarchy *h) { return h ? (int)h->H->levels.size() + 1 : 0; }
+
+static const DCsr &level_op(const Hierarchy &H, int level, int which) {
+    const int nl = (int)H.levels.size();
+    SA_REQUIRE(level >= 0 && level < nl, "bad level");
+    const Level &L = *H.levels[level];
+    switch (which) {
+        case 0: return L.A;
+        case 1: return L.P;
+        case 2: return L.R;
+        case 3: return (level + 1 < nl) ? H.levels[level + 1]->A : L.Ac;
+    }
+    throw Error(1, "bad operator selector");
+}
+
+int saamge_amd_level_info(const saamge_amd_hierarchy *h, int level, long long info[16]) {
+    SA_API_BEGIN
+    SA_REQUIRE(h && info, "null argument");
+    const Hierarchy &H = *h->H;
+    for (int i = 0; i < 16; ++i) info[i] = 0;
+    const Level &L = *H.levels.at(level);
+    info[0] = L.A.nrows;
+    info[1] = L.A.nnz;
+    info[2] = L.rel.nparts;
+    info[3] = L.rel.num_mises;
+    info[4] = L.P.ncols;
+    info[5] = L.P.nnz;
+    info[6] = level_op(H, level, 3).nnz;
+    long long tot = 0;
+    for (int m : L.ae_m) tot += m;
+    info[7] = tot;
+    info[8] = H.last_coarse_iters;
+    info[9] = L.ae_xoff.empty() ? 0 : L.ae_xoff.back();
+    info[10] = L.mis_s_off.empty() ? 0 : L.mis_s_off.back();
+    long long usz = 0;
+    for (int m = 0; m < L.rel.num_mises; ++m) usz += (long long)L.mis_k[m] * L.rel.mis_to_dof.row_size(m);
+    info[11] = usz;
+    SA_API_END
+}
+
+int saamge_amd_get_csr(const saamge_amd_hierarchy *h, int level, int which, int *rowptr, int *col,
+                       double *val) {
+    SA_API_BEGIN
+    SA_REQUIRE(h, "null argument");
+    const Hierarchy &H = *h->H;
+    const DCsr &M = level_op(H, level, which);
+    hipStream_t s = H.stream;
+    if (rowptr) SA_HIP_CHECK(hipMemcpyAsync(rowptr, M.rowptr.p, 4 * ((size_t)M.nrows + 1), hipMemcpyDeviceToHost, s));
+    if (col && M.nnz) SA_HIP_CHECK(hipMemcpyAsync(col, M.col.p, 4 * (size_t)M.nnz, hipMemcpyDeviceToHost, s));
+    if (val && M.nnz) SA_HIP_CHECK(hipMemcpyAsync(val, M.val.p, 8 * (size_t)M.nnz, hipMemcpyDeviceToHost, s));
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    SA_API_END
+}
+
+int saamge_amd_get_table(const saamge_amd_hierarchy *h, int level, int which, int *nrows,
+                         long long *nconn, int *I, int *J) {
+    SA_API_BEGIN
+    SA_REQUIRE(h, "null argument");
+    const Relations &r = h->H->levels.at(level)->rel;
+    const Table *T = nullptr;
+    switch (which) {
+        case 0: T = &r.AE_to_dof; break;
+        case 1: T = &r.dof_to_AE; break;
+        case 2: T = &r.mis_to_dof; break;
+        case 3: T = &r.mis_to_AE; break;
+        case 4: T = &r.AE_to_mis; break;
+        case 5: T = &r.elem_to_dof; break;
+        default: throw Error(1, "bad table selector");
+    }
+    if (nrows) *nrows = T->nrows();
+    if (nconn) *nconn = (long long)T->J.size();
+    if (I) std::copy(T->I.begin(), T->I.end(), I);
+    if (J) std::copy(T->J.begin(), T->J.end(), J);
+    SA_API_END
+}
+
+int saamge_amd_get_mis(const saamge_amd_hierarchy *h, int level, int *mises, int *mis_k,
+                       int *mis_ncols, signed char *agg_flags) {
+    SA_API_BEGIN
+    SA_REQUIRE(h, "null argument");
+    const Level &L = *h->H->levels.at(level);
+    if (mises) std::copy(L.rel.mises.begin(), L.rel.mises.end(), mises);
+    if (mis_k) std::copy(L.mis_k.begin(), L.mis_k.end(), mis_k);
+    if (mis_ncols) std::copy(L.mis_ncols.begin(), L.mis_ncols.end(), mis_ncols);
+    if (agg_flags) std::copy(L.rel.agg_flags.begin(), L.rel.agg_flags.end(), agg_flags);
+    SA_API_END
+}
+
+int saamge_amd_get_ae_eigens(const saamge_amd_hierarchy *h, int level, int *ae_m, double *evals,
+                             double *evecs, double *ae_D) {
+    SA_API_BEGIN
+    SA_REQUIRE(h, "null argument");
+    const Hierarchy &H = *h->H;
+    const Level &L = *H.levels.at(level);
+    hipStream_t s = H.stream;
+    if (ae_m) std::copy(L.ae_m.begin(), L.ae_m.end(), ae_m);
+    if (evals || evecs || ae_D) SA_REQUIRE(H.params.keep_debug, "hierarchy was built without keep_debug");
+    if (evals && L.evals.n) SA_HIP_CHECK(hipMemcpyAsync(evals, L.evals.p, 8 * L.evals.n, hipMemcpyDeviceToHost, s));
+    if (evecs && L.evecs.n) SA_HIP_CHECK(hipMemcpyAsync(evecs, L.evecs.p, 8 * L.evecs.n, hipMemcpyDeviceToHost, s));
+    if (ae_D && L.ae_D.n) SA_HIP_CHECK(hipMemcpyAsync(ae_D, L.ae_D.p, 8 * L.ae_D.n, hipMemcpyDeviceToHost, s));
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    SA_API_END
+}
+
+int saamge_amd_get_mis_svd(const saamge_amd_hierarchy *h, int level, long long *sig_off,
+                           double *sig, double *U) {
+    SA_API_BEGIN
+    SA_REQUIRE(h, "null argument");
+    const Hierarchy &H = *h->H;
+    const Level &L = *H.levels.at(level);
+    hipStream_t s = H.stream;
+    const int nm = L.rel.num_mises;
+    if (sig_off) for (int m = 0; m <= nm; ++m) sig_off[m] = L.mis_s_off[m];
+    if (sig) {
+        SA_REQUIRE(H.params.keep_debug, "hierarchy was built without keep_debug");
+        if (L.mis_s_off[nm]) SA_HIP_CHECK(hipMemcpyAsync(sig, L.mis_sig.p, 8 * (size_t)L.mis_s_off[nm], hipMemcpyDeviceToHost, s));
+    }
+    if (U) {
+        std::vector<double> all = L.mis_U.to_host(s);
+        size_t o = 0;
+        for (int m = 0; m < nm; ++m) {
+            const size_t cnt = (size_t)L.mis_k[m] * L.rel.mis_to_dof.row_size(m);
+            std::copy(all.begin() + L.mis_u_off[m], all.begin() + L.mis_u_off[m] + cnt, U + o);
+            o += cnt;
+        }
+    }
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    SA_API_END
+}
+
+int saamge_amd_spmv(int nrows, int ncols, const int *rowptr, const int *col, const double *val,
+                    const double *x, double *y) {
+    SA_API_BEGIN
+    SA_REQUIRE(rowptr && col && val && x && y && nrows >= 0, "bad argument");
+    hipStream_t s = 0;
+    DCsr A;
+    A.nrows = nrows;
+    A.ncols = ncols;
+    A.nnz = fetch_host(rowptr + nrows, 1, s)[0];
+    import_array(A.rowptr, rowptr, (size_t)nrows + 1, s);
+    import_array(A.col, col, (size_t)A.nnz, s);
+    import_array(A.val, val, (size_t)A.nnz, s);
+    A.lanes_per_row = pick_lanes_per_row(A.nnz, nrows > 0 ? nrows : 1);
+    VecIn vx(x, (size_t)ncols, s);
+    VecOut vy(y, (size_t)nrows, s, false);
+    spmv(s, A, vx.p, vy.p);
+    vy.finish();
+    SA_API_END
+}
+
+__global__ void apply_dscale_kernel(int count, const int *ns, const int64_t *moff, const int64_t *voff,
+                                    double *W, const double *D, double *dis) {
+    const int b = blockIdx.x;
+    const int n = ns[b];
+    double *Wm = W + moff[b];
+    const double *Dm = D + voff[b];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dis[voff[b] + i] = 1.0 / sqrt(Dm[i]);
+    __syncthreads();
+    for (size_t idx = threadIdx.x; idx < (size_t)n * n; idx += blockDim.x) {
+        const int r = (int)(idx % n), c = (int)(idx / n);
+        Wm[idx] = dis[voff[b] + r] * Wm[idx] * dis[voff[b] + c];
+    }
+}
+
+int saamge_amd_lower_eigens_batched(int count, const int *n, const double *A, const double *D,
+                                    double vl, double vu, int *m, double *evals, double *evecs) {
+    SA_API_BEGIN
+    SA_REQUIRE(count >= 0 && n && A && D && m && evals && evecs, "bad argument");
+    hipStream_t s = 0;
+    std::vector<int> sizes(n, n + count);
+    EigBatch b;
+    eig_batch_alloc(b, sizes, s);
+    SA_HIP_CHECK(hipMemcpyAsync(b.W.p, A, 8 * (size_t)b.h_moff[count], hipMemcpyDefault, s));
+    DBuf<double> dD;
+    dD.assign(D, (size_t)b.h_voff[count], s);
+    hipLaunchKernelGGL(apply_dscale_kernel, dim3(count), dim3(256), 0, s, count, b.n.p, b.moff.p,
+                       b.voff.p, b.W.p, dD.p, b.dis.p);
+    eig_tridiagonalize(s, b);
+    eig_count(s, b, vl, vu);
+    std::vector<int64_t> eoff((size_t)count + 1, 0), xoff((size_t)count + 1, 0);
+    for (int i = 0; i < count; ++i) {
+        eoff[i + 1] = eoff[i] + b.h_m[i];
+        xoff[i + 1] = xoff[i] + (int64_t)b.h_m[i] * sizes[i];
+        m[i] = b.h_m[i];
+    }
+    DBuf<int64_t> de, dx;
+    de.from_host(eoff, s);
+    dx.from_host(xoff, s);
+    DBuf<double> ev((size_t)eoff[count] + 1), xv((size_t)xoff[count] + 1);
+    eig_vectors(s, b, de.p, dx.p, ev.p, xv.p);
+    std::vector<double> hev = ev.to_host(s), hxv = xv.to_host(s);
+    for (int i = 0; i < count; ++i) {
+        std::copy(hev.begin() + eoff[i], hev.begin() + eoff[i + 1], evals + b.h_voff[i]);
+        std::copy(hxv.begin() + xoff[i], hxv.begin() + xoff[i + 1], evecs + b.h_moff[i]);
+    }
+    SA_API_END
+}
+
+void saamge_amd_profile_enable(int on) { profiler().enabled = on != 0; }
+void saamge_amd_profile_reset(void) { profiler().stats.clear(); }
+int saamge_amd_profile_count(void) { return (int)profiler().stats.size(); }
+int saamge_amd_profile_get(int i, char *name, int name_len, double *ms, long long *launches,
+                           double *bytes, double *flops) {
+    if (i < 0 || i >= (int)profiler().stats.size()) return 1;
+    const KernelStat &k = profiler().stats[i];
+    if (name && name_len > 0) {
+        std::snprintf(name, (size_t)name_len, "%s", k.name.c_str());
+    }
+    if (ms) *ms = k.ms;
+    if (launches) *launches = k.launches;
+    if (bytes) *bytes = k.bytes;
+    if (flops) *flops = k.flops;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,191 @@
+// Shared host-side utilities for the saamge_amd HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace saamge_amd {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define SA_HIP_CHECK(expr)                                                              \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            throw ::saamge_amd::Error(2, std::string(__FILE__) + ":" +                  \
+                                             std::to_string(__LINE__) + " " + #expr +   \
+                                             " -> " + hipGetErrorString(e_));           \
+    } while (0)
+
+// The reference aborts through SA_ASSERT (amg/inc/common.hpp:635-647); we throw and
+// translate to an error code at the C ABI.
+#define SA_REQUIRE(cond, msg)                                                           \
+    do {                                                                                \
+        if (!(cond))                                                                    \
+            throw ::saamge_amd::Error(1, std::string(__FILE__) + ":" +                  \
+                                             std::to_string(__LINE__) + " " + (msg));   \
+    } while (0)
+
+inline bool is_device_ptr(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // clear: plain host memory reports an error
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+// RAII device buffer.
+template <class T>
+struct DBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    bool owned = true;
+    DBuf() {}
+    explicit DBuf(size_t n_) { alloc(n_); }
+    DBuf(const DBuf &) = delete;
+    DBuf &operator=(const DBuf &) = delete;
+    DBuf(DBuf &&o) noexcept : p(o.p), n(o.n), owned(o.owned) { o.p = nullptr; o.n = 0; }
+    DBuf &operator=(DBuf &&o) noexcept {
+        if (this != &o) {
+            release();
+            p = o.p; n = o.n; owned = o.owned;
+            o.p = nullptr; o.n = 0;
+        }
+        return *this;
+    }
+    ~DBuf() { release(); }
+    void release() {
+        if (p && owned) (void)hipFree(p);
+        p = nullptr; n = 0; owned = true;
+    }
+    void alloc(size_t n_) {
+        release();
+        n = n_;
+        if (n) SA_HIP_CHECK(hipMalloc((void **)&p, n * sizeof(T)));
+    }
+    void zero(hipStream_t s = 0) {
+        if (n) SA_HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), s));
+    }
+    // copy from a host OR device pointer
+    void assign(const T *src, size_t n_, hipStream_t s = 0) {
+        alloc(n_);
+        if (!n) return;
+        SA_HIP_CHECK(hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyDefault, s));
+    }
+    void from_host(const std::vector<T> &v, hipStream_t s = 0) {
+        alloc(v.size());
+        if (n) {
+            SA_HIP_CHECK(hipMemcpyAsync(p, v.data(), n * sizeof(T), hipMemcpyHostToDevice, s));
+            SA_HIP_CHECK(hipStreamSynchronize(s));  // v may be a temporary
+        }
+    }
+    std::vector<T> to_host(hipStream_t s = 0) const {
+        std::vector<T> v(n);
+        if (n) {
+            SA_HIP_CHECK(hipMemcpyAsync(v.data(), p, n * sizeof(T), hipMemcpyDeviceToHost, s));
+            SA_HIP_CHECK(hipStreamSynchronize(s));
+        }
+        return v;
+    }
+    // non-owning view of an existing device pointer
+    void view(T *ptr, size_t n_) {
+        release();
+        p = ptr; n = n_; owned = false;
+    }
+};
+
+// Bring an input array (host or device pointer) to the device: device pointers are
+// viewed in place (zero copy), host pointers are uploaded once.
+template <class T>
+inline void import_array(DBuf<T> &dst, const T *src, size_t n, hipStream_t s) {
+    if (is_device_ptr(src))
+        dst.view(const_cast<T *>(src), n);
+    else
+        dst.assign(src, n, s);
+}
+
+// Fetch an input array to the host (for host-side topology).
+template <class T>
+inline std::vector<T> fetch_host(const T *src, size_t n, hipStream_t s) {
+    std::vector<T> v(n);
+    if (n) {
+        SA_HIP_CHECK(hipMemcpyAsync(v.data(), src, n * sizeof(T), hipMemcpyDefault, s));
+        SA_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    return v;
+}
+
+// Device CSR matrix (int32 indices like the reference's hypre/MFEM types).
+struct DCsr {
+    int nrows = 0, ncols = 0;
+    int64_t nnz = 0;
+    DBuf<int> rowptr, col;
+    DBuf<double> val;
+    int lanes_per_row = 8;  // SpMV launch shape, chosen from the average row length
+};
+
+inline int pick_lanes_per_row(int64_t nnz, int nrows) {
+    double avg = nrows ? double(nnz) / nrows : 1.0;
+    int l = 1;
+    while (l < 64 && l * 2 <= avg * 0.75 + 1.0) l *= 2;  // ~ half-full last pass at worst
+    return l;
+}
+
+inline int div_up(int64_t a, int64_t b) { return int((a + b - 1) / b); }
+
+// ---- optional per-kernel timing (bench.py's roofline leg) -------------------------
+struct KernelStat {
+    std::string name;
+    double ms = 0.0;
+    int64_t launches = 0;
+    double bytes = 0.0;  // ALGORITHMIC bytes summed over launches
+    double flops = 0.0;  // ALGORITHMIC flops summed over launches
+};
+
+struct Profiler {
+    bool enabled = false;
+    std::vector<KernelStat> stats;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    KernelStat &get(const char *name) {
+        for (auto &s : stats)
+            if (s.name == name) return s;
+        stats.push_back(KernelStat());
+        stats.back().name = name;
+        return stats.back();
+    }
+    void begin(hipStream_t s) {
+        if (!enabled) return;
+        if (!e0) {
+            SA_HIP_CHECK(hipEventCreate(&e0));
+            SA_HIP_CHECK(hipEventCreate(&e1));
+        }
+        SA_HIP_CHECK(hipEventRecord(e0, s));
+    }
+    void end(hipStream_t s, const char *name, double bytes, double flops) {
+        if (!enabled) return;
+        SA_HIP_CHECK(hipEventRecord(e1, s));
+        SA_HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        SA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        KernelStat &k = get(name);
+        k.ms += ms;
+        k.launches += 1;
+        k.bytes += bytes;
+        k.flops += flops;
+    }
+};
+
+Profiler &profiler();
+
+}  // namespace saamge_amd

@@ -1,0 +1,42 @@
+// Batched dense symmetric eigensolver: all eigenpairs of C_i with eigenvalue in
+// (vl, vu], at least one (the smallest) -- the device counterpart of
+// xpacks_calc_lower_eigens_dense / LAPACK dsygvx (reference: amg/src/xpacks.cpp:222-314)
+// after the generalized problem A x = lambda D x has been reduced with the diagonal D:
+// C = D^-1/2 A D^-1/2, x = D^-1/2 y.
+#pragma once
+#include "common.h"
+
+namespace saamge_amd {
+
+constexpr int EIG_NB = 32;  // panel width of the blocked tridiagonalisation
+
+struct EigBatch {
+    int count = 0;          // matrices in the batch
+    int max_n = 0;
+    DBuf<int> n;            // [count] sizes
+    DBuf<int64_t> moff;     // [count] offset of matrix i in W (doubles), column-major ld = n_i
+    DBuf<int64_t> voff;     // [count] offset of matrix i's row block in the per-row arrays
+    DBuf<double> W;         // matrices, overwritten by the reflectors
+    DBuf<double> panel;     // [sum n_i * EIG_NB] W-panel of the blocked reduction
+    DBuf<double> d, e, tau; // [sum n_i] tridiagonal + reflector scalars
+    DBuf<double> dis;       // [sum n_i] D^-1/2 (row scaling applied to the vectors)
+    DBuf<int> m, j0;        // [count] number of wanted pairs, index of the first
+    std::vector<int> h_n, h_m;
+    std::vector<int64_t> h_moff, h_voff;
+};
+
+// sizes known on the host; allocates everything but leaves W/dis to be filled by the caller
+void eig_batch_alloc(EigBatch &b, const std::vector<int> &sizes, hipStream_t s);
+
+// Phase 1: tridiagonalise every matrix in place.
+void eig_tridiagonalize(hipStream_t s, EigBatch &b);
+// Phase 2: count eigenvalues in (vl, vu] (Sturm); fills b.m / b.j0 and the host copy b.h_m
+// (m_i = max(count, 1): the reference takes the single smallest pair when none qualifies).
+void eig_count(hipStream_t s, EigBatch &b, double vl, double vu);
+// Phase 3: eigenvalues by multisection, vectors by inverse iteration, back-transform,
+// scale rows by dis.  evals/evecs are packed per matrix: eoff[i] (eigenvalues),
+// xoff[i] (vectors, column-major n_i x m_i).
+void eig_vectors(hipStream_t s, EigBatch &b, const int64_t *eoff, const int64_t *xoff,
+                 double *evals, double *evecs);
+
+}  // namespace saamge_amd

@@ -1,0 +1,695 @@
+// Batched symmetric eigensolver for gfx950 -- one workgroup per agglomerate matrix.
+//
+//   phase 1  blocked Householder tridiagonalisation (LAPACK dsytrd/dlatrd 'L' arithmetic):
+//            per column one matrix-vector product with the trailing block (streamed from
+//            L2/MALL/HBM, coalesced down the columns), thin panel corrections, and one
+//            rank-2*NB update per panel with 4x4 register micro-tiles.
+//   phase 2  Sturm counts at vl/vu (LAPACK dstebz/dlaebz pivot rule) -> number of wanted pairs.
+//   phase 3  eigenvalues by 64-way multisection (one wavefront per eigenvalue, one shift per
+//            lane), eigenvectors by inverse iteration with LAPACK dstein's logic
+//            (dlagtf/dlagts pivoting LU, cluster re-orthogonalisation), back-transformation
+//            by the stored reflectors, row scaling by D^-1/2.
+//
+// Reference behaviour: amg/src/xpacks.cpp:222-314 (dsygvx, range 'V' on (-1, theta],
+// fallback to the single smallest pair), amg/src/spectral.cpp:124-237.
+#include "eig.h"
+
+#include <cfloat>
+
+namespace saamge_amd {
+
+constexpr int TRI_NT = 1024;  // threads per workgroup in phase 1 (16 wavefronts)
+constexpr int VEC_NT = 256;   // threads per workgroup in phase 3
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return __shfl(v, 0, 64);
+}
+
+template <int NT>
+__device__ inline double block_sum(double v, double *red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) r += red[i];
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// phase 1
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TRI_NT) void tridiag_kernel(const int *__restrict__ ns,
+                                                         const int64_t *__restrict__ moff,
+                                                         const int64_t *__restrict__ voff,
+                                                         double *__restrict__ Wm,
+                                                         double *__restrict__ panel,
+                                                         double *__restrict__ dd,
+                                                         double *__restrict__ ee,
+                                                         double *__restrict__ tt) {
+    constexpr int NT = TRI_NT;
+    constexpr int NB = EIG_NB;
+    extern __shared__ __align__(16) double lds[];
+    const int b = blockIdx.x;
+    const int n = ns[b];
+    double *A = Wm + moff[b];
+    const int64_t vo = voff[b];
+    double *d = dd + vo, *e = ee + vo, *tau = tt + vo;
+    double *Wp = panel + vo * NB;
+    double *v = lds;             // [n]
+    double *p = v + n;           // [n]
+    double *psum = p + n;        // [NT]
+    double *tmpV = psum + NT;    // [NB]
+    double *tmpW = tmpV + NB;    // [NB]
+    double *red = tmpW + NB;     // [NT/64]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = NT / 64;
+
+    for (int k0 = 0; k0 < n - 1; k0 += NB) {
+        const int jb = min(NB, n - 1 - k0);
+        for (int j = 0; j < jb; ++j) {
+            const int k = k0 + j;
+            const int len = n - k - 1;
+            double *colk = A + (size_t)k * n;
+            // (1) bring column k up to date with the panel's previous reflectors
+            if (j > 0) {
+                for (int i = k + tid; i < n; i += NT) {
+                    double a = colk[i];
+                    for (int c = 0; c < j; ++c) {
+                        const double *Vc = A + (size_t)(k0 + c) * n;
+                        const double *Wc = Wp + (size_t)c * n;
+                        a -= Vc[i] * Wc[k] + Wc[i] * Vc[k];
+                    }
+                    colk[i] = a;
+                }
+                __syncthreads();
+            }
+            // (2) Householder vector of colk[k+1:n]  (dlarfg)
+            const double alpha = colk[k + 1];
+            double ss = 0.0;
+            for (int i = k + 2 + tid; i < n; i += NT) {
+                const double x = colk[i];
+                ss = fma(x, x, ss);
+            }
+            ss = block_sum<NT>(ss, red);
+            double tauk = 0.0, beta = alpha, scale = 0.0;
+            if (ss != 0.0) {
+                beta = -copysign(sqrt(fma(alpha, alpha, ss)), alpha);
+                tauk = (beta - alpha) / beta;
+                scale = 1.0 / (alpha - beta);
+            }
+            for (int i = k + 1 + tid; i < n; i += NT) {
+                const double x = (i == k + 1) ? 1.0 : colk[i] * scale;
+                colk[i] = x;
+                v[i - k - 1] = x;
+            }
+            if (tid == 0) {
+                d[k] = colk[k];
+                e[k] = beta;
+                tau[k] = tauk;
+            }
+            __syncthreads();
+            double *Wj = Wp + (size_t)j * n;
+            if (tauk == 0.0) {  // H = I: w = 0
+                for (int i = k + 1 + tid; i < n; i += NT) Wj[i] = 0.0;
+                __syncthreads();
+                continue;
+            }
+            // (3) p = A22 v, A22 = A[k+1:, k+1:] (not yet updated by this panel)
+            int RT = 64;
+            while (RT < len && RT < NT) RT <<= 1;
+            const int NG = NT / RT;
+            {
+                const int r = tid & (RT - 1), g = tid / RT;
+                const int cb = (int)(((long)len * g) / NG), ce = (int)(((long)len * (g + 1)) / NG);
+                const double *A22 = A + (size_t)(k + 1) * n + (k + 1);
+                for (int r0 = 0; r0 < len; r0 += RT) {
+                    const int row = r0 + r;
+                    double sum = 0.0;
+                    if (row < len) {
+                        const double *Ar = A22 + row;
+                        int c = cb;
+                        for (; c + 4 <= ce; c += 4) {
+                            const double a0 = Ar[(size_t)c * n], a1 = Ar[(size_t)(c + 1) * n];
+                            const double a2 = Ar[(size_t)(c + 2) * n], a3 = Ar[(size_t)(c + 3) * n];
+                            sum = fma(a0, v[c], sum);
+                            sum = fma(a1, v[c + 1], sum);
+                            sum = fma(a2, v[c + 2], sum);
+                            sum = fma(a3, v[c + 3], sum);
+                        }
+                        for (; c < ce; ++c) sum = fma(Ar[(size_t)c * n], v[c], sum);
+                    }
+                    if (NG == 1) {
+                        if (row < len) p[row] = sum;
+                    } else {
+                        psum[g * RT + r] = sum;
+                    }
+                }
+                __syncthreads();
+                if (NG > 1) {
+                    for (int row = tid; row < len; row += NT) {
+                        double s = 0.0;
+                        for (int g2 = 0; g2 < NG; ++g2) s += psum[g2 * RT + row];
+                        p[row] = s;
+                    }
+                    __syncthreads();
+                }
+            }
+            // (4) tmpW = W^T v, tmpV = V^T v over rows k+1..n-1 (one wavefront per dot)
+            for (int q = wave; q < 2 * j; q += NW) {
+                const int c = q >> 1;
+                const double *X = (q & 1) ? (A + (size_t)(k0 + c) * n) : (Wp + (size_t)c * n);
+                double s = 0.0;
+                for (int r = lane; r < len; r += 64) s = fma(X[k + 1 + r], v[r], s);
+                s = wave_sum(s);
+                if (lane == 0) ((q & 1) ? tmpV : tmpW)[c] = s;
+            }
+            __syncthreads();
+            // (5) p = tau (p - V tmpW - W tmpV);  (6) w = p - tau/2 (p.v) v
+            double part = 0.0;
+            for (int row = tid; row < len; row += NT) {
+                double s = p[row];
+                for (int c = 0; c < j; ++c)
+                    s -= A[(size_t)(k0 + c) * n + k + 1 + row] * tmpW[c] +
+                         Wp[(size_t)c * n + k + 1 + row] * tmpV[c];
+                s *= tauk;
+                p[row] = s;
+                part = fma(s, v[row], part);
+            }
+            const double pv = block_sum<NT>(part, red);
+            const double alpha2 = -0.5 * tauk * pv;
+            for (int row = tid; row < len; row += NT) Wj[k + 1 + row] = fma(alpha2, v[row], p[row]);
+            __syncthreads();
+        }
+        // (7) A22 -= V W^T + W V^T on the block behind the panel, 4x4 register micro-tiles
+        const int kk = k0 + jb;
+        const int nt = n - kk;
+        const int tiles = (nt + 3) >> 2;
+        const long total = (long)tiles * tiles;
+        for (long t = tid; t < total; t += NT) {
+            const int ti = (int)(t % tiles), tl = (int)(t / tiles);
+            const int i0 = kk + 4 * ti, l0 = kk + 4 * tl;
+            double acc[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c2 = 0; c2 < 4; ++c2) acc[a][c2] = 0.0;
+            const bool full = (i0 + 4 <= n) && (l0 + 4 <= n);
+            for (int c = 0; c < jb; ++c) {
+                const double *Vc = A + (size_t)(k0 + c) * n;
+                const double *Wc = Wp + (size_t)c * n;
+                double vi[4], wi[4], vl[4], wl[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int ii = (full || i0 + a < n) ? i0 + a : n - 1;
+                    const int ll = (full || l0 + a < n) ? l0 + a : n - 1;
+                    vi[a] = Vc[ii];
+                    wi[a] = Wc[ii];
+                    vl[a] = Vc[ll];
+                    wl[a] = Wc[ll];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int c2 = 0; c2 < 4; ++c2)
+                        acc[a][c2] = fma(vi[a], wl[c2], fma(wi[a], vl[c2], acc[a][c2]));
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < 4; ++c2)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    if (i0 + a < n && l0 + c2 < n) A[(size_t)(l0 + c2) * n + i0 + a] -= acc[a][c2];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        d[n - 1] = A[(size_t)(n - 1) * n + (n - 1)];
+        e[n - 1] = 0.0;
+        tau[n - 1] = 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Sturm sequence (dlaebz pivot rule): number of eigenvalues <= x
+// ---------------------------------------------------------------------------------------
+__device__ inline int sturm_count(int n, const double *d, const double *e, double x, double pivmin) {
+    double q = d[0] - x;
+    if (fabs(q) < pivmin) q = -pivmin;
+    int cnt = (q <= 0.0) ? 1 : 0;
+    for (int i = 1; i < n; ++i) {
+        const double ei = e[i - 1];
+        q = d[i] - (ei * ei) / q - x;
+        if (fabs(q) < pivmin) q = -pivmin;
+        cnt += (q <= 0.0) ? 1 : 0;
+    }
+    return cnt;
+}
+
+__global__ __launch_bounds__(64) void count_kernel(const int *__restrict__ ns,
+                                                   const int64_t *__restrict__ voff,
+                                                   const double *__restrict__ dd,
+                                                   const double *__restrict__ ee, double vl,
+                                                   double vu, int *__restrict__ m_out,
+                                                   int *__restrict__ j0_out) {
+    extern __shared__ __align__(16) double lds[];
+    const int b = blockIdx.x;
+    const int n = ns[b];
+    const double *dg = dd + voff[b], *eg = ee + voff[b];
+    double *d = lds, *e = lds + n;
+    const int lane = threadIdx.x;
+    double emax = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        d[i] = dg[i];
+        const double ei = eg[i];
+        e[i] = ei;
+        emax = fmax(emax, ei * ei);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) emax = fmax(emax, __shfl_xor(emax, o, 64));
+    __syncthreads();
+    const double pivmin = DBL_MIN * fmax(1.0, emax);
+    int cnt = 0;
+    if (lane < 2) cnt = sturm_count(n, d, e, lane == 0 ? vl : vu, pivmin);
+    const int cl = __shfl(cnt, 0, 64), cu = __shfl(cnt, 1, 64);
+    if (lane == 0) {
+        int m = cu - cl, j0 = cl;
+        if (m <= 0) {  // "atleast_one": the single smallest eigenpair (range 'I', il=iu=1)
+            m = 1;
+            j0 = 0;
+        }
+        m_out[b] = m;
+        j0_out[b] = j0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// phase 3
+// ---------------------------------------------------------------------------------------
+__device__ inline double unit_rand(unsigned a, unsigned b) {  // deterministic uniform(-1,1)
+    unsigned h = a * 2654435761u ^ (b + 0x9e3779b9u + (a << 6) + (a >> 2));
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return ((double)h + 0.5) * (2.0 / 4294967296.0) - 1.0;
+}
+
+__global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
+    const int *__restrict__ ns, const int64_t *__restrict__ moff, const int64_t *__restrict__ voff,
+    const double *__restrict__ Wm, const double *__restrict__ dd, const double *__restrict__ ee,
+    const double *__restrict__ tt, const double *__restrict__ dis, const int *__restrict__ ms,
+    const int *__restrict__ j0s, const int64_t *__restrict__ eoff, const int64_t *__restrict__ xoff,
+    double *__restrict__ evals, double *__restrict__ evecs) {
+    constexpr int NT = VEC_NT;
+    constexpr int NW = NT / 64;
+    extern __shared__ __align__(16) double lds[];
+    const int bi = blockIdx.x;
+    const int n = ns[bi];
+    const int m = ms[bi], j0 = j0s[bi];
+    const double *A = Wm + moff[bi];
+    const int64_t vo = voff[bi];
+    const double *tau = tt + vo;
+    double *lam = evals + eoff[bi];
+    double *Y = evecs + xoff[bi];
+    double *d = lds;        // [n]
+    double *e = d + n;      // [n]
+    double *la = e + n;     // [n] LU diag
+    double *lb = la + n;    // [n] LU super 1
+    double *lc = lb + n;    // [n] multipliers
+    double *ld2 = lc + n;   // [n] LU super 2
+    double *z = ld2 + n;    // [n]
+    double *red = z + n;    // [8]
+    int *pin = (int *)(red + 8);  // [n]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    double emax = 0.0, gl = DBL_MAX, gu = -DBL_MAX, onenrm = 0.0;
+    for (int i = tid; i < n; i += NT) {
+        d[i] = dd[vo + i];
+        e[i] = ee[vo + i];
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) {
+        const double el = (i > 0) ? fabs(e[i - 1]) : 0.0, er = (i < n - 1) ? fabs(e[i]) : 0.0;
+        emax = fmax(emax, er * er);
+        gl = fmin(gl, d[i] - el - er);
+        gu = fmax(gu, d[i] + el + er);
+        onenrm = fmax(onenrm, fabs(d[i]) + el + er);
+    }
+    // block max/min reductions through LDS
+    {
+        double vals[4] = {emax, -gl, gu, onenrm};
+        for (int q = 0; q < 4; ++q) {
+            double x = vals[q];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o, 64));
+            __syncthreads();
+            if (lane == 0) red[wave] = x;
+            __syncthreads();
+            double r = red[0];
+            for (int w2 = 1; w2 < NW; ++w2) r = fmax(r, red[w2]);
+            vals[q] = r;
+        }
+        emax = vals[0]; gl = -vals[1]; gu = vals[2]; onenrm = vals[3];
+    }
+    const double ulp = DBL_EPSILON;  // dlamch('P')
+    const double pivmin = DBL_MIN * fmax(1.0, emax);
+    const double tnorm = fmax(fabs(gl), fabs(gu));
+    gl -= 2.1 * tnorm * ulp * n + 2.1 * pivmin;
+    gu += 2.1 * tnorm * ulp * n + 2.1 * pivmin;
+
+    // ---- A: eigenvalues j0 .. j0+m-1 by 64-way multisection, one wavefront each ----
+    for (int jj = wave; jj < m; jj += NW) {
+        const int want = j0 + jj;  // count(lo) <= want < count(hi)
+        double lo = gl, hi = gu;
+        for (int it = 0; it < 40; ++it) {
+            const double width = hi - lo;
+            const double tol = fmax(2.0 * ulp * fmax(fabs(lo), fabs(hi)), pivmin);
+            if (width <= tol) break;
+            const double x = lo + width * ((double)(lane + 1) / 65.0);
+            const int c = sturm_count(n, d, e, x, pivmin);
+            const unsigned long long ge = __ballot(c >= want + 1);
+            double nlo = lo, nhi = hi;
+            if (ge == 0ull) {
+                nlo = __shfl(x, 63, 64);
+            } else {
+                const int f = __ffsll((long long)ge) - 1;
+                nhi = __shfl(x, f, 64);
+                if (f > 0) nlo = __shfl(x, f - 1, 64);
+            }
+            if (!(nhi - nlo < width)) break;  // no progress (rounding)
+            lo = nlo;
+            hi = nhi;
+        }
+        if (lane == 0) lam[jj] = 0.5 * (lo + hi);
+    }
+    __syncthreads();
+
+    // ---- B: inverse iteration (dstein), vectors stored in Y (unit 2-norm) ----
+    const double eps = ulp;
+    const double ortol = 1e-3 * onenrm;
+    const double dtpcrt = sqrt(0.1 / (double)n);
+    double xjm = 0.0;
+    int gpind = 0;
+    for (int jj = 0; jj < m; ++jj) {
+        double xj = lam[jj];
+        if (jj > 0) {
+            const double pertol = 10.0 * fabs(eps * xj);
+            if (xj - xjm < pertol) xj = xjm + pertol;
+        }
+        double *Yj = Y + (size_t)jj * n;
+        if (n == 1) {
+            if (tid == 0) Yj[0] = 1.0;
+            xjm = xj;
+            __syncthreads();
+            continue;
+        }
+        for (int i = tid; i < n; i += NT) z[i] = unit_rand((unsigned)i, (unsigned)(jj + 1));
+        // dlagtf: LU of T - xj I with partial pivoting (sequential, thread 0)
+        if (tid == 0) {
+            for (int i = 0; i < n; ++i) {
+                la[i] = d[i] - xj;
+                if (i < n - 1) { lb[i] = e[i]; lc[i] = e[i]; }
+            }
+            pin[n - 1] = 0;
+            const double tl = eps;
+            double scale1 = fabs(la[0]) + fabs(lb[0]);
+            for (int k = 0; k < n - 1; ++k) {
+                double scale2 = fabs(lc[k]) + fabs(la[k + 1]);
+                if (k < n - 2) scale2 += fabs(lb[k + 1]);
+                const double piv1 = (la[k] == 0.0) ? 0.0 : fabs(la[k]) / scale1;
+                double piv2;
+                if (lc[k] == 0.0) {
+                    pin[k] = 0;
+                    piv2 = 0.0;
+                    scale1 = scale2;
+                    if (k < n - 2) ld2[k] = 0.0;
+                } else {
+                    piv2 = fabs(lc[k]) / scale2;
+                    if (piv2 <= piv1) {
+                        pin[k] = 0;
+                        scale1 = scale2;
+                        lc[k] = lc[k] / la[k];
+                        la[k + 1] -= lc[k] * lb[k];
+                        if (k < n - 2) ld2[k] = 0.0;
+                    } else {
+                        pin[k] = 1;
+                        const double mult = la[k] / lc[k];
+                        la[k] = lc[k];
+                        const double temp = la[k + 1];
+                        la[k + 1] = lb[k] - mult * temp;
+                        if (k < n - 2) {
+                            ld2[k] = lb[k + 1];
+                            lb[k + 1] = -mult * ld2[k];
+                        }
+                        lb[k] = temp;
+                        lc[k] = mult;
+                    }
+                }
+                if (fmax(piv1, piv2) <= tl && pin[n - 1] == 0) pin[n - 1] = k + 1;
+            }
+            if (fabs(la[n - 1]) <= scale1 * tl && pin[n - 1] == 0) pin[n - 1] = n;
+        }
+        __syncthreads();
+        // dlagts tolerance
+        double tolp = 0.0;
+        for (int i = tid; i < n; i += NT) {
+            double t = fabs(la[i]);
+            if (i < n - 1) t = fmax(t, fabs(lb[i]));
+            if (i < n - 2) t = fmax(t, fabs(ld2[i]));
+            tolp = fmax(tolp, t);
+        }
+        {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) tolp = fmax(tolp, __shfl_xor(tolp, o, 64));
+            __syncthreads();
+            if (lane == 0) red[wave] = tolp;
+            __syncthreads();
+            tolp = red[0];
+            for (int w2 = 1; w2 < NW; ++w2) tolp = fmax(tolp, red[w2]);
+            tolp *= eps;
+            if (tolp == 0.0) tolp = eps;
+        }
+        if (jj > 0 && fabs(xj - xjm) > ortol) gpind = jj;
+        if (jj == 0) gpind = 0;
+        int nrmchk = 0;
+        for (int its = 0; its < 5; ++its) {
+            // scale the right-hand side
+            double zmax = 0.0;
+            for (int i = tid; i < n; i += NT) zmax = fmax(zmax, fabs(z[i]));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) zmax = fmax(zmax, __shfl_xor(zmax, o, 64));
+            __syncthreads();
+            if (lane == 0) red[wave] = zmax;
+            __syncthreads();
+            zmax = red[0];
+            for (int w2 = 1; w2 < NW; ++w2) zmax = fmax(zmax, red[w2]);
+            const double scl = (double)n * onenrm * fmax(eps, fabs(la[n - 1])) / zmax;
+            for (int i = tid; i < n; i += NT) z[i] *= scl;
+            __syncthreads();
+            // dlagts job = -1 (sequential, thread 0)
+            if (tid == 0) {
+                for (int k = 1; k < n; ++k) {
+                    if (pin[k - 1] == 0) {
+                        z[k] -= lc[k - 1] * z[k - 1];
+                    } else {
+                        const double temp = z[k - 1];
+                        z[k - 1] = z[k];
+                        z[k] = temp - lc[k - 1] * z[k];
+                    }
+                }
+                const double sfmin = DBL_MIN, bignum = 1.0 / DBL_MIN;
+                for (int k = n - 1; k >= 0; --k) {
+                    double temp;
+                    if (k <= n - 3) temp = z[k] - lb[k] * z[k + 1] - ld2[k] * z[k + 2];
+                    else if (k == n - 2) temp = z[k] - lb[k] * z[k + 1];
+                    else temp = z[k];
+                    double ak = la[k];
+                    double pert = copysign(tolp, ak);
+                    for (;;) {
+                        const double absak = fabs(ak);
+                        if (absak < 1.0) {
+                            if (absak < sfmin) {
+                                if (absak == 0.0 || fabs(temp) * sfmin > absak) {
+                                    ak += pert;
+                                    pert *= 2.0;
+                                    continue;
+                                } else {
+                                    temp *= bignum;
+                                    ak *= bignum;
+                                }
+                            } else if (fabs(temp) > absak * bignum) {
+                                ak += pert;
+                                pert *= 2.0;
+                                continue;
+                            }
+                        }
+                        break;
+                    }
+                    z[k] = temp / ak;
+                }
+            }
+            __syncthreads();
+            // re-orthogonalise against the cluster (modified Gram-Schmidt)
+            for (int g = gpind; g < jj; ++g) {
+                const double *Yg = Y + (size_t)g * n;
+                double s = 0.0;
+                for (int i = tid; i < n; i += NT) s = fma(z[i], Yg[i], s);
+                s = block_sum<NT>(s, red);
+                for (int i = tid; i < n; i += NT) z[i] = fma(-s, Yg[i], z[i]);
+                __syncthreads();
+            }
+            double nrm = 0.0;
+            for (int i = tid; i < n; i += NT) nrm = fmax(nrm, fabs(z[i]));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) nrm = fmax(nrm, __shfl_xor(nrm, o, 64));
+            __syncthreads();
+            if (lane == 0) red[wave] = nrm;
+            __syncthreads();
+            nrm = red[0];
+            for (int w2 = 1; w2 < NW; ++w2) nrm = fmax(nrm, red[w2]);
+            if (nrm < dtpcrt) continue;
+            if (++nrmchk < 3) continue;
+            break;
+        }
+        // normalise: unit 2-norm, largest component positive
+        double s2 = 0.0, amax = 0.0;
+        int imax = n;
+        for (int i = tid; i < n; i += NT) {
+            s2 = fma(z[i], z[i], s2);
+            if (fabs(z[i]) > amax) { amax = fabs(z[i]); imax = i; }
+        }
+        s2 = block_sum<NT>(s2, red);
+        // first index attaining the max (idamax)
+        double gm = amax;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o, 64));
+        __syncthreads();
+        if (lane == 0) red[wave] = gm;
+        __syncthreads();
+        gm = red[0];
+        for (int w2 = 1; w2 < NW; ++w2) gm = fmax(gm, red[w2]);
+        int cand = (amax == gm) ? imax : n;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+        __syncthreads();
+        if (lane == 0) pin[wave] = cand;  // pin is free now
+        __syncthreads();
+        cand = pin[0];
+        for (int w2 = 1; w2 < NW; ++w2) cand = min(cand, pin[w2]);
+        double sc = 1.0 / sqrt(s2);
+        if (z[cand] < 0.0) sc = -sc;
+        __syncthreads();
+        for (int i = tid; i < n; i += NT) Yj[i] = z[i] * sc;
+        xjm = xj;
+        __syncthreads();
+    }
+
+    // ---- C: back-transformation y = H_0 H_1 ... H_{n-2} z, one wavefront per vector ----
+    for (int jj = wave; jj < m; jj += NW) {
+        double *Yj = Y + (size_t)jj * n;
+        for (int k = n - 2; k >= 0; --k) {
+            const double tk = tau[k];
+            if (tk == 0.0) continue;
+            const int len = n - k - 1;
+            const double *vk = A + (size_t)k * n + (k + 1);
+            double *y = Yj + (k + 1);
+            double s = 0.0;
+            for (int r = lane; r < len; r += 64) s = fma(vk[r], y[r], s);
+            s = wave_sum(s) * tk;
+            for (int r = lane; r < len; r += 64) y[r] = fma(-s, vk[r], y[r]);
+        }
+        // ---- D: x = D^-1/2 y ----
+        for (int r = lane; r < n; r += 64) Yj[r] *= dis[vo + r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+void eig_batch_alloc(EigBatch &b, const std::vector<int> &sizes, hipStream_t s) {
+    b.count = (int)sizes.size();
+    b.h_n = sizes;
+    b.h_moff.assign(b.count + 1, 0);
+    b.h_voff.assign(b.count + 1, 0);
+    b.max_n = 0;
+    for (int i = 0; i < b.count; ++i) {
+        const int n = sizes[i];
+        SA_REQUIRE(n >= 1, "empty agglomerate matrix");
+        b.h_moff[i + 1] = b.h_moff[i] + (int64_t)n * n;
+        b.h_voff[i + 1] = b.h_voff[i] + n;
+        if (n > b.max_n) b.max_n = n;
+    }
+    b.n.from_host(b.h_n, s);
+    b.moff.from_host(b.h_moff, s);
+    b.voff.from_host(b.h_voff, s);
+    const size_t rows = (size_t)b.h_voff[b.count];
+    b.W.alloc((size_t)b.h_moff[b.count]);
+    b.panel.alloc(rows * EIG_NB);
+    b.d.alloc(rows);
+    b.e.alloc(rows);
+    b.tau.alloc(rows);
+    b.dis.alloc(rows);
+    b.m.alloc(b.count);
+    b.j0.alloc(b.count);
+}
+
+static size_t tri_lds_bytes(int n) { return sizeof(double) * (2 * (size_t)n + TRI_NT + 2 * EIG_NB + TRI_NT / 64); }
+static size_t vec_lds_bytes(int n) { return sizeof(double) * (7 * (size_t)n + 8) + sizeof(int) * ((size_t)n + 8); }
+constexpr size_t LDS_MAX = 160 * 1024;
+
+void eig_tridiagonalize(hipStream_t s, EigBatch &b) {
+    if (!b.count) return;
+    const size_t lds = tri_lds_bytes(b.max_n);
+    SA_REQUIRE(lds <= LDS_MAX, "agglomerate too large for the LDS-resident reflector vectors");
+    static bool attr_set = false;
+    if (!attr_set) {
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)tridiag_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)eigvec_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)count_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+        attr_set = true;
+    }
+    double flops = 0.0, bytes = 0.0;
+    for (int n : b.h_n) {
+        flops += 4.0 / 3.0 * (double)n * n * n;
+        bytes += 8.0 * (double)n * n;
+    }
+    profiler().begin(s);
+    hipLaunchKernelGGL(tridiag_kernel, dim3(b.count), dim3(TRI_NT), lds, s, b.n.p, b.moff.p,
+                       b.voff.p, b.W.p, b.panel.p, b.d.p, b.e.p, b.tau.p);
+    SA_HIP_CHECK(hipGetLastError());
+    profiler().end(s, "eig_tridiag", bytes, flops);
+}
+
+void eig_count(hipStream_t s, EigBatch &b, double vl, double vu) {
+    if (!b.count) return;
+    const size_t lds = sizeof(double) * 2 * (size_t)b.max_n;
+    SA_REQUIRE(lds <= LDS_MAX, "agglomerate too large for the Sturm kernel");
+    profiler().begin(s);
+    hipLaunchKernelGGL(count_kernel, dim3(b.count), dim3(64), lds, s, b.n.p, b.voff.p, b.d.p,
+                       b.e.p, vl, vu, b.m.p, b.j0.p);
+    SA_HIP_CHECK(hipGetLastError());
+    profiler().end(s, "eig_count", 0.0, 0.0);
+    b.h_m = b.m.to_host(s);
+}
+
+void eig_vectors(hipStream_t s, EigBatch &b, const int64_t *eoff, const int64_t *xoff,
+                 double *evals, double *evecs) {
+    if (!b.count) return;
+    const size_t lds = vec_lds_bytes(b.max_n);
+    SA_REQUIRE(lds <= LDS_MAX, "agglomerate too large for the LDS-resident inverse iteration");
+    double flops = 0.0;
+    for (int i = 0; i < b.count; ++i) flops += 2.0 * (double)b.h_n[i] * b.h_n[i] * b.h_m[i];
+    profiler().begin(s);
+    hipLaunchKernelGGL(eigvec_kernel, dim3(b.count), dim3(VEC_NT), lds, s, b.n.p, b.moff.p,
+                       b.voff.p, b.W.p, b.d.p, b.e.p, b.tau.p, b.dis.p, b.m.p, b.j0.p, eoff, xoff,
+                       evals, evecs);
+    SA_HIP_CHECK(hipGetLastError());
+    profiler().end(s, "eig_vectors", 0.0, flops);
+}
+
+}  // namespace saamge_amd

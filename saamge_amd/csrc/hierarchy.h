@@ -1,0 +1,89 @@
+// The multilevel hierarchy: device-side counterpart of ml_data_t / levels_level_t /
+// tg_data_t / interp_data_t (reference: amg/inc/ml.hpp:118-120, amg/inc/levels.hpp:47-64,
+// amg/inc/tg_data.hpp:47-83, amg/inc/interp.hpp:54-100).
+#pragma once
+#include <memory>
+
+#include "assemble.h"
+#include "common.h"
+#include "eig.h"
+#include "mis.h"
+#include "sparse.h"
+#include "topology.h"
+
+namespace saamge_amd {
+
+constexpr int MAX_LEVELS = 8;
+
+struct Params {                 // MultilevelParameters (amg/inc/ml.hpp:59-114)
+    int num_coarsenings = 1;
+    double theta[MAX_LEVELS];
+    int nu_relax[MAX_LEVELS];
+    int nu_pro[MAX_LEVELS];     // only 0 is supported in this round
+    int avoid_ess_bdr_dofs = 1; // amg/src/ml.cpp:64
+    int testmesh = 0;           // mltest fixture: extra ones-vector on AE 0 (amg/src/interp.cpp:510-524)
+    int coarse_solver = 0;      // 0 auto, 1 dense Cholesky, 2 inner PCG
+    double coarse_rtol = 1e-14; // inner PCG: relative (B r, r) reduction, un-squared
+    int coarse_max_iter = 2000;
+    size_t workspace_bytes = (size_t)8 << 30;  // dense AE matrices are processed in chunks of this size
+    int keep_debug = 0;         // keep per-AE eigenpairs / per-MIS data for parity tests
+};
+
+struct Level {                  // tg_data_t + interp_data_t + agg_partitioning_relations_t
+    DCsr A;                     // level operator (level 0: the user's matrix, viewed or copied)
+    DCsr P, R, Ac;              // interp, restr, coarse operator
+    DBuf<double> dinv_neg;      // smpr_poly_data_t::Dinv_neg
+    std::vector<double> roots;  // smpr_poly_data_t::roots (SAS)
+    double theta = 0.0;
+    int nu_relax = 3;
+    Relations rel;              // host topology
+    DevRelations drel;          // device mirror
+    DevElmats elmat;            // element matrices of this level
+    // interp_data_t
+    std::vector<int> ae_m;              // eigenvectors per AE
+    std::vector<int64_t> ae_xoff, ae_eoff;
+    DBuf<double> evals, evecs;          // cut_evects_arr (packed)
+    DBuf<double> ae_D;                  // rhs_matrices_arr (diagonals, packed per AE rows), debug only
+    std::vector<int> mis_k;             // mis_numcoarsedof
+    std::vector<int> mis_coloff;        // mis_coarsedofoffsets
+    std::vector<int> mis_ncols;         // columns that entered each SVD (debug)
+    std::vector<int64_t> mis_u_off, mis_s_off;
+    DBuf<double> mis_U, mis_sig;        // mis_tent_interps (packed r x k, column-major), singular values
+    DBuf<int> d_mis_k, d_mis_coloff;
+    DBuf<int64_t> d_mis_u_off;
+    // solve-phase work vectors
+    DBuf<double> x, b, r, t0, t1;
+};
+
+struct KernelTiming { double setup_ms = 0, solve_ms = 0; };
+
+struct Hierarchy {              // ml_data_t
+    Params params;
+    hipStream_t stream = 0;
+    std::vector<std::unique_ptr<Level>> levels;
+    // coarsest solver
+    int coarse_kind = 2;
+    DBuf<double> c_dinv, c_r, c_z, c_d, c_q, c_t0, c_t1, c_b, c_x;
+    std::vector<double> c_roots;
+    // PCG scratch
+    DBuf<double> pcg_r, pcg_z, pcg_d, pcg_q, scal, partials;
+    int last_coarse_iters = 0;
+};
+
+// ml_produce_data (amg/src/ml.cpp:379-472).  All array arguments may be host or device
+// pointers.  partitions[k] maps level-k elements to level-k AEs.
+Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const double *Aval, int NE,
+                            int nde, const int *elem_to_dof, const double *elmat,
+                            const signed char *bdr, const int *const *partitions,
+                            const int *nparts, const Params &p, hipStream_t stream);
+
+// VCycleSolver::Mult with iterative_mode = false (amg/src/solve.cpp:309-323): x = B b.
+void vcycle_apply(Hierarchy &h, int level, const double *b, double *x);
+// smpr_sym_poly (amg/src/smpr.cpp:213-234): x += M^-1 (b - A x)
+void smoother_apply(Hierarchy &h, int level, const double *b, double *x);
+// MFEM CGSolver / kalchev_pcg (amg/src/mfem_addons.cpp:106-248).  b, x device pointers.
+// Returns iterations; hist (host, may be null) receives (B r_k, r_k), k = 0..iters.
+int pcg_solve(Hierarchy &h, const double *b, double *x, double rel_tol, double abs_tol,
+              int max_iter, int squared_tol, int zero_guess, int *converged, double *hist);
+
+}  // namespace saamge_amd

@@ -1,0 +1,487 @@
+// Setup (ml_produce_data) and solve (V-cycle, PCG) orchestration.  Host C++ driving the HIP
+// kernels; all numerics run on the device, the integer topology on the host.
+#include "hierarchy.h"
+
+#include <algorithm>
+#include <cmath>
+#include <functional>
+
+namespace saamge_amd {
+
+Profiler &profiler() {
+    static Profiler p;
+    return p;
+}
+
+// smpr_sas_poly_roots (amg/src/smpr.cpp:282-306)
+static std::vector<double> sas_poly_roots(int nu) {
+    SA_REQUIRE(nu > 0, "nu_relax must be positive");
+    std::vector<double> r;
+    const double denom = (double)(2 * nu + 1);
+    for (int i = 0; i <= 2 * nu; ++i) {
+        const double v = std::cos(((double)i * M_PI) / denom);
+        r.push_back(v * v);
+    }
+    for (int i = 1; i <= nu; ++i) {
+        const double v = std::sin(((double)i * M_PI) / denom);
+        r.push_back(v * v);
+    }
+    return r;
+}
+
+static void finish_csr(DCsr &A) { A.lanes_per_row = pick_lanes_per_row(A.nnz, A.nrows > 0 ? A.nrows : 1); }
+
+__global__ void fill_kernel(long n, double *p, double v) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------
+// one coarsening: tg_init_data + tg_build_hierarchy + tg_update_coarse_operator
+// ---------------------------------------------------------------------------------------
+static void build_level(Hierarchy &H, int lev, Table &&e2d, const std::vector<int> &part, int nparts,
+                        const signed char *bdr_host) {
+    Level &L = *H.levels[lev];
+    hipStream_t s = H.stream;
+    const Params &P = H.params;
+    L.theta = P.theta[lev];
+    L.nu_relax = P.nu_relax[lev];
+    SA_REQUIRE(P.nu_pro[lev] == 0, "prolongator smoothing (nu_pro > 0) is not implemented yet");
+    build_relations(L.rel, std::move(e2d), part, nparts, L.A.nrows, bdr_host);
+    upload_relations(L.drel, L.rel, s);
+    const Relations &rel = L.rel;
+    // smoother data (smpr_init_poly_data, amg/src/smpr.cpp:359-423)
+    L.dinv_neg.alloc((size_t)L.A.nrows);
+    {
+        DBuf<double> tmp((size_t)L.A.nrows);
+        build_dinv_neg(s, L.A, tmp.p, L.dinv_neg.p);
+        SA_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    L.roots = sas_poly_roots(L.nu_relax);
+
+    // ---- local spectral problems, chunked over AEs (interp_compute_vectors) ----
+    std::vector<int> sizes((size_t)nparts);
+    for (int p = 0; p < nparts; ++p) sizes[p] = rel.AE_to_dof.row_size(p);
+    L.ae_m.assign((size_t)nparts, 0);
+    struct Chunk { int ae0, count; DBuf<double> evals, evecs; std::vector<int64_t> eoff, xoff; };
+    std::vector<Chunk> chunks;
+    if (P.keep_debug) L.ae_D.alloc((size_t)rel.AE_to_dof.J.size());
+    int64_t row0 = 0;
+    for (int ae0 = 0; ae0 < nparts;) {
+        size_t bytes = 0;
+        int cnt = 0;
+        while (ae0 + cnt < nparts) {
+            const size_t n = (size_t)sizes[ae0 + cnt];
+            const size_t add = 8 * (n * n + n * (EIG_NB + 8));
+            if (cnt > 0 && bytes + add > P.workspace_bytes) break;
+            bytes += add;
+            ++cnt;
+        }
+        EigBatch batch;
+        eig_batch_alloc(batch, std::vector<int>(sizes.begin() + ae0, sizes.begin() + ae0 + cnt), s);
+        ae_assemble(s, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch);
+        ae_scale(s, batch, P.keep_debug ? L.ae_D.p + row0 : nullptr);
+        eig_tridiagonalize(s, batch);
+        eig_count(s, batch, -1.0, L.theta);
+        chunks.emplace_back();
+        Chunk &c = chunks.back();
+        c.ae0 = ae0;
+        c.count = cnt;
+        c.eoff.assign((size_t)cnt + 1, 0);
+        c.xoff.assign((size_t)cnt + 1, 0);
+        for (int i = 0; i < cnt; ++i) {
+            L.ae_m[ae0 + i] = batch.h_m[i];
+            c.eoff[i + 1] = c.eoff[i] + batch.h_m[i];
+            c.xoff[i + 1] = c.xoff[i] + (int64_t)batch.h_m[i] * sizes[ae0 + i];
+        }
+        c.evals.alloc((size_t)c.eoff[cnt]);
+        c.evecs.alloc((size_t)c.xoff[cnt]);
+        DBuf<int64_t> d_eoff, d_xoff;
+        d_eoff.from_host(c.eoff, s);
+        d_xoff.from_host(c.xoff, s);
+        eig_vectors(s, batch, d_eoff.p, d_xoff.p, c.evals.p, c.evecs.p);
+        SA_HIP_CHECK(hipStreamSynchronize(s));
+        row0 += batch.h_voff[cnt];
+        ae0 += cnt;
+    }
+    // concatenate (+ the mltest fixture's extra all-ones vector on AE 0 of the finest level)
+    const bool extra = (P.testmesh && lev == 0);
+    L.ae_xoff.assign((size_t)nparts + 1, 0);
+    L.ae_eoff.assign((size_t)nparts + 1, 0);
+    std::vector<int> m_tot = L.ae_m;
+    if (extra) m_tot[0] += 1;
+    for (int p = 0; p < nparts; ++p) {
+        L.ae_xoff[p + 1] = L.ae_xoff[p] + (int64_t)m_tot[p] * sizes[p];
+        L.ae_eoff[p + 1] = L.ae_eoff[p] + L.ae_m[p];
+    }
+    L.evals.alloc((size_t)L.ae_eoff[nparts]);
+    L.evecs.alloc((size_t)L.ae_xoff[nparts]);
+    for (Chunk &c : chunks) {
+        if (c.evals.n)
+            SA_HIP_CHECK(hipMemcpyAsync(L.evals.p + L.ae_eoff[c.ae0], c.evals.p, 8 * c.evals.n,
+                                        hipMemcpyDeviceToDevice, s));
+        if (extra && c.ae0 == 0) {
+            const int64_t first = (int64_t)L.ae_m[0] * sizes[0];
+            SA_HIP_CHECK(hipMemcpyAsync(L.evecs.p, c.evecs.p, 8 * first, hipMemcpyDeviceToDevice, s));
+            hipLaunchKernelGGL(fill_kernel, dim3(div_up(sizes[0], 256)), dim3(256), 0, s, (long)sizes[0],
+                               L.evecs.p + first, 1.0);
+            if (c.evecs.n > (size_t)first)
+                SA_HIP_CHECK(hipMemcpyAsync(L.evecs.p + L.ae_xoff[1], c.evecs.p + first,
+                                            8 * (c.evecs.n - first), hipMemcpyDeviceToDevice, s));
+        } else if (c.evecs.n) {
+            SA_HIP_CHECK(hipMemcpyAsync(L.evecs.p + L.ae_xoff[c.ae0], c.evecs.p, 8 * c.evecs.n,
+                                        hipMemcpyDeviceToDevice, s));
+        }
+    }
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    chunks.clear();
+    L.ae_m = m_tot;
+
+    // ---- MIS stage (ContribTent::contrib_mises) ----
+    const int nm = rel.num_mises;
+    std::vector<int64_t> g_off((size_t)nm + 1, 0);
+    L.mis_u_off.assign((size_t)nm + 1, 0);
+    L.mis_s_off.assign((size_t)nm + 1, 0);
+    int max_ctot = 0;
+    for (int m = 0; m < nm; ++m) {
+        int ctot = 0;
+        for (int q = rel.mis_to_AE.I[m]; q < rel.mis_to_AE.I[m + 1]; ++q) ctot += L.ae_m[rel.mis_to_AE.J[q]];
+        const int r = rel.mis_to_dof.row_size(m);
+        g_off[m + 1] = g_off[m] + (int64_t)r * ctot;
+        L.mis_u_off[m + 1] = L.mis_u_off[m] + (int64_t)r * std::max(1, std::min(r, ctot));
+        L.mis_s_off[m + 1] = L.mis_s_off[m] + ctot;
+        max_ctot = std::max(max_ctot, ctot);
+    }
+    L.mis_U.alloc((size_t)L.mis_u_off[nm]);
+    L.mis_sig.alloc((size_t)L.mis_s_off[nm] + 1);
+    L.mis_sig.zero(s);
+    L.d_mis_k.alloc((size_t)nm);
+    {
+        DBuf<double> gather((size_t)g_off[nm] + 1);
+        DBuf<int64_t> d_goff, d_soff, d_xoff;
+        DBuf<int> d_aem, d_ncols((size_t)nm);
+        d_goff.from_host(g_off, s);
+        d_soff.from_host(L.mis_s_off, s);
+        L.d_mis_u_off.from_host(L.mis_u_off, s);
+        d_xoff.from_host(L.ae_xoff, s);
+        d_aem.from_host(L.ae_m, s);
+        MisSvdIO io;
+        io.ae_m = d_aem.p;
+        io.ae_xoff = d_xoff.p;
+        io.evecs = L.evecs.p;
+        io.g_off = d_goff.p;
+        io.gather = gather.p;
+        io.u_off = L.d_mis_u_off.p;
+        io.s_off = d_soff.p;
+        io.U = L.mis_U.p;
+        io.sig = L.mis_sig.p;
+        io.k = L.d_mis_k.p;
+        io.ncols = d_ncols.p;
+        io.avoid_ess = P.avoid_ess_bdr_dofs;
+        mis_svd(s, L.drel, nm, max_ctot, io);
+        L.mis_k = L.d_mis_k.to_host(s);
+        L.mis_ncols = d_ncols.to_host(s);
+    }
+    L.mis_coloff.assign((size_t)nm + 1, 0);
+    for (int m = 0; m < nm; ++m) L.mis_coloff[m + 1] = L.mis_coloff[m] + L.mis_k[m];
+    L.d_mis_coloff.from_host(L.mis_coloff, s);
+    build_P_R(s, L.drel, rel, L.mis_k, L.mis_u_off, L.d_mis_k.p, L.d_mis_coloff.p, L.d_mis_u_off.p,
+              L.mis_U.p, L.P, L.R);
+    rap_mis(s, L.drel, rel, L.A, L.mis_k, L.mis_coloff, L.d_mis_k.p, L.d_mis_coloff.p,
+            L.d_mis_u_off.p, L.mis_U.p, L.Ac);
+    if (!P.keep_debug) {
+        L.evals.release();
+        L.evecs.release();
+        L.mis_sig.release();
+    }
+    // work vectors
+    const size_t n = (size_t)L.A.nrows;
+    L.x.alloc(n); L.b.alloc(n); L.r.alloc(n); L.t0.alloc(n);
+}
+
+// ---------------------------------------------------------------------------------------
+// next level's inputs: coarse elements = AEs, coarse element matrices = P_loc^T A_e P_loc
+// (agg_create_partitioning_coarse / elmat_parallel)
+// ---------------------------------------------------------------------------------------
+static Table prepare_next_level(Hierarchy &H, int lev) {
+    Level &L = *H.levels[lev];
+    hipStream_t s = H.stream;
+    const Relations &rel = L.rel;
+    const int nparts = rel.nparts;
+    // coarse elem_to_dof: walk the AE's dofs in AE order, append a MIS's coarse dofs when the
+    // MIS is first met (== AE_to_dof x pattern(P_tent) in first-encounter order)
+    Table e2d;
+    e2d.ncols = L.mis_coloff.back();
+    e2d.I.assign((size_t)nparts + 1, 0);
+    std::vector<int> colbase(rel.AE_to_mis.J.size(), -1);
+    std::vector<int> stamp((size_t)rel.num_mises, -1);
+    for (int e = 0; e < nparts; ++e) {
+        int run = 0;
+        for (int k = rel.AE_to_dof.I[e]; k < rel.AE_to_dof.I[e + 1]; ++k) {
+            const int m = rel.mises[rel.AE_to_dof.J[k]];
+            if (stamp[m] == e) continue;
+            stamp[m] = e;
+            if (L.mis_k[m] == 0) continue;
+            const int *row = rel.AE_to_mis.row(e);
+            const int t = (int)(std::lower_bound(row, row + rel.AE_to_mis.row_size(e), m) - row);
+            colbase[(size_t)rel.AE_to_mis.I[e] + t] = run;
+            for (int v = 0; v < L.mis_k[m]; ++v) e2d.J.push_back(L.mis_coloff[m] + v);
+            run += L.mis_k[m];
+        }
+        e2d.I[e + 1] = e2d.I[e] + run;
+    }
+    // coarse element matrices
+    Level &N = *H.levels[lev + 1];
+    std::vector<int64_t> out_off((size_t)nparts + 1, 0);
+    for (int e = 0; e < nparts; ++e) {
+        const int64_t ke = e2d.row_size(e);
+        out_off[e + 1] = out_off[e] + ke * ke;
+    }
+    N.elmat.off.from_host(out_off, s);
+    N.elmat.val.alloc((size_t)out_off[nparts] + 1);
+    DBuf<int> d_colbase;
+    d_colbase.from_host(colbase, s);
+    std::vector<int> sizes((size_t)nparts);
+    for (int p = 0; p < nparts; ++p) sizes[p] = rel.AE_to_dof.row_size(p);
+    for (int ae0 = 0; ae0 < nparts;) {
+        size_t bytes = 0;
+        int cnt = 0;
+        while (ae0 + cnt < nparts) {
+            const size_t n = (size_t)sizes[ae0 + cnt];
+            const size_t add = 8 * (n * n + n * (EIG_NB + 8) + n * (size_t)e2d.row_size(ae0 + cnt));
+            if (cnt > 0 && bytes + add > H.params.workspace_bytes) break;
+            bytes += add;
+            ++cnt;
+        }
+        EigBatch batch;
+        eig_batch_alloc(batch, std::vector<int>(sizes.begin() + ae0, sizes.begin() + ae0 + cnt), s);
+        ae_assemble(s, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch);
+        std::vector<int64_t> soff((size_t)cnt + 1, 0);
+        for (int i = 0; i < cnt; ++i) soff[i + 1] = soff[i] + (int64_t)sizes[ae0 + i] * e2d.row_size(ae0 + i);
+        DBuf<int64_t> d_soff;
+        d_soff.from_host(soff, s);
+        DBuf<double> scratch((size_t)soff[cnt] + 1);
+        coarse_elmats(s, L.drel, ae0, batch, L.d_mis_k.p, L.d_mis_u_off.p, L.mis_U.p, d_colbase.p,
+                      N.elmat.off.p, N.elmat.val.p, scratch.p, d_soff.p);
+        SA_HIP_CHECK(hipStreamSynchronize(s));
+        ae0 += cnt;
+    }
+    return e2d;
+}
+
+// ---------------------------------------------------------------------------------------
+// coarsest solver: PCG on the coarsest operator, preconditioned by its own polynomial smoother
+// (the reference's parallel "coarse direct" is likewise an inner PCG to 1e-16,
+// amg/src/tg.cpp:998-1003)
+// ---------------------------------------------------------------------------------------
+static const DCsr &coarsest_op(const Hierarchy &H) { return H.levels.back()->Ac; }
+
+static void setup_coarse_solver(Hierarchy &H) {
+    const DCsr &Ac = coarsest_op(H);
+    hipStream_t s = H.stream;
+    const size_t n = (size_t)Ac.nrows;
+    H.coarse_kind = 2;
+    H.c_dinv.alloc(n);
+    H.c_r.alloc(n); H.c_z.alloc(n); H.c_d.alloc(n); H.c_q.alloc(n); H.c_t0.alloc(n); H.c_t1.alloc(n);
+    if (n) {
+        DBuf<double> tmp(n);
+        build_dinv_neg(s, Ac, tmp.p, H.c_dinv.p);
+        SA_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    H.c_roots = sas_poly_roots(H.levels.back()->nu_relax);
+}
+
+// x = poly(b) starting from x = 0; result lands in x, `tmp` is the ping-pong partner
+static void smooth_from_zero(hipStream_t s, const DCsr &A, const double *dinv,
+                             const std::vector<double> &roots, const double *b, double *x, double *tmp) {
+    const int deg = (int)roots.size();
+    double *cur = ((deg - 1) % 2 == 0) ? x : tmp;
+    double *oth = (cur == x) ? tmp : x;
+    smooth_first(s, A.nrows, dinv, b, cur, 1.0 / roots[0]);
+    for (int i = 1; i < deg; ++i) {
+        smooth_step(s, A, dinv, b, cur, oth, 1.0 / roots[i]);
+        std::swap(cur, oth);
+    }
+}
+
+// x += M^-1 (b - A x)
+static void smooth_inplace(hipStream_t s, const DCsr &A, const double *dinv,
+                           const std::vector<double> &roots, const double *b, double *x, double *tmp) {
+    const int deg = (int)roots.size();
+    double *cur = x, *oth = tmp;
+    for (int i = 0; i < deg; ++i) {
+        smooth_step(s, A, dinv, b, cur, oth, 1.0 / roots[i]);
+        std::swap(cur, oth);
+    }
+    if (cur != x) vec_copy(s, A.nrows, cur, x);
+}
+
+static double read_scalar(hipStream_t s, const double *dptr) {
+    double v;
+    SA_HIP_CHECK(hipMemcpyAsync(&v, dptr, sizeof(double), hipMemcpyDeviceToHost, s));
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    return v;
+}
+
+// The PCG loop shared by the outer solve and the coarsest solver (MFEM CGSolver::Mult order
+// of operations == kalchev_pcg, amg/src/mfem_addons.cpp:106-248).
+static int pcg_loop(Hierarchy &H, const DCsr &A, const std::function<void(const double *, double *)> &prec,
+                    const double *b, double *x, double *r, double *z, double *d, double *q,
+                    double rel_tol, double abs_tol, int max_iter, bool squared, bool zero_guess,
+                    int *converged, double *hist, double *sc) {
+    hipStream_t s = H.stream;
+    const int n = A.nrows;
+    if (zero_guess) {
+        vec_zero(s, n, x);
+        vec_copy(s, n, b, r);
+    } else {
+        spmv_residual(s, A, x, b, r);
+    }
+    prec(r, z);
+    vec_copy(s, n, z, d);
+    dot(s, n, d, r, H.partials.p, sc + 0);
+    const double nom0 = read_scalar(s, sc + 0);
+    if (hist) hist[0] = nom0;
+    const double r0 = squared ? std::max(nom0 * rel_tol * rel_tol, abs_tol * abs_tol)
+                              : std::max(nom0 * rel_tol, abs_tol);
+    if (converged) *converged = 0;
+    if (nom0 <= r0) {
+        if (converged) *converged = 1;
+        return 0;
+    }
+    spmv(s, A, d, q);
+    dot(s, n, q, d, H.partials.p, sc + 1);
+    if (read_scalar(s, sc + 1) == 0.0) return 0;
+    int i = 1;
+    int final_iter = max_iter;
+    for (;;) {
+        pcg_update_xr(s, n, sc, x, r, d, q);
+        prec(r, z);
+        dot(s, n, r, z, H.partials.p, sc + 2);
+        const double betanom = read_scalar(s, sc + 2);
+        if (hist) hist[i] = betanom;
+        if (betanom < r0) {
+            if (converged) *converged = 1;
+            final_iter = i;
+            break;
+        }
+        if (++i > max_iter) break;
+        pcg_update_d(s, n, sc, d, z);
+        spmv(s, A, d, q);
+        dot(s, n, d, q, H.partials.p, sc + 1);
+        SA_HIP_CHECK(hipMemcpyAsync(sc + 0, sc + 2, sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    return final_iter;
+}
+
+static void coarse_solve(Hierarchy &H, const double *rc, double *xc) {
+    const DCsr &Ac = coarsest_op(H);
+    if (Ac.nrows == 0) return;
+    hipStream_t s = H.stream;
+    auto prec = [&](const double *r, double *z) {
+        smooth_from_zero(s, Ac, H.c_dinv.p, H.c_roots, r, z, H.c_t0.p);
+    };
+    // scalar slots 4.. so the outer PCG's scalars (slots 0..2) survive
+    int conv = 0;
+    H.last_coarse_iters = pcg_loop(H, Ac, prec, rc, xc, H.c_r.p, H.c_z.p, H.c_d.p, H.c_q.p,
+                                   H.params.coarse_rtol, 0.0, H.params.coarse_max_iter, false, true,
+                                   &conv, nullptr, H.scal.p + 4);
+}
+
+void smoother_apply(Hierarchy &H, int level, const double *b, double *x) {
+    Level &L = *H.levels[level];
+    smooth_inplace(H.stream, L.A, L.dinv_neg.p, L.roots, b, x, L.t0.p);
+}
+
+void vcycle_apply(Hierarchy &H, int level, const double *b, double *x) {
+    Level &L = *H.levels[level];
+    hipStream_t s = H.stream;
+    const bool last = (level + 1 == (int)H.levels.size());
+    smooth_from_zero(s, L.A, L.dinv_neg.p, L.roots, b, x, L.t0.p);     // pre_smoother, x0 = 0
+    spmv_residual(s, L.A, x, b, L.r.p);                                // res = b - A x
+    double *rc = last ? H.c_b.p : H.levels[level + 1]->b.p;
+    double *xc = last ? H.c_x.p : H.levels[level + 1]->x.p;
+    spmv(s, L.R, L.r.p, rc);                                           // resc = R res
+    if (last)
+        coarse_solve(H, rc, xc);
+    else
+        vcycle_apply(H, level + 1, rc, xc);
+    spmv_add(s, L.P, xc, x);                                           // x += P xc
+    smooth_inplace(s, L.A, L.dinv_neg.p, L.roots, b, x, L.t0.p);       // post_smoother
+}
+
+int pcg_solve(Hierarchy &H, const double *b, double *x, double rel_tol, double abs_tol,
+              int max_iter, int squared_tol, int zero_guess, int *converged, double *hist) {
+    Level &L0 = *H.levels[0];
+    auto prec = [&](const double *r, double *z) { vcycle_apply(H, 0, r, z); };
+    return pcg_loop(H, L0.A, prec, b, x, H.pcg_r.p, H.pcg_z.p, H.pcg_d.p, H.pcg_q.p, rel_tol,
+                    abs_tol, max_iter, squared_tol != 0, zero_guess != 0, converged, hist, H.scal.p);
+}
+
+// ---------------------------------------------------------------------------------------
+// ml_produce_data
+// ---------------------------------------------------------------------------------------
+Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const double *Aval, int NE,
+                            int nde, const int *elem_to_dof, const double *elmat,
+                            const signed char *bdr, const int *const *partitions,
+                            const int *nparts, const Params &p, hipStream_t stream) {
+    SA_REQUIRE(p.num_coarsenings >= 1 && p.num_coarsenings < MAX_LEVELS, "bad number of coarsenings");
+    SA_REQUIRE(n > 0 && NE > 0 && nde > 0, "empty problem");
+    std::unique_ptr<Hierarchy> Hp(new Hierarchy);
+    Hierarchy &H = *Hp;
+    H.params = p;
+    H.stream = stream;
+    hipStream_t s = stream;
+    H.scal.alloc(8);
+    H.partials.alloc(1024);
+    for (int l = 0; l < p.num_coarsenings; ++l) H.levels.emplace_back(new Level);
+    // level 0 inputs
+    Level &L0 = *H.levels[0];
+    {
+        std::vector<int> last = fetch_host(Arow + n, 1, s);
+        const int64_t nnz = last[0];
+        L0.A.nrows = L0.A.ncols = n;
+        L0.A.nnz = nnz;
+        import_array(L0.A.rowptr, Arow, (size_t)n + 1, s);
+        import_array(L0.A.col, Acol, (size_t)nnz, s);
+        import_array(L0.A.val, Aval, (size_t)nnz, s);
+        finish_csr(L0.A);
+    }
+    {
+        std::vector<int64_t> off((size_t)NE + 1);
+        for (int e = 0; e <= NE; ++e) off[e] = (int64_t)e * nde * nde;
+        L0.elmat.off.from_host(off, s);
+        import_array(L0.elmat.val, elmat, (size_t)NE * nde * nde, s);
+    }
+    Table e2d;
+    {
+        std::vector<int> J = fetch_host(elem_to_dof, (size_t)NE * nde, s);
+        e2d.J = std::move(J);
+        e2d.I.resize((size_t)NE + 1);
+        for (int e = 0; e <= NE; ++e) e2d.I[e] = e * nde;
+        e2d.ncols = n;
+    }
+    std::vector<signed char> bdr_h;
+    if (bdr) bdr_h = fetch_host(bdr, (size_t)n, s);
+    int n_elem = NE;
+    for (int lev = 0; lev < p.num_coarsenings; ++lev) {
+        std::vector<int> part = fetch_host(partitions[lev], (size_t)n_elem, s);
+        build_level(H, lev, std::move(e2d), part, nparts[lev], (lev == 0 && bdr) ? bdr_h.data() : nullptr);
+        Level &L = *H.levels[lev];
+        if (lev + 1 < p.num_coarsenings) {
+            e2d = prepare_next_level(H, lev);
+            Level &N = *H.levels[lev + 1];
+            N.A = std::move(L.Ac);  // A_{l+1} = Ac_l  (amg/src/ml.cpp:134)
+            n_elem = L.rel.nparts;
+        }
+    }
+    setup_coarse_solver(H);
+    const size_t nc = (size_t)coarsest_op(H).nrows;
+    H.c_b.alloc(nc);
+    H.c_x.alloc(nc);
+    H.pcg_r.alloc((size_t)n); H.pcg_z.alloc((size_t)n); H.pcg_d.alloc((size_t)n); H.pcg_q.alloc((size_t)n);
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    return Hp.release();
+}
+
+}  // namespace saamge_amd

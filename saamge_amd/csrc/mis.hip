@@ -1,0 +1,522 @@
+// MIS stage on gfx950: one wavefront per minimal intersection set gathers the
+// MIS-restricted agglomerate eigenvectors, filters essential rows, normalises the columns
+// and orthogonalises them with a one-sided (Hestenes) Jacobi SVD -- all cross-lane
+// reductions are wavefront shuffles, no LDS traffic besides the tiny sort scratch.
+#include "mis.h"
+
+#include <cfloat>
+
+namespace saamge_amd {
+
+__device__ inline double wsum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void mis_svd_kernel(
+    const int *__restrict__ mis2d_I, const int *__restrict__ mis2d_J,
+    const int *__restrict__ mis2ae_I, const int *__restrict__ mis2ae_J,
+    const int *__restrict__ ae2d_I, const int64_t *__restrict__ pair_loc_off,
+    const int *__restrict__ pair_loc, const signed char *__restrict__ flags, MisSvdIO io) {
+    extern __shared__ __align__(16) double lds[];  // sig[ctot], then perm[ctot] (ints)
+    const int m = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int r = mis2d_I[m + 1] - mis2d_I[m];
+    const int *dofs = mis2d_J + mis2d_I[m];
+    double *M = io.gather + io.g_off[m];
+    double *Uout = io.U + io.u_off[m];
+    double *sigout = io.sig + io.s_off[m];
+    const int ctot = (int)(io.s_off[m + 1] - io.s_off[m]);
+    double *sg = lds;
+    int *perm = (int *)(lds + ctot);
+
+    // skip MISes whose dofs are all on the essential boundary (contrib.cpp:578-605)
+    if (io.avoid_ess) {
+        int interior = 0;
+        for (int i = lane; i < r; i += 64) interior |= !(flags[dofs[i]] & FLAG_ON_ESS_BORDER);
+        if (__ballot(interior) == 0ull) {
+            if (lane == 0) { io.k[m] = 0; io.ncols[m] = 0; }
+            return;
+        }
+    }
+    if (r == 1) {  // contrib.cpp:607-612
+        if (lane == 0) {
+            Uout[0] = 1.0;
+            io.k[m] = 1;
+            io.ncols[m] = 1;
+            if (ctot > 0) sigout[0] = 1.0;
+        }
+        return;
+    }
+    // gather + boundary filter + normalisation (contrib.cpp:102-163, xpacks.cpp:537-559)
+    int c = 0;
+    for (int q = mis2ae_I[m]; q < mis2ae_I[m + 1]; ++q) {
+        const int ae = mis2ae_J[q];
+        const int na = ae2d_I[ae + 1] - ae2d_I[ae];
+        const int ma = io.ae_m[ae];
+        const double *X = io.evecs + io.ae_xoff[ae];
+        const int *loc = pair_loc + pair_loc_off[q];
+        for (int v = 0; v < ma; ++v) {
+            double *col = M + (size_t)c * r;
+            double ss = 0.0;
+            int nz = 0;
+            for (int i = lane; i < r; i += 64) {
+                double x = X[(size_t)v * na + loc[i]];
+                if (io.avoid_ess && (flags[dofs[i]] & FLAG_ON_ESS_BORDER)) x = 0.0;
+                nz |= (x != 0.0);
+                ss = fma(x, x, ss);
+                col[i] = x;
+            }
+            if (__ballot(nz) == 0ull) continue;  // entirely zero column: ignored
+            const double nrm = sqrt(wsum(ss));
+            if (nrm <= 1e-10) continue;          // SA_REAL_ALMOST_LE(norm, 0.)
+            const double sc = 1.0 / nrm;
+            for (int i = lane; i < r; i += 64) col[i] *= sc;
+            ++c;
+        }
+    }
+    if (lane == 0) io.ncols[m] = c;
+    if (c == 0) {
+        if (lane == 0) io.k[m] = 0;
+        return;
+    }
+    // one-sided Jacobi: rotate column pairs until mutually orthogonal
+    const double tol = DBL_EPSILON * sqrt((double)r);
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        int rotated = 0;
+        for (int p = 0; p < c - 1; ++p) {
+            double *ap = M + (size_t)p * r;
+            for (int q = p + 1; q < c; ++q) {
+                double *aq = M + (size_t)q * r;
+                double al = 0.0, be = 0.0, ga = 0.0;
+                for (int i = lane; i < r; i += 64) {
+                    const double x = ap[i], y = aq[i];
+                    al = fma(x, x, al);
+                    be = fma(y, y, be);
+                    ga = fma(x, y, ga);
+                }
+                al = wsum(al); be = wsum(be); ga = wsum(ga);
+                if (al == 0.0 || be == 0.0) continue;
+                if (fabs(ga) <= tol * sqrt(al * be)) continue;
+                rotated = 1;
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                for (int i = lane; i < r; i += 64) {
+                    const double x = ap[i], y = aq[i];
+                    ap[i] = cs * x - sn * y;
+                    aq[i] = sn * x + cs * y;
+                }
+            }
+        }
+        if (!rotated) break;
+    }
+    // singular values = column norms; order descending (stable)
+    for (int j = 0; j < c; ++j) {
+        const double *aj = M + (size_t)j * r;
+        double ss = 0.0;
+        for (int i = lane; i < r; i += 64) ss = fma(aj[i], aj[i], ss);
+        ss = wsum(ss);
+        if (lane == 0) sg[j] = sqrt(ss);
+    }
+    __syncthreads();
+    for (int j = lane; j < c; j += 64) {
+        const double sj = sg[j];
+        int rank = 0;
+        for (int i = 0; i < c; ++i) rank += (sg[i] > sj) || (sg[i] == sj && i < j);
+        perm[rank] = j;
+    }
+    __syncthreads();
+    const double s0 = sg[perm[0]];
+    const int kmax = min(r, c);  // dgesvd returns min(m, n) singular triplets
+    int k = 0;
+    while (k < kmax && sg[perm[k]] > 1e-10 * s0) ++k;  // xpack_orth_set
+    for (int j = lane; j < c; j += 64) sigout[j] = sg[perm[j]];
+    for (int t = 0; t < k; ++t) {
+        const double *aj = M + (size_t)perm[t] * r;
+        const double inv = 1.0 / sg[perm[t]];
+        for (int i = lane; i < r; i += 64) Uout[(size_t)t * r + i] = aj[i] * inv;
+    }
+    if (lane == 0) io.k[m] = k;
+}
+
+void mis_svd(hipStream_t s, const DevRelations &rel, int num_mises, int max_ctot, const MisSvdIO &io) {
+    if (!num_mises) return;
+    const size_t lds = (sizeof(double) + sizeof(int)) * (size_t)(max_ctot + 2);
+    profiler().begin(s);
+    hipLaunchKernelGGL(mis_svd_kernel, dim3(num_mises), dim3(64), lds, s, rel.mis2d_I.p,
+                       rel.mis2d_J.p, rel.mis2ae_I.p, rel.mis2ae_J.p, rel.ae2d_I.p,
+                       rel.pair_loc_off.p, rel.pair_loc.p, rel.flags.p, io);
+    SA_HIP_CHECK(hipGetLastError());
+    profiler().end(s, "mis_svd", 0.0, 0.0);
+}
+
+// ---------------------------------------------------------------------------------------
+// P and R
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void p_count_kernel(int ND, const int *__restrict__ mises,
+                                                      const int *__restrict__ k, int *__restrict__ cnt) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < ND) cnt[i] = k[mises[i]];
+}
+
+// exclusive scan of ints, three small kernels (tile = 1024)
+__global__ __launch_bounds__(256) void scan_tile_kernel(int n, const int *__restrict__ in,
+                                                        int *__restrict__ out, int *__restrict__ tsum) {
+    __shared__ int sh[256];
+    const long base = (long)blockIdx.x * 1024;
+    int v[4], run = 0;
+    for (int q = 0; q < 4; ++q) {
+        const long i = base + threadIdx.x * 4 + q;
+        v[q] = (i < n) ? in[i] : 0;
+        run += v[q];
+    }
+    sh[threadIdx.x] = run;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int t = (threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int excl = sh[threadIdx.x] - run;
+    for (int q = 0; q < 4; ++q) {
+        const long i = base + threadIdx.x * 4 + q;
+        if (i < n) out[i] = excl;
+        excl += v[q];
+    }
+    if (threadIdx.x == 255) tsum[blockIdx.x] = sh[255];
+}
+__global__ __launch_bounds__(256) void scan_sums_kernel(int nt, int *__restrict__ tsum, int *__restrict__ total) {
+    __shared__ int sh[256];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nt; base += 256) {
+        const int i = base + threadIdx.x;
+        const int x = (i < nt) ? tsum[i] : 0;
+        sh[threadIdx.x] = x;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int t = (threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nt) tsum[i] = carry + sh[threadIdx.x] - x;
+        __syncthreads();
+        if (threadIdx.x == 255) carry += sh[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ __launch_bounds__(256) void scan_add_kernel(int n, int *__restrict__ out,
+                                                       const int *__restrict__ tsum,
+                                                       const int *__restrict__ total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] += tsum[i >> 10];
+    if (i == 0) out[n] = *total;
+}
+
+// out has n+1 entries
+static void exclusive_scan(hipStream_t s, int n, const int *in, int *out) {
+    const int nt = div_up(n, 1024);
+    DBuf<int> tsum((size_t)nt + 1);
+    hipLaunchKernelGGL(scan_tile_kernel, dim3(nt), dim3(256), 0, s, n, in, out, tsum.p);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, s, nt, tsum.p, tsum.p + nt);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, out, tsum.p, tsum.p + nt);
+    SA_HIP_CHECK(hipGetLastError());
+    SA_HIP_CHECK(hipStreamSynchronize(s));  // tsum is freed on return
+}
+
+__global__ __launch_bounds__(256) void p_fill_kernel(int ND, const int *__restrict__ mises,
+                                                     const int *__restrict__ row_in_mis,
+                                                     const int *__restrict__ mis2d_I,
+                                                     const int *__restrict__ k,
+                                                     const int *__restrict__ coloff,
+                                                     const int64_t *__restrict__ u_off,
+                                                     const double *__restrict__ U,
+                                                     const int *__restrict__ rowptr,
+                                                     int *__restrict__ col, double *__restrict__ val) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ND) return;
+    const int m = mises[i], km = k[m];
+    const int r = mis2d_I[m + 1] - mis2d_I[m];
+    const double *Um = U + u_off[m] + row_in_mis[i];
+    const int base = rowptr[i], c0 = coloff[m];
+    for (int v = 0; v < km; ++v) {
+        col[base + v] = c0 + v;
+        val[base + v] = Um[(size_t)v * r];
+    }
+}
+
+__global__ __launch_bounds__(256) void r_fill_kernel(int num_mises, const int *__restrict__ mis2d_I,
+                                                     const int *__restrict__ mis2d_J,
+                                                     const int *__restrict__ k,
+                                                     const int *__restrict__ coloff,
+                                                     const int64_t *__restrict__ u_off,
+                                                     const double *__restrict__ U,
+                                                     const int *__restrict__ rowptr,
+                                                     int *__restrict__ col, double *__restrict__ val) {
+    const int m = blockIdx.x;
+    const int km = k[m];
+    if (km == 0) return;
+    const int r = mis2d_I[m + 1] - mis2d_I[m];
+    const int *dofs = mis2d_J + mis2d_I[m];
+    const double *Um = U + u_off[m];
+    for (int idx = threadIdx.x; idx < km * r; idx += 256) {
+        const int v = idx / r, i = idx % r;
+        const int base = rowptr[coloff[m] + v];
+        col[base + i] = dofs[i];
+        val[base + i] = Um[(size_t)v * r + i];
+    }
+}
+
+void build_P_R(hipStream_t s, const DevRelations &rel, const Relations &hrel,
+               const std::vector<int> &h_k, const std::vector<int64_t> &h_u_off, const int *d_k,
+               const int *d_coloff, const int64_t *d_u_off, const double *U, DCsr &P, DCsr &R) {
+    (void)h_u_off;
+    const int ND = hrel.ND;
+    int nc = 0;
+    int64_t nnz = 0;
+    std::vector<int> r_rowptr;
+    r_rowptr.push_back(0);
+    for (int m = 0; m < hrel.num_mises; ++m) {
+        const int r = hrel.mis_to_dof.row_size(m);
+        nc += h_k[m];
+        nnz += (int64_t)h_k[m] * r;
+        for (int v = 0; v < h_k[m]; ++v) r_rowptr.push_back(r_rowptr.back() + r);
+    }
+    SA_REQUIRE(nnz < (int64_t)1 << 31, "prolongator too large for 32-bit indices");
+    P.nrows = ND; P.ncols = nc; P.nnz = nnz;
+    P.rowptr.alloc((size_t)ND + 1);
+    P.col.alloc((size_t)nnz);
+    P.val.alloc((size_t)nnz);
+    {
+        DBuf<int> cnt((size_t)ND);
+        hipLaunchKernelGGL(p_count_kernel, dim3(div_up(ND, 256)), dim3(256), 0, s, ND, rel.mises.p, d_k, cnt.p);
+        exclusive_scan(s, ND, cnt.p, P.rowptr.p);
+    }
+    hipLaunchKernelGGL(p_fill_kernel, dim3(div_up(ND, 256)), dim3(256), 0, s, ND, rel.mises.p,
+                       rel.dof_row_in_mis.p, rel.mis2d_I.p, d_k, d_coloff, d_u_off, U, P.rowptr.p,
+                       P.col.p, P.val.p);
+    P.lanes_per_row = pick_lanes_per_row(nnz, ND);
+    R.nrows = nc; R.ncols = ND; R.nnz = nnz;
+    R.rowptr.from_host(r_rowptr, s);
+    R.col.alloc((size_t)nnz);
+    R.val.alloc((size_t)nnz);
+    if (hrel.num_mises)
+        hipLaunchKernelGGL(r_fill_kernel, dim3(hrel.num_mises), dim3(256), 0, s, hrel.num_mises,
+                           rel.mis2d_I.p, rel.mis2d_J.p, d_k, d_coloff, d_u_off, U, R.rowptr.p,
+                           R.col.p, R.val.p);
+    SA_HIP_CHECK(hipGetLastError());
+    R.lanes_per_row = pick_lanes_per_row(nnz, nc > 0 ? nc : 1);
+}
+
+// ---------------------------------------------------------------------------------------
+// Galerkin product through the MIS blocks
+// ---------------------------------------------------------------------------------------
+constexpr int RAP_NT = 256;
+constexpr int RAP_HASH = 2048;
+
+// symbolic: neighbour MISes (with k > 0) of every MIS; pass 0 counts, pass 1 writes the
+// ascending list.
+__global__ __launch_bounds__(RAP_NT) void rap_symbolic_kernel(
+    int pass, const int *__restrict__ mis2d_I, const int *__restrict__ mis2d_J,
+    const int *__restrict__ Arow, const int *__restrict__ Acol, const int *__restrict__ mises,
+    const int *__restrict__ k, int *__restrict__ cnt, const int *__restrict__ nbr_ptr,
+    int *__restrict__ nbr, int *__restrict__ err) {
+    __shared__ int table[RAP_HASH];
+    __shared__ int nfound;
+    const int m1 = blockIdx.x;
+    if (k[m1] == 0) {
+        if (pass == 0 && threadIdx.x == 0) cnt[m1] = 0;
+        return;
+    }
+    for (int i = threadIdx.x; i < RAP_HASH; i += RAP_NT) table[i] = -1;
+    if (threadIdx.x == 0) nfound = 0;
+    __syncthreads();
+    const int r1 = mis2d_I[m1 + 1] - mis2d_I[m1];
+    const int *dofs = mis2d_J + mis2d_I[m1];
+    for (int il = threadIdx.x; il < r1; il += RAP_NT) {
+        const int g = dofs[il];
+        for (int q = Arow[g]; q < Arow[g + 1]; ++q) {
+            const int m2 = mises[Acol[q]];
+            if (k[m2] == 0) continue;
+            unsigned h = ((unsigned)m2 * 2654435761u) & (RAP_HASH - 1);
+            for (int probe = 0; probe < RAP_HASH; ++probe) {
+                const int old = atomicCAS(&table[h], -1, m2);
+                if (old == -1) { atomicAdd(&nfound, 1); break; }
+                if (old == m2) break;
+                h = (h + 1) & (RAP_HASH - 1);
+                if (probe == RAP_HASH - 1) atomicExch(err, 1);
+            }
+        }
+    }
+    __syncthreads();
+    if (pass == 0) {
+        if (threadIdx.x == 0) cnt[m1] = nfound;
+        return;
+    }
+    // pass 1: rank every entry among the others (lists are short) and write in order
+    int *out = nbr + nbr_ptr[m1];
+    for (int i = threadIdx.x; i < RAP_HASH; i += RAP_NT) {
+        const int v = table[i];
+        if (v < 0) continue;
+        int rank = 0;
+        for (int j = 0; j < RAP_HASH; ++j) {
+            const int w = table[j];
+            rank += (w >= 0 && w < v);
+        }
+        out[rank] = v;
+    }
+}
+
+__global__ __launch_bounds__(RAP_NT) void rap_numeric_kernel(
+    const int *__restrict__ mis2d_I, const int *__restrict__ mis2d_J, const int *__restrict__ Arow,
+    const int *__restrict__ Acol, const double *__restrict__ Aval, const int *__restrict__ mises,
+    const int *__restrict__ row_in_mis, const int *__restrict__ k, const int *__restrict__ coloff,
+    const int64_t *__restrict__ u_off, const double *__restrict__ U,
+    const int *__restrict__ nbr_ptr, const int *__restrict__ nbr, const int *__restrict__ crowptr,
+    int *__restrict__ ccol, double *__restrict__ cval, int lds_doubles) {
+    extern __shared__ __align__(16) double lds[];
+    const int m1 = blockIdx.x;
+    const int k1 = k[m1];
+    if (k1 == 0) return;
+    const int tid = threadIdx.x;
+    const int nn = nbr_ptr[m1 + 1] - nbr_ptr[m1];
+    const int *nb = nbr + nbr_ptr[m1];
+    const int r1 = mis2d_I[m1 + 1] - mis2d_I[m1];
+    const int *dofs = mis2d_J + mis2d_I[m1];
+    const double *U1 = U + u_off[m1];
+    // LDS: pos[nn+1] (ints), acc[k1*ncol], T[RC*ncol]
+    int *pos = (int *)lds;
+    const int pos_d = (nn + 2 + 1) / 2;
+    if (tid == 0) {
+        int run = 0;
+        for (int t = 0; t < nn; ++t) { pos[t] = run; run += k[nb[t]]; }
+        pos[nn] = run;
+    }
+    __syncthreads();
+    const int ncol = pos[nn];
+    double *acc = lds + pos_d;
+    double *T = acc + (size_t)k1 * ncol;
+    const int RC = (lds_doubles - pos_d - k1 * ncol) / ncol;  // rows per chunk (host guarantees >= 1)
+    for (int i = tid; i < k1 * ncol; i += RAP_NT) acc[i] = 0.0;
+    // column indices of the k1 output rows
+    for (int idx = tid; idx < k1 * ncol; idx += RAP_NT) {
+        const int v1 = idx / ncol, cc = idx % ncol;
+        int t = 0;  // neighbour owning local column cc
+        int lo = 0, hi = nn;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pos[mid] <= cc) lo = mid; else hi = mid; }
+        t = lo;
+        ccol[crowptr[coloff[m1] + v1] + cc] = coloff[nb[t]] + (cc - pos[t]);
+    }
+    for (int c0 = 0; c0 < r1; c0 += RC) {
+        const int rc = min(RC, r1 - c0);
+        __syncthreads();
+        for (int i = tid; i < rc * ncol; i += RAP_NT) T[i] = 0.0;
+        __syncthreads();
+        for (int il = tid; il < rc; il += RAP_NT) {
+            const int g = dofs[c0 + il];
+            double *Trow = T + (size_t)il * ncol;
+            for (int q = Arow[g]; q < Arow[g + 1]; ++q) {
+                const int j = Acol[q];
+                const int m2 = mises[j];
+                const int k2 = k[m2];
+                if (k2 == 0) continue;
+                int lo = 0, hi = nn;
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (nb[mid] <= m2) lo = mid; else hi = mid; }
+                const int r2 = mis2d_I[m2 + 1] - mis2d_I[m2];
+                const double *U2 = U + u_off[m2] + row_in_mis[j];
+                const double a = Aval[q];
+                double *dst = Trow + pos[lo];
+                for (int v = 0; v < k2; ++v) dst[v] = fma(a, U2[(size_t)v * r2], dst[v]);
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < k1 * ncol; idx += RAP_NT) {
+            const int v1 = idx / ncol, cc = idx % ncol;
+            double sum = acc[idx];
+            const double *u = U1 + (size_t)v1 * r1 + c0;
+            for (int il = 0; il < rc; ++il) sum = fma(u[il], T[(size_t)il * ncol + cc], sum);
+            acc[idx] = sum;
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < k1 * ncol; idx += RAP_NT) {
+        const int v1 = idx / ncol, cc = idx % ncol;
+        cval[crowptr[coloff[m1] + v1] + cc] = acc[idx];
+    }
+}
+
+void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, const DCsr &A,
+             const std::vector<int> &h_k, const std::vector<int> &h_coloff, const int *d_k,
+             const int *d_coloff, const int64_t *d_u_off, const double *U, DCsr &Ac) {
+    const int nm = hrel.num_mises;
+    int nc = 0;
+    for (int m = 0; m < nm; ++m) nc += h_k[m];
+    Ac.nrows = Ac.ncols = nc;
+    Ac.nnz = 0;
+    if (nm == 0 || nc == 0) {
+        Ac.rowptr.from_host(std::vector<int>(1, 0), s);
+        return;
+    }
+    DBuf<int> cnt((size_t)nm), err(1);
+    err.zero(s);
+    profiler().begin(s);
+    hipLaunchKernelGGL(rap_symbolic_kernel, dim3(nm), dim3(RAP_NT), 0, s, 0, rel.mis2d_I.p,
+                       rel.mis2d_J.p, A.rowptr.p, A.col.p, rel.mises.p, d_k, cnt.p, nullptr, nullptr, err.p);
+    SA_HIP_CHECK(hipGetLastError());
+    std::vector<int> h_cnt = cnt.to_host(s);
+    SA_REQUIRE(err.to_host(s)[0] == 0, "RAP: MIS neighbour table overflow");
+    std::vector<int> h_nbr_ptr((size_t)nm + 1, 0);
+    for (int m = 0; m < nm; ++m) h_nbr_ptr[m + 1] = h_nbr_ptr[m] + h_cnt[m];
+    DBuf<int> nbr_ptr, nbr((size_t)h_nbr_ptr[nm] + 1);
+    nbr_ptr.from_host(h_nbr_ptr, s);
+    hipLaunchKernelGGL(rap_symbolic_kernel, dim3(nm), dim3(RAP_NT), 0, s, 1, rel.mis2d_I.p,
+                       rel.mis2d_J.p, A.rowptr.p, A.col.p, rel.mises.p, d_k, cnt.p, nbr_ptr.p, nbr.p, err.p);
+    SA_HIP_CHECK(hipGetLastError());
+    std::vector<int> h_nbr = nbr.to_host(s);
+    // row pointers of Ac and LDS sizing
+    std::vector<int> crow((size_t)nc + 1, 0);
+    int64_t nnz = 0;
+    size_t need_max = 0;
+    for (int m = 0; m < nm; ++m) {
+        if (h_k[m] == 0) continue;
+        int ncol = 0;
+        for (int t = h_nbr_ptr[m]; t < h_nbr_ptr[m + 1]; ++t) ncol += h_k[h_nbr[t]];
+        for (int v = 0; v < h_k[m]; ++v) {
+            crow[(size_t)h_coloff[m] + v + 1] = ncol;
+            nnz += ncol;
+        }
+        const size_t need = (size_t)(h_cnt[m] + 3) / 2 + (size_t)h_k[m] * ncol + (size_t)ncol;  // >= 1 row of T
+        if (need > need_max) need_max = need;
+    }
+    SA_REQUIRE(nnz < (int64_t)1 << 31, "coarse operator too large for 32-bit indices");
+    for (int i = 0; i < nc; ++i) crow[i + 1] += crow[i];
+    size_t lds_doubles = 8192;  // 64 KiB default: several workgroups per CU
+    if (need_max > lds_doubles) lds_doubles = need_max;
+    SA_REQUIRE(lds_doubles * 8 <= 160 * 1024, "RAP: MIS block too wide for LDS");
+    static bool attr = false;
+    if (!attr) {
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)rap_numeric_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    Ac.nnz = nnz;
+    Ac.rowptr.from_host(crow, s);
+    Ac.col.alloc((size_t)nnz);
+    Ac.val.alloc((size_t)nnz);
+    hipLaunchKernelGGL(rap_numeric_kernel, dim3(nm), dim3(RAP_NT), lds_doubles * 8, s, rel.mis2d_I.p,
+                       rel.mis2d_J.p, A.rowptr.p, A.col.p, A.val.p, rel.mises.p, rel.dof_row_in_mis.p,
+                       d_k, d_coloff, d_u_off, U, nbr_ptr.p, nbr.p, Ac.rowptr.p, Ac.col.p, Ac.val.p,
+                       (int)lds_doubles);
+    SA_HIP_CHECK(hipGetLastError());
+    SA_HIP_CHECK(hipStreamSynchronize(s));  // nbr buffers are freed on return
+    profiler().end(s, "rap", 12.0 * (double)(A.nnz + nnz) + 4.0 * A.nrows, 0.0);
+    Ac.lanes_per_row = pick_lanes_per_row(nnz, nc);
+}
+
+}  // namespace saamge_amd

@@ -1,0 +1,242 @@
+// CSR SpMV family for gfx950: L lanes of a 64-wide wavefront cooperate on one row
+// (L chosen from the average row length), val/col streamed with non-temporal loads so
+// the XCD L2 keeps the gathered x entries, fused epilogues for the residual, the
+// prolongation-add and the polynomial-smoother step.  HBM-bound: 12 B per nonzero.
+#include "sparse.h"
+
+namespace saamge_amd {
+
+enum { MODE_PLAIN = 0, MODE_RESIDUAL = 1, MODE_ADD = 2, MODE_SMOOTH = 3 };
+
+template <int L, int MODE>
+__global__ __launch_bounds__(256) void spmv_kernel(int nrows, const int *__restrict__ rowptr,
+                                                   const int *__restrict__ col,
+                                                   const double *__restrict__ val,
+                                                   const double *__restrict__ x,
+                                                   double *__restrict__ y,
+                                                   const double *__restrict__ b,
+                                                   const double *__restrict__ dinv, double scale) {
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & (L - 1);
+    const long row = gtid / L;
+    if (row >= nrows) return;  // whole L-group leaves together (256 % L == 0)
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    double sum = 0.0;
+    for (int k = beg + lane; k < end; k += L) {
+        const double v = __builtin_nontemporal_load(val + k);
+        const int c = __builtin_nontemporal_load(col + k);
+        sum = fma(v, x[c], sum);
+    }
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, L);
+    if (lane == 0) {
+        if (MODE == MODE_PLAIN) {
+            y[row] = sum;
+        } else if (MODE == MODE_RESIDUAL) {
+            y[row] = b[row] - sum;
+        } else if (MODE == MODE_ADD) {
+            y[row] += sum;
+        } else {  // x_out = x_in + scale * dinv_neg * (A x - b)
+            y[row] = x[row] + scale * (dinv[row] * (sum - b[row]));
+        }
+    }
+}
+
+template <int MODE>
+static void launch_spmv(hipStream_t s, const DCsr &A, const double *x, double *y, const double *b,
+                        const double *dinv, double scale) {
+    if (A.nrows == 0) return;
+    const int L = A.lanes_per_row;
+    const long threads = (long)A.nrows * L;
+    const int grid = div_up(threads, 256);
+#define SA_CASE(LL)                                                                              \
+    case LL:                                                                                     \
+        hipLaunchKernelGGL((spmv_kernel<LL, MODE>), dim3(grid), dim3(256), 0, s, A.nrows,        \
+                           A.rowptr.p, A.col.p, A.val.p, x, y, b, dinv, scale);                  \
+        break;
+    switch (L) {
+        SA_CASE(1) SA_CASE(2) SA_CASE(4) SA_CASE(8) SA_CASE(16) SA_CASE(32) SA_CASE(64)
+        default: SA_REQUIRE(false, "bad lanes_per_row");
+    }
+#undef SA_CASE
+    SA_HIP_CHECK(hipGetLastError());
+}
+
+static inline double spmv_bytes(const DCsr &A) { return 12.0 * A.nnz + 20.0 * A.nrows; }
+
+void spmv(hipStream_t s, const DCsr &A, const double *x, double *y) {
+    profiler().begin(s);
+    launch_spmv<MODE_PLAIN>(s, A, x, y, nullptr, nullptr, 0.0);
+    profiler().end(s, "spmv", spmv_bytes(A), 2.0 * A.nnz);
+}
+void spmv_residual(hipStream_t s, const DCsr &A, const double *x, const double *b, double *r) {
+    profiler().begin(s);
+    launch_spmv<MODE_RESIDUAL>(s, A, x, r, b, nullptr, 0.0);
+    profiler().end(s, "spmv_residual", spmv_bytes(A) + 8.0 * A.nrows, 2.0 * A.nnz);
+}
+void spmv_add(hipStream_t s, const DCsr &P, const double *xc, double *x) {
+    profiler().begin(s);
+    launch_spmv<MODE_ADD>(s, P, xc, x, nullptr, nullptr, 0.0);
+    profiler().end(s, "spmv_add", spmv_bytes(P) + 8.0 * P.nrows, 2.0 * P.nnz);
+}
+void smooth_step(hipStream_t s, const DCsr &A, const double *dinv_neg, const double *b,
+                 const double *xin, double *xout, double scale) {
+    profiler().begin(s);
+    launch_spmv<MODE_SMOOTH>(s, A, xin, xout, b, dinv_neg, scale);
+    profiler().end(s, "smooth_step", spmv_bytes(A) + 24.0 * A.nrows, 2.0 * A.nnz);
+}
+
+__global__ __launch_bounds__(256) void smooth_first_kernel(int n, const double *__restrict__ dinv,
+                                                           const double *__restrict__ b,
+                                                           double *__restrict__ xout, double scale) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) xout[i] = scale * (dinv[i] * (0.0 - b[i]));
+}
+void smooth_first(hipStream_t s, int n, const double *dinv_neg, const double *b, double *xout,
+                  double scale) {
+    if (!n) return;
+    profiler().begin(s);
+    hipLaunchKernelGGL(smooth_first_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, dinv_neg, b,
+                       xout, scale);
+    SA_HIP_CHECK(hipGetLastError());
+    profiler().end(s, "smooth_first", 24.0 * n, 2.0 * n);
+}
+
+// ---- weighted-l1 smoother diagonal ----------------------------------------------------
+__global__ __launch_bounds__(256) void sqrt_abs_diag_kernel(int nrows, const int *__restrict__ rowptr,
+                                                            const int *__restrict__ col,
+                                                            const double *__restrict__ val,
+                                                            double *__restrict__ sd) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= nrows) return;
+    double d = 0.0;
+    for (int k = rowptr[row]; k < rowptr[row + 1]; ++k)
+        if (col[k] == row) d += val[k];
+    sd[row] = sqrt(fabs(d));
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void dinv_neg_kernel(int nrows, const int *__restrict__ rowptr,
+                                                       const int *__restrict__ col,
+                                                       const double *__restrict__ val,
+                                                       const double *__restrict__ sd,
+                                                       double *__restrict__ out) {
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & (L - 1);
+    const long row = gtid / L;
+    if (row >= nrows) return;
+    double sum = 0.0;
+    for (int k = rowptr[row] + lane; k < rowptr[row + 1]; k += L) sum += fabs(val[k]) / sd[col[k]];
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, L);
+    if (lane == 0) out[row] = -1.0 / (sd[row] * sum);
+}
+
+void build_dinv_neg(hipStream_t s, const DCsr &A, double *sd, double *out) {
+    if (!A.nrows) return;
+    hipLaunchKernelGGL(sqrt_abs_diag_kernel, dim3(div_up(A.nrows, 256)), dim3(256), 0, s, A.nrows,
+                       A.rowptr.p, A.col.p, A.val.p, sd);
+    const int grid = div_up((long)A.nrows * 8, 256);
+    hipLaunchKernelGGL((dinv_neg_kernel<8>), dim3(grid), dim3(256), 0, s, A.nrows, A.rowptr.p,
+                       A.col.p, A.val.p, sd, out);
+    SA_HIP_CHECK(hipGetLastError());
+}
+
+// ---- deterministic dot product -----------------------------------------------------------
+__device__ inline double block_sum_256(double v, double *sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+    return r;  // valid on thread 0
+}
+
+__global__ __launch_bounds__(256) void dot_partial_kernel(int n, const double *__restrict__ a,
+                                                          const double *__restrict__ b,
+                                                          double *__restrict__ partials) {
+    __shared__ double sh[4];
+    double v = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        v = fma(a[i], b[i], v);
+    const double r = block_sum_256(v, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+__global__ __launch_bounds__(256) void dot_final_kernel(int np, const double *__restrict__ partials,
+                                                        double *__restrict__ out) {
+    __shared__ double sh[4];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) v += partials[i];
+    const double r = block_sum_256(v, sh);
+    if (threadIdx.x == 0) out[0] = r;
+}
+
+void dot(hipStream_t s, int n, const double *a, const double *b, double *partials, double *out) {
+    int grid = div_up(n, 256 * 8);
+    if (grid > 1024) grid = 1024;
+    if (grid < 1) grid = 1;
+    profiler().begin(s);
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(grid), dim3(256), 0, s, n, a, b, partials);
+    hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, s, grid, partials, out);
+    SA_HIP_CHECK(hipGetLastError());
+    profiler().end(s, "dot", 16.0 * n, 2.0 * n);
+}
+
+__global__ __launch_bounds__(256) void pcg_update_xr_kernel(int n, const double *__restrict__ sc,
+                                                            double *__restrict__ x,
+                                                            double *__restrict__ r,
+                                                            const double *__restrict__ d,
+                                                            const double *__restrict__ z) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double alpha = sc[0] / sc[1];
+    x[i] = fma(alpha, d[i], x[i]);
+    r[i] = fma(-alpha, z[i], r[i]);
+}
+void pcg_update_xr(hipStream_t s, int n, const double *sc, double *x, double *r, const double *d,
+                   const double *z) {
+    if (!n) return;
+    profiler().begin(s);
+    hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, sc, x, r, d, z);
+    SA_HIP_CHECK(hipGetLastError());
+    profiler().end(s, "pcg_update_xr", 48.0 * n, 4.0 * n);
+}
+
+__global__ __launch_bounds__(256) void pcg_update_d_kernel(int n, const double *__restrict__ sc,
+                                                           double *__restrict__ d,
+                                                           const double *__restrict__ z) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double beta = sc[2] / sc[0];
+    d[i] = fma(beta, d[i], z[i]);
+}
+void pcg_update_d(hipStream_t s, int n, const double *sc, double *d, const double *z) {
+    if (!n) return;
+    profiler().begin(s);
+    hipLaunchKernelGGL(pcg_update_d_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, sc, d, z);
+    SA_HIP_CHECK(hipGetLastError());
+    profiler().end(s, "pcg_update_d", 24.0 * n, 2.0 * n);
+}
+
+void vec_copy(hipStream_t s, int n, const double *src, double *dst) {
+    if (n) SA_HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+}
+void vec_zero(hipStream_t s, int n, double *dst) {
+    if (n) SA_HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(double) * n, s));
+}
+__global__ __launch_bounds__(256) void axpy_kernel(int n, double a, const double *__restrict__ x,
+                                                   double *__restrict__ y) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = fma(a, x[i], y[i]);
+}
+void vec_axpy(hipStream_t s, int n, double a, const double *x, double *y) {
+    if (!n) return;
+    hipLaunchKernelGGL(axpy_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, a, x, y);
+    SA_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace saamge_amd

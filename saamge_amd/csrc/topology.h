@@ -1,0 +1,58 @@
+// Integer topology of one level: the agg_partitioning_relations_t of the reference
+// (amg/inc/aggregates.hpp:120-179), single rank, built on the host and mirrored to
+// the device for the assembly / MIS kernels.
+#pragma once
+#include "common.h"
+
+namespace saamge_amd {
+
+struct Table {  // mfem::Table: CSR of ints
+    std::vector<int> I, J;
+    int ncols = 0;
+    int nrows() const { return (int)I.size() - 1; }
+    int row_size(int i) const { return I[i + 1] - I[i]; }
+    const int *row(int i) const { return J.data() + I[i]; }
+};
+
+Table table_transpose(const Table &T);                   // rows ascending (mfem::Transpose)
+Table table_mult(const Table &A, const Table &B);        // first-encounter order (mfem::Mult)
+
+constexpr signed char FLAG_BETWEEN_AES = 0x01;           // amg/inc/aggregates.hpp:102
+constexpr signed char FLAG_ON_ESS_BORDER = 0x02;         // amg/inc/aggregates.hpp:103
+
+struct Relations {
+    int ND = 0, NE = 0, nparts = 0, num_mises = 0;
+    Table elem_to_dof, dof_to_elem, AE_to_elem, AE_to_dof, dof_to_AE;
+    Table mis_to_dof, mis_to_AE, AE_to_mis;
+    std::vector<int> partitioning;   // elem -> AE
+    std::vector<int> dof_id_inAE;    // aligned with dof_to_AE.J
+    std::vector<int> elem_ldof;      // aligned with elem_to_dof.J: index of that dof in the element's AE
+    std::vector<int> mises;          // dof -> MIS
+    std::vector<int> dof_row_in_mis; // dof -> position inside its MIS
+    std::vector<signed char> agg_flags;
+    // (MIS, AE) incidence pairs, MIS-major (== mis_to_AE entries): local AE indices of the
+    // MIS's dofs, used to restrict AE eigenvectors to the MIS and to build P_loc.
+    std::vector<int64_t> pair_loc_off;  // [npairs+1] offsets into pair_loc
+    std::vector<int> pair_loc;          // AE-local index of each MIS dof
+    std::vector<int> ae_pair;           // aligned with AE_to_mis.J: pair id of (AE, mis)
+};
+
+// agg_create_partitioning_tables + agg_produce_mises + agg_construct_agg_flags
+// (amg/src/aggregates.cpp:1357-1443, :501-653, :198-216).  bdr may be null (coarse levels).
+void build_relations(Relations &r, Table &&elem_to_dof, const std::vector<int> &partitioning,
+                     int nparts, int ND, const signed char *bdr);
+
+struct DevRelations {
+    DBuf<int> e2d_I, e2d_J, elem_ldof, part;
+    DBuf<int> d2e_I, d2e_J;
+    DBuf<int> ae2d_I, ae2d_J;
+    DBuf<int> d2ae_I, d2ae_J, dof_id_inAE;
+    DBuf<int> mis2d_I, mis2d_J, mis2ae_I, mis2ae_J, ae2mis_I, ae2mis_J, ae_pair;
+    DBuf<int> mises, dof_row_in_mis;
+    DBuf<int64_t> pair_loc_off;
+    DBuf<int> pair_loc;
+    DBuf<signed char> flags;
+};
+void upload_relations(DevRelations &d, const Relations &r, hipStream_t s);
+
+}  // namespace saamge_amd

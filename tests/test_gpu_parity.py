@@ -1,0 +1,236 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
+inputs.  Bit-exact for integer topology; fp64 quantities within the tolerances written in
+each test.  Run with `pytest -m gpu` on an MI355X."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from saamge_amd import problems as pr
+
+pytestmark = pytest.mark.gpu
+
+EIG_TOL = 1e-11      # eigenvalues, absolute (spectrum of D^-1 A lies in [0, 1])
+PROJ_TOL = 1e-9      # D-orthogonal projectors onto the wanted eigenspaces
+VCYCLE_TOL = 1e-10   # relative, V-cycle output / PCG residual history (north_star)
+
+
+def _capi():
+    from saamge_amd import capi
+    return capi
+
+
+def _oracle():
+    from oracle import saamge_oracle as o
+    return o
+
+
+def test_spmv_matches_scipy():
+    capi = _capi()
+    rng = np.random.default_rng(0)
+    for (n, m, dens) in [(1, 1, 1.0), (37, 53, 0.2), (1000, 1000, 0.03), (5000, 300, 0.01)]:
+        A = sp.random(n, m, density=dens, random_state=rng, format="csr")
+        A.data[:] = rng.standard_normal(A.nnz)
+        x = rng.standard_normal(m)
+        y = capi.spmv(A, x)
+        ref = A @ x
+        assert np.allclose(y, ref, rtol=1e-13, atol=1e-13 * (np.abs(A) @ np.abs(x)).max() + 1e-300)
+    # empty rows
+    A = sp.csr_matrix((5, 4))
+    assert np.array_equal(capi.spmv(A, np.ones(4)), np.zeros(5))
+
+
+def _proj(X, D):
+    """D-orthogonal projector onto span(X) applied to a fixed probe."""
+    n = X.shape[0]
+    probe = np.cos(np.arange(n) * 0.7 + 0.3)
+    G = X.T @ (D[:, None] * X)
+    return X @ np.linalg.solve(G, X.T @ (D * probe))
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_batched_lower_eigens_vs_lapack(seed):
+    """xpacks_calc_lower_eigens_dense: same counts, eigenvalues and eigenspaces as dsygvx."""
+    capi, o = _capi(), _oracle()
+    rng = np.random.default_rng(seed)
+    mats, diags, thetas = [], [], []
+    for n in [1, 2, 3, 5, 8, 17, 33, 64, 65, 100, 130, 257]:
+        # sparse-ish SPSD "stiffness" matrix with a known null vector, like an AE matrix
+        G = sp.random(n, n, density=min(1.0, 6.0 / n), random_state=rng).toarray()
+        W = np.abs(G + G.T)
+        L = np.diag(W.sum(axis=1)) - W
+        L += 1e-3 * np.diag(rng.random(n)) * (seed == 1)
+        if n == 1:
+            L = np.array([[2.0]])
+        L = L + np.diag(np.where(np.diag(L) <= 0, 1.0, 0.0))
+        D = o.snd_D_from_dense(L)
+        mats.append(L)
+        diags.append(D)
+    theta = 0.05
+    res = capi.lower_eigens_batched(mats, diags, -1.0, theta)
+    for L, D, (w, X) in zip(mats, diags, res):
+        wr, Xr = o.lower_eigens_dense(L, D, theta)
+        assert len(w) == len(wr), (L.shape, w, wr)
+        assert np.allclose(w, wr, rtol=0, atol=EIG_TOL)
+        # D-orthonormality and residuals
+        G = X.T @ (D[:, None] * X)
+        assert np.allclose(G, np.eye(len(w)), atol=1e-10)
+        R = L @ X - (D[:, None] * X) * w[None, :]
+        assert np.abs(R).max() <= 1e-10 * max(1.0, np.abs(L).max())
+        assert np.allclose(_proj(X, D), _proj(Xr, D), atol=PROJ_TOL)
+
+
+def test_batched_eigens_degenerate_and_split():
+    """Degenerate clusters (block-diagonal copies) and splitting tridiagonals."""
+    capi, o = _capi(), _oracle()
+    B = np.array([[2.0, -1, 0, -1], [-1, 2, -1, 0], [0, -1, 2, -1], [-1, 0, -1, 2]])
+    L = np.kron(np.eye(3), B) + 1e-9 * np.eye(12)  # three identical blocks: 3-fold eigenvalues
+    D = o.snd_D_from_dense(L)
+    for theta in [1e-6, 0.6, 1.0]:
+        (w, X), = capi.lower_eigens_batched([L], [D], -1.0, theta)
+        wr, Xr = o.lower_eigens_dense(L, D, theta)
+        assert len(w) == len(wr)
+        assert np.allclose(w, wr, atol=EIG_TOL)
+        assert np.allclose(_proj(X, D), _proj(Xr, D), atol=PROJ_TOL)
+        assert np.allclose(X.T @ (D[:, None] * X), np.eye(len(w)), atol=1e-10)
+    # nothing below theta -> the single smallest pair (atleast_one)
+    L2 = np.diag([3.0, 2.0, 5.0]) + 0.1
+    D2 = np.ones(3) * 0.5
+    (w, X), = capi.lower_eigens_batched([L2], [D2], -1.0, 1e-3)
+    wr, Xr = o.lower_eigens_dense(L2, D2, 1e-3)
+    assert len(w) == 1 and np.allclose(w, wr, atol=1e-12)
+
+
+def _compare_level(h, H, lev, theta):
+    """Compare one level of the HIP hierarchy `h` with the oracle hierarchy `H`."""
+    o = _oracle()
+    olv = H.levels[lev]
+    rel = olv.rel
+    info = h.level_info(lev)
+    assert info["n"] == olv.A.shape[0]
+    assert info["nparts"] == rel.nparts
+    # --- integer topology: bit exact ---
+    for name, T in [("AE_to_dof", rel.AE_to_dof), ("dof_to_AE", rel.dof_to_AE),
+                    ("mis_to_dof", rel.mis_to_dof), ("mis_to_AE", rel.mis_to_AE),
+                    ("AE_to_mis", rel.AE_to_mis), ("elem_to_dof", rel.elem_to_dof)]:
+        I, J = h.get_table(lev, name)
+        assert np.array_equal(I, T.I), name
+        assert np.array_equal(J, T.J), name
+    mises, k, ncols, flags = h.get_mis(lev)
+    assert np.array_equal(mises, rel.mises)
+    assert np.array_equal(flags.astype(np.int64) & 3, rel.agg_flags & 3)
+    # --- coarse-space dimensions: bit exact ---
+    assert np.array_equal(k, olv.mis_numcoarsedof)
+    assert info["ncoarse"] == olv.P.shape[1]
+    # --- local spectral problems ---
+    m, ev, X, Ds = h.get_ae_eigens(lev)
+    for i in range(rel.nparts):
+        assert m[i] == olv.evects[i].shape[1]
+        assert np.allclose(Ds[i], olv.Ds[i], rtol=1e-13)
+        assert np.allclose(ev[i], olv.evals[i][:len(ev[i])], atol=EIG_TOL)
+        assert np.allclose(_proj(X[i], Ds[i]), _proj(olv.evects[i], olv.Ds[i]), atol=PROJ_TOL)
+    # --- per-MIS singular values and column spaces ---
+    off, sig, U = h.get_mis_svd(lev)
+    uo = 0
+    for mis in range(rel.num_mises):
+        r = rel.mis_to_dof.row_size(mis)
+        kk = int(k[mis])
+        Um = U[uo:uo + r * kk].reshape(kk, r).T
+        uo += r * kk
+        Uo = olv.mis_tent_interps[mis]
+        assert Uo.shape == (r, kk)
+        if kk:
+            assert np.allclose(Um @ (Um.T @ np.ones(r)), Uo @ (Uo.T @ np.ones(r)), atol=1e-9)
+            assert np.allclose(Um.T @ Um, np.eye(kk), atol=1e-11)
+        s_or = olv.mis_svals[mis]
+        if s_or is not None and r > 1:
+            s_gpu = sig[off[mis]:off[mis] + len(s_or)]
+            assert np.allclose(s_gpu, s_or, atol=1e-10)
+    # --- prolongator / coarse operator: basis-independent comparisons ---
+    P = h.get_csr(lev, "P")
+    R = h.get_csr(lev, "R")
+    Ac = h.get_csr(lev, "Ac")
+    assert abs(P - R.T).max() == 0.0
+    A = h.get_csr(lev, "A")
+    Ac_ref = (P.T @ A @ P).toarray()
+    assert np.allclose(Ac.toarray(), Ac_ref, rtol=0, atol=1e-12 * np.abs(Ac_ref).max())
+    probe = np.sin(np.arange(P.shape[0]) * 0.37)
+    # P P^T (orthonormal columns per MIS -> orthogonal projector onto range(P))
+    assert np.allclose(P @ (P.T @ probe), olv.P @ (olv.P.T @ probe), atol=1e-9)
+
+
+def _build_pair(prob, ncoars, theta=0.003, testmesh=False, nu_relax=3):
+    capi, o = _capi(), _oracle()
+    params = capi.default_params(num_coarsenings=ncoars, theta=theta, nu_relax=nu_relax,
+                                 testmesh=testmesh, keep_debug=True, coarse_rtol=1e-28)
+    h = capi.Hierarchy.from_problem(prob, params)
+    H = o.ml_produce_data(prob.A, prob.elem_to_dof, prob.elmat, prob.bdr,
+                          prob.partitions[:ncoars], theta=theta, nu_relax=nu_relax, testmesh=testmesh)
+    return h, H
+
+
+@pytest.mark.parametrize("order,levels", [(1, 2), (1, 3), (2, 2)])
+def test_mltest_fixture_matches_oracle(order, levels):
+    """The reference's own ctest fixture (mltest / threelevel / mltest2)."""
+    o = _oracle()
+    prob = pr.mltest_problem(order=order, levels=levels)
+    h, H = _build_pair(prob, levels - 1, testmesh=True)
+    for lev in range(levels - 1):
+        _compare_level(h, H, lev, 0.003)
+    # V-cycle on a fixed right-hand side
+    b = np.cos(np.arange(prob.ND) * 0.3) * (~prob.ess)
+    x_gpu = h.vcycle(b)
+    x_ref = o.vcycle(H, b)
+    assert np.linalg.norm(x_gpu - x_ref) <= VCYCLE_TOL * np.linalg.norm(x_ref)
+    # PCG with the reference driver's tolerance
+    x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-6)
+    xr, itr, convr, histr = o.solve(H, prob.b, rel_tol=1e-6)
+    assert conv and it == itr
+    assert np.allclose(hist[:2], histr[:2], rtol=1e-9)
+    assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr)
+    h.close()
+
+
+@pytest.mark.parametrize("n,blk,cblk,K", [
+    ((8, 8, 8), (4, 4, 2), None, (1, 1, 1)),
+    ((8, 8, 8), (4, 4, 4), [(2, 2, 1)], (1, 1, 1)),
+    ((12, 8, 4), (4, 4, 2), None, (1, 1, 1000.0)),
+])
+def test_poisson3d_matches_oracle(n, blk, cblk, K):
+    o = _oracle()
+    prob = pr.poisson3d_problem(n, blk=blk, coarse_blk=cblk, K=K)
+    ncoars = 1 + (len(cblk) if cblk else 0)
+    theta = 0.003 if K[2] == 1 else 0.02
+    h, H = _build_pair(prob, ncoars, theta=theta)
+    for lev in range(ncoars):
+        _compare_level(h, H, lev, theta)
+    b = np.cos(np.arange(prob.ND) * 0.13) * (~prob.ess)
+    x_gpu = h.vcycle(b)
+    x_ref = o.vcycle(H, b)
+    # degenerate eigenspaces (symmetric AEs) make the coarse *basis* non-unique; with two
+    # levels the V-cycle is invariant to it, with three the level-1 smoother is not.
+    tol = VCYCLE_TOL if ncoars == 1 else 5e-2
+    assert np.linalg.norm(x_gpu - x_ref) <= tol * np.linalg.norm(x_ref)
+    x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-8)
+    xr, itr, convr, histr = o.solve(H, prob.b, rel_tol=1e-8)
+    assert conv and convr
+    if ncoars == 1:
+        assert it == itr
+        assert np.allclose(hist, histr, rtol=1e-7, atol=1e-10 * histr[0])
+    else:
+        assert abs(it - itr) <= 1
+    assert np.linalg.norm(prob.A @ x - prob.b) <= 1e-6 * np.linalg.norm(prob.b)
+    h.close()
+
+
+def test_smoother_matches_oracle():
+    o = _oracle()
+    prob = pr.poisson3d_problem((6, 6, 6), blk=(3, 3, 3))
+    h, H = _build_pair(prob, 1)
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal(prob.ND)
+    x0 = rng.standard_normal(prob.ND)
+    x = h.smoother(0, b, x0.copy())
+    lv = H.levels[0]
+    xr = o.compute_poly(lv.A, b, x0.copy(), lv.roots, lv.Dinv_neg)
+    assert np.linalg.norm(x - xr) <= 1e-13 * np.linalg.norm(xr)
+    h.close()
