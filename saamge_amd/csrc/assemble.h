@@ -28,7 +28,7 @@ void ae_scale(hipStream_t s, EigBatch &batch, double *Dout);
 // the *unscaled* AE matrices.  Output row-major at out[out_off[e]], k_e x k_e.
 void coarse_elmats(hipStream_t s, const DevRelations &rel, int ae0, const EigBatch &batch,
                    const int *mis_k, const int64_t *mis_u_off, const double *mis_u,
-                   const int *ae_mis_colbase, const int64_t *out_off, double *out,
+                   const int *colpos_ptr, const int *colpos, const int64_t *out_off, double *out,
                    double *scratch, const int64_t *scratch_off);
 
 }  // namespace saamge_amd

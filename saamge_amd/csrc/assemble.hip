@@ -134,7 +134,8 @@ __global__ __launch_bounds__(ASM_NT) void coarse_elmat_kernel(
     const int64_t *__restrict__ pair_loc_off, const int *__restrict__ pair_loc,
     const int *__restrict__ mis2d_I, const int *__restrict__ mis_k,
     const int64_t *__restrict__ mis_u_off, const double *__restrict__ mis_u,
-    const int *__restrict__ colbase, const int64_t *__restrict__ out_off, double *__restrict__ out,
+    const int *__restrict__ colpos_ptr, const int *__restrict__ colpos,
+    const int64_t *__restrict__ out_off, double *__restrict__ out,
     double *__restrict__ scratch, const int64_t *__restrict__ scratch_off) {
     const int b = blockIdx.x, e = ae0 + b, n = ns[b];
     const double *Am = W + moff[b];
@@ -150,12 +151,12 @@ __global__ __launch_bounds__(ASM_NT) void coarse_elmat_kernel(
         const int r = mis2d_I[mis + 1] - mis2d_I[mis];
         const int *loc = pair_loc + pair_loc_off[ae_pair[t]];
         const double *U = mis_u + mis_u_off[mis];
-        const int cb = colbase[t];
+        const int *cp = colpos + colpos_ptr[t];
         for (int idx = tid; idx < n * k; idx += ASM_NT) {
             const int i = idx % n, v = idx / n;
             double sum = 0.0;
             for (int q = 0; q < r; ++q) sum = fma(Am[(size_t)loc[q] * n + i], U[(size_t)v * r + q], sum);
-            T[(size_t)(cb + v) * n + i] = sum;
+            T[(size_t)cp[v] * n + i] = sum;
         }
     }
     __syncthreads();
@@ -166,26 +167,26 @@ __global__ __launch_bounds__(ASM_NT) void coarse_elmat_kernel(
         const int r = mis2d_I[mis + 1] - mis2d_I[mis];
         const int *loc = pair_loc + pair_loc_off[ae_pair[t]];
         const double *U = mis_u + mis_u_off[mis];
-        const int cb = colbase[t];
+        const int *cp = colpos + colpos_ptr[t];
         for (int idx = tid; idx < k * ke; idx += ASM_NT) {
             const int col = idx % ke, v = idx / ke;
             double sum = 0.0;
             for (int q = 0; q < r; ++q) sum = fma(U[(size_t)v * r + q], T[(size_t)col * n + loc[q]], sum);
-            E[(size_t)(cb + v) * ke + col] = sum;
+            E[(size_t)cp[v] * ke + col] = sum;
         }
     }
 }
 
 void coarse_elmats(hipStream_t s, const DevRelations &rel, int ae0, const EigBatch &batch,
                    const int *mis_k, const int64_t *mis_u_off, const double *mis_u,
-                   const int *ae_mis_colbase, const int64_t *out_off, double *out,
+                   const int *colpos_ptr, const int *colpos, const int64_t *out_off, double *out,
                    double *scratch, const int64_t *scratch_off) {
     if (!batch.count) return;
     profiler().begin(s);
     hipLaunchKernelGGL(coarse_elmat_kernel, dim3(batch.count), dim3(ASM_NT), 0, s, ae0, batch.n.p,
                        batch.moff.p, batch.W.p, rel.ae2mis_I.p, rel.ae2mis_J.p, rel.ae_pair.p,
                        rel.pair_loc_off.p, rel.pair_loc.p, rel.mis2d_I.p, mis_k, mis_u_off, mis_u,
-                       ae_mis_colbase, out_off, out, scratch, scratch_off);
+                       colpos_ptr, colpos, out_off, out, scratch, scratch_off);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "coarse_elmats", 0.0, 0.0);
 }

@@ -208,28 +208,45 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
     hipStream_t s = H.stream;
     const Relations &rel = L.rel;
     const int nparts = rel.nparts;
-    // coarse elem_to_dof: walk the AE's dofs in AE order, append a MIS's coarse dofs when the
-    // MIS is first met (== AE_to_dof x pattern(P_tent) in first-encounter order)
+    // coarse elem_to_dof = AE_to_dof x pattern(P_tent), first-encounter order
+    // (agg_create_rels_except_elem_coarse, amg/src/aggregates.cpp:1510-1514).  The pattern is
+    // the *numerically non-zero* entries of P_tent (contrib_tent_insert_simple drops exact
+    // zeros, amg/src/contrib.cpp:186-187), so P's values are inspected on the host.
     Table e2d;
     e2d.ncols = L.mis_coloff.back();
     e2d.I.assign((size_t)nparts + 1, 0);
-    std::vector<int> colbase(rel.AE_to_mis.J.size(), -1);
-    std::vector<int> stamp((size_t)rel.num_mises, -1);
+    std::vector<int> p_rowptr = L.P.rowptr.to_host(s);
+    std::vector<double> p_val = L.P.val.to_host(s);
+    // colpos: for every (AE, MIS) incidence (aligned with AE_to_mis.J) the position of each of
+    // the MIS's coarse dofs in the coarse element's dof list
+    std::vector<int> colpos_ptr(rel.AE_to_mis.J.size() + 1, 0);
+    for (int e = 0; e < nparts; ++e)
+        for (int t = rel.AE_to_mis.I[e]; t < rel.AE_to_mis.I[e + 1]; ++t)
+            colpos_ptr[(size_t)t + 1] = colpos_ptr[t] + L.mis_k[rel.AE_to_mis.J[t]];
+    std::vector<int> colpos((size_t)colpos_ptr.back(), -1);
+    std::vector<int> stamp((size_t)e2d.ncols, -1);
     for (int e = 0; e < nparts; ++e) {
         int run = 0;
+        const int *misrow = rel.AE_to_mis.row(e);
+        const int nmis = rel.AE_to_mis.row_size(e);
         for (int k = rel.AE_to_dof.I[e]; k < rel.AE_to_dof.I[e + 1]; ++k) {
-            const int m = rel.mises[rel.AE_to_dof.J[k]];
-            if (stamp[m] == e) continue;
-            stamp[m] = e;
-            if (L.mis_k[m] == 0) continue;
-            const int *row = rel.AE_to_mis.row(e);
-            const int t = (int)(std::lower_bound(row, row + rel.AE_to_mis.row_size(e), m) - row);
-            colbase[(size_t)rel.AE_to_mis.I[e] + t] = run;
-            for (int v = 0; v < L.mis_k[m]; ++v) e2d.J.push_back(L.mis_coloff[m] + v);
-            run += L.mis_k[m];
+            const int dof = rel.AE_to_dof.J[k];
+            const int m = rel.mises[dof];
+            const int km = L.mis_k[m];
+            if (km == 0) continue;
+            const int t = rel.AE_to_mis.I[e] + (int)(std::lower_bound(misrow, misrow + nmis, m) - misrow);
+            for (int v = 0; v < km; ++v) {
+                const int cd = L.mis_coloff[m] + v;
+                if (stamp[cd] == e) continue;
+                if (p_val[(size_t)p_rowptr[dof] + v] == 0.0) continue;
+                stamp[cd] = e;
+                colpos[(size_t)colpos_ptr[t] + v] = run++;
+                e2d.J.push_back(cd);
+            }
         }
         e2d.I[e + 1] = e2d.I[e] + run;
     }
+    for (int v : colpos) SA_REQUIRE(v >= 0, "coarse dof with an all-zero prolongator column in an AE");
     // coarse element matrices
     Level &N = *H.levels[lev + 1];
     std::vector<int64_t> out_off((size_t)nparts + 1, 0);
@@ -239,8 +256,9 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
     }
     N.elmat.off.from_host(out_off, s);
     N.elmat.val.alloc((size_t)out_off[nparts] + 1);
-    DBuf<int> d_colbase;
-    d_colbase.from_host(colbase, s);
+    DBuf<int> d_colpos_ptr, d_colpos;
+    d_colpos_ptr.from_host(colpos_ptr, s);
+    d_colpos.from_host(colpos, s);
     std::vector<int> sizes((size_t)nparts);
     for (int p = 0; p < nparts; ++p) sizes[p] = rel.AE_to_dof.row_size(p);
     for (int ae0 = 0; ae0 < nparts;) {
@@ -261,8 +279,8 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
         DBuf<int64_t> d_soff;
         d_soff.from_host(soff, s);
         DBuf<double> scratch((size_t)soff[cnt] + 1);
-        coarse_elmats(s, L.drel, ae0, batch, L.d_mis_k.p, L.d_mis_u_off.p, L.mis_U.p, d_colbase.p,
-                      N.elmat.off.p, N.elmat.val.p, scratch.p, d_soff.p);
+        coarse_elmats(s, L.drel, ae0, batch, L.d_mis_k.p, L.d_mis_u_off.p, L.mis_U.p, d_colpos_ptr.p,
+                      d_colpos.p, N.elmat.off.p, N.elmat.val.p, scratch.p, d_soff.p);
         SA_HIP_CHECK(hipStreamSynchronize(s));
         ae0 += cnt;
     }
