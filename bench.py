@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- AMG setup+solve throughput on synthetic 3-D Poisson (BASELINE.json metric).
+
+One "step" = one full pass of the hot path over one problem that is already resident in
+HBM: ml_produce_data (topology -> spectral problems -> P -> RAP, all levels) followed by
+PCG to sqrt((B r_k,r_k)/(B r_0,r_0)) < 1e-8.  value = DoF/s = N * steps / time.
+
+    python bench.py --gpus 1 --steps K --warmup W [--n 256] [--levels 3]
+
+Prints ONE JSON line (rank 0).  Extra legs, outside the timed region:
+  * roofline: HIP-event timing of every kernel launch of one more step (the library's own
+    event pairs on the launch stream), reported for the dominant kernel;
+  * cpu_baseline: the CPU oracle (numpy + LAPACK dsygvx/dgesvd) on a bounded sample of the
+    same workload, timed on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_PEAK_TFLOPS = 78.6    # MI355X datasheet fp64 vector == matrix
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_problem(n, levels, dev):
+    from saamge_amd import problems
+    cb = [(8, 8, 4)] * (levels - 2)
+    return problems.poisson3d_device(n, blk=(8, 8, 4), coarse_blk=cb, device=dev)
+
+
+def one_step(capi, prob, params, rel_tol=1e-8):
+    import torch
+    h = capi.Hierarchy(prob.rowptr, prob.col, prob.val, prob.n, prob.elem_to_dof, prob.elmat,
+                       prob.bdr, prob.partitions, prob.nparts, params, prob.NE_, 8)
+    x = torch.zeros_like(prob.b)
+    _, it, conv, hist = h.pcg(prob.b, x, rel_tol=rel_tol, max_iter=200)
+    return h, x, it, conv, hist
+
+
+def cpu_baseline(n_sample, levels):
+    """Oracle setup+solve on a bounded sample: the same discretisation and AE shape on a
+    smaller cube, scaled per dof."""
+    import numpy as np
+    from saamge_amd import problems
+    from oracle import saamge_oracle as oracle
+    cb = [(2, 2, 2)] * (levels - 2)
+    prob = problems.poisson3d_problem(n_sample, blk=(8, 8, 4), coarse_blk=cb)
+    t0 = time.perf_counter()
+    H = oracle.ml_produce_data(prob.A, prob.elem_to_dof, prob.elmat, prob.bdr,
+                               prob.partitions, theta=0.003, nu_relax=3)
+    t1 = time.perf_counter()
+    x, it, conv, hist = oracle.solve(H, prob.b, rel_tol=1e-8)
+    t2 = time.perf_counter()
+    nd = prob.A.shape[0]
+    return {"value": nd / (t2 - t0), "unit": "DoF/s", "cores": 1, "kind": "port",
+            "sample": "oracle (numpy + LAPACK dsygvx/dgesvd, 1 thread) on 3-D Poisson %s, %d-level, "
+                      "8x8x4-element AEs: setup %.2f s, solve %.2f s, %d PCG its"
+                      % ("x".join(str(v) for v in n_sample), levels, t1 - t0, t2 - t1, it)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=128)
+    ap.add_argument("--levels", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from saamge_amd import capi
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    prob = build_problem(args.n, args.levels, dev)
+    torch.cuda.synchronize()
+    params = capi.default_params(num_coarsenings=args.levels - 1, theta=0.003, nu_relax=3)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    its = conv = None
+    for _ in range(args.warmup):
+        h, x, its, conv, hist = one_step(capi, prob, params)
+        h.close()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        h, x, its, conv, hist = one_step(capi, prob, params)
+        if _ < args.steps - 1:
+            h.close()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    infos = [h.level_info(l) for l in range(args.levels - 1)]
+    h.close()
+
+    res = {
+        "metric": "AMG setup+solve DoF/s (3D Poisson, PCG to 1e-8)",
+        "value": world * prob.n * args.steps / dt,
+        "unit": "DoF/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "3D Poisson %d^3 Q1 hexes, %d-level SAAMGE, theta=0.003, nu_relax=3, "
+                               "8x8x4-element AEs" % (args.n, args.levels),
+                   "dofs": prob.n, "pcg_iterations": its, "converged": bool(conv),
+                   "level_dims": [i["n"] for i in infos] + [infos[-1]["ncoarse"]],
+                   "parallelism": "replicas" if world > 1 else "single"},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        capi.profile(True)
+        capi.profile_reset()
+        h, x, its2, conv2, hist2 = one_step(capi, prob, params)
+        h.close()
+        capi.profile(False)
+        stats = sorted(capi.profile_stats(), key=lambda s: -s["ms"])
+        tot = sum(s["ms"] for s in stats)
+        for s in stats:
+            log("  %-16s %9.3f ms %6d launches  %8.1f GB/s  %8.2f TFLOP/s"
+                % (s["name"], s["ms"], s["launches"], s["bytes"] / max(s["ms"], 1e-9) / 1e6,
+                   s["flops"] / max(s["ms"], 1e-9) / 1e9))
+        log("  kernel total %.3f ms (profiled step)" % tot)
+        d = stats[0]
+        avg_ms = d["ms"] / d["launches"]
+        if d["name"].startswith("eig_"):
+            ach = d["flops"] / d["ms"] / 1e9
+            res["roofline"] = {"kernel": d["name"], "bound": "mfma", "achieved": ach,
+                               "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
+                               "traffic": None, "avg_launch_ms": avg_ms, "launches": d["launches"]}
+        else:
+            ach = d["bytes"] / d["ms"] / 1e6
+            res["roofline"] = {"kernel": d["name"], "bound": "hbm", "achieved": ach,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "traffic": None, "avg_launch_ms": avg_ms, "launches": d["launches"]}
+        res["kernels"] = [{"name": s["name"], "ms": round(s["ms"], 3), "launches": s["launches"]}
+                          for s in stats[:8]]
+    if rank == 0 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline((16, 16, 8), args.levels)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -283,3 +283,98 @@ def poisson3d_problem(n, blk=(8, 8, 4), K=(1.0, 1.0, 1.0), coarse_blk=None,
     return Problem(A=A, b=b, elem_to_dof=elem_to_dof,
                    elmat=np.ascontiguousarray(elmat) if with_elmat else None,
                    bdr=bdr, ess=ess, partitions=parts, dims=n, order=1, Kref=Kref, coefs=c)
+
+
+# --------------------------------------------------------------------------
+# device-resident generator (torch is plumbing: it only allocates/fills HBM)
+# --------------------------------------------------------------------------
+def poisson3d_device(n, blk=(8, 8, 4), coarse_blk=None, K=(1.0, 1.0, 1.0), device="cuda"):
+    """Same problem as poisson3d_problem (constant coefficient), generated directly in
+    HBM with torch so that 128^3 / 256^3 inputs never touch the host.  Returns a Problem
+    whose arrays are torch tensors on `device` (A as rowptr/col/val tensors)."""
+    import torch
+    if np.isscalar(n):
+        n = (int(n),) * 3
+    nx, ny, nz = n
+    h = (1.0 / nx, 1.0 / ny, 1.0 / nz)
+    nvx, nvy, nvz = nx + 1, ny + 1, nz + 1
+    ND = nvx * nvy * nvz
+    NE = nx * ny * nz
+    dev = torch.device(device)
+    Kref = torch.tensor(hex_element_matrix(h, K), dtype=torch.float64, device=dev)
+    # local index of the vertex with offset (ox,oy,oz) in {0,1}^3 inside an element
+    lidx = {}
+    for a, (ox, oy, oz) in enumerate(_HEX_LOC):
+        lidx[(ox, oy, oz)] = a
+    iz = torch.arange(nvz, device=dev).view(-1, 1, 1)
+    iy = torch.arange(nvy, device=dev).view(1, -1, 1)
+    ix = torch.arange(nvx, device=dev).view(1, 1, -1)
+    ess = ((ix == 0) | (ix == nx) | (iy == 0) | (iy == ny) | (iz == 0) | (iz == nz)).reshape(-1)
+    node = ((iz * nvy + iy) * nvx + ix).reshape(-1)
+    vals = torch.zeros((ND, 27), dtype=torch.float64, device=dev)
+    cols = torch.zeros((ND, 27), dtype=torch.int32, device=dev)
+    valid = torch.zeros((ND, 27), dtype=torch.bool, device=dev)
+    o = 0
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                jx, jy, jz = ix + dx, iy + dy, iz + dz
+                ok = ((jx >= 0) & (jx <= nx) & (jy >= 0) & (jy <= ny) & (jz >= 0) & (jz <= nz))
+                acc = torch.zeros((nvz, nvy, nvx), dtype=torch.float64, device=dev)
+                # elements containing both nodes, ascending element id (ez, ey, ex)
+                for sz in (-1, 0):
+                    for sy in (-1, 0):
+                        for sx in (-1, 0):
+                            ex, ey, ez = ix + sx, iy + sy, iz + sz
+                            a = (-sx, -sy, -sz)                     # this node inside the element
+                            b = (dx - sx, dy - sy, dz - sz)         # neighbour inside the element
+                            if min(b) < 0 or max(b) > 1:
+                                continue
+                            inside = ((ex >= 0) & (ex < nx) & (ey >= 0) & (ey < ny) &
+                                      (ez >= 0) & (ez < nz))
+                            acc = acc + torch.where(inside & ok, Kref[lidx[a], lidx[b]], 0.0)
+                vals[:, o] = acc.reshape(-1)
+                cols[:, o] = ((jz * nvy + jy) * nvx + jx).reshape(-1).to(torch.int32)
+                valid[:, o] = ok.expand(nvz, nvy, nvx).reshape(-1)
+                o += 1
+    # eliminate essential rows / columns, keep the diagonal and the explicit zeros
+    colc = cols.clamp(0, ND - 1).long()
+    kill = (ess.view(-1, 1) | ess[colc]) & (colc != node.view(-1, 1))
+    vals = torch.where(kill, torch.zeros_like(vals), vals)
+    counts = valid.sum(dim=1)
+    rowptr = torch.zeros(ND + 1, dtype=torch.int32, device=dev)
+    rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    flat = valid.reshape(-1)
+    A_col = cols.reshape(-1)[flat].contiguous()
+    A_val = vals.reshape(-1)[flat].contiguous()
+    del vals, cols, valid, colc, kill
+    # elements
+    ez = torch.arange(nz, device=dev).view(-1, 1, 1)
+    ey = torch.arange(ny, device=dev).view(1, -1, 1)
+    ex = torch.arange(nx, device=dev).view(1, 1, -1)
+    e2d = torch.stack([(((ez + c) * nvy + (ey + b_)) * nvx + (ex + a)).reshape(-1)
+                       for (a, b_, c) in _HEX_LOC], dim=1).to(torch.int32).contiguous()
+    elmat = Kref.reshape(1, 64).expand(NE, 64).contiguous()
+    # right-hand side f = 1
+    wx = torch.full((nvx,), 1.0, dtype=torch.float64, device=dev); wx[0] = wx[-1] = 0.5
+    wy = torch.full((nvy,), 1.0, dtype=torch.float64, device=dev); wy[0] = wy[-1] = 0.5
+    wz = torch.full((nvz,), 1.0, dtype=torch.float64, device=dev); wz[0] = wz[-1] = 0.5
+    b = (h[0] * h[1] * h[2]) * (wz.view(-1, 1, 1) * wy.view(1, -1, 1) * wx.view(1, 1, -1)).reshape(-1)
+    b = torch.where(ess, torch.zeros_like(b), b).contiguous()
+    bdr = torch.where(ess, AGG_ON_ESS_DOMAIN_BORDER_FLAG | AGG_OWNED_FLAG, AGG_OWNED_FLAG).to(torch.int8)
+    # partitions
+    def blockpart(dims, bl):
+        mx, my, mz = dims
+        nbx, nby, nbz = -(-mx // bl[0]), -(-my // bl[1]), -(-mz // bl[2])
+        kz = torch.arange(mz, device=dev).view(-1, 1, 1) // bl[2]
+        ky = torch.arange(my, device=dev).view(1, -1, 1) // bl[1]
+        kx = torch.arange(mx, device=dev).view(1, 1, -1) // bl[0]
+        return ((kz * nby + ky) * nbx + kx).reshape(-1).to(torch.int32).contiguous(), (nbx, nby, nbz)
+    part0, nb = blockpart(n, blk)
+    parts, nparts = [part0], [nb[0] * nb[1] * nb[2]]
+    for cb in (coarse_blk or []):
+        p, nb = blockpart(nb, cb)
+        parts.append(p)
+        nparts.append(nb[0] * nb[1] * nb[2])
+    return Problem(rowptr=rowptr, col=A_col, val=A_val, n=ND, b=b, elem_to_dof=e2d, elmat=elmat,
+                   bdr=bdr, partitions=parts, nparts=nparts, dims=n, NE_=NE, ess=ess)
