@@ -69,10 +69,10 @@ def cpu_baseline(n_sample, levels):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=128)
-    ap.add_argument("--levels", type=int, default=2)
+    ap.add_argument("--n", type=int, default=256)
+    ap.add_argument("--levels", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
