@@ -4,6 +4,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <cstdlib>
 #include <functional>
 
 namespace saamge_amd {
@@ -29,6 +31,24 @@ static std::vector<double> sas_poly_roots(int nu) {
     return r;
 }
 
+// SAAMGE_AMD_TIMING=1 prints host-side phase times (the reference's "TIMING:" lines)
+struct PhaseTimer {
+    bool on;
+    hipStream_t s;
+    std::chrono::steady_clock::time_point t0;
+    explicit PhaseTimer(hipStream_t st) : on(std::getenv("SAAMGE_AMD_TIMING") != nullptr), s(st) {
+        t0 = std::chrono::steady_clock::now();
+    }
+    void lap(const char *what, int lev) {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "TIMING: level %d %-28s %9.3f ms\n", lev, what,
+                     std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = std::chrono::steady_clock::now();
+    }
+};
+
 static void finish_csr(DCsr &A) { A.lanes_per_row = pick_lanes_per_row(A.nnz, A.nrows > 0 ? A.nrows : 1); }
 
 __global__ void fill_kernel(long n, double *p, double v) {
@@ -47,8 +67,11 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const std::vector<in
     L.theta = P.theta[lev];
     L.nu_relax = P.nu_relax[lev];
     SA_REQUIRE(P.nu_pro[lev] == 0, "prolongator smoothing (nu_pro > 0) is not implemented yet");
+    PhaseTimer tm(s);
     build_relations(L.rel, std::move(e2d), part, nparts, L.A.nrows, bdr_host);
+    tm.lap("host topology", lev);
     upload_relations(L.drel, L.rel, s);
+    tm.lap("upload topology", lev);
     const Relations &rel = L.rel;
     // smoother data (smpr_init_poly_data, amg/src/smpr.cpp:359-423)
     L.dinv_neg.alloc((size_t)L.A.nrows);
@@ -104,6 +127,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const std::vector<in
         row0 += batch.h_voff[cnt];
         ae0 += cnt;
     }
+    tm.lap("local eigenproblems", lev);
     // concatenate (+ the mltest fixture's extra all-ones vector on AE 0 of the finest level)
     const bool extra = (P.testmesh && lev == 0);
     L.ae_xoff.assign((size_t)nparts + 1, 0);
@@ -182,6 +206,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const std::vector<in
         L.mis_k = L.d_mis_k.to_host(s);
         L.mis_ncols = d_ncols.to_host(s);
     }
+    tm.lap("MIS gather + SVD", lev);
     L.mis_coloff.assign((size_t)nm + 1, 0);
     for (int m = 0; m < nm; ++m) L.mis_coloff[m + 1] = L.mis_coloff[m] + L.mis_k[m];
     L.d_mis_coloff.from_host(L.mis_coloff, s);
@@ -189,6 +214,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const std::vector<in
               L.mis_U.p, L.P, L.R);
     rap_mis(s, L.drel, rel, L.A, L.mis_k, L.mis_coloff, L.d_mis_k.p, L.d_mis_coloff.p,
             L.d_mis_u_off.p, L.mis_U.p, L.Ac);
+    tm.lap("P, R, RAP", lev);
     if (!P.keep_debug) {
         L.evals.release();
         L.evecs.release();
@@ -481,13 +507,16 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
     }
     std::vector<signed char> bdr_h;
     if (bdr) bdr_h = fetch_host(bdr, (size_t)n, s);
+    { PhaseTimer tm(s); tm.lap("(inputs fetched)", 0); }
     int n_elem = NE;
     for (int lev = 0; lev < p.num_coarsenings; ++lev) {
         std::vector<int> part = fetch_host(partitions[lev], (size_t)n_elem, s);
         build_level(H, lev, std::move(e2d), part, nparts[lev], (lev == 0 && bdr) ? bdr_h.data() : nullptr);
         Level &L = *H.levels[lev];
         if (lev + 1 < p.num_coarsenings) {
+            PhaseTimer tm(s);
             e2d = prepare_next_level(H, lev);
+            tm.lap("next-level elements", lev);
             Level &N = *H.levels[lev + 1];
             N.A = std::move(L.Ac);  // A_{l+1} = Ac_l  (amg/src/ml.cpp:134)
             n_elem = L.rel.nparts;
