@@ -8,7 +8,8 @@
 
 namespace saamge_amd {
 
-constexpr int EIG_NB = 32;  // panel width of the blocked tridiagonalisation
+constexpr int EIG_NB = 32;  // panel width of the one-stage blocked tridiagonalisation
+constexpr int EIG_SB = 16;  // band width of the two-stage reduction
 
 struct EigBatch {
     int count = 0;          // matrices in the batch
@@ -21,6 +22,14 @@ struct EigBatch {
     DBuf<double> d, e, tau; // [sum n_i] tridiagonal + reflector scalars
     DBuf<double> dis;       // [sum n_i] D^-1/2 (row scaling applied to the vectors)
     DBuf<int> m, j0;        // [count] number of wanted pairs, index of the first
+    // two-stage reduction (eig2.hip)
+    bool two_stage = false;
+    DBuf<double> Tfac;      // [sum n_i * SB] compact-WY T factors, one SB x SB block per panel
+    DBuf<double> Xbuf, Zbuf;// [sum n_i * SB] panel products
+    DBuf<double> rv, rtau;  // bulge-chasing reflectors (SB entries each) and their scalars
+    DBuf<double> bandg;     // band + bulge storage when it does not fit in LDS
+    DBuf<int64_t> roff;     // [count+1] reflector offsets
+    std::vector<int64_t> h_roff;
     std::vector<int> h_n, h_m;
     std::vector<int64_t> h_moff, h_voff;
 };
@@ -28,8 +37,14 @@ struct EigBatch {
 // sizes known on the host; allocates everything but leaves W/dis to be filled by the caller
 void eig_batch_alloc(EigBatch &b, const std::vector<int> &sizes, hipStream_t s);
 
-// Phase 1: tridiagonalise every matrix in place.
+// Phase 1: tridiagonalise every matrix in place.  The default is the two-stage reduction
+// (eig2.hip); SAAMGE_AMD_EIG=onestage selects the one-stage blocked Householder kernel.
 void eig_tridiagonalize(hipStream_t s, EigBatch &b);
+void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b);
+void eig_backtransform_two_stage(hipStream_t s, EigBatch &b, const int64_t *xoff, double *evecs);
+int64_t chase_reflector_count(int n);
+// bytes of device workspace one matrix of size n needs (for chunk sizing)
+size_t eig_workspace_bytes(int n);
 // Phase 2: count eigenvalues in (vl, vu] (Sturm); fills b.m / b.j0 and the host copy b.h_m
 // (m_i = max(count, 1): the reference takes the single smallest pair when none qualifies).
 void eig_count(hipStream_t s, EigBatch &b, double vl, double vu);

@@ -15,6 +15,8 @@
 #include "eig.h"
 
 #include <cfloat>
+#include <cstdlib>
+#include <string>
 
 namespace saamge_amd {
 
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
     const double *__restrict__ Wm, const double *__restrict__ dd, const double *__restrict__ ee,
     const double *__restrict__ tt, const double *__restrict__ dis, const int *__restrict__ ms,
     const int *__restrict__ j0s, const int64_t *__restrict__ eoff, const int64_t *__restrict__ xoff,
-    double *__restrict__ evals, double *__restrict__ evecs) {
+    double *__restrict__ evals, double *__restrict__ evecs, int do_backtransform) {
     constexpr int NT = VEC_NT;
     constexpr int NW = NT / 64;
     extern __shared__ __align__(16) double lds[];
@@ -586,6 +588,7 @@ __global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
         __syncthreads();
     }
 
+    if (!do_backtransform) return;  // two-stage path: eig2.hip applies Q1 Q2 and the row scaling
     // ---- C: back-transformation y = H_0 H_1 ... H_{n-2} z, one wavefront per vector ----
     for (int jj = wave; jj < m; jj += NW) {
         double *Yj = Y + (size_t)jj * n;
@@ -599,6 +602,7 @@ __global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
             for (int r = lane; r < len; r += 64) s = fma(vk[r], y[r], s);
             s = wave_sum(s) * tk;
             for (int r = lane; r < len; r += 64) y[r] = fma(-s, vk[r], y[r]);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // next k reads y through other lanes
         }
         // ---- D: x = D^-1/2 y ----
         for (int r = lane; r < n; r += 64) Yj[r] *= dis[vo + r];
@@ -639,8 +643,36 @@ static size_t tri_lds_bytes(int n) { return sizeof(double) * (2 * (size_t)n + TR
 static size_t vec_lds_bytes(int n) { return sizeof(double) * (7 * (size_t)n + 8) + sizeof(int) * ((size_t)n + 8); }
 constexpr size_t LDS_MAX = 160 * 1024;
 
+size_t eig_workspace_bytes(int n) {
+    const size_t nn = (size_t)n;
+    return 8 * (nn * nn + nn * (EIG_NB + 8) + nn * nn / 2 + nn * (3 * EIG_SB + 2 * EIG_SB) + 64);
+}
+
+static bool use_one_stage() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = std::getenv("SAAMGE_AMD_EIG");
+        v = (e && std::string(e) == "onestage") ? 1 : 0;
+    }
+    return v == 1;
+}
+
 void eig_tridiagonalize(hipStream_t s, EigBatch &b) {
     if (!b.count) return;
+    static bool attr0 = false;
+    if (!attr0) {
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)eigvec_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)count_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+        attr0 = true;
+    }
+    if (!use_one_stage()) {
+        b.two_stage = true;
+        eig_tridiagonalize_two_stage(s, b);
+        return;
+    }
+    b.two_stage = false;
     const size_t lds = tri_lds_bytes(b.max_n);
     SA_REQUIRE(lds <= LDS_MAX, "agglomerate too large for the LDS-resident reflector vectors");
     static bool attr_set = false;
@@ -687,9 +719,10 @@ void eig_vectors(hipStream_t s, EigBatch &b, const int64_t *eoff, const int64_t 
     profiler().begin(s);
     hipLaunchKernelGGL(eigvec_kernel, dim3(b.count), dim3(VEC_NT), lds, s, b.n.p, b.moff.p,
                        b.voff.p, b.W.p, b.d.p, b.e.p, b.tau.p, b.dis.p, b.m.p, b.j0.p, eoff, xoff,
-                       evals, evecs);
+                       evals, evecs, b.two_stage ? 0 : 1);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "eig_vectors", 0.0, flops);
+    if (b.two_stage) eig_backtransform_two_stage(s, b, xoff, evecs);
 }
 
 }  // namespace saamge_amd

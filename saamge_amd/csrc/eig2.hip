@@ -1,0 +1,675 @@
+// Two-stage batched symmetric tridiagonalisation for gfx950.
+//
+//   stage 1  dense -> band (bandwidth SB):  per panel of SB columns, batched over all matrices
+//            of the chunk (grid.y = matrix):
+//              sbr_qr_kernel     Householder QR of the block below the band, compact WY (V, T)
+//              sbr_symm_kernel   X = A22 V        tall-skinny product, A22 streamed ONCE per panel
+//              sbr_small_kernel  Y = X T, S = T^T V^T Y, Z = Y - V S / 2
+//              sbr_syr2k_kernel  A22 -= Z V^T + V Z^T   64x64 tiles, 4x4 register micro-tiles
+//            HBM traffic 24 n'^2 B per panel  ->  8 n^3 / SB bytes per matrix instead of the
+//            one-stage 8 n^3 / 3 (x3 with its rank-2 update): bandwidth-bound at 4 flop/byte.
+//   stage 2  band -> tridiagonal by bulge chasing, one workgroup per matrix, band resident in
+//            LDS (n*2*SB doubles) when it fits; the 16 wavefronts run 16 sweeps at once in a
+//            lock-step software pipeline (sweep s does its q-th chase step at time G*s + q).
+//   back-transformation  y = Q1 Q2 z : the chase reflectors (length <= SB) are applied per
+//            sweep by 16-lane groups, the panel reflectors through their compact WY form.
+//
+// Same mathematics as LAPACK's dsytrd + dstebz + dstein + dormtr used by the reference through
+// dsygvx (amg/src/xpacks.cpp:222-314); only the reduction is organised in two stages.
+#include <cfloat>
+
+#include "eig.h"
+
+namespace saamge_amd {
+
+constexpr int SB = EIG_SB;      // band width
+constexpr int LDB = 2 * SB;     // band storage: distances 0 .. 2*SB-1 (band + bulge)
+
+__device__ inline double wsum64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int NT>
+__device__ inline double bsum(double v, double *red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) r += red[i];
+    return r;
+}
+
+// V(r, c) of the current panel, read in place from A (unit diagonal implicit, zero above)
+__device__ inline double vmask(const double *A, int n, int k0, int r, int c) {
+    if (r < c) return 0.0;
+    if (r == c) return 1.0;
+    return A[(size_t)(k0 + c) * n + (k0 + SB + r)];
+}
+
+// ---------------------------------------------------------------------------------------
+// stage 1
+// ---------------------------------------------------------------------------------------
+constexpr int QR_NT = 256;
+
+__global__ __launch_bounds__(QR_NT) void sbr_qr_kernel(int k0, const int *__restrict__ ns,
+                                                       const int64_t *__restrict__ moff,
+                                                       const int64_t *__restrict__ voff,
+                                                       double *__restrict__ Wm,
+                                                       double *__restrict__ Tfac) {
+    __shared__ double red[QR_NT / 64];
+    __shared__ double zs[SB];
+    __shared__ double Ts[SB * SB];
+    const int b = blockIdx.x;
+    const int n = ns[b];
+    const int np = n - k0 - SB;  // rows below the band
+    if (np < 2) return;
+    double *A = Wm + moff[b];
+    double *T = Tfac + voff[b] * SB + (size_t)(k0 / SB) * SB * SB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = QR_NT / 64;
+    // panel P(i, c) = A[k0+SB+i, k0+c], i < np, c < SB
+    double *P = A + (size_t)k0 * n + (k0 + SB);
+    for (int i = tid; i < SB * SB; i += QR_NT) Ts[i] = 0.0;
+    __syncthreads();
+    const int nref = min(SB, np - 1);
+    for (int c = 0; c < nref; ++c) {
+        double *pc = P + (size_t)c * n;
+        const double alpha = pc[c];
+        double ss = 0.0;
+        for (int i = c + 1 + tid; i < np; i += QR_NT) ss = fma(pc[i], pc[i], ss);
+        ss = bsum<QR_NT>(ss, red);
+        double tau = 0.0, beta = alpha, scale = 0.0;
+        if (ss != 0.0) {
+            beta = -copysign(sqrt(fma(alpha, alpha, ss)), alpha);
+            tau = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        for (int i = c + 1 + tid; i < np; i += QR_NT) pc[i] *= scale;
+        if (tid == 0) pc[c] = beta;
+        __syncthreads();
+        if (tau != 0.0) {
+            // apply H_c to the remaining columns of the panel, one wavefront per column
+            for (int j = c + 1 + wave; j < SB; j += NW) {
+                double *pj = P + (size_t)j * n;
+                double w = 0.0;
+                for (int i = c + 1 + lane; i < np; i += 64) w = fma(pc[i], pj[i], w);
+                w = wsum64(w) + pj[c];
+                const double tw = tau * w;
+                for (int i = c + 1 + lane; i < np; i += 64) pj[i] = fma(-tw, pc[i], pj[i]);
+                if (lane == 0) pj[c] -= tw;
+            }
+            // z_j = V(:, j)^T v_c  for j < c
+            for (int j = wave; j < c; j += NW) {
+                const double *pj = P + (size_t)j * n;
+                double z = 0.0;
+                for (int i = c + 1 + lane; i < np; i += 64) z = fma(pj[i], pc[i], z);
+                z = wsum64(z) + pj[c];  // row c of V(:, j) times v_c[c] = 1
+                if (lane == 0) zs[j] = z;
+            }
+        }
+        __syncthreads();
+        if (tid <= c) {  // T(0:c, c) = -tau T(0:c,0:c) z ; T(c,c) = tau   (dlarft, forward columnwise)
+            double t = 0.0;
+            if (tid == c) {
+                t = tau;
+            } else if (tau != 0.0) {
+                for (int j = tid; j < c; ++j) t = fma(Ts[j * SB + tid], zs[j], t);
+                t = -tau * t;
+            }
+            Ts[c * SB + tid] = t;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < SB * SB; i += QR_NT) T[i] = Ts[i];
+}
+
+// X(r, :) = sum_c A22(r, c) V(c, :)
+constexpr int SY_NT = 256;
+constexpr int SY_KC = 256;  // V rows staged per LDS chunk
+
+__global__ __launch_bounds__(SY_NT) void sbr_symm_kernel(int k0, const int *__restrict__ ns,
+                                                         const int64_t *__restrict__ moff,
+                                                         const int64_t *__restrict__ voff,
+                                                         const double *__restrict__ Wm,
+                                                         double *__restrict__ Xbuf) {
+    __shared__ __align__(16) double Vs[SY_KC * SB];  // 32 KiB, reused for the K-split reduction
+    const int b = blockIdx.y;
+    const int n = ns[b];
+    const int np = n - k0 - SB;
+    if (np < 2) return;
+    const int r0 = blockIdx.x * 64;
+    if (r0 >= np) return;
+    const double *A = Wm + moff[b];
+    const double *A22 = A + (size_t)(k0 + SB) * n + (k0 + SB);
+    double *X = Xbuf + voff[b] * SB;
+    const int tid = threadIdx.x;
+    const int r = tid & 63, g = tid >> 6;
+    const int row = r0 + r;
+    double acc[SB];
+#pragma unroll
+    for (int j = 0; j < SB; ++j) acc[j] = 0.0;
+    for (int c0 = 0; c0 < np; c0 += SY_KC) {
+        const int kc = min(SY_KC, np - c0);
+        __syncthreads();
+        for (int idx = tid; idx < kc * SB; idx += SY_NT) {
+            const int cc = idx % kc, j = idx / kc;  // consecutive threads -> consecutive rows
+            Vs[cc * SB + j] = vmask(A, n, k0, c0 + cc, j);
+        }
+        __syncthreads();
+        if (row < np) {
+            const int cb = g * (SY_KC / 4), ce = min(cb + SY_KC / 4, kc);
+            const double *Ar = A22 + (size_t)c0 * n + row;
+            for (int cc = cb; cc < ce; ++cc) {
+                const double a = Ar[(size_t)cc * n];
+                const double *vr = Vs + cc * SB;
+#pragma unroll
+                for (int j = 0; j < SB; ++j) acc[j] = fma(a, vr[j], acc[j]);
+            }
+        }
+    }
+    __syncthreads();
+    // reduce the 4 K-splits
+    double *red = Vs;  // [4][64][SB]
+#pragma unroll
+    for (int j = 0; j < SB; ++j) red[(g * 64 + r) * SB + j] = acc[j];
+    __syncthreads();
+    for (int idx = tid; idx < 64 * SB; idx += SY_NT) {
+        const int rr = idx & 63, j = idx >> 6;
+        if (r0 + rr < np) {
+            const double s = (red[(0 * 64 + rr) * SB + j] + red[(1 * 64 + rr) * SB + j]) +
+                             (red[(2 * 64 + rr) * SB + j] + red[(3 * 64 + rr) * SB + j]);
+            X[(size_t)j * n + r0 + rr] = s;
+        }
+    }
+}
+
+// Y = X T ; S = T^T (V^T Y) ; Z = Y - V S / 2
+constexpr int SM_NT = 256;
+__global__ __launch_bounds__(SM_NT) void sbr_small_kernel(int k0, const int *__restrict__ ns,
+                                                          const int64_t *__restrict__ moff,
+                                                          const int64_t *__restrict__ voff,
+                                                          const double *__restrict__ Wm,
+                                                          const double *__restrict__ Tfac,
+                                                          double *__restrict__ Xbuf,
+                                                          double *__restrict__ Zbuf) {
+    __shared__ double Ts[SB * SB], Ms[SB * SB], Ss[SB * SB];
+    const int b = blockIdx.x;
+    const int n = ns[b];
+    const int np = n - k0 - SB;
+    if (np < 2) return;
+    const double *A = Wm + moff[b];
+    const double *T = Tfac + voff[b] * SB + (size_t)(k0 / SB) * SB * SB;
+    double *X = Xbuf + voff[b] * SB;
+    double *Z = Zbuf + voff[b] * SB;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < SB * SB; i += SM_NT) Ts[i] = T[i];
+    __syncthreads();
+    // Y = X T (in place, row by row; T upper triangular, column-major Ts[j' * SB + j])
+    for (int r = tid; r < np; r += SM_NT) {
+        double x[SB], y[SB];
+#pragma unroll
+        for (int j = 0; j < SB; ++j) x[j] = X[(size_t)j * n + r];
+#pragma unroll
+        for (int jp = 0; jp < SB; ++jp) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j <= jp; ++j) s = fma(x[j], Ts[jp * SB + j], s);
+            y[jp] = s;
+        }
+#pragma unroll
+        for (int j = 0; j < SB; ++j) X[(size_t)j * n + r] = y[j];
+    }
+    __syncthreads();
+    // M(a, c) = sum_r V(r, a) Y(r, c)
+    {
+        const int a = tid >> 4, c = tid & 15;
+        double s = 0.0;
+        const double *Yc = X + (size_t)c * n;
+        for (int r = a; r < np; ++r) s = fma(vmask(A, n, k0, r, a), Yc[r], s);
+        Ms[a * SB + c] = s;
+    }
+    __syncthreads();
+    {  // S(a, c) = sum_j T(j, a) M(j, c)
+        const int a = tid >> 4, c = tid & 15;
+        double s = 0.0;
+        for (int j = 0; j <= a; ++j) s = fma(Ts[a * SB + j], Ms[j * SB + c], s);
+        Ss[a * SB + c] = s;
+    }
+    __syncthreads();
+    for (int r = tid; r < np; r += SM_NT) {
+        double v[SB];
+#pragma unroll
+        for (int a = 0; a < SB; ++a) v[a] = vmask(A, n, k0, r, a);
+#pragma unroll
+        for (int c = 0; c < SB; ++c) {
+            double s = 0.0;
+#pragma unroll
+            for (int a = 0; a < SB; ++a) s = fma(v[a], Ss[a * SB + c], s);
+            Z[(size_t)c * n + r] = X[(size_t)c * n + r] - 0.5 * s;
+        }
+    }
+}
+
+// A22 -= Z V^T + V Z^T on 64x64 tiles (both triangles: the mat-vec product reads full rows)
+constexpr int S2_NT = 256;
+__global__ __launch_bounds__(S2_NT) void sbr_syr2k_kernel(int k0, const int *__restrict__ ns,
+                                                          const int64_t *__restrict__ moff,
+                                                          const int64_t *__restrict__ voff,
+                                                          double *__restrict__ Wm,
+                                                          const double *__restrict__ Zbuf,
+                                                          int tiles_per_dim) {
+    __shared__ __align__(16) double Zi[64 * SB], Vi[64 * SB], Zl[64 * SB], Vl[64 * SB];
+    const int b = blockIdx.y;
+    const int n = ns[b];
+    const int np = n - k0 - SB;
+    if (np < 2) return;
+    const int ti = blockIdx.x % tiles_per_dim, tl = blockIdx.x / tiles_per_dim;
+    const int i0 = ti * 64, l0 = tl * 64;
+    if (i0 >= np || l0 >= np) return;
+    double *A = Wm + moff[b];
+    double *A22 = A + (size_t)(k0 + SB) * n + (k0 + SB);
+    const double *Z = Zbuf + voff[b] * SB;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 64 * SB; idx += S2_NT) {
+        const int rr = idx & 63, c = idx >> 6;
+        const int ri = i0 + rr, rl = l0 + rr;
+        Zi[c * 64 + rr] = (ri < np) ? Z[(size_t)c * n + ri] : 0.0;
+        Vi[c * 64 + rr] = (ri < np) ? vmask(A, n, k0, ri, c) : 0.0;
+        Zl[c * 64 + rr] = (rl < np) ? Z[(size_t)c * n + rl] : 0.0;
+        Vl[c * 64 + rr] = (rl < np) ? vmask(A, n, k0, rl, c) : 0.0;
+    }
+    __syncthreads();
+    const int tr = tid & 15, tc = tid >> 4;  // 4 rows (tr + 16 a), 4 cols (tc + 16 q)
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[a][q] = 0.0;
+#pragma unroll 4
+    for (int c = 0; c < SB; ++c) {
+        double zi[4], vi[4], zl[4], vl[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            zi[a] = Zi[c * 64 + tr + 16 * a];
+            vi[a] = Vi[c * 64 + tr + 16 * a];
+            zl[a] = Zl[c * 64 + tc + 16 * a];
+            vl[a] = Vl[c * 64 + tc + 16 * a];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[a][q] = fma(zi[a], vl[q], fma(vi[a], zl[q], acc[a][q]));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int l = l0 + tc + 16 * q;
+        if (l >= np) continue;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int i = i0 + tr + 16 * a;
+            if (i < np) A22[(size_t)l * n + i] -= acc[a][q];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// stage 2: bulge chasing
+// ---------------------------------------------------------------------------------------
+constexpr int CH_NT = 1024;
+constexpr int CH_NW = CH_NT / 64;
+
+// number of chase steps of sweep s
+__device__ __host__ inline int chase_steps(int n, int s) { return (n - 1 - s + SB - 1) / SB; }
+
+struct BandRef {
+    double *p;
+    __device__ inline double &operator()(int i, int j) const { return p[(size_t)j * LDB + (i - j)]; }
+    __device__ inline double sym(int i, int j) const { return i >= j ? p[(size_t)j * LDB + (i - j)] : p[(size_t)i * LDB + (j - i)]; }
+};
+
+// One chase step of sweep s (q-th block), executed by one wavefront.  Lane l: r = l & 15 is
+// the row inside the SB x SB block, cq = l >> 4 selects 4 of its 16 columns.
+__device__ inline void chase_step(const BandRef &B, int n, int s, int q, double *vprev_tau,
+                                  double *refl_v, double *refl_tau, int lane) {
+    const int r = lane & 15, cq = lane >> 4;
+    const int i0 = s + 1 + q * SB;              // first row of I_q
+    const int L = min(SB, n - i0);              // |I_q| >= 1
+    double vr = 0.0, tau = 0.0;                 // new reflector (entry r), built below
+    if (q == 0) {
+        // eliminate column s below its first sub-diagonal entry
+        const double x = (r < L) ? B(i0 + r, s) : 0.0;
+        double ss = (r >= 1 && cq == 0) ? x * x : 0.0;
+        ss = wsum64(ss);
+        const double alpha = __shfl(x, 0, 64);
+        double beta = alpha, scale = 0.0;
+        if (ss != 0.0 && L >= 2) {
+            beta = -copysign(sqrt(fma(alpha, alpha, ss)), alpha);
+            tau = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        vr = (r == 0) ? 1.0 : x * scale;
+        if (r >= L) vr = 0.0;
+        if (tau != 0.0 && cq == 0 && r < L) B(i0 + r, s) = (r == 0) ? beta : 0.0;
+    } else {
+        const int j0 = i0 - SB;                  // I_{q-1} = [j0, j0 + SB)
+        const double tprev = vprev_tau[SB];
+        // C(r, c) = A[i0 + r, j0 + c], 4 columns per lane
+        double cv[4], vp[4];
+        double w = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * cq + k;
+            vp[k] = vprev_tau[c];
+            cv[k] = (r < L) ? B(i0 + r, j0 + c) : 0.0;
+            w = fma(cv[k], vp[k], w);
+        }
+        w += __shfl_xor(w, 16, 64);
+        w += __shfl_xor(w, 32, 64);
+        const double tw = tprev * w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cv[k] = fma(-tw, vp[k], cv[k]);   // C <- C H_prev
+        // new reflector from the first column of C
+        const double x = __shfl(cv[0], r, 64);    // column 0 lives in the cq == 0 lanes
+        double ss = (r >= 1 && r < L && cq == 0) ? x * x : 0.0;
+        ss = wsum64(ss);
+        const double alpha = __shfl(x, 0, 64);
+        double beta = alpha, scale = 0.0;
+        if (ss != 0.0 && L >= 2) {
+            beta = -copysign(sqrt(fma(alpha, alpha, ss)), alpha);
+            tau = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        vr = (r == 0) ? 1.0 : x * scale;
+        if (r >= L) vr = 0.0;
+        if (tau != 0.0) {
+            // C <- H C : z_c = sum_r v_r C(r, c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double z = vr * cv[k];
+                z += __shfl_xor(z, 1, 64);
+                z += __shfl_xor(z, 2, 64);
+                z += __shfl_xor(z, 4, 64);
+                z += __shfl_xor(z, 8, 64);
+                cv[k] = fma(-tau * z, vr, cv[k]);
+            }
+            if (cq == 0) cv[0] = (r == 0) ? beta : 0.0;   // exact zeros in the annihilated column
+        }
+        if (r < L) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) B(i0 + r, j0 + 4 * cq + k) = cv[k];
+        }
+    }
+    // two-sided update of the diagonal block D = A[I_q, I_q] (lower part stored)
+    if (tau != 0.0) {
+        double dv[4], vc[4];
+        double p = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * cq + k;
+            vc[k] = __shfl(vr, c, 64);            // v_c (lane c has r == c, cq == 0)
+            dv[k] = (r < L && c < L) ? B.sym(i0 + r, i0 + c) : 0.0;
+            p = fma(dv[k], vc[k], p);
+        }
+        p += __shfl_xor(p, 16, 64);
+        p += __shfl_xor(p, 32, 64);
+        p *= tau;                                   // p_r
+        double pv = (cq == 0) ? p * vr : 0.0;
+        pv = wsum64(pv);
+        const double wr = fma(-0.5 * tau * pv, vr, p);   // w_r = p_r - tau/2 (p.v) v_r
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * cq + k;
+            const double wc = __shfl(wr, c, 64);
+            if (r < L && c <= r) B(i0 + r, i0 + c) = dv[k] - vr * wc - wr * vc[k];
+        }
+    }
+    // hand the reflector to the next step and to the back-transformation
+    if (cq == 0) {
+        vprev_tau[r] = vr;
+        refl_v[r] = vr;
+    }
+    if (lane == 0) {
+        vprev_tau[SB] = tau;
+        *refl_tau = tau;
+    }
+}
+
+__global__ __launch_bounds__(CH_NT) void band_chase_kernel(
+    const int *__restrict__ ns, const int64_t *__restrict__ moff, const int64_t *__restrict__ voff,
+    const int64_t *__restrict__ roff, const double *__restrict__ Wm, double *__restrict__ bandg,
+    int band_in_lds, double *__restrict__ dd, double *__restrict__ ee, double *__restrict__ rv,
+    double *__restrict__ rtau) {
+    extern __shared__ __align__(16) double lds[];
+    const int b = blockIdx.x;
+    const int n = ns[b];
+    const double *A = Wm + moff[b];
+    const int64_t vo = voff[b];
+    double *d = dd + vo, *e = ee + vo;
+    double *RV = rv + roff[b] * SB;
+    double *RT = rtau + roff[b];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // LDS: per-wave reflector hand-off [CH_NW][SB+1], cum[n+1] ints, then (optionally) the band
+    double *hand = lds;
+    int *cum = (int *)(hand + CH_NW * (SB + 2));
+    double *bandl = (double *)(cum + ((n + 2 + 1) & ~1));
+    BandRef B;
+    B.p = band_in_lds ? bandl : (bandg + vo * LDB);
+    // load the band (zero beyond it) -- A holds it in its lower triangle
+    for (int idx = tid; idx < n * LDB; idx += CH_NT) {
+        const int j = idx / LDB, t = idx % LDB;
+        const int i = j + t;
+        B.p[idx] = (t <= SB && i < n) ? A[(size_t)j * n + i] : 0.0;
+    }
+    if (tid == 0) {
+        int run = 0;
+        for (int s = 0; s < n; ++s) {
+            cum[s] = run;
+            if (s <= n - 3) run += chase_steps(n, s);
+        }
+        cum[n] = run;
+    }
+    __syncthreads();
+    if (n >= 3) {
+        const int nsweeps = n - 2;
+        const int maxsteps = chase_steps(n, 0);
+        int G = (maxsteps + 1 + CH_NW - 1) / CH_NW;
+        if (G < 2) G = 2;
+        const int tend = (nsweeps - 1) * G + maxsteps;
+        double *myhand = hand + wave * (SB + 2);
+        for (int t = 0; t < tend; ++t) {
+            // the sweep of this wavefront that is active at time t (at most one)
+            int s = -1, q = 0;
+            {
+                // sweeps s = wave + k*CH_NW start at time G*s
+                const int smax = min(nsweeps - 1, t / G);
+                if (smax >= wave) {
+                    const int sc = smax - ((smax - wave) % CH_NW);  // largest s <= smax, s == wave mod NW
+                    const int qq = t - G * sc;
+                    if (qq < chase_steps(n, sc)) { s = sc; q = qq; }
+                }
+            }
+            if (s >= 0) {
+                const int rid = cum[s] + q;
+                chase_step(B, n, s, q, myhand, RV + (size_t)rid * SB, RT + rid, lane);
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < n; i += CH_NT) {
+        d[i] = B(i, i);
+        e[i] = (i + 1 < n) ? B(i + 1, i) : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// back-transformation of the eigenvectors:  y = Q1 Q2 z , then x = D^-1/2 y
+// ---------------------------------------------------------------------------------------
+constexpr int BT_NT = 256;
+__global__ __launch_bounds__(BT_NT) void backtransform2_kernel(
+    const int *__restrict__ ns, const int64_t *__restrict__ moff, const int64_t *__restrict__ voff,
+    const int64_t *__restrict__ roff, const double *__restrict__ Wm, const double *__restrict__ Tfac,
+    const double *__restrict__ rv, const double *__restrict__ rtau, const double *__restrict__ dis,
+    const int *__restrict__ ms, const int64_t *__restrict__ xoff, double *__restrict__ evecs) {
+    extern __shared__ __align__(16) double lds[];
+    const int b = blockIdx.x;
+    const int n = ns[b], m = ms[b];
+    const double *A = Wm + moff[b];
+    const int64_t vo = voff[b];
+    const double *RV = rv + roff[b] * SB;
+    const double *RT = rtau + roff[b];
+    double *Y = evecs + xoff[b];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = BT_NT / 64;
+    int *cum = (int *)lds;
+    double *gs = (double *)(cum + ((n + 2 + 1) & ~1));  // [NW][2*SB] scratch
+    if (tid == 0) {
+        int run = 0;
+        for (int s = 0; s < n; ++s) {
+            cum[s] = run;
+            if (s <= n - 3) run += chase_steps(n, s);
+        }
+        cum[n] = run;
+    }
+    __syncthreads();
+    const int grp = lane >> 4, r = lane & 15;
+    for (int jj = wave; jj < m; jj += NW) {
+        double *y = Y + (size_t)jj * n;
+        // Q2: sweeps in reverse order; inside a sweep the reflectors touch disjoint rows
+        for (int s = n - 3; s >= 0; --s) {
+            const int nst = chase_steps(n, s);
+            for (int q0 = 0; q0 < nst; q0 += 4) {
+                const int q = q0 + grp;
+                double yr = 0.0, vr = 0.0, tau = 0.0;
+                const int i0 = s + 1 + q * SB;
+                const bool act = (q < nst) && (i0 + r < n);
+                if (q < nst) tau = RT[cum[s] + q];
+                if (act) {
+                    vr = RV[(size_t)(cum[s] + q) * SB + r];
+                    yr = y[i0 + r];
+                }
+                double dot = vr * yr;
+                dot += __shfl_xor(dot, 1, 64);
+                dot += __shfl_xor(dot, 2, 64);
+                dot += __shfl_xor(dot, 4, 64);
+                dot += __shfl_xor(dot, 8, 64);
+                if (act && tau != 0.0) y[i0 + r] = fma(-tau * dot, vr, yr);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // next sweep overlaps these rows
+        }
+        // Q1: panels in reverse order, y[k0+SB:] -= V (T (V^T y))
+        double *g = gs + wave * 2 * SB, *hv = g + SB;
+        int kmax = 0;
+        while (n - (kmax + SB) - SB >= 2) kmax += SB;   // last panel with np >= 2
+        for (int k0 = (n - SB >= 2) ? kmax : -1; k0 >= 0; k0 -= SB) {
+            const int np = n - k0 - SB;
+            if (np < 2) continue;
+            const double *T = Tfac + vo * SB + (size_t)(k0 / SB) * SB * SB;
+            double *yp = y + k0 + SB;
+            for (int c = 0; c < SB; ++c) {
+                double s2 = 0.0;
+                for (int i = lane; i < np; i += 64) s2 = fma(vmask(A, n, k0, i, c), yp[i], s2);
+                s2 = wsum64(s2);
+                if (lane == 0) g[c] = s2;
+            }
+            if (lane < SB) {  // h = T g  (T upper triangular)
+                double s2 = 0.0;
+                for (int c = lane; c < SB; ++c) s2 = fma(T[c * SB + lane], g[c], s2);
+                hv[lane] = s2;
+            }
+            for (int i = lane; i < np; i += 64) {
+                double s2 = 0.0;
+#pragma unroll
+                for (int c = 0; c < SB; ++c) s2 = fma(vmask(A, n, k0, i, c), hv[c], s2);
+                yp[i] -= s2;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+        for (int i = lane; i < n; i += 64) y[i] *= dis[vo + i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------------------
+int64_t chase_reflector_count(int n) {
+    int64_t r = 0;
+    for (int s = 0; s + 3 <= n; ++s) r += chase_steps(n, s);
+    return r;
+}
+
+void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b) {
+    if (!b.count) return;
+    static bool attr = false;
+    if (!attr) {
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)band_chase_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)backtransform2_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    const size_t rows = (size_t)b.h_voff[b.count];
+    // workspaces (allocated once per batch object)
+    if (b.Tfac.n < rows * SB) b.Tfac.alloc(rows * SB + SB * SB);
+    if (b.Xbuf.n < rows * SB) b.Xbuf.alloc(rows * SB);
+    if (b.Zbuf.n < rows * SB) b.Zbuf.alloc(rows * SB);
+    b.h_roff.assign((size_t)b.count + 1, 0);
+    for (int i = 0; i < b.count; ++i) b.h_roff[i + 1] = b.h_roff[i] + chase_reflector_count(b.h_n[i]);
+    b.roff.from_host(b.h_roff, s);
+    const size_t nrefl = (size_t)b.h_roff[b.count];
+    if (b.rv.n < nrefl * SB + SB) b.rv.alloc(nrefl * SB + SB);
+    if (b.rtau.n < nrefl + 1) b.rtau.alloc(nrefl + 1);
+    double flops = 0.0, bytes = 0.0;
+    for (int n : b.h_n) {
+        flops += 4.0 / 3.0 * (double)n * n * n;
+        bytes += 8.0 * (double)n * n;
+    }
+    // ---- stage 1 ----
+    profiler().begin(s);
+    const int nmax = b.max_n;
+    for (int k0 = 0; nmax - k0 - SB >= 2; k0 += SB) {
+        const int npmax = nmax - k0 - SB;
+        hipLaunchKernelGGL(sbr_qr_kernel, dim3(b.count), dim3(QR_NT), 0, s, k0, b.n.p, b.moff.p,
+                           b.voff.p, b.W.p, b.Tfac.p);
+        hipLaunchKernelGGL(sbr_symm_kernel, dim3(div_up(npmax, 64), b.count), dim3(SY_NT), 0, s, k0,
+                           b.n.p, b.moff.p, b.voff.p, b.W.p, b.Xbuf.p);
+        hipLaunchKernelGGL(sbr_small_kernel, dim3(b.count), dim3(SM_NT), 0, s, k0, b.n.p, b.moff.p,
+                           b.voff.p, b.W.p, b.Tfac.p, b.Xbuf.p, b.Zbuf.p);
+        const int tpd = div_up(npmax, 64);
+        hipLaunchKernelGGL(sbr_syr2k_kernel, dim3(tpd * tpd, b.count), dim3(S2_NT), 0, s, k0,
+                           b.n.p, b.moff.p, b.voff.p, b.W.p, b.Zbuf.p, tpd);
+    }
+    SA_HIP_CHECK(hipGetLastError());
+    profiler().end(s, "eig_band_reduce", bytes, flops);
+    // ---- stage 2 ----
+    const size_t fixed = sizeof(double) * (CH_NW * (SB + 2)) + sizeof(int) * ((size_t)nmax + 4);
+    const size_t band_bytes = sizeof(double) * (size_t)nmax * LDB;
+    const int in_lds = (fixed + band_bytes + 64 <= 160 * 1024) ? 1 : 0;
+    if (!in_lds && b.bandg.n < rows * LDB) b.bandg.alloc(rows * LDB);
+    double cflops = 0.0;
+    for (int n : b.h_n) cflops += 6.0 * (double)n * n * SB;
+    profiler().begin(s);
+    hipLaunchKernelGGL(band_chase_kernel, dim3(b.count), dim3(CH_NT), fixed + (in_lds ? band_bytes : 0) + 64,
+                       s, b.n.p, b.moff.p, b.voff.p, b.roff.p, b.W.p, b.bandg.p, in_lds, b.d.p, b.e.p,
+                       b.rv.p, b.rtau.p);
+    SA_HIP_CHECK(hipGetLastError());
+    profiler().end(s, "eig_band_chase", 0.0, cflops);
+}
+
+void eig_backtransform_two_stage(hipStream_t s, EigBatch &b, const int64_t *xoff, double *evecs) {
+    if (!b.count) return;
+    const size_t lds = sizeof(int) * ((size_t)b.max_n + 4) + sizeof(double) * (BT_NT / 64) * 2 * SB + 64;
+    double flops = 0.0;
+    for (int i = 0; i < b.count; ++i) flops += 4.0 * (double)b.h_n[i] * b.h_n[i] * b.h_m[i];
+    profiler().begin(s);
+    hipLaunchKernelGGL(backtransform2_kernel, dim3(b.count), dim3(BT_NT), lds, s, b.n.p, b.moff.p,
+                       b.voff.p, b.roff.p, b.W.p, b.Tfac.p, b.rv.p, b.rtau.p, b.dis.p, b.m.p, xoff, evecs);
+    SA_HIP_CHECK(hipGetLastError());
+    profiler().end(s, "eig_backtransform", 0.0, flops);
+}
+
+}  // namespace saamge_amd

@@ -94,8 +94,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const std::vector<in
         size_t bytes = 0;
         int cnt = 0;
         while (ae0 + cnt < nparts) {
-            const size_t n = (size_t)sizes[ae0 + cnt];
-            const size_t add = 8 * (n * n + n * (EIG_NB + 8));
+            const size_t add = eig_workspace_bytes(sizes[ae0 + cnt]);
             if (cnt > 0 && bytes + add > P.workspace_bytes) break;
             bytes += add;
             ++cnt;
