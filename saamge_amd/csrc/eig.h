@@ -43,6 +43,8 @@ void eig_tridiagonalize(hipStream_t s, EigBatch &b);
 void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b);
 void eig_backtransform_two_stage(hipStream_t s, EigBatch &b, const int64_t *xoff, double *evecs);
 int64_t chase_reflector_count(int n);
+void eig_batch_two_stage_buffers(EigBatch &b, size_t nrefl, bool need_bandg, hipStream_t s);
+void eig_arena_release();   // frees the persistent workspace
 // bytes of device workspace one matrix of size n needs (for chunk sizing)
 size_t eig_workspace_bytes(int n);
 // Phase 2: count eigenvalues in (vl, vu] (Sturm); fills b.m / b.j0 and the host copy b.h_m

@@ -612,6 +612,37 @@ __global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
+static bool use_one_stage() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = std::getenv("SAAMGE_AMD_EIG");
+        v = (e && std::string(e) == "onestage") ? 1 : 0;
+    }
+    return v == 1;
+}
+
+// Persistent, grow-only device workspace shared by all batches (hipMalloc/hipFree of
+// multi-GB buffers costs 0.1-0.4 s each on this platform; the arena is allocated once per
+// process and reused by every chunk / level / hierarchy).  Single stream, sequential use.
+struct EigArena {
+    DBuf<double> W, panel, d, e, tau, dis, Tfac, Xbuf, Zbuf, rv, rtau, bandg;
+    DBuf<int> n, m, j0;
+    DBuf<int64_t> moff, voff, roff;
+};
+static EigArena &arena() {
+    static EigArena a;
+    return a;
+}
+template <class T>
+static void arena_view(DBuf<T> &dst, DBuf<T> &pool, size_t need) {
+    if (pool.n < need) pool.alloc(need + need / 8 + 64);
+    dst.view(pool.p, need);
+}
+void eig_arena_release() {
+    EigArena &a = arena();
+    a = EigArena();
+}
+
 void eig_batch_alloc(EigBatch &b, const std::vector<int> &sizes, hipStream_t s) {
     b.count = (int)sizes.size();
     b.h_n = sizes;
@@ -625,18 +656,37 @@ void eig_batch_alloc(EigBatch &b, const std::vector<int> &sizes, hipStream_t s) 
         b.h_voff[i + 1] = b.h_voff[i] + n;
         if (n > b.max_n) b.max_n = n;
     }
-    b.n.from_host(b.h_n, s);
-    b.moff.from_host(b.h_moff, s);
-    b.voff.from_host(b.h_voff, s);
+    EigArena &a = arena();
     const size_t rows = (size_t)b.h_voff[b.count];
-    b.W.alloc((size_t)b.h_moff[b.count]);
-    b.panel.alloc(rows * EIG_NB);
-    b.d.alloc(rows);
-    b.e.alloc(rows);
-    b.tau.alloc(rows);
-    b.dis.alloc(rows);
-    b.m.alloc(b.count);
-    b.j0.alloc(b.count);
+    arena_view(b.n, a.n, (size_t)b.count);
+    arena_view(b.moff, a.moff, (size_t)b.count + 1);
+    arena_view(b.voff, a.voff, (size_t)b.count + 1);
+    SA_HIP_CHECK(hipMemcpyAsync(b.n.p, b.h_n.data(), 4 * (size_t)b.count, hipMemcpyHostToDevice, s));
+    SA_HIP_CHECK(hipMemcpyAsync(b.moff.p, b.h_moff.data(), 8 * ((size_t)b.count + 1), hipMemcpyHostToDevice, s));
+    SA_HIP_CHECK(hipMemcpyAsync(b.voff.p, b.h_voff.data(), 8 * ((size_t)b.count + 1), hipMemcpyHostToDevice, s));
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    arena_view(b.W, a.W, (size_t)b.h_moff[b.count]);
+    arena_view(b.d, a.d, rows);
+    arena_view(b.e, a.e, rows);
+    arena_view(b.tau, a.tau, rows);
+    arena_view(b.dis, a.dis, rows);
+    arena_view(b.m, a.m, (size_t)b.count);
+    arena_view(b.j0, a.j0, (size_t)b.count);
+    if (use_one_stage()) arena_view(b.panel, a.panel, rows * EIG_NB);
+}
+
+void eig_batch_two_stage_buffers(EigBatch &b, size_t nrefl, bool need_bandg, hipStream_t s) {
+    EigArena &a = arena();
+    const size_t rows = (size_t)b.h_voff[b.count];
+    arena_view(b.Tfac, a.Tfac, rows * EIG_SB + EIG_SB * EIG_SB);
+    arena_view(b.Xbuf, a.Xbuf, rows * EIG_SB);
+    arena_view(b.Zbuf, a.Zbuf, rows * EIG_SB);
+    arena_view(b.roff, a.roff, (size_t)b.count + 1);
+    SA_HIP_CHECK(hipMemcpyAsync(b.roff.p, b.h_roff.data(), 8 * ((size_t)b.count + 1), hipMemcpyHostToDevice, s));
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    arena_view(b.rv, a.rv, nrefl * EIG_SB + EIG_SB);
+    arena_view(b.rtau, a.rtau, nrefl + 1);
+    if (need_bandg) arena_view(b.bandg, a.bandg, rows * 2 * EIG_SB);
 }
 
 static size_t tri_lds_bytes(int n) { return sizeof(double) * (2 * (size_t)n + TRI_NT + 2 * EIG_NB + TRI_NT / 64); }
@@ -646,15 +696,6 @@ constexpr size_t LDS_MAX = 160 * 1024;
 size_t eig_workspace_bytes(int n) {
     const size_t nn = (size_t)n;
     return 8 * (nn * nn + nn * (EIG_NB + 8) + nn * nn / 2 + nn * (3 * EIG_SB + 2 * EIG_SB) + 64);
-}
-
-static bool use_one_stage() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = std::getenv("SAAMGE_AMD_EIG");
-        v = (e && std::string(e) == "onestage") ? 1 : 0;
-    }
-    return v == 1;
 }
 
 void eig_tridiagonalize(hipStream_t s, EigBatch &b) {

@@ -613,16 +613,14 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b) {
         attr = true;
     }
     const size_t rows = (size_t)b.h_voff[b.count];
-    // workspaces (allocated once per batch object)
-    if (b.Tfac.n < rows * SB) b.Tfac.alloc(rows * SB + SB * SB);
-    if (b.Xbuf.n < rows * SB) b.Xbuf.alloc(rows * SB);
-    if (b.Zbuf.n < rows * SB) b.Zbuf.alloc(rows * SB);
+    (void)rows;
     b.h_roff.assign((size_t)b.count + 1, 0);
     for (int i = 0; i < b.count; ++i) b.h_roff[i + 1] = b.h_roff[i] + chase_reflector_count(b.h_n[i]);
-    b.roff.from_host(b.h_roff, s);
     const size_t nrefl = (size_t)b.h_roff[b.count];
-    if (b.rv.n < nrefl * SB + SB) b.rv.alloc(nrefl * SB + SB);
-    if (b.rtau.n < nrefl + 1) b.rtau.alloc(nrefl + 1);
+    const int nmax0 = b.max_n;
+    const size_t fixed0 = sizeof(double) * (CH_NW * (SB + 2)) + sizeof(int) * ((size_t)nmax0 + 4);
+    const bool in_lds0 = fixed0 + sizeof(double) * (size_t)nmax0 * LDB + 64 <= 160 * 1024;
+    eig_batch_two_stage_buffers(b, nrefl, !in_lds0, s);
     double flops = 0.0, bytes = 0.0;
     for (int n : b.h_n) {
         flops += 4.0 / 3.0 * (double)n * n * n;
@@ -649,7 +647,6 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b) {
     const size_t fixed = sizeof(double) * (CH_NW * (SB + 2)) + sizeof(int) * ((size_t)nmax + 4);
     const size_t band_bytes = sizeof(double) * (size_t)nmax * LDB;
     const int in_lds = (fixed + band_bytes + 64 <= 160 * 1024) ? 1 : 0;
-    if (!in_lds && b.bandg.n < rows * LDB) b.bandg.alloc(rows * LDB);
     double cflops = 0.0;
     for (int n : b.h_n) cflops += 6.0 * (double)n * n * SB;
     profiler().begin(s);

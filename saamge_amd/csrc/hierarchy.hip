@@ -49,6 +49,17 @@ struct PhaseTimer {
     }
 };
 
+// grow-only scratch buffers that survive across chunks / levels / hierarchies
+static DBuf<double> &scratch_pool(int slot) {
+    static DBuf<double> pools[4];
+    return pools[slot];
+}
+static double *scratch_get(int slot, size_t need) {
+    DBuf<double> &p = scratch_pool(slot);
+    if (p.n < need) p.alloc(need + need / 8 + 64);
+    return p.p;
+}
+
 static void finish_csr(DCsr &A) { A.lanes_per_row = pick_lanes_per_row(A.nnz, A.nrows > 0 ? A.nrows : 1); }
 
 __global__ void fill_kernel(long n, double *p, double v) {
@@ -99,11 +110,15 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const std::vector<in
             bytes += add;
             ++cnt;
         }
+        PhaseTimer tc(s);
         EigBatch batch;
         eig_batch_alloc(batch, std::vector<int>(sizes.begin() + ae0, sizes.begin() + ae0 + cnt), s);
+        tc.lap("  chunk alloc", lev);
         ae_assemble(s, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch);
         ae_scale(s, batch, P.keep_debug ? L.ae_D.p + row0 : nullptr);
+        tc.lap("  chunk assemble+scale", lev);
         eig_tridiagonalize(s, batch);
+        tc.lap("  chunk tridiagonalize", lev);
         eig_count(s, batch, -1.0, L.theta);
         chunks.emplace_back();
         Chunk &c = chunks.back();
@@ -180,7 +195,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const std::vector<in
     L.mis_sig.zero(s);
     L.d_mis_k.alloc((size_t)nm);
     {
-        DBuf<double> gather((size_t)g_off[nm] + 1);
+        double *gather = scratch_get(1, (size_t)g_off[nm] + 1);
         DBuf<int64_t> d_goff, d_soff, d_xoff;
         DBuf<int> d_aem, d_ncols((size_t)nm);
         d_goff.from_host(g_off, s);
@@ -193,7 +208,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const std::vector<in
         io.ae_xoff = d_xoff.p;
         io.evecs = L.evecs.p;
         io.g_off = d_goff.p;
-        io.gather = gather.p;
+        io.gather = gather;
         io.u_off = L.d_mis_u_off.p;
         io.s_off = d_soff.p;
         io.U = L.mis_U.p;
@@ -303,9 +318,9 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
         for (int i = 0; i < cnt; ++i) soff[i + 1] = soff[i] + (int64_t)sizes[ae0 + i] * e2d.row_size(ae0 + i);
         DBuf<int64_t> d_soff;
         d_soff.from_host(soff, s);
-        DBuf<double> scratch((size_t)soff[cnt] + 1);
+        double *scratch = scratch_get(0, (size_t)soff[cnt] + 1);
         coarse_elmats(s, L.drel, ae0, batch, L.d_mis_k.p, L.d_mis_u_off.p, L.mis_U.p, d_colpos_ptr.p,
-                      d_colpos.p, N.elmat.off.p, N.elmat.val.p, scratch.p, d_soff.p);
+                      d_colpos.p, N.elmat.off.p, N.elmat.val.p, scratch, d_soff.p);
         SA_HIP_CHECK(hipStreamSynchronize(s));
         ae0 += cnt;
     }
@@ -457,6 +472,8 @@ int pcg_solve(Hierarchy &H, const double *b, double *x, double rel_tol, double a
               int max_iter, int squared_tol, int zero_guess, int *converged, double *hist) {
     Level &L0 = *H.levels[0];
     auto prec = [&](const double *r, double *z) { vcycle_apply(H, 0, r, z); };
+    PhaseTimer tm(H.stream);
+    struct Lap { PhaseTimer &t; ~Lap() { t.lap("TOTAL pcg_solve", 0); } } lap{tm};
     return pcg_loop(H, L0.A, prec, b, x, H.pcg_r.p, H.pcg_z.p, H.pcg_d.p, H.pcg_q.p, rel_tol,
                     abs_tol, max_iter, squared_tol != 0, zero_guess != 0, converged, hist, H.scal.p);
 }
@@ -470,6 +487,7 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
                             const int *nparts, const Params &p, hipStream_t stream) {
     SA_REQUIRE(p.num_coarsenings >= 1 && p.num_coarsenings < MAX_LEVELS, "bad number of coarsenings");
     SA_REQUIRE(n > 0 && NE > 0 && nde > 0, "empty problem");
+    PhaseTimer tm_all(stream), tm0(stream);
     std::unique_ptr<Hierarchy> Hp(new Hierarchy);
     Hierarchy &H = *Hp;
     H.params = p;
@@ -506,7 +524,7 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
     }
     std::vector<signed char> bdr_h;
     if (bdr) bdr_h = fetch_host(bdr, (size_t)n, s);
-    { PhaseTimer tm(s); tm.lap("(inputs fetched)", 0); }
+    tm0.lap("inputs fetched/imported", 0);
     int n_elem = NE;
     for (int lev = 0; lev < p.num_coarsenings; ++lev) {
         std::vector<int> part = fetch_host(partitions[lev], (size_t)n_elem, s);
@@ -521,12 +539,15 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
             n_elem = L.rel.nparts;
         }
     }
+    tm0 = PhaseTimer(s);
     setup_coarse_solver(H);
     const size_t nc = (size_t)coarsest_op(H).nrows;
     H.c_b.alloc(nc);
     H.c_x.alloc(nc);
     H.pcg_r.alloc((size_t)n); H.pcg_z.alloc((size_t)n); H.pcg_d.alloc((size_t)n); H.pcg_q.alloc((size_t)n);
     SA_HIP_CHECK(hipStreamSynchronize(s));
+    tm0.lap("coarse solver + vectors", 0);
+    tm_all.lap("TOTAL ml_produce_data", 0);
     return Hp.release();
 }
 
