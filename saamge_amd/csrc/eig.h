@@ -29,7 +29,9 @@ struct EigBatch {
     DBuf<double> rv, rtau;  // bulge-chasing reflectors (SB entries each) and their scalars
     DBuf<double> bandg;     // band + bulge storage when it does not fit in LDS
     DBuf<int64_t> roff;     // [count+1] reflector offsets
-    std::vector<int64_t> h_roff;
+    DBuf<double> Gbuf;      // per (matrix, 64-row block) partial V^T X (SB x SB each)
+    DBuf<int64_t> goff;
+    std::vector<int64_t> h_roff, h_goff;
     std::vector<int> h_n, h_m;
     std::vector<int64_t> h_moff, h_voff;
 };

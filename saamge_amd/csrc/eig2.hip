@@ -54,14 +54,14 @@ __device__ inline double vmask(const double *A, int n, int k0, int r, int c) {
 // ---------------------------------------------------------------------------------------
 // stage 1
 // ---------------------------------------------------------------------------------------
-constexpr int QR_NT = 256;
-
-__global__ __launch_bounds__(QR_NT) void sbr_qr_kernel(int k0, const int *__restrict__ ns,
-                                                       const int64_t *__restrict__ moff,
-                                                       const int64_t *__restrict__ voff,
-                                                       double *__restrict__ Wm,
-                                                       double *__restrict__ Tfac) {
-    __shared__ double red[QR_NT / 64];
+template <int NT, bool LDSP>
+__global__ __launch_bounds__(NT) void sbr_qr_kernel(int k0, const int *__restrict__ ns,
+                                                    const int64_t *__restrict__ moff,
+                                                    const int64_t *__restrict__ voff,
+                                                    double *__restrict__ Wm,
+                                                    double *__restrict__ Tfac) {
+    extern __shared__ __align__(16) double plds[];
+    __shared__ double red[NT / 64];
     __shared__ double zs[SB];
     __shared__ double Ts[SB * SB];
     const int b = blockIdx.x;
@@ -71,31 +71,39 @@ __global__ __launch_bounds__(QR_NT) void sbr_qr_kernel(int k0, const int *__rest
     double *A = Wm + moff[b];
     double *T = Tfac + voff[b] * SB + (size_t)(k0 / SB) * SB * SB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = QR_NT / 64;
+    constexpr int NW = NT / 64;
     // panel P(i, c) = A[k0+SB+i, k0+c], i < np, c < SB
-    double *P = A + (size_t)k0 * n + (k0 + SB);
-    for (int i = tid; i < SB * SB; i += QR_NT) Ts[i] = 0.0;
+    double *Pg = A + (size_t)k0 * n + (k0 + SB);
+    double *P = LDSP ? plds : Pg;
+    const int ldp = LDSP ? np : n;
+    if (LDSP) {
+        for (int idx = tid; idx < np * SB; idx += NT) {
+            const int i = idx % np, c = idx / np;
+            P[(size_t)c * ldp + i] = Pg[(size_t)c * n + i];
+        }
+    }
+    for (int i = tid; i < SB * SB; i += NT) Ts[i] = 0.0;
     __syncthreads();
     const int nref = min(SB, np - 1);
     for (int c = 0; c < nref; ++c) {
-        double *pc = P + (size_t)c * n;
+        double *pc = P + (size_t)c * ldp;
         const double alpha = pc[c];
         double ss = 0.0;
-        for (int i = c + 1 + tid; i < np; i += QR_NT) ss = fma(pc[i], pc[i], ss);
-        ss = bsum<QR_NT>(ss, red);
+        for (int i = c + 1 + tid; i < np; i += NT) ss = fma(pc[i], pc[i], ss);
+        ss = bsum<NT>(ss, red);
         double tau = 0.0, beta = alpha, scale = 0.0;
         if (ss != 0.0) {
             beta = -copysign(sqrt(fma(alpha, alpha, ss)), alpha);
             tau = (beta - alpha) / beta;
             scale = 1.0 / (alpha - beta);
         }
-        for (int i = c + 1 + tid; i < np; i += QR_NT) pc[i] *= scale;
+        for (int i = c + 1 + tid; i < np; i += NT) pc[i] *= scale;
         if (tid == 0) pc[c] = beta;
         __syncthreads();
         if (tau != 0.0) {
             // apply H_c to the remaining columns of the panel, one wavefront per column
             for (int j = c + 1 + wave; j < SB; j += NW) {
-                double *pj = P + (size_t)j * n;
+                double *pj = P + (size_t)j * ldp;
                 double w = 0.0;
                 for (int i = c + 1 + lane; i < np; i += 64) w = fma(pc[i], pj[i], w);
                 w = wsum64(w) + pj[c];
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(QR_NT) void sbr_qr_kernel(int k0, const int *__rest
             }
             // z_j = V(:, j)^T v_c  for j < c
             for (int j = wave; j < c; j += NW) {
-                const double *pj = P + (size_t)j * n;
+                const double *pj = P + (size_t)j * ldp;
                 double z = 0.0;
                 for (int i = c + 1 + lane; i < np; i += 64) z = fma(pj[i], pc[i], z);
                 z = wsum64(z) + pj[c];  // row c of V(:, j) times v_c[c] = 1
@@ -125,7 +133,13 @@ __global__ __launch_bounds__(QR_NT) void sbr_qr_kernel(int k0, const int *__rest
         }
         __syncthreads();
     }
-    for (int i = tid; i < SB * SB; i += QR_NT) T[i] = Ts[i];
+    for (int i = tid; i < SB * SB; i += NT) T[i] = Ts[i];
+    if (LDSP) {
+        for (int idx = tid; idx < np * SB; idx += NT) {
+            const int i = idx % np, c = idx / np;
+            Pg[(size_t)c * n + i] = P[(size_t)c * ldp + i];
+        }
+    }
 }
 
 // X(r, :) = sum_c A22(r, c) V(c, :)
@@ -136,8 +150,11 @@ __global__ __launch_bounds__(SY_NT) void sbr_symm_kernel(int k0, const int *__re
                                                          const int64_t *__restrict__ moff,
                                                          const int64_t *__restrict__ voff,
                                                          const double *__restrict__ Wm,
-                                                         double *__restrict__ Xbuf) {
+                                                         double *__restrict__ Xbuf,
+                                                         const int64_t *__restrict__ goff,
+                                                         double *__restrict__ Gbuf) {
     __shared__ __align__(16) double Vs[SY_KC * SB];  // 32 KiB, reused for the K-split reduction
+    __shared__ double xs[64 * SB], vs2[64 * SB];
     const int b = blockIdx.y;
     const int n = ns[b];
     const int np = n - k0 - SB;
@@ -184,74 +201,83 @@ __global__ __launch_bounds__(SY_NT) void sbr_symm_kernel(int k0, const int *__re
             const double s = (red[(0 * 64 + rr) * SB + j] + red[(1 * 64 + rr) * SB + j]) +
                              (red[(2 * 64 + rr) * SB + j] + red[(3 * 64 + rr) * SB + j]);
             X[(size_t)j * n + r0 + rr] = s;
+            xs[rr * SB + j] = s;
+        } else {
+            xs[rr * SB + j] = 0.0;
         }
+        vs2[rr * SB + j] = (r0 + rr < np) ? vmask(A, n, k0, r0 + rr, j) : 0.0;
+    }
+    __syncthreads();
+    {   // partial G(a, c) = sum_rr V(r0+rr, a) X(r0+rr, c), reduced over row blocks by sbr_z_kernel
+        const int a = tid >> 4, c = tid & 15;
+        double s = 0.0;
+        for (int rr = 0; rr < 64; ++rr) s = fma(vs2[rr * SB + a], xs[rr * SB + c], s);
+        Gbuf[goff[b] + (size_t)blockIdx.x * (SB * SB) + tid] = s;
     }
 }
 
-// Y = X T ; S = T^T (V^T Y) ; Z = Y - V S / 2
+// Z = X T - V S / 2 with S = T^T (G T), G = V^T X summed over the row-block partials
 constexpr int SM_NT = 256;
-__global__ __launch_bounds__(SM_NT) void sbr_small_kernel(int k0, const int *__restrict__ ns,
-                                                          const int64_t *__restrict__ moff,
-                                                          const int64_t *__restrict__ voff,
-                                                          const double *__restrict__ Wm,
-                                                          const double *__restrict__ Tfac,
-                                                          double *__restrict__ Xbuf,
-                                                          double *__restrict__ Zbuf) {
-    __shared__ double Ts[SB * SB], Ms[SB * SB], Ss[SB * SB];
-    const int b = blockIdx.x;
+__global__ __launch_bounds__(SM_NT) void sbr_z_kernel(int k0, const int *__restrict__ ns,
+                                                      const int64_t *__restrict__ moff,
+                                                      const int64_t *__restrict__ voff,
+                                                      const double *__restrict__ Wm,
+                                                      const double *__restrict__ Tfac,
+                                                      const double *__restrict__ Xbuf,
+                                                      const int64_t *__restrict__ goff,
+                                                      const double *__restrict__ Gbuf,
+                                                      double *__restrict__ Zbuf) {
+    __shared__ double Ts[SB * SB], Gs[SB * SB], GT[SB * SB], Ss[SB * SB];
+    const int b = blockIdx.y;
     const int n = ns[b];
     const int np = n - k0 - SB;
     if (np < 2) return;
+    const int r0 = blockIdx.x * SM_NT;
+    if (r0 >= np) return;
     const double *A = Wm + moff[b];
     const double *T = Tfac + voff[b] * SB + (size_t)(k0 / SB) * SB * SB;
-    double *X = Xbuf + voff[b] * SB;
+    const double *X = Xbuf + voff[b] * SB;
     double *Z = Zbuf + voff[b] * SB;
     const int tid = threadIdx.x;
-    for (int i = tid; i < SB * SB; i += SM_NT) Ts[i] = T[i];
-    __syncthreads();
-    // Y = X T (in place, row by row; T upper triangular, column-major Ts[j' * SB + j])
-    for (int r = tid; r < np; r += SM_NT) {
-        double x[SB], y[SB];
-#pragma unroll
-        for (int j = 0; j < SB; ++j) x[j] = X[(size_t)j * n + r];
-#pragma unroll
-        for (int jp = 0; jp < SB; ++jp) {
-            double s = 0.0;
-#pragma unroll
-            for (int j = 0; j <= jp; ++j) s = fma(x[j], Ts[jp * SB + j], s);
-            y[jp] = s;
-        }
-#pragma unroll
-        for (int j = 0; j < SB; ++j) X[(size_t)j * n + r] = y[j];
-    }
-    __syncthreads();
-    // M(a, c) = sum_r V(r, a) Y(r, c)
     {
-        const int a = tid >> 4, c = tid & 15;
+        Ts[tid] = T[tid];
+        const int nblk = (np + 63) / 64;
+        const double *Gp = Gbuf + goff[b] + tid;
         double s = 0.0;
-        const double *Yc = X + (size_t)c * n;
-        for (int r = a; r < np; ++r) s = fma(vmask(A, n, k0, r, a), Yc[r], s);
-        Ms[a * SB + c] = s;
+        for (int k = 0; k < nblk; ++k) s += Gp[(size_t)k * (SB * SB)];
+        Gs[tid] = s;   // G(a, c) at a * SB + c
     }
     __syncthreads();
-    {  // S(a, c) = sum_j T(j, a) M(j, c)
+    {   // GT(a, c) = sum_{j <= c} G(a, j) T(j, c)      (T column-major: T(j, c) = Ts[c * SB + j])
         const int a = tid >> 4, c = tid & 15;
         double s = 0.0;
-        for (int j = 0; j <= a; ++j) s = fma(Ts[a * SB + j], Ms[j * SB + c], s);
+        for (int j = 0; j <= c; ++j) s = fma(Gs[a * SB + j], Ts[c * SB + j], s);
+        GT[a * SB + c] = s;
+    }
+    __syncthreads();
+    {   // S(a, c) = sum_{j <= a} T(j, a) GT(j, c)
+        const int a = tid >> 4, c = tid & 15;
+        double s = 0.0;
+        for (int j = 0; j <= a; ++j) s = fma(Ts[a * SB + j], GT[j * SB + c], s);
         Ss[a * SB + c] = s;
     }
     __syncthreads();
-    for (int r = tid; r < np; r += SM_NT) {
-        double v[SB];
+    const int r = r0 + tid;
+    if (r >= np) return;
+    double x[SB], v[SB];
 #pragma unroll
-        for (int a = 0; a < SB; ++a) v[a] = vmask(A, n, k0, r, a);
+    for (int j = 0; j < SB; ++j) {
+        x[j] = X[(size_t)j * n + r];
+        v[j] = vmask(A, n, k0, r, j);
+    }
 #pragma unroll
-        for (int c = 0; c < SB; ++c) {
-            double s = 0.0;
+    for (int c = 0; c < SB; ++c) {
+        double y = 0.0, s = 0.0;
 #pragma unroll
-            for (int a = 0; a < SB; ++a) s = fma(v[a], Ss[a * SB + c], s);
-            Z[(size_t)c * n + r] = X[(size_t)c * n + r] - 0.5 * s;
-        }
+        for (int j = 0; j <= c; ++j) y = fma(x[j], Ts[c * SB + j], y);
+#pragma unroll
+        for (int a = 0; a < SB; ++a) s = fma(v[a], Ss[a * SB + c], s);
+        Z[(size_t)c * n + r] = fma(-0.5, s, y);
     }
 }
 
@@ -610,6 +636,8 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SA_HIP_CHECK(hipFuncSetAttribute((const void *)backtransform2_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)sbr_qr_kernel<256, true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr = true;
     }
     const size_t rows = (size_t)b.h_voff[b.count];
@@ -620,6 +648,9 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b) {
     const int nmax0 = b.max_n;
     const size_t fixed0 = sizeof(double) * (CH_NW * (SB + 2)) + sizeof(int) * ((size_t)nmax0 + 4);
     const bool in_lds0 = fixed0 + sizeof(double) * (size_t)nmax0 * LDB + 64 <= 160 * 1024;
+    b.h_goff.assign((size_t)b.count + 1, 0);
+    for (int i = 0; i < b.count; ++i)
+        b.h_goff[i + 1] = b.h_goff[i] + (int64_t)((b.h_n[i] + 63) / 64) * SB * SB;
     eig_batch_two_stage_buffers(b, nrefl, !in_lds0, s);
     double flops = 0.0, bytes = 0.0;
     for (int n : b.h_n) {
@@ -631,12 +662,18 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b) {
     const int nmax = b.max_n;
     for (int k0 = 0; nmax - k0 - SB >= 2; k0 += SB) {
         const int npmax = nmax - k0 - SB;
-        hipLaunchKernelGGL(sbr_qr_kernel, dim3(b.count), dim3(QR_NT), 0, s, k0, b.n.p, b.moff.p,
-                           b.voff.p, b.W.p, b.Tfac.p);
+        if ((size_t)npmax * SB * sizeof(double) <= 96 * 1024)
+            hipLaunchKernelGGL((sbr_qr_kernel<256, true>), dim3(b.count), dim3(256),
+                               (size_t)npmax * SB * sizeof(double), s, k0, b.n.p, b.moff.p, b.voff.p,
+                               b.W.p, b.Tfac.p);
+        else
+            hipLaunchKernelGGL((sbr_qr_kernel<1024, false>), dim3(b.count), dim3(1024), 0, s, k0,
+                               b.n.p, b.moff.p, b.voff.p, b.W.p, b.Tfac.p);
         hipLaunchKernelGGL(sbr_symm_kernel, dim3(div_up(npmax, 64), b.count), dim3(SY_NT), 0, s, k0,
-                           b.n.p, b.moff.p, b.voff.p, b.W.p, b.Xbuf.p);
-        hipLaunchKernelGGL(sbr_small_kernel, dim3(b.count), dim3(SM_NT), 0, s, k0, b.n.p, b.moff.p,
-                           b.voff.p, b.W.p, b.Tfac.p, b.Xbuf.p, b.Zbuf.p);
+                           b.n.p, b.moff.p, b.voff.p, b.W.p, b.Xbuf.p, b.goff.p, b.Gbuf.p);
+        hipLaunchKernelGGL(sbr_z_kernel, dim3(div_up(npmax, SM_NT), b.count), dim3(SM_NT), 0, s, k0,
+                           b.n.p, b.moff.p, b.voff.p, b.W.p, b.Tfac.p, b.Xbuf.p, b.goff.p, b.Gbuf.p,
+                           b.Zbuf.p);
         const int tpd = div_up(npmax, 64);
         hipLaunchKernelGGL(sbr_syr2k_kernel, dim3(tpd * tpd, b.count), dim3(S2_NT), 0, s, k0,
                            b.n.p, b.moff.p, b.voff.p, b.W.p, b.Zbuf.p, tpd);
