@@ -80,6 +80,8 @@ void ae_assemble(hipStream_t s, const DevRelations &rel, const DCsr *A, const De
     profiler().end(s, "ae_assemble", bytes, 0.0);
 }
 
+// D and the symmetric scaling.  Row sums are split over 4 column groups per 64-row block
+// (coalesced down the columns) so large agglomerates keep all lanes busy.
 __global__ __launch_bounds__(ASM_NT) void ae_scale_kernel(const int *__restrict__ ns,
                                                           const int64_t *__restrict__ moff,
                                                           const int64_t *__restrict__ voff,
@@ -90,23 +92,42 @@ __global__ __launch_bounds__(ASM_NT) void ae_scale_kernel(const int *__restrict_
     const int b = blockIdx.x, n = ns[b];
     double *Wm = W + moff[b];
     const int64_t vo = voff[b];
-    double *dg = lds, *dis = lds + n;
+    double *dg = lds, *dis = lds + n, *part = lds + 2 * n;  // part[4][64]
     const int tid = threadIdx.x;
     for (int i = tid; i < n; i += ASM_NT) dg[i] = Wm[(size_t)i * n + i];
     __syncthreads();
-    for (int r = tid; r < n; r += ASM_NT) {
-        const double dr = dg[r];
+    const int rr = tid & 63, g = tid >> 6;
+    for (int r0 = 0; r0 < n; r0 += 64) {
+        const int r = r0 + rr;
         double sum = 0.0;
-        for (int j = 0; j < n; ++j) {
-            const double a = Wm[(size_t)j * n + r];
-            if (a != 0.0) sum += fabs(a) * sqrt(dr / dg[j]);
+        if (r < n) {
+            const double dr = dg[r];
+            const int cb = (int)(((long)n * g) / 4), ce = (int)(((long)n * (g + 1)) / 4);
+            int j = cb;
+            for (; j + 8 <= ce; j += 8) {   // 8 independent loads in flight per lane
+                double a[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] = Wm[(size_t)(j + u) * n + r];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (a[u] != 0.0) sum += fabs(a[u]) * sqrt(dr / dg[j + u]);
+            }
+            for (; j < ce; ++j) {
+                const double a = Wm[(size_t)j * n + r];
+                if (a != 0.0) sum += fabs(a) * sqrt(dr / dg[j]);
+            }
         }
-        const double di = 1.0 / sqrt(sum);
-        dis[r] = di;
-        dis_out[vo + r] = di;
-        if (D_out) D_out[vo + r] = sum;
+        part[g * 64 + rr] = sum;
+        __syncthreads();
+        if (g == 0 && r < n) {
+            const double s4 = (part[rr] + part[64 + rr]) + (part[128 + rr] + part[192 + rr]);
+            const double di = 1.0 / sqrt(s4);
+            dis[r] = di;
+            dis_out[vo + r] = di;
+            if (D_out) D_out[vo + r] = s4;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const size_t nn = (size_t)n * n;
     for (size_t idx = tid; idx < nn; idx += ASM_NT) {
         const int r = (int)(idx % n), j = (int)(idx / n);
@@ -120,7 +141,7 @@ void ae_scale(hipStream_t s, EigBatch &batch, double *Dout) {
     for (int n : batch.h_n) bytes += 24.0 * (double)n * n;
     profiler().begin(s);
     hipLaunchKernelGGL(ae_scale_kernel, dim3(batch.count), dim3(ASM_NT),
-                       2 * sizeof(double) * (size_t)batch.max_n, s, batch.n.p, batch.moff.p,
+                       (2 * (size_t)batch.max_n + 256) * sizeof(double), s, batch.n.p, batch.moff.p,
                        batch.voff.p, batch.W.p, batch.dis.p, Dout);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "ae_scale", bytes, 0.0);

@@ -25,6 +25,14 @@ namespace saamge_amd {
 constexpr int SB = EIG_SB;      // band width
 constexpr int LDB = 2 * SB;     // band storage: distances 0 .. 2*SB-1 (band + bulge)
 
+__device__ inline double gsum16(double v) {   // sum inside each 16-lane group
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
 __device__ inline double wsum64(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -358,20 +366,43 @@ struct BandRef {
     __device__ inline double sym(int i, int j) const { return i >= j ? p[(size_t)j * LDB + (i - j)] : p[(size_t)i * LDB + (j - i)]; }
 };
 
+// 16-lane all-reduce with DPP row rotations (no LDS crossbar): {8,4,2,1} rotations cover the row
+template <int CTRL>
+__device__ inline double dpp_rot(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double rsum16(double v) {
+    v += dpp_rot<0x128>(v);  // row_ror:8
+    v += dpp_rot<0x124>(v);  // row_ror:4
+    v += dpp_rot<0x122>(v);  // row_ror:2
+    v += dpp_rot<0x121>(v);  // row_ror:1
+    return v;
+}
+__device__ inline void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+
+constexpr int HAND = 4 * SB + 2;  // per-wave LDS scratch: vprev[SB], tau, pad, sv[SB], sw[SB], sx[SB]
+
 // One chase step of sweep s (q-th block), executed by one wavefront.  Lane l: r = l & 15 is
-// the row inside the SB x SB block, cq = l >> 4 selects 4 of its 16 columns.
-__device__ inline void chase_step(const BandRef &B, int n, int s, int q, double *vprev_tau,
+// the row inside the SB x SB block, cq = l >> 4 selects 4 of its 16 columns.  Vectors that
+// every lane needs (v, w, first column) go through a wave-private LDS scratch instead of
+// cross-lane permutes; the 16-lane sums use DPP row rotations.
+__device__ inline void chase_step(const BandRef &B, int n, int s, int q, double *hand,
                                   double *refl_v, double *refl_tau, int lane) {
     const int r = lane & 15, cq = lane >> 4;
+    double *vprev = hand, *sv = hand + SB + 2, *sw = sv + SB, *sx = sw + SB;
     const int i0 = s + 1 + q * SB;              // first row of I_q
     const int L = min(SB, n - i0);              // |I_q| >= 1
     double vr = 0.0, tau = 0.0;                 // new reflector (entry r), built below
     if (q == 0) {
         // eliminate column s below its first sub-diagonal entry
         const double x = (r < L) ? B(i0 + r, s) : 0.0;
-        double ss = (r >= 1 && cq == 0) ? x * x : 0.0;
-        ss = wsum64(ss);
-        const double alpha = __shfl(x, 0, 64);
+        const double ss = rsum16((r >= 1) ? x * x : 0.0);   // every 16-lane group holds the column
+        if (lane == 0) sx[0] = x;
+        wave_lds_fence();
+        const double alpha = sx[0];
         double beta = alpha, scale = 0.0;
         if (ss != 0.0 && L >= 2) {
             beta = -copysign(sqrt(fma(alpha, alpha, ss)), alpha);
@@ -383,14 +414,14 @@ __device__ inline void chase_step(const BandRef &B, int n, int s, int q, double 
         if (tau != 0.0 && cq == 0 && r < L) B(i0 + r, s) = (r == 0) ? beta : 0.0;
     } else {
         const int j0 = i0 - SB;                  // I_{q-1} = [j0, j0 + SB)
-        const double tprev = vprev_tau[SB];
+        const double tprev = vprev[SB];
         // C(r, c) = A[i0 + r, j0 + c], 4 columns per lane
         double cv[4], vp[4];
         double w = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = 4 * cq + k;
-            vp[k] = vprev_tau[c];
+            vp[k] = vprev[c];
             cv[k] = (r < L) ? B(i0 + r, j0 + c) : 0.0;
             w = fma(cv[k], vp[k], w);
         }
@@ -399,11 +430,12 @@ __device__ inline void chase_step(const BandRef &B, int n, int s, int q, double 
         const double tw = tprev * w;
 #pragma unroll
         for (int k = 0; k < 4; ++k) cv[k] = fma(-tw, vp[k], cv[k]);   // C <- C H_prev
-        // new reflector from the first column of C
-        const double x = __shfl(cv[0], r, 64);    // column 0 lives in the cq == 0 lanes
-        double ss = (r >= 1 && r < L && cq == 0) ? x * x : 0.0;
-        ss = wsum64(ss);
-        const double alpha = __shfl(x, 0, 64);
+        // new reflector from the first column of C (held by the cq == 0 lanes)
+        if (cq == 0) sx[r] = cv[0];
+        wave_lds_fence();
+        const double x = sx[r];
+        const double alpha = sx[0];
+        const double ss = rsum16((r >= 1 && r < L) ? x * x : 0.0);
         double beta = alpha, scale = 0.0;
         if (ss != 0.0 && L >= 2) {
             beta = -copysign(sqrt(fma(alpha, alpha, ss)), alpha);
@@ -416,11 +448,7 @@ __device__ inline void chase_step(const BandRef &B, int n, int s, int q, double 
             // C <- H C : z_c = sum_r v_r C(r, c)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                double z = vr * cv[k];
-                z += __shfl_xor(z, 1, 64);
-                z += __shfl_xor(z, 2, 64);
-                z += __shfl_xor(z, 4, 64);
-                z += __shfl_xor(z, 8, 64);
+                const double z = rsum16(vr * cv[k]);
                 cv[k] = fma(-tau * z, vr, cv[k]);
             }
             if (cq == 0) cv[0] = (r == 0) ? beta : 0.0;   // exact zeros in the annihilated column
@@ -430,6 +458,13 @@ __device__ inline void chase_step(const BandRef &B, int n, int s, int q, double 
             for (int k = 0; k < 4; ++k) B(i0 + r, j0 + 4 * cq + k) = cv[k];
         }
     }
+    // publish v: next step of this sweep, the D update below, and the back-transformation
+    if (cq == 0) {
+        sv[r] = vr;
+        refl_v[r] = vr;
+    }
+    if (lane == 0) *refl_tau = tau;
+    wave_lds_fence();
     // two-sided update of the diagonal block D = A[I_q, I_q] (lower part stored)
     if (tau != 0.0) {
         double dv[4], vc[4];
@@ -437,32 +472,27 @@ __device__ inline void chase_step(const BandRef &B, int n, int s, int q, double 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = 4 * cq + k;
-            vc[k] = __shfl(vr, c, 64);            // v_c (lane c has r == c, cq == 0)
+            vc[k] = sv[c];
             dv[k] = (r < L && c < L) ? B.sym(i0 + r, i0 + c) : 0.0;
             p = fma(dv[k], vc[k], p);
         }
         p += __shfl_xor(p, 16, 64);
         p += __shfl_xor(p, 32, 64);
         p *= tau;                                   // p_r
-        double pv = (cq == 0) ? p * vr : 0.0;
-        pv = wsum64(pv);
+        const double pv = rsum16(p * vr);           // p and v are replicated in the four groups
         const double wr = fma(-0.5 * tau * pv, vr, p);   // w_r = p_r - tau/2 (p.v) v_r
+        if (cq == 0) sw[r] = wr;
+        wave_lds_fence();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = 4 * cq + k;
-            const double wc = __shfl(wr, c, 64);
+            const double wc = sw[c];
             if (r < L && c <= r) B(i0 + r, i0 + c) = dv[k] - vr * wc - wr * vc[k];
         }
     }
-    // hand the reflector to the next step and to the back-transformation
-    if (cq == 0) {
-        vprev_tau[r] = vr;
-        refl_v[r] = vr;
-    }
-    if (lane == 0) {
-        vprev_tau[SB] = tau;
-        *refl_tau = tau;
-    }
+    // hand the reflector to the next step (same wavefront)
+    if (cq == 0) vprev[r] = vr;
+    if (lane == 0) vprev[SB] = tau;
 }
 
 __global__ __launch_bounds__(CH_NT) void band_chase_kernel(
@@ -481,7 +511,7 @@ __global__ __launch_bounds__(CH_NT) void band_chase_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // LDS: per-wave reflector hand-off [CH_NW][SB+1], cum[n+1] ints, then (optionally) the band
     double *hand = lds;
-    int *cum = (int *)(hand + CH_NW * (SB + 2));
+    int *cum = (int *)(hand + CH_NW * HAND);
     double *bandl = (double *)(cum + ((n + 2 + 1) & ~1));
     BandRef B;
     B.p = band_in_lds ? bandl : (bandg + vo * LDB);
@@ -506,7 +536,7 @@ __global__ __launch_bounds__(CH_NT) void band_chase_kernel(
         int G = (maxsteps + 1 + CH_NW - 1) / CH_NW;
         if (G < 2) G = 2;
         const int tend = (nsweeps - 1) * G + maxsteps;
-        double *myhand = hand + wave * (SB + 2);
+        double *myhand = hand + wave * HAND;
         for (int t = 0; t < tend; ++t) {
             // the sweep of this wavefront that is active at time t (at most one)
             int s = -1, q = 0;
@@ -535,8 +565,11 @@ __global__ __launch_bounds__(CH_NT) void band_chase_kernel(
 // ---------------------------------------------------------------------------------------
 // back-transformation of the eigenvectors:  y = Q1 Q2 z , then x = D^-1/2 y
 // ---------------------------------------------------------------------------------------
-constexpr int BT_NT = 256;
-__global__ __launch_bounds__(BT_NT) void backtransform2_kernel(
+// One workgroup per matrix, vectors one after the other with y resident in LDS.  Q2: per sweep
+// every 16-lane group applies one chase reflector (they touch disjoint rows), one barrier per
+// sweep.  Q1: compact-WY panels in reverse order.
+template <int NT>
+__global__ __launch_bounds__(NT) void backtransform2_kernel(
     const int *__restrict__ ns, const int64_t *__restrict__ moff, const int64_t *__restrict__ voff,
     const int64_t *__restrict__ roff, const double *__restrict__ Wm, const double *__restrict__ Tfac,
     const double *__restrict__ rv, const double *__restrict__ rtau, const double *__restrict__ dis,
@@ -550,9 +583,12 @@ __global__ __launch_bounds__(BT_NT) void backtransform2_kernel(
     const double *RT = rtau + roff[b];
     double *Y = evecs + xoff[b];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = BT_NT / 64;
-    int *cum = (int *)lds;
-    double *gs = (double *)(cum + ((n + 2 + 1) & ~1));  // [NW][2*SB] scratch
+    constexpr int NW = NT / 64;
+    constexpr int NGRP = NT / 16;
+    double *y = lds;                 // [n]
+    double *g = y + n;               // [SB]
+    double *hv = g + SB;             // [SB]
+    int *cum = (int *)(hv + SB);     // [n + 1]
     if (tid == 0) {
         int run = 0;
         for (int s = 0; s < n; ++s) {
@@ -561,23 +597,27 @@ __global__ __launch_bounds__(BT_NT) void backtransform2_kernel(
         }
         cum[n] = run;
     }
-    __syncthreads();
-    const int grp = lane >> 4, r = lane & 15;
-    for (int jj = wave; jj < m; jj += NW) {
-        double *y = Y + (size_t)jj * n;
-        // Q2: sweeps in reverse order; inside a sweep the reflectors touch disjoint rows
+    const int grp = tid >> 4, r = tid & 15;
+    int kmax = -1;
+    if (n - SB >= 2) {
+        kmax = 0;
+        while (n - (kmax + SB) - SB >= 2) kmax += SB;
+    }
+    for (int jj = 0; jj < m; ++jj) {
+        double *Yj = Y + (size_t)jj * n;
+        __syncthreads();
+        for (int i = tid; i < n; i += NT) y[i] = Yj[i];
+        __syncthreads();
+        // Q2: sweeps in reverse order
         for (int s = n - 3; s >= 0; --s) {
             const int nst = chase_steps(n, s);
-            for (int q0 = 0; q0 < nst; q0 += 4) {
-                const int q = q0 + grp;
-                double yr = 0.0, vr = 0.0, tau = 0.0;
+            const int base = cum[s];
+            for (int q = grp; q < nst; q += NGRP) {
                 const int i0 = s + 1 + q * SB;
-                const bool act = (q < nst) && (i0 + r < n);
-                if (q < nst) tau = RT[cum[s] + q];
-                if (act) {
-                    vr = RV[(size_t)(cum[s] + q) * SB + r];
-                    yr = y[i0 + r];
-                }
+                const bool act = (i0 + r < n);
+                const double tau = RT[base + q];
+                const double vr = act ? RV[(size_t)(base + q) * SB + r] : 0.0;
+                const double yr = act ? y[i0 + r] : 0.0;
                 double dot = vr * yr;
                 dot += __shfl_xor(dot, 1, 64);
                 dot += __shfl_xor(dot, 2, 64);
@@ -585,37 +625,35 @@ __global__ __launch_bounds__(BT_NT) void backtransform2_kernel(
                 dot += __shfl_xor(dot, 8, 64);
                 if (act && tau != 0.0) y[i0 + r] = fma(-tau * dot, vr, yr);
             }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // next sweep overlaps these rows
+            __syncthreads();
         }
         // Q1: panels in reverse order, y[k0+SB:] -= V (T (V^T y))
-        double *g = gs + wave * 2 * SB, *hv = g + SB;
-        int kmax = 0;
-        while (n - (kmax + SB) - SB >= 2) kmax += SB;   // last panel with np >= 2
-        for (int k0 = (n - SB >= 2) ? kmax : -1; k0 >= 0; k0 -= SB) {
+        for (int k0 = kmax; k0 >= 0; k0 -= SB) {
             const int np = n - k0 - SB;
-            if (np < 2) continue;
             const double *T = Tfac + vo * SB + (size_t)(k0 / SB) * SB * SB;
             double *yp = y + k0 + SB;
-            for (int c = 0; c < SB; ++c) {
+            for (int c = wave; c < SB; c += NW) {
                 double s2 = 0.0;
                 for (int i = lane; i < np; i += 64) s2 = fma(vmask(A, n, k0, i, c), yp[i], s2);
                 s2 = wsum64(s2);
                 if (lane == 0) g[c] = s2;
             }
-            if (lane < SB) {  // h = T g  (T upper triangular)
+            __syncthreads();
+            if (tid < SB) {  // h = T g  (T upper triangular)
                 double s2 = 0.0;
-                for (int c = lane; c < SB; ++c) s2 = fma(T[c * SB + lane], g[c], s2);
-                hv[lane] = s2;
+                for (int c = tid; c < SB; ++c) s2 = fma(T[c * SB + tid], g[c], s2);
+                hv[tid] = s2;
             }
-            for (int i = lane; i < np; i += 64) {
+            __syncthreads();
+            for (int i = tid; i < np; i += NT) {
                 double s2 = 0.0;
 #pragma unroll
                 for (int c = 0; c < SB; ++c) s2 = fma(vmask(A, n, k0, i, c), hv[c], s2);
                 yp[i] -= s2;
             }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __syncthreads();
         }
-        for (int i = lane; i < n; i += 64) y[i] *= dis[vo + i];
+        for (int i = tid; i < n; i += NT) Yj[i] = y[i] * dis[vo + i];
     }
 }
 
@@ -634,7 +672,9 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b) {
     if (!attr) {
         SA_HIP_CHECK(hipFuncSetAttribute((const void *)band_chase_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SA_HIP_CHECK(hipFuncSetAttribute((const void *)backtransform2_kernel,
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)backtransform2_kernel<256>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)backtransform2_kernel<1024>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SA_HIP_CHECK(hipFuncSetAttribute((const void *)sbr_qr_kernel<256, true>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -646,7 +686,7 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b) {
     for (int i = 0; i < b.count; ++i) b.h_roff[i + 1] = b.h_roff[i] + chase_reflector_count(b.h_n[i]);
     const size_t nrefl = (size_t)b.h_roff[b.count];
     const int nmax0 = b.max_n;
-    const size_t fixed0 = sizeof(double) * (CH_NW * (SB + 2)) + sizeof(int) * ((size_t)nmax0 + 4);
+    const size_t fixed0 = sizeof(double) * (CH_NW * HAND) + sizeof(int) * ((size_t)nmax0 + 4);
     const bool in_lds0 = fixed0 + sizeof(double) * (size_t)nmax0 * LDB + 64 <= 160 * 1024;
     b.h_goff.assign((size_t)b.count + 1, 0);
     for (int i = 0; i < b.count; ++i)
@@ -681,7 +721,7 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b) {
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "eig_band_reduce", bytes, flops);
     // ---- stage 2 ----
-    const size_t fixed = sizeof(double) * (CH_NW * (SB + 2)) + sizeof(int) * ((size_t)nmax + 4);
+    const size_t fixed = sizeof(double) * (CH_NW * HAND) + sizeof(int) * ((size_t)nmax + 4);
     const size_t band_bytes = sizeof(double) * (size_t)nmax * LDB;
     const int in_lds = (fixed + band_bytes + 64 <= 160 * 1024) ? 1 : 0;
     double cflops = 0.0;
@@ -696,12 +736,19 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b) {
 
 void eig_backtransform_two_stage(hipStream_t s, EigBatch &b, const int64_t *xoff, double *evecs) {
     if (!b.count) return;
-    const size_t lds = sizeof(int) * ((size_t)b.max_n + 4) + sizeof(double) * (BT_NT / 64) * 2 * SB + 64;
+    const size_t lds = sizeof(double) * ((size_t)b.max_n + 2 * SB) + sizeof(int) * ((size_t)b.max_n + 4) + 64;
+    SA_REQUIRE(lds <= 160 * 1024, "agglomerate too large for the LDS-resident back-transformation");
     double flops = 0.0;
     for (int i = 0; i < b.count; ++i) flops += 4.0 * (double)b.h_n[i] * b.h_n[i] * b.h_m[i];
     profiler().begin(s);
-    hipLaunchKernelGGL(backtransform2_kernel, dim3(b.count), dim3(BT_NT), lds, s, b.n.p, b.moff.p,
-                       b.voff.p, b.roff.p, b.W.p, b.Tfac.p, b.rv.p, b.rtau.p, b.dis.p, b.m.p, xoff, evecs);
+    if (b.max_n > 1024)
+        hipLaunchKernelGGL((backtransform2_kernel<1024>), dim3(b.count), dim3(1024), lds, s, b.n.p,
+                           b.moff.p, b.voff.p, b.roff.p, b.W.p, b.Tfac.p, b.rv.p, b.rtau.p, b.dis.p,
+                           b.m.p, xoff, evecs);
+    else
+        hipLaunchKernelGGL((backtransform2_kernel<256>), dim3(b.count), dim3(256), lds, s, b.n.p,
+                           b.moff.p, b.voff.p, b.roff.p, b.W.p, b.Tfac.p, b.rv.p, b.rtau.p, b.dis.p,
+                           b.m.p, xoff, evecs);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "eig_backtransform", 0.0, flops);
 }
