@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void scan_add_kernel(int n, int *__restrict__ 
 }
 
 // out has n+1 entries
-static void exclusive_scan(hipStream_t s, int n, const int *in, int *out) {
+void exclusive_scan_int(hipStream_t s, int n, const int *in, int *out) {
     const int nt = div_up(n, 1024);
     DBuf<int> tsum((size_t)nt + 1);
     hipLaunchKernelGGL(scan_tile_kernel, dim3(nt), dim3(256), 0, s, n, in, out, tsum.p);
@@ -296,7 +296,7 @@ void build_P_R(hipStream_t s, const DevRelations &rel, const Relations &hrel,
     {
         DBuf<int> cnt((size_t)ND);
         hipLaunchKernelGGL(p_count_kernel, dim3(div_up(ND, 256)), dim3(256), 0, s, ND, rel.mises.p, d_k, cnt.p);
-        exclusive_scan(s, ND, cnt.p, P.rowptr.p);
+        exclusive_scan_int(s, ND, cnt.p, P.rowptr.p);
     }
     hipLaunchKernelGGL(p_fill_kernel, dim3(div_up(ND, 256)), dim3(256), 0, s, ND, rel.mises.p,
                        rel.dof_row_in_mis.p, rel.mis2d_I.p, d_k, d_coloff, d_u_off, U, P.rowptr.p,

@@ -1,13 +1,49 @@
-// Host-side integer topology (single rank).  Output is bit-identical to the reference's
+// Integer topology of one level (single rank).  Output is bit-identical to the reference's
 // tables; the reference's O(#MIS x ND) MIS loop (amg/src/aggregates.cpp:541-607) is replaced
-// by a signature hash with the same numbering (first appearance scanning dofs upward,
-// dofs inside a MIS ascending).
+// by a signature hash with the same numbering (first appearance scanning dofs upward, dofs
+// inside a MIS ascending).  The tables that drive the numbering are built on the host with a
+// small thread pool; dof_to_elem and elem_ldof (only consumed by the assembly kernel) are
+// built on the device.
 #include "topology.h"
 
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <functional>
+#include <thread>
 #include <unordered_map>
 
 namespace saamge_amd {
+
+// ---------------------------------------------------------------------------------------
+// tiny fork-join helper
+// ---------------------------------------------------------------------------------------
+static int num_threads() {
+    static int nt = 0;
+    if (!nt) {
+        const char *e = std::getenv("SAAMGE_AMD_THREADS");
+        nt = e ? std::atoi(e) : (int)std::thread::hardware_concurrency();
+        if (nt < 1) nt = 1;
+        if (nt > 16) nt = 16;
+    }
+    return nt;
+}
+
+// fn(begin, end, tid) over [0, n) split into contiguous ranges
+static void parallel_for(int64_t n, const std::function<void(int64_t, int64_t, int)> &fn, int64_t grain = 4096) {
+    int T = num_threads();
+    if (n < grain * 2) T = 1;
+    if (T == 1) {
+        fn(0, n, 0);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) {
+        const int64_t b = n * t / T, e = n * (t + 1) / T;
+        th.emplace_back([=, &fn]() { fn(b, e, t); });
+    }
+    for (auto &x : th) x.join();
+}
 
 Table table_transpose(const Table &T) {
     Table R;
@@ -29,7 +65,6 @@ Table table_mult(const Table &A, const Table &B) {
     C.ncols = B.ncols;
     C.I.assign((size_t)nr + 1, 0);
     std::vector<int> stamp((size_t)B.ncols, -1);
-    // count
     for (int i = 0; i < nr; ++i) {
         int cnt = 0;
         for (int k = A.I[i]; k < A.I[i + 1]; ++k) {
@@ -56,6 +91,50 @@ Table table_mult(const Table &A, const Table &B) {
     return C;
 }
 
+// Stable parallel counting sort of items 0..n-1 by key(item) in [0, nkeys): returns the CSR
+// (I, J) with J listing the items of each key in ascending item order (== mfem::Transpose).
+static void counting_sort_rows(int64_t n, int nkeys, const std::function<int(int64_t)> &key,
+                               std::vector<int> &I, std::vector<int> &J) {
+    int T = num_threads();
+    if (n < 1 << 16 || (int64_t)nkeys * T > ((int64_t)1 << 27)) T = 1;
+    I.assign((size_t)nkeys + 1, 0);
+    J.resize((size_t)n);
+    if (T == 1) {
+        for (int64_t i = 0; i < n; ++i) I[(size_t)key(i) + 1]++;
+        for (int k = 0; k < nkeys; ++k) I[k + 1] += I[k];
+        std::vector<int> pos(I.begin(), I.end() - 1);
+        for (int64_t i = 0; i < n; ++i) J[pos[key(i)]++] = (int)i;
+        return;
+    }
+    std::vector<std::vector<int>> cnt(T, std::vector<int>((size_t)nkeys, 0));
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+        th.emplace_back([&, t]() {
+            const int64_t b = n * t / T, e = n * (t + 1) / T;
+            int *c = cnt[t].data();
+            for (int64_t i = b; i < e; ++i) c[key(i)]++;
+        });
+    for (auto &x : th) x.join();
+    th.clear();
+    int run = 0;
+    for (int k = 0; k < nkeys; ++k) {
+        I[k] = run;
+        for (int t = 0; t < T; ++t) {
+            const int c = cnt[t][k];
+            cnt[t][k] = run;
+            run += c;
+        }
+    }
+    I[nkeys] = run;
+    for (int t = 0; t < T; ++t)
+        th.emplace_back([&, t]() {
+            const int64_t b = n * t / T, e = n * (t + 1) / T;
+            int *c = cnt[t].data();
+            for (int64_t i = b; i < e; ++i) J[c[key(i)]++] = (int)i;
+        });
+    for (auto &x : th) x.join();
+}
+
 static inline uint64_t hash_row(const int *r, int n) {
     uint64_t h = 1469598103934665603ull ^ (uint64_t)n;
     for (int i = 0; i < n; ++i) {
@@ -72,139 +151,295 @@ void build_relations(Relations &r, Table &&elem_to_dof, const std::vector<int> &
     r.elem_to_dof = std::move(elem_to_dof);
     r.elem_to_dof.ncols = ND;
     r.NE = r.elem_to_dof.nrows();
+    const Table &e2d = r.elem_to_dof;
     SA_REQUIRE((int)partitioning.size() == r.NE, "partitioning size != number of elements");
     r.partitioning = partitioning;
-    for (int e = 0; e < r.NE; ++e)
-        SA_REQUIRE(partitioning[e] >= 0 && partitioning[e] < nparts, "partition id out of range");
-    for (int v : r.elem_to_dof.J) SA_REQUIRE(v >= 0 && v < ND, "elem_to_dof entry out of range");
-    r.dof_to_elem = table_transpose(r.elem_to_dof);
-    // elem_to_AE / AE_to_elem (agg_construct_tables_from_arr)
-    Table elem_to_AE;
-    elem_to_AE.ncols = nparts;
-    elem_to_AE.I.resize((size_t)r.NE + 1);
-    for (int e = 0; e <= r.NE; ++e) elem_to_AE.I[e] = e;
-    elem_to_AE.J = partitioning;
-    r.AE_to_elem = table_transpose(elem_to_AE);
-    for (int p = 0; p < nparts; ++p) SA_REQUIRE(r.AE_to_elem.row_size(p) > 0, "empty agglomerate");
-    r.AE_to_dof = table_mult(r.AE_to_elem, r.elem_to_dof);   // first-encounter order
-    r.dof_to_AE = table_transpose(r.AE_to_dof);               // ascending AE ids
-    // dof_id_inAE (agg_build_glob_to_AE_id_map, :1202-1244)
-    r.dof_id_inAE.assign(r.dof_to_AE.J.size(), -1);
     {
-        std::vector<int> pos(r.dof_to_AE.I.begin(), r.dof_to_AE.I.end() - 1);
-        // dof_to_AE rows are ascending in AE and AEs are visited ascending -> pos walks each row
-        for (int p = 0; p < nparts; ++p)
+        std::atomic<int> bad(0);
+        parallel_for(r.NE, [&](int64_t b, int64_t e, int) {
+            for (int64_t i = b; i < e; ++i)
+                if (partitioning[i] < 0 || partitioning[i] >= nparts) bad = 1;
+        });
+        SA_REQUIRE(!bad, "partition id out of range");
+        parallel_for((int64_t)e2d.J.size(), [&](int64_t b, int64_t e, int) {
+            for (int64_t i = b; i < e; ++i)
+                if (e2d.J[i] < 0 || e2d.J[i] >= ND) bad = 1;
+        });
+        SA_REQUIRE(!bad, "elem_to_dof entry out of range");
+    }
+    // AE_to_elem (agg_construct_tables_from_arr): elements of each AE, ascending
+    r.AE_to_elem.ncols = r.NE;
+    counting_sort_rows(r.NE, nparts, [&](int64_t e) { return partitioning[e]; }, r.AE_to_elem.I,
+                       r.AE_to_elem.J);
+    for (int p = 0; p < nparts; ++p) SA_REQUIRE(r.AE_to_elem.row_size(p) > 0, "empty agglomerate");
+    // AE_to_dof = AE_to_elem x elem_to_dof in first-encounter order, one hash set per thread
+    r.AE_to_dof.ncols = ND;
+    r.AE_to_dof.I.assign((size_t)nparts + 1, 0);
+    std::vector<std::vector<int>> rows((size_t)nparts);
+    parallel_for(nparts, [&](int64_t pb, int64_t pe, int) {
+        std::vector<int> table;
+        for (int64_t p = pb; p < pe; ++p) {
+            size_t cand = 0;
+            for (int k = r.AE_to_elem.I[p]; k < r.AE_to_elem.I[p + 1]; ++k) cand += (size_t)e2d.row_size(r.AE_to_elem.J[k]);
+            size_t cap = 16;
+            while (cap < 2 * cand) cap <<= 1;
+            table.assign(cap, -1);
+            std::vector<int> &out = rows[(size_t)p];
+            out.reserve(cand / 2 + 8);
+            for (int k = r.AE_to_elem.I[p]; k < r.AE_to_elem.I[p + 1]; ++k) {
+                const int el = r.AE_to_elem.J[k];
+                for (int q = e2d.I[el]; q < e2d.I[el + 1]; ++q) {
+                    const int d = e2d.J[q];
+                    size_t h = ((size_t)(uint32_t)d * 2654435761u) & (cap - 1);
+                    while (table[h] != -1 && table[h] != d) h = (h + 1) & (cap - 1);
+                    if (table[h] == -1) {
+                        table[h] = d;
+                        out.push_back(d);
+                    }
+                }
+            }
+        }
+    }, 8);
+    for (int p = 0; p < nparts; ++p) r.AE_to_dof.I[p + 1] = r.AE_to_dof.I[p] + (int)rows[p].size();
+    r.AE_to_dof.J.resize((size_t)r.AE_to_dof.I[nparts]);
+    parallel_for(nparts, [&](int64_t pb, int64_t pe, int) {
+        for (int64_t p = pb; p < pe; ++p)
+            std::copy(rows[(size_t)p].begin(), rows[(size_t)p].end(), r.AE_to_dof.J.begin() + r.AE_to_dof.I[p]);
+    }, 8);
+    rows.clear();
+    rows.shrink_to_fit();
+    // dof_to_AE = transpose, rows ascending in AE: atomic counts + cursors, then sort the short rows
+    const int64_t nconn = (int64_t)r.AE_to_dof.J.size();
+    r.dof_to_AE.ncols = nparts;
+    r.dof_to_AE.I.assign((size_t)ND + 1, 0);
+    {
+        std::vector<int> cnt((size_t)ND, 0);
+        parallel_for(nconn, [&](int64_t b, int64_t e, int) {
+            for (int64_t k = b; k < e; ++k) __atomic_fetch_add(&cnt[r.AE_to_dof.J[k]], 1, __ATOMIC_RELAXED);
+        });
+        for (int i = 0; i < ND; ++i) {
+            SA_REQUIRE(cnt[i] > 0, "dof without any element");
+            r.dof_to_AE.I[i + 1] = r.dof_to_AE.I[i] + cnt[i];
+        }
+        r.dof_to_AE.J.resize((size_t)nconn);
+        std::fill(cnt.begin(), cnt.end(), 0);
+        parallel_for(nparts, [&](int64_t pb, int64_t pe, int) {
+            for (int64_t p = pb; p < pe; ++p)
+                for (int k = r.AE_to_dof.I[p]; k < r.AE_to_dof.I[p + 1]; ++k) {
+                    const int d = r.AE_to_dof.J[k];
+                    const int pos = __atomic_fetch_add(&cnt[d], 1, __ATOMIC_RELAXED);
+                    r.dof_to_AE.J[(size_t)r.dof_to_AE.I[d] + pos] = (int)p;
+                }
+        }, 8);
+        parallel_for(ND, [&](int64_t b, int64_t e, int) {
+            for (int64_t i = b; i < e; ++i)
+                if (r.dof_to_AE.I[i + 1] - r.dof_to_AE.I[i] > 1)
+                    std::sort(r.dof_to_AE.J.begin() + r.dof_to_AE.I[i], r.dof_to_AE.J.begin() + r.dof_to_AE.I[i + 1]);
+        });
+    }
+    // dof_id_inAE (agg_build_glob_to_AE_id_map, :1202-1244)
+    r.dof_id_inAE.assign((size_t)nconn, -1);
+    parallel_for(nparts, [&](int64_t pb, int64_t pe, int) {
+        for (int64_t p = pb; p < pe; ++p)
             for (int k = r.AE_to_dof.I[p]; k < r.AE_to_dof.I[p + 1]; ++k) {
-                const int dof = r.AE_to_dof.J[k];
-                r.dof_id_inAE[pos[dof]++] = k - r.AE_to_dof.I[p];
+                const int d = r.AE_to_dof.J[k];
+                const int *row = r.dof_to_AE.row(d);
+                const int rs = r.dof_to_AE.row_size(d);
+                const int t = (int)(std::lower_bound(row, row + rs, (int)p) - row);
+                r.dof_id_inAE[(size_t)r.dof_to_AE.I[d] + t] = k - r.AE_to_dof.I[p];
             }
+    }, 8);
+    // ---- MISes: groups of dofs with identical AE lists, numbered by first appearance ----
+    // group representative = smallest dof of the group
+    std::vector<int> rep_of((size_t)ND, -1);        // dof -> representative dof
+    {
+        const int T = num_threads();
+        // single-AE dofs: representative = min dof per AE
+        std::vector<std::vector<int>> mins(T, std::vector<int>((size_t)nparts, ND));
+        parallel_for(ND, [&](int64_t b, int64_t e, int t) {
+            int *m = mins[t].data();
+            for (int64_t i = b; i < e; ++i)
+                if (r.dof_to_AE.row_size((int)i) == 1) {
+                    const int p = r.dof_to_AE.row((int)i)[0];
+                    if ((int)i < m[p]) m[p] = (int)i;
+                }
+        }, 1);
+        std::vector<int> single((size_t)nparts, ND);
+        for (int t = 0; t < T; ++t)
+            for (int p = 0; p < nparts; ++p) single[p] = std::min(single[p], mins[t][p]);
+        mins.clear();
+        // multi-AE dofs: hash of the AE list, grouped in T hash buckets built concurrently
+        std::vector<uint64_t> hv((size_t)ND, 0);
+        parallel_for(ND, [&](int64_t b, int64_t e, int) {
+            for (int64_t i = b; i < e; ++i) {
+                const int rs = r.dof_to_AE.row_size((int)i);
+                if (rs > 1) hv[(size_t)i] = hash_row(r.dof_to_AE.row((int)i), rs);
+            }
+        });
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t]() {
+                std::unordered_map<uint64_t, std::vector<int>> groups;  // hash -> representatives
+                for (int i = 0; i < ND; ++i) {
+                    const int rs = r.dof_to_AE.row_size(i);
+                    if (rs == 1) {
+                        if (t == 0) rep_of[i] = single[r.dof_to_AE.row(i)[0]];
+                        continue;
+                    }
+                    const uint64_t h = hv[(size_t)i];
+                    if ((int)((h >> 40) % (uint64_t)T) != t) continue;
+                    std::vector<int> &cands = groups[h];
+                    const int *row = r.dof_to_AE.row(i);
+                    int rep = -1;
+                    for (int c : cands)
+                        if (r.dof_to_AE.row_size(c) == rs && std::equal(row, row + rs, r.dof_to_AE.row(c))) { rep = c; break; }
+                    if (rep < 0) { rep = i; cands.push_back(i); }   // ascending scan: first seen = smallest
+                    rep_of[i] = rep;
+                }
+            });
+        for (auto &x : th) x.join();
     }
-    // elem_ldof: AE-local index of every element dof (each element lies in exactly one AE)
-    r.elem_ldof.resize(r.elem_to_dof.J.size());
-    for (int e = 0; e < r.NE; ++e) {
-        const int p = partitioning[e];
-        for (int k = r.elem_to_dof.I[e]; k < r.elem_to_dof.I[e + 1]; ++k) {
-            const int dof = r.elem_to_dof.J[k];
-            const int *row = r.dof_to_AE.row(dof);
-            const int rs = r.dof_to_AE.row_size(dof);
-            const int *it = std::lower_bound(row, row + rs, p);
-            r.elem_ldof[k] = r.dof_id_inAE[r.dof_to_AE.I[dof] + (int)(it - row)];
-        }
-    }
-    // MISes
+    // MIS ids = rank of the representative among all representatives (first appearance order)
+    std::vector<int> reps;
+    for (int i = 0; i < ND; ++i)
+        if (rep_of[i] == i) reps.push_back(i);
+    r.num_mises = (int)reps.size();
+    std::vector<int> mis_of_rep((size_t)ND, -1);
+    for (int m = 0; m < r.num_mises; ++m) mis_of_rep[reps[m]] = m;
     r.mises.assign((size_t)ND, -1);
-    r.dof_row_in_mis.assign((size_t)ND, 0);
-    std::vector<int> single((size_t)nparts, -1);          // MIS of dofs living in exactly one AE
-    std::unordered_map<uint64_t, std::vector<int>> multi;  // hash -> candidate MIS ids
-    std::vector<int> mis_rep;                              // representative dof of each MIS
-    std::vector<int> mis_size;
-    for (int i = 0; i < ND; ++i) {
-        const int rs = r.dof_to_AE.row_size(i);
-        const int *row = r.dof_to_AE.row(i);
-        SA_REQUIRE(rs > 0, "dof without any element");
-        int mid = -1;
-        if (rs == 1) {
-            mid = single[row[0]];
-            if (mid < 0) {
-                mid = (int)mis_rep.size();
-                single[row[0]] = mid;
-                mis_rep.push_back(i);
-                mis_size.push_back(0);
-            }
-        } else {
-            std::vector<int> &cands = multi[hash_row(row, rs)];
-            for (int c : cands) {
-                const int rep = mis_rep[c];
-                if (r.dof_to_AE.row_size(rep) == rs &&
-                    std::equal(row, row + rs, r.dof_to_AE.row(rep))) { mid = c; break; }
-            }
-            if (mid < 0) {
-                mid = (int)mis_rep.size();
-                cands.push_back(mid);
-                mis_rep.push_back(i);
-                mis_size.push_back(0);
-            }
-        }
-        r.mises[i] = mid;
-        r.dof_row_in_mis[i] = mis_size[mid]++;
-    }
-    r.num_mises = (int)mis_rep.size();
+    parallel_for(ND, [&](int64_t b, int64_t e, int) {
+        for (int64_t i = b; i < e; ++i) r.mises[(size_t)i] = mis_of_rep[rep_of[(size_t)i]];
+    });
+    mis_of_rep.clear();
+    mis_of_rep.shrink_to_fit();
+    // mis_to_dof: dofs of each MIS ascending
     r.mis_to_dof.ncols = ND;
-    r.mis_to_dof.I.assign((size_t)r.num_mises + 1, 0);
-    for (int m = 0; m < r.num_mises; ++m) r.mis_to_dof.I[m + 1] = r.mis_to_dof.I[m] + mis_size[m];
-    r.mis_to_dof.J.resize((size_t)ND);
-    for (int i = 0; i < ND; ++i) r.mis_to_dof.J[r.mis_to_dof.I[r.mises[i]] + r.dof_row_in_mis[i]] = i;
+    counting_sort_rows(ND, r.num_mises, [&](int64_t i) { return r.mises[(size_t)i]; }, r.mis_to_dof.I,
+                       r.mis_to_dof.J);
+    r.dof_row_in_mis.assign((size_t)ND, 0);
+    parallel_for(r.num_mises, [&](int64_t mb, int64_t me, int) {
+        for (int64_t m = mb; m < me; ++m)
+            for (int k = r.mis_to_dof.I[m]; k < r.mis_to_dof.I[m + 1]; ++k)
+                r.dof_row_in_mis[(size_t)r.mis_to_dof.J[k]] = k - r.mis_to_dof.I[m];
+    }, 64);
     // mis_to_AE = mis_to_dof x dof_to_AE == the (ascending) AE list of any member dof
     r.mis_to_AE.ncols = nparts;
     r.mis_to_AE.I.assign((size_t)r.num_mises + 1, 0);
     for (int m = 0; m < r.num_mises; ++m)
-        r.mis_to_AE.I[m + 1] = r.mis_to_AE.I[m] + r.dof_to_AE.row_size(mis_rep[m]);
+        r.mis_to_AE.I[m + 1] = r.mis_to_AE.I[m] + r.dof_to_AE.row_size(reps[m]);
     r.mis_to_AE.J.resize((size_t)r.mis_to_AE.I[r.num_mises]);
-    for (int m = 0; m < r.num_mises; ++m)
-        std::copy(r.dof_to_AE.row(mis_rep[m]), r.dof_to_AE.row(mis_rep[m]) + r.dof_to_AE.row_size(mis_rep[m]),
-                  r.mis_to_AE.J.begin() + r.mis_to_AE.I[m]);
-    r.AE_to_mis = table_transpose(r.mis_to_AE);  // ascending MIS ids == the "sorted" order of elmat.cpp:121-123
-    // flags
-    r.agg_flags.assign((size_t)ND, 0);
-    for (int i = 0; i < ND; ++i) {
-        signed char f = bdr ? bdr[i] : 0;
-        if (r.dof_to_AE.row_size(i) > 1) f |= FLAG_BETWEEN_AES;
-        r.agg_flags[i] = f;
+    parallel_for(r.num_mises, [&](int64_t mb, int64_t me, int) {
+        for (int64_t m = mb; m < me; ++m)
+            std::copy(r.dof_to_AE.row(reps[m]), r.dof_to_AE.row(reps[m]) + r.dof_to_AE.row_size(reps[m]),
+                      r.mis_to_AE.J.begin() + r.mis_to_AE.I[m]);
+    }, 64);
+    // AE_to_mis = transpose (ascending MIS ids == the "sorted" order of elmat.cpp:121-123);
+    // ae_pair keeps, for each (AE, mis) entry, the id of the (mis, AE) pair
+    const int64_t npairs = (int64_t)r.mis_to_AE.J.size();
+    r.AE_to_mis.ncols = r.num_mises;
+    counting_sort_rows(npairs, nparts, [&](int64_t q) { return r.mis_to_AE.J[(size_t)q]; }, r.AE_to_mis.I,
+                       r.ae_pair);
+    r.AE_to_mis.J.resize((size_t)npairs);
+    {
+        // pair q belongs to the MIS whose row contains q
+        std::vector<int> mis_of_pair((size_t)npairs);
+        parallel_for(r.num_mises, [&](int64_t mb, int64_t me, int) {
+            for (int64_t m = mb; m < me; ++m)
+                for (int q = r.mis_to_AE.I[m]; q < r.mis_to_AE.I[m + 1]; ++q) mis_of_pair[(size_t)q] = (int)m;
+        }, 64);
+        parallel_for(npairs, [&](int64_t b, int64_t e, int) {
+            for (int64_t k = b; k < e; ++k) r.AE_to_mis.J[(size_t)k] = mis_of_pair[(size_t)r.ae_pair[(size_t)k]];
+        });
     }
-    // (MIS, AE) pairs and AE-local indices
-    const size_t npairs = r.mis_to_AE.J.size();
-    r.pair_loc_off.assign(npairs + 1, 0);
-    for (int m = 0; m < r.num_mises; ++m)
-        for (int q = r.mis_to_AE.I[m]; q < r.mis_to_AE.I[m + 1]; ++q)
-            r.pair_loc_off[(size_t)q + 1] = r.pair_loc_off[q] + mis_size[m];
-    r.pair_loc.resize((size_t)r.pair_loc_off[npairs]);
+    // flags (agg_construct_agg_flags, :198-216)
+    r.agg_flags.assign((size_t)ND, 0);
+    parallel_for(ND, [&](int64_t b, int64_t e, int) {
+        for (int64_t i = b; i < e; ++i) {
+            signed char f = bdr ? bdr[i] : 0;
+            if (r.dof_to_AE.row_size((int)i) > 1) f |= FLAG_BETWEEN_AES;
+            r.agg_flags[(size_t)i] = f;
+        }
+    });
+    // (MIS, AE) pairs: AE-local indices of the MIS dofs
+    r.pair_loc_off.assign((size_t)npairs + 1, 0);
     for (int m = 0; m < r.num_mises; ++m) {
-        const int na = r.mis_to_AE.row_size(m);
-        for (int t = 0; t < na; ++t) {
-            const int q = r.mis_to_AE.I[m] + t;
-            int *dst = r.pair_loc.data() + r.pair_loc_off[q];
-            for (int k = 0; k < mis_size[m]; ++k) {
-                const int dof = r.mis_to_dof.J[r.mis_to_dof.I[m] + k];
-                // every dof of the MIS has the same AE list: the t-th AE of the dof's row
-                dst[k] = r.dof_id_inAE[r.dof_to_AE.I[dof] + t];
+        const int sz = r.mis_to_dof.row_size(m);
+        for (int q = r.mis_to_AE.I[m]; q < r.mis_to_AE.I[m + 1]; ++q)
+            r.pair_loc_off[(size_t)q + 1] = r.pair_loc_off[q] + sz;
+    }
+    r.pair_loc.resize((size_t)r.pair_loc_off[npairs]);
+    parallel_for(r.num_mises, [&](int64_t mb, int64_t me, int) {
+        for (int64_t m = mb; m < me; ++m) {
+            const int na = r.mis_to_AE.row_size((int)m);
+            const int sz = r.mis_to_dof.row_size((int)m);
+            for (int t = 0; t < na; ++t) {
+                const int q = r.mis_to_AE.I[m] + t;
+                int *dst = r.pair_loc.data() + r.pair_loc_off[q];
+                for (int k = 0; k < sz; ++k) {
+                    const int dof = r.mis_to_dof.J[(size_t)r.mis_to_dof.I[m] + k];
+                    // every dof of the MIS has the same AE list: the t-th AE of the dof's row
+                    dst[k] = r.dof_id_inAE[(size_t)r.dof_to_AE.I[dof] + t];
+                }
             }
         }
+    }, 64);
+}
+
+// ---------------------------------------------------------------------------------------
+// device-side pieces: dof_to_elem (transpose with ascending rows) and elem_ldof
+// ---------------------------------------------------------------------------------------
+void exclusive_scan_int(hipStream_t s, int n, const int *in, int *out);  // mis.hip
+
+__global__ __launch_bounds__(256) void d2e_count_kernel(long nconn, const int *__restrict__ e2d_J,
+                                                        int *__restrict__ cnt) {
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    if (k < nconn) atomicAdd(&cnt[e2d_J[k]], 1);
+}
+__global__ __launch_bounds__(256) void d2e_fill_kernel(int NE, const int *__restrict__ e2d_I,
+                                                       const int *__restrict__ e2d_J,
+                                                       const int *__restrict__ d2e_I,
+                                                       int *__restrict__ cursor, int *__restrict__ d2e_J) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= NE) return;
+    for (int k = e2d_I[e]; k < e2d_I[e + 1]; ++k) {
+        const int d = e2d_J[k];
+        d2e_J[d2e_I[d] + atomicAdd(&cursor[d], 1)] = (int)e;
     }
-    r.ae_pair.resize(r.AE_to_mis.J.size());
-    {
-        std::vector<int> pos(r.AE_to_mis.I.begin(), r.AE_to_mis.I.end() - 1);
-        for (int m = 0; m < r.num_mises; ++m)
-            for (int q = r.mis_to_AE.I[m]; q < r.mis_to_AE.I[m + 1]; ++q) r.ae_pair[pos[r.mis_to_AE.J[q]]++] = q;
+}
+__global__ __launch_bounds__(256) void d2e_sort_kernel(int ND, const int *__restrict__ d2e_I,
+                                                       int *__restrict__ d2e_J) {
+    const long d = (long)blockIdx.x * 256 + threadIdx.x;
+    if (d >= ND) return;
+    const int b = d2e_I[d], e = d2e_I[d + 1];
+    for (int i = b + 1; i < e; ++i) {  // insertion sort, rows are short
+        const int v = d2e_J[i];
+        int j = i - 1;
+        while (j >= b && d2e_J[j] > v) { d2e_J[j + 1] = d2e_J[j]; --j; }
+        d2e_J[j + 1] = v;
+    }
+}
+__global__ __launch_bounds__(256) void elem_ldof_kernel(int NE, const int *__restrict__ e2d_I,
+                                                        const int *__restrict__ e2d_J,
+                                                        const int *__restrict__ part,
+                                                        const int *__restrict__ d2ae_I,
+                                                        const int *__restrict__ d2ae_J,
+                                                        const int *__restrict__ dof_id_inAE,
+                                                        int *__restrict__ elem_ldof) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= NE) return;
+    const int p = part[e];
+    for (int k = e2d_I[e]; k < e2d_I[e + 1]; ++k) {
+        const int d = e2d_J[k];
+        int idx = d2ae_I[d];
+        while (d2ae_J[idx] != p) ++idx;  // every element dof lies in the element's AE
+        elem_ldof[k] = dof_id_inAE[idx];
     }
 }
 
 void upload_relations(DevRelations &d, const Relations &r, hipStream_t s) {
     d.e2d_I.from_host(r.elem_to_dof.I, s);
     d.e2d_J.from_host(r.elem_to_dof.J, s);
-    d.elem_ldof.from_host(r.elem_ldof, s);
     d.part.from_host(r.partitioning, s);
-    d.d2e_I.from_host(r.dof_to_elem.I, s);
-    d.d2e_J.from_host(r.dof_to_elem.J, s);
     d.ae2d_I.from_host(r.AE_to_dof.I, s);
     d.ae2d_J.from_host(r.AE_to_dof.J, s);
     d.d2ae_I.from_host(r.dof_to_AE.I, s);
@@ -222,6 +457,25 @@ void upload_relations(DevRelations &d, const Relations &r, hipStream_t s) {
     d.pair_loc_off.from_host(r.pair_loc_off, s);
     d.pair_loc.from_host(r.pair_loc, s);
     d.flags.from_host(r.agg_flags, s);
+    // dof_to_elem on the device
+    const long nconn = (long)r.elem_to_dof.J.size();
+    d.d2e_I.alloc((size_t)r.ND + 1);
+    d.d2e_J.alloc((size_t)nconn);
+    d.elem_ldof.alloc((size_t)nconn);
+    {
+        DBuf<int> cnt((size_t)r.ND);
+        cnt.zero(s);
+        hipLaunchKernelGGL(d2e_count_kernel, dim3(div_up(nconn, 256)), dim3(256), 0, s, nconn, d.e2d_J.p, cnt.p);
+        exclusive_scan_int(s, r.ND, cnt.p, d.d2e_I.p);
+        cnt.zero(s);
+        hipLaunchKernelGGL(d2e_fill_kernel, dim3(div_up(r.NE, 256)), dim3(256), 0, s, r.NE, d.e2d_I.p,
+                           d.e2d_J.p, d.d2e_I.p, cnt.p, d.d2e_J.p);
+        hipLaunchKernelGGL(d2e_sort_kernel, dim3(div_up(r.ND, 256)), dim3(256), 0, s, r.ND, d.d2e_I.p, d.d2e_J.p);
+        hipLaunchKernelGGL(elem_ldof_kernel, dim3(div_up(r.NE, 256)), dim3(256), 0, s, r.NE, d.e2d_I.p,
+                           d.e2d_J.p, d.part.p, d.d2ae_I.p, d.d2ae_J.p, d.dof_id_inAE.p, d.elem_ldof.p);
+        SA_HIP_CHECK(hipGetLastError());
+        SA_HIP_CHECK(hipStreamSynchronize(s));
+    }
 }
 
 }  // namespace saamge_amd
