@@ -133,6 +133,13 @@ struct DCsr {
     DBuf<int> rowptr, col;
     DBuf<double> val;
     int lanes_per_row = 8;  // SpMV launch shape, chosen from the average row length
+    // optional SELL-64 copy for the SpMV family: slice s = rows 64s..64s+63, entry (k, lane)
+    // at sell_ptr[s] + 64 k + lane (padded with zero values), fully coalesced per wavefront
+    bool has_sell = false;
+    int nslices = 0;
+    int64_t sell_size = 0;
+    DBuf<int> sell_ptr, sell_col;
+    DBuf<double> sell_val;
 };
 
 inline int pick_lanes_per_row(int64_t nnz, int nrows) {

@@ -84,6 +84,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const std::vector<in
     upload_relations(L.drel, L.rel, s);
     tm.lap("upload topology", lev);
     const Relations &rel = L.rel;
+    build_sell(s, L.A);   // SELL-64 copy of the level operator for the SpMV family
     // smoother data (smpr_init_poly_data, amg/src/smpr.cpp:359-423)
     L.dinv_neg.alloc((size_t)L.A.nrows);
     {
@@ -335,9 +336,10 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
 static const DCsr &coarsest_op(const Hierarchy &H) { return H.levels.back()->Ac; }
 
 static void setup_coarse_solver(Hierarchy &H) {
-    const DCsr &Ac = coarsest_op(H);
+    DCsr &Ac = H.levels.back()->Ac;
     hipStream_t s = H.stream;
     const size_t n = (size_t)Ac.nrows;
+    build_sell(s, Ac);
     H.coarse_kind = 2;
     H.c_dinv.alloc(n);
     H.c_r.alloc(n); H.c_z.alloc(n); H.c_d.alloc(n); H.c_q.alloc(n); H.c_t0.alloc(n); H.c_t1.alloc(n);

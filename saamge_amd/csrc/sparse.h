@@ -4,6 +4,8 @@
 
 namespace saamge_amd {
 
+// build the SELL-64 copy of A (used by every routine below when present)
+void build_sell(hipStream_t s, DCsr &A);
 // y = A x
 void spmv(hipStream_t s, const DCsr &A, const double *x, double *y);
 // r = b - A x                                   (reference: amg/src/tg.cpp:115-116)

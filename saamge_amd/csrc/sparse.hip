@@ -42,10 +42,113 @@ __global__ __launch_bounds__(256) void spmv_kernel(int nrows, const int *__restr
     }
 }
 
+// SELL-64: one lane per row, the wavefront walks its slice column by column; val/col loads are
+// 512 B / 256 B contiguous per step and, for stencil-like matrices, so are the x gathers.
+template <int MODE>
+__global__ __launch_bounds__(256) void sell_spmv_kernel(int nrows, const int *__restrict__ sptr,
+                                                        const int *__restrict__ col,
+                                                        const double *__restrict__ val,
+                                                        const double *__restrict__ x,
+                                                        double *__restrict__ y,
+                                                        const double *__restrict__ b,
+                                                        const double *__restrict__ dinv, double scale) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    const int slice = (int)(row >> 6), lane = threadIdx.x & 63;
+    if ((long)slice * 64 >= nrows) return;
+    const int beg = sptr[slice], end = sptr[slice + 1];
+    const int *cp = col + beg + lane;
+    const double *vp = val + beg + lane;
+    const int w = (end - beg) >> 6;
+    double s0 = 0.0, s1 = 0.0;
+    int k = 0;
+    for (; k + 4 <= w; k += 4) {
+        const int c0 = __builtin_nontemporal_load(cp + 64 * k), c1 = __builtin_nontemporal_load(cp + 64 * (k + 1));
+        const int c2 = __builtin_nontemporal_load(cp + 64 * (k + 2)), c3 = __builtin_nontemporal_load(cp + 64 * (k + 3));
+        const double v0 = __builtin_nontemporal_load(vp + 64 * k), v1 = __builtin_nontemporal_load(vp + 64 * (k + 1));
+        const double v2 = __builtin_nontemporal_load(vp + 64 * (k + 2)), v3 = __builtin_nontemporal_load(vp + 64 * (k + 3));
+        s0 = fma(v0, x[c0], s0);
+        s1 = fma(v1, x[c1], s1);
+        s0 = fma(v2, x[c2], s0);
+        s1 = fma(v3, x[c3], s1);
+    }
+    for (; k < w; ++k) s0 = fma(__builtin_nontemporal_load(vp + 64 * k), x[__builtin_nontemporal_load(cp + 64 * k)], s0);
+    const double sum = s0 + s1;
+    if (row >= nrows) return;
+    if (MODE == MODE_PLAIN) {
+        y[row] = sum;
+    } else if (MODE == MODE_RESIDUAL) {
+        y[row] = b[row] - sum;
+    } else if (MODE == MODE_ADD) {
+        y[row] += sum;
+    } else {
+        y[row] = x[row] + scale * (dinv[row] * (sum - b[row]));
+    }
+}
+
+__global__ __launch_bounds__(256) void sell_width_kernel(int nrows, const int *__restrict__ rowptr,
+                                                         int *__restrict__ width64) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    int len = (row < nrows) ? rowptr[row + 1] - rowptr[row] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_xor(len, o, 64));
+    const long slice = row >> 6;
+    if ((threadIdx.x & 63) == 0 && slice * 64 < nrows) width64[slice] = len * 64;
+}
+
+__global__ __launch_bounds__(256) void sell_fill_kernel(int nrows, const int *__restrict__ rowptr,
+                                                        const int *__restrict__ col,
+                                                        const double *__restrict__ val,
+                                                        const int *__restrict__ sptr,
+                                                        int *__restrict__ scol, double *__restrict__ sval) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    const int slice = (int)(row >> 6), lane = threadIdx.x & 63;
+    if ((long)slice * 64 >= nrows) return;
+    const int beg = sptr[slice], w = (sptr[slice + 1] - beg) >> 6;
+    int rb = 0, re = 0;
+    if (row < nrows) { rb = rowptr[row]; re = rowptr[row + 1]; }
+    const int pad = (row < nrows) ? (int)row : nrows - 1;
+    for (int k = 0; k < w; ++k) {
+        const bool in = rb + k < re;
+        scol[beg + 64 * k + lane] = in ? col[rb + k] : pad;
+        sval[beg + 64 * k + lane] = in ? val[rb + k] : 0.0;
+    }
+}
+
+void exclusive_scan_int(hipStream_t s, int n, const int *in, int *out);  // mis.hip
+
+void build_sell(hipStream_t s, DCsr &A) {
+    A.has_sell = false;
+    if (A.nrows == 0) return;
+    A.nslices = div_up(A.nrows, 64);
+    DBuf<int> w64((size_t)A.nslices);
+    const int grid = div_up((long)A.nslices * 64, 256);
+    hipLaunchKernelGGL(sell_width_kernel, dim3(grid), dim3(256), 0, s, A.nrows, A.rowptr.p, w64.p);
+    A.sell_ptr.alloc((size_t)A.nslices + 1);
+    exclusive_scan_int(s, A.nslices, w64.p, A.sell_ptr.p);
+    int total = 0;
+    SA_HIP_CHECK(hipMemcpyAsync(&total, A.sell_ptr.p + A.nslices, sizeof(int), hipMemcpyDeviceToHost, s));
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    SA_REQUIRE(total >= 0, "SELL storage exceeds 32-bit indexing");
+    A.sell_size = total;
+    A.sell_col.alloc((size_t)total + 64);
+    A.sell_val.alloc((size_t)total + 64);
+    hipLaunchKernelGGL(sell_fill_kernel, dim3(grid), dim3(256), 0, s, A.nrows, A.rowptr.p, A.col.p,
+                       A.val.p, A.sell_ptr.p, A.sell_col.p, A.sell_val.p);
+    SA_HIP_CHECK(hipGetLastError());
+    A.has_sell = true;
+}
+
 template <int MODE>
 static void launch_spmv(hipStream_t s, const DCsr &A, const double *x, double *y, const double *b,
                         const double *dinv, double scale) {
     if (A.nrows == 0) return;
+    if (A.has_sell) {
+        const int grid = div_up((long)A.nslices * 64, 256);
+        hipLaunchKernelGGL((sell_spmv_kernel<MODE>), dim3(grid), dim3(256), 0, s, A.nrows, A.sell_ptr.p,
+                           A.sell_col.p, A.sell_val.p, x, y, b, dinv, scale);
+        SA_HIP_CHECK(hipGetLastError());
+        return;
+    }
     const int L = A.lanes_per_row;
     const long threads = (long)A.nrows * L;
     const int grid = div_up(threads, 256);
