@@ -162,7 +162,7 @@ __global__ __launch_bounds__(SY_NT) void sbr_symm_kernel(int k0, const int *__re
                                                          const int64_t *__restrict__ goff,
                                                          double *__restrict__ Gbuf) {
     __shared__ __align__(16) double Vs[SY_KC * SB];  // 32 KiB, reused for the K-split reduction
-    __shared__ double xs[64 * SB], vs2[64 * SB];
+    __shared__ double xs[64 * SB], vs2[64 * SB];     // [j][rr] layouts: conflict-free
     const int b = blockIdx.y;
     const int n = ns[b];
     const int np = n - k0 - SB;
@@ -181,15 +181,25 @@ __global__ __launch_bounds__(SY_NT) void sbr_symm_kernel(int k0, const int *__re
     for (int c0 = 0; c0 < np; c0 += SY_KC) {
         const int kc = min(SY_KC, np - c0);
         __syncthreads();
+        // Vs[cc][j]: consecutive threads write consecutive LDS words (j fastest)
         for (int idx = tid; idx < kc * SB; idx += SY_NT) {
-            const int cc = idx % kc, j = idx / kc;  // consecutive threads -> consecutive rows
-            Vs[cc * SB + j] = vmask(A, n, k0, c0 + cc, j);
+            const int j = idx & (SB - 1), cc = idx >> 4;
+            Vs[idx] = vmask(A, n, k0, c0 + cc, j);
         }
         __syncthreads();
         if (row < np) {
             const int cb = g * (SY_KC / 4), ce = min(cb + SY_KC / 4, kc);
             const double *Ar = A22 + (size_t)c0 * n + row;
-            for (int cc = cb; cc < ce; ++cc) {
+            int cc = cb;
+            for (; cc + 4 <= ce; cc += 4) {   // four loads in flight per lane
+                const double a0 = Ar[(size_t)cc * n], a1 = Ar[(size_t)(cc + 1) * n];
+                const double a2 = Ar[(size_t)(cc + 2) * n], a3 = Ar[(size_t)(cc + 3) * n];
+                const double *vr = Vs + cc * SB;
+#pragma unroll
+                for (int j = 0; j < SB; ++j)
+                    acc[j] = fma(a3, vr[3 * SB + j], fma(a2, vr[2 * SB + j], fma(a1, vr[SB + j], fma(a0, vr[j], acc[j]))));
+            }
+            for (; cc < ce; ++cc) {
                 const double a = Ar[(size_t)cc * n];
                 const double *vr = Vs + cc * SB;
 #pragma unroll
@@ -198,28 +208,27 @@ __global__ __launch_bounds__(SY_NT) void sbr_symm_kernel(int k0, const int *__re
         }
     }
     __syncthreads();
-    // reduce the 4 K-splits
-    double *red = Vs;  // [4][64][SB]
+    // reduce the 4 K-splits: red[g][j][r]
+    double *red = Vs;
 #pragma unroll
-    for (int j = 0; j < SB; ++j) red[(g * 64 + r) * SB + j] = acc[j];
+    for (int j = 0; j < SB; ++j) red[(g * SB + j) * 64 + r] = acc[j];
     __syncthreads();
     for (int idx = tid; idx < 64 * SB; idx += SY_NT) {
         const int rr = idx & 63, j = idx >> 6;
+        double s = 0.0;
         if (r0 + rr < np) {
-            const double s = (red[(0 * 64 + rr) * SB + j] + red[(1 * 64 + rr) * SB + j]) +
-                             (red[(2 * 64 + rr) * SB + j] + red[(3 * 64 + rr) * SB + j]);
+            s = (red[(0 * SB + j) * 64 + rr] + red[(1 * SB + j) * 64 + rr]) +
+                (red[(2 * SB + j) * 64 + rr] + red[(3 * SB + j) * 64 + rr]);
             X[(size_t)j * n + r0 + rr] = s;
-            xs[rr * SB + j] = s;
-        } else {
-            xs[rr * SB + j] = 0.0;
         }
-        vs2[rr * SB + j] = (r0 + rr < np) ? vmask(A, n, k0, r0 + rr, j) : 0.0;
+        xs[j * 64 + rr] = s;
+        vs2[j * 64 + rr] = (r0 + rr < np) ? vmask(A, n, k0, r0 + rr, j) : 0.0;
     }
     __syncthreads();
     {   // partial G(a, c) = sum_rr V(r0+rr, a) X(r0+rr, c), reduced over row blocks by sbr_z_kernel
         const int a = tid >> 4, c = tid & 15;
         double s = 0.0;
-        for (int rr = 0; rr < 64; ++rr) s = fma(vs2[rr * SB + a], xs[rr * SB + c], s);
+        for (int rr = 0; rr < 64; ++rr) s = fma(vs2[a * 64 + rr], xs[c * 64 + rr], s);
         Gbuf[goff[b] + (size_t)blockIdx.x * (SB * SB) + tid] = s;
     }
 }
@@ -289,64 +298,82 @@ __global__ __launch_bounds__(SM_NT) void sbr_z_kernel(int k0, const int *__restr
     }
 }
 
-// A22 -= Z V^T + V Z^T on 64x64 tiles (both triangles: the mat-vec product reads full rows)
+// A22 -= Z V^T + V Z^T on 64x64 tiles (both triangles: the mat-vec product reads full rows).
+// One workgroup per (row tile, matrix): its Z/V row panel is staged once, then it walks the
+// column tiles of its block row.
 constexpr int S2_NT = 256;
 __global__ __launch_bounds__(S2_NT) void sbr_syr2k_kernel(int k0, const int *__restrict__ ns,
                                                           const int64_t *__restrict__ moff,
                                                           const int64_t *__restrict__ voff,
                                                           double *__restrict__ Wm,
-                                                          const double *__restrict__ Zbuf,
-                                                          int tiles_per_dim) {
+                                                          const double *__restrict__ Zbuf) {
     __shared__ __align__(16) double Zi[64 * SB], Vi[64 * SB], Zl[64 * SB], Vl[64 * SB];
     const int b = blockIdx.y;
     const int n = ns[b];
     const int np = n - k0 - SB;
     if (np < 2) return;
-    const int ti = blockIdx.x % tiles_per_dim, tl = blockIdx.x / tiles_per_dim;
-    const int i0 = ti * 64, l0 = tl * 64;
-    if (i0 >= np || l0 >= np) return;
+    const int i0 = blockIdx.x * 64;
+    if (i0 >= np) return;
     double *A = Wm + moff[b];
     double *A22 = A + (size_t)(k0 + SB) * n + (k0 + SB);
     const double *Z = Zbuf + voff[b] * SB;
     const int tid = threadIdx.x;
     for (int idx = tid; idx < 64 * SB; idx += S2_NT) {
         const int rr = idx & 63, c = idx >> 6;
-        const int ri = i0 + rr, rl = l0 + rr;
+        const int ri = i0 + rr;
         Zi[c * 64 + rr] = (ri < np) ? Z[(size_t)c * n + ri] : 0.0;
         Vi[c * 64 + rr] = (ri < np) ? vmask(A, n, k0, ri, c) : 0.0;
-        Zl[c * 64 + rr] = (rl < np) ? Z[(size_t)c * n + rl] : 0.0;
-        Vl[c * 64 + rr] = (rl < np) ? vmask(A, n, k0, rl, c) : 0.0;
     }
-    __syncthreads();
     const int tr = tid & 15, tc = tid >> 4;  // 4 rows (tr + 16 a), 4 cols (tc + 16 q)
-    double acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[a][q] = 0.0;
-#pragma unroll 4
-    for (int c = 0; c < SB; ++c) {
-        double zi[4], vi[4], zl[4], vl[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            zi[a] = Zi[c * 64 + tr + 16 * a];
-            vi[a] = Vi[c * 64 + tr + 16 * a];
-            zl[a] = Zl[c * 64 + tc + 16 * a];
-            vl[a] = Vl[c * 64 + tc + 16 * a];
+    for (int l0 = 0; l0 < np; l0 += 64) {
+        __syncthreads();
+        for (int idx = tid; idx < 64 * SB; idx += S2_NT) {
+            const int rr = idx & 63, c = idx >> 6;
+            const int rl = l0 + rr;
+            Zl[c * 64 + rr] = (rl < np) ? Z[(size_t)c * n + rl] : 0.0;
+            Vl[c * 64 + rr] = (rl < np) ? vmask(A, n, k0, rl, c) : 0.0;
         }
+        // the tile itself (independent of the staging: issue the loads before the barrier)
+        double t[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int l = l0 + tc + 16 * q;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int i = i0 + tr + 16 * a;
+                t[a][q] = (i < np && l < np) ? A22[(size_t)l * n + i] : 0.0;
+            }
+        }
+        __syncthreads();
+        double acc[4][4];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[a][q] = fma(zi[a], vl[q], fma(vi[a], zl[q], acc[a][q]));
-    }
+            for (int q = 0; q < 4; ++q) acc[a][q] = 0.0;
+#pragma unroll 4
+        for (int c = 0; c < SB; ++c) {
+            double zi[4], vi[4], zl[4], vl[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int l = l0 + tc + 16 * q;
-        if (l >= np) continue;
+            for (int a = 0; a < 4; ++a) {
+                zi[a] = Zi[c * 64 + tr + 16 * a];
+                vi[a] = Vi[c * 64 + tr + 16 * a];
+                zl[a] = Zl[c * 64 + tc + 16 * a];
+                vl[a] = Vl[c * 64 + tc + 16 * a];
+            }
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int i = i0 + tr + 16 * a;
-            if (i < np) A22[(size_t)l * n + i] -= acc[a][q];
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[a][q] = fma(zi[a], vl[q], fma(vi[a], zl[q], acc[a][q]));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int l = l0 + tc + 16 * q;
+            if (l >= np) continue;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int i = i0 + tr + 16 * a;
+                if (i < np) A22[(size_t)l * n + i] = t[a][q] - acc[a][q];
+            }
         }
     }
 }
@@ -698,10 +725,22 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b) {
         bytes += 8.0 * (double)n * n;
     }
     // ---- stage 1 ----
-    profiler().begin(s);
     const int nmax = b.max_n;
+    const bool prof = profiler().enabled;
+    double sbytes = 0.0, ubytes = 0.0;   // algorithmic bytes of the product / update kernels
+    if (prof) {
+        for (int n : b.h_n)
+            for (int k0 = 0; n - k0 - SB >= 2; k0 += SB) {
+                const double np = n - k0 - SB;
+                sbytes += 8.0 * np * np;
+                ubytes += 16.0 * np * np;
+            }
+    }
+    if (!prof) profiler().begin(s);
+    bool first = true;
     for (int k0 = 0; nmax - k0 - SB >= 2; k0 += SB) {
         const int npmax = nmax - k0 - SB;
+        if (prof) profiler().begin(s);
         if ((size_t)npmax * SB * sizeof(double) <= 96 * 1024)
             hipLaunchKernelGGL((sbr_qr_kernel<256, true>), dim3(b.count), dim3(256),
                                (size_t)npmax * SB * sizeof(double), s, k0, b.n.p, b.moff.p, b.voff.p,
@@ -709,17 +748,21 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b) {
         else
             hipLaunchKernelGGL((sbr_qr_kernel<1024, false>), dim3(b.count), dim3(1024), 0, s, k0,
                                b.n.p, b.moff.p, b.voff.p, b.W.p, b.Tfac.p);
+        if (prof) { profiler().end(s, "eig_sbr_qr", 0.0, 0.0); profiler().begin(s); }
         hipLaunchKernelGGL(sbr_symm_kernel, dim3(div_up(npmax, 64), b.count), dim3(SY_NT), 0, s, k0,
                            b.n.p, b.moff.p, b.voff.p, b.W.p, b.Xbuf.p, b.goff.p, b.Gbuf.p);
+        if (prof) { profiler().end(s, "eig_sbr_symm", first ? sbytes : 0.0, 0.0); profiler().begin(s); }
         hipLaunchKernelGGL(sbr_z_kernel, dim3(div_up(npmax, SM_NT), b.count), dim3(SM_NT), 0, s, k0,
                            b.n.p, b.moff.p, b.voff.p, b.W.p, b.Tfac.p, b.Xbuf.p, b.goff.p, b.Gbuf.p,
                            b.Zbuf.p);
-        const int tpd = div_up(npmax, 64);
-        hipLaunchKernelGGL(sbr_syr2k_kernel, dim3(tpd * tpd, b.count), dim3(S2_NT), 0, s, k0,
-                           b.n.p, b.moff.p, b.voff.p, b.W.p, b.Zbuf.p, tpd);
+        if (prof) { profiler().end(s, "eig_sbr_z", 0.0, 0.0); profiler().begin(s); }
+        hipLaunchKernelGGL(sbr_syr2k_kernel, dim3(div_up(npmax, 64), b.count), dim3(S2_NT), 0, s, k0,
+                           b.n.p, b.moff.p, b.voff.p, b.W.p, b.Zbuf.p);
+        if (prof) profiler().end(s, "eig_sbr_syr2k", first ? ubytes : 0.0, 0.0);
+        first = false;
     }
     SA_HIP_CHECK(hipGetLastError());
-    profiler().end(s, "eig_band_reduce", bytes, flops);
+    if (!prof) profiler().end(s, "eig_band_reduce", bytes, flops);
     // ---- stage 2 ----
     const size_t fixed = sizeof(double) * (CH_NW * HAND) + sizeof(int) * ((size_t)nmax + 4);
     const size_t band_bytes = sizeof(double) * (size_t)nmax * LDB;
