@@ -39,7 +39,7 @@ typedef struct saamge_amd_params {
     int coarse_solver;                        /* 0 auto, 2 inner PCG on the coarsest operator */
     double coarse_rtol;                       /* inner PCG tolerance on (B r, r), un-squared */
     int coarse_max_iter;
-    long long workspace_bytes;                /* dense AE matrices are processed in chunks of this size */
+    long long workspace_bytes;                /* dense AE matrices are processed in chunks of this size (default 32 GiB) */
     int keep_debug;                           /* keep eigenpairs / singular values for inspection */
 } saamge_amd_params;
 

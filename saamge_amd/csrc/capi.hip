@@ -43,7 +43,7 @@ void saamge_amd_params_default(saamge_amd_params *p) {
     p->coarse_solver = 0;
     p->coarse_rtol = 1e-14;
     p->coarse_max_iter = 2000;
-    p->workspace_bytes = (long long)8 << 30;
+    p->workspace_bytes = (long long)32 << 30;
     p->keep_debug = 0;
 }
 
@@ -269,7 +269,7 @@ int saamge_amd_get_mis_svd(const saamge_amd_hierarchy *h, int level, long long *
         if (L.mis_s_off[nm]) SA_HIP_CHECK(hipMemcpyAsync(sig, L.mis_sig.p, 8 * (size_t)L.mis_s_off[nm], hipMemcpyDeviceToHost, s));
     }
     if (U) {
-        std::vector<double> all = L.mis_U.to_host(s);
+        auto all = L.mis_U.to_host(s);
         size_t o = 0;
         for (int m = 0; m < nm; ++m) {
             const size_t cnt = (size_t)L.mis_k[m] * L.rel.mis_to_dof.row_size(m);
@@ -341,7 +341,8 @@ int saamge_amd_lower_eigens_batched(int count, const int *n, const double *A, co
     dx.from_host(xoff, s);
     DBuf<double> ev((size_t)eoff[count] + 1), xv((size_t)xoff[count] + 1);
     eig_vectors(s, b, de.p, dx.p, ev.p, xv.p);
-    std::vector<double> hev = ev.to_host(s), hxv = xv.to_host(s);
+    auto hev = ev.to_host(s);
+    auto hxv = xv.to_host(s);
     for (int i = 0; i < count; ++i) {
         std::copy(hev.begin() + eoff[i], hev.begin() + eoff[i + 1], evals + b.h_voff[i]);
         std::copy(hxv.begin() + xoff[i], hxv.begin() + xoff[i + 1], evecs + b.h_moff[i]);

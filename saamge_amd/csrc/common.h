@@ -34,6 +34,30 @@ struct Error : std::runtime_error {
                                              std::to_string(__LINE__) + " " + (msg));   \
     } while (0)
 
+// ---- pinned host memory: pooled allocator for the big host-side tables -----------------
+// Pageable <-> device copies run at a few GB/s; page-locked ones at PCIe speed.  hipHostMalloc
+// itself is slow (it pins pages), so freed blocks are kept in a size-class pool and reused
+// by the next level / hierarchy.
+void *pinned_alloc(size_t bytes);
+void pinned_free(void *p, size_t bytes);
+void pinned_pool_release();
+
+template <class T>
+struct PinnedAlloc {
+    typedef T value_type;
+    PinnedAlloc() {}
+    template <class U>
+    PinnedAlloc(const PinnedAlloc<U> &) {}
+    T *allocate(size_t n) { return (T *)pinned_alloc(n * sizeof(T)); }
+    void deallocate(T *p, size_t n) { pinned_free((void *)p, n * sizeof(T)); }
+    template <class U>
+    bool operator==(const PinnedAlloc<U> &) const { return true; }
+    template <class U>
+    bool operator!=(const PinnedAlloc<U> &) const { return false; }
+};
+template <class T>
+using hvec = std::vector<T, PinnedAlloc<T>>;
+
 inline bool is_device_ptr(const void *p) {
     if (!p) return false;
     hipPointerAttribute_t a;
@@ -83,15 +107,16 @@ struct DBuf {
         if (!n) return;
         SA_HIP_CHECK(hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyDefault, s));
     }
-    void from_host(const std::vector<T> &v, hipStream_t s = 0) {
+    template <class V>
+    void from_host(const V &v, hipStream_t s = 0) {
         alloc(v.size());
         if (n) {
             SA_HIP_CHECK(hipMemcpyAsync(p, v.data(), n * sizeof(T), hipMemcpyHostToDevice, s));
             SA_HIP_CHECK(hipStreamSynchronize(s));  // v may be a temporary
         }
     }
-    std::vector<T> to_host(hipStream_t s = 0) const {
-        std::vector<T> v(n);
+    hvec<T> to_host(hipStream_t s = 0) const {
+        hvec<T> v(n);
         if (n) {
             SA_HIP_CHECK(hipMemcpyAsync(v.data(), p, n * sizeof(T), hipMemcpyDeviceToHost, s));
             SA_HIP_CHECK(hipStreamSynchronize(s));
@@ -117,8 +142,8 @@ inline void import_array(DBuf<T> &dst, const T *src, size_t n, hipStream_t s) {
 
 // Fetch an input array to the host (for host-side topology).
 template <class T>
-inline std::vector<T> fetch_host(const T *src, size_t n, hipStream_t s) {
-    std::vector<T> v(n);
+inline hvec<T> fetch_host(const T *src, size_t n, hipStream_t s) {
+    hvec<T> v(n);
     if (n) {
         SA_HIP_CHECK(hipMemcpyAsync(v.data(), src, n * sizeof(T), hipMemcpyDefault, s));
         SA_HIP_CHECK(hipStreamSynchronize(s));

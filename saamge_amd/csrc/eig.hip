@@ -750,7 +750,7 @@ void eig_count(hipStream_t s, EigBatch &b, double vl, double vu) {
                        b.e.p, vl, vu, b.m.p, b.j0.p);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "eig_count", 0.0, 0.0);
-    b.h_m = b.m.to_host(s);
+    { auto t_ = b.m.to_host(s); b.h_m.assign(t_.begin(), t_.end()); }
 }
 
 void eig_vectors(hipStream_t s, EigBatch &b, const int64_t *eoff, const int64_t *xoff,

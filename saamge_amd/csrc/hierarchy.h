@@ -25,7 +25,7 @@ struct Params {                 // MultilevelParameters (amg/inc/ml.hpp:59-114)
     int coarse_solver = 0;      // 0 auto, 1 dense Cholesky, 2 inner PCG
     double coarse_rtol = 1e-14; // inner PCG: relative (B r, r) reduction, un-squared
     int coarse_max_iter = 2000;
-    size_t workspace_bytes = (size_t)8 << 30;  // dense AE matrices are processed in chunks of this size
+    size_t workspace_bytes = (size_t)32 << 30;  // dense AE matrices are processed in chunks of this size
     int keep_debug = 0;         // keep per-AE eigenpairs / per-MIS data for parity tests
 };
 

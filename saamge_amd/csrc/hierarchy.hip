@@ -70,7 +70,7 @@ __global__ void fill_kernel(long n, double *p, double v) {
 // ---------------------------------------------------------------------------------------
 // one coarsening: tg_init_data + tg_build_hierarchy + tg_update_coarse_operator
 // ---------------------------------------------------------------------------------------
-static void build_level(Hierarchy &H, int lev, Table &&e2d, const std::vector<int> &part, int nparts,
+static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &part, int nparts,
                         const signed char *bdr_host) {
     Level &L = *H.levels[lev];
     hipStream_t s = H.stream;
@@ -218,8 +218,8 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const std::vector<in
         io.ncols = d_ncols.p;
         io.avoid_ess = P.avoid_ess_bdr_dofs;
         mis_svd(s, L.drel, nm, max_ctot, io);
-        L.mis_k = L.d_mis_k.to_host(s);
-        L.mis_ncols = d_ncols.to_host(s);
+        { auto t_ = L.d_mis_k.to_host(s); L.mis_k.assign(t_.begin(), t_.end()); }
+        { auto t_ = d_ncols.to_host(s); L.mis_ncols.assign(t_.begin(), t_.end()); }
     }
     tm.lap("MIS gather + SVD", lev);
     L.mis_coloff.assign((size_t)nm + 1, 0);
@@ -256,8 +256,8 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
     Table e2d;
     e2d.ncols = L.mis_coloff.back();
     e2d.I.assign((size_t)nparts + 1, 0);
-    std::vector<int> p_rowptr = L.P.rowptr.to_host(s);
-    std::vector<double> p_val = L.P.val.to_host(s);
+    auto p_rowptr = L.P.rowptr.to_host(s);
+    auto p_val = L.P.val.to_host(s);
     // colpos: for every (AE, MIS) incidence (aligned with AE_to_mis.J) the position of each of
     // the MIS's coarse dofs in the coarse element's dof list
     std::vector<int> colpos_ptr(rel.AE_to_mis.J.size() + 1, 0);
@@ -501,7 +501,7 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
     // level 0 inputs
     Level &L0 = *H.levels[0];
     {
-        std::vector<int> last = fetch_host(Arow + n, 1, s);
+        auto last = fetch_host(Arow + n, 1, s);
         const int64_t nnz = last[0];
         L0.A.nrows = L0.A.ncols = n;
         L0.A.nnz = nnz;
@@ -518,18 +518,18 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
     }
     Table e2d;
     {
-        std::vector<int> J = fetch_host(elem_to_dof, (size_t)NE * nde, s);
+        auto J = fetch_host(elem_to_dof, (size_t)NE * nde, s);
         e2d.J = std::move(J);
         e2d.I.resize((size_t)NE + 1);
         for (int e = 0; e <= NE; ++e) e2d.I[e] = e * nde;
         e2d.ncols = n;
     }
-    std::vector<signed char> bdr_h;
+    hvec<signed char> bdr_h;
     if (bdr) bdr_h = fetch_host(bdr, (size_t)n, s);
     tm0.lap("inputs fetched/imported", 0);
     int n_elem = NE;
     for (int lev = 0; lev < p.num_coarsenings; ++lev) {
-        std::vector<int> part = fetch_host(partitions[lev], (size_t)n_elem, s);
+        auto part = fetch_host(partitions[lev], (size_t)n_elem, s);
         build_level(H, lev, std::move(e2d), part, nparts[lev], (lev == 0 && bdr) ? bdr_h.data() : nullptr);
         Level &L = *H.levels[lev];
         if (lev + 1 < p.num_coarsenings) {

@@ -469,7 +469,7 @@ void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, cons
     hipLaunchKernelGGL(rap_symbolic_kernel, dim3(nm), dim3(RAP_NT), 0, s, 0, rel.mis2d_I.p,
                        rel.mis2d_J.p, A.rowptr.p, A.col.p, rel.mises.p, d_k, cnt.p, nullptr, nullptr, err.p);
     SA_HIP_CHECK(hipGetLastError());
-    std::vector<int> h_cnt = cnt.to_host(s);
+    auto h_cnt = cnt.to_host(s);
     SA_REQUIRE(err.to_host(s)[0] == 0, "RAP: MIS neighbour table overflow");
     std::vector<int> h_nbr_ptr((size_t)nm + 1, 0);
     for (int m = 0; m < nm; ++m) h_nbr_ptr[m + 1] = h_nbr_ptr[m] + h_cnt[m];
@@ -478,7 +478,7 @@ void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, cons
     hipLaunchKernelGGL(rap_symbolic_kernel, dim3(nm), dim3(RAP_NT), 0, s, 1, rel.mis2d_I.p,
                        rel.mis2d_J.p, A.rowptr.p, A.col.p, rel.mises.p, d_k, cnt.p, nbr_ptr.p, nbr.p, err.p);
     SA_HIP_CHECK(hipGetLastError());
-    std::vector<int> h_nbr = nbr.to_host(s);
+    auto h_nbr = nbr.to_host(s);
     // row pointers of Ac and LDS sizing
     std::vector<int> crow((size_t)nc + 1, 0);
     int64_t nnz = 0;

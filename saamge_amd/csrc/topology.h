@@ -7,7 +7,7 @@
 namespace saamge_amd {
 
 struct Table {  // mfem::Table: CSR of ints
-    std::vector<int> I, J;
+    hvec<int> I, J;
     int ncols = 0;
     int nrows() const { return (int)I.size() - 1; }
     int row_size(int i) const { return I[i + 1] - I[i]; }
@@ -24,22 +24,22 @@ struct Relations {
     int ND = 0, NE = 0, nparts = 0, num_mises = 0;
     Table elem_to_dof, dof_to_elem, AE_to_elem, AE_to_dof, dof_to_AE;
     Table mis_to_dof, mis_to_AE, AE_to_mis;
-    std::vector<int> partitioning;   // elem -> AE
-    std::vector<int> dof_id_inAE;    // aligned with dof_to_AE.J
-    std::vector<int> elem_ldof;      // aligned with elem_to_dof.J: index of that dof in the element's AE
-    std::vector<int> mises;          // dof -> MIS
-    std::vector<int> dof_row_in_mis; // dof -> position inside its MIS
-    std::vector<signed char> agg_flags;
+    hvec<int> partitioning;   // elem -> AE
+    hvec<int> dof_id_inAE;    // aligned with dof_to_AE.J
+    hvec<int> elem_ldof;      // aligned with elem_to_dof.J: index of that dof in the element's AE
+    hvec<int> mises;          // dof -> MIS
+    hvec<int> dof_row_in_mis; // dof -> position inside its MIS
+    hvec<signed char> agg_flags;
     // (MIS, AE) incidence pairs, MIS-major (== mis_to_AE entries): local AE indices of the
     // MIS's dofs, used to restrict AE eigenvectors to the MIS and to build P_loc.
-    std::vector<int64_t> pair_loc_off;  // [npairs+1] offsets into pair_loc
-    std::vector<int> pair_loc;          // AE-local index of each MIS dof
-    std::vector<int> ae_pair;           // aligned with AE_to_mis.J: pair id of (AE, mis)
+    hvec<int64_t> pair_loc_off;  // [npairs+1] offsets into pair_loc
+    hvec<int> pair_loc;          // AE-local index of each MIS dof
+    hvec<int> ae_pair;           // aligned with AE_to_mis.J: pair id of (AE, mis)
 };
 
 // agg_create_partitioning_tables + agg_produce_mises + agg_construct_agg_flags
 // (amg/src/aggregates.cpp:1357-1443, :501-653, :198-216).  bdr may be null (coarse levels).
-void build_relations(Relations &r, Table &&elem_to_dof, const std::vector<int> &partitioning,
+void build_relations(Relations &r, Table &&elem_to_dof, const hvec<int> &partitioning,
                      int nparts, int ND, const signed char *bdr);
 
 struct DevRelations {

@@ -8,12 +8,65 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <functional>
 #include <thread>
 #include <unordered_map>
 
+#include <map>
+#include <mutex>
+
 namespace saamge_amd {
+
+// ---------------------------------------------------------------------------------------
+// pinned host memory pool
+// ---------------------------------------------------------------------------------------
+namespace {
+std::mutex g_pin_mu;
+std::multimap<size_t, void *> g_pin_free;
+constexpr size_t PIN_MIN = 256 * 1024;
+size_t pin_class(size_t bytes) {
+    size_t c = PIN_MIN;
+    while (c < bytes) c <<= 1;
+    return c;
+}
+}  // namespace
+
+void *pinned_alloc(size_t bytes) {
+    if (bytes == 0) return nullptr;
+    if (bytes < PIN_MIN) return std::malloc(bytes);
+    const size_t c = pin_class(bytes);
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        auto it = g_pin_free.find(c);
+        if (it != g_pin_free.end()) {
+            void *p = it->second;
+            g_pin_free.erase(it);
+            return p;
+        }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, c, hipHostMallocDefault) != hipSuccess || !p) {
+        (void)hipGetLastError();
+        throw std::bad_alloc();
+    }
+    return p;
+}
+void pinned_free(void *p, size_t bytes) {
+    if (!p) return;
+    if (bytes < PIN_MIN) {
+        std::free(p);
+        return;
+    }
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pin_free.insert(std::make_pair(pin_class(bytes), p));
+}
+void pinned_pool_release() {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (auto &kv : g_pin_free) (void)hipHostFree(kv.second);
+    g_pin_free.clear();
+}
 
 // ---------------------------------------------------------------------------------------
 // tiny fork-join helper
@@ -94,7 +147,7 @@ Table table_mult(const Table &A, const Table &B) {
 // Stable parallel counting sort of items 0..n-1 by key(item) in [0, nkeys): returns the CSR
 // (I, J) with J listing the items of each key in ascending item order (== mfem::Transpose).
 static void counting_sort_rows(int64_t n, int nkeys, const std::function<int(int64_t)> &key,
-                               std::vector<int> &I, std::vector<int> &J) {
+                               hvec<int> &I, hvec<int> &J) {
     int T = num_threads();
     if (n < 1 << 16 || (int64_t)nkeys * T > ((int64_t)1 << 27)) T = 1;
     I.assign((size_t)nkeys + 1, 0);
@@ -144,8 +197,17 @@ static inline uint64_t hash_row(const int *r, int n) {
     return h;
 }
 
-void build_relations(Relations &r, Table &&elem_to_dof, const std::vector<int> &partitioning,
+void build_relations(Relations &r, Table &&elem_to_dof, const hvec<int> &partitioning,
                      int nparts, int ND, const signed char *bdr) {
+    const bool timing = std::getenv("SAAMGE_AMD_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "TIMING:     topology %-22s %8.3f ms\n", what,
+                     std::chrono::duration<double, std::milli>(t - t_last).count());
+        t_last = t;
+    };
     r.ND = ND;
     r.nparts = nparts;
     r.elem_to_dof = std::move(elem_to_dof);
@@ -167,11 +229,13 @@ void build_relations(Relations &r, Table &&elem_to_dof, const std::vector<int> &
         });
         SA_REQUIRE(!bad, "elem_to_dof entry out of range");
     }
+    lap("checks");
     // AE_to_elem (agg_construct_tables_from_arr): elements of each AE, ascending
     r.AE_to_elem.ncols = r.NE;
     counting_sort_rows(r.NE, nparts, [&](int64_t e) { return partitioning[e]; }, r.AE_to_elem.I,
                        r.AE_to_elem.J);
     for (int p = 0; p < nparts; ++p) SA_REQUIRE(r.AE_to_elem.row_size(p) > 0, "empty agglomerate");
+    lap("AE_to_elem");
     // AE_to_dof = AE_to_elem x elem_to_dof in first-encounter order, one hash set per thread
     r.AE_to_dof.ncols = ND;
     r.AE_to_dof.I.assign((size_t)nparts + 1, 0);
@@ -208,6 +272,7 @@ void build_relations(Relations &r, Table &&elem_to_dof, const std::vector<int> &
     }, 8);
     rows.clear();
     rows.shrink_to_fit();
+    lap("AE_to_dof");
     // dof_to_AE = transpose, rows ascending in AE: atomic counts + cursors, then sort the short rows
     const int64_t nconn = (int64_t)r.AE_to_dof.J.size();
     r.dof_to_AE.ncols = nparts;
@@ -237,6 +302,7 @@ void build_relations(Relations &r, Table &&elem_to_dof, const std::vector<int> &
                     std::sort(r.dof_to_AE.J.begin() + r.dof_to_AE.I[i], r.dof_to_AE.J.begin() + r.dof_to_AE.I[i + 1]);
         });
     }
+    lap("dof_to_AE");
     // dof_id_inAE (agg_build_glob_to_AE_id_map, :1202-1244)
     r.dof_id_inAE.assign((size_t)nconn, -1);
     parallel_for(nparts, [&](int64_t pb, int64_t pe, int) {
@@ -249,6 +315,7 @@ void build_relations(Relations &r, Table &&elem_to_dof, const std::vector<int> &
                 r.dof_id_inAE[(size_t)r.dof_to_AE.I[d] + t] = k - r.AE_to_dof.I[p];
             }
     }, 8);
+    lap("dof_id_inAE");
     // ---- MISes: groups of dofs with identical AE lists, numbered by first appearance ----
     // group representative = smallest dof of the group
     std::vector<int> rep_of((size_t)ND, -1);        // dof -> representative dof
@@ -268,33 +335,41 @@ void build_relations(Relations &r, Table &&elem_to_dof, const std::vector<int> &
         for (int t = 0; t < T; ++t)
             for (int p = 0; p < nparts; ++p) single[p] = std::min(single[p], mins[t][p]);
         mins.clear();
-        // multi-AE dofs: hash of the AE list, grouped in T hash buckets built concurrently
+        // multi-AE dofs: hash of the AE list; dofs are bucketed by hash (stable counting sort, so
+        // each bucket lists its dofs in ascending order) and every bucket is grouped by one thread
         std::vector<uint64_t> hv((size_t)ND, 0);
         parallel_for(ND, [&](int64_t b, int64_t e, int) {
             for (int64_t i = b; i < e; ++i) {
                 const int rs = r.dof_to_AE.row_size((int)i);
                 if (rs > 1) hv[(size_t)i] = hash_row(r.dof_to_AE.row((int)i), rs);
+                else rep_of[(size_t)i] = single[r.dof_to_AE.row((int)i)[0]];
             }
         });
+        const int NBK = 4 * T;
+        hvec<int> bk_I, bk_J;
+        counting_sort_rows(ND, NBK + 1, [&](int64_t i) {
+            return r.dof_to_AE.row_size((int)i) > 1 ? (int)((hv[(size_t)i] >> 40) % (uint64_t)NBK) : NBK;
+        }, bk_I, bk_J);
+        std::atomic<int> next(0);
         std::vector<std::thread> th;
         for (int t = 0; t < T; ++t)
-            th.emplace_back([&, t]() {
-                std::unordered_map<uint64_t, std::vector<int>> groups;  // hash -> representatives
-                for (int i = 0; i < ND; ++i) {
-                    const int rs = r.dof_to_AE.row_size(i);
-                    if (rs == 1) {
-                        if (t == 0) rep_of[i] = single[r.dof_to_AE.row(i)[0]];
-                        continue;
+            th.emplace_back([&]() {
+                for (;;) {
+                    const int bk = next.fetch_add(1);
+                    if (bk >= NBK) break;
+                    std::unordered_map<uint64_t, std::vector<int>> groups;  // hash -> representatives
+                    groups.reserve((size_t)(bk_I[bk + 1] - bk_I[bk]) / 4 + 16);
+                    for (int q = bk_I[bk]; q < bk_I[bk + 1]; ++q) {
+                        const int i = bk_J[q];
+                        const int rs = r.dof_to_AE.row_size(i);
+                        std::vector<int> &cands = groups[hv[(size_t)i]];
+                        const int *row = r.dof_to_AE.row(i);
+                        int rep = -1;
+                        for (int c : cands)
+                            if (r.dof_to_AE.row_size(c) == rs && std::equal(row, row + rs, r.dof_to_AE.row(c))) { rep = c; break; }
+                        if (rep < 0) { rep = i; cands.push_back(i); }   // ascending scan: first seen = smallest
+                        rep_of[(size_t)i] = rep;
                     }
-                    const uint64_t h = hv[(size_t)i];
-                    if ((int)((h >> 40) % (uint64_t)T) != t) continue;
-                    std::vector<int> &cands = groups[h];
-                    const int *row = r.dof_to_AE.row(i);
-                    int rep = -1;
-                    for (int c : cands)
-                        if (r.dof_to_AE.row_size(c) == rs && std::equal(row, row + rs, r.dof_to_AE.row(c))) { rep = c; break; }
-                    if (rep < 0) { rep = i; cands.push_back(i); }   // ascending scan: first seen = smallest
-                    rep_of[i] = rep;
                 }
             });
         for (auto &x : th) x.join();
@@ -312,6 +387,7 @@ void build_relations(Relations &r, Table &&elem_to_dof, const std::vector<int> &
     });
     mis_of_rep.clear();
     mis_of_rep.shrink_to_fit();
+    lap("MIS ids");
     // mis_to_dof: dofs of each MIS ascending
     r.mis_to_dof.ncols = ND;
     counting_sort_rows(ND, r.num_mises, [&](int64_t i) { return r.mises[(size_t)i]; }, r.mis_to_dof.I,
@@ -322,6 +398,7 @@ void build_relations(Relations &r, Table &&elem_to_dof, const std::vector<int> &
             for (int k = r.mis_to_dof.I[m]; k < r.mis_to_dof.I[m + 1]; ++k)
                 r.dof_row_in_mis[(size_t)r.mis_to_dof.J[k]] = k - r.mis_to_dof.I[m];
     }, 64);
+    lap("mis_to_dof");
     // mis_to_AE = mis_to_dof x dof_to_AE == the (ascending) AE list of any member dof
     r.mis_to_AE.ncols = nparts;
     r.mis_to_AE.I.assign((size_t)r.num_mises + 1, 0);
@@ -351,6 +428,7 @@ void build_relations(Relations &r, Table &&elem_to_dof, const std::vector<int> &
             for (int64_t k = b; k < e; ++k) r.AE_to_mis.J[(size_t)k] = mis_of_pair[(size_t)r.ae_pair[(size_t)k]];
         });
     }
+    lap("mis_to_AE/AE_to_mis");
     // flags (agg_construct_agg_flags, :198-216)
     r.agg_flags.assign((size_t)ND, 0);
     parallel_for(ND, [&](int64_t b, int64_t e, int) {
@@ -360,6 +438,7 @@ void build_relations(Relations &r, Table &&elem_to_dof, const std::vector<int> &
             r.agg_flags[(size_t)i] = f;
         }
     });
+    lap("flags");
     // (MIS, AE) pairs: AE-local indices of the MIS dofs
     r.pair_loc_off.assign((size_t)npairs + 1, 0);
     for (int m = 0; m < r.num_mises; ++m) {
@@ -383,6 +462,7 @@ void build_relations(Relations &r, Table &&elem_to_dof, const std::vector<int> &
             }
         }
     }, 64);
+    lap("pairs");
 }
 
 // ---------------------------------------------------------------------------------------
