@@ -52,11 +52,22 @@ __device__ inline double bsum(double v, double *red) {
     return r;
 }
 
+// XCD-aware work decode: workgroups are dealt round-robin over the 8 XCDs, so linear id
+// 8 (g T + t) + x  ->  matrix 8 g + x, tile t : all tiles of one matrix run back to back on ONE
+// XCD and share its L2 (panel V/Z, T factors).  grid = 8 * ceil(count / 8) * T.
+__device__ inline void xcd_decode(int T, int &matrix, int &tile) {
+    const int id = blockIdx.x;
+    const int x = id & 7, rest = id >> 3;
+    tile = rest % T;
+    matrix = 8 * (rest / T) + x;
+}
+
 // V(r, c) of the current panel, read in place from A (unit diagonal implicit, zero above)
+// Branch-free: the load is always in bounds (r < np, c < SB), so unrolled staging loops can
+// keep many of them in flight.
 __device__ inline double vmask(const double *A, int n, int k0, int r, int c) {
-    if (r < c) return 0.0;
-    if (r == c) return 1.0;
-    return A[(size_t)(k0 + c) * n + (k0 + SB + r)];
+    const double v = A[(size_t)(k0 + c) * n + (k0 + SB + r)];
+    return (r > c) ? v : ((r == c) ? 1.0 : 0.0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -160,14 +171,18 @@ __global__ __launch_bounds__(SY_NT) void sbr_symm_kernel(int k0, const int *__re
                                                          const double *__restrict__ Wm,
                                                          double *__restrict__ Xbuf,
                                                          const int64_t *__restrict__ goff,
-                                                         double *__restrict__ Gbuf) {
-    __shared__ __align__(16) double Vs[SY_KC * SB];  // 32 KiB, reused for the K-split reduction
-    __shared__ double xs[64 * SB], vs2[64 * SB];     // [j][rr] layouts: conflict-free
-    const int b = blockIdx.y;
+                                                         double *__restrict__ Gbuf, int count,
+                                                         int tiles) {
+    constexpr int SBP = SB + 1;                        // padded row: conflict-light transposed writes
+    __shared__ __align__(16) double Vs[SY_KC * SBP];  // 34 KiB, reused for the K-split reduction
+    __shared__ double xs[64 * SBP], vs2[64 * SBP];   // padded [rr][j]: conflict-free reads below
+    int b, blk;
+    xcd_decode(tiles, b, blk);
+    if (b >= count) return;
     const int n = ns[b];
     const int np = n - k0 - SB;
     if (np < 2) return;
-    const int r0 = blockIdx.x * 64;
+    const int r0 = blk * 64;
     if (r0 >= np) return;
     const double *A = Wm + moff[b];
     const double *A22 = A + (size_t)(k0 + SB) * n + (k0 + SB);
@@ -181,10 +196,17 @@ __global__ __launch_bounds__(SY_NT) void sbr_symm_kernel(int k0, const int *__re
     for (int c0 = 0; c0 < np; c0 += SY_KC) {
         const int kc = min(SY_KC, np - c0);
         __syncthreads();
-        // Vs[cc][j]: consecutive threads write consecutive LDS words (j fastest)
-        for (int idx = tid; idx < kc * SB; idx += SY_NT) {
-            const int j = idx & (SB - 1), cc = idx >> 4;
-            Vs[idx] = vmask(A, n, k0, c0 + cc, j);
+        // coalesced reads down the panel columns (cc fastest), padded transposed LDS image
+        {
+            double vreg[SB];
+            const int cc = tid;                         // SY_KC == SY_NT: one panel row per thread
+            const int rcl = min(c0 + cc, np - 1);       // clamp: keeps every load in bounds
+#pragma unroll
+            for (int j = 0; j < SB; ++j) vreg[j] = vmask(A, n, k0, rcl, j);
+            if (cc < kc) {
+#pragma unroll
+                for (int j = 0; j < SB; ++j) Vs[cc * SBP + j] = vreg[j];
+            }
         }
         __syncthreads();
         if (row < np) {
@@ -194,14 +216,14 @@ __global__ __launch_bounds__(SY_NT) void sbr_symm_kernel(int k0, const int *__re
             for (; cc + 4 <= ce; cc += 4) {   // four loads in flight per lane
                 const double a0 = Ar[(size_t)cc * n], a1 = Ar[(size_t)(cc + 1) * n];
                 const double a2 = Ar[(size_t)(cc + 2) * n], a3 = Ar[(size_t)(cc + 3) * n];
-                const double *vr = Vs + cc * SB;
+                const double *vr = Vs + cc * SBP;
 #pragma unroll
                 for (int j = 0; j < SB; ++j)
-                    acc[j] = fma(a3, vr[3 * SB + j], fma(a2, vr[2 * SB + j], fma(a1, vr[SB + j], fma(a0, vr[j], acc[j]))));
+                    acc[j] = fma(a3, vr[3 * SBP + j], fma(a2, vr[2 * SBP + j], fma(a1, vr[SBP + j], fma(a0, vr[j], acc[j]))));
             }
             for (; cc < ce; ++cc) {
                 const double a = Ar[(size_t)cc * n];
-                const double *vr = Vs + cc * SB;
+                const double *vr = Vs + cc * SBP;
 #pragma unroll
                 for (int j = 0; j < SB; ++j) acc[j] = fma(a, vr[j], acc[j]);
             }
@@ -221,15 +243,15 @@ __global__ __launch_bounds__(SY_NT) void sbr_symm_kernel(int k0, const int *__re
                 (red[(2 * SB + j) * 64 + rr] + red[(3 * SB + j) * 64 + rr]);
             X[(size_t)j * n + r0 + rr] = s;
         }
-        xs[j * 64 + rr] = s;
-        vs2[j * 64 + rr] = (r0 + rr < np) ? vmask(A, n, k0, r0 + rr, j) : 0.0;
+        xs[rr * SBP + j] = s;
+        vs2[rr * SBP + j] = (r0 + rr < np) ? vmask(A, n, k0, min(r0 + rr, np - 1), j) : 0.0;
     }
     __syncthreads();
     {   // partial G(a, c) = sum_rr V(r0+rr, a) X(r0+rr, c), reduced over row blocks by sbr_z_kernel
         const int a = tid >> 4, c = tid & 15;
         double s = 0.0;
-        for (int rr = 0; rr < 64; ++rr) s = fma(vs2[a * 64 + rr], xs[c * 64 + rr], s);
-        Gbuf[goff[b] + (size_t)blockIdx.x * (SB * SB) + tid] = s;
+        for (int rr = 0; rr < 64; ++rr) s = fma(vs2[rr * SBP + a], xs[rr * SBP + c], s);
+        Gbuf[goff[b] + (size_t)blk * (SB * SB) + tid] = s;
     }
 }
 
@@ -243,13 +265,15 @@ __global__ __launch_bounds__(SM_NT) void sbr_z_kernel(int k0, const int *__restr
                                                       const double *__restrict__ Xbuf,
                                                       const int64_t *__restrict__ goff,
                                                       const double *__restrict__ Gbuf,
-                                                      double *__restrict__ Zbuf) {
+                                                      double *__restrict__ Zbuf, int count, int tiles) {
     __shared__ double Ts[SB * SB], Gs[SB * SB], GT[SB * SB], Ss[SB * SB];
-    const int b = blockIdx.y;
+    int b, blk;
+    xcd_decode(tiles, b, blk);
+    if (b >= count) return;
     const int n = ns[b];
     const int np = n - k0 - SB;
     if (np < 2) return;
-    const int r0 = blockIdx.x * SM_NT;
+    const int r0 = blk * SM_NT;
     if (r0 >= np) return;
     const double *A = Wm + moff[b];
     const double *T = Tfac + voff[b] * SB + (size_t)(k0 / SB) * SB * SB;
@@ -298,81 +322,85 @@ __global__ __launch_bounds__(SM_NT) void sbr_z_kernel(int k0, const int *__restr
     }
 }
 
-// A22 -= Z V^T + V Z^T on 64x64 tiles (both triangles: the mat-vec product reads full rows).
-// One workgroup per (row tile, matrix): its Z/V row panel is staged once, then it walks the
-// column tiles of its block row.
+// A22 -= Z V^T + V Z^T (both triangles: the mat-vec product reads full rows).  One workgroup
+// per (128-row strip, matrix): its Z/V row panel is staged once, then it walks the 64-column
+// tiles of the strip; 8x4 register micro-tiles.
 constexpr int S2_NT = 256;
+constexpr int S2_ROWS = 128;
 __global__ __launch_bounds__(S2_NT) void sbr_syr2k_kernel(int k0, const int *__restrict__ ns,
                                                           const int64_t *__restrict__ moff,
                                                           const int64_t *__restrict__ voff,
                                                           double *__restrict__ Wm,
-                                                          const double *__restrict__ Zbuf) {
-    __shared__ __align__(16) double Zi[64 * SB], Vi[64 * SB], Zl[64 * SB], Vl[64 * SB];
-    const int b = blockIdx.y;
+                                                          const double *__restrict__ Zbuf, int count,
+                                                          int tiles) {
+    __shared__ __align__(16) double Zi[S2_ROWS * SB], Vi[S2_ROWS * SB], Zl[64 * SB], Vl[64 * SB];
+    int b, blk;
+    xcd_decode(tiles, b, blk);
+    if (b >= count) return;
     const int n = ns[b];
     const int np = n - k0 - SB;
     if (np < 2) return;
-    const int i0 = blockIdx.x * 64;
+    const int i0 = blk * S2_ROWS;
     if (i0 >= np) return;
     double *A = Wm + moff[b];
     double *A22 = A + (size_t)(k0 + SB) * n + (k0 + SB);
     const double *Z = Zbuf + voff[b] * SB;
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < 64 * SB; idx += S2_NT) {
-        const int rr = idx & 63, c = idx >> 6;
+#pragma unroll
+    for (int idx = tid; idx < S2_ROWS * SB; idx += S2_NT) {
+        const int rr = idx & (S2_ROWS - 1), c = idx >> 7;
         const int ri = i0 + rr;
-        Zi[c * 64 + rr] = (ri < np) ? Z[(size_t)c * n + ri] : 0.0;
-        Vi[c * 64 + rr] = (ri < np) ? vmask(A, n, k0, ri, c) : 0.0;
+        const int rc = min(ri, np - 1);
+        const double zz = Z[(size_t)c * n + rc], vv = vmask(A, n, k0, rc, c);
+        Zi[c * S2_ROWS + rr] = (ri < np) ? zz : 0.0;
+        Vi[c * S2_ROWS + rr] = (ri < np) ? vv : 0.0;
     }
-    const int tr = tid & 15, tc = tid >> 4;  // 4 rows (tr + 16 a), 4 cols (tc + 16 q)
+    const int tr = tid & 15, tc = tid >> 4;  // 8 rows (tr + 16 a), 4 cols (tc + 16 q)
     for (int l0 = 0; l0 < np; l0 += 64) {
         __syncthreads();
+#pragma unroll
         for (int idx = tid; idx < 64 * SB; idx += S2_NT) {
             const int rr = idx & 63, c = idx >> 6;
             const int rl = l0 + rr;
-            Zl[c * 64 + rr] = (rl < np) ? Z[(size_t)c * n + rl] : 0.0;
-            Vl[c * 64 + rr] = (rl < np) ? vmask(A, n, k0, rl, c) : 0.0;
+            const int rc = min(rl, np - 1);
+            const double zz = Z[(size_t)c * n + rc], vv = vmask(A, n, k0, rc, c);
+            Zl[c * 64 + rr] = (rl < np) ? zz : 0.0;
+            Vl[c * 64 + rr] = (rl < np) ? vv : 0.0;
         }
-        // the tile itself (independent of the staging: issue the loads before the barrier)
-        double t[4][4];
+        double t[8][4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int l = l0 + tc + 16 * q;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
+            for (int a = 0; a < 8; ++a) {
                 const int i = i0 + tr + 16 * a;
                 t[a][q] = (i < np && l < np) ? A22[(size_t)l * n + i] : 0.0;
             }
         }
         __syncthreads();
-        double acc[4][4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[a][q] = 0.0;
-#pragma unroll 4
+#pragma unroll 2
         for (int c = 0; c < SB; ++c) {
-            double zi[4], vi[4], zl[4], vl[4];
+            double zl[4], vl[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                zi[a] = Zi[c * 64 + tr + 16 * a];
-                vi[a] = Vi[c * 64 + tr + 16 * a];
-                zl[a] = Zl[c * 64 + tc + 16 * a];
-                vl[a] = Vl[c * 64 + tc + 16 * a];
+            for (int q = 0; q < 4; ++q) {
+                zl[q] = Zl[c * 64 + tc + 16 * q];
+                vl[q] = Vl[c * 64 + tc + 16 * q];
             }
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < 8; ++a) {
+                const double zi = Zi[c * S2_ROWS + tr + 16 * a], vi = Vi[c * S2_ROWS + tr + 16 * a];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[a][q] = fma(zi[a], vl[q], fma(vi[a], zl[q], acc[a][q]));
+                for (int q = 0; q < 4; ++q) t[a][q] = fma(-zi, vl[q], fma(-vi, zl[q], t[a][q]));
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int l = l0 + tc + 16 * q;
             if (l >= np) continue;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
+            for (int a = 0; a < 8; ++a) {
                 const int i = i0 + tr + 16 * a;
-                if (i < np) A22[(size_t)l * n + i] = t[a][q] - acc[a][q];
+                if (i < np) A22[(size_t)l * n + i] = t[a][q];
             }
         }
     }
@@ -749,15 +777,17 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b) {
             hipLaunchKernelGGL((sbr_qr_kernel<1024, false>), dim3(b.count), dim3(1024), 0, s, k0,
                                b.n.p, b.moff.p, b.voff.p, b.W.p, b.Tfac.p);
         if (prof) { profiler().end(s, "eig_sbr_qr", 0.0, 0.0); profiler().begin(s); }
-        hipLaunchKernelGGL(sbr_symm_kernel, dim3(div_up(npmax, 64), b.count), dim3(SY_NT), 0, s, k0,
-                           b.n.p, b.moff.p, b.voff.p, b.W.p, b.Xbuf.p, b.goff.p, b.Gbuf.p);
+        const int cnt8 = 8 * div_up(b.count, 8);
+        hipLaunchKernelGGL(sbr_symm_kernel, dim3(cnt8 * div_up(npmax, 64)), dim3(SY_NT), 0, s, k0,
+                           b.n.p, b.moff.p, b.voff.p, b.W.p, b.Xbuf.p, b.goff.p, b.Gbuf.p, b.count,
+                           div_up(npmax, 64));
         if (prof) { profiler().end(s, "eig_sbr_symm", first ? sbytes : 0.0, 0.0); profiler().begin(s); }
-        hipLaunchKernelGGL(sbr_z_kernel, dim3(div_up(npmax, SM_NT), b.count), dim3(SM_NT), 0, s, k0,
+        hipLaunchKernelGGL(sbr_z_kernel, dim3(cnt8 * div_up(npmax, SM_NT)), dim3(SM_NT), 0, s, k0,
                            b.n.p, b.moff.p, b.voff.p, b.W.p, b.Tfac.p, b.Xbuf.p, b.goff.p, b.Gbuf.p,
-                           b.Zbuf.p);
+                           b.Zbuf.p, b.count, div_up(npmax, SM_NT));
         if (prof) { profiler().end(s, "eig_sbr_z", 0.0, 0.0); profiler().begin(s); }
-        hipLaunchKernelGGL(sbr_syr2k_kernel, dim3(div_up(npmax, 64), b.count), dim3(S2_NT), 0, s, k0,
-                           b.n.p, b.moff.p, b.voff.p, b.W.p, b.Zbuf.p);
+        hipLaunchKernelGGL(sbr_syr2k_kernel, dim3(cnt8 * div_up(npmax, S2_ROWS)), dim3(S2_NT), 0, s, k0,
+                           b.n.p, b.moff.p, b.voff.p, b.W.p, b.Zbuf.p, b.count, div_up(npmax, S2_ROWS));
         if (prof) profiler().end(s, "eig_sbr_syr2k", first ? ubytes : 0.0, 0.0);
         first = false;
     }
