@@ -2,16 +2,24 @@
 """bench.py -- AMG setup+solve throughput on synthetic 3-D Poisson (BASELINE.json metric).
 
 One "step" = one full pass of the hot path over one problem that is already resident in
-HBM: ml_produce_data (topology -> spectral problems -> P -> RAP, all levels) followed by
-PCG to sqrt((B r_k,r_k)/(B r_0,r_0)) < 1e-8.  value = DoF/s = N * steps / time.
+HBM: ml_produce_data (topology -> local spectral problems -> P -> RAP, all levels) followed
+by PCG to sqrt((B r_k,r_k)/(B r_0,r_0)) < 1e-8.  value = DoF/s = N * steps / time.
+Default workload = the configuration BASELINE.json quotes the metric on: 3-D Poisson 256^3,
+3-level SAAMGE (it fits one MI355X).
 
     python bench.py --gpus 1 --steps K --warmup W [--n 256] [--levels 3]
 
 Prints ONE JSON line (rank 0).  Extra legs, outside the timed region:
-  * roofline: HIP-event timing of every kernel launch of one more step (the library's own
-    event pairs on the launch stream), reported for the dominant kernel;
-  * cpu_baseline: the CPU oracle (numpy + LAPACK dsygvx/dgesvd) on a bounded sample of the
-    same workload, timed on this box's host cores.
+  * roofline: one more step with the library's HIP-event pair around every kernel launch
+    (events recorded on the launch stream); reported for the kernel with the largest total
+    time.  `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes of this
+    same command (profiles/r01_pmc_traffic.json, produced by tools/pmc_traffic.py; FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950, calibrated on pcg_update_xr).
+  * cpu_baseline: the CPU oracle (numpy + LAPACK dsygvx/dgesvd, 1 thread) on a bounded
+    sample of the same workload, timed on this box's host cores.
+
+N > 1 (torchrun): the row-partitioned hierarchy of SURVEY section 8(e) is not built yet; every
+rank runs an independent replica (no data-path collective), value = N * dofs * steps / max time.
 """
 import argparse
 import json
@@ -24,6 +32,20 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # MI355X datasheet fp64 vector == matrix
+
+# profiler label -> (kernel symbol in rocprofv3 output, roofline bound)
+KERNELS = {
+    "smooth_step": ("sell_spmv_kernel<3>", "hbm"),
+    "spmv": ("sell_spmv_kernel<0>", "hbm"),
+    "spmv_residual": ("sell_spmv_kernel<1>", "hbm"),
+    "eig_sbr_symm": ("sbr_symm_kernel", "hbm"),
+    "eig_sbr_syr2k": ("sbr_syr2k_kernel", "hbm"),
+    "eig_band_chase": ("band_chase_kernel", "mfma"),
+    "eig_sbr_qr": ("sbr_qr_kernel<256, true>", "mfma"),
+    "ae_assemble": ("ae_assemble_kernel", "hbm"),
+    "ae_scale": ("ae_scale_kernel", "hbm"),
+    "rap": ("rap_numeric_kernel", "hbm"),
+}
 
 
 def log(*a):
@@ -47,8 +69,7 @@ def one_step(capi, prob, params, rel_tol=1e-8):
 
 def cpu_baseline(n_sample, levels):
     """Oracle setup+solve on a bounded sample: the same discretisation and AE shape on a
-    smaller cube, scaled per dof."""
-    import numpy as np
+    smaller box, reported per dof."""
     from saamge_amd import problems
     from oracle import saamge_oracle as oracle
     cb = [(2, 2, 2)] * (levels - 2)
@@ -61,9 +82,24 @@ def cpu_baseline(n_sample, levels):
     t2 = time.perf_counter()
     nd = prob.A.shape[0]
     return {"value": nd / (t2 - t0), "unit": "DoF/s", "cores": 1, "kind": "port",
-            "sample": "oracle (numpy + LAPACK dsygvx/dgesvd, 1 thread) on 3-D Poisson %s, %d-level, "
-                      "8x8x4-element AEs: setup %.2f s, solve %.2f s, %d PCG its"
-                      % ("x".join(str(v) for v in n_sample), levels, t1 - t0, t2 - t1, it)}
+            "sample": "oracle (numpy + LAPACK dsygvx/dgesvd, 1 thread) on 3-D Poisson %s (%d dofs), "
+                      "%d-level, 8x8x4-element AEs: setup %.2f s, solve %.2f s, %d PCG its"
+                      % ("x".join(str(v) for v in n_sample), nd, levels, t1 - t0, t2 - t1, it)}
+
+
+def pmc_traffic(symbol, n, levels):
+    """Per-launch HBM bytes of `symbol` from the committed PMC passes of this command."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    if d.get("_config") != {"n": n, "levels": levels}:
+        return None
+    k = d.get(symbol)
+    if not k or not k.get("launches"):
+        return None
+    return (2.0 * k["fetch_bytes_raw"] + k["write_bytes"]) / k["launches"]
 
 
 def main():
@@ -79,43 +115,37 @@ def main():
 
     import torch
     from saamge_amd import capi
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    from saamge_amd.dist import Group
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+    grp = Group(backend="nccl", device=dev)
+    world, rank = grp.world, grp.rank
 
     prob = build_problem(args.n, args.levels, dev)
     torch.cuda.synchronize()
     params = capi.default_params(num_coarsenings=args.levels - 1, theta=0.003, nu_relax=3)
 
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
     its = conv = None
     for _ in range(args.warmup):
         h, x, its, conv, hist = one_step(capi, prob, params)
         h.close()
-    barrier()
+    grp.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         h, x, its, conv, hist = one_step(capi, prob, params)
-        if _ < args.steps - 1:
+        if i < args.steps - 1:
             h.close()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    grp.barrier()
+    torch.cuda.synchronize()
+    dt = grp.max_time(time.perf_counter() - t0)
     infos = [h.level_info(l) for l in range(args.levels - 1)]
+    # size-independent check on the full-size problem: true residual of the computed solution
+    A_rowptr, A_col, A_val = prob.rowptr, prob.col, prob.val
+    Acsr = torch.sparse_csr_tensor(A_rowptr.long(), A_col.long(), A_val, size=(prob.n, prob.n))
+    relres = float(torch.linalg.norm(Acsr @ x - prob.b) / torch.linalg.norm(prob.b))
+    del Acsr
     h.close()
 
     res = {
@@ -134,8 +164,10 @@ def main():
         "config": {"workload": "3D Poisson %d^3 Q1 hexes, %d-level SAAMGE, theta=0.003, nu_relax=3, "
                                "8x8x4-element AEs" % (args.n, args.levels),
                    "dofs": prob.n, "pcg_iterations": its, "converged": bool(conv),
+                   "true_relative_residual": relres,
                    "level_dims": [i["n"] for i in infos] + [infos[-1]["ncoarse"]],
-                   "parallelism": "replicas" if world > 1 else "single"},
+                   "parallelism": ("%d independent replicas (row-partitioned hierarchy not built)" % world)
+                   if world > 1 else "single GPU"},
     }
 
     if rank == 0 and not args.no_roofline:
@@ -147,31 +179,34 @@ def main():
         stats = sorted(capi.profile_stats(), key=lambda s: -s["ms"])
         tot = sum(s["ms"] for s in stats)
         for s in stats:
-            log("  %-16s %9.3f ms %6d launches  %8.1f GB/s  %8.2f TFLOP/s"
+            log("  %-18s %9.3f ms %6d launches  %8.1f GB/s  %8.2f TFLOP/s"
                 % (s["name"], s["ms"], s["launches"], s["bytes"] / max(s["ms"], 1e-9) / 1e6,
                    s["flops"] / max(s["ms"], 1e-9) / 1e9))
         log("  kernel total %.3f ms (profiled step)" % tot)
         d = stats[0]
+        symbol, bound = KERNELS.get(d["name"], (d["name"], "hbm"))
         avg_ms = d["ms"] / d["launches"]
-        if d["name"].startswith("eig_"):
-            ach = d["flops"] / d["ms"] / 1e9
-            res["roofline"] = {"kernel": d["name"], "bound": "mfma", "achieved": ach,
-                               "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
-                               "traffic": None, "avg_launch_ms": avg_ms, "launches": d["launches"]}
-        else:
+        traffic = pmc_traffic(symbol, args.n, args.levels)
+        if bound == "hbm":
             ach = d["bytes"] / d["ms"] / 1e6
-            res["roofline"] = {"kernel": d["name"], "bound": "hbm", "achieved": ach,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": None, "avg_launch_ms": avg_ms, "launches": d["launches"]}
-        res["kernels"] = [{"name": s["name"], "ms": round(s["ms"], 3), "launches": s["launches"]}
-                          for s in stats[:8]]
+            res["roofline"] = {"kernel": symbol, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                               "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+                               "avg_launch_ms": avg_ms, "launches": d["launches"]}
+        else:
+            ach = d["flops"] / d["ms"] / 1e9
+            res["roofline"] = {"kernel": symbol, "bound": "mfma", "achieved": ach,
+                               "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic,
+                               "avg_launch_ms": avg_ms, "launches": d["launches"]}
+        res["kernels"] = [{"name": s["name"], "ms": round(s["ms"], 3), "launches": s["launches"],
+                           "GBps": round(s["bytes"] / max(s["ms"], 1e-9) / 1e6, 1)}
+                          for s in stats[:10]]
     if rank == 0 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline((16, 16, 8), args.levels)
+        res["cpu_baseline"] = cpu_baseline((48, 48, 32), args.levels)
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,167 @@
+"""GPU tests that do not need the oracle at full size: committed golden fixtures, and
+size-independent properties on larger problems / edge cases."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from saamge_amd import problems as pr
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _capi():
+    from saamge_amd import capi
+    return capi
+
+
+@pytest.mark.parametrize("name,prob_fn,nco,testmesh,theta", [
+    ("mltest_q1_2level", lambda: pr.mltest_problem(order=1, levels=2), 1, True, 0.003),
+    ("mltest_q1_3level", lambda: pr.mltest_problem(order=1, levels=3), 2, True, 0.003),
+    ("mltest_q2_2level", lambda: pr.mltest_problem(order=2, levels=2), 1, True, 0.003),
+    ("poisson3d_8_2level", lambda: pr.poisson3d_problem((8, 8, 8), blk=(4, 4, 2)), 1, False, 0.003),
+    ("poisson3d_aniso_2level", lambda: pr.poisson3d_problem((12, 8, 4), blk=(4, 4, 2), K=(1, 1, 1000.0)), 1, False, 0.02),
+])
+def test_against_golden_fixture(name, prob_fn, nco, testmesh, theta):
+    capi = _capi()
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    prob = prob_fn()
+    params = capi.default_params(num_coarsenings=nco, theta=theta, testmesh=testmesh, keep_debug=True,
+                                 coarse_rtol=1e-28)
+    h = capi.Hierarchy.from_problem(prob, params)
+    for l in range(nco):
+        mises, k, ncols, flags = h.get_mis(l)
+        assert np.array_equal(mises, g["l%d_mises" % l])                      # bit exact
+        I, J = h.get_table(l, "mis_to_dof")
+        assert np.array_equal(I, g["l%d_mis_to_dof_I" % l]) and np.array_equal(J, g["l%d_mis_to_dof_J" % l])
+        assert np.array_equal(h.get_table(l, "mis_to_AE")[1], g["l%d_mis_to_AE_J" % l])
+        assert np.array_equal(np.diff(h.get_table(l, "AE_to_dof")[0]), g["l%d_AE_sizes" % l])
+        m, ev, X, Ds = h.get_ae_eigens(l)
+        assert np.array_equal(m, g["l%d_ae_m" % l])
+        assert np.array_equal(k, g["l%d_mis_k" % l])
+        if l == 0 or name.startswith("mltest"):
+            evg = g["l%d_evals" % l]
+            assert np.allclose(np.concatenate(ev), evg[:sum(len(e) for e in ev)] if len(evg) != sum(len(e) for e in ev) else evg, atol=1e-11)
+        Ac = h.get_csr(l, "Ac")
+        assert Ac.shape[0] == int(g["l%d_Ac_dim" % l][0])
+        assert np.isclose(Ac.diagonal().sum(), g["l%d_Ac_trace" % l][0], rtol=1e-10)
+        assert np.isclose(np.sqrt(Ac.multiply(Ac).sum()), g["l%d_Ac_fro" % l][0], rtol=1e-10)
+    if "vcycle_x" in g.files:
+        x = h.vcycle(prob.b)
+        assert np.linalg.norm(x - g["vcycle_x"]) <= 1e-10 * np.linalg.norm(g["vcycle_x"])
+    x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-6)
+    assert conv and it == int(g["pcg_iters"][0])
+    assert np.allclose(hist[:2], g["pcg_hist"][:2], rtol=1e-9)
+    assert np.linalg.norm(x - g["pcg_x"]) <= 1e-8 * np.linalg.norm(g["pcg_x"])
+    h.close()
+
+
+@pytest.mark.parametrize("levels", [2, 3])
+def test_properties_32cubed(levels):
+    """Size-independent checks at a size the python oracle does not reach quickly."""
+    capi = _capi()
+    cb = [(2, 2, 2)] if levels == 3 else None
+    prob = pr.poisson3d_problem((32, 32, 32), blk=(8, 8, 4), coarse_blk=cb, coef="checkerboard")
+    params = capi.default_params(num_coarsenings=levels - 1, keep_debug=True)
+    h = capi.Hierarchy.from_problem(prob, params)
+    rng = np.random.default_rng(7)
+    for l in range(levels - 1):
+        A, P, R, Ac = (h.get_csr(l, w) for w in ("A", "P", "R", "Ac"))
+        info = h.level_info(l)
+        # coarse dims are consistent, P^T P = I (orthonormal MIS blocks), R = P^T exactly
+        mises, k, ncols, flags = h.get_mis(l)
+        assert k.sum() == info["ncoarse"] == P.shape[1]
+        assert abs(P - R.T).max() == 0.0
+        PtP = (P.T @ P).toarray()
+        assert np.allclose(PtP, np.eye(P.shape[1]), atol=1e-11)
+        # Galerkin product and symmetry
+        ref = (P.T @ A @ P).toarray()
+        assert np.allclose(Ac.toarray(), ref, atol=1e-12 * np.abs(ref).max())
+        assert abs(Ac - Ac.T).max() <= 1e-12 * abs(Ac).max()
+        # essential rows of P vanish (contrib_filter_boundary) on the finest level
+        if l == 0:
+            assert abs(P[prob.ess]).max() == 0.0
+        # every AE contributed at least one vector (atleast_one)
+        m, ev, X, Ds = h.get_ae_eigens(l)
+        assert m.min() >= 1
+        for e in ev:
+            assert np.all(np.diff(e) >= -1e-14) and (len(e) == 1 or e[-1] <= params.theta[l] + 1e-12)
+    # the V-cycle is a symmetric positive definite, linear operator
+    u = rng.standard_normal(prob.ND) * (~prob.ess)
+    v = rng.standard_normal(prob.ND) * (~prob.ess)
+    Bu, Bv = h.vcycle(u), h.vcycle(v)
+    assert abs(Bu @ v - u @ Bv) <= 1e-9 * abs(Bu @ v)
+    assert Bu @ u > 0
+    assert np.linalg.norm(h.vcycle(2.0 * u - 3.0 * v) - (2.0 * Bu - 3.0 * Bv)) <= 1e-9 * np.linalg.norm(Bu)
+    # PCG: converged means the TRUE residual is small
+    x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-8)
+    assert conv and it < 60
+    assert np.all(np.diff(hist) < 0)
+    assert np.linalg.norm(prob.A @ x - prob.b) <= 1e-6 * np.linalg.norm(prob.b)
+    h.close()
+
+
+def test_edge_cases():
+    capi = _capi()
+    # one AE only (no interface MIS), tiny theta -> the single smallest pair per AE
+    prob = pr.poisson3d_problem((3, 3, 3), blk=(3, 3, 3))
+    h = capi.Hierarchy.from_problem(prob, capi.default_params(theta=1e-12, keep_debug=True))
+    m, ev, X, Ds = h.get_ae_eigens(0)
+    assert list(m) == [1]
+    x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-10)
+    assert conv and np.linalg.norm(prob.A @ x - prob.b) <= 1e-8 * np.linalg.norm(prob.b)
+    h.close()
+    # ragged partition: AEs of 1 .. many elements, MISes of size 1, all-essential MISes on the boundary
+    prob = pr.poisson3d_problem((5, 4, 3), blk=(2, 3, 2))
+    part = prob.partitions[0].copy()
+    part[0] = part.max() + 1            # a single-element AE in the corner
+    prob.partitions = [part]
+    h = capi.Hierarchy.from_problem(prob, capi.default_params(keep_debug=True))
+    mises, k, ncols, flags = h.get_mis(0)
+    I, J = h.get_table(0, "mis_to_dof")
+    sizes = np.diff(I)
+    ess_all = np.array([np.all(prob.ess[J[I[i]:I[i + 1]]]) for i in range(len(sizes))])
+    assert np.all(k[ess_all] == 0)                      # skipped (contrib.cpp:578-605)
+    assert np.all(k[(sizes == 1) & ~ess_all] == 1)      # size-1 MIS -> [1]
+    x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-10)
+    assert conv and np.linalg.norm(prob.A @ x - prob.b) <= 1e-8 * np.linalg.norm(prob.b)
+    h.close()
+    # error behaviour: bad partition ids are reported, not crashed on
+    bad = pr.poisson3d_problem((4, 4, 4), blk=(2, 2, 2))
+    p2 = bad.partitions[0].copy()
+    p2[3] = 1000
+    bad.partitions = [p2]
+    params = capi.default_params()
+    with pytest.raises(RuntimeError):
+        e2d = np.ascontiguousarray(bad.elem_to_dof, dtype=np.int32)
+        A = bad.A.tocsr()
+        capi.Hierarchy(np.ascontiguousarray(A.indptr, dtype=np.int32), np.ascontiguousarray(A.indices, dtype=np.int32),
+                       np.ascontiguousarray(A.data), A.shape[0], e2d, np.ascontiguousarray(bad.elmat),
+                       np.ascontiguousarray(bad.bdr), [p2.astype(np.int32)], [8], params, e2d.shape[0], 8)
+
+
+def test_one_stage_and_two_stage_eigensolvers_agree():
+    """SAAMGE_AMD_EIG=onestage selects the one-stage blocked Householder kernel; both paths must
+    give the same hierarchy (coarse dims) and PCG history."""
+    code = (
+        "import sys, json; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from saamge_amd import capi, problems as pr\n"
+        "prob = pr.poisson3d_problem((16,16,8), blk=(8,8,4))\n"
+        "h = capi.Hierarchy.from_problem(prob, capi.default_params(coarse_rtol=1e-28))\n"
+        "x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-8)\n"
+        "print(json.dumps({'nc': h.level_info(0)['ncoarse'], 'it': it, 'hist': list(hist)}))\n" % ROOT)
+    outs = []
+    for mode in ("onestage", "twostage"):
+        env = dict(os.environ, SAAMGE_AMD_EIG=mode)
+        o = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert o.returncode == 0, o.stderr[-2000:]
+        import json
+        outs.append(json.loads(o.stdout.strip().splitlines()[-1]))
+    assert outs[0]["nc"] == outs[1]["nc"] and outs[0]["it"] == outs[1]["it"]
+    assert np.allclose(outs[0]["hist"], outs[1]["hist"], rtol=1e-8)
