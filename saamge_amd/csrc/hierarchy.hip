@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <functional>
+#include <thread>
 
 namespace saamge_amd {
 
@@ -79,10 +80,16 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     L.nu_relax = P.nu_relax[lev];
     SA_REQUIRE(P.nu_pro[lev] == 0, "prolongator smoothing (nu_pro > 0) is not implemented yet");
     PhaseTimer tm(s);
-    build_relations(L.rel, std::move(e2d), part, nparts, L.A.nrows, bdr_host);
-    tm.lap("host topology", lev);
-    upload_relations(L.drel, L.rel, s);
+    build_relations_ae(L.rel, std::move(e2d), part, nparts, L.A.nrows, bdr_host);
+    tm.lap("host topology (AE tables)", lev);
+    upload_relations_ae(L.drel, L.rel, s);
     tm.lap("upload topology", lev);
+    // the MIS tables are built on a host thread while the GPU solves the local eigenproblems
+    std::exception_ptr mis_err;
+    std::thread mis_thread([&]() {
+        try { build_relations_mis(L.rel); } catch (...) { mis_err = std::current_exception(); }
+    });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{mis_thread};
     const Relations &rel = L.rel;
     build_sell(s, L.A);   // SELL-64 copy of the level operator for the SpMV family
     // smoother data (smpr_init_poly_data, amg/src/smpr.cpp:359-423)
@@ -177,6 +184,10 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     L.ae_m = m_tot;
 
     // ---- MIS stage (ContribTent::contrib_mises) ----
+    mis_thread.join();
+    if (mis_err) std::rethrow_exception(mis_err);
+    upload_relations_mis(L.drel, L.rel, s);
+    tm.lap("MIS tables (join + upload)", lev);
     const int nm = rel.num_mises;
     std::vector<int64_t> g_off((size_t)nm + 1, 0);
     L.mis_u_off.assign((size_t)nm + 1, 0);
@@ -265,27 +276,53 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
         for (int t = rel.AE_to_mis.I[e]; t < rel.AE_to_mis.I[e + 1]; ++t)
             colpos_ptr[(size_t)t + 1] = colpos_ptr[t] + L.mis_k[rel.AE_to_mis.J[t]];
     std::vector<int> colpos((size_t)colpos_ptr.back(), -1);
-    std::vector<int> stamp((size_t)e2d.ncols, -1);
-    for (int e = 0; e < nparts; ++e) {
-        int run = 0;
-        const int *misrow = rel.AE_to_mis.row(e);
-        const int nmis = rel.AE_to_mis.row_size(e);
-        for (int k = rel.AE_to_dof.I[e]; k < rel.AE_to_dof.I[e + 1]; ++k) {
-            const int dof = rel.AE_to_dof.J[k];
-            const int m = rel.mises[dof];
-            const int km = L.mis_k[m];
-            if (km == 0) continue;
-            const int t = rel.AE_to_mis.I[e] + (int)(std::lower_bound(misrow, misrow + nmis, m) - misrow);
-            for (int v = 0; v < km; ++v) {
-                const int cd = L.mis_coloff[m] + v;
-                if (stamp[cd] == e) continue;
-                if (p_val[(size_t)p_rowptr[dof] + v] == 0.0) continue;
-                stamp[cd] = e;
-                colpos[(size_t)colpos_ptr[t] + v] = run++;
-                e2d.J.push_back(cd);
+    // two passes over the AEs (count, then fill), both split over host threads
+    {
+        int T = (int)std::thread::hardware_concurrency();
+        if (T < 1) T = 1;
+        if (T > 16) T = 16;
+        if (nparts < 64) T = 1;
+        auto walk = [&](int e, std::vector<int> &stamp, int *out, bool fill) -> int {
+            int run = 0;
+            const int *misrow = rel.AE_to_mis.row(e);
+            const int nmis = rel.AE_to_mis.row_size(e);
+            for (int k = rel.AE_to_dof.I[e]; k < rel.AE_to_dof.I[e + 1]; ++k) {
+                const int dof = rel.AE_to_dof.J[k];
+                const int m = rel.mises[dof];
+                const int km = L.mis_k[m];
+                if (km == 0) continue;
+                const int t = rel.AE_to_mis.I[e] + (int)(std::lower_bound(misrow, misrow + nmis, m) - misrow);
+                for (int v = 0; v < km; ++v) {
+                    const int cd = L.mis_coloff[m] + v;
+                    if (stamp[cd] == e) continue;
+                    if (p_val[(size_t)p_rowptr[dof] + v] == 0.0) continue;
+                    stamp[cd] = e;
+                    if (fill) {
+                        colpos[(size_t)colpos_ptr[t] + v] = run;
+                        out[run] = cd;
+                    }
+                    ++run;
+                }
+            }
+            return run;
+        };
+        for (int pass = 0; pass < 2; ++pass) {
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t)
+                th.emplace_back([&, t, pass]() {
+                    std::vector<int> stamp((size_t)e2d.ncols, -1);
+                    const int eb = (int)((int64_t)nparts * t / T), ee = (int)((int64_t)nparts * (t + 1) / T);
+                    for (int e = eb; e < ee; ++e) {
+                        if (pass == 0) e2d.I[e + 1] = walk(e, stamp, nullptr, false);
+                        else walk(e, stamp, e2d.J.data() + e2d.I[e], true);
+                    }
+                });
+            for (auto &x : th) x.join();
+            if (pass == 0) {
+                for (int e = 0; e < nparts; ++e) e2d.I[e + 1] += e2d.I[e];
+                e2d.J.resize((size_t)e2d.I[nparts]);
             }
         }
-        e2d.I[e + 1] = e2d.I[e] + run;
     }
     for (int v : colpos) SA_REQUIRE(v >= 0, "coarse dof with an all-zero prolongator column in an AE");
     // coarse element matrices

@@ -39,8 +39,11 @@ struct Relations {
 
 // agg_create_partitioning_tables + agg_produce_mises + agg_construct_agg_flags
 // (amg/src/aggregates.cpp:1357-1443, :501-653, :198-216).  bdr may be null (coarse levels).
-void build_relations(Relations &r, Table &&elem_to_dof, const hvec<int> &partitioning,
-                     int nparts, int ND, const signed char *bdr);
+// Split in two so that the MIS half can run on a host thread while the GPU already works on the
+// AE matrices (which only need the first half).
+void build_relations_ae(Relations &r, Table &&elem_to_dof, const hvec<int> &partitioning,
+                        int nparts, int ND, const signed char *bdr);
+void build_relations_mis(Relations &r);
 
 struct DevRelations {
     DBuf<int> e2d_I, e2d_J, elem_ldof, part;
@@ -53,6 +56,7 @@ struct DevRelations {
     DBuf<int> pair_loc;
     DBuf<signed char> flags;
 };
-void upload_relations(DevRelations &d, const Relations &r, hipStream_t s);
+void upload_relations_ae(DevRelations &d, const Relations &r, hipStream_t s);
+void upload_relations_mis(DevRelations &d, const Relations &r, hipStream_t s);
 
 }  // namespace saamge_amd

@@ -197,8 +197,8 @@ static inline uint64_t hash_row(const int *r, int n) {
     return h;
 }
 
-void build_relations(Relations &r, Table &&elem_to_dof, const hvec<int> &partitioning,
-                     int nparts, int ND, const signed char *bdr) {
+void build_relations_ae(Relations &r, Table &&elem_to_dof, const hvec<int> &partitioning,
+                        int nparts, int ND, const signed char *bdr) {
     const bool timing = std::getenv("SAAMGE_AMD_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -316,6 +316,31 @@ void build_relations(Relations &r, Table &&elem_to_dof, const hvec<int> &partiti
             }
     }, 8);
     lap("dof_id_inAE");
+    // flags (agg_construct_agg_flags, :198-216)
+    r.agg_flags.assign((size_t)ND, 0);
+    parallel_for(ND, [&](int64_t b, int64_t e, int) {
+        for (int64_t i = b; i < e; ++i) {
+            signed char f = bdr ? bdr[i] : 0;
+            if (r.dof_to_AE.row_size((int)i) > 1) f |= FLAG_BETWEEN_AES;
+            r.agg_flags[(size_t)i] = f;
+        }
+    });
+    lap("flags");
+}
+
+// Part 2 (MIS tables): independent of the device work on the AE matrices, so the caller runs
+// it on a host thread while the GPU solves the local eigenproblems.
+void build_relations_mis(Relations &r) {
+    const bool timing = std::getenv("SAAMGE_AMD_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "TIMING:     topology %-22s %8.3f ms\n", what,
+                     std::chrono::duration<double, std::milli>(t - t_last).count());
+        t_last = t;
+    };
+    const int ND = r.ND, nparts = r.nparts;
     // ---- MISes: groups of dofs with identical AE lists, numbered by first appearance ----
     // group representative = smallest dof of the group
     std::vector<int> rep_of((size_t)ND, -1);        // dof -> representative dof
@@ -429,16 +454,6 @@ void build_relations(Relations &r, Table &&elem_to_dof, const hvec<int> &partiti
         });
     }
     lap("mis_to_AE/AE_to_mis");
-    // flags (agg_construct_agg_flags, :198-216)
-    r.agg_flags.assign((size_t)ND, 0);
-    parallel_for(ND, [&](int64_t b, int64_t e, int) {
-        for (int64_t i = b; i < e; ++i) {
-            signed char f = bdr ? bdr[i] : 0;
-            if (r.dof_to_AE.row_size((int)i) > 1) f |= FLAG_BETWEEN_AES;
-            r.agg_flags[(size_t)i] = f;
-        }
-    });
-    lap("flags");
     // (MIS, AE) pairs: AE-local indices of the MIS dofs
     r.pair_loc_off.assign((size_t)npairs + 1, 0);
     for (int m = 0; m < r.num_mises; ++m) {
@@ -516,7 +531,7 @@ __global__ __launch_bounds__(256) void elem_ldof_kernel(int NE, const int *__res
     }
 }
 
-void upload_relations(DevRelations &d, const Relations &r, hipStream_t s) {
+void upload_relations_ae(DevRelations &d, const Relations &r, hipStream_t s) {
     d.e2d_I.from_host(r.elem_to_dof.I, s);
     d.e2d_J.from_host(r.elem_to_dof.J, s);
     d.part.from_host(r.partitioning, s);
@@ -525,17 +540,6 @@ void upload_relations(DevRelations &d, const Relations &r, hipStream_t s) {
     d.d2ae_I.from_host(r.dof_to_AE.I, s);
     d.d2ae_J.from_host(r.dof_to_AE.J, s);
     d.dof_id_inAE.from_host(r.dof_id_inAE, s);
-    d.mis2d_I.from_host(r.mis_to_dof.I, s);
-    d.mis2d_J.from_host(r.mis_to_dof.J, s);
-    d.mis2ae_I.from_host(r.mis_to_AE.I, s);
-    d.mis2ae_J.from_host(r.mis_to_AE.J, s);
-    d.ae2mis_I.from_host(r.AE_to_mis.I, s);
-    d.ae2mis_J.from_host(r.AE_to_mis.J, s);
-    d.ae_pair.from_host(r.ae_pair, s);
-    d.mises.from_host(r.mises, s);
-    d.dof_row_in_mis.from_host(r.dof_row_in_mis, s);
-    d.pair_loc_off.from_host(r.pair_loc_off, s);
-    d.pair_loc.from_host(r.pair_loc, s);
     d.flags.from_host(r.agg_flags, s);
     // dof_to_elem on the device
     const long nconn = (long)r.elem_to_dof.J.size();
@@ -556,6 +560,20 @@ void upload_relations(DevRelations &d, const Relations &r, hipStream_t s) {
         SA_HIP_CHECK(hipGetLastError());
         SA_HIP_CHECK(hipStreamSynchronize(s));
     }
+}
+
+void upload_relations_mis(DevRelations &d, const Relations &r, hipStream_t s) {
+    d.mis2d_I.from_host(r.mis_to_dof.I, s);
+    d.mis2d_J.from_host(r.mis_to_dof.J, s);
+    d.mis2ae_I.from_host(r.mis_to_AE.I, s);
+    d.mis2ae_J.from_host(r.mis_to_AE.J, s);
+    d.ae2mis_I.from_host(r.AE_to_mis.I, s);
+    d.ae2mis_J.from_host(r.AE_to_mis.J, s);
+    d.ae_pair.from_host(r.ae_pair, s);
+    d.mises.from_host(r.mises, s);
+    d.dof_row_in_mis.from_host(r.dof_row_in_mis, s);
+    d.pair_loc_off.from_host(r.pair_loc_off, s);
+    d.pair_loc.from_host(r.pair_loc, s);
 }
 
 }  // namespace saamge_amd
