@@ -39,6 +39,21 @@ __device__ inline double wsum64(double v) {
     return v;
 }
 
+// 16-lane all-reduce with DPP row rotations (no LDS crossbar): {8,4,2,1} rotations cover the row
+template <int CTRL>
+__device__ inline double dpp_rot(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double rsum16(double v) {
+    v += dpp_rot<0x128>(v);  // row_ror:8
+    v += dpp_rot<0x124>(v);  // row_ror:4
+    v += dpp_rot<0x122>(v);  // row_ror:2
+    v += dpp_rot<0x121>(v);  // row_ror:1
+    return v;
+}
 template <int NT>
 __device__ inline double bsum(double v, double *red) {
 #pragma unroll
@@ -158,6 +173,109 @@ __global__ __launch_bounds__(NT) void sbr_qr_kernel(int k0, const int *__restric
             const int i = idx % np, c = idx / np;
             Pg[(size_t)c * n + i] = P[(size_t)c * ldp + i];
         }
+    }
+}
+
+// Register-resident panel QR for np <= 512: thread t owns panel rows t and t + 256 (2 x SB
+// doubles in VGPRs).  Per column: one block reduction for the norm and ONE fused multi-dot
+// (the 15 products v_c . P(:, j)) -- 16-lane partial sums by DPP row rotations, the rest through
+// a small LDS buffer -- instead of one pass over LDS/global per column pair.
+__global__ __launch_bounds__(256) void sbr_qr_reg_kernel(int k0, const int *__restrict__ ns,
+                                                         const int64_t *__restrict__ moff,
+                                                         const int64_t *__restrict__ voff,
+                                                         double *__restrict__ Wm,
+                                                         double *__restrict__ Tfac) {
+    __shared__ double red[4];
+    __shared__ double part[SB * 16];   // [j][row-of-16]
+    __shared__ double dots[SB];        // w_j (j > c) / z_j (j < c)
+    __shared__ double Ts[SB * SB];
+    __shared__ double salpha;
+    const int b = blockIdx.x;
+    const int n = ns[b];
+    const int np = n - k0 - SB;
+    if (np < 2) return;
+    double *A = Wm + moff[b];
+    double *T = Tfac + voff[b] * SB + (size_t)(k0 / SB) * SB * SB;
+    const int tid = threadIdx.x;
+    double *Pg = A + (size_t)k0 * n + (k0 + SB);
+    const int r0 = tid, r1 = tid + 256;
+    double p0[SB], p1[SB];
+#pragma unroll
+    for (int c = 0; c < SB; ++c) {
+        p0[c] = (r0 < np) ? Pg[(size_t)c * n + r0] : 0.0;
+        p1[c] = (r1 < np) ? Pg[(size_t)c * n + r1] : 0.0;
+    }
+    for (int i = tid; i < SB * SB; i += 256) Ts[i] = 0.0;
+    const int nref = min(SB, np - 1);
+#pragma unroll
+    for (int c = 0; c < SB; ++c) {
+        if (c < nref) {   // uniform: the loop stays fully unrolled, the panel stays in registers
+        // ---- Householder vector of column c ----
+        double ss = 0.0;
+        if (r0 > c) ss = p0[c] * p0[c];
+        ss = fma(p1[c], p1[c], ss);          // rows >= 256 > c; zero beyond np
+        if (tid == c) salpha = p0[c];
+        ss = bsum<256>(ss, red);             // contains the barriers that publish salpha
+        const double alpha = salpha;
+        double tau = 0.0, beta = alpha, scale = 0.0;
+        if (ss != 0.0) {
+            beta = -copysign(sqrt(fma(alpha, alpha, ss)), alpha);
+            tau = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        // v entries of my rows (v_c = 1 on row c, 0 above)
+        double v0 = (r0 > c) ? p0[c] * scale : ((r0 == c) ? 1.0 : 0.0);
+        double v1 = p1[c] * scale;
+        if (r0 > c) p0[c] = v0;
+        if (r0 == c) p0[c] = beta;
+        p1[c] = v1;
+        if (tau != 0.0) {
+            // ---- all dots v . P(:, j), j != c, at once ----
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                if (j == c) continue;
+                // for j < c the column holds V(:, j): rows <= j are not part of it (R entries)
+                double a0 = p0[j];
+                if (j < c && r0 <= j) a0 = (r0 == j) ? 1.0 : 0.0;
+                double s = fma(v1, p1[j], v0 * a0);
+                s = rsum16(s);
+                if ((tid & 15) == 0) part[j * 16 + (tid >> 4)] = s;
+            }
+            __syncthreads();
+            if (tid < SB) {
+                double s = 0.0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) s += part[tid * 16 + q];
+                dots[tid] = s;
+            }
+            __syncthreads();
+            // ---- apply H_c to the columns right of c ----
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                if (j <= c) continue;
+                const double tw = tau * dots[j];
+                p0[j] = fma(-tw, v0, p0[j]);
+                p1[j] = fma(-tw, v1, p1[j]);
+            }
+        }
+        if (tid <= c) {  // T(0:c, c) = -tau T(0:c,0:c) z ; T(c,c) = tau
+            double t = 0.0;
+            if (tid == c) {
+                t = tau;
+            } else if (tau != 0.0) {
+                for (int j = tid; j < c; ++j) t = fma(Ts[j * SB + tid], dots[j], t);
+                t = -tau * t;
+            }
+            Ts[c * SB + tid] = t;
+        }
+        __syncthreads();
+        }
+    }
+    for (int i = tid; i < SB * SB; i += 256) T[i] = Ts[i];
+#pragma unroll
+    for (int c = 0; c < SB; ++c) {
+        if (r0 < np) Pg[(size_t)c * n + r0] = p0[c];
+        if (r1 < np) Pg[(size_t)c * n + r1] = p1[c];
     }
 }
 
@@ -421,21 +539,6 @@ struct BandRef {
     __device__ inline double sym(int i, int j) const { return i >= j ? p[(size_t)j * LDB + (i - j)] : p[(size_t)i * LDB + (j - i)]; }
 };
 
-// 16-lane all-reduce with DPP row rotations (no LDS crossbar): {8,4,2,1} rotations cover the row
-template <int CTRL>
-__device__ inline double dpp_rot(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ inline double rsum16(double v) {
-    v += dpp_rot<0x128>(v);  // row_ror:8
-    v += dpp_rot<0x124>(v);  // row_ror:4
-    v += dpp_rot<0x122>(v);  // row_ror:2
-    v += dpp_rot<0x121>(v);  // row_ror:1
-    return v;
-}
 __device__ inline void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
 constexpr int HAND = 4 * SB + 2;  // per-wave LDS scratch: vprev[SB], tau, pad, sv[SB], sw[SB], sx[SB]
@@ -769,7 +872,10 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b) {
     for (int k0 = 0; nmax - k0 - SB >= 2; k0 += SB) {
         const int npmax = nmax - k0 - SB;
         if (prof) profiler().begin(s);
-        if ((size_t)npmax * SB * sizeof(double) <= 96 * 1024)
+        if (npmax <= 512)
+            hipLaunchKernelGGL(sbr_qr_reg_kernel, dim3(b.count), dim3(256), 0, s, k0, b.n.p, b.moff.p,
+                               b.voff.p, b.W.p, b.Tfac.p);
+        else if ((size_t)npmax * SB * sizeof(double) <= 96 * 1024)
             hipLaunchKernelGGL((sbr_qr_kernel<256, true>), dim3(b.count), dim3(256),
                                (size_t)npmax * SB * sizeof(double), s, k0, b.n.p, b.moff.p, b.voff.p,
                                b.W.p, b.Tfac.p);

@@ -359,16 +359,22 @@ __global__ __launch_bounds__(RAP_NT) void rap_symbolic_kernel(
         if (threadIdx.x == 0) cnt[m1] = nfound;
         return;
     }
-    // pass 1: rank every entry among the others (lists are short) and write in order
-    int *out = nbr + nbr_ptr[m1];
+    // pass 1: compact the table into a short list, then rank inside the list and write in order
+    __shared__ int list[RAP_HASH];
+    __shared__ int nlist;
+    if (threadIdx.x == 0) nlist = 0;
+    __syncthreads();
     for (int i = threadIdx.x; i < RAP_HASH; i += RAP_NT) {
         const int v = table[i];
-        if (v < 0) continue;
+        if (v >= 0) list[atomicAdd(&nlist, 1)] = v;
+    }
+    __syncthreads();
+    const int nl = nlist;
+    int *out = nbr + nbr_ptr[m1];
+    for (int i = threadIdx.x; i < nl; i += RAP_NT) {
+        const int v = list[i];
         int rank = 0;
-        for (int j = 0; j < RAP_HASH; ++j) {
-            const int w = table[j];
-            rank += (w >= 0 && w < v);
-        }
+        for (int j = 0; j < nl; ++j) rank += (list[j] < v);
         out[rank] = v;
     }
 }
