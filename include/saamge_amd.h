@@ -41,9 +41,21 @@ typedef struct saamge_amd_params {
     int coarse_max_iter;
     long long workspace_bytes;                /* dense AE matrices are processed in chunks of this size (default 32 GiB) */
     int keep_debug;                           /* keep eigenpairs / singular values for inspection */
+    /* Multi-GPU, one process per GPU (reference: MPI ranks, src/process.cpp).  Every rank passes
+     * the SAME global problem; the AEs of each level are split into `world` contiguous ranges,
+     * a rank solves the local spectral problems (src/interp.cpp:387-556) of its range only and
+     * the eigenvectors are all-gathered in place through `allgather` (buf is a device pointer;
+     * rank r owns bytes [byte_off[r], byte_off[r+1]); return 0 on success).  The bench/tests
+     * implement it with torch.distributed (nccl = RCCL on ROCm, gloo for rehearsals). */
+    int rank, world;
+    int (*allgather)(void *ctx, void *buf_dev, const long long *byte_off);
+    void *allgather_ctx;
 } saamge_amd_params;
 
 void saamge_amd_params_default(saamge_amd_params *p);
+/* hipMemcpy(hipMemcpyDefault) helper for all-gather callbacks written outside C (host or device
+ * pointers on either side) */
+int saamge_amd_memcpy(void *dst, const void *src, long long bytes);
 const char *saamge_amd_last_error(void);
 
 /* ml_produce_data (inc/ml.hpp:192-194, src/ml.cpp:379-472) on raw arrays:

@@ -21,8 +21,10 @@ SYMBOLS = [
     "saamge_amd_num_levels", "saamge_amd_level_info", "saamge_amd_get_csr", "saamge_amd_get_table",
     "saamge_amd_get_mis", "saamge_amd_get_ae_eigens", "saamge_amd_get_mis_svd", "saamge_amd_spmv",
     "saamge_amd_lower_eigens_batched", "saamge_amd_profile_enable", "saamge_amd_profile_reset",
-    "saamge_amd_profile_count", "saamge_amd_profile_get",
+    "saamge_amd_profile_count", "saamge_amd_profile_get", "saamge_amd_memcpy",
 ]
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong))
 
 
 class Params(C.Structure):
@@ -38,6 +40,10 @@ class Params(C.Structure):
         ("coarse_max_iter", C.c_int),
         ("workspace_bytes", C.c_longlong),
         ("keep_debug", C.c_int),
+        ("rank", C.c_int),
+        ("world", C.c_int),
+        ("allgather", ALLGATHER_FN),
+        ("allgather_ctx", C.c_void_p),
     ]
 
 
@@ -97,9 +103,15 @@ class Hierarchy(object):
     sequence: ml_produce_data -> VCycleSolver::Mult / CGSolver::Mult -> ml_free_data."""
 
     def __init__(self, A_rowptr, A_col, A_val, n, elem_to_dof, elmat, bdr, partitions, nparts,
-                 params, NE, nde, stream=0):
+                 params, NE, nde, stream=0, group=None):
         lib = load()
         self._keep = (A_rowptr, A_col, A_val, elem_to_dof, elmat, bdr, partitions)
+        if group is not None and group.world > 1:
+            # distributed setup: this rank solves the eigenproblems of its AE range only
+            self._cb = group.allgather_callback()
+            params.rank = group.rank
+            params.world = group.world
+            params.allgather = self._cb
         parts = (C.c_void_p * len(partitions))(*[_ptr(p).value for p in partitions])
         npa = (C.c_int * len(nparts))(*[int(x) for x in nparts])
         h = C.c_void_p()
@@ -112,7 +124,7 @@ class Hierarchy(object):
         self.testmesh = bool(params.testmesh)
 
     @classmethod
-    def from_problem(cls, prob, params, stream=0):
+    def from_problem(cls, prob, params, stream=0, group=None):
         """Build from a saamge_amd.problems.Problem (host numpy arrays)."""
         A = prob.A.tocsr()
         rowptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
@@ -124,7 +136,7 @@ class Hierarchy(object):
         parts = [np.ascontiguousarray(p, dtype=np.int32) for p in prob.partitions[:params.num_coarsenings]]
         nparts = [int(p.max()) + 1 for p in parts]
         return cls(rowptr, col, val, A.shape[0], e2d, elmat, bdr, parts, nparts, params,
-                   e2d.shape[0], e2d.shape[1], stream)
+                   e2d.shape[0], e2d.shape[1], stream, group)
 
     def close(self):
         if self.h:

@@ -45,6 +45,20 @@ void saamge_amd_params_default(saamge_amd_params *p) {
     p->coarse_max_iter = 2000;
     p->workspace_bytes = (long long)32 << 30;
     p->keep_debug = 0;
+    p->rank = 0;
+    p->world = 1;
+    p->allgather = nullptr;
+    p->allgather_ctx = nullptr;
+}
+
+int saamge_amd_memcpy(void *dst, const void *src, long long bytes) {
+    if (bytes <= 0) return 0;
+    if (hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDefault) != hipSuccess) {
+        g_last_error = "saamge_amd_memcpy failed";
+        (void)hipGetLastError();
+        return 2;
+    }
+    return 0;
 }
 
 int saamge_amd_ml_produce_data(int n, const int *rowptr, const int *col, const double *val,
@@ -70,6 +84,11 @@ int saamge_amd_ml_produce_data(int n, const int *rowptr, const int *col, const d
     p.coarse_max_iter = params->coarse_max_iter;
     p.workspace_bytes = (size_t)params->workspace_bytes;
     p.keep_debug = params->keep_debug;
+    p.rank = params->rank;
+    p.world = params->world > 1 ? params->world : 1;
+    p.allgather = params->allgather;
+    p.allgather_ctx = params->allgather_ctx;
+    SA_REQUIRE(p.world == 1 || (p.rank >= 0 && p.rank < p.world), "bad rank");
     Hierarchy *H = hierarchy_create(n, rowptr, col, val, NE, nde, elem_to_dof, elmat, bdr_dofs,
                                     partitions, nparts, p, (hipStream_t)stream);
     *out = new saamge_amd_hierarchy{H};

@@ -27,6 +27,13 @@ struct Params {                 // MultilevelParameters (amg/inc/ml.hpp:59-114)
     int coarse_max_iter = 2000;
     size_t workspace_bytes = (size_t)32 << 30;  // dense AE matrices are processed in chunks of this size
     int keep_debug = 0;         // keep per-AE eigenpairs / per-MIS data for parity tests
+    // multi-GPU (one process per GPU): the AEs of every level are split into `world` contiguous
+    // ranges; a rank solves the local eigenproblems of its range only and the results are
+    // all-gathered in place through `allgather` (buf is a device pointer, rank r's part is
+    // [byte_off[r], byte_off[r+1]) ).  Everything else is replicated.
+    int rank = 0, world = 1;
+    int (*allgather)(void *ctx, void *buf_dev, const long long *byte_off) = nullptr;
+    void *allgather_ctx = nullptr;
 };
 
 struct Level {                  // tg_data_t + interp_data_t + agg_partitioning_relations_t

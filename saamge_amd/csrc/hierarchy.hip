@@ -108,11 +108,32 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     struct Chunk { int ae0, count; DBuf<double> evals, evecs; std::vector<int64_t> eoff, xoff; };
     std::vector<Chunk> chunks;
     if (P.keep_debug) L.ae_D.alloc((size_t)rel.AE_to_dof.J.size());
+    // AE ownership: contiguous ranges balanced by the n^3 cost of the eigenproblems
+    const int world = P.world > 1 ? P.world : 1;
+    std::vector<int> ae_begin((size_t)world + 1, nparts);
+    {
+        double total = 0.0;
+        for (int p = 0; p < nparts; ++p) total += (double)sizes[p] * sizes[p] * sizes[p];
+        double run = 0.0;
+        int r = 0;
+        ae_begin[0] = 0;
+        for (int p = 0; p < nparts && r + 1 < world; ++p) {
+            run += (double)sizes[p] * sizes[p] * sizes[p];
+            while (r + 1 < world && run >= total * (r + 1) / world) ae_begin[++r] = p + 1;
+        }
+        ae_begin[world] = nparts;
+    }
+    if (world > 1) {
+        SA_REQUIRE(P.allgather != nullptr, "world > 1 needs an all-gather callback");
+        SA_REQUIRE(!(P.testmesh && lev == 0), "the mltest fixture is single-rank only");
+    }
+    const int ae_lo = ae_begin[world > 1 ? P.rank : 0], ae_hi = ae_begin[world > 1 ? P.rank + 1 : 1];
     int64_t row0 = 0;
-    for (int ae0 = 0; ae0 < nparts;) {
+    for (int p = 0; p < ae_lo; ++p) row0 += sizes[p];
+    for (int ae0 = ae_lo; ae0 < ae_hi;) {
         size_t bytes = 0;
         int cnt = 0;
-        while (ae0 + cnt < nparts) {
+        while (ae0 + cnt < ae_hi) {
             const size_t add = eig_workspace_bytes(sizes[ae0 + cnt]);
             if (cnt > 0 && bytes + add > P.workspace_bytes) break;
             bytes += add;
@@ -150,6 +171,15 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         ae0 += cnt;
     }
     tm.lap("local eigenproblems", lev);
+    if (world > 1) {   // exchange the number of eigenvectors per AE
+        DBuf<int> d_m;
+        d_m.from_host(L.ae_m, s);
+        std::vector<long long> off((size_t)world + 1);
+        for (int r = 0; r <= world; ++r) off[r] = 4ll * ae_begin[r];
+        SA_REQUIRE(P.allgather(P.allgather_ctx, d_m.p, off.data()) == 0, "all-gather (counts) failed");
+        auto t_ = d_m.to_host(s);
+        L.ae_m.assign(t_.begin(), t_.end());
+    }
     // concatenate (+ the mltest fixture's extra all-ones vector on AE 0 of the finest level)
     const bool extra = (P.testmesh && lev == 0);
     L.ae_xoff.assign((size_t)nparts + 1, 0);
@@ -182,6 +212,22 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     SA_HIP_CHECK(hipStreamSynchronize(s));
     chunks.clear();
     L.ae_m = m_tot;
+    if (world > 1) {   // all-gather the eigenvectors (and, for inspection, eigenvalues and D) in place
+        std::vector<long long> off((size_t)world + 1);
+        for (int r = 0; r <= world; ++r) off[r] = 8ll * L.ae_xoff[ae_begin[r]];
+        SA_REQUIRE(P.allgather(P.allgather_ctx, L.evecs.p, off.data()) == 0, "all-gather (eigenvectors) failed");
+        if (P.keep_debug) {
+            for (int r = 0; r <= world; ++r) off[r] = 8ll * L.ae_eoff[ae_begin[r]];
+            SA_REQUIRE(P.allgather(P.allgather_ctx, L.evals.p, off.data()) == 0, "all-gather (eigenvalues) failed");
+            int64_t rows = 0;
+            std::vector<int64_t> rowoff((size_t)nparts + 1, 0);
+            for (int p = 0; p < nparts; ++p) rowoff[p + 1] = rowoff[p] + sizes[p];
+            (void)rows;
+            for (int r = 0; r <= world; ++r) off[r] = 8ll * rowoff[ae_begin[r]];
+            SA_REQUIRE(P.allgather(P.allgather_ctx, L.ae_D.p, off.data()) == 0, "all-gather (D) failed");
+        }
+        tm.lap("all-gather eigenvectors", lev);
+    }
 
     // ---- MIS stage (ContribTent::contrib_mises) ----
     mis_thread.join();

@@ -24,6 +24,7 @@ def test_params_struct_matches_header_defaults():
     p = capi.default_params()
     assert p.num_coarsenings == 1 and abs(p.theta[0] - 0.003) < 1e-15 and p.nu_relax[0] == 3
     assert p.avoid_ess_bdr_dofs == 1 and p.nu_pro[0] == 0 and p.workspace_bytes == 32 << 30
+    assert p.world == 1 and p.rank == 0
 
 
 def test_product_has_no_oracle_dependency():
