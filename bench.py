@@ -55,10 +55,10 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_problem(n, levels, dev):
+def build_problem(n, levels, dev, aniso=1.0):
     from saamge_amd import problems
     cb = [(8, 8, 4)] * (levels - 2)
-    return problems.poisson3d_device(n, blk=(8, 8, 4), coarse_blk=cb, device=dev)
+    return problems.poisson3d_device(n, blk=(8, 8, 4), coarse_blk=cb, K=(1.0, 1.0, aniso), device=dev)
 
 
 def one_step(capi, prob, params, rel_tol=1e-8, group=None):
@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", "--n", dest="n", type=int, default=256)
     ap.add_argument("--levels", type=int, default=3)
+    ap.add_argument("--theta", type=float, default=0.003)
+    ap.add_argument("--aniso", type=float, default=1.0, help="K = diag(1, 1, aniso) (BASELINE config 4: 1000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -126,9 +128,9 @@ def main():
     grp = Group(backend=os.environ.get("SAAMGE_AMD_DIST_BACKEND", "nccl"), device=dev)
     world, rank = grp.world, grp.rank
 
-    prob = build_problem(args.n, args.levels, dev)
+    prob = build_problem(args.n, args.levels, dev, args.aniso)
     torch.cuda.synchronize()
-    params = capi.default_params(num_coarsenings=args.levels - 1, theta=0.003, nu_relax=3)
+    params = capi.default_params(num_coarsenings=args.levels - 1, theta=args.theta, nu_relax=3)
 
     its = conv = None
     for _ in range(args.warmup):
@@ -165,8 +167,10 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "3D Poisson %d^3 Q1 hexes, %d-level SAAMGE, theta=0.003, nu_relax=3, "
-                               "8x8x4-element AEs" % (args.n, args.levels),
+        "config": {"workload": "3D Poisson %d^3 Q1 hexes%s, %d-level SAAMGE, theta=%g, nu_relax=3, "
+                               "8x8x4-element AEs" % (args.n, "" if args.aniso == 1.0 else
+                                                       " K=diag(1,1,%g)" % args.aniso, args.levels, args.theta),
+                   "eigenvectors_per_AE": [round(i["nvec"] / max(i["nparts"], 1), 2) for i in infos],
                    "dofs": prob.n, "pcg_iterations": its, "converged": bool(conv),
                    "true_relative_residual": relres,
                    "level_dims": [i["n"] for i in infos] + [infos[-1]["ncoarse"]],

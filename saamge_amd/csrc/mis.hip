@@ -49,7 +49,14 @@ __global__ __launch_bounds__(64) void mis_svd_kernel(
         }
         return;
     }
-    // gather + boundary filter + normalisation (contrib.cpp:102-163, xpacks.cpp:537-559)
+    // gather + boundary filter + normalisation (contrib.cpp:102-163, xpacks.cpp:537-559).
+    // Tall blocks (ctot <= r) are stored column-major r x c and orthogonalised by columns; wide
+    // blocks (more candidate vectors than dofs: edge/vertex MISes, many eigenvectors per AE) are
+    // stored row-major with leading dimension ctot and orthogonalised by ROWS (Jacobi on M^T,
+    // r(r-1)/2 pairs instead of c(c-1)/2), accumulating the rotations: M^T V = W Sigma, so the
+    // left singular vectors of M are the columns of V.
+    const bool wide = ctot > r;
+    const size_t sr = wide ? (size_t)ctot : 1, sc = wide ? 1 : (size_t)r;  // strides of M(i, j)
     int c = 0;
     for (int q = mis2ae_I[m]; q < mis2ae_I[m + 1]; ++q) {
         const int ae = mis2ae_J[q];
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(64) void mis_svd_kernel(
         const double *X = io.evecs + io.ae_xoff[ae];
         const int *loc = pair_loc + pair_loc_off[q];
         for (int v = 0; v < ma; ++v) {
-            double *col = M + (size_t)c * r;
+            double *col = M + (size_t)c * sc;
             double ss = 0.0;
             int nz = 0;
             for (int i = lane; i < r; i += 64) {
@@ -66,13 +73,13 @@ __global__ __launch_bounds__(64) void mis_svd_kernel(
                 if (io.avoid_ess && (flags[dofs[i]] & FLAG_ON_ESS_BORDER)) x = 0.0;
                 nz |= (x != 0.0);
                 ss = fma(x, x, ss);
-                col[i] = x;
+                col[i * sr] = x;
             }
             if (__ballot(nz) == 0ull) continue;  // entirely zero column: ignored
             const double nrm = sqrt(wsum(ss));
             if (nrm <= 1e-10) continue;          // SA_REAL_ALMOST_LE(norm, 0.)
-            const double sc = 1.0 / nrm;
-            for (int i = lane; i < r; i += 64) col[i] *= sc;
+            const double scl = 1.0 / nrm;
+            for (int i = lane; i < r; i += 64) col[i * sr] *= scl;
             ++c;
         }
     }
@@ -81,16 +88,22 @@ __global__ __launch_bounds__(64) void mis_svd_kernel(
         if (lane == 0) io.k[m] = 0;
         return;
     }
-    // one-sided Jacobi: rotate column pairs until mutually orthogonal
-    const double tol = DBL_EPSILON * sqrt((double)r);
+    // one-sided Jacobi: rotate vector pairs until mutually orthogonal
+    const int nv = wide ? r : c;       // vectors being orthogonalised
+    const int len = wide ? c : r;      // their length
+    const size_t ldv = wide ? (size_t)ctot : (size_t)r;
+    double *V = Uout;                  // wide only: r x r accumulated rotations
+    if (wide)
+        for (int idx = lane; idx < r * r; idx += 64) V[idx] = (idx / r == idx % r) ? 1.0 : 0.0;
+    const double tol = DBL_EPSILON * sqrt((double)len);
     for (int sweep = 0; sweep < 60; ++sweep) {
         int rotated = 0;
-        for (int p = 0; p < c - 1; ++p) {
-            double *ap = M + (size_t)p * r;
-            for (int q = p + 1; q < c; ++q) {
-                double *aq = M + (size_t)q * r;
+        for (int p = 0; p < nv - 1; ++p) {
+            double *ap = M + (size_t)p * ldv;
+            for (int q = p + 1; q < nv; ++q) {
+                double *aq = M + (size_t)q * ldv;
                 double al = 0.0, be = 0.0, ga = 0.0;
-                for (int i = lane; i < r; i += 64) {
+                for (int i = lane; i < len; i += 64) {
                     const double x = ap[i], y = aq[i];
                     al = fma(x, x, al);
                     be = fma(y, y, be);
@@ -103,28 +116,36 @@ __global__ __launch_bounds__(64) void mis_svd_kernel(
                 const double zeta = (be - al) / (2.0 * ga);
                 const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                 const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
-                for (int i = lane; i < r; i += 64) {
+                for (int i = lane; i < len; i += 64) {
                     const double x = ap[i], y = aq[i];
                     ap[i] = cs * x - sn * y;
                     aq[i] = sn * x + cs * y;
+                }
+                if (wide) {
+                    double *vp = V + (size_t)p * r, *vq = V + (size_t)q * r;
+                    for (int i = lane; i < r; i += 64) {
+                        const double x = vp[i], y = vq[i];
+                        vp[i] = cs * x - sn * y;
+                        vq[i] = sn * x + cs * y;
+                    }
                 }
             }
         }
         if (!rotated) break;
     }
-    // singular values = column norms; order descending (stable)
-    for (int j = 0; j < c; ++j) {
-        const double *aj = M + (size_t)j * r;
+    // singular values = vector norms; order descending (stable)
+    for (int j = 0; j < nv; ++j) {
+        const double *aj = M + (size_t)j * ldv;
         double ss = 0.0;
-        for (int i = lane; i < r; i += 64) ss = fma(aj[i], aj[i], ss);
+        for (int i = lane; i < len; i += 64) ss = fma(aj[i], aj[i], ss);
         ss = wsum(ss);
         if (lane == 0) sg[j] = sqrt(ss);
     }
     __syncthreads();
-    for (int j = lane; j < c; j += 64) {
+    for (int j = lane; j < nv; j += 64) {
         const double sj = sg[j];
         int rank = 0;
-        for (int i = 0; i < c; ++i) rank += (sg[i] > sj) || (sg[i] == sj && i < j);
+        for (int i = 0; i < nv; ++i) rank += (sg[i] > sj) || (sg[i] == sj && i < j);
         perm[rank] = j;
     }
     __syncthreads();
@@ -132,11 +153,20 @@ __global__ __launch_bounds__(64) void mis_svd_kernel(
     const int kmax = min(r, c);  // dgesvd returns min(m, n) singular triplets
     int k = 0;
     while (k < kmax && sg[perm[k]] > 1e-10 * s0) ++k;  // xpack_orth_set
-    for (int j = lane; j < c; j += 64) sigout[j] = sg[perm[j]];
-    for (int t = 0; t < k; ++t) {
-        const double *aj = M + (size_t)perm[t] * r;
-        const double inv = 1.0 / sg[perm[t]];
-        for (int i = lane; i < r; i += 64) Uout[(size_t)t * r + i] = aj[i] * inv;
+    for (int j = lane; j < ctot; j += 64) sigout[j] = (j < nv) ? sg[perm[j]] : 0.0;
+    if (wide) {
+        // V sits in the output buffer: park it in the (now free) gather block, then write the
+        // kept columns in descending-sigma order
+        for (int idx = lane; idx < r * r; idx += 64) M[idx] = V[idx];
+        __syncthreads();
+        for (int t = 0; t < k; ++t)
+            for (int i = lane; i < r; i += 64) Uout[(size_t)t * r + i] = M[(size_t)perm[t] * r + i];
+    } else {
+        for (int t = 0; t < k; ++t) {
+            const double *aj = M + (size_t)perm[t] * r;
+            const double inv = 1.0 / sg[perm[t]];
+            for (int i = lane; i < r; i += 64) Uout[(size_t)t * r + i] = aj[i] * inv;
+        }
     }
     if (lane == 0) io.k[m] = k;
 }
@@ -407,53 +437,60 @@ __global__ __launch_bounds__(RAP_NT) void rap_numeric_kernel(
     __syncthreads();
     const int ncol = pos[nn];
     double *acc = lds + pos_d;
-    double *T = acc + (size_t)k1 * ncol;
-    const int RC = (lds_doubles - pos_d - k1 * ncol) / ncol;  // rows per chunk (host guarantees >= 1)
-    for (int i = tid; i < k1 * ncol; i += RAP_NT) acc[i] = 0.0;
+    // LDS rows of ncol doubles: KC accumulator rows + RC rows of T = (A U)[chunk of MIS rows].
+    // Normally KC = k1; a very wide block (many eigenvectors per AE) is done in several passes
+    // over the output rows, recomputing T for each (host guarantees >= 2 rows).
+    const int rows_total = (lds_doubles - pos_d) / ncol;
+    const int KC = (k1 + 1 <= rows_total) ? k1 : rows_total / 2;
+    const int RC = rows_total - KC;
+    double *T = acc + (size_t)KC * ncol;
     // column indices of the k1 output rows
     for (int idx = tid; idx < k1 * ncol; idx += RAP_NT) {
         const int v1 = idx / ncol, cc = idx % ncol;
-        int t = 0;  // neighbour owning local column cc
-        int lo = 0, hi = nn;
+        int lo = 0, hi = nn;  // neighbour owning local column cc
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pos[mid] <= cc) lo = mid; else hi = mid; }
-        t = lo;
-        ccol[crowptr[coloff[m1] + v1] + cc] = coloff[nb[t]] + (cc - pos[t]);
+        ccol[crowptr[coloff[m1] + v1] + cc] = coloff[nb[lo]] + (cc - pos[lo]);
     }
-    for (int c0 = 0; c0 < r1; c0 += RC) {
-        const int rc = min(RC, r1 - c0);
+    for (int v0 = 0; v0 < k1; v0 += KC) {
+        const int kc = min(KC, k1 - v0);
         __syncthreads();
-        for (int i = tid; i < rc * ncol; i += RAP_NT) T[i] = 0.0;
-        __syncthreads();
-        for (int il = tid; il < rc; il += RAP_NT) {
-            const int g = dofs[c0 + il];
-            double *Trow = T + (size_t)il * ncol;
-            for (int q = Arow[g]; q < Arow[g + 1]; ++q) {
-                const int j = Acol[q];
-                const int m2 = mises[j];
-                const int k2 = k[m2];
-                if (k2 == 0) continue;
-                int lo = 0, hi = nn;
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (nb[mid] <= m2) lo = mid; else hi = mid; }
-                const int r2 = mis2d_I[m2 + 1] - mis2d_I[m2];
-                const double *U2 = U + u_off[m2] + row_in_mis[j];
-                const double a = Aval[q];
-                double *dst = Trow + pos[lo];
-                for (int v = 0; v < k2; ++v) dst[v] = fma(a, U2[(size_t)v * r2], dst[v]);
+        for (int i = tid; i < kc * ncol; i += RAP_NT) acc[i] = 0.0;
+        for (int c0 = 0; c0 < r1; c0 += RC) {
+            const int rc = min(RC, r1 - c0);
+            __syncthreads();
+            for (int i = tid; i < rc * ncol; i += RAP_NT) T[i] = 0.0;
+            __syncthreads();
+            for (int il = tid; il < rc; il += RAP_NT) {
+                const int g = dofs[c0 + il];
+                double *Trow = T + (size_t)il * ncol;
+                for (int q = Arow[g]; q < Arow[g + 1]; ++q) {
+                    const int j = Acol[q];
+                    const int m2 = mises[j];
+                    const int k2 = k[m2];
+                    if (k2 == 0) continue;
+                    int lo = 0, hi = nn;
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (nb[mid] <= m2) lo = mid; else hi = mid; }
+                    const int r2 = mis2d_I[m2 + 1] - mis2d_I[m2];
+                    const double *U2 = U + u_off[m2] + row_in_mis[j];
+                    const double a = Aval[q];
+                    double *dst = Trow + pos[lo];
+                    for (int v = 0; v < k2; ++v) dst[v] = fma(a, U2[(size_t)v * r2], dst[v]);
+                }
+            }
+            __syncthreads();
+            for (int idx = tid; idx < kc * ncol; idx += RAP_NT) {
+                const int v1 = idx / ncol, cc = idx % ncol;
+                double sum = acc[idx];
+                const double *u = U1 + (size_t)(v0 + v1) * r1 + c0;
+                for (int il = 0; il < rc; ++il) sum = fma(u[il], T[(size_t)il * ncol + cc], sum);
+                acc[idx] = sum;
             }
         }
         __syncthreads();
-        for (int idx = tid; idx < k1 * ncol; idx += RAP_NT) {
+        for (int idx = tid; idx < kc * ncol; idx += RAP_NT) {
             const int v1 = idx / ncol, cc = idx % ncol;
-            double sum = acc[idx];
-            const double *u = U1 + (size_t)v1 * r1 + c0;
-            for (int il = 0; il < rc; ++il) sum = fma(u[il], T[(size_t)il * ncol + cc], sum);
-            acc[idx] = sum;
+            cval[crowptr[coloff[m1] + v0 + v1] + cc] = acc[idx];
         }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < k1 * ncol; idx += RAP_NT) {
-        const int v1 = idx / ncol, cc = idx % ncol;
-        cval[crowptr[coloff[m1] + v1] + cc] = acc[idx];
     }
 }
 
@@ -497,7 +534,10 @@ void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, cons
             crow[(size_t)h_coloff[m] + v + 1] = ncol;
             nnz += ncol;
         }
-        const size_t need = (size_t)(h_cnt[m] + 3) / 2 + (size_t)h_k[m] * ncol + (size_t)ncol;  // >= 1 row of T
+        // all k rows of the block + 1 row of T if that fits 160 KiB, else 2 rows (multi-pass)
+        size_t need = (size_t)(h_cnt[m] + 3) / 2 + (size_t)(h_k[m] + 1) * ncol;
+        const size_t cap = 160 * 1024 / 8;
+        if (need > cap) need = std::max((size_t)(h_cnt[m] + 3) / 2 + 2 * (size_t)ncol, std::min(need, cap));
         if (need > need_max) need_max = need;
     }
     SA_REQUIRE(nnz < (int64_t)1 << 31, "coarse operator too large for 32-bit indices");

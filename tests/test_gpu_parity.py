@@ -219,12 +219,14 @@ def test_mltest_fixture_matches_oracle(order, levels):
     ((8, 8, 8), (4, 4, 2), None, (1, 1, 1)),
     ((8, 8, 8), (4, 4, 4), [(2, 2, 1)], (1, 1, 1)),
     ((12, 8, 4), (4, 4, 2), None, (1, 1, 1000.0)),
+    # 64 eigenvectors on the interior AEs: wide MIS blocks (row-wise Jacobi SVD) and multi-pass RAP blocks
+    ((16, 16, 16), (8, 8, 4), None, (1, 1.3, 1000.0001)),
 ])
 def test_poisson3d_matches_oracle(n, blk, cblk, K):
     o = _oracle()
     prob = pr.poisson3d_problem(n, blk=blk, coarse_blk=cblk, K=K)
     ncoars = 1 + (len(cblk) if cblk else 0)
-    theta = 0.003 if K[2] == 1 else 0.02
+    theta = 0.003 if K[2] in (1, 1000.0001) else 0.02
     h, H = _build_pair(prob, ncoars, theta=theta)
     for lev in range(ncoars):
         _compare_level(h, H, lev, theta, strict=False)
@@ -233,14 +235,18 @@ def test_poisson3d_matches_oracle(n, blk, cblk, K):
     x_ref = o.vcycle(H, b)
     # degenerate eigenspaces (symmetric AEs) make the coarse *basis* non-unique; with two
     # levels the V-cycle is invariant to it, with three the level-1 smoother is not.
-    tol = VCYCLE_TOL if ncoars == 1 else 5e-2
+    # The 64-vector case keeps singular directions down to 1e-10 sigma_0 on rank-deficient MIS
+    # blocks; those directions are round-off (LAPACK's differs from ours), so the coarse spaces
+    # agree only to ~1e-8 there.
+    many = K[2] == 1000.0001
+    tol = (1e-6 if many else VCYCLE_TOL) if ncoars == 1 else 5e-2
     assert np.linalg.norm(x_gpu - x_ref) <= tol * np.linalg.norm(x_ref)
     x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-8)
     xr, itr, convr, histr = o.solve(H, prob.b, rel_tol=1e-8)
     assert conv and convr
     if ncoars == 1:
         assert it == itr
-        assert np.allclose(hist, histr, rtol=1e-7, atol=1e-10 * histr[0])
+        assert np.allclose(hist, histr, rtol=1e-4 if many else 1e-7, atol=1e-10 * histr[0])
     else:
         assert abs(it - itr) <= 1
     assert np.linalg.norm(prob.A @ x - prob.b) <= 1e-6 * np.linalg.norm(prob.b)
