@@ -288,6 +288,78 @@ def poisson3d_problem(n, blk=(8, 8, 4), K=(1.0, 1.0, 1.0), coarse_blk=None,
 # --------------------------------------------------------------------------
 # device-resident generator (torch is plumbing: it only allocates/fills HBM)
 # --------------------------------------------------------------------------
+def hex_elasticity_matrix(h, lam=1.0, mu=1.0):
+    """24 x 24 stiffness of isotropic linear elasticity on an h[0] x h[1] x h[2] trilinear hex
+    (2x2x2 Gauss, exact for the box), vertex order _HEX_LOC, dofs ordered byVDIM
+    (3*vertex + component; the ordering of the reference's elasticity driver,
+    amg/src/fem.cpp:493-504)."""
+    g = np.array([-1.0, 1.0]) / np.sqrt(3.0)
+    sgn = np.array([[2 * a - 1, 2 * b - 1, 2 * c - 1] for (a, b, c) in _HEX_LOC], dtype=float)
+    C = np.zeros((6, 6))
+    C[:3, :3] = lam
+    C[np.arange(3), np.arange(3)] += 2 * mu
+    C[np.arange(3, 6), np.arange(3, 6)] = mu
+    Ke = np.zeros((24, 24))
+    detJ = h[0] * h[1] * h[2] / 8.0
+    for xi in g:
+        for eta in g:
+            for zeta in g:
+                pt = np.array([xi, eta, zeta])
+                dN = np.zeros((8, 3))
+                for a in range(8):
+                    f = 1.0 + sgn[a] * pt
+                    dN[a, 0] = sgn[a, 0] * f[1] * f[2] / 8.0 * (2.0 / h[0])
+                    dN[a, 1] = sgn[a, 1] * f[0] * f[2] / 8.0 * (2.0 / h[1])
+                    dN[a, 2] = sgn[a, 2] * f[0] * f[1] / 8.0 * (2.0 / h[2])
+                B = np.zeros((6, 24))
+                for a in range(8):
+                    dx, dy, dz = dN[a]
+                    B[0, 3 * a] = dx
+                    B[1, 3 * a + 1] = dy
+                    B[2, 3 * a + 2] = dz
+                    B[3, 3 * a], B[3, 3 * a + 1] = dy, dx
+                    B[4, 3 * a + 1], B[4, 3 * a + 2] = dz, dy
+                    B[5, 3 * a], B[5, 3 * a + 2] = dz, dx
+                Ke += detJ * (B.T @ C @ B)
+    return 0.5 * (Ke + Ke.T)
+
+
+def elasticity3d_problem(n, blk=(4, 4, 4), lam=1.0, mu=1.0, coarse_blk=None):
+    """Unit cube of n Q1 hexes, 3 displacement components per vertex (byVDIM), clamped on the
+    face x = 0, body force (0, 0, -1): the vector-dof workload of the reference's elasticity
+    drivers (lambda = mu = 1, amg/test/mltest/mltest.cpp:581).  AEs away from the clamped face
+    carry the six rigid-body modes as exact zero eigenvalues."""
+    if np.isscalar(n):
+        n = (int(n),) * 3
+    nx, ny, nz = n
+    h = (1.0 / nx, 1.0 / ny, 1.0 / nz)
+    nvx, nvy, nvz = nx + 1, ny + 1, nz + 1
+    NV = nvx * nvy * nvz
+    ND = 3 * NV
+    NE = nx * ny * nz
+    ez, ey, ex = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    ex, ey, ez = ex.ravel(), ey.ravel(), ez.ravel()
+    vid = lambda i, j, k: (k * nvy + j) * nvx + i
+    e2v = np.stack([vid(ex + a, ey + b_, ez + c) for (a, b_, c) in _HEX_LOC], axis=1)
+    elem_to_dof = (3 * e2v[:, :, None] + np.arange(3)[None, None, :]).reshape(NE, 24).astype(np.int32)
+    Kref = hex_elasticity_matrix(h, lam, mu)
+    elmat = np.ascontiguousarray(np.broadcast_to(Kref, (NE, 24, 24)))
+    A0 = _assemble(ND, elem_to_dof, elmat)
+    b0 = np.zeros(ND)
+    np.add.at(b0, elem_to_dof[:, 2::3].ravel(), -h[0] * h[1] * h[2] / 8.0)
+    iz, iy, ix = np.meshgrid(np.arange(nvz), np.arange(nvy), np.arange(nvx), indexing="ij")
+    ess = np.repeat((ix == 0).ravel(), 3)
+    A, b = _eliminate(A0, b0, ess)
+    bdr = (np.where(ess, AGG_ON_ESS_DOMAIN_BORDER_FLAG, 0) | AGG_OWNED_FLAG).astype(np.int8)
+    part0, nb = block_partition(n, blk)
+    parts = [part0]
+    for cb in (coarse_blk or []):
+        p, nb = block_partition(nb, cb)
+        parts.append(p)
+    return Problem(A=A, b=b, elem_to_dof=elem_to_dof, elmat=elmat, bdr=bdr, ess=ess,
+                   partitions=parts, dims=n, order=1, Kref=Kref, coefs=np.ones(NE))
+
+
 def poisson3d_device(n, blk=(8, 8, 4), coarse_blk=None, K=(1.0, 1.0, 1.0), device="cuda"):
     """Same problem as poisson3d_problem (constant coefficient), generated directly in
     HBM with torch so that 128^3 / 256^3 inputs never touch the host.  Returns a Problem

@@ -123,3 +123,20 @@ def test_table_algebra():
     B = o.Table.from_rows([[5, 4], [4, 3], [3, 5]], 6)
     C = o.table_mult(T, B)
     assert [list(C.row(i)) for i in range(4)] == [[3, 5, 4], [4, 3], [5, 4, 3], []]
+
+
+def test_elasticity_rigid_body_modes():
+    """Vector-dof workload: the element matrix has exactly the six rigid-body modes in its
+    kernel, AEs away from the clamped face keep six vectors, and the oracle PCG converges."""
+    from saamge_amd import problems as pr
+    from oracle import saamge_oracle as o
+    Ke = pr.hex_elasticity_matrix((0.5, 0.25, 1.0))
+    w = np.linalg.eigvalsh(Ke)
+    assert (np.abs(w) < 1e-12 * w.max()).sum() == 6 and w[6] > 1e-3
+    prob = pr.elasticity3d_problem((8, 6, 4), blk=(4, 3, 2))
+    H = o.ml_produce_data(prob.A, prob.elem_to_dof, prob.elmat, prob.bdr, prob.partitions[:1],
+                          theta=0.003, nu_relax=3)
+    assert [e.shape[1] for e in H.levels[0].evects] == [1, 6, 1, 6, 1, 6, 1, 6]
+    x, it, conv, hist = o.solve(H, prob.b, rel_tol=1e-8)
+    assert conv and it <= 8
+    assert np.linalg.norm(prob.A @ x - prob.b) <= 1e-6 * np.linalg.norm(prob.b)
