@@ -50,6 +50,22 @@ typedef struct saamge_amd_params {
     int rank, world;
     int (*allgather)(void *ctx, void *buf_dev, const long long *byte_off);
     void *allgather_ctx;
+    /* Row-partitioned solve (reference: HypreParMatrix::Mult's halo exchange in every operator
+     * application of src/tg.cpp:91-132, MPI_Allreduce of the inner products of
+     * src/mfem_addons.cpp:106-248).  When both callbacks are set, levels with at least
+     * dist_min_local_rows rows per rank are applied by contiguous row blocks: before each SpMV
+     * the interface entries of the input vector travel through `alltoallv` (device buffers; the
+     * part for / from rank r is [byte_off[r], byte_off[r+1]) ), inner products and the restricted
+     * residual are summed with `allreduce_sum`, coarse corrections and the final solution come
+     * back through `allgather`.  Smaller levels and the coarsest solve stay replicated.  Both
+     * callbacks receive allgather_ctx.  comm_stream_ordered != 0 promises that the callbacks
+     * enqueue their work on the hierarchy's stream (RCCL through torch.distributed on the same
+     * stream), so the library does not synchronise the stream around them. */
+    int (*allreduce_sum)(void *ctx, double *buf_dev, long long count);
+    int (*alltoallv)(void *ctx, const void *send_dev, const long long *send_byte_off, void *recv_dev,
+                     const long long *recv_byte_off);
+    long long dist_min_local_rows;            /* default 262144 */
+    int comm_stream_ordered;
 } saamge_amd_params;
 
 void saamge_amd_params_default(saamge_amd_params *p);
@@ -94,7 +110,8 @@ int saamge_amd_pcg(saamge_amd_hierarchy *h, const double *b, double *x, double r
 /* ---- inspection (ml_print_dims / tg_data_t field access, src/ml.cpp:296-355) ---- */
 int saamge_amd_num_levels(const saamge_amd_hierarchy *h); /* number of operators = coarsenings + 1 */
 /* info[0]=rows(A_l) [1]=nnz(A_l) [2]=nparts [3]=num_mises [4]=coarse dim [5]=nnz(P) [6]=nnz(Ac)
- * [7]=total eigenvectors [8]=inner PCG iterations of the last coarsest solve */
+ * [7]=total eigenvectors [8]=inner PCG iterations of the last coarsest solve
+ * [12]=1 if the level is row-partitioned [13]=first own row [14]=own rows [15]=halo entries received */
 int saamge_amd_level_info(const saamge_amd_hierarchy *h, int level, long long info[16]);
 /* which: 0 A_l, 1 interp, 2 restr, 3 Ac (host output buffers sized from level_info) */
 int saamge_amd_get_csr(const saamge_amd_hierarchy *h, int level, int which, int *rowptr, int *col,

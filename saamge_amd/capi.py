@@ -25,6 +25,9 @@ SYMBOLS = [
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong))
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_longlong)
+ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p,
+                           C.POINTER(C.c_longlong))
 
 
 class Params(C.Structure):
@@ -44,6 +47,10 @@ class Params(C.Structure):
         ("world", C.c_int),
         ("allgather", ALLGATHER_FN),
         ("allgather_ctx", C.c_void_p),
+        ("allreduce_sum", ALLREDUCE_FN),
+        ("alltoallv", ALLTOALLV_FN),
+        ("dist_min_local_rows", C.c_longlong),
+        ("comm_stream_ordered", C.c_int),
     ]
 
 
@@ -83,7 +90,7 @@ def _ptr(a):
 
 
 def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, keep_debug=False,
-                   coarse_rtol=1e-14, workspace_bytes=None):
+                   coarse_rtol=1e-14, workspace_bytes=None, dist_min_local_rows=None):
     p = Params()
     load().saamge_amd_params_default(C.byref(p))
     p.num_coarsenings = num_coarsenings
@@ -95,6 +102,8 @@ def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, k
     p.coarse_rtol = coarse_rtol
     if workspace_bytes is not None:
         p.workspace_bytes = int(workspace_bytes)
+    if dist_min_local_rows is not None:
+        p.dist_min_local_rows = int(dist_min_local_rows)
     return p
 
 
@@ -103,15 +112,20 @@ class Hierarchy(object):
     sequence: ml_produce_data -> VCycleSolver::Mult / CGSolver::Mult -> ml_free_data."""
 
     def __init__(self, A_rowptr, A_col, A_val, n, elem_to_dof, elmat, bdr, partitions, nparts,
-                 params, NE, nde, stream=0, group=None):
+                 params, NE, nde, stream=0, group=None, dist_solve=True):
         lib = load()
         self._keep = (A_rowptr, A_col, A_val, elem_to_dof, elmat, bdr, partitions)
         if group is not None and group.world > 1:
-            # distributed setup: this rank solves the eigenproblems of its AE range only
+            # distributed setup: this rank solves the eigenproblems of its AE range only;
+            # distributed solve: large levels are applied by row blocks with halo exchange
             self._cb = group.allgather_callback()
             params.rank = group.rank
             params.world = group.world
             params.allgather = self._cb
+            if dist_solve:
+                self._cb2 = group.solve_callbacks(stream)
+                params.allreduce_sum, params.alltoallv = self._cb2
+                params.comm_stream_ordered = int(group.stream_ordered(stream))
         parts = (C.c_void_p * len(partitions))(*[_ptr(p).value for p in partitions])
         npa = (C.c_int * len(nparts))(*[int(x) for x in nparts])
         h = C.c_void_p()
@@ -124,7 +138,7 @@ class Hierarchy(object):
         self.testmesh = bool(params.testmesh)
 
     @classmethod
-    def from_problem(cls, prob, params, stream=0, group=None):
+    def from_problem(cls, prob, params, stream=0, group=None, dist_solve=True):
         """Build from a saamge_amd.problems.Problem (host numpy arrays)."""
         A = prob.A.tocsr()
         rowptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
@@ -136,7 +150,7 @@ class Hierarchy(object):
         parts = [np.ascontiguousarray(p, dtype=np.int32) for p in prob.partitions[:params.num_coarsenings]]
         nparts = [int(p.max()) + 1 for p in parts]
         return cls(rowptr, col, val, A.shape[0], e2d, elmat, bdr, parts, nparts, params,
-                   e2d.shape[0], e2d.shape[1], stream, group)
+                   e2d.shape[0], e2d.shape[1], stream, group, dist_solve)
 
     def close(self):
         if self.h:
@@ -181,7 +195,8 @@ class Hierarchy(object):
         info = (C.c_longlong * 16)()
         _check(load().saamge_amd_level_info(self.h, C.c_int(level), info))
         keys = ["n", "nnz", "nparts", "num_mises", "ncoarse", "nnzP", "nnzAc", "nvec",
-                "coarse_iters", "evecs_size", "sig_size", "U_size"]
+                "coarse_iters", "evecs_size", "sig_size", "U_size", "row_partitioned", "row0",
+                "own_rows", "halo_recv"]
         return dict(zip(keys, [int(v) for v in info[:len(keys)]]))
 
     def get_csr(self, level, which):

@@ -49,6 +49,10 @@ void saamge_amd_params_default(saamge_amd_params *p) {
     p->world = 1;
     p->allgather = nullptr;
     p->allgather_ctx = nullptr;
+    p->allreduce_sum = nullptr;
+    p->alltoallv = nullptr;
+    p->dist_min_local_rows = 262144;
+    p->comm_stream_ordered = 0;
 }
 
 int saamge_amd_memcpy(void *dst, const void *src, long long bytes) {
@@ -88,6 +92,10 @@ int saamge_amd_ml_produce_data(int n, const int *rowptr, const int *col, const d
     p.world = params->world > 1 ? params->world : 1;
     p.allgather = params->allgather;
     p.allgather_ctx = params->allgather_ctx;
+    p.allreduce_sum = params->allreduce_sum;
+    p.alltoallv = params->alltoallv;
+    p.dist_min_local_rows = params->dist_min_local_rows;
+    p.comm_stream_ordered = params->comm_stream_ordered;
     SA_REQUIRE(p.world == 1 || (p.rank >= 0 && p.rank < p.world), "bad rank");
     Hierarchy *H = hierarchy_create(n, rowptr, col, val, NE, nde, elem_to_dof, elmat, bdr_dofs,
                                     partitions, nparts, p, (hipStream_t)stream);
@@ -207,6 +215,10 @@ int saamge_amd_level_info(const saamge_amd_hierarchy *h, int level, long long in
     long long usz = 0;
     for (int m = 0; m < L.rel.num_mises; ++m) usz += (long long)L.mis_k[m] * L.rel.mis_to_dof.row_size(m);
     info[11] = usz;
+    info[12] = L.dist.on ? 1 : 0;
+    info[13] = L.dist.row0;
+    info[14] = L.dist.nloc;
+    info[15] = L.dist.nrecv;
     SA_API_END
 }
 

@@ -1,0 +1,177 @@
+// Row-partitioned solve phase (one process per GPU): ownership ranges, halo-exchange lists and
+// the exchange itself.  Reference counterpart: hypre's ParCSR communication package behind
+// every HypreParMatrix::Mult of the V-cycle (amg/src/tg.cpp:91-132) and the MPI_Allreduce of
+// the PCG inner products (amg/src/mfem_addons.cpp:106-248).
+//
+// Layout: every rank keeps GLOBAL-length vectors; rank r owns rows [row_off[r], row_off[r+1])
+// (boundaries are multiples of 64 so that SELL-64 slices are never split) and applies only those
+// rows of A_l, reading x by global column index.  Entries of x outside the own range are valid
+// only at the halo positions (the columns the own rows reference), which are refreshed from
+// their owners before each SpMV: pack kernel -> alltoallv (RCCL send/recv groups through
+// torch.distributed) -> unpack kernel.  No column renumbering, no second matrix copy.
+#include "dist.h"
+
+#include <algorithm>
+
+namespace saamge_amd {
+
+void exclusive_scan_int(hipStream_t s, int n, const int *in, int *out);  // mis.hip
+
+__global__ __launch_bounds__(256) void halo_mark_kernel(int row0, int nloc, const int *__restrict__ rowptr,
+                                                        const int *__restrict__ col, int *__restrict__ flag) {
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 7;
+    const long r = gtid >> 3;
+    if (r >= nloc) return;
+    const int row = row0 + (int)r;
+    for (int k = rowptr[row] + lane; k < rowptr[row + 1]; k += 8) {
+        const int c = col[k];
+        if (c < row0 || c >= row0 + nloc) flag[c] = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void halo_compact_kernel(int n, const int *__restrict__ flag,
+                                                           const int *__restrict__ pos, int *__restrict__ idx) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && flag[i]) idx[pos[i]] = (int)i;
+}
+
+__global__ __launch_bounds__(256) void halo_pack_kernel(int n, const int *__restrict__ idx,
+                                                        const double *__restrict__ x, double *__restrict__ buf) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) buf[i] = x[idx[i]];
+}
+
+__global__ __launch_bounds__(256) void halo_unpack_kernel(int n, const int *__restrict__ idx,
+                                                          const double *__restrict__ buf, double *__restrict__ x) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[idx[i]] = buf[i];
+}
+
+static void comm_fence(Hierarchy &H) {
+    if (!H.params.comm_stream_ordered) SA_HIP_CHECK(hipStreamSynchronize(H.stream));
+}
+
+void dist_allreduce(Hierarchy &H, double *buf, long long count) {
+    if (H.params.world <= 1 || count == 0) return;
+    comm_fence(H);
+    SA_REQUIRE(H.params.allreduce_sum(H.params.allgather_ctx, buf, count) == 0, "allreduce callback failed");
+}
+
+void dist_allgather_rows(Hierarchy &H, Level::Dist &D, double *x) {
+    comm_fence(H);
+    SA_REQUIRE(H.params.allgather(H.params.allgather_ctx, x, D.own_off.data()) == 0,
+               "allgather callback failed");
+}
+
+void halo_exchange(Hierarchy &H, Level::Dist &D, double *x) {
+    hipStream_t s = H.stream;
+    if (D.nsend) {
+        profiler().begin(s);
+        hipLaunchKernelGGL(halo_pack_kernel, dim3(div_up(D.nsend, 256)), dim3(256), 0, s, D.nsend,
+                           D.send_idx.p, x, D.send_buf.p);
+        SA_HIP_CHECK(hipGetLastError());
+        profiler().end(s, "halo_pack", 20.0 * D.nsend, 0.0);
+    }
+    comm_fence(H);
+    SA_REQUIRE(H.params.alltoallv(H.params.allgather_ctx, D.send_buf.p, D.send_off.data(), D.recv_buf.p,
+                                  D.recv_off.data()) == 0,
+               "alltoallv callback failed");
+    if (D.nrecv) {
+        profiler().begin(s);
+        hipLaunchKernelGGL(halo_unpack_kernel, dim3(div_up(D.nrecv, 256)), dim3(256), 0, s, D.nrecv,
+                           D.recv_idx.p, D.recv_buf.p, x);
+        SA_HIP_CHECK(hipGetLastError());
+        profiler().end(s, "halo_unpack", 20.0 * D.nrecv, 0.0);
+    }
+}
+
+bool dist_setup_level(Hierarchy &H, int lev) {
+    const Params &p = H.params;
+    Level &L = *H.levels[lev];
+    Level::Dist &D = L.dist;
+    D.on = false;
+    const int world = p.world, rank = p.rank, n = L.A.nrows;
+    if (world <= 1 || !p.allreduce_sum || !p.alltoallv || !p.allgather) return false;
+    if ((long long)n < p.dist_min_local_rows * (long long)world) return false;
+    if (lev > 0 && !H.levels[lev - 1]->dist.on) return false;
+    hipStream_t s = H.stream;
+    D.row_off.assign((size_t)world + 1, 0);
+    for (int r = 1; r < world; ++r) {
+        long long b = ((long long)n * r / world + 63) / 64 * 64;
+        D.row_off[r] = (int)std::min<long long>(std::max<long long>(b, D.row_off[r - 1]), n);
+    }
+    D.row_off[world] = n;
+    D.row0 = D.row_off[rank];
+    D.nloc = D.row_off[rank + 1] - D.row0;
+    D.own_off.resize((size_t)world + 1);
+    for (int r = 0; r <= world; ++r) D.own_off[r] = 8ll * D.row_off[r];
+    // columns referenced by the own rows outside the own range, ascending == grouped by owner
+    DBuf<int> flag((size_t)n + 1), pos((size_t)n + 2);
+    flag.zero(s);
+    if (D.nloc)
+        hipLaunchKernelGGL(halo_mark_kernel, dim3(div_up((long)D.nloc * 8, 256)), dim3(256), 0, s, D.row0,
+                           D.nloc, L.A.rowptr.p, L.A.col.p, flag.p);
+    SA_HIP_CHECK(hipGetLastError());
+    exclusive_scan_int(s, n, flag.p, pos.p);
+    int nrecv = 0;
+    SA_HIP_CHECK(hipMemcpyAsync(&nrecv, pos.p + n, sizeof(int), hipMemcpyDeviceToHost, s));
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    D.nrecv = nrecv;
+    D.recv_idx.alloc((size_t)nrecv + 1);
+    hipLaunchKernelGGL(halo_compact_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, flag.p, pos.p,
+                       D.recv_idx.p);
+    SA_HIP_CHECK(hipGetLastError());
+    std::vector<long long> rcnt((size_t)world, 0);
+    {
+        DBuf<int> view;
+        view.view(D.recv_idx.p, (size_t)nrecv);
+        auto h_idx = view.to_host(s);
+        int r = 0;
+        for (int k = 0; k < nrecv; ++k) {
+            while (h_idx[k] >= D.row_off[r + 1]) ++r;
+            ++rcnt[r];
+        }
+    }
+    SA_REQUIRE(rcnt[rank] == 0, "halo list contains own rows");
+    // every rank learns how much every other rank needs from it
+    std::vector<long long> M((size_t)world * world, 0), moff((size_t)world + 1);
+    for (int r = 0; r < world; ++r) M[(size_t)rank * world + r] = rcnt[r];
+    for (int r = 0; r <= world; ++r) moff[r] = 8ll * world * r;
+    DBuf<long long> dM;
+    dM.from_host(M, s);
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    SA_REQUIRE(p.allgather(p.allgather_ctx, dM.p, moff.data()) == 0, "allgather callback failed");
+    auto hM = dM.to_host(s);
+    D.send_off.assign((size_t)world + 1, 0);
+    D.recv_off.assign((size_t)world + 1, 0);
+    std::vector<long long> ioff_s((size_t)world + 1, 0), ioff_r((size_t)world + 1, 0);
+    for (int r = 0; r < world; ++r) {
+        const long long sc = hM[(size_t)r * world + rank];
+        D.send_off[r + 1] = D.send_off[r] + 8 * sc;
+        D.recv_off[r + 1] = D.recv_off[r] + 8 * rcnt[r];
+        ioff_s[r + 1] = ioff_s[r] + 4 * sc;
+        ioff_r[r + 1] = ioff_r[r] + 4 * rcnt[r];
+    }
+    D.nsend = (int)(D.send_off[world] / 8);
+    D.send_idx.alloc((size_t)D.nsend + 1);
+    // tell each owner which of its entries are needed here
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    SA_REQUIRE(p.alltoallv(p.allgather_ctx, D.recv_idx.p, ioff_r.data(), D.send_idx.p, ioff_s.data()) == 0,
+               "alltoallv callback failed");
+    {
+        DBuf<int> view;
+        view.view(D.send_idx.p, (size_t)D.nsend);
+        auto h_idx = view.to_host(s);
+        for (int k = 0; k < D.nsend; ++k)
+            SA_REQUIRE(h_idx[k] >= D.row0 && h_idx[k] < D.row0 + D.nloc, "halo request outside the own rows");
+    }
+    D.send_buf.alloc((size_t)D.nsend + 1);
+    D.recv_buf.alloc((size_t)D.nrecv + 1);
+    L.r.zero(s);  // the restriction R r sums over ranks: r must vanish outside the own rows
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    D.on = true;
+    return true;
+}
+
+}  // namespace saamge_amd

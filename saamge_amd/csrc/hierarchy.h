@@ -34,6 +34,16 @@ struct Params {                 // MultilevelParameters (amg/inc/ml.hpp:59-114)
     int rank = 0, world = 1;
     int (*allgather)(void *ctx, void *buf_dev, const long long *byte_off) = nullptr;
     void *allgather_ctx = nullptr;
+    // Row-partitioned solve: levels with at least dist_min_local_rows
+    // rows per rank are applied by row blocks -- every SpMV is preceded by a halo exchange of
+    // the interface entries (`alltoallv`), dot products and the restricted residual are summed
+    // with `allreduce_sum`, corrections come back through `allgather`.  Smaller levels and the
+    // coarsest solve stay replicated.  Both callbacks get the same ctx as `allgather`.
+    int (*allreduce_sum)(void *ctx, double *buf_dev, long long count) = nullptr;
+    int (*alltoallv)(void *ctx, const void *send_dev, const long long *send_byte_off, void *recv_dev,
+                     const long long *recv_byte_off) = nullptr;
+    long long dist_min_local_rows = 262144;
+    int comm_stream_ordered = 0;  // callbacks enqueue on the hierarchy's stream (no host sync needed)
 };
 
 struct Level {                  // tg_data_t + interp_data_t + agg_partitioning_relations_t
@@ -60,6 +70,18 @@ struct Level {                  // tg_data_t + interp_data_t + agg_partitioning_
     DBuf<int64_t> d_mis_u_off;
     // solve-phase work vectors
     DBuf<double> x, b, r, t0, t1;
+    // row-partitioned solve: own rows [row_off[rank], row_off[rank+1]) (multiples of 64), halo
+    // exchange lists of A's input vector (global indices, grouped by peer rank)
+    struct Dist {
+        bool on = false;
+        int row0 = 0, nloc = 0;
+        std::vector<int> row_off;
+        std::vector<long long> send_off, recv_off;  // byte offsets into send_buf / recv_buf, world+1
+        std::vector<long long> own_off;             // byte offsets of the ownership ranges (all-gather)
+        DBuf<int> send_idx, recv_idx;
+        DBuf<double> send_buf, recv_buf;
+        int nsend = 0, nrecv = 0;
+    } dist;
 };
 
 struct KernelTiming { double setup_ms = 0, solve_ms = 0; };

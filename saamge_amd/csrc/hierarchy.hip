@@ -1,6 +1,7 @@
 // Setup (ml_produce_data) and solve (V-cycle, PCG) orchestration.  Host C++ driving the HIP
 // kernels; all numerics run on the device, the integer topology on the host.
 #include "hierarchy.h"
+#include "dist.h"
 
 #include <algorithm>
 #include <cmath>
@@ -434,29 +435,46 @@ static void setup_coarse_solver(Hierarchy &H) {
     H.c_roots = sas_poly_roots(H.levels.back()->nu_relax);
 }
 
-// x = poly(b) starting from x = 0; result lands in x, `tmp` is the ping-pong partner
-static void smooth_from_zero(hipStream_t s, const DCsr &A, const double *dinv,
-                             const std::vector<double> &roots, const double *b, double *x, double *tmp) {
+static inline RowRange rows_of(const Level::Dist *D) {
+    RowRange rr;
+    if (D) { rr.row0 = D->row0; rr.nrows = D->nloc; }
+    return rr;
+}
+
+// x = poly(b) starting from x = 0; result lands in x, `tmp` is the ping-pong partner.
+// Row-partitioned (D != null): own rows only; the halo of the result is refreshed on return.
+static void smooth_from_zero(Hierarchy &H, const DCsr &A, const double *dinv,
+                             const std::vector<double> &roots, const double *b, double *x, double *tmp,
+                             Level::Dist *D = nullptr) {
+    hipStream_t s = H.stream;
     const int deg = (int)roots.size();
+    const int off = D ? D->row0 : 0, nl = D ? D->nloc : A.nrows;
     double *cur = ((deg - 1) % 2 == 0) ? x : tmp;
     double *oth = (cur == x) ? tmp : x;
-    smooth_first(s, A.nrows, dinv, b, cur, 1.0 / roots[0]);
+    smooth_first(s, nl, dinv + off, b + off, cur + off, 1.0 / roots[0]);
+    if (D) halo_exchange(H, *D, cur);
     for (int i = 1; i < deg; ++i) {
-        smooth_step(s, A, dinv, b, cur, oth, 1.0 / roots[i]);
+        smooth_step(s, A, dinv, b, cur, oth, 1.0 / roots[i], rows_of(D));
         std::swap(cur, oth);
+        if (D) halo_exchange(H, *D, cur);
     }
 }
 
-// x += M^-1 (b - A x)
-static void smooth_inplace(hipStream_t s, const DCsr &A, const double *dinv,
-                           const std::vector<double> &roots, const double *b, double *x, double *tmp) {
+// x += M^-1 (b - A x).  Row-partitioned: the halo of x must be valid on entry; on return only
+// the own rows are.
+static void smooth_inplace(Hierarchy &H, const DCsr &A, const double *dinv,
+                           const std::vector<double> &roots, const double *b, double *x, double *tmp,
+                           Level::Dist *D = nullptr) {
+    hipStream_t s = H.stream;
     const int deg = (int)roots.size();
+    const int off = D ? D->row0 : 0, nl = D ? D->nloc : A.nrows;
     double *cur = x, *oth = tmp;
     for (int i = 0; i < deg; ++i) {
-        smooth_step(s, A, dinv, b, cur, oth, 1.0 / roots[i]);
+        smooth_step(s, A, dinv, b, cur, oth, 1.0 / roots[i], rows_of(D));
         std::swap(cur, oth);
+        if (D && i + 1 < deg) halo_exchange(H, *D, cur);
     }
-    if (cur != x) vec_copy(s, A.nrows, cur, x);
+    if (cur != x) vec_copy(s, nl, cur + off, x + off);
 }
 
 static double read_scalar(hipStream_t s, const double *dptr) {
@@ -467,22 +485,30 @@ static double read_scalar(hipStream_t s, const double *dptr) {
 }
 
 // The PCG loop shared by the outer solve and the coarsest solver (MFEM CGSolver::Mult order
-// of operations == kalchev_pcg, amg/src/mfem_addons.cpp:106-248).
+// of operations == kalchev_pcg, amg/src/mfem_addons.cpp:106-248).  Row-partitioned (D != null):
+// vector updates and inner products run on the own rows, the products are summed over ranks,
+// the search direction's halo is refreshed before each A d.
 static int pcg_loop(Hierarchy &H, const DCsr &A, const std::function<void(const double *, double *)> &prec,
                     const double *b, double *x, double *r, double *z, double *d, double *q,
                     double rel_tol, double abs_tol, int max_iter, bool squared, bool zero_guess,
-                    int *converged, double *hist, double *sc) {
+                    int *converged, double *hist, double *sc, Level::Dist *D = nullptr) {
     hipStream_t s = H.stream;
-    const int n = A.nrows;
+    const int off = D ? D->row0 : 0, n = D ? D->nloc : A.nrows;
+    const RowRange rr = rows_of(D);
+    auto pdot = [&](const double *u, const double *v, double *out) {
+        dot(s, n, u + off, v + off, H.partials.p, out);
+        if (D) dist_allreduce(H, out, 1);
+    };
     if (zero_guess) {
-        vec_zero(s, n, x);
-        vec_copy(s, n, b, r);
+        vec_zero(s, n, x + off);
+        vec_copy(s, n, b + off, r + off);
     } else {
-        spmv_residual(s, A, x, b, r);
+        if (D) halo_exchange(H, *D, x);
+        spmv_residual(s, A, x, b, r, rr);
     }
     prec(r, z);
-    vec_copy(s, n, z, d);
-    dot(s, n, d, r, H.partials.p, sc + 0);
+    vec_copy(s, n, z + off, d + off);
+    pdot(d, r, sc + 0);
     const double nom0 = read_scalar(s, sc + 0);
     if (hist) hist[0] = nom0;
     const double r0 = squared ? std::max(nom0 * rel_tol * rel_tol, abs_tol * abs_tol)
@@ -492,15 +518,16 @@ static int pcg_loop(Hierarchy &H, const DCsr &A, const std::function<void(const 
         if (converged) *converged = 1;
         return 0;
     }
-    spmv(s, A, d, q);
-    dot(s, n, q, d, H.partials.p, sc + 1);
+    if (D) halo_exchange(H, *D, d);
+    spmv(s, A, d, q, rr);
+    pdot(q, d, sc + 1);
     if (read_scalar(s, sc + 1) == 0.0) return 0;
     int i = 1;
     int final_iter = max_iter;
     for (;;) {
-        pcg_update_xr(s, n, sc, x, r, d, q);
+        pcg_update_xr(s, n, sc, x + off, r + off, d + off, q + off);
         prec(r, z);
-        dot(s, n, r, z, H.partials.p, sc + 2);
+        pdot(r, z, sc + 2);
         const double betanom = read_scalar(s, sc + 2);
         if (hist) hist[i] = betanom;
         if (betanom < r0) {
@@ -509,9 +536,10 @@ static int pcg_loop(Hierarchy &H, const DCsr &A, const std::function<void(const 
             break;
         }
         if (++i > max_iter) break;
-        pcg_update_d(s, n, sc, d, z);
-        spmv(s, A, d, q);
-        dot(s, n, d, q, H.partials.p, sc + 1);
+        pcg_update_d(s, n, sc, d + off, z + off);
+        if (D) halo_exchange(H, *D, d);
+        spmv(s, A, d, q, rr);
+        pdot(d, q, sc + 1);
         SA_HIP_CHECK(hipMemcpyAsync(sc + 0, sc + 2, sizeof(double), hipMemcpyDeviceToDevice, s));
     }
     return final_iter;
@@ -520,9 +548,8 @@ static int pcg_loop(Hierarchy &H, const DCsr &A, const std::function<void(const 
 static void coarse_solve(Hierarchy &H, const double *rc, double *xc) {
     const DCsr &Ac = coarsest_op(H);
     if (Ac.nrows == 0) return;
-    hipStream_t s = H.stream;
     auto prec = [&](const double *r, double *z) {
-        smooth_from_zero(s, Ac, H.c_dinv.p, H.c_roots, r, z, H.c_t0.p);
+        smooth_from_zero(H, Ac, H.c_dinv.p, H.c_roots, r, z, H.c_t0.p);
     };
     // scalar slots 4.. so the outer PCG's scalars (slots 0..2) survive
     int conv = 0;
@@ -531,36 +558,58 @@ static void coarse_solve(Hierarchy &H, const double *rc, double *xc) {
                                    &conv, nullptr, H.scal.p + 4);
 }
 
+static Level::Dist *dist_of(Level &L) { return L.dist.on ? &L.dist : nullptr; }
+
+// One V(1,1)-cycle from x = 0 (tg_cycle_atb, amg/src/tg.cpp:91-132).  On a row-partitioned
+// level b is read and x is written on the own rows only.
+static void vcycle_rec(Hierarchy &H, int level, const double *b, double *x) {
+    Level &L = *H.levels[level];
+    hipStream_t s = H.stream;
+    Level::Dist *D = dist_of(L);
+    const bool last = (level + 1 == (int)H.levels.size());
+    smooth_from_zero(H, L.A, L.dinv_neg.p, L.roots, b, x, L.t0.p, D);   // pre_smoother, x0 = 0
+    spmv_residual(s, L.A, x, b, L.r.p, rows_of(D));                     // res = b - A x
+    double *rc = last ? H.c_b.p : H.levels[level + 1]->b.p;
+    double *xc = last ? H.c_x.p : H.levels[level + 1]->x.p;
+    spmv(s, L.R, L.r.p, rc);                                            // resc = R res
+    if (D) dist_allreduce(H, rc, L.R.nrows);    // res is zero outside the own rows: partial sums
+    if (last) {
+        coarse_solve(H, rc, xc);
+    } else {
+        vcycle_rec(H, level + 1, rc, xc);
+        Level &N = *H.levels[level + 1];
+        if (N.dist.on) dist_allgather_rows(H, N.dist, xc);
+    }
+    spmv_add(s, L.P, xc, x, rows_of(D));                                // x += P xc
+    if (D) halo_exchange(H, *D, x);
+    smooth_inplace(H, L.A, L.dinv_neg.p, L.roots, b, x, L.t0.p, D);     // post_smoother
+}
+
 void smoother_apply(Hierarchy &H, int level, const double *b, double *x) {
     Level &L = *H.levels[level];
-    smooth_inplace(H.stream, L.A, L.dinv_neg.p, L.roots, b, x, L.t0.p);
+    Level::Dist *D = dist_of(L);
+    smooth_inplace(H, L.A, L.dinv_neg.p, L.roots, b, x, L.t0.p, D);
+    if (D) dist_allgather_rows(H, *D, x);
 }
 
 void vcycle_apply(Hierarchy &H, int level, const double *b, double *x) {
+    vcycle_rec(H, level, b, x);
     Level &L = *H.levels[level];
-    hipStream_t s = H.stream;
-    const bool last = (level + 1 == (int)H.levels.size());
-    smooth_from_zero(s, L.A, L.dinv_neg.p, L.roots, b, x, L.t0.p);     // pre_smoother, x0 = 0
-    spmv_residual(s, L.A, x, b, L.r.p);                                // res = b - A x
-    double *rc = last ? H.c_b.p : H.levels[level + 1]->b.p;
-    double *xc = last ? H.c_x.p : H.levels[level + 1]->x.p;
-    spmv(s, L.R, L.r.p, rc);                                           // resc = R res
-    if (last)
-        coarse_solve(H, rc, xc);
-    else
-        vcycle_apply(H, level + 1, rc, xc);
-    spmv_add(s, L.P, xc, x);                                           // x += P xc
-    smooth_inplace(s, L.A, L.dinv_neg.p, L.roots, b, x, L.t0.p);       // post_smoother
+    if (L.dist.on) dist_allgather_rows(H, L.dist, x);
 }
 
 int pcg_solve(Hierarchy &H, const double *b, double *x, double rel_tol, double abs_tol,
               int max_iter, int squared_tol, int zero_guess, int *converged, double *hist) {
     Level &L0 = *H.levels[0];
-    auto prec = [&](const double *r, double *z) { vcycle_apply(H, 0, r, z); };
+    Level::Dist *D = dist_of(L0);
+    auto prec = [&](const double *r, double *z) { vcycle_rec(H, 0, r, z); };
     PhaseTimer tm(H.stream);
     struct Lap { PhaseTimer &t; ~Lap() { t.lap("TOTAL pcg_solve", 0); } } lap{tm};
-    return pcg_loop(H, L0.A, prec, b, x, H.pcg_r.p, H.pcg_z.p, H.pcg_d.p, H.pcg_q.p, rel_tol,
-                    abs_tol, max_iter, squared_tol != 0, zero_guess != 0, converged, hist, H.scal.p);
+    const int it = pcg_loop(H, L0.A, prec, b, x, H.pcg_r.p, H.pcg_z.p, H.pcg_d.p, H.pcg_q.p, rel_tol,
+                            abs_tol, max_iter, squared_tol != 0, zero_guess != 0, converged, hist,
+                            H.scal.p, D);
+    if (D) dist_allgather_rows(H, *D, x);  // every rank returns the full solution
+    return it;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -632,6 +681,11 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
     H.pcg_r.alloc((size_t)n); H.pcg_z.alloc((size_t)n); H.pcg_d.alloc((size_t)n); H.pcg_q.alloc((size_t)n);
     SA_HIP_CHECK(hipStreamSynchronize(s));
     tm0.lap("coarse solver + vectors", 0);
+    if (p.world > 1 && p.alltoallv) {
+        for (int lev = 0; lev < p.num_coarsenings; ++lev)
+            if (!dist_setup_level(H, lev)) break;
+        tm0.lap("row-partitioned solve: halo lists", 0);
+    }
     tm_all.lap("TOTAL ml_produce_data", 0);
     return Hp.release();
 }

@@ -4,17 +4,24 @@
 
 namespace saamge_amd {
 
+// Optional row range of an operator application (row-partitioned solve: a rank applies only its
+// own rows; x stays indexed by global column).  nrows < 0 = all rows.
+struct RowRange {
+    int row0 = 0, nrows = -1;
+};
+
 // build the SELL-64 copy of A (used by every routine below when present)
 void build_sell(hipStream_t s, DCsr &A);
 // y = A x
-void spmv(hipStream_t s, const DCsr &A, const double *x, double *y);
+void spmv(hipStream_t s, const DCsr &A, const double *x, double *y, RowRange rr = RowRange());
 // r = b - A x                                   (reference: amg/src/tg.cpp:115-116)
-void spmv_residual(hipStream_t s, const DCsr &A, const double *x, const double *b, double *r);
+void spmv_residual(hipStream_t s, const DCsr &A, const double *x, const double *b, double *r,
+                   RowRange rr = RowRange());
 // x += P xc                                     (reference: amg/src/tg.cpp:129)
-void spmv_add(hipStream_t s, const DCsr &P, const double *xc, double *x);
+void spmv_add(hipStream_t s, const DCsr &P, const double *xc, double *x, RowRange rr = RowRange());
 // xout = xin + scale * dinv_neg .* (A xin - b)  (reference: amg/inc/smpr.hpp:330-338)
 void smooth_step(hipStream_t s, const DCsr &A, const double *dinv_neg, const double *b,
-                 const double *xin, double *xout, double scale);
+                 const double *xin, double *xout, double scale, RowRange rr = RowRange());
 // xout = scale * dinv_neg .* (-b)   (the same step for xin == 0, no matrix traffic)
 void smooth_first(hipStream_t s, int n, const double *dinv_neg, const double *b, double *xout,
                   double scale);

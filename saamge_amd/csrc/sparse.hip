@@ -15,7 +15,8 @@ __global__ __launch_bounds__(256) void spmv_kernel(int nrows, const int *__restr
                                                    const double *__restrict__ x,
                                                    double *__restrict__ y,
                                                    const double *__restrict__ b,
-                                                   const double *__restrict__ dinv, double scale) {
+                                                   const double *__restrict__ dinv, double scale,
+                                                   const double *__restrict__ xrow) {
     const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & (L - 1);
     const long row = gtid / L;
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void spmv_kernel(int nrows, const int *__restr
         } else if (MODE == MODE_ADD) {
             y[row] += sum;
         } else {  // x_out = x_in + scale * dinv_neg * (A x - b)
-            y[row] = x[row] + scale * (dinv[row] * (sum - b[row]));
+            y[row] = xrow[row] + scale * (dinv[row] * (sum - b[row]));
         }
     }
 }
@@ -51,7 +52,8 @@ __global__ __launch_bounds__(256) void sell_spmv_kernel(int nrows, const int *__
                                                         const double *__restrict__ x,
                                                         double *__restrict__ y,
                                                         const double *__restrict__ b,
-                                                        const double *__restrict__ dinv, double scale) {
+                                                        const double *__restrict__ dinv, double scale,
+                                                        const double *__restrict__ xrow) {
     const long row = (long)blockIdx.x * 256 + threadIdx.x;
     const int slice = (int)(row >> 6), lane = threadIdx.x & 63;
     if ((long)slice * 64 >= nrows) return;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void sell_spmv_kernel(int nrows, const int *__
     } else if (MODE == MODE_ADD) {
         y[row] += sum;
     } else {
-        y[row] = x[row] + scale * (dinv[row] * (sum - b[row]));
+        y[row] = xrow[row] + scale * (dinv[row] * (sum - b[row]));
     }
 }
 
@@ -138,24 +140,33 @@ void build_sell(hipStream_t s, DCsr &A) {
     A.has_sell = true;
 }
 
+// Rows [rr.row0, rr.row0 + rr.nrows) of A (row0 a multiple of 64 so that SELL slices line up);
+// x is indexed by GLOBAL column, the row-indexed arrays y, b, dinv are global-length too.
 template <int MODE>
-static void launch_spmv(hipStream_t s, const DCsr &A, const double *x, double *y, const double *b,
-                        const double *dinv, double scale) {
-    if (A.nrows == 0) return;
+static void launch_spmv(hipStream_t s, const DCsr &A, RowRange rr, const double *x, double *y,
+                        const double *b, const double *dinv, double scale) {
+    const int row0 = rr.nrows < 0 ? 0 : rr.row0;
+    const int nrows = rr.nrows < 0 ? A.nrows : rr.nrows;
+    if (nrows == 0) return;
+    SA_REQUIRE(row0 % 64 == 0 && row0 + nrows <= A.nrows, "bad row range");
+    y += row0;
+    if (b) b += row0;
+    if (dinv) dinv += row0;
+    const double *xrow = x + row0;
     if (A.has_sell) {
-        const int grid = div_up((long)A.nslices * 64, 256);
-        hipLaunchKernelGGL((sell_spmv_kernel<MODE>), dim3(grid), dim3(256), 0, s, A.nrows, A.sell_ptr.p,
-                           A.sell_col.p, A.sell_val.p, x, y, b, dinv, scale);
+        const int grid = div_up((long)div_up(nrows, 64) * 64, 256);
+        hipLaunchKernelGGL((sell_spmv_kernel<MODE>), dim3(grid), dim3(256), 0, s, nrows,
+                           A.sell_ptr.p + row0 / 64, A.sell_col.p, A.sell_val.p, x, y, b, dinv, scale, xrow);
         SA_HIP_CHECK(hipGetLastError());
         return;
     }
     const int L = A.lanes_per_row;
-    const long threads = (long)A.nrows * L;
+    const long threads = (long)nrows * L;
     const int grid = div_up(threads, 256);
 #define SA_CASE(LL)                                                                              \
     case LL:                                                                                     \
-        hipLaunchKernelGGL((spmv_kernel<LL, MODE>), dim3(grid), dim3(256), 0, s, A.nrows,        \
-                           A.rowptr.p, A.col.p, A.val.p, x, y, b, dinv, scale);                  \
+        hipLaunchKernelGGL((spmv_kernel<LL, MODE>), dim3(grid), dim3(256), 0, s, nrows,          \
+                           A.rowptr.p + row0, A.col.p, A.val.p, x, y, b, dinv, scale, xrow);     \
         break;
     switch (L) {
         SA_CASE(1) SA_CASE(2) SA_CASE(4) SA_CASE(8) SA_CASE(16) SA_CASE(32) SA_CASE(64)
@@ -165,28 +176,35 @@ static void launch_spmv(hipStream_t s, const DCsr &A, const double *x, double *y
     SA_HIP_CHECK(hipGetLastError());
 }
 
-static inline double spmv_bytes(const DCsr &A) { return 12.0 * A.nnz + 20.0 * A.nrows; }
+static inline double spmv_bytes(const DCsr &A, RowRange rr) {
+    const double frac = (rr.nrows < 0 || A.nrows == 0) ? 1.0 : (double)rr.nrows / A.nrows;
+    return (12.0 * A.nnz + 20.0 * A.nrows) * frac;
+}
+static inline double spmv_rows(const DCsr &A, RowRange rr) { return rr.nrows < 0 ? A.nrows : rr.nrows; }
+static inline double spmv_flops(const DCsr &A, RowRange rr) {
+    return 2.0 * A.nnz * ((rr.nrows < 0 || A.nrows == 0) ? 1.0 : (double)rr.nrows / A.nrows);
+}
 
-void spmv(hipStream_t s, const DCsr &A, const double *x, double *y) {
+void spmv(hipStream_t s, const DCsr &A, const double *x, double *y, RowRange rr) {
     profiler().begin(s);
-    launch_spmv<MODE_PLAIN>(s, A, x, y, nullptr, nullptr, 0.0);
-    profiler().end(s, "spmv", spmv_bytes(A), 2.0 * A.nnz);
+    launch_spmv<MODE_PLAIN>(s, A, rr, x, y, nullptr, nullptr, 0.0);
+    profiler().end(s, "spmv", spmv_bytes(A, rr), spmv_flops(A, rr));
 }
-void spmv_residual(hipStream_t s, const DCsr &A, const double *x, const double *b, double *r) {
+void spmv_residual(hipStream_t s, const DCsr &A, const double *x, const double *b, double *r, RowRange rr) {
     profiler().begin(s);
-    launch_spmv<MODE_RESIDUAL>(s, A, x, r, b, nullptr, 0.0);
-    profiler().end(s, "spmv_residual", spmv_bytes(A) + 8.0 * A.nrows, 2.0 * A.nnz);
+    launch_spmv<MODE_RESIDUAL>(s, A, rr, x, r, b, nullptr, 0.0);
+    profiler().end(s, "spmv_residual", spmv_bytes(A, rr) + 8.0 * spmv_rows(A, rr), spmv_flops(A, rr));
 }
-void spmv_add(hipStream_t s, const DCsr &P, const double *xc, double *x) {
+void spmv_add(hipStream_t s, const DCsr &P, const double *xc, double *x, RowRange rr) {
     profiler().begin(s);
-    launch_spmv<MODE_ADD>(s, P, xc, x, nullptr, nullptr, 0.0);
-    profiler().end(s, "spmv_add", spmv_bytes(P) + 8.0 * P.nrows, 2.0 * P.nnz);
+    launch_spmv<MODE_ADD>(s, P, rr, xc, x, nullptr, nullptr, 0.0);
+    profiler().end(s, "spmv_add", spmv_bytes(P, rr) + 8.0 * spmv_rows(P, rr), spmv_flops(P, rr));
 }
 void smooth_step(hipStream_t s, const DCsr &A, const double *dinv_neg, const double *b,
-                 const double *xin, double *xout, double scale) {
+                 const double *xin, double *xout, double scale, RowRange rr) {
     profiler().begin(s);
-    launch_spmv<MODE_SMOOTH>(s, A, xin, xout, b, dinv_neg, scale);
-    profiler().end(s, "smooth_step", spmv_bytes(A) + 24.0 * A.nrows, 2.0 * A.nnz);
+    launch_spmv<MODE_SMOOTH>(s, A, rr, xin, xout, b, dinv_neg, scale);
+    profiler().end(s, "smooth_step", spmv_bytes(A, rr) + 24.0 * spmv_rows(A, rr), spmv_flops(A, rr));
 }
 
 __global__ __launch_bounds__(256) void smooth_first_kernel(int n, const double *__restrict__ dinv,

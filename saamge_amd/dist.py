@@ -1,13 +1,17 @@
 """Process-group plumbing (one process per GPU, torch.distributed; nccl == RCCL on ROCm).
 
-Multi-GPU state of the hot path: the per-agglomerate spectral problems (the dominant setup
-cost) are sharded -- every level's AEs are split into `world` contiguous ranges, each rank
-solves its range and the eigenvectors are all-gathered IN PLACE through the callback built
-here (the reference's exchange of MIS-restricted eigenvectors, amg/src/contrib.cpp:519-548, is
-a subset of it).  Topology, P, RAP and the solve are still replicated on every rank; the
-row-partitioned operators with halo exchange are the next step.
+Multi-GPU state of the hot path:
+  * setup: the per-agglomerate spectral problems (the dominant setup cost) are sharded -- every
+    level's AEs are split into `world` contiguous ranges, each rank solves its range and the
+    eigenvectors are all-gathered IN PLACE through `allgather_callback` (the reference's exchange
+    of MIS-restricted eigenvectors, amg/src/contrib.cpp:519-548, is a subset of it).  Topology, P
+    and RAP are still replicated on every rank.
+  * solve: large levels are row-partitioned (csrc/dist.hip): halo exchange before every SpMV
+    (`alltoallv` = grouped send/recv), summed inner products and restricted residuals
+    (`allreduce_sum`), all-gathered corrections -- `solve_callbacks`.
 The collectives are written against torch.distributed only, so the same code is rehearsed
-with gloo (tests) and runs on RCCL in bench.py."""
+with gloo (tests, staged through host memory) and runs on RCCL in bench.py (zero-copy on the
+library's device buffers, enqueued on the library's stream)."""
 import os
 
 
@@ -97,6 +101,105 @@ class Group(object):
                 return 4
 
         return capi.ALLGATHER_FN(cb)
+
+    # ---- solve-phase collectives ------------------------------------------------------
+    def stream_ordered(self, stream=0):
+        """True when the callbacks enqueue on the library's stream (RCCL on torch's current
+        stream == the hierarchy's stream), so that no host synchronisation is needed."""
+        if self.dist is None or self.dist.get_backend() != "nccl":
+            return False
+        import torch
+        return int(torch.cuda.current_stream().cuda_stream) == int(stream or 0)
+
+    def _wrap(self, ptr, count, dtype):
+        """zero-copy torch view of library-owned device memory (cached: the library reuses its
+        communication buffers)."""
+        import torch
+        key = (int(ptr), int(count), dtype)
+        t = self._views.get(key)
+        if t is None:
+            typestr = {torch.float64: "<f8", torch.uint8: "|u1"}[dtype]
+
+            class _Mem(object):
+                pass
+            m = _Mem()
+            m.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr,
+                                          "data": (int(ptr), False), "version": 2}
+            t = torch.as_tensor(m, device=self.device)
+            if len(self._views) > 256:
+                self._views.clear()
+            self._views[key] = t
+        return t
+
+    def solve_callbacks(self, stream=0):
+        """(allreduce_sum, alltoallv) ctypes callbacks for saamge_amd_params."""
+        import sys
+        import torch
+        from . import capi
+        C = capi.C
+        lib = capi.load()
+        dist = self.dist
+        use_cuda = dist.get_backend() == "nccl"
+        ordered = self.stream_ordered(stream)
+        self._views = {}
+        world, rank = self.world, self.rank
+
+        def memcpy(dst, src, nbytes):
+            return lib.saamge_amd_memcpy(C.c_void_p(dst), C.c_void_p(src), C.c_longlong(nbytes))
+
+        def allreduce(ctx, buf, count):
+            try:
+                if use_cuda:
+                    dist.all_reduce(self._wrap(buf, count, torch.float64))
+                    if not ordered:
+                        torch.cuda.current_stream().synchronize()
+                    return 0
+                t = torch.empty(int(count), dtype=torch.float64)
+                rc = memcpy(t.data_ptr(), buf, 8 * count)
+                if rc:
+                    return rc
+                dist.all_reduce(t)
+                return memcpy(buf, t.data_ptr(), 8 * count)
+            except Exception as e:
+                print("saamge_amd allreduce callback failed: %r" % (e,), file=sys.stderr)
+                return 4
+
+        def alltoallv(ctx, send, soff, recv, roff):
+            try:
+                so = [int(soff[r]) for r in range(world + 1)]
+                ro = [int(roff[r]) for r in range(world + 1)]
+                if use_cuda:
+                    st = self._wrap(send, so[world], torch.uint8) if so[world] else None
+                    rt = self._wrap(recv, ro[world], torch.uint8) if ro[world] else None
+                else:
+                    st = torch.empty(so[world], dtype=torch.uint8)
+                    rt = torch.empty(ro[world], dtype=torch.uint8)
+                    if so[world]:
+                        rc = memcpy(st.data_ptr(), send, so[world])
+                        if rc:
+                            return rc
+                ops = []
+                for r in range(world):
+                    if r == rank:
+                        continue
+                    if so[r + 1] > so[r]:
+                        ops.append(dist.P2POp(dist.isend, st[so[r]:so[r + 1]], r))
+                    if ro[r + 1] > ro[r]:
+                        ops.append(dist.P2POp(dist.irecv, rt[ro[r]:ro[r + 1]], r))
+                if ops:
+                    for w in dist.batch_isend_irecv(ops):
+                        w.wait()
+                if use_cuda:
+                    if not ordered:
+                        torch.cuda.current_stream().synchronize()
+                elif ro[world]:
+                    return memcpy(recv, rt.data_ptr(), ro[world])
+                return 0
+            except Exception as e:
+                print("saamge_amd alltoallv callback failed: %r" % (e,), file=sys.stderr)
+                return 4
+
+        return capi.ALLREDUCE_FN(allreduce), capi.ALLTOALLV_FN(alltoallv)
 
     def aggregate_rate(self, units_per_rank, steps, dt):
         """whole-job throughput of N replicas: sum of units / slowest rank's time"""

@@ -1,6 +1,11 @@
-"""Distributed setup rehearsal on ONE GPU: two processes (gloo) split the per-AE eigenproblems of
-every level and all-gather the eigenvectors; the resulting hierarchy must be bit-identical to the
-single-process one (every AE is computed by exactly one rank with the same kernels)."""
+"""Multi-rank rehearsals on ONE GPU (gloo, ranks share the card).
+
+Setup: the ranks split the per-AE eigenproblems of every level and all-gather the eigenvectors;
+the resulting hierarchy must be bit-identical to the single-process one (every AE is computed by
+exactly one rank with the same kernels).
+Solve: with dist_min_local_rows = 1 every level is row-partitioned (halo exchange before each
+SpMV, summed inner products / restricted residuals, all-gathered corrections); iteration counts
+must match the single-process run and vectors agree to summation-order round-off."""
 import json
 import os
 import socket
@@ -22,8 +27,10 @@ WORKER = textwrap.dedent("""
     from saamge_amd.dist import Group
     grp = Group(backend="gloo")
     prob = pr.poisson3d_problem((16, 16, 16), blk=(8, 8, 4), coarse_blk=[(2, 2, 2)], coef="checkerboard")
-    params = capi.default_params(num_coarsenings=2, keep_debug=True, coarse_rtol=1e-28)
+    params = capi.default_params(num_coarsenings=2, keep_debug=True, coarse_rtol=1e-28,
+                                 dist_min_local_rows=int(sys.argv[2]))
     h = capi.Hierarchy.from_problem(prob, params, group=grp if grp.world > 1 else None)
+    out_info = [h.level_info(l) for l in range(2)]
     out = {}
     for l in range(2):
         P = h.get_csr(l, "P"); Ac = h.get_csr(l, "Ac")
@@ -34,6 +41,11 @@ WORKER = textwrap.dedent("""
         out["ev%%d" %% l] = np.concatenate(ev)
     x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-8)
     out["hist"] = hist; out["x"] = x; out["it"] = np.array([it])
+    bb = np.cos(np.arange(prob.ND) * 0.13) * (~prob.ess)
+    out["vc"] = h.vcycle(bb)
+    out["sm"] = h.smoother(0, bb, np.sin(np.arange(prob.ND) * 0.7))
+    out["part"] = np.array([i["row_partitioned"] for i in out_info])
+    out["own"] = np.array([i["own_rows"] for i in out_info])
     np.savez(sys.argv[1], **out)
     h.close()
     grp.barrier()
@@ -50,7 +62,7 @@ def _free_port():
     return p
 
 
-def _run(tmp_path, world):
+def _run(tmp_path, world, min_rows=262144):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = _free_port()
@@ -60,7 +72,7 @@ def _run(tmp_path, world):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         out = str(tmp_path / ("w%d_r%d.npz" % (world, rank)))
         outs.append(out)
-        procs.append(subprocess.Popen([sys.executable, str(script), out], env=env,
+        procs.append(subprocess.Popen([sys.executable, str(script), out, str(min_rows)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for p, lg in zip(procs, logs):
@@ -74,4 +86,23 @@ def test_two_rank_setup_matches_single_rank(tmp_path):
     for r in (r0, r1):
         for k in ref.files:
             assert np.array_equal(ref[k], r[k]), k      # bit-identical hierarchy and PCG history
-    assert int(ref["it"][0]) > 0
+    assert int(ref["it"][0]) > 0 and not r0["part"].any()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_partitioned_solve_matches_single_rank(tmp_path, world):
+    ref, = _run(tmp_path, 1)
+    ranks = _run(tmp_path, world, min_rows=1)
+    n = [4913, None]
+    for r in ranks:
+        assert r["part"].all()                          # both levels row-partitioned
+        assert int(r["it"][0]) == int(ref["it"][0])
+        assert np.allclose(r["hist"], ref["hist"], rtol=1e-8)
+        for k in ("x", "vc", "sm"):
+            assert np.linalg.norm(r[k] - ref[k]) <= 1e-10 * np.linalg.norm(ref[k]), k
+        for k in ref.files:                             # the setup is untouched by the solve mode
+            if k.startswith(("P", "Ac", "m", "ev")):
+                assert np.array_equal(ref[k], r[k]), k
+    assert sum(int(r["own"][0]) for r in ranks) == n[0]
+    for k in ("x", "vc", "sm"):                         # every rank returns the full vectors
+        assert np.array_equal(ranks[0][k], ranks[-1][k]), k
