@@ -20,8 +20,9 @@ Prints ONE JSON line (rank 0).  Extra legs, outside the timed region:
 
 N > 1 (torchrun, one rank per GPU, RCCL): STRONG scaling on the same global problem -- the
 per-agglomerate spectral problems of every level (the dominant setup cost) are sharded over the
-ranks and their eigenvectors all-gathered in place; topology, P, RAP and the PCG solve are still
-replicated on every rank (the row-partitioned operators of SURVEY section 8(e) are not built yet).
+ranks and their eigenvectors all-gathered in place; the PCG solve is row-partitioned on the large
+levels (halo exchange before every SpMV, all-reduced inner products and restricted residuals);
+topology, P and RAP are still replicated on every rank.
 value = dofs * steps / max-over-ranks time.
 """
 import argparse
@@ -174,8 +175,10 @@ def main():
                    "dofs": prob.n, "pcg_iterations": its, "converged": bool(conv),
                    "true_relative_residual": relres,
                    "level_dims": [i["n"] for i in infos] + [infos[-1]["ncoarse"]],
-                   "parallelism": ("%d ranks: per-AE spectral problems sharded + all-gather over RCCL; "
-                                   "topology/P/RAP/solve replicated" % world)
+                   "parallelism": ("%d ranks: per-AE spectral problems sharded + all-gather; levels %s "
+                                   "solved row-partitioned (halo exchange per SpMV, all-reduced dots); "
+                                   "topology/P/RAP and smaller levels replicated"
+                                   % (world, [l for l, i in enumerate(infos) if i["row_partitioned"]]))
                    if world > 1 else "single GPU"},
     }
 

@@ -11,6 +11,7 @@ namespace saamge_amd {
 struct DevElmats {
     DBuf<int64_t> off;  // [NE+1]
     DBuf<double> val;
+    int nde = 0;        // > 0: every element has exactly nde dofs and e2d_J / val are dense arrays
 };
 
 // Dense AE matrices for the AEs [ae0, ae0+count) into batch.W (column-major, ld = n_i).
@@ -22,6 +23,11 @@ void ae_assemble(hipStream_t s, const DevRelations &rel, const DCsr *A, const De
 // D_ii = sum_j |a_ij| sqrt(a_ii/a_jj)  (amg/src/mbox.cpp:913-949);  batch.dis = D^-1/2 and
 // W <- D^-1/2 W D^-1/2 in place.  Dout (optional, packed like batch.d) receives D.
 void ae_scale(hipStream_t s, EigBatch &batch, double *Dout);
+
+// ae_assemble (+ ae_scale when `scale`): on the fine level, when the sparse rows of one AE fit in
+// LDS, as ONE fused kernel that writes the dense image once (see assemble.hip).
+void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevElmats &el, int ae0,
+              EigBatch &batch, bool scale, double *Dout);
 
 // Coarse element matrices E_e = P_loc^T A_e P_loc for AEs [ae0, ae0+count)
 // (ElementMatrixParallelCoarse::GetMatrix, amg/src/elmat.cpp:105-195).  batch.W must hold

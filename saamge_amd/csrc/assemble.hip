@@ -4,6 +4,8 @@
 // the sums are bit-reproducible and match the reference's accumulation order.
 #include "assemble.h"
 
+#include <cstdlib>
+
 namespace saamge_amd {
 
 constexpr int ASM_NT = 256;
@@ -145,6 +147,233 @@ void ae_scale(hipStream_t s, EigBatch &batch, double *Dout) {
                        batch.voff.p, batch.W.p, batch.dis.p, Dout);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "ae_scale", bytes, 0.0);
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused fine-level path: sparse assembly in LDS -> D -> ONE coalesced write of the dense
+// (optionally scaled) matrix.  The AE matrix has the sparsity of A's rows (<= RW entries per
+// row), so the n x RW value/column tables of one AE fit in LDS; the dense n x n image that the
+// eigensolver wants is then written exactly once (8 n^2 bytes, whole cache lines) instead of
+// zero-fill + scatter + read-modify-write scaling (32 n^2 bytes and a latency-bound scatter).
+// Entry (row lr, slot k) is produced by ONE thread, contributions added in the element order of
+// the row's dof: bit-identical to the scatter kernel above and run-to-run deterministic.
+// The dense image is written by sparse ROWS into column-major columns, i.e. as the transpose;
+// the matrix is symmetric up to the round-off of the element-matrix sums.
+// ---------------------------------------------------------------------------------------
+constexpr int AB_NT = 512;
+
+__global__ __launch_bounds__(256) void max_row_kernel(int n, const int *__restrict__ rowptr, int *__restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    int len = (i < n) ? rowptr[i + 1] - rowptr[i] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_xor(len, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, len);
+}
+
+constexpr int AB_MAXE = 8;   // elements per dof kept in the LDS row tables (hexes: <= 8)
+
+// NDE > 0: every element has exactly NDE dofs (level 0: elem_to_dof is a dense NE x NDE array),
+// which turns the per-element searches into a few independent vector loads.
+template <bool SCALE, int NDE>
+__global__ __launch_bounds__(AB_NT) void ae_build_kernel(
+    int ae0, int RW, const int *__restrict__ ns, const int64_t *__restrict__ moff,
+    const int64_t *__restrict__ voff, double *__restrict__ W, double *__restrict__ dis_out,
+    double *__restrict__ D_out, const int *__restrict__ ae2d_I, const int *__restrict__ ae2d_J,
+    const int *__restrict__ d2ae_I, const int *__restrict__ d2ae_J,
+    const int *__restrict__ dof_id_inAE, const signed char *__restrict__ flags,
+    const int *__restrict__ d2e_I, const int *__restrict__ d2e_J, const int *__restrict__ part,
+    const int *__restrict__ e2d_I, const int *__restrict__ e2d_J, const int64_t *__restrict__ eloff,
+    const double *__restrict__ elval, const int *__restrict__ Arow, const int *__restrict__ Acol,
+    const double *__restrict__ Aval) {
+    extern __shared__ __align__(16) double lds[];
+    __shared__ int anybig;
+    const int b = blockIdx.x, p = ae0 + b, n = ns[b];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = AB_NT / 64;
+    double *vals = lds;                                   // [n * RW]
+    double *dg = vals + (size_t)n * RW;                   // [n]
+    double *dis = dg + n;                                 // [n]
+    double *colbuf = dis + n;                             // [NW][n]; phases 0-1: the row tables
+    int *rowel = (int *)colbuf;                           // [n * AB_MAXE] elements of the row's dof in this AE
+    short *rowkk = (short *)(rowel + (size_t)n * AB_MAXE);  // [n * AB_MAXE] position of the dof in them
+    short *cols = (short *)(colbuf + (size_t)NW * n);     // [n * RW] AE-local column or -1
+    int *gdof = (int *)(cols + (((size_t)n * RW + 3) & ~(size_t)3));  // [n] global dof of each row
+    const int *aedofs = ae2d_J + ae2d_I[p];
+    if (tid == 0) anybig = 0;
+    for (int lr = tid; lr < n; lr += AB_NT) gdof[lr] = aedofs[lr];
+    __syncthreads();
+    // ---- 0. per row: the elements of its dof that lie in this AE, and the dof's slot in them ----
+    for (int it = tid; it < n * AB_MAXE; it += AB_NT) {
+        const int lr = it / AB_MAXE, q = it - lr * AB_MAXE;
+        const int g = gdof[lr];
+        const int qb = d2e_I[g], cnt = d2e_I[g + 1] - qb;
+        int e = -1, kk = 0;
+        if (q == 0 && cnt > AB_MAXE) anybig = 1;
+        if (q < cnt) {
+            e = d2e_J[qb + q];
+            if (part[e] != p) {
+                e = -1;
+            } else if (NDE == 8) {
+                const int4 lo = *(const int4 *)(e2d_J + (size_t)e * 8), hi = *(const int4 *)(e2d_J + (size_t)e * 8 + 4);
+                kk = (lo.x == g) ? 0 : (lo.y == g) ? 1 : (lo.z == g) ? 2 : (lo.w == g) ? 3 :
+                     (hi.x == g) ? 4 : (hi.y == g) ? 5 : (hi.z == g) ? 6 : 7;
+            } else {
+                const int eb = e2d_I[e], nd = e2d_I[e + 1] - eb;
+                while (kk < nd && e2d_J[eb + kk] != g) ++kk;
+            }
+        }
+        rowel[it] = e;
+        rowkk[it] = (short)kk;
+    }
+    __syncthreads();
+    const bool big = anybig != 0;
+    // ---- 1. sparse rows ----
+    for (int it = tid; it < n * RW; it += AB_NT) {
+        const int lr = it / RW, k = it - lr * RW;
+        const int g = gdof[lr];
+        const int a0 = Arow[g];
+        int lc = -1;
+        double v = 0.0;
+        if (k < Arow[g + 1] - a0) {
+            const int c = Acol[a0 + k];
+            for (int q = d2ae_I[c]; q < d2ae_I[c + 1]; ++q)
+                if (d2ae_J[q] == p) { lc = dof_id_inAE[q]; break; }
+            if (lc >= 0) {
+                const int fg = flags[g], fc = flags[c];
+                const bool assembled = (fg & 1) && (fc & 1) && (!((fg | fc) & 2) || c == g);
+                if (!assembled) {
+                    v = Aval[a0 + k];           // copied from the global matrix (aggregates.cpp:930-934)
+                } else if (NDE == 8 && !big) {  // agg_assemble_value, aggregates.cpp:68-184
+                    int es[AB_MAXE], jj[AB_MAXE];
+#pragma unroll
+                    for (int q = 0; q < AB_MAXE; ++q) {
+                        es[q] = rowel[lr * AB_MAXE + q];
+                        const int ec = max(es[q], 0);
+                        const int4 lo = *(const int4 *)(e2d_J + (size_t)ec * 8), hi = *(const int4 *)(e2d_J + (size_t)ec * 8 + 4);
+                        jj[q] = (lo.x == c) ? 0 : (lo.y == c) ? 1 : (lo.z == c) ? 2 : (lo.w == c) ? 3 :
+                                (hi.x == c) ? 4 : (hi.y == c) ? 5 : (hi.z == c) ? 6 : (hi.w == c) ? 7 : -1;
+                    }
+                    double m[AB_MAXE];
+#pragma unroll
+                    for (int q = 0; q < AB_MAXE; ++q) {
+                        const bool on = es[q] >= 0 && jj[q] >= 0;
+                        const int kk = rowkk[lr * AB_MAXE + q];
+                        m[q] = on ? elval[((size_t)es[q] * 8 + kk) * 8 + jj[q]] : 0.0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < AB_MAXE; ++q)
+                        if (es[q] >= 0 && jj[q] >= 0) v += m[q];
+                } else {
+                    for (int q = d2e_I[g]; q < d2e_I[g + 1]; ++q) {
+                        const int e = d2e_J[q];
+                        if (part[e] != p) continue;
+                        const int eb = e2d_I[e], nd = e2d_I[e + 1] - eb;
+                        int kk = -1, j2 = -1;
+                        for (int t = 0; t < nd; ++t) {
+                            const int dd = e2d_J[eb + t];
+                            if (dd == g && kk < 0) kk = t;
+                            if (dd == c && j2 < 0) j2 = t;
+                        }
+                        if (j2 >= 0) v += elval[eloff[e] + (size_t)kk * nd + j2];
+                    }
+                }
+            }
+        }
+        vals[it] = v;
+        cols[it] = (short)lc;
+    }
+    __syncthreads();
+    // ---- 2. diagonal, 3. D and D^-1/2 ----
+    for (int lr = tid; lr < n; lr += AB_NT) {
+        double d = 0.0;
+        for (int k = 0; k < RW; ++k)
+            if (cols[lr * RW + k] == lr) d = vals[lr * RW + k];
+        dg[lr] = d;
+    }
+    __syncthreads();
+    if (SCALE) {
+        for (int lr = tid; lr < n; lr += AB_NT) {
+            const double dr = dg[lr];
+            double sum = 0.0;
+            for (int k = 0; k < RW; ++k) {
+                const int lc = cols[lr * RW + k];
+                const double a = vals[lr * RW + k];
+                if (lc >= 0 && a != 0.0) sum += fabs(a) * sqrt(dr / dg[lc]);
+            }
+            const double di = 1.0 / sqrt(sum);
+            dis[lr] = di;
+            dis_out[voff[b] + lr] = di;
+            if (D_out) D_out[voff[b] + lr] = sum;
+        }
+        __syncthreads();
+    }
+    // ---- 4. dense image: wavefront w writes columns w, w + NW, ... ----
+    double *Wm = W + moff[b];
+    double *cb = colbuf + (size_t)wave * n;
+    for (int r = lane; r < n; r += 64) cb[r] = 0.0;
+    for (int j = wave; j < n; j += NW) {
+        const double dj = SCALE ? dis[j] : 1.0;
+        for (int k = lane; k < RW; k += 64) {
+            const int lc = cols[j * RW + k];
+            if (lc >= 0) cb[lc] = SCALE ? dj * vals[j * RW + k] * dis[lc] : vals[j * RW + k];
+        }
+        // (wave-private LDS: program order within the wavefront is enough)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        double *col = Wm + (size_t)j * n;
+        for (int r = lane; r < n; r += 64) col[r] = cb[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        for (int k = lane; k < RW; k += 64) {
+            const int lc = cols[j * RW + k];
+            if (lc >= 0) cb[lc] = 0.0;
+        }
+    }
+}
+
+static int csr_max_row(hipStream_t s, const DCsr &A) {
+    DBuf<int> m(1);
+    m.zero(s);
+    if (A.nrows)
+        hipLaunchKernelGGL(max_row_kernel, dim3(div_up(A.nrows, 256)), dim3(256), 0, s, A.nrows, A.rowptr.p, m.p);
+    SA_HIP_CHECK(hipGetLastError());
+    return m.to_host(s)[0];
+}
+
+void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevElmats &el, int ae0,
+              EigBatch &batch, bool scale, double *Dout) {
+    if (!batch.count) return;
+    static const bool no_fused = std::getenv("SAAMGE_AMD_NO_FUSED_ASSEMBLY") != nullptr;
+    size_t lds = 0;
+    int RW = 0;
+    if (A && !no_fused) {
+        if (A->max_row < 0) A->max_row = csr_max_row(s, *A);
+        RW = A->max_row;
+        const size_t n = (size_t)batch.max_n;
+        lds = 8 * (n * RW + 2 * n + (AB_NT / 64) * n) + 2 * n * RW + 4 * n + 64;
+    }
+    if (!A || no_fused || lds > 160 * 1024 - 256 || batch.max_n > 32767) {
+        ae_assemble(s, rel, A, el, ae0, batch);
+        if (scale) ae_scale(s, batch, Dout);
+        return;
+    }
+    const bool nde8 = el.nde == 8;
+    auto launch = [&](auto kern) {
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        hipLaunchKernelGGL(kern, dim3(batch.count), dim3(AB_NT), lds, s, ae0, RW, batch.n.p, batch.moff.p,
+                           batch.voff.p, batch.W.p, batch.dis.p, Dout, rel.ae2d_I.p, rel.ae2d_J.p,
+                           rel.d2ae_I.p, rel.d2ae_J.p, rel.dof_id_inAE.p, rel.flags.p, rel.d2e_I.p,
+                           rel.d2e_J.p, rel.part.p, rel.e2d_I.p, rel.e2d_J.p, el.off.p, el.val.p,
+                           A->rowptr.p, A->col.p, A->val.p);
+    };
+    double bytes = 0.0;
+    for (int n : batch.h_n) bytes += 8.0 * (double)n * n;
+    profiler().begin(s);
+    if (scale) {
+        if (nde8) launch(ae_build_kernel<true, 8>); else launch(ae_build_kernel<true, 0>);
+    } else {
+        if (nde8) launch(ae_build_kernel<false, 8>); else launch(ae_build_kernel<false, 0>);
+    }
+    SA_HIP_CHECK(hipGetLastError());
+    profiler().end(s, "ae_build", bytes, 0.0);
 }
 
 // E_e = P_loc^T A_e P_loc.  T = A_e P_loc goes through a global scratch block (n x k_e).

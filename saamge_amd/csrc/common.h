@@ -158,6 +158,7 @@ struct DCsr {
     DBuf<int> rowptr, col;
     DBuf<double> val;
     int lanes_per_row = 8;  // SpMV launch shape, chosen from the average row length
+    mutable int max_row = -1;  // longest row (computed on first use by the fused AE assembly)
     // optional SELL-64 copy for the SpMV family: slice s = rows 64s..64s+63, entry (k, lane)
     // at sell_ptr[s] + 64 k + lane (padded with zero values), fully coalesced per wavefront
     bool has_sell = false;
@@ -189,7 +190,8 @@ struct Profiler {
     bool enabled = false;
     std::vector<KernelStat> stats;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    KernelStat &get(const char *name) {
+    int level_tag = 0;  // SAAMGE_AMD_PROFILE_LEVELS=1: setup kernels of level l > 0 are listed as name@Ll
+    KernelStat &get(const std::string &name) {
         for (auto &s : stats)
             if (s.name == name) return s;
         stats.push_back(KernelStat());
@@ -210,7 +212,7 @@ struct Profiler {
         SA_HIP_CHECK(hipEventSynchronize(e1));
         float ms = 0.f;
         SA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-        KernelStat &k = get(name);
+        KernelStat &k = level_tag > 0 ? get(std::string(name) + "@L" + std::to_string(level_tag)) : get(name);
         k.ms += ms;
         k.launches += 1;
         k.bytes += bytes;

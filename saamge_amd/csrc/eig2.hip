@@ -93,7 +93,8 @@ __global__ __launch_bounds__(NT) void sbr_qr_kernel(int k0, const int *__restric
                                                     const int64_t *__restrict__ moff,
                                                     const int64_t *__restrict__ voff,
                                                     double *__restrict__ Wm,
-                                                    double *__restrict__ Tfac) {
+                                                    double *__restrict__ Tfac,
+                                                    double *__restrict__ Vpk) {
     extern __shared__ __align__(16) double plds[];
     __shared__ double red[NT / 64];
     __shared__ double zs[SB];
@@ -174,6 +175,13 @@ __global__ __launch_bounds__(NT) void sbr_qr_kernel(int k0, const int *__restric
             Pg[(size_t)c * n + i] = P[(size_t)c * ldp + i];
         }
     }
+    // row-major copy of V with the implicit unit diagonal / zeros made explicit: the product and
+    // update kernels read whole rows of it through the scalar cache
+    double *Vp = Vpk + voff[b] * SB;
+    for (int idx = tid; idx < np * SB; idx += NT) {
+        const int i = idx / SB, c = idx % SB;
+        Vp[idx] = (i > c) ? P[(size_t)c * ldp + i] : ((i == c) ? 1.0 : 0.0);
+    }
 }
 
 // Register-resident panel QR for np <= 512: thread t owns panel rows t and t + 256 (2 x SB
@@ -184,7 +192,8 @@ __global__ __launch_bounds__(256) void sbr_qr_reg_kernel(int k0, const int *__re
                                                          const int64_t *__restrict__ moff,
                                                          const int64_t *__restrict__ voff,
                                                          double *__restrict__ Wm,
-                                                         double *__restrict__ Tfac) {
+                                                         double *__restrict__ Tfac,
+                                                         double *__restrict__ Vpk) {
     __shared__ double red[4];
     __shared__ double part[SB * 16];   // [j][row-of-16]
     __shared__ double dots[SB];        // w_j (j > c) / z_j (j < c)
@@ -272,27 +281,37 @@ __global__ __launch_bounds__(256) void sbr_qr_reg_kernel(int k0, const int *__re
         }
     }
     for (int i = tid; i < SB * SB; i += 256) T[i] = Ts[i];
+    double *Vp = Vpk + voff[b] * SB;
 #pragma unroll
     for (int c = 0; c < SB; ++c) {
-        if (r0 < np) Pg[(size_t)c * n + r0] = p0[c];
-        if (r1 < np) Pg[(size_t)c * n + r1] = p1[c];
+        if (r0 < np) {
+            Pg[(size_t)c * n + r0] = p0[c];
+            Vp[(size_t)r0 * SB + c] = (r0 > c) ? p0[c] : ((r0 == c) ? 1.0 : 0.0);
+        }
+        if (r1 < np) {
+            Pg[(size_t)c * n + r1] = p1[c];
+            Vp[(size_t)r1 * SB + c] = (r1 > c) ? p1[c] : ((r1 == c) ? 1.0 : 0.0);
+        }
     }
 }
 
-// X(r, :) = sum_c A22(r, c) V(c, :)
+// X(r, :) = sum_c A22(r, c) V(c, :).  One workgroup per (64-row block, matrix); lane = row, the
+// four wavefronts split the columns.  The column index is wave-uniform, so V(c, 0..15) comes in
+// through the scalar cache (s_load from the packed row-major V) and every FMA takes it as an
+// SGPR operand: no LDS traffic in the main loop, A22 streamed once with coalesced 512-B loads.
 constexpr int SY_NT = 256;
-constexpr int SY_KC = 256;  // V rows staged per LDS chunk
 
 __global__ __launch_bounds__(SY_NT) void sbr_symm_kernel(int k0, const int *__restrict__ ns,
                                                          const int64_t *__restrict__ moff,
                                                          const int64_t *__restrict__ voff,
                                                          const double *__restrict__ Wm,
+                                                         const double *__restrict__ Vpk,
                                                          double *__restrict__ Xbuf,
                                                          const int64_t *__restrict__ goff,
                                                          double *__restrict__ Gbuf, int count,
                                                          int tiles) {
-    constexpr int SBP = SB + 1;                        // padded row: conflict-light transposed writes
-    __shared__ __align__(16) double Vs[SY_KC * SBP];  // 34 KiB, reused for the K-split reduction
+    constexpr int SBP = SB + 1;
+    __shared__ double red[4 * SB * 64];              // K-split reduction, [g][j][r]
     __shared__ double xs[64 * SBP], vs2[64 * SBP];   // padded [rr][j]: conflict-free reads below
     int b, blk;
     xcd_decode(tiles, b, blk);
@@ -304,52 +323,35 @@ __global__ __launch_bounds__(SY_NT) void sbr_symm_kernel(int k0, const int *__re
     if (r0 >= np) return;
     const double *A = Wm + moff[b];
     const double *A22 = A + (size_t)(k0 + SB) * n + (k0 + SB);
+    const double *__restrict__ Vp = Vpk + voff[b] * SB;
     double *X = Xbuf + voff[b] * SB;
     const int tid = threadIdx.x;
-    const int r = tid & 63, g = tid >> 6;
-    const int row = r0 + r;
+    const int r = tid & 63;
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rowc = min(r0 + r, np - 1);            // clamped: every load stays in bounds
     double acc[SB];
 #pragma unroll
     for (int j = 0; j < SB; ++j) acc[j] = 0.0;
-    for (int c0 = 0; c0 < np; c0 += SY_KC) {
-        const int kc = min(SY_KC, np - c0);
-        __syncthreads();
-        // coalesced reads down the panel columns (cc fastest), padded transposed LDS image
-        {
-            double vreg[SB];
-            const int cc = tid;                         // SY_KC == SY_NT: one panel row per thread
-            const int rcl = min(c0 + cc, np - 1);       // clamp: keeps every load in bounds
+    {
+        const int q = (np + 3) >> 2;
+        const int cb = g * q, ce = min(cb + q, np);
+        const double *Ar = A22 + rowc;
+        int cc = cb;
+        for (; cc + 4 <= ce; cc += 4) {   // four 512-B loads in flight per wavefront
+            const double a0 = Ar[(size_t)cc * n], a1 = Ar[(size_t)(cc + 1) * n];
+            const double a2 = Ar[(size_t)(cc + 2) * n], a3 = Ar[(size_t)(cc + 3) * n];
+            const double *vr = Vp + (size_t)cc * SB;   // wave-uniform
 #pragma unroll
-            for (int j = 0; j < SB; ++j) vreg[j] = vmask(A, n, k0, rcl, j);
-            if (cc < kc) {
-#pragma unroll
-                for (int j = 0; j < SB; ++j) Vs[cc * SBP + j] = vreg[j];
-            }
+            for (int j = 0; j < SB; ++j)
+                acc[j] = fma(a3, vr[3 * SB + j], fma(a2, vr[2 * SB + j], fma(a1, vr[SB + j], fma(a0, vr[j], acc[j]))));
         }
-        __syncthreads();
-        if (row < np) {
-            const int cb = g * (SY_KC / 4), ce = min(cb + SY_KC / 4, kc);
-            const double *Ar = A22 + (size_t)c0 * n + row;
-            int cc = cb;
-            for (; cc + 4 <= ce; cc += 4) {   // four loads in flight per lane
-                const double a0 = Ar[(size_t)cc * n], a1 = Ar[(size_t)(cc + 1) * n];
-                const double a2 = Ar[(size_t)(cc + 2) * n], a3 = Ar[(size_t)(cc + 3) * n];
-                const double *vr = Vs + cc * SBP;
+        for (; cc < ce; ++cc) {
+            const double a = Ar[(size_t)cc * n];
+            const double *vr = Vp + (size_t)cc * SB;
 #pragma unroll
-                for (int j = 0; j < SB; ++j)
-                    acc[j] = fma(a3, vr[3 * SBP + j], fma(a2, vr[2 * SBP + j], fma(a1, vr[SBP + j], fma(a0, vr[j], acc[j]))));
-            }
-            for (; cc < ce; ++cc) {
-                const double a = Ar[(size_t)cc * n];
-                const double *vr = Vs + cc * SBP;
-#pragma unroll
-                for (int j = 0; j < SB; ++j) acc[j] = fma(a, vr[j], acc[j]);
-            }
+            for (int j = 0; j < SB; ++j) acc[j] = fma(a, vr[j], acc[j]);
         }
     }
-    __syncthreads();
-    // reduce the 4 K-splits: red[g][j][r]
-    double *red = Vs;
 #pragma unroll
     for (int j = 0; j < SB; ++j) red[(g * SB + j) * 64 + r] = acc[j];
     __syncthreads();
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(SY_NT) void sbr_symm_kernel(int k0, const int *__re
             X[(size_t)j * n + r0 + rr] = s;
         }
         xs[rr * SBP + j] = s;
-        vs2[rr * SBP + j] = (r0 + rr < np) ? vmask(A, n, k0, min(r0 + rr, np - 1), j) : 0.0;
+        vs2[rr * SBP + j] = (r0 + rr < np) ? Vp[(size_t)(r0 + rr) * SB + j] : 0.0;
     }
     __syncthreads();
     {   // partial G(a, c) = sum_rr V(r0+rr, a) X(r0+rr, c), reduced over row blocks by sbr_z_kernel
@@ -373,12 +375,12 @@ __global__ __launch_bounds__(SY_NT) void sbr_symm_kernel(int k0, const int *__re
     }
 }
 
-// Z = X T - V S / 2 with S = T^T (G T), G = V^T X summed over the row-block partials
+// Z = X T - V S / 2 with S = T^T (G T), G = V^T X summed over the row-block partials.
+// Z is written row-major (Z(r, c) at r * SB + c) for the scalar-operand reads of the update.
 constexpr int SM_NT = 256;
 __global__ __launch_bounds__(SM_NT) void sbr_z_kernel(int k0, const int *__restrict__ ns,
-                                                      const int64_t *__restrict__ moff,
                                                       const int64_t *__restrict__ voff,
-                                                      const double *__restrict__ Wm,
+                                                      const double *__restrict__ Vpk,
                                                       const double *__restrict__ Tfac,
                                                       const double *__restrict__ Xbuf,
                                                       const int64_t *__restrict__ goff,
@@ -393,9 +395,9 @@ __global__ __launch_bounds__(SM_NT) void sbr_z_kernel(int k0, const int *__restr
     if (np < 2) return;
     const int r0 = blk * SM_NT;
     if (r0 >= np) return;
-    const double *A = Wm + moff[b];
     const double *T = Tfac + voff[b] * SB + (size_t)(k0 / SB) * SB * SB;
     const double *X = Xbuf + voff[b] * SB;
+    const double *Vp = Vpk + voff[b] * SB;
     double *Z = Zbuf + voff[b] * SB;
     const int tid = threadIdx.x;
     {
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(SM_NT) void sbr_z_kernel(int k0, const int *__restr
 #pragma unroll
     for (int j = 0; j < SB; ++j) {
         x[j] = X[(size_t)j * n + r];
-        v[j] = vmask(A, n, k0, r, j);
+        v[j] = Vp[(size_t)r * SB + j];
     }
 #pragma unroll
     for (int c = 0; c < SB; ++c) {
@@ -436,22 +438,28 @@ __global__ __launch_bounds__(SM_NT) void sbr_z_kernel(int k0, const int *__restr
         for (int j = 0; j <= c; ++j) y = fma(x[j], Ts[c * SB + j], y);
 #pragma unroll
         for (int a = 0; a < SB; ++a) s = fma(v[a], Ss[a * SB + c], s);
-        Z[(size_t)c * n + r] = fma(-0.5, s, y);
+        Z[(size_t)r * SB + c] = fma(-0.5, s, y);
     }
 }
 
 // A22 -= Z V^T + V Z^T (both triangles: the mat-vec product reads full rows).  One workgroup
-// per (128-row strip, matrix): its Z/V row panel is staged once, then it walks the 64-column
-// tiles of the strip; 8x4 register micro-tiles.
+// per (128-row strip, matrix).  Lane = two rows of the strip (lane, lane + 64): its Z/V rows stay
+// in registers for the whole strip and every A22 access is a 512-B coalesced wave access.
+// Wavefront w owns columns 8 w .. 8 w + 7 of each 32-column tile: the column operands
+// Z(l, :), V(l, :) are wave-uniform and arrive through the scalar cache as SGPR operands of the
+// FMAs -- no LDS at all.
 constexpr int S2_NT = 256;
 constexpr int S2_ROWS = 128;
+constexpr int S2_KC = 8;   // columns per wavefront per step (bounded by the SGPR budget)
+
 __global__ __launch_bounds__(S2_NT) void sbr_syr2k_kernel(int k0, const int *__restrict__ ns,
                                                           const int64_t *__restrict__ moff,
                                                           const int64_t *__restrict__ voff,
                                                           double *__restrict__ Wm,
-                                                          const double *__restrict__ Zbuf, int count,
+                                                          const double *__restrict__ Vpk,
+                                                          const double *__restrict__ Zbuf,
+                                                          double *__restrict__ Xbuf, int count,
                                                           int tiles) {
-    __shared__ __align__(16) double Zi[S2_ROWS * SB], Vi[S2_ROWS * SB], Zl[64 * SB], Vl[64 * SB];
     int b, blk;
     xcd_decode(tiles, b, blk);
     if (b >= count) return;
@@ -460,65 +468,68 @@ __global__ __launch_bounds__(S2_NT) void sbr_syr2k_kernel(int k0, const int *__r
     if (np < 2) return;
     const int i0 = blk * S2_ROWS;
     if (i0 >= np) return;
-    double *A = Wm + moff[b];
-    double *A22 = A + (size_t)(k0 + SB) * n + (k0 + SB);
-    const double *Z = Zbuf + voff[b] * SB;
-    const int tid = threadIdx.x;
+    double *A22 = Wm + moff[b] + (size_t)(k0 + SB) * n + (k0 + SB);
+    const double *__restrict__ Z = Zbuf + voff[b] * SB;
+    const double *__restrict__ Vp = Vpk + voff[b] * SB;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // Rows past the end of the matrix (last strip) are redirected to per-lane trash slots in the
+    // already consumed X buffer (n * SB >= 128 doubles) with column stride 0: loads and stores
+    // stay unconditional (conditional stores make the compiler sink the arithmetic into the
+    // store branches and reload the scalar operands there).
+    const int ia = i0 + lane, ib = i0 + lane + 64;
+    const bool oka = ia < np, okb = ib < np;
+    double *trash = Xbuf + voff[b] * SB;
+    double *pa = oka ? A22 + ia : trash + lane;
+    double *pb = okb ? A22 + ib : trash + 64 + lane;
+    const size_t sa = oka ? (size_t)n : 0, sb = okb ? (size_t)n : 0;
+    const int iac = min(ia, np - 1), ibc = min(ib, np - 1);
+    double za[SB], va[SB], zb[SB], vb[SB];   // negated row operands
 #pragma unroll
-    for (int idx = tid; idx < S2_ROWS * SB; idx += S2_NT) {
-        const int rr = idx & (S2_ROWS - 1), c = idx >> 7;
-        const int ri = i0 + rr;
-        const int rc = min(ri, np - 1);
-        const double zz = Z[(size_t)c * n + rc], vv = vmask(A, n, k0, rc, c);
-        Zi[c * S2_ROWS + rr] = (ri < np) ? zz : 0.0;
-        Vi[c * S2_ROWS + rr] = (ri < np) ? vv : 0.0;
+    for (int c = 0; c < SB; ++c) {
+        za[c] = -Z[(size_t)iac * SB + c];
+        va[c] = -Vp[(size_t)iac * SB + c];
+        zb[c] = -Z[(size_t)ibc * SB + c];
+        vb[c] = -Vp[(size_t)ibc * SB + c];
     }
-    const int tr = tid & 15, tc = tid >> 4;  // 8 rows (tr + 16 a), 4 cols (tc + 16 q)
-    for (int l0 = 0; l0 < np; l0 += 64) {
-        __syncthreads();
+    for (int l0 = S2_KC * w; l0 < np; l0 += 4 * S2_KC) {
+        const int kn = min(S2_KC, np - l0);   // wave-uniform
+        if (kn == S2_KC) {
+            double ta[S2_KC], tb[S2_KC];
 #pragma unroll
-        for (int idx = tid; idx < 64 * SB; idx += S2_NT) {
-            const int rr = idx & 63, c = idx >> 6;
-            const int rl = l0 + rr;
-            const int rc = min(rl, np - 1);
-            const double zz = Z[(size_t)c * n + rc], vv = vmask(A, n, k0, rc, c);
-            Zl[c * 64 + rr] = (rl < np) ? zz : 0.0;
-            Vl[c * 64 + rr] = (rl < np) ? vv : 0.0;
-        }
-        double t[8][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int l = l0 + tc + 16 * q;
-#pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const int i = i0 + tr + 16 * a;
-                t[a][q] = (i < np && l < np) ? A22[(size_t)l * n + i] : 0.0;
-            }
-        }
-        __syncthreads();
-#pragma unroll 2
-        for (int c = 0; c < SB; ++c) {
-            double zl[4], vl[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                zl[q] = Zl[c * 64 + tc + 16 * q];
-                vl[q] = Vl[c * 64 + tc + 16 * q];
+            for (int k = 0; k < S2_KC; ++k) {
+                ta[k] = pa[(size_t)(l0 + k) * sa];
+                tb[k] = pb[(size_t)(l0 + k) * sb];
             }
 #pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const double zi = Zi[c * S2_ROWS + tr + 16 * a], vi = Vi[c * S2_ROWS + tr + 16 * a];
+            for (int k = 0; k < S2_KC; ++k) {
+                const double *zl = Z + (size_t)(l0 + k) * SB;    // wave-uniform: scalar loads
+                const double *vl = Vp + (size_t)(l0 + k) * SB;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) t[a][q] = fma(-zi, vl[q], fma(-vi, zl[q], t[a][q]));
+                for (int c = 0; c < SB; ++c) {
+                    ta[k] = fma(za[c], vl[c], fma(va[c], zl[c], ta[k]));
+                    tb[k] = fma(zb[c], vl[c], fma(vb[c], zl[c], tb[k]));
+                }
+                // the scheduler must not hoist the scalar loads of all columns (64 SGPRs each)
+                if (k & 1) __builtin_amdgcn_sched_barrier(0);
             }
-        }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int l = l0 + tc + 16 * q;
-            if (l >= np) continue;
+            for (int k = 0; k < S2_KC; ++k) {
+                pa[(size_t)(l0 + k) * sa] = ta[k];
+                pb[(size_t)(l0 + k) * sb] = tb[k];
+            }
+        } else {
+            for (int k = 0; k < kn; ++k) {
+                double t0 = pa[(size_t)(l0 + k) * sa], t1 = pb[(size_t)(l0 + k) * sb];
+                const double *zl = Z + (size_t)(l0 + k) * SB;
+                const double *vl = Vp + (size_t)(l0 + k) * SB;
 #pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const int i = i0 + tr + 16 * a;
-                if (i < np) A22[(size_t)l * n + i] = t[a][q];
+                for (int c = 0; c < SB; ++c) {
+                    t0 = fma(za[c], vl[c], fma(va[c], zl[c], t0));
+                    t1 = fma(zb[c], vl[c], fma(vb[c], zl[c], t1));
+                }
+                pa[(size_t)(l0 + k) * sa] = t0;
+                pb[(size_t)(l0 + k) * sb] = t1;
             }
         }
     }
@@ -874,26 +885,27 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b) {
         if (prof) profiler().begin(s);
         if (npmax <= 512)
             hipLaunchKernelGGL(sbr_qr_reg_kernel, dim3(b.count), dim3(256), 0, s, k0, b.n.p, b.moff.p,
-                               b.voff.p, b.W.p, b.Tfac.p);
+                               b.voff.p, b.W.p, b.Tfac.p, b.Vpk.p);
         else if ((size_t)npmax * SB * sizeof(double) <= 96 * 1024)
             hipLaunchKernelGGL((sbr_qr_kernel<256, true>), dim3(b.count), dim3(256),
                                (size_t)npmax * SB * sizeof(double), s, k0, b.n.p, b.moff.p, b.voff.p,
-                               b.W.p, b.Tfac.p);
+                               b.W.p, b.Tfac.p, b.Vpk.p);
         else
             hipLaunchKernelGGL((sbr_qr_kernel<1024, false>), dim3(b.count), dim3(1024), 0, s, k0,
-                               b.n.p, b.moff.p, b.voff.p, b.W.p, b.Tfac.p);
+                               b.n.p, b.moff.p, b.voff.p, b.W.p, b.Tfac.p, b.Vpk.p);
         if (prof) { profiler().end(s, "eig_sbr_qr", 0.0, 0.0); profiler().begin(s); }
         const int cnt8 = 8 * div_up(b.count, 8);
         hipLaunchKernelGGL(sbr_symm_kernel, dim3(cnt8 * div_up(npmax, 64)), dim3(SY_NT), 0, s, k0,
-                           b.n.p, b.moff.p, b.voff.p, b.W.p, b.Xbuf.p, b.goff.p, b.Gbuf.p, b.count,
+                           b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Xbuf.p, b.goff.p, b.Gbuf.p, b.count,
                            div_up(npmax, 64));
         if (prof) { profiler().end(s, "eig_sbr_symm", first ? sbytes : 0.0, 0.0); profiler().begin(s); }
         hipLaunchKernelGGL(sbr_z_kernel, dim3(cnt8 * div_up(npmax, SM_NT)), dim3(SM_NT), 0, s, k0,
-                           b.n.p, b.moff.p, b.voff.p, b.W.p, b.Tfac.p, b.Xbuf.p, b.goff.p, b.Gbuf.p,
+                           b.n.p, b.voff.p, b.Vpk.p, b.Tfac.p, b.Xbuf.p, b.goff.p, b.Gbuf.p,
                            b.Zbuf.p, b.count, div_up(npmax, SM_NT));
         if (prof) { profiler().end(s, "eig_sbr_z", 0.0, 0.0); profiler().begin(s); }
         hipLaunchKernelGGL(sbr_syr2k_kernel, dim3(cnt8 * div_up(npmax, S2_ROWS)), dim3(S2_NT), 0, s, k0,
-                           b.n.p, b.moff.p, b.voff.p, b.W.p, b.Zbuf.p, b.count, div_up(npmax, S2_ROWS));
+                           b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.Xbuf.p, b.count,
+                           div_up(npmax, S2_ROWS));
         if (prof) profiler().end(s, "eig_sbr_syr2k", first ? ubytes : 0.0, 0.0);
         first = false;
     }

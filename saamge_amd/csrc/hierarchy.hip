@@ -144,8 +144,8 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         EigBatch batch;
         eig_batch_alloc(batch, std::vector<int>(sizes.begin() + ae0, sizes.begin() + ae0 + cnt), s);
         tc.lap("  chunk alloc", lev);
-        ae_assemble(s, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch);
-        ae_scale(s, batch, P.keep_debug ? L.ae_D.p + row0 : nullptr);
+        ae_build(s, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch, true,
+                 P.keep_debug ? L.ae_D.p + row0 : nullptr);
         tc.lap("  chunk assemble+scale", lev);
         eig_tridiagonalize(s, batch);
         tc.lap("  chunk tridiagonalize", lev);
@@ -398,7 +398,7 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
         }
         EigBatch batch;
         eig_batch_alloc(batch, std::vector<int>(sizes.begin() + ae0, sizes.begin() + ae0 + cnt), s);
-        ae_assemble(s, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch);
+        ae_build(s, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch, false, nullptr);
         std::vector<int64_t> soff((size_t)cnt + 1, 0);
         for (int i = 0; i < cnt; ++i) soff[i + 1] = soff[i] + (int64_t)sizes[ae0 + i] * e2d.row_size(ae0 + i);
         DBuf<int64_t> d_soff;
@@ -647,6 +647,7 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
         for (int e = 0; e <= NE; ++e) off[e] = (int64_t)e * nde * nde;
         L0.elmat.off.from_host(off, s);
         import_array(L0.elmat.val, elmat, (size_t)NE * nde * nde, s);
+        L0.elmat.nde = nde;
     }
     Table e2d;
     {
@@ -662,6 +663,8 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
     int n_elem = NE;
     for (int lev = 0; lev < p.num_coarsenings; ++lev) {
         auto part = fetch_host(partitions[lev], (size_t)n_elem, s);
+        static const bool tag_levels = std::getenv("SAAMGE_AMD_PROFILE_LEVELS") != nullptr;
+        profiler().level_tag = tag_levels ? lev : 0;
         build_level(H, lev, std::move(e2d), part, nparts[lev], (lev == 0 && bdr) ? bdr_h.data() : nullptr);
         Level &L = *H.levels[lev];
         if (lev + 1 < p.num_coarsenings) {
@@ -673,6 +676,7 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
             n_elem = L.rel.nparts;
         }
     }
+    profiler().level_tag = 0;
     tm0 = PhaseTimer(s);
     setup_coarse_solver(H);
     const size_t nc = (size_t)coarsest_op(H).nrows;

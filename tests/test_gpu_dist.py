@@ -106,3 +106,43 @@ def test_row_partitioned_solve_matches_single_rank(tmp_path, world):
     assert sum(int(r["own"][0]) for r in ranks) == n[0]
     for k in ("x", "vc", "sm"):                         # every rank returns the full vectors
         assert np.array_equal(ranks[0][k], ranks[-1][k]), k
+
+
+RCCL_WORKER = textwrap.dedent("""
+    import sys, os
+    sys.path.insert(0, %r)
+    import torch, ctypes as C
+    import torch.distributed as dist
+    from saamge_amd import capi
+    from saamge_amd.dist import Group
+    os.environ.update(WORLD_SIZE="1", RANK="0")
+    g = Group(backend="nccl", device="cuda:0")          # world 1: no process group yet
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    g.dist = dist
+    assert g.stream_ordered(0)
+    allreduce, alltoallv = g.solve_callbacks(0)
+    t = torch.arange(1000, dtype=torch.float64, device="cuda:0")
+    w = g._wrap(t.data_ptr(), t.numel(), torch.float64)  # zero-copy view of raw device memory
+    assert w.data_ptr() == t.data_ptr() and w.device == t.device
+    w += 1.0
+    assert float(t[0]) == 1.0 and float(t[999]) == 1000.0
+    assert allreduce(None, t.data_ptr(), t.numel()) == 0  # RCCL all-reduce on the raw pointer
+    torch.cuda.synchronize()
+    assert float(t.sum()) == 1000 * 1001 / 2
+    off = (C.c_longlong * 2)(0, 0)
+    assert alltoallv(None, t.data_ptr(), off, t.data_ptr(), off) == 0
+    dist.destroy_process_group()
+    print("ok")
+""" % ROOT)
+
+
+def test_rccl_callbacks_on_raw_device_pointers(tmp_path):
+    """The RCCL flavour of the solve-phase callbacks works on library-owned device memory
+    through a zero-copy __cuda_array_interface__ view (one rank: the multi-rank logic is the
+    gloo-tested one, two RCCL ranks cannot share a GPU)."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0 and b"ok" in p.stdout, p.stdout.decode()[-3000:]
