@@ -44,6 +44,8 @@ KERNELS = {
     "spmv_residual": ("sell_spmv_kernel<1>", "hbm"),
     "eig_sbr_symm": ("sbr_symm_kernel", "hbm"),
     "eig_sbr_syr2k": ("sbr_syr2k_kernel", "hbm"),
+    "eig_sbr_fused": ("sbr_fused_kernel", "hbm"),
+    "ae_build": ("ae_build_kernel<true, 8>", "hbm"),
     "eig_band_chase": ("band_chase_kernel", "mfma"),
     "eig_sbr_qr": ("sbr_qr_kernel<256, true>", "mfma"),
     "ae_assemble": ("ae_assemble_kernel", "hbm"),

@@ -26,7 +26,8 @@ struct EigBatch {
     bool two_stage = false;
     DBuf<double> Tfac;      // [sum n_i * SB] compact-WY T factors, one SB x SB block per panel
     DBuf<double> Xbuf, Zbuf;// [sum n_i * SB] panel products (Z row-major: Z(r, c) at r * SB + c)
-    DBuf<double> Vpk;       // [sum n_i * SB] current panel's V, row-major, unit diagonal / zeros explicit
+    DBuf<double> Vpk, Vpk2; // [sum n_i * SB] panel V (current / next), row-major, unit diagonal / zeros explicit
+    DBuf<double> trash;     // 128 slots: target of the masked-off rows of the update kernels
     DBuf<double> rv, rtau;  // bulge-chasing reflectors (SB entries each) and their scalars
     DBuf<double> bandg;     // band + bulge storage when it does not fit in LDS
     DBuf<int64_t> roff;     // [count+1] reflector offsets

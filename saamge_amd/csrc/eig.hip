@@ -625,7 +625,7 @@ static bool use_one_stage() {
 // multi-GB buffers costs 0.1-0.4 s each on this platform; the arena is allocated once per
 // process and reused by every chunk / level / hierarchy).  Single stream, sequential use.
 struct EigArena {
-    DBuf<double> W, panel, d, e, tau, dis, Tfac, Xbuf, Zbuf, Vpk, rv, rtau, bandg, Gbuf;
+    DBuf<double> W, panel, d, e, tau, dis, Tfac, Xbuf, Zbuf, Vpk, Vpk2, trash, rv, rtau, bandg, Gbuf;
     DBuf<int> n, m, j0;
     DBuf<int64_t> moff, voff, roff, goff;
 };
@@ -682,6 +682,8 @@ void eig_batch_two_stage_buffers(EigBatch &b, size_t nrefl, bool need_bandg, hip
     arena_view(b.Xbuf, a.Xbuf, rows * EIG_SB);
     arena_view(b.Zbuf, a.Zbuf, rows * EIG_SB);
     arena_view(b.Vpk, a.Vpk, rows * EIG_SB);
+    arena_view(b.Vpk2, a.Vpk2, rows * EIG_SB);
+    arena_view(b.trash, a.trash, 256);
     arena_view(b.roff, a.roff, (size_t)b.count + 1);
     arena_view(b.goff, a.goff, (size_t)b.count + 1);
     arena_view(b.Gbuf, a.Gbuf, (size_t)b.h_goff[b.count] + 1);

@@ -20,6 +20,8 @@
 
 #include "eig.h"
 
+#include <cstdlib>
+
 namespace saamge_amd {
 
 constexpr int SB = EIG_SB;      // band width
@@ -535,6 +537,314 @@ __global__ __launch_bounds__(S2_NT) void sbr_syr2k_kernel(int k0, const int *__r
     }
 }
 
+// ---- look-ahead variant: the product of the NEXT panel is fused into the update -------------
+// Per panel p (V_p, T_p, Z_p known):
+//   sbr_panel_update_kernel   A22(:, 0:SB) -= Z V^T + V Z^T      (the next panel's columns only)
+//   sbr_qr_*                  QR of the next panel -> V_{p+1}, T_{p+1}
+//   sbr_fused_kernel          A22' -= Z V^T + V Z^T on the rest (A22' = A22(SB:, SB:)) and, in the
+//                             same pass over A22', X_{p+1} = A22' V_{p+1} (+ the partial V^T X)
+//   sbr_z_kernel              Z_{p+1}
+// The trailing matrix is read and written ONCE per panel (16 n'^2 bytes instead of 24 n'^2).
+
+// rows [r0, r0 + 256) of the first SB columns of A22
+__global__ __launch_bounds__(256) void sbr_panel_update_kernel(int k0, const int *__restrict__ ns,
+                                                               const int64_t *__restrict__ moff,
+                                                               const int64_t *__restrict__ voff,
+                                                               double *__restrict__ Wm,
+                                                               const double *__restrict__ Vpk,
+                                                               const double *__restrict__ Zbuf, int count,
+                                                               int tiles) {
+    int b, blk;
+    xcd_decode(tiles, b, blk);
+    if (b >= count) return;
+    const int n = ns[b];
+    const int np = n - k0 - SB;
+    if (np < 2) return;
+    const int r = blk * 256 + threadIdx.x;
+    if (r >= np) return;
+    double *A22 = Wm + moff[b] + (size_t)(k0 + SB) * n + (k0 + SB);
+    const double *__restrict__ Z = Zbuf + voff[b] * SB;
+    const double *__restrict__ Vp = Vpk + voff[b] * SB;
+    double zr[SB], vr[SB];
+#pragma unroll
+    for (int k = 0; k < SB; ++k) {
+        zr[k] = Z[(size_t)r * SB + k];
+        vr[k] = Vp[(size_t)r * SB + k];
+    }
+    const int nc = min(SB, np);
+    for (int c = 0; c < nc; ++c) {
+        const double *zc = Z + (size_t)c * SB;   // uniform
+        const double *vc = Vp + (size_t)c * SB;
+        double t = A22[(size_t)c * n + r];
+#pragma unroll
+        for (int k = 0; k < SB; ++k) t = fma(-zr[k], vc[k], fma(-vr[k], zc[k], t));
+        A22[(size_t)c * n + r] = t;
+    }
+}
+
+constexpr int SF_ROWS = 64;   // one row per lane: 2 x 16 row operands + 16 accumulators in VGPRs
+__global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__restrict__ ns,
+                                                          const int64_t *__restrict__ moff,
+                                                          const int64_t *__restrict__ voff,
+                                                          double *__restrict__ Wm,
+                                                          const double *__restrict__ Vcur,
+                                                          const double *__restrict__ Zbuf,
+                                                          const double *__restrict__ Vnext,
+                                                          double *__restrict__ Xbuf,
+                                                          const int64_t *__restrict__ goff,
+                                                          double *__restrict__ Gbuf,
+                                                          double *__restrict__ trashbuf, int count,
+                                                          int tiles) {
+    constexpr int SBP = SB + 1;
+    __shared__ double red[4 * SB * SF_ROWS];   // 32 KiB: K-split reduction
+    __shared__ double xs[SF_ROWS * SBP], vs2[SF_ROWS * SBP];
+    int b, blk;
+    xcd_decode(tiles, b, blk);
+    if (b >= count) return;
+    const int n = ns[b];
+    if (n - k0 - SB < 2) return;               // this matrix has no panel k0
+    const int np = n - k0 - 2 * SB;            // order of A22' (may be < 2: update only)
+    if (np < 1) return;
+    const int i0 = blk * SF_ROWS;
+    if (i0 >= np) return;
+    const bool prod = np >= 2;                 // the next panel has reflectors
+    double *A22 = Wm + moff[b] + (size_t)(k0 + 2 * SB) * n + (k0 + 2 * SB);
+    const double *__restrict__ Z = Zbuf + voff[b] * SB + SB * SB;     // rows shifted by SB
+    const double *__restrict__ Vc = Vcur + voff[b] * SB + SB * SB;
+    const double *__restrict__ Vn = Vnext + voff[b] * SB;
+    double *X = Xbuf + voff[b] * SB;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ia = i0 + lane;
+    const bool oka = ia < np;
+    double *pa = oka ? A22 + ia : trashbuf + lane;          // rows past the end: see sbr_syr2k_kernel
+    const size_t sa = oka ? (size_t)n : 0;
+    const int iac = min(ia, np - 1);
+    double za[SB], va[SB];   // negated row operands
+    double xa[SB];
+#pragma unroll
+    for (int c = 0; c < SB; ++c) {
+        za[c] = -Z[(size_t)iac * SB + c];
+        va[c] = -Vc[(size_t)iac * SB + c];
+        xa[c] = 0.0;
+    }
+    for (int l0 = S2_KC * w; l0 < np; l0 += 4 * S2_KC) {
+        const int kn = min(S2_KC, np - l0);   // wave-uniform
+        if (kn == S2_KC) {
+            double ta[S2_KC];
+#pragma unroll
+            for (int k = 0; k < S2_KC; ++k) ta[k] = pa[(size_t)(l0 + k) * sa];
+#pragma unroll
+            for (int k = 0; k < S2_KC; ++k) {
+                const double *zl = Z + (size_t)(l0 + k) * SB;    // wave-uniform: scalar loads
+                const double *vl = Vc + (size_t)(l0 + k) * SB;
+#pragma unroll
+                for (int c = 0; c < SB; ++c) ta[k] = fma(za[c], vl[c], fma(va[c], zl[c], ta[k]));
+                if (prod) {
+                    const double *vn = Vn + (size_t)(l0 + k) * SB;
+#pragma unroll
+                    for (int j = 0; j < SB; ++j) xa[j] = fma(ta[k], vn[j], xa[j]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int k = 0; k < S2_KC; ++k) pa[(size_t)(l0 + k) * sa] = ta[k];
+        } else {
+            for (int k = 0; k < kn; ++k) {
+                double t0 = pa[(size_t)(l0 + k) * sa];
+                const double *zl = Z + (size_t)(l0 + k) * SB;
+                const double *vl = Vc + (size_t)(l0 + k) * SB;
+#pragma unroll
+                for (int c = 0; c < SB; ++c) t0 = fma(za[c], vl[c], fma(va[c], zl[c], t0));
+                if (prod) {
+                    const double *vn = Vn + (size_t)(l0 + k) * SB;
+#pragma unroll
+                    for (int j = 0; j < SB; ++j) xa[j] = fma(t0, vn[j], xa[j]);
+                }
+                pa[(size_t)(l0 + k) * sa] = t0;
+            }
+        }
+    }
+    if (!prod) return;   // block-uniform
+    // ---- X = sum of the four column splits; partial G = V^T X of this 64-row block ----
+#pragma unroll
+    for (int j = 0; j < SB; ++j) red[(w * SB + j) * SF_ROWS + lane] = xa[j];
+    __syncthreads();
+    for (int idx = tid; idx < SF_ROWS * SB; idx += S2_NT) {
+        const int rr = idx & (SF_ROWS - 1), j = idx >> 6;
+        double s = 0.0;
+        if (i0 + rr < np) {
+            s = (red[(0 * SB + j) * SF_ROWS + rr] + red[(1 * SB + j) * SF_ROWS + rr]) +
+                (red[(2 * SB + j) * SF_ROWS + rr] + red[(3 * SB + j) * SF_ROWS + rr]);
+            X[(size_t)j * n + i0 + rr] = s;
+        }
+        xs[rr * SBP + j] = s;
+        vs2[rr * SBP + j] = (i0 + rr < np) ? Vn[(size_t)(i0 + rr) * SB + j] : 0.0;
+    }
+    __syncthreads();
+    {
+        const int a = tid >> 4, c = tid & 15;
+        double s = 0.0;
+        for (int rr = 0; rr < SF_ROWS; ++rr) s = fma(vs2[rr * SBP + a], xs[rr * SBP + c], s);
+        Gbuf[goff[b] + (size_t)blk * (SB * SB) + tid] = s;
+    }
+}
+
+// ---- the same fused update + product on the matrix cores ------------------------------------
+// v_mfma_f64_16x16x4_f64 (D = A(16x4) B(4x16) + C; A: row = lane & 15, k = lane >> 4; B: col =
+// lane & 15, k = lane >> 4; C/D register r: col = lane & 15, row = (lane >> 4) + 4 r).
+// A wavefront owns 16 rows I of a 64-row block and walks the 16-column tiles L of A22'.  It holds
+// the TRANSPOSED tile, D(l, i) = A22'(i, l): the D columns are then consecutive rows i, so every
+// load/store of register r is four 128-B row segments (columns l0 + 4 r + 0..3).
+//   update   D -= [V_L Z_L] [Z_I V_I]^T         8 MFMAs, K = 2 SB; the row operands stay in VGPRs
+//   product  X^T(:, I) += Vn_L^T D              4 MFMAs: register r of D IS the B operand of
+//                                               K-group r (k = l - l0 - 4 r), no shuffles
+// The vector-FMA version above needs its column operands as SGPRs and is bound by the scalar-load
+// latency (tools/fma64_bench.hip); here operands are plain coalesced vector loads of the packed
+// row-major V / Z and 12 instructions do the 12288 FMAs of a tile.  Kept as an alternative
+// (SAAMGE_AMD_EIG_FUSED=2): on MI355X the fp64 MFMA sustains ~110 cycles per instruction per
+// SIMD, which makes this variant as fast as the vector one, not faster.
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// RG 64-row sub-blocks per workgroup (wavefront w owns rows 64 g + 16 w .. + 15 of sub-block g):
+// taller strips mean longer contiguous column segments (64 RG x 8 B) per DRAM visit and the
+// column operands are shared by the RG row groups.
+template <int RG>
+__global__ __launch_bounds__(256) void sbr_fused_mfma_kernel(int k0, const int *__restrict__ ns,
+                                                             const int64_t *__restrict__ moff,
+                                                             const int64_t *__restrict__ voff,
+                                                             double *__restrict__ Wm,
+                                                             const double *__restrict__ Vcur,
+                                                             const double *__restrict__ Zbuf,
+                                                             const double *__restrict__ Vnext,
+                                                             double *__restrict__ Xbuf,
+                                                             const int64_t *__restrict__ goff,
+                                                             double *__restrict__ Gbuf, int count,
+                                                             int tiles) {
+    constexpr int SBP = SB + 1;
+    __shared__ double xs[64 * SBP], vs2[64 * SBP];
+    int b, blk;
+    xcd_decode(tiles, b, blk);
+    if (b >= count) return;
+    const int n = ns[b];
+    if (n - k0 - SB < 2) return;               // this matrix has no panel k0
+    const int np = n - k0 - 2 * SB;            // order of A22' (may be < 2: update only)
+    if (np < 1) return;
+    const int i0 = blk * (64 * RG);
+    if (i0 >= np) return;
+    const bool prod = np >= 2;                 // the next panel has reflectors
+    double *A22 = Wm + moff[b] + (size_t)(k0 + 2 * SB) * n + (k0 + 2 * SB);
+    const double *__restrict__ Z = Zbuf + voff[b] * SB + SB * SB;     // rows shifted by SB
+    const double *__restrict__ Vc = Vcur + voff[b] * SB + SB * SB;
+    const double *__restrict__ Vn = Vnext + voff[b] * SB;
+    double *X = Xbuf + voff[b] * SB;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    int ig[RG];
+    bool iok[RG];
+    double bz[RG][4], bv[RG][4];               // negated row operands: -Z(i, 4 kg + lk), -V(i, 4 kg + lk)
+    v4d xacc[RG];
+    double *colp[RG];
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+        ig[g] = i0 + 64 * g + 16 * w + li;
+        iok[g] = ig[g] < np;
+        const int ic = min(ig[g], np - 1);
+        colp[g] = A22 + ic;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            const double z = Z[(size_t)ic * SB + 4 * kg + lk], v = Vc[(size_t)ic * SB + 4 * kg + lk];
+            bz[g][kg] = iok[g] ? -z : 0.0;
+            bv[g][kg] = iok[g] ? -v : 0.0;
+        }
+        xacc[g] = v4d{0.0, 0.0, 0.0, 0.0};
+    }
+    if (i0 + 16 * w < np) {                    // wave-uniform: the wavefront has rows
+        for (int l0 = 0; l0 < np; l0 += 16) {
+            const int l = l0 + li;
+            const bool lok = l < np;
+            const int lc = min(l, np - 1);
+            double av[4], az[4];               // column operands V(l, 4 kg + lk), Z(l, 4 kg + lk)
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                const double v = Vc[(size_t)lc * SB + 4 * kg + lk], z = Z[(size_t)lc * SB + 4 * kg + lk];
+                av[kg] = lok ? v : 0.0;
+                az[kg] = lok ? z : 0.0;
+            }
+            double an[4];
+            if (prod) {
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) {
+                    const int lrow = l0 + 4 * kg + lk;
+                    const double a = Vn[(size_t)min(lrow, np - 1) * SB + li];
+                    an[kg] = lrow < np ? a : 0.0;
+                }
+            }
+            size_t coff[4];
+            bool cin[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = l0 + 4 * r + lk;
+                cin[r] = col < np;
+                coff[r] = (size_t)min(col, np - 1) * n;
+            }
+            v4d acc[RG];
+#pragma unroll
+            for (int g = 0; g < RG; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double t = colp[g][coff[r]];
+                    acc[g][r] = (iok[g] && cin[r]) ? t : 0.0;
+                }
+#pragma unroll
+            for (int g = 0; g < RG; ++g) {
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg)
+                    acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kg], bz[g][kg], acc[g], 0, 0, 0);
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg)
+                    acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(az[kg], bv[g][kg], acc[g], 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < RG; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (iok[g] && cin[r]) A22[coff[r] + ig[g]] = acc[g][r];
+            if (prod) {
+#pragma unroll
+                for (int g = 0; g < RG; ++g)
+#pragma unroll
+                    for (int kg = 0; kg < 4; ++kg)
+                        xacc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[kg], acc[g][kg], xacc[g], 0, 0, 0);
+            }
+        }
+    }
+    if (!prod) return;   // block-uniform
+    // ---- X(i, j), j = lk + 4 r; partial G = V^T X per 64-row sub-block ----
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+        if (i0 + 64 * g >= np) break;          // block-uniform
+        if (g) __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = lk + 4 * r;
+            if (iok[g]) X[(size_t)j * n + ig[g]] = xacc[g][r];
+            xs[(16 * w + li) * SBP + j] = iok[g] ? xacc[g][r] : 0.0;
+        }
+        for (int idx = tid; idx < 64 * SB; idx += 256) {
+            const int rr = idx >> 4, j = idx & 15;
+            const int row = i0 + 64 * g + rr;
+            vs2[rr * SBP + j] = (row < np) ? Vn[(size_t)row * SB + j] : 0.0;
+        }
+        __syncthreads();
+        const int a = tid >> 4, c = tid & 15;
+        double s = 0.0;
+        for (int rr = 0; rr < 64; ++rr) s = fma(vs2[rr * SBP + a], xs[rr * SBP + c], s);
+        Gbuf[goff[b] + (size_t)(blk * RG + g) * (SB * SB) + tid] = s;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // stage 2: bulge chasing
 // ---------------------------------------------------------------------------------------
@@ -869,45 +1179,115 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b) {
     // ---- stage 1 ----
     const int nmax = b.max_n;
     const bool prof = profiler().enabled;
-    double sbytes = 0.0, ubytes = 0.0;   // algorithmic bytes of the product / update kernels
+    // algorithmic bytes of the product / update / fused kernels (trailing matrix read once by
+    // the product; read + written once by the update, also when the next product rides on it)
+    double sbytes = 0.0, ubytes = 0.0, fbytes = 0.0;
     if (prof) {
         for (int n : b.h_n)
             for (int k0 = 0; n - k0 - SB >= 2; k0 += SB) {
-                const double np = n - k0 - SB;
+                const double np = n - k0 - SB, npn = std::max(0.0, np - SB);
                 sbytes += 8.0 * np * np;
                 ubytes += 16.0 * np * np;
+                fbytes += 16.0 * npn * npn;
             }
     }
+    // SAAMGE_AMD_EIG_FUSED: 0 = separate product / update kernels, 1 (default) = fused, vector
+    // FMAs with scalar-cache operands, 2 = fused on the matrix cores.  Measured on MI355X
+    // (256^3, profiles/r01_*): 1 is the fastest; fp64 MFMA (tools/fma64_bench.hip: 46 TFLOP/s
+    // sustained vs 69 for v_fma_f64) buys nothing here because none of the variants is bound by
+    // FMA issue or by HBM bytes -- they are bound by operand delivery (scalar-load latency).
+    static const int fused_mode = []() {
+        const char *e = std::getenv("SAAMGE_AMD_EIG_FUSED");
+        return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+    }();
+    const bool fused = fused_mode != 0;
     if (!prof) profiler().begin(s);
-    bool first = true;
-    for (int k0 = 0; nmax - k0 - SB >= 2; k0 += SB) {
+    const int cnt8 = 8 * div_up(b.count, 8);
+    auto launch_qr = [&](int k0, double *Vp) {
         const int npmax = nmax - k0 - SB;
-        if (prof) profiler().begin(s);
         if (npmax <= 512)
             hipLaunchKernelGGL(sbr_qr_reg_kernel, dim3(b.count), dim3(256), 0, s, k0, b.n.p, b.moff.p,
-                               b.voff.p, b.W.p, b.Tfac.p, b.Vpk.p);
+                               b.voff.p, b.W.p, b.Tfac.p, Vp);
         else if ((size_t)npmax * SB * sizeof(double) <= 96 * 1024)
             hipLaunchKernelGGL((sbr_qr_kernel<256, true>), dim3(b.count), dim3(256),
                                (size_t)npmax * SB * sizeof(double), s, k0, b.n.p, b.moff.p, b.voff.p,
-                               b.W.p, b.Tfac.p, b.Vpk.p);
+                               b.W.p, b.Tfac.p, Vp);
         else
             hipLaunchKernelGGL((sbr_qr_kernel<1024, false>), dim3(b.count), dim3(1024), 0, s, k0,
-                               b.n.p, b.moff.p, b.voff.p, b.W.p, b.Tfac.p, b.Vpk.p);
-        if (prof) { profiler().end(s, "eig_sbr_qr", 0.0, 0.0); profiler().begin(s); }
-        const int cnt8 = 8 * div_up(b.count, 8);
+                               b.n.p, b.moff.p, b.voff.p, b.W.p, b.Tfac.p, Vp);
+    };
+    auto launch_symm = [&](int k0, double *Vp) {
+        const int npmax = nmax - k0 - SB;
         hipLaunchKernelGGL(sbr_symm_kernel, dim3(cnt8 * div_up(npmax, 64)), dim3(SY_NT), 0, s, k0,
-                           b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Xbuf.p, b.goff.p, b.Gbuf.p, b.count,
+                           b.n.p, b.moff.p, b.voff.p, b.W.p, Vp, b.Xbuf.p, b.goff.p, b.Gbuf.p, b.count,
                            div_up(npmax, 64));
-        if (prof) { profiler().end(s, "eig_sbr_symm", first ? sbytes : 0.0, 0.0); profiler().begin(s); }
+    };
+    auto launch_z = [&](int k0, double *Vp) {
+        const int npmax = nmax - k0 - SB;
         hipLaunchKernelGGL(sbr_z_kernel, dim3(cnt8 * div_up(npmax, SM_NT)), dim3(SM_NT), 0, s, k0,
-                           b.n.p, b.voff.p, b.Vpk.p, b.Tfac.p, b.Xbuf.p, b.goff.p, b.Gbuf.p,
+                           b.n.p, b.voff.p, Vp, b.Tfac.p, b.Xbuf.p, b.goff.p, b.Gbuf.p,
                            b.Zbuf.p, b.count, div_up(npmax, SM_NT));
-        if (prof) { profiler().end(s, "eig_sbr_z", 0.0, 0.0); profiler().begin(s); }
-        hipLaunchKernelGGL(sbr_syr2k_kernel, dim3(cnt8 * div_up(npmax, S2_ROWS)), dim3(S2_NT), 0, s, k0,
-                           b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.Xbuf.p, b.count,
-                           div_up(npmax, S2_ROWS));
-        if (prof) profiler().end(s, "eig_sbr_syr2k", first ? ubytes : 0.0, 0.0);
-        first = false;
+    };
+    bool first = true;
+    if (!fused) {
+        for (int k0 = 0; nmax - k0 - SB >= 2; k0 += SB) {
+            const int npmax = nmax - k0 - SB;
+            if (prof) profiler().begin(s);
+            launch_qr(k0, b.Vpk.p);
+            if (prof) { profiler().end(s, "eig_sbr_qr", 0.0, 0.0); profiler().begin(s); }
+            launch_symm(k0, b.Vpk.p);
+            if (prof) { profiler().end(s, "eig_sbr_symm", first ? sbytes : 0.0, 0.0); profiler().begin(s); }
+            launch_z(k0, b.Vpk.p);
+            if (prof) { profiler().end(s, "eig_sbr_z", 0.0, 0.0); profiler().begin(s); }
+            hipLaunchKernelGGL(sbr_syr2k_kernel, dim3(cnt8 * div_up(npmax, S2_ROWS)), dim3(S2_NT), 0, s, k0,
+                               b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.Xbuf.p, b.count,
+                               div_up(npmax, S2_ROWS));
+            if (prof) profiler().end(s, "eig_sbr_syr2k", first ? ubytes : 0.0, 0.0);
+            first = false;
+        }
+    } else if (nmax - SB >= 2) {
+        // look-ahead pipeline: the product of panel p+1 rides on the update of panel p
+        double *Vcur = b.Vpk.p, *Vnext = b.Vpk2.p;
+        if (prof) profiler().begin(s);
+        launch_qr(0, Vcur);
+        if (prof) { profiler().end(s, "eig_sbr_qr", 0.0, 0.0); profiler().begin(s); }
+        launch_symm(0, Vcur);
+        if (prof) { profiler().end(s, "eig_sbr_symm", 0.0, 0.0); profiler().begin(s); }
+        launch_z(0, Vcur);
+        if (prof) profiler().end(s, "eig_sbr_z", 0.0, 0.0);
+        for (int k0 = 0; nmax - k0 - SB >= 2; k0 += SB) {
+            const int npmax = nmax - k0 - SB;          // order of A22(k0)
+            const int npn = npmax - SB;                // order of A22' = A22(k0 + SB)
+            const bool has_next = npn >= 2;
+            if (prof) profiler().begin(s);
+            hipLaunchKernelGGL(sbr_panel_update_kernel, dim3(cnt8 * div_up(npmax, 256)), dim3(256), 0, s,
+                               k0, b.n.p, b.moff.p, b.voff.p, b.W.p, Vcur, b.Zbuf.p, b.count,
+                               div_up(npmax, 256));
+            if (prof) { profiler().end(s, "eig_sbr_panel", 0.0, 0.0); profiler().begin(s); }
+            if (has_next) launch_qr(k0 + SB, Vnext);
+            if (prof) { profiler().end(s, "eig_sbr_qr", 0.0, 0.0); profiler().begin(s); }
+            static const int rg = []() {
+                const char *e = std::getenv("SAAMGE_AMD_EIG_RG");
+                return (e && (e[0] == '1' || e[0] == '2' || e[0] == '4')) ? e[0] - '0' : 2;
+            }();
+            if (npn >= 1 && fused_mode == 2) {
+#define SA_FUSED(RGV)                                                                                      \
+    hipLaunchKernelGGL((sbr_fused_mfma_kernel<RGV>), dim3(cnt8 * div_up(npn, 64 * RGV)), dim3(256), 0, s,  \
+                       k0, b.n.p, b.moff.p, b.voff.p, b.W.p, Vcur, b.Zbuf.p, Vnext, b.Xbuf.p, b.goff.p,    \
+                       b.Gbuf.p, b.count, div_up(npn, 64 * RGV))
+                if (rg == 1) SA_FUSED(1); else if (rg == 2) SA_FUSED(2); else SA_FUSED(4);
+#undef SA_FUSED
+            }
+            else if (npn >= 1)
+                hipLaunchKernelGGL(sbr_fused_kernel, dim3(cnt8 * div_up(npn, SF_ROWS)), dim3(S2_NT), 0, s,
+                                   k0, b.n.p, b.moff.p, b.voff.p, b.W.p, Vcur, b.Zbuf.p, Vnext, b.Xbuf.p,
+                                   b.goff.p, b.Gbuf.p, b.trash.p, b.count, div_up(npn, SF_ROWS));
+            if (prof) { profiler().end(s, "eig_sbr_fused", first ? fbytes : 0.0, 0.0); profiler().begin(s); }
+            if (has_next) launch_z(k0 + SB, Vnext);
+            if (prof) profiler().end(s, "eig_sbr_z", 0.0, 0.0);
+            std::swap(Vcur, Vnext);
+            first = false;
+        }
     }
     SA_HIP_CHECK(hipGetLastError());
     if (!prof) profiler().end(s, "eig_band_reduce", bytes, flops);
