@@ -13,6 +13,7 @@ constexpr int EIG_SB = 16;  // band width of the two-stage reduction
 
 struct EigBatch {
     int count = 0;          // matrices in the batch
+    int slot = 0;           // which of the two persistent workspaces backs this batch (chunk pipelining)
     int max_n = 0;
     DBuf<int> n;            // [count] sizes
     DBuf<int64_t> moff;     // [count] offset of matrix i in W (doubles), column-major ld = n_i
@@ -39,12 +40,16 @@ struct EigBatch {
 };
 
 // sizes known on the host; allocates everything but leaves W/dis to be filled by the caller
-void eig_batch_alloc(EigBatch &b, const std::vector<int> &sizes, hipStream_t s);
+void eig_batch_alloc(EigBatch &b, const std::vector<int> &sizes, hipStream_t s, int slot = 0);
 
 // Phase 1: tridiagonalise every matrix in place.  The default is the two-stage reduction
 // (eig2.hip); SAAMGE_AMD_EIG=onestage selects the one-stage blocked Householder kernel.
-void eig_tridiagonalize(hipStream_t s, EigBatch &b);
-void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b);
+// `phases`: 1 = dense -> band only, 2 = band -> tridiagonal only, 3 = both.  The split lets the
+// caller run the (latency-bound) bulge chasing of one chunk beside the (bandwidth-hungry)
+// band reduction of the next one on another stream.
+void eig_tridiagonalize(hipStream_t s, EigBatch &b, int phases = 3);
+void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases);
+bool eig_uses_two_stage();
 void eig_backtransform_two_stage(hipStream_t s, EigBatch &b, const int64_t *xoff, double *evecs);
 int64_t chase_reflector_count(int n);
 void eig_batch_two_stage_buffers(EigBatch &b, size_t nrefl, bool need_bandg, hipStream_t s);

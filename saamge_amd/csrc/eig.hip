@@ -629,9 +629,10 @@ struct EigArena {
     DBuf<int> n, m, j0;
     DBuf<int64_t> moff, voff, roff, goff;
 };
+static int g_slot = 0;   // workspace of the batch being set up (single host thread)
 static EigArena &arena() {
-    static EigArena a;
-    return a;
+    static EigArena a[2];
+    return a[g_slot];
 }
 template <class T>
 static void arena_view(DBuf<T> &dst, DBuf<T> &pool, size_t need) {
@@ -639,11 +640,16 @@ static void arena_view(DBuf<T> &dst, DBuf<T> &pool, size_t need) {
     dst.view(pool.p, need);
 }
 void eig_arena_release() {
-    EigArena &a = arena();
-    a = EigArena();
+    for (g_slot = 0; g_slot < 2; ++g_slot) {
+        EigArena &a = arena();
+        a = EigArena();
+    }
+    g_slot = 0;
 }
+bool eig_uses_two_stage() { return !use_one_stage(); }
 
-void eig_batch_alloc(EigBatch &b, const std::vector<int> &sizes, hipStream_t s) {
+void eig_batch_alloc(EigBatch &b, const std::vector<int> &sizes, hipStream_t s, int slot) {
+    b.slot = g_slot = slot & 1;
     b.count = (int)sizes.size();
     b.h_n = sizes;
     b.h_moff.assign(b.count + 1, 0);
@@ -676,6 +682,7 @@ void eig_batch_alloc(EigBatch &b, const std::vector<int> &sizes, hipStream_t s) 
 }
 
 void eig_batch_two_stage_buffers(EigBatch &b, size_t nrefl, bool need_bandg, hipStream_t s) {
+    g_slot = b.slot;
     EigArena &a = arena();
     const size_t rows = (size_t)b.h_voff[b.count];
     arena_view(b.Tfac, a.Tfac, rows * EIG_SB + EIG_SB * EIG_SB);
@@ -704,7 +711,7 @@ size_t eig_workspace_bytes(int n) {
     return 8 * (nn * nn + nn * (EIG_NB + 8) + nn * nn / 2 + nn * (3 * EIG_SB + 2 * EIG_SB) + 64);
 }
 
-void eig_tridiagonalize(hipStream_t s, EigBatch &b) {
+void eig_tridiagonalize(hipStream_t s, EigBatch &b, int phases) {
     if (!b.count) return;
     static bool attr0 = false;
     if (!attr0) {
@@ -716,10 +723,11 @@ void eig_tridiagonalize(hipStream_t s, EigBatch &b) {
     }
     if (!use_one_stage()) {
         b.two_stage = true;
-        eig_tridiagonalize_two_stage(s, b);
+        eig_tridiagonalize_two_stage(s, b, phases);
         return;
     }
     b.two_stage = false;
+    if (!(phases & 1)) return;   // one-stage: everything happens in "phase 1"
     const size_t lds = tri_lds_bytes(b.max_n);
     SA_REQUIRE(lds <= LDS_MAX, "agglomerate too large for the LDS-resident reflector vectors");
     static bool attr_set = false;

@@ -1145,7 +1145,7 @@ int64_t chase_reflector_count(int n) {
     return r;
 }
 
-void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b) {
+void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
     if (!b.count) return;
     static bool attr = false;
     if (!attr) {
@@ -1170,7 +1170,7 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b) {
     b.h_goff.assign((size_t)b.count + 1, 0);
     for (int i = 0; i < b.count; ++i)
         b.h_goff[i + 1] = b.h_goff[i] + (int64_t)((b.h_n[i] + 63) / 64) * SB * SB;
-    eig_batch_two_stage_buffers(b, nrefl, !in_lds0, s);
+    if (phases & 1) eig_batch_two_stage_buffers(b, nrefl, !in_lds0, s);
     double flops = 0.0, bytes = 0.0;
     for (int n : b.h_n) {
         flops += 4.0 / 3.0 * (double)n * n * n;
@@ -1201,6 +1201,7 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b) {
         return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
     }();
     const bool fused = fused_mode != 0;
+    if (phases & 1) {
     if (!prof) profiler().begin(s);
     const int cnt8 = 8 * div_up(b.count, 8);
     auto launch_qr = [&](int k0, double *Vp) {
@@ -1291,6 +1292,8 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b) {
     }
     SA_HIP_CHECK(hipGetLastError());
     if (!prof) profiler().end(s, "eig_band_reduce", bytes, flops);
+    }
+    if (!(phases & 2)) return;
     // ---- stage 2 ----
     const size_t fixed = sizeof(double) * (CH_NW * HAND) + sizeof(int) * ((size_t)nmax + 4);
     const size_t band_bytes = sizeof(double) * (size_t)nmax * LDB;

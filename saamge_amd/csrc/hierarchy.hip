@@ -106,7 +106,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     std::vector<int> sizes((size_t)nparts);
     for (int p = 0; p < nparts; ++p) sizes[p] = rel.AE_to_dof.row_size(p);
     L.ae_m.assign((size_t)nparts, 0);
-    struct Chunk { int ae0, count; DBuf<double> evals, evecs; std::vector<int64_t> eoff, xoff; };
+    struct Chunk { int ae0, count; DBuf<double> evals, evecs; std::vector<int64_t> eoff, xoff; DBuf<int64_t> d_eoff, d_xoff; };
     std::vector<Chunk> chunks;
     if (P.keep_debug) L.ae_D.alloc((size_t)rel.AE_to_dof.J.size());
     // AE ownership: contiguous ranges balanced by the n^3 cost of the eigenproblems
@@ -131,25 +131,39 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     const int ae_lo = ae_begin[world > 1 ? P.rank : 0], ae_hi = ae_begin[world > 1 ? P.rank + 1 : 1];
     int64_t row0 = 0;
     for (int p = 0; p < ae_lo; ++p) row0 += sizes[p];
-    for (int ae0 = ae_lo; ae0 < ae_hi;) {
-        size_t bytes = 0;
-        int cnt = 0;
-        while (ae0 + cnt < ae_hi) {
-            const size_t add = eig_workspace_bytes(sizes[ae0 + cnt]);
-            if (cnt > 0 && bytes + add > P.workspace_bytes) break;
-            bytes += add;
-            ++cnt;
-        }
-        PhaseTimer tc(s);
-        EigBatch batch;
-        eig_batch_alloc(batch, std::vector<int>(sizes.begin() + ae0, sizes.begin() + ae0 + cnt), s);
-        tc.lap("  chunk alloc", lev);
-        ae_build(s, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch, true,
-                 P.keep_debug ? L.ae_D.p + row0 : nullptr);
-        tc.lap("  chunk assemble+scale", lev);
-        eig_tridiagonalize(s, batch);
-        tc.lap("  chunk tridiagonalize", lev);
-        eig_count(s, batch, -1.0, L.theta);
+    // Optional chunk pipeline (SAAMGE_AMD_PIPELINE=1): dense -> band of chunk i on stream A beside
+    // the bulge chasing / Sturm counts / inverse iteration / back-transformation of chunk i-1 on
+    // stream B, two persistent workspaces alternating; the streams are internal and non-blocking
+    // (the caller's stream may be the null stream, which would serialise them).  Measured on
+    // MI355X: no gain (256^3: 3.48 s vs 3.29 s sequential, 128^3: equal) -- the two kernel families
+    // do not co-schedule profitably and the smaller chunks cost more than the overlap returns --
+    // so it is off by default.
+    static hipStream_t sA = nullptr, sB = nullptr;
+    static hipEvent_t ev_band[2] = {nullptr, nullptr};
+    static const bool want_pipe = std::getenv("SAAMGE_AMD_PIPELINE") != nullptr;
+    const bool pipelined = want_pipe && eig_uses_two_stage() && !profiler().enabled && !tm.on;
+    if (pipelined && !sA) {
+        SA_HIP_CHECK(hipStreamCreateWithFlags(&sA, hipStreamNonBlocking));
+        SA_HIP_CHECK(hipStreamCreateWithFlags(&sB, hipStreamNonBlocking));
+        SA_HIP_CHECK(hipEventCreateWithFlags(&ev_band[0], hipEventDisableTiming));
+        SA_HIP_CHECK(hipEventCreateWithFlags(&ev_band[1], hipEventDisableTiming));
+    }
+    hipStream_t qa = pipelined ? sA : s, qb = pipelined ? sB : s;
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    size_t chunk_bytes = P.workspace_bytes;
+    if (pipelined) {   // at least ~4 chunks when there is enough work to overlap
+        size_t total = 0;
+        for (int p = ae_lo; p < ae_hi; ++p) total += eig_workspace_bytes(sizes[p]);
+        if (total > ((size_t)4 << 30)) chunk_bytes = std::min(chunk_bytes, std::max(total / 4 + 1, (size_t)2 << 30));
+    }
+    EigBatch batches[2];
+    int pend_ae0[2] = {0, 0}, pend_cnt[2] = {0, 0};
+    auto post = [&](int slot) {   // band -> tridiagonal, counts, eigenvectors of the chunk in `slot`
+        EigBatch &batch = batches[slot];
+        const int ae0 = pend_ae0[slot], cnt = pend_cnt[slot];
+        if (pipelined) SA_HIP_CHECK(hipStreamWaitEvent(qb, ev_band[slot], 0));
+        eig_tridiagonalize(qb, batch, 2);
+        eig_count(qb, batch, -1.0, L.theta);
         chunks.emplace_back();
         Chunk &c = chunks.back();
         c.ae0 = ae0;
@@ -163,13 +177,40 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         }
         c.evals.alloc((size_t)c.eoff[cnt]);
         c.evecs.alloc((size_t)c.xoff[cnt]);
-        DBuf<int64_t> d_eoff, d_xoff;
-        d_eoff.from_host(c.eoff, s);
-        d_xoff.from_host(c.xoff, s);
-        eig_vectors(s, batch, d_eoff.p, d_xoff.p, c.evals.p, c.evecs.p);
-        SA_HIP_CHECK(hipStreamSynchronize(s));
+        c.d_eoff.from_host(c.eoff, qb);
+        c.d_xoff.from_host(c.xoff, qb);
+        eig_vectors(qb, batch, c.d_eoff.p, c.d_xoff.p, c.evals.p, c.evecs.p);
+        SA_HIP_CHECK(hipStreamSynchronize(qb));
+    };
+    int prev = -1, idx = 0;
+    for (int ae0 = ae_lo; ae0 < ae_hi; ++idx) {
+        size_t bytes = 0;
+        int cnt = 0;
+        while (ae0 + cnt < ae_hi) {
+            const size_t add = eig_workspace_bytes(sizes[ae0 + cnt]);
+            if (cnt > 0 && bytes + add > chunk_bytes) break;
+            bytes += add;
+            ++cnt;
+        }
+        const int slot = idx & 1;
+        EigBatch &batch = batches[slot];
+        batch = EigBatch();
+        eig_batch_alloc(batch, std::vector<int>(sizes.begin() + ae0, sizes.begin() + ae0 + cnt), qa, slot);
+        ae_build(qa, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch, true,
+                 P.keep_debug ? L.ae_D.p + row0 : nullptr);
+        eig_tridiagonalize(qa, batch, 1);
+        if (pipelined) SA_HIP_CHECK(hipEventRecord(ev_band[slot], qa));
+        pend_ae0[slot] = ae0;
+        pend_cnt[slot] = cnt;
+        if (prev >= 0) post(prev);
+        prev = slot;
         row0 += batch.h_voff[cnt];
         ae0 += cnt;
+    }
+    if (prev >= 0) post(prev);
+    if (pipelined) {
+        SA_HIP_CHECK(hipStreamSynchronize(qa));
+        SA_HIP_CHECK(hipStreamSynchronize(qb));
     }
     tm.lap("local eigenproblems", lev);
     if (world > 1) {   // exchange the number of eigenvectors per AE
