@@ -57,6 +57,27 @@ class Params(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME
+    as the system one this library links to); whichever is loaded first serves both.  If OUR
+    library came first, torch would later bring in its own copy as a second runtime and find
+    "No HIP GPUs are available".  So when torch is installed but not imported yet, map ITS
+    runtime first: this library then binds to it, exactly as when torch is imported first."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass   # no torch / unusual layout: the system runtime is used
+
+
 def load():
     """Load the HIP library; raises if it has not been built (no fallback)."""
     global _lib
@@ -65,6 +86,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("saamge_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; "
                            "g.build()'` (hipcc, gfx950); there is no CPU fallback" % LIB_PATH)
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     lib.saamge_amd_last_error.restype = C.c_char_p
     lib.saamge_amd_num_levels.restype = C.c_int

@@ -248,7 +248,17 @@ int saamge_amd_get_table(const saamge_amd_hierarchy *h, int level, int which, in
         case 2: T = &r.mis_to_dof; break;
         case 3: T = &r.mis_to_AE; break;
         case 4: T = &r.AE_to_mis; break;
-        case 5: T = &r.elem_to_dof; break;
+        case 5: {
+            if (r.elem_to_dof.I.empty()) {   // built on the device: fetch the host copy on demand
+                Level &L = *h->H->levels.at(level);
+                Relations &rw = L.rel;
+                rw.elem_to_dof.I = L.drel.e2d_I.to_host(h->H->stream);
+                rw.elem_to_dof.J = L.drel.e2d_J.to_host(h->H->stream);
+                rw.elem_to_dof.ncols = rw.ND;
+            }
+            T = &r.elem_to_dof;
+            break;
+        }
         default: throw Error(1, "bad table selector");
     }
     if (nrows) *nrows = T->nrows();

@@ -64,6 +64,11 @@ static double *scratch_get(int slot, size_t need) {
 
 static void finish_csr(DCsr &A) { A.lanes_per_row = pick_lanes_per_row(A.nnz, A.nrows > 0 ? A.nrows : 1); }
 
+__global__ void iota64_kernel(long n, int64_t scale, int64_t *p) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = i * scale;
+}
+
 __global__ void fill_kernel(long n, double *p, double v) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
@@ -72,8 +77,14 @@ __global__ void fill_kernel(long n, double *p, double v) {
 // ---------------------------------------------------------------------------------------
 // one coarsening: tg_init_data + tg_build_hierarchy + tg_update_coarse_operator
 // ---------------------------------------------------------------------------------------
+struct DeviceInputs {   // level-0 inputs that already live on the device (see hierarchy_create)
+    const int *e2d = nullptr, *part = nullptr;
+    const signed char *bdr = nullptr;
+    int NE = 0, nde = 0;
+};
+
 static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &part, int nparts,
-                        const signed char *bdr_host) {
+                        const signed char *bdr_host, const DeviceInputs *din = nullptr) {
     Level &L = *H.levels[lev];
     hipStream_t s = H.stream;
     const Params &P = H.params;
@@ -81,10 +92,29 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     L.nu_relax = P.nu_relax[lev];
     SA_REQUIRE(P.nu_pro[lev] == 0, "prolongator smoothing (nu_pro > 0) is not implemented yet");
     PhaseTimer tm(s);
-    build_relations_ae(L.rel, std::move(e2d), part, nparts, L.A.nrows, bdr_host);
-    tm.lap("host topology (AE tables)", lev);
-    upload_relations_ae(L.drel, L.rel, s);
-    tm.lap("upload topology", lev);
+    bool on_device = false;
+    if (din) {
+        on_device = build_relations_ae_device(L.rel, L.drel, din->e2d, din->NE, din->nde, din->part, nparts,
+                                              L.A.nrows, din->bdr, s);
+        tm.lap("device topology (AE tables)", lev);
+    }
+    if (!on_device) {
+        hvec<int> part_h;
+        hvec<signed char> bdr_h;
+        if (din) {   // agglomerates too large for the device kernels: fetch and take the host path
+            e2d.J = fetch_host(din->e2d, (size_t)din->NE * din->nde, s);
+            e2d.I.resize((size_t)din->NE + 1);
+            for (int e = 0; e <= din->NE; ++e) e2d.I[e] = e * din->nde;
+            e2d.ncols = L.A.nrows;
+            part_h = fetch_host(din->part, (size_t)din->NE, s);
+            if (din->bdr) bdr_h = fetch_host(din->bdr, (size_t)L.A.nrows, s);
+        }
+        build_relations_ae(L.rel, std::move(e2d), din ? part_h : part, nparts, L.A.nrows,
+                           din ? (din->bdr ? bdr_h.data() : nullptr) : bdr_host);
+        tm.lap("host topology (AE tables)", lev);
+        upload_relations_ae(L.drel, L.rel, s);
+        tm.lap("upload topology", lev);
+    }
     // the MIS tables are built on a host thread while the GPU solves the local eigenproblems
     std::exception_ptr mis_err;
     std::thread mis_thread([&]() {
@@ -684,29 +714,43 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
         finish_csr(L0.A);
     }
     {
-        std::vector<int64_t> off((size_t)NE + 1);
-        for (int e = 0; e <= NE; ++e) off[e] = (int64_t)e * nde * nde;
-        L0.elmat.off.from_host(off, s);
+        L0.elmat.off.alloc((size_t)NE + 1);
+        hipLaunchKernelGGL(iota64_kernel, dim3(div_up((long)NE + 1, 256)), dim3(256), 0, s, (long)NE + 1,
+                           (int64_t)nde * nde, L0.elmat.off.p);
+        SA_HIP_CHECK(hipGetLastError());
         import_array(L0.elmat.val, elmat, (size_t)NE * nde * nde, s);
         L0.elmat.nde = nde;
     }
+    // Level-0 topology inputs that are device-resident stay there (device build of the AE tables)
+    static const bool host_topo = std::getenv("SAAMGE_AMD_HOST_TOPOLOGY") != nullptr;
+    DeviceInputs din;
+    const bool dev_inputs = !host_topo && is_device_ptr(elem_to_dof) && is_device_ptr(partitions[0]) &&
+                            (!bdr || is_device_ptr(bdr));
     Table e2d;
-    {
+    hvec<signed char> bdr_h;
+    if (dev_inputs) {
+        din.e2d = elem_to_dof;
+        din.part = partitions[0];
+        din.bdr = bdr;
+        din.NE = NE;
+        din.nde = nde;
+    } else {
         auto J = fetch_host(elem_to_dof, (size_t)NE * nde, s);
         e2d.J = std::move(J);
         e2d.I.resize((size_t)NE + 1);
         for (int e = 0; e <= NE; ++e) e2d.I[e] = e * nde;
         e2d.ncols = n;
+        if (bdr) bdr_h = fetch_host(bdr, (size_t)n, s);
     }
-    hvec<signed char> bdr_h;
-    if (bdr) bdr_h = fetch_host(bdr, (size_t)n, s);
     tm0.lap("inputs fetched/imported", 0);
     int n_elem = NE;
     for (int lev = 0; lev < p.num_coarsenings; ++lev) {
-        auto part = fetch_host(partitions[lev], (size_t)n_elem, s);
+        hvec<int> part;
+        if (!(lev == 0 && dev_inputs)) part = fetch_host(partitions[lev], (size_t)n_elem, s);
         static const bool tag_levels = std::getenv("SAAMGE_AMD_PROFILE_LEVELS") != nullptr;
         profiler().level_tag = tag_levels ? lev : 0;
-        build_level(H, lev, std::move(e2d), part, nparts[lev], (lev == 0 && bdr) ? bdr_h.data() : nullptr);
+        build_level(H, lev, std::move(e2d), part, nparts[lev], (lev == 0 && bdr && !dev_inputs) ? bdr_h.data() : nullptr,
+                    (lev == 0 && dev_inputs) ? &din : nullptr);
         Level &L = *H.levels[lev];
         if (lev + 1 < p.num_coarsenings) {
             PhaseTimer tm(s);

@@ -57,6 +57,13 @@ struct DevRelations {
     DBuf<signed char> flags;
 };
 void upload_relations_ae(DevRelations &d, const Relations &r, hipStream_t s);
+// build_relations_ae + upload_relations_ae entirely on the device for device-resident inputs with
+// a fixed number of dofs per element (level 0); the host receives the tables the MIS stage and
+// the next level need, never elem_to_dof.  Returns false (nothing built) when an agglomerate is
+// too large for the LDS kernels: the caller then takes the host path.
+bool build_relations_ae_device(Relations &r, DevRelations &d, const int *e2d_dev, int NE, int nde,
+                               const int *part_dev, int nparts, int ND, const signed char *bdr_dev,
+                               hipStream_t s);
 void upload_relations_mis(DevRelations &d, const Relations &r, hipStream_t s);
 
 }  // namespace saamge_amd

@@ -562,6 +562,260 @@ void upload_relations_ae(DevRelations &d, const Relations &r, hipStream_t s) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Device build of the AE tables (level 0 with device-resident inputs): the same tables as
+// build_relations_ae, bit for bit, without moving elem_to_dof to the host.
+//   AE_to_elem   count + scan + atomic fill, rows sorted in LDS (bitonic)       ascending elements
+//   AE_to_dof    one workgroup per AE: LDS hash set keyed by dof holding the MIN rank of its
+//                appearances (rank = element position * nde + slot); a dof is kept at its minimum
+//                rank, so compacting the ranks in order gives mfem::Mult's first-encounter order
+//   dof_to_AE    count + scan + atomic fill, short rows sorted per dof (with dof_id_inAE payload)
+// ---------------------------------------------------------------------------------------
+constexpr int TOPO_MAXK = 4096;   // candidate (element, slot) pairs per AE handled in LDS
+
+__global__ __launch_bounds__(256) void topo_check_kernel(long NE, long nconn, int nparts, int ND,
+                                                         const int *__restrict__ part,
+                                                         const int *__restrict__ e2d_J, int *__restrict__ err) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < NE && (part[i] < 0 || part[i] >= nparts)) atomicOr(err, 1);
+    if (i < nconn && (e2d_J[i] < 0 || e2d_J[i] >= ND)) atomicOr(err, 2);
+}
+__global__ __launch_bounds__(256) void iota_scaled_kernel(long n, int scale, int *__restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (int)(i * scale);
+}
+__global__ __launch_bounds__(256) void key_count_kernel(long n, const int *__restrict__ key, int *__restrict__ cnt) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&cnt[key[i]], 1);
+}
+__global__ __launch_bounds__(256) void key_fill_kernel(long n, const int *__restrict__ key,
+                                                       const int *__restrict__ rowI, int *__restrict__ cursor,
+                                                       int *__restrict__ J) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) J[rowI[key[i]] + atomicAdd(&cursor[key[i]], 1)] = (int)i;
+}
+__global__ __launch_bounds__(256) void any_zero_kernel(long n, const int *__restrict__ cnt, int bit, int *__restrict__ err) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && cnt[i] == 0) atomicOr(err, bit);
+}
+// ascending sort of every row (row length <= cap, a power of two <= 4096), one workgroup per row
+__global__ __launch_bounds__(256) void row_sort_kernel(const int *__restrict__ I, int *__restrict__ J, int cap) {
+    extern __shared__ int sh[];
+    const int p = blockIdx.x;
+    const int b = I[p], len = I[p + 1] - b;
+    for (int i = threadIdx.x; i < cap; i += 256) sh[i] = (i < len) ? J[b + i] : 0x7fffffff;
+    __syncthreads();
+    for (int k = 2; k <= cap; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < cap; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const int a = sh[i], c = sh[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) { sh[i] = c; sh[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < len; i += 256) J[b + i] = sh[i];
+}
+
+// mode 0: rowcnt[p] = number of distinct dofs; mode 1: write them at out[outI[p] ...] in
+// first-encounter order
+__global__ __launch_bounds__(256) void ae_to_dof_kernel(int mode, int nde, int HS,
+                                                        const int *__restrict__ ae2e_I,
+                                                        const int *__restrict__ ae2e_J,
+                                                        const int *__restrict__ e2d_J, int *__restrict__ rowcnt,
+                                                        const int *__restrict__ outI, int *__restrict__ out) {
+    extern __shared__ int sh[];
+    __shared__ int wsum[4], total;
+    int *keys = sh, *ranks = sh + HS, *first = sh + 2 * HS;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int eb = ae2e_I[p], ne = ae2e_I[p + 1] - eb;
+    const int K = ne * nde;
+    for (int i = tid; i < HS; i += 256) { keys[i] = -1; ranks[i] = 0x7fffffff; }
+    const int Kpad = (K + 255) & ~255;
+    for (int i = tid; i < Kpad; i += 256) first[i] = 0;
+    __syncthreads();
+    for (int idx = tid; idx < K; idx += 256) {
+        const int q = idx / nde, t = idx - q * nde;
+        const int d = e2d_J[(size_t)ae2e_J[eb + q] * nde + t];
+        unsigned h = ((unsigned)d * 2654435761u) & (unsigned)(HS - 1);
+        for (;;) {
+            const int prev = atomicCAS(&keys[h], -1, d);
+            if (prev == -1 || prev == d) { atomicMin(&ranks[h], idx); break; }
+            h = (h + 1) & (unsigned)(HS - 1);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < HS; i += 256)
+        if (keys[i] != -1) first[ranks[i]] = 1;
+    __syncthreads();
+    // exclusive scan of first[0..Kpad): each thread owns a contiguous run
+    const int per = Kpad / 256;
+    int run = 0;
+    for (int u = 0; u < per; ++u) run += first[tid * per + u];
+    int incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if ((tid & 63) >= o) incl += v;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int w = 0; w < 4; ++w) { const int v = wsum[w]; wsum[w] = acc; acc += v; }
+        total = acc;
+    }
+    __syncthreads();
+    if (mode == 0) {
+        if (tid == 0) rowcnt[p] = total;
+        return;
+    }
+    int pos = wsum[tid >> 6] + incl - run;
+    int *o = out + outI[p];
+    for (int u = 0; u < per; ++u) {
+        const int idx = tid * per + u;
+        if (first[idx]) {
+            const int q = idx / nde, t = idx - q * nde;
+            o[pos++] = e2d_J[(size_t)ae2e_J[eb + q] * nde + t];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void d2ae_fill_kernel(const int *__restrict__ ae2d_I, const int *__restrict__ ae2d_J,
+                                                        const int *__restrict__ d2ae_I, int *__restrict__ cursor,
+                                                        int *__restrict__ d2ae_J, int *__restrict__ did) {
+    const int p = blockIdx.x;
+    const int b = ae2d_I[p], e = ae2d_I[p + 1];
+    for (int k = b + threadIdx.x; k < e; k += 256) {
+        const int d = ae2d_J[k];
+        const int pos = d2ae_I[d] + atomicAdd(&cursor[d], 1);
+        d2ae_J[pos] = p;
+        did[pos] = k - b;
+    }
+}
+__global__ __launch_bounds__(256) void d2ae_sort_flags_kernel(int ND, const int *__restrict__ d2ae_I,
+                                                              int *__restrict__ d2ae_J, int *__restrict__ did,
+                                                              const signed char *__restrict__ bdr,
+                                                              signed char *__restrict__ flags) {
+    const long d = (long)blockIdx.x * 256 + threadIdx.x;
+    if (d >= ND) return;
+    const int b = d2ae_I[d], e = d2ae_I[d + 1];
+    for (int i = b + 1; i < e; ++i) {  // insertion sort by AE id, rows are short
+        const int v = d2ae_J[i], w = did[i];
+        int j = i - 1;
+        while (j >= b && d2ae_J[j] > v) { d2ae_J[j + 1] = d2ae_J[j]; did[j + 1] = did[j]; --j; }
+        d2ae_J[j + 1] = v;
+        did[j + 1] = w;
+    }
+    signed char f = bdr ? bdr[d] : 0;
+    if (e - b > 1) f |= FLAG_BETWEEN_AES;
+    flags[d] = f;
+}
+
+template <class T>
+static void download(hvec<T> &dst, const DBuf<T> &src, size_t n, hipStream_t s) {
+    dst.resize(n);
+    if (n) SA_HIP_CHECK(hipMemcpyAsync(dst.data(), src.p, n * sizeof(T), hipMemcpyDeviceToHost, s));
+}
+
+bool build_relations_ae_device(Relations &r, DevRelations &d, const int *e2d_dev, int NE, int nde,
+                               const int *part_dev, int nparts, int ND, const signed char *bdr_dev,
+                               hipStream_t s) {
+    const long nconn = (long)NE * nde;
+    r.ND = ND;
+    r.NE = NE;
+    r.nparts = nparts;
+    d.e2d_J.view(const_cast<int *>(e2d_dev), (size_t)nconn);
+    d.part.view(const_cast<int *>(part_dev), (size_t)NE);
+    d.e2d_I.alloc((size_t)NE + 1);
+    hipLaunchKernelGGL(iota_scaled_kernel, dim3(div_up((long)NE + 1, 256)), dim3(256), 0, s, (long)NE + 1, nde, d.e2d_I.p);
+    DBuf<int> err(1), cnt((size_t)std::max(nparts, ND) + 1);
+    err.zero(s);
+    hipLaunchKernelGGL(topo_check_kernel, dim3(div_up(nconn, 256)), dim3(256), 0, s, (long)NE, nconn, nparts, ND,
+                       part_dev, e2d_dev, err.p);
+    {
+        auto h = err.to_host(s);
+        SA_REQUIRE(!(h[0] & 1), "partition id out of range");
+        SA_REQUIRE(!(h[0] & 2), "elem_to_dof entry out of range");
+    }
+    // ---- AE_to_elem ----
+    DBuf<int> ae2e_I((size_t)nparts + 1), ae2e_J((size_t)NE);
+    SA_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(int) * (size_t)nparts, s));
+    hipLaunchKernelGGL(key_count_kernel, dim3(div_up(NE, 256)), dim3(256), 0, s, (long)NE, part_dev, cnt.p);
+    hipLaunchKernelGGL(any_zero_kernel, dim3(div_up(nparts, 256)), dim3(256), 0, s, (long)nparts, cnt.p, 4, err.p);
+    exclusive_scan_int(s, nparts, cnt.p, ae2e_I.p);
+    auto h_ae2e_I = ae2e_I.to_host(s);
+    SA_REQUIRE(!(err.to_host(s)[0] & 4), "empty agglomerate");
+    int max_ne = 0;
+    for (int p = 0; p < nparts; ++p) max_ne = std::max(max_ne, h_ae2e_I[p + 1] - h_ae2e_I[p]);
+    if ((long)max_ne * nde > TOPO_MAXK || max_ne > 4096) return false;   // host path handles it
+    SA_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(int) * (size_t)nparts, s));
+    hipLaunchKernelGGL(key_fill_kernel, dim3(div_up(NE, 256)), dim3(256), 0, s, (long)NE, part_dev, ae2e_I.p, cnt.p,
+                       ae2e_J.p);
+    int cap = 2;
+    while (cap < max_ne) cap <<= 1;
+    hipLaunchKernelGGL(row_sort_kernel, dim3(nparts), dim3(256), sizeof(int) * (size_t)cap, s, ae2e_I.p, ae2e_J.p, cap);
+    // ---- AE_to_dof ----
+    const int K = max_ne * nde;
+    int HS = 64;
+    while (HS < 2 * K) HS <<= 1;
+    const size_t lds = sizeof(int) * ((size_t)2 * HS + ((K + 255) & ~255));
+    DBuf<int> rowcnt((size_t)nparts);
+    d.ae2d_I.alloc((size_t)nparts + 1);
+    hipLaunchKernelGGL(ae_to_dof_kernel, dim3(nparts), dim3(256), lds, s, 0, nde, HS, ae2e_I.p, ae2e_J.p, e2d_dev,
+                       rowcnt.p, nullptr, nullptr);
+    exclusive_scan_int(s, nparts, rowcnt.p, d.ae2d_I.p);
+    download(r.AE_to_dof.I, d.ae2d_I, (size_t)nparts + 1, s);
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    const long nae2d = r.AE_to_dof.I[nparts];
+    d.ae2d_J.alloc((size_t)nae2d);
+    hipLaunchKernelGGL(ae_to_dof_kernel, dim3(nparts), dim3(256), lds, s, 1, nde, HS, ae2e_I.p, ae2e_J.p, e2d_dev,
+                       rowcnt.p, d.ae2d_I.p, d.ae2d_J.p);
+    // ---- dof_to_AE, dof_id_inAE, flags ----
+    d.d2ae_I.alloc((size_t)ND + 1);
+    d.d2ae_J.alloc((size_t)nae2d);
+    d.dof_id_inAE.alloc((size_t)nae2d);
+    d.flags.alloc((size_t)ND);
+    SA_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(int) * (size_t)ND, s));
+    hipLaunchKernelGGL(key_count_kernel, dim3(div_up(nae2d, 256)), dim3(256), 0, s, nae2d, d.ae2d_J.p, cnt.p);
+    hipLaunchKernelGGL(any_zero_kernel, dim3(div_up(ND, 256)), dim3(256), 0, s, (long)ND, cnt.p, 8, err.p);
+    exclusive_scan_int(s, ND, cnt.p, d.d2ae_I.p);
+    SA_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(int) * (size_t)ND, s));
+    hipLaunchKernelGGL(d2ae_fill_kernel, dim3(nparts), dim3(256), 0, s, d.ae2d_I.p, d.ae2d_J.p, d.d2ae_I.p, cnt.p,
+                       d.d2ae_J.p, d.dof_id_inAE.p);
+    hipLaunchKernelGGL(d2ae_sort_flags_kernel, dim3(div_up(ND, 256)), dim3(256), 0, s, ND, d.d2ae_I.p, d.d2ae_J.p,
+                       d.dof_id_inAE.p, bdr_dev, d.flags.p);
+    SA_HIP_CHECK(hipGetLastError());
+    // host copies for the MIS tables and the later (host) phases
+    download(r.AE_to_dof.J, d.ae2d_J, (size_t)nae2d, s);
+    download(r.dof_to_AE.I, d.d2ae_I, (size_t)ND + 1, s);
+    download(r.dof_to_AE.J, d.d2ae_J, (size_t)nae2d, s);
+    download(r.dof_id_inAE, d.dof_id_inAE, (size_t)nae2d, s);
+    download(r.agg_flags, d.flags, (size_t)ND, s);
+    r.AE_to_dof.ncols = ND;
+    r.dof_to_AE.ncols = nparts;
+    // dof_to_elem / elem_ldof for the assembly kernels (as in upload_relations_ae)
+    d.d2e_I.alloc((size_t)ND + 1);
+    d.d2e_J.alloc((size_t)nconn);
+    d.elem_ldof.alloc((size_t)nconn);
+    SA_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(int) * (size_t)ND, s));
+    hipLaunchKernelGGL(d2e_count_kernel, dim3(div_up(nconn, 256)), dim3(256), 0, s, nconn, d.e2d_J.p, cnt.p);
+    exclusive_scan_int(s, ND, cnt.p, d.d2e_I.p);
+    SA_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(int) * (size_t)ND, s));
+    hipLaunchKernelGGL(d2e_fill_kernel, dim3(div_up(NE, 256)), dim3(256), 0, s, NE, d.e2d_I.p, d.e2d_J.p, d.d2e_I.p,
+                       cnt.p, d.d2e_J.p);
+    hipLaunchKernelGGL(d2e_sort_kernel, dim3(div_up(ND, 256)), dim3(256), 0, s, ND, d.d2e_I.p, d.d2e_J.p);
+    hipLaunchKernelGGL(elem_ldof_kernel, dim3(div_up(NE, 256)), dim3(256), 0, s, NE, d.e2d_I.p, d.e2d_J.p, d.part.p,
+                       d.d2ae_I.p, d.d2ae_J.p, d.dof_id_inAE.p, d.elem_ldof.p);
+    SA_HIP_CHECK(hipGetLastError());
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    SA_REQUIRE(!(err.to_host(s)[0] & 8), "dof without any element");
+    return true;
+}
+
 void upload_relations_mis(DevRelations &d, const Relations &r, hipStream_t s) {
     d.mis2d_I.from_host(r.mis_to_dof.I, s);
     d.mis2d_J.from_host(r.mis_to_dof.J, s);

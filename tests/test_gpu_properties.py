@@ -166,3 +166,50 @@ def test_one_stage_and_two_stage_eigensolvers_agree():
         outs.append(json.loads(o.stdout.strip().splitlines()[-1]))
     assert outs[0]["nc"] == outs[1]["nc"] and outs[0]["it"] == outs[1]["it"]
     assert np.allclose(outs[0]["hist"], outs[1]["hist"], rtol=1e-8)
+
+
+@pytest.mark.parametrize("case", ["poisson3d", "mltest1", "mltest2", "random_partition"])
+def test_device_resident_inputs_build_the_same_hierarchy(case):
+    """Level-0 inputs handed over as DEVICE pointers take the device build of the AE tables
+    (csrc/topology.hip: build_relations_ae_device); host pointers take the host build.  Both must
+    give bit-identical topology (first-encounter orders included) and the same P / Ac."""
+    import torch
+    capi = _capi()
+    if case == "poisson3d":
+        prob = pr.poisson3d_problem((12, 8, 8), blk=(4, 4, 2), coarse_blk=[(2, 2, 2)], coef="checkerboard")
+        nco = 2
+    elif case == "random_partition":
+        prob = pr.poisson3d_problem((6, 5, 4), blk=(3, 5, 2))
+        rng = np.random.default_rng(5)
+        part = rng.integers(0, 7, size=prob.elem_to_dof.shape[0]).astype(np.int32)
+        part[:7] = np.arange(7)                      # no empty agglomerate
+        prob.partitions = [part]
+        nco = 1
+    else:
+        prob = pr.mltest_problem(order=int(case[-1]), levels=3)
+        nco = 2
+    params = capi.default_params(num_coarsenings=nco, keep_debug=True, testmesh=case.startswith("mltest"))
+    h_host = capi.Hierarchy.from_problem(prob, params)
+    A = prob.A.tocsr()
+    dev = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt)).cuda()
+    e2d = np.ascontiguousarray(prob.elem_to_dof, dtype=np.int32)
+    parts = [np.ascontiguousarray(p_, dtype=np.int32) for p_ in prob.partitions[:nco]]
+    nparts = [int(p_.max()) + 1 for p_ in parts]
+    parts_in = [dev(parts[0], np.int32)] + parts[1:]
+    params2 = capi.default_params(num_coarsenings=nco, keep_debug=True, testmesh=case.startswith("mltest"))
+    h_dev = capi.Hierarchy(dev(A.indptr, np.int32), dev(A.indices, np.int32), dev(A.data, np.float64),
+                           A.shape[0], dev(e2d, np.int32), dev(prob.elmat, np.float64),
+                           dev(prob.bdr, np.int8), parts_in, nparts, params2, e2d.shape[0], e2d.shape[1])
+    for lev in range(nco):
+        for name in ("AE_to_dof", "dof_to_AE", "mis_to_dof", "mis_to_AE", "AE_to_mis", "elem_to_dof"):
+            Ih, Jh = h_host.get_table(lev, name)
+            Id, Jd = h_dev.get_table(lev, name)
+            assert np.array_equal(Ih, Id) and np.array_equal(Jh, Jd), (lev, name)
+        mh, md = h_host.get_mis(lev), h_dev.get_mis(lev)
+        for a, b in zip(mh, md):
+            assert np.array_equal(a, b)
+        for which in ("P", "Ac"):
+            Mh, Md = h_host.get_csr(lev, which), h_dev.get_csr(lev, which)
+            assert np.array_equal(Mh.indices, Md.indices) and np.array_equal(Mh.data, Md.data), (lev, which)
+    h_host.close()
+    h_dev.close()
