@@ -74,23 +74,28 @@ def one_step(capi, prob, params, rel_tol=1e-8, group=None):
 
 
 def cpu_baseline(n_sample, levels):
-    """Oracle setup+solve on a bounded sample: the same discretisation and AE shape on a
-    smaller box, reported per dof."""
-    from saamge_amd import problems
-    from oracle import saamge_oracle as oracle
-    cb = [(2, 2, 2)] * (levels - 2)
-    prob = problems.poisson3d_problem(n_sample, blk=(8, 8, 4), coarse_blk=cb)
-    t0 = time.perf_counter()
-    H = oracle.ml_produce_data(prob.A, prob.elem_to_dof, prob.elmat, prob.bdr,
-                               prob.partitions, theta=0.003, nu_relax=3)
-    t1 = time.perf_counter()
-    x, it, conv, hist = oracle.solve(H, prob.b, rel_tol=1e-8)
-    t2 = time.perf_counter()
-    nd = prob.A.shape[0]
-    return {"value": nd / (t2 - t0), "unit": "DoF/s", "cores": 1, "kind": "port",
-            "sample": "oracle (numpy + LAPACK dsygvx/dgesvd, 1 thread) on 3-D Poisson %s (%d dofs), "
-                      "%d-level, 8x8x4-element AEs: setup %.2f s, solve %.2f s, %d PCG its"
-                      % ("x".join(str(v) for v in n_sample), nd, levels, t1 - t0, t2 - t1, it)}
+    """Oracle setup+solve on a bounded sample: the same discretisation and AE shape on a smaller
+    box, reported per dof.  Runs in a GPU-free child process (oracle/baseline_worker.py) with the
+    per-AE eigenproblems spread over the host cores, one LAPACK thread per process."""
+    import subprocess
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "baseline_worker.py")] + \
+          [str(v) for v in n_sample] + [str(levels), str(cores)]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    if out.returncode != 0:
+        raise RuntimeError("cpu_baseline worker failed: " + out.stderr.decode()[-2000:])
+    r = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    return {"value": r["dofs"] / (r["setup_s"] + r["solve_s"]), "unit": "DoF/s", "cores": r["cores"],
+            "kind": "port",
+            "sample": "oracle (numpy + LAPACK dsygvx/dgesvd; per-AE eigenproblems on %d processes, 1 LAPACK "
+                      "thread each; the rest serial) on 3-D Poisson %s (%d dofs), %d-level, 8x8x4-element AEs: "
+                      "setup %.2f s, solve %.2f s, %d PCG its"
+                      % (r["cores"], "x".join(str(v) for v in n_sample), r["dofs"], levels, r["setup_s"],
+                         r["solve_s"], r["iters"])}
 
 
 def pmc_traffic(symbol, n, levels):

@@ -254,14 +254,35 @@ def lower_eigens_dense(A, D, upper):
     return w[:m].copy(), np.array(z[:, :m], order="F", copy=True)
 
 
+# Optional process pool for the per-AE work -- fine-level AE assembly and all eigenproblems --
+# (bench.py's cpu_baseline times the oracle on the host cores: the reference is MPI-parallel over
+# AEs, one rank per core).  PARALLEL_CORES > 1 makes ml_produce_data fork a pool once the
+# relations exist, so the workers inherit the matrix and the tables instead of unpickling them.
+PARALLEL_CORES = 1
+PARALLEL_MAP = None
+_SHARED = None
+
+
+def _stiff_task(p):
+    A, rel, elmat = _SHARED
+    return build_AE_stiffm_with_global(A, p, rel, elmat)
+
+
+def _eig_task(args):
+    A_i, theta = args
+    D_i = snd_D_from_dense(A_i)
+    w, z = lower_eigens_dense(A_i, D_i, theta * 1.0)
+    return w, z, D_i
+
+
 def compute_vectors(rel, AEs_stiffm, theta, testmesh=False):
     """interp_compute_vectors + Eigensolver::SolveDirect
     (src/interp.cpp:387-556, src/spectral.cpp:124-237)."""
     evals, evects, Ds = [], [], []
+    mapper = PARALLEL_MAP or map
+    results = list(mapper(_eig_task, [(AEs_stiffm[i], theta) for i in range(rel.nparts)]))
     for i in range(rel.nparts):
-        A_i = AEs_stiffm[i]
-        D_i = snd_D_from_dense(A_i)
-        w, z = lower_eigens_dense(A_i, D_i, theta * 1.0)
+        w, z, D_i = results[i]
         if testmesh and i == 0:
             # extra all-ones vector on AE 0 of rank 0 (src/interp.cpp:510-524)
             z = np.concatenate([z, np.ones((z.shape[0], 1))], axis=1)
@@ -456,7 +477,16 @@ def ml_produce_data(A, elem_to_dof, elmat, bdr, partitions, theta=0.003, nu_rela
     H.levels = []
     nparts0 = int(np.max(partitions[0])) + 1
     rel = build_relations(e2d, partitions[0], nparts0, ND, bdr=bdr)
-    stiff = [build_AE_stiffm_with_global(A, p, rel, elmat) for p in range(rel.nparts)]
+    global PARALLEL_MAP, _SHARED
+    pool = None
+    if PARALLEL_CORES > 1:
+        import multiprocessing
+        _SHARED = (A, rel, elmat)
+        pool = multiprocessing.get_context("fork").Pool(PARALLEL_CORES)
+        PARALLEL_MAP = lambda f, it: pool.map(f, it, chunksize=2)
+        stiff = pool.map(_stiff_task, range(rel.nparts), chunksize=2)
+    else:
+        stiff = [build_AE_stiffm_with_global(A, p, rel, elmat) for p in range(rel.nparts)]
     lv = build_level(A, rel, stiff, theta, nu_relax, nu_pro, testmesh)
     H.levels.append(lv)
     for k in range(1, len(partitions)):
@@ -468,6 +498,11 @@ def ml_produce_data(A, elem_to_dof, elmat, bdr, partitions, theta=0.003, nu_rela
         lv = build_level(prev.Ac, rel_c, stiff, theta, nu_relax, nu_pro, False)
         lv.coarse_elmats = cel
         H.levels.append(lv)
+    if pool is not None:
+        pool.close()
+        pool.join()
+        PARALLEL_MAP = None
+        _SHARED = None
     H.coarse_dense = H.levels[-1].Ac.toarray()
     H.coarse_lu = None
     return H

@@ -16,7 +16,8 @@ import os
 
 
 class Group(object):
-    def __init__(self, backend=None, device=None):
+    def __init__(self, backend=None, device=None, host_buffers=False):
+        self.host_buffers = bool(host_buffers)
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -62,12 +63,26 @@ class Group(object):
         dist.all_gather(recv, send)
         return [recv[r][:sizes[r]] for r in range(self.world)]
 
+    def _memcpy(self):
+        """hipMemcpy(hipMemcpyDefault) through the library, or -- for the CPU-only tests of the
+        collective logic (`host_buffers=True`) -- a plain memmove."""
+        from . import capi
+        C = capi.C
+        if self.host_buffers:
+            def mv(dst, src, nbytes):
+                C.memmove(C.c_void_p(int(dst)), C.c_void_p(int(src)), int(nbytes))
+                return 0
+            return mv
+        lib = capi.load()
+        return lambda dst, src, nbytes: lib.saamge_amd_memcpy(C.c_void_p(int(dst)), C.c_void_p(int(src)),
+                                                                C.c_longlong(int(nbytes)))
+
     def allgather_callback(self):
         """ctypes callback for saamge_amd_params.allgather: in-place all-gather of a device
         buffer whose rank-r part is [off[r], off[r+1]) bytes."""
         import torch
         from . import capi
-        lib = capi.load()
+        memcpy = self._memcpy()
         use_cuda = self.dist.get_backend() == "nccl"
         dev = self.device if use_cuda else "cpu"
 
@@ -76,8 +91,7 @@ class Group(object):
                 lo, hi = int(off[self.rank]), int(off[self.rank + 1])
                 mine = torch.empty(max(hi - lo, 0), dtype=torch.uint8, device=dev)
                 if hi > lo:
-                    rc = lib.saamge_amd_memcpy(capi.C.c_void_p(mine.data_ptr()),
-                                               capi.C.c_void_p(buf + lo), capi.C.c_longlong(hi - lo))
+                    rc = memcpy(mine.data_ptr(), buf + lo, hi - lo)
                     if rc:
                         return rc
                 parts = self.allgather_bytes(mine)
@@ -88,8 +102,7 @@ class Group(object):
                     if parts[r].numel() != b - a:
                         return 3
                     src = parts[r].contiguous()
-                    rc = lib.saamge_amd_memcpy(capi.C.c_void_p(buf + a), capi.C.c_void_p(src.data_ptr()),
-                                               capi.C.c_longlong(b - a))
+                    rc = memcpy(buf + a, src.data_ptr(), b - a)
                     if rc:
                         return rc
                 if use_cuda:
@@ -136,16 +149,12 @@ class Group(object):
         import sys
         import torch
         from . import capi
-        C = capi.C
-        lib = capi.load()
         dist = self.dist
         use_cuda = dist.get_backend() == "nccl"
         ordered = self.stream_ordered(stream)
         self._views = {}
         world, rank = self.world, self.rank
-
-        def memcpy(dst, src, nbytes):
-            return lib.saamge_amd_memcpy(C.c_void_p(dst), C.c_void_p(src), C.c_longlong(nbytes))
+        memcpy = self._memcpy()
 
         def allreduce(ctx, buf, count):
             try:
