@@ -112,7 +112,8 @@ def _ptr(a):
 
 
 def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, keep_debug=False,
-                   coarse_rtol=1e-14, workspace_bytes=None, dist_min_local_rows=None):
+                   coarse_rtol=1e-14, workspace_bytes=None, dist_min_local_rows=None,
+                   coarse_solver=None):
     p = Params()
     load().saamge_amd_params_default(C.byref(p))
     p.num_coarsenings = num_coarsenings
@@ -126,6 +127,8 @@ def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, k
         p.workspace_bytes = int(workspace_bytes)
     if dist_min_local_rows is not None:
         p.dist_min_local_rows = int(dist_min_local_rows)
+    if coarse_solver is not None:
+        p.coarse_solver = int(coarse_solver)   # 0 auto, 1 dense Cholesky, 2 inner PCG
     return p
 
 

@@ -91,8 +91,9 @@ struct Hierarchy {              // ml_data_t
     hipStream_t stream = 0;
     std::vector<std::unique_ptr<Level>> levels;
     // coarsest solver
-    int coarse_kind = 2;
+    int coarse_kind = 2;        // 1 dense Cholesky, 2 inner PCG
     DBuf<double> c_dinv, c_r, c_z, c_d, c_q, c_t0, c_t1, c_b, c_x;
+    DBuf<double> c_L, c_work;   // dense Cholesky factor of the coarsest operator (coarse_kind 1)
     std::vector<double> c_roots;
     // PCG scratch
     DBuf<double> pcg_r, pcg_z, pcg_d, pcg_q, scal, partials;

@@ -213,3 +213,24 @@ def test_device_resident_inputs_build_the_same_hierarchy(case):
             assert np.array_equal(Mh.indices, Md.indices) and np.array_equal(Mh.data, Md.data), (lev, which)
     h_host.close()
     h_dev.close()
+
+
+def test_dense_and_iterative_coarsest_solvers_agree():
+    """Coarsest solve: dense Cholesky (the reference's serial --coarse-direct) and
+    the inner PCG to 1e-28 give the same V-cycle and the same PCG run; the Cholesky path is
+    exercised over many 64-column blocks (coarse dim > 1000)."""
+    capi = _capi()
+    prob = pr.poisson3d_problem((32, 32, 16), blk=(4, 4, 2))
+    out = {}
+    for kind in (1, 2):
+        h = capi.Hierarchy.from_problem(prob, capi.default_params(coarse_solver=kind, coarse_rtol=1e-28))
+        assert h.level_info(0)["ncoarse"] > 1000
+        b = np.cos(np.arange(prob.ND) * 0.21) * (~prob.ess)
+        x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-8)
+        out[kind] = (h.vcycle(b), x, it, h.level_info(0)["coarse_iters"])
+        assert conv
+        h.close()
+    assert out[1][3] == 0 and out[2][3] > 0          # direct vs iterative really ran
+    assert out[1][2] == out[2][2]
+    for i in (0, 1):
+        assert np.linalg.norm(out[1][i] - out[2][i]) <= 1e-9 * np.linalg.norm(out[2][i])
