@@ -33,7 +33,7 @@ typedef struct saamge_amd_params {
     int num_coarsenings;                      /* levels - 1 */
     double theta[SAAMGE_AMD_MAX_LEVELS];      /* spectral tolerance per coarsening */
     int nu_relax[SAAMGE_AMD_MAX_LEVELS];      /* smoother: SAS polynomial of degree 3 nu + 1 */
-    int nu_pro[SAAMGE_AMD_MAX_LEVELS];        /* prolongator smoothing degree (0 only, this round) */
+    int nu_pro[SAAMGE_AMD_MAX_LEVELS];        /* prolongator smoothing degree (interp_smooth, src/interp.cpp:172-229); 0 = tentative */
     int avoid_ess_bdr_dofs;                   /* src/ml.cpp:64, always true in the reference */
     int testmesh;                             /* mltest fixture: ones-vector on AE 0, src/interp.cpp:510-524 */
     int coarse_solver;                        /* 0 auto (dense Cholesky up to 1024 rows, else inner PCG), 1 dense Cholesky, 2 inner PCG */

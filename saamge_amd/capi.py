@@ -113,13 +113,14 @@ def _ptr(a):
 
 def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, keep_debug=False,
                    coarse_rtol=1e-14, workspace_bytes=None, dist_min_local_rows=None,
-                   coarse_solver=None):
+                   coarse_solver=None, nu_pro=0):
     p = Params()
     load().saamge_amd_params_default(C.byref(p))
     p.num_coarsenings = num_coarsenings
     for i in range(MAX_LEVELS):
         p.theta[i] = theta
         p.nu_relax[i] = nu_relax
+        p.nu_pro[i] = nu_pro
     p.testmesh = int(testmesh)
     p.keep_debug = int(keep_debug)
     p.coarse_rtol = coarse_rtol

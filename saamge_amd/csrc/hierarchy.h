@@ -19,7 +19,7 @@ struct Params {                 // MultilevelParameters (amg/inc/ml.hpp:59-114)
     int num_coarsenings = 1;
     double theta[MAX_LEVELS];
     int nu_relax[MAX_LEVELS];
-    int nu_pro[MAX_LEVELS];     // only 0 is supported in this round
+    int nu_pro[MAX_LEVELS];     // prolongator smoothing degree (0 = tentative)
     int avoid_ess_bdr_dofs = 1; // amg/src/ml.cpp:64
     int testmesh = 0;           // mltest fixture: extra ones-vector on AE 0 (amg/src/interp.cpp:510-524)
     int coarse_solver = 0;      // 0 auto, 1 dense Cholesky, 2 inner PCG
@@ -49,6 +49,7 @@ struct Params {                 // MultilevelParameters (amg/inc/ml.hpp:59-114)
 struct Level {                  // tg_data_t + interp_data_t + agg_partitioning_relations_t
     DCsr A;                     // level operator (level 0: the user's matrix, viewed or copied)
     DCsr P, R, Ac;              // interp, restr, coarse operator
+    DCsr Ptent;                 // tentative prolongator, kept apart only when nu_pro > 0 (P is then the smoothed one)
     DBuf<double> dinv_neg;      // smpr_poly_data_t::Dinv_neg
     std::vector<double> roots;  // smpr_poly_data_t::roots (SAS)
     double theta = 0.0;

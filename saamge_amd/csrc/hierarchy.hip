@@ -3,6 +3,7 @@
 #include "hierarchy.h"
 #include "dist.h"
 #include "dense.h"
+#include "spgemm.h"
 
 #include <algorithm>
 #include <cmath>
@@ -91,7 +92,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     const Params &P = H.params;
     L.theta = P.theta[lev];
     L.nu_relax = P.nu_relax[lev];
-    SA_REQUIRE(P.nu_pro[lev] == 0, "prolongator smoothing (nu_pro > 0) is not implemented yet");
+    SA_REQUIRE(P.nu_pro[lev] >= 0 && P.nu_pro[lev] <= 8, "bad prolongator smoothing degree");
     PhaseTimer tm(s);
     bool on_device = false;
     if (din) {
@@ -357,8 +358,30 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     L.d_mis_coloff.from_host(L.mis_coloff, s);
     build_P_R(s, L.drel, rel, L.mis_k, L.mis_u_off, L.d_mis_k.p, L.d_mis_coloff.p, L.d_mis_u_off.p,
               L.mis_U.p, L.P, L.R);
-    rap_mis(s, L.drel, rel, L.A, L.mis_k, L.mis_coloff, L.d_mis_k.p, L.d_mis_coloff.p,
-            L.d_mis_u_off.p, L.mis_U.p, L.Ac);
+    if (P.nu_pro[lev] == 0) {
+        rap_mis(s, L.drel, rel, L.A, L.mis_k, L.mis_coloff, L.d_mis_k.p, L.d_mis_coloff.p,
+                L.d_mis_u_off.p, L.mis_U.p, L.Ac);
+    } else {
+        // interp_smooth (amg/src/interp.cpp:172-229): P = prod_k (I + (1/tau_k) Dinv_neg A) P_tent with
+        // tau_k = sin^2(k pi / (2 nu + 1)) (smpr_sa_poly_roots, amg/src/smpr.cpp:266-280); then
+        // R = P^T and Ac = R A P (mfem::RAP, amg/inc/tg.hpp:696-709) as general sparse products.
+        const int nu = P.nu_pro[lev];
+        L.Ptent = std::move(L.P);
+        DCsr tmp[2];
+        const DCsr *cur = &L.Ptent;
+        for (int k = 1; k <= nu; ++k) {
+            const double sn = std::sin((double)k * M_PI / (double)(2 * nu + 1));
+            DCsr &dst = tmp[k & 1];
+            dst = DCsr();
+            spgemm(s, L.A, *cur, cur, L.dinv_neg.p, 1.0 / (sn * sn), 1.0, dst);
+            cur = &dst;
+        }
+        L.P = std::move(tmp[nu & 1]);
+        csr_transpose(s, L.P, L.R);
+        DCsr AP;
+        spgemm(s, L.A, L.P, nullptr, nullptr, 1.0, 0.0, AP);
+        spgemm(s, L.R, AP, nullptr, nullptr, 1.0, 0.0, L.Ac);
+    }
     tm.lap("P, R, RAP", lev);
     if (!P.keep_debug) {
         L.evals.release();
@@ -386,8 +409,10 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
     Table e2d;
     e2d.ncols = L.mis_coloff.back();
     e2d.I.assign((size_t)nparts + 1, 0);
-    auto p_rowptr = L.P.rowptr.to_host(s);
-    auto p_val = L.P.val.to_host(s);
+    // (always the TENTATIVE prolongator: the coarse elements are built from mis_tent_interps)
+    const DCsr &PT = L.Ptent.nrows ? L.Ptent : L.P;
+    auto p_rowptr = PT.rowptr.to_host(s);
+    auto p_val = PT.val.to_host(s);
     // colpos: for every (AE, MIS) incidence (aligned with AE_to_mis.J) the position of each of
     // the MIS's coarse dofs in the coarse element's dof list
     std::vector<int> colpos_ptr(rel.AE_to_mis.J.size() + 1, 0);

@@ -280,6 +280,41 @@ def test_elasticity3d_matches_oracle(levels):
     h.close()
 
 
+@pytest.mark.parametrize("nu_pro,levels", [(1, 2), (2, 2), (1, 3)])
+def test_smoothed_prolongator_matches_oracle(nu_pro, levels):
+    """P = prod_k (I - tau_k^-1 D^-1 A) P_tent (interp_smooth), R = P^T and
+    Ac = R A P through the general sparse products (csrc/spgemm.hip)."""
+    capi, o = _capi(), _oracle()
+    cblk = [(2, 2, 2)] if levels == 3 else None
+    prob = pr.poisson3d_problem((8, 8, 8), blk=(4, 4, 2), coarse_blk=cblk, coef="checkerboard")
+    nco = levels - 1
+    params = capi.default_params(num_coarsenings=nco, keep_debug=True, coarse_rtol=1e-28, nu_pro=nu_pro)
+    h = capi.Hierarchy.from_problem(prob, params)
+    H = o.ml_produce_data(prob.A, prob.elem_to_dof, prob.elmat, prob.bdr, prob.partitions[:nco],
+                          theta=0.003, nu_relax=3, nu_pro=nu_pro)
+    for lev in range(nco):
+        P, R, Ac, A = (h.get_csr(lev, w) for w in ("P", "R", "Ac", "A"))
+        olv = H.levels[lev]
+        assert P.shape == olv.P.shape and Ac.shape == olv.Ac.shape
+        assert abs(P - R.T).max() == 0.0
+        ref = (P.T @ A @ P).toarray()
+        assert np.allclose(Ac.toarray(), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+        assert P.nnz > h.level_info(lev)["n"]            # really smoothed: wider than the tentative one
+    # level 0: same prolongator range as the oracle (columns are sign-ambiguous)
+    probe = np.sin(np.arange(prob.ND) * 0.37)
+    P0 = h.get_csr(0, "P")
+    assert np.allclose(_range_projection(sp.csr_matrix(P0), probe),
+                       _range_projection(sp.csr_matrix(H.levels[0].P), probe), atol=1e-8)
+    b = np.cos(np.arange(prob.ND) * 0.13) * (~prob.ess)
+    x_gpu, x_ref = h.vcycle(b), o.vcycle(H, b)
+    assert np.linalg.norm(x_gpu - x_ref) <= (1e-9 if levels == 2 else 5e-2) * np.linalg.norm(x_ref)
+    x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-8)
+    xr, itr, convr, histr = o.solve(H, prob.b, rel_tol=1e-8)
+    assert conv and convr and abs(it - itr) <= (0 if levels == 2 else 1)
+    assert np.linalg.norm(prob.A @ x - prob.b) <= 1e-6 * np.linalg.norm(prob.b)
+    h.close()
+
+
 def test_smoother_matches_oracle():
     o = _oracle()
     prob = pr.poisson3d_problem((6, 6, 6), blk=(3, 3, 3))
