@@ -66,6 +66,12 @@ typedef struct saamge_amd_params {
                      const long long *recv_byte_off);
     long long dist_min_local_rows;            /* default 262144 */
     int comm_stream_ordered;
+    /* MultilevelParameters::use_correct_nullspace (inc/ml.hpp, default true in the reference's
+     * drivers): one more two-grid level under the coarsest spectral operator, interp = scaling_P
+     * (src/contrib.cpp:655-668, src/interp.cpp:842-909), SAS smoother nu = 3 (CorrectNullspace,
+     * src/solve.cpp:52-164, src/ml.cpp:225-236).  Its own coarse solve (one BoomerAMG V-cycle in
+     * the reference) is this library's coarsest solver.  Default 0. */
+    int correct_nullspace;
 } saamge_amd_params;
 
 void saamge_amd_params_default(saamge_amd_params *p);

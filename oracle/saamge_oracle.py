@@ -466,8 +466,43 @@ class Hierarchy(object):
     pass
 
 
+def scaling_P_from_level(lv):
+    """ContribTent::SVDInsert with scaling_P (src/contrib.cpp:655-668) + interp_scaling_P_assemble
+    (src/interp.cpp:842-909): one column per MIS with coarse dofs; its entries are the normalised
+    least-squares coefficients of the constant vector in that MIS's basis (xpack_solve_lls)."""
+    rows, cols, vals = [], [], []
+    row = col = 0
+    for mis, k in enumerate(lv.mis_numcoarsedof):
+        if k == 0:
+            continue
+        U = lv.mis_tent_interps[mis]
+        x, *_ = np.linalg.lstsq(U, np.ones(U.shape[0]), rcond=None)
+        x = x / math.sqrt(float(np.dot(x, x)))
+        for v in range(k):
+            rows.append(row + v)
+            cols.append(col)
+            vals.append(x[v])
+        row += k
+        col += 1
+    return sp.csr_matrix((vals, (rows, cols)), shape=(row, col))
+
+
+def nullspace_level(lv_last):
+    """CorrectNullspace (src/solve.cpp:52-164) as configured by ml_produce_hierarchy_from_level
+    (src/ml.cpp:225-236: smoother_steps = 3, smooth_phat = false): one more two-grid level under
+    the coarsest spectral operator, interp = scaling_P, SAS polynomial smoother of nu = 3."""
+    lv = Level()
+    lv.A = lv_last.Ac.tocsr()
+    lv.P = scaling_P_from_level(lv_last)
+    lv.R = lv.P.T.tocsr()
+    lv.Ac = (lv.R @ lv.A @ lv.P).tocsr()
+    lv.Dinv_neg = build_Dinv_neg(lv.A)
+    lv.roots = sas_poly_roots(3)
+    return lv
+
+
 def ml_produce_data(A, elem_to_dof, elmat, bdr, partitions, theta=0.003, nu_relax=3,
-                    nu_pro=0, testmesh=False):
+                    nu_pro=0, testmesh=False, correct_nullspace=False):
     """ml_produce_data + ml_produce_hierarchy_from_level (src/ml.cpp:379-472,:111-236).
     `partitions[k]` maps level-k elements to level-k AEs.  Exact coarsest solve."""
     A = sp.csr_matrix(A)
@@ -503,6 +538,10 @@ def ml_produce_data(A, elem_to_dof, elmat, bdr, partitions, theta=0.003, nu_rela
         pool.join()
         PARALLEL_MAP = None
         _SHARED = None
+    if correct_nullspace:
+        # (the reference solves the null-space level with one BoomerAMG V-cycle -- third party;
+        # here, as for the plain coarsest level, exactly)
+        H.levels.append(nullspace_level(H.levels[-1]))
     H.coarse_dense = H.levels[-1].Ac.toarray()
     H.coarse_lu = None
     return H

@@ -51,6 +51,7 @@ class Params(C.Structure):
         ("alltoallv", ALLTOALLV_FN),
         ("dist_min_local_rows", C.c_longlong),
         ("comm_stream_ordered", C.c_int),
+        ("correct_nullspace", C.c_int),
     ]
 
 
@@ -113,7 +114,7 @@ def _ptr(a):
 
 def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, keep_debug=False,
                    coarse_rtol=1e-14, workspace_bytes=None, dist_min_local_rows=None,
-                   coarse_solver=None, nu_pro=0):
+                   coarse_solver=None, nu_pro=0, correct_nullspace=False):
     p = Params()
     load().saamge_amd_params_default(C.byref(p))
     p.num_coarsenings = num_coarsenings
@@ -122,6 +123,7 @@ def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, k
         p.nu_relax[i] = nu_relax
         p.nu_pro[i] = nu_pro
     p.testmesh = int(testmesh)
+    p.correct_nullspace = int(correct_nullspace)
     p.keep_debug = int(keep_debug)
     p.coarse_rtol = coarse_rtol
     if workspace_bytes is not None:

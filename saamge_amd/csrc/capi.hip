@@ -53,6 +53,7 @@ void saamge_amd_params_default(saamge_amd_params *p) {
     p->alltoallv = nullptr;
     p->dist_min_local_rows = 262144;
     p->comm_stream_ordered = 0;
+    p->correct_nullspace = 0;
 }
 
 int saamge_amd_memcpy(void *dst, const void *src, long long bytes) {
@@ -96,6 +97,7 @@ int saamge_amd_ml_produce_data(int n, const int *rowptr, const int *col, const d
     p.alltoallv = params->alltoallv;
     p.dist_min_local_rows = params->dist_min_local_rows;
     p.comm_stream_ordered = params->comm_stream_ordered;
+    p.correct_nullspace = params->correct_nullspace;
     SA_REQUIRE(p.world == 1 || (p.rank >= 0 && p.rank < p.world), "bad rank");
     Hierarchy *H = hierarchy_create(n, rowptr, col, val, NE, nde, elem_to_dof, elmat, bdr_dofs,
                                     partitions, nparts, p, (hipStream_t)stream);

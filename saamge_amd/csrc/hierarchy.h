@@ -44,6 +44,7 @@ struct Params {                 // MultilevelParameters (amg/inc/ml.hpp:59-114)
                      const long long *recv_byte_off) = nullptr;
     long long dist_min_local_rows = 262144;
     int comm_stream_ordered = 0;  // callbacks enqueue on the hierarchy's stream (no host sync needed)
+    int correct_nullspace = 0;    // extra scaling_P level under the coarsest spectral operator
 };
 
 struct Level {                  // tg_data_t + interp_data_t + agg_partitioning_relations_t

@@ -730,6 +730,91 @@ int pcg_solve(Hierarchy &H, const double *b, double *x, double rel_tol, double a
 }
 
 // ---------------------------------------------------------------------------------------
+// corrected null-space level (CorrectNullspace, amg/src/solve.cpp:52-164, configured by
+// amg/src/ml.cpp:225-236): one more two-grid level under the coarsest spectral operator.
+// interp = scaling_P (amg/src/contrib.cpp:655-668, amg/src/interp.cpp:842-909): one column per
+// MIS that has coarse dofs, holding the normalised coefficients of the constant vector in the
+// MIS's orthonormal basis (x = U^T 1 / |U^T 1|).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void scaling_p_kernel(const int *__restrict__ mis2d_I, const int *__restrict__ k,
+                                                       const int *__restrict__ coloff,
+                                                       const int64_t *__restrict__ u_off,
+                                                       const double *__restrict__ U,
+                                                       const int *__restrict__ active, int *__restrict__ prow,
+                                                       int *__restrict__ pcol, double *__restrict__ pval) {
+    extern __shared__ double xs[];
+    const int m = blockIdx.x, lane = threadIdx.x;
+    const int km = k[m];
+    if (km == 0) return;
+    const int r = mis2d_I[m + 1] - mis2d_I[m];
+    const double *Um = U + u_off[m];
+    double nn = 0.0;
+    for (int v = 0; v < km; ++v) {
+        double sum = 0.0;
+        for (int i = lane; i < r; i += 64) sum += Um[(size_t)v * r + i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (lane == 0) xs[v] = sum;
+        nn = fma(sum, sum, nn);
+    }
+    __syncthreads();
+    const double inv = 1.0 / sqrt(nn);
+    for (int v = lane; v < km; v += 64) {
+        const int row = coloff[m] + v;
+        prow[row] = row;
+        pcol[row] = active[m];
+        pval[row] = xs[v] * inv;
+    }
+}
+
+static void add_nullspace_level(Hierarchy &H) {
+    hipStream_t s = H.stream;
+    Level &L = *H.levels.back();
+    const int nm = L.rel.num_mises;
+    const int nc = L.Ac.nrows;
+    SA_REQUIRE(!H.params.testmesh, "the corrected null-space level is not available with the mltest fixture vectors");
+    std::vector<int> active((size_t)nm, -1);
+    int nact = 0, kmax = 1;
+    for (int m = 0; m < nm; ++m)
+        if (L.mis_k[m] > 0) { active[m] = nact++; kmax = std::max(kmax, L.mis_k[m]); }
+    H.levels.emplace_back(new Level);
+    Level &N = *H.levels.back();
+    N.A = std::move(L.Ac);
+    N.theta = 0.0;
+    N.nu_relax = 3;
+    N.roots = sas_poly_roots(3);
+    build_sell(s, N.A);
+    N.dinv_neg.alloc((size_t)nc);
+    {
+        DBuf<double> tmp((size_t)nc);
+        build_dinv_neg(s, N.A, tmp.p, N.dinv_neg.p);
+        SA_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    N.P.nrows = nc;
+    N.P.ncols = nact;
+    N.P.nnz = nc;
+    N.P.rowptr.alloc((size_t)nc + 1);
+    N.P.col.alloc((size_t)nc + 1);
+    N.P.val.alloc((size_t)nc + 1);
+    DBuf<int> d_active;
+    d_active.from_host(active, s);
+    hipLaunchKernelGGL(scaling_p_kernel, dim3(nm), dim3(64), sizeof(double) * (size_t)kmax, s, L.drel.mis2d_I.p,
+                       L.d_mis_k.p, L.d_mis_coloff.p, L.d_mis_u_off.p, L.mis_U.p, d_active.p, N.P.rowptr.p,
+                       N.P.col.p, N.P.val.p);
+    SA_HIP_CHECK(hipGetLastError());
+    SA_HIP_CHECK(hipMemcpyAsync(N.P.rowptr.p + nc, &nc, sizeof(int), hipMemcpyHostToDevice, s));
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    N.P.lanes_per_row = 1;
+    csr_transpose(s, N.P, N.R);
+    DCsr AP;
+    spgemm(s, N.A, N.P, nullptr, nullptr, 1.0, 0.0, AP);
+    spgemm(s, N.R, AP, nullptr, nullptr, 1.0, 0.0, N.Ac);
+    N.rel.ND = nc;
+    N.rel.nparts = nact;
+    N.x.alloc((size_t)nc); N.b.alloc((size_t)nc); N.r.alloc((size_t)nc); N.t0.alloc((size_t)nc);
+}
+
+// ---------------------------------------------------------------------------------------
 // ml_produce_data
 // ---------------------------------------------------------------------------------------
 Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const double *Aval, int NE,
@@ -809,6 +894,10 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
     }
     profiler().level_tag = 0;
     tm0 = PhaseTimer(s);
+    if (p.correct_nullspace) {
+        add_nullspace_level(H);
+        tm0.lap("corrected null-space level", 0);
+    }
     setup_coarse_solver(H);
     const size_t nc = (size_t)coarsest_op(H).nrows;
     H.c_b.alloc(nc);

@@ -315,6 +315,44 @@ def test_smoothed_prolongator_matches_oracle(nu_pro, levels):
     h.close()
 
 
+@pytest.mark.parametrize("levels", [2, 3])
+def test_corrected_nullspace_level_matches_oracle(levels):
+    """CorrectNullspace (src/solve.cpp:52-164) = one more two-grid level on
+    scaling_P under the coarsest spectral operator (the reference drivers' default)."""
+    capi, o = _capi(), _oracle()
+    cblk = [(2, 2, 2)] if levels == 3 else None
+    prob = pr.poisson3d_problem((8, 8, 8), blk=(4, 4, 2), coarse_blk=cblk, coef="checkerboard")
+    nco = levels - 1
+    params = capi.default_params(num_coarsenings=nco, keep_debug=True, coarse_rtol=1e-28, correct_nullspace=True)
+    h = capi.Hierarchy.from_problem(prob, params)
+    H = o.ml_produce_data(prob.A, prob.elem_to_dof, prob.elmat, prob.bdr, prob.partitions[:nco],
+                          theta=0.003, nu_relax=3, correct_nullspace=True)
+    assert h.num_levels == len(H.levels) + 1 == nco + 2
+    lv = nco                                          # the extra level
+    P, R, Ac, A = (h.get_csr(lv, w) for w in ("P", "R", "Ac", "A"))
+    oP = H.levels[lv].P
+    assert P.shape == oP.shape and abs(P - R.T).max() == 0.0
+    # Two levels: the image of scaling_P on the fine level is the normalised projection of the
+    # constants onto each MIS's span -- unique up to the sign of each column.  Deeper: the reference
+    # projects the all-ones COEFFICIENT vector of the coarse level (src/contrib.cpp:657-659), which
+    # depends on the arbitrary signs of that level's basis, so only structure is comparable.
+    if levels == 2:
+        Cg, Co = h.get_csr(0, "P") @ P, H.levels[0].P @ oP
+        assert np.allclose(np.abs(Cg.toarray()), np.abs(Co.toarray()), atol=1e-8)
+    assert np.array_equal(P.indices, oP.indices) and np.array_equal(P.indptr, oP.indptr)
+    assert np.allclose(np.linalg.norm(P.toarray(), axis=0), 1.0, atol=1e-12)
+    ref = (P.T @ A @ P).toarray()
+    assert np.allclose(Ac.toarray(), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    b = np.cos(np.arange(prob.ND) * 0.13) * (~prob.ess)
+    x_gpu, x_ref = h.vcycle(b), o.vcycle(H, b)
+    assert np.linalg.norm(x_gpu - x_ref) <= (1e-9 if levels == 2 else 2e-1) * np.linalg.norm(x_ref)
+    x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-8)
+    xr, itr, convr, histr = o.solve(H, prob.b, rel_tol=1e-8)
+    assert conv and convr and abs(it - itr) <= (0 if levels == 2 else 2)
+    assert np.linalg.norm(prob.A @ x - prob.b) <= 1e-6 * np.linalg.norm(prob.b)
+    h.close()
+
+
 def test_smoother_matches_oracle():
     o = _oracle()
     prob = pr.poisson3d_problem((6, 6, 6), blk=(3, 3, 3))

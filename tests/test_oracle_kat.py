@@ -140,3 +140,23 @@ def test_elasticity_rigid_body_modes():
     x, it, conv, hist = o.solve(H, prob.b, rel_tol=1e-8)
     assert conv and it <= 8
     assert np.linalg.norm(prob.A @ x - prob.b) <= 1e-6 * np.linalg.norm(prob.b)
+
+
+def test_corrected_nullspace_level():
+    """scaling_P (src/contrib.cpp:655-668): unit columns, one per MIS with coarse dofs, spanning the
+    coarse representation of the constants; the extra level keeps PCG convergent."""
+    prob = pr.poisson3d_problem((8, 8, 8), blk=(4, 4, 2), coef="checkerboard")
+    H = o.ml_produce_data(prob.A, prob.elem_to_dof, prob.elmat, prob.bdr, prob.partitions[:1],
+                          theta=0.003, nu_relax=3, correct_nullspace=True)
+    assert len(H.levels) == 2
+    lv0, ns = H.levels
+    P = ns.P.toarray()
+    assert P.shape == (lv0.P.shape[1], int((np.asarray(lv0.mis_numcoarsedof) > 0).sum()))
+    assert np.allclose(np.linalg.norm(P, axis=0), 1.0)
+    assert ((P != 0).sum(axis=1) == 1).all()          # block diagonal: one MIS per coarse dof
+    # the constant vector on every MIS is reproduced through tent * scaling_P up to a scale per MIS
+    ones_c = lv0.tent.T @ np.ones(prob.ND)            # coefficients of 1 in each orthonormal MIS basis
+    proj = P @ (P.T @ ones_c)
+    assert np.allclose(proj, ones_c, atol=1e-10)
+    x, it, conv, hist = o.solve(H, prob.b, rel_tol=1e-8)
+    assert conv and np.linalg.norm(prob.A @ x - prob.b) <= 1e-6 * np.linalg.norm(prob.b)
