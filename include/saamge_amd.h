@@ -72,6 +72,12 @@ typedef struct saamge_amd_params {
      * src/solve.cpp:52-164, src/ml.cpp:225-236).  Its own coarse solve (one BoomerAMG V-cycle in
      * the reference) is this library's coarsest solver.  Default 0. */
     int correct_nullspace;
+    /* ContribTent::ExtendWithPolynomials / ExtendWithRBMs (src/contrib.cpp:302-436): extra modes
+     * given per fine dof -- constants, coordinates, rigid-body modes: the caller evaluates them --
+     * are restricted to every MIS and appended after the spectral columns before the SVD (finest
+     * level only, like the reference).  n x num_extra_modes, column-major, host or device. */
+    const double *extra_modes;
+    int num_extra_modes;
 } saamge_amd_params;
 
 void saamge_amd_params_default(saamge_amd_params *p);

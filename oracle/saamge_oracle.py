@@ -312,7 +312,7 @@ def svd_dense_normalized(M):
     return u, s
 
 
-def contrib_mises(rel, evects, avoid_ess=True):
+def contrib_mises(rel, evects, avoid_ess=True, extra=None):
     """ContribTent::contrib_mises -> CommunicateEigenvectors + SVDInsert
     (src/contrib.cpp:492-687) with contrib_filter_boundary (:102-163),
     xpack_orth_set (src/xpacks.cpp:591-620) and contrib_tent_insert_simple
@@ -341,6 +341,11 @@ def contrib_mises(rel, evects, avoid_ess=True):
                 li = np.array([loc[int(d)] for d in mdofs])
                 blocks.append(evects[int(AE)][li, :])          # agg_restrict_to_agg_enforce
             M = np.concatenate(blocks, axis=1)
+            if extra is not None:
+                # ContribTent::ExtendWithPolynomials / ExtendWithRBMs (src/contrib.cpp:302-436):
+                # extra per-dof modes (constants, coordinates, rigid-body modes) restricted to
+                # the MIS are appended after the spectral columns, before filter and SVD
+                M = np.concatenate([M, extra[mdofs, :]], axis=1)
             # contrib_filter_boundary: zero essential rows, drop all-zero columns
             M = M.copy()
             if avoid_ess:
@@ -430,7 +435,7 @@ class Level(object):
     pass
 
 
-def build_level(A, rel, AEs_stiffm, theta, nu_relax, nu_pro=0, testmesh=False):
+def build_level(A, rel, AEs_stiffm, theta, nu_relax, nu_pro=0, testmesh=False, extra=None):
     """tg_init_data + tg_build_hierarchy + tg_update_coarse_operator
     (src/tg.cpp:402-430, :502-540, :979-1014)."""
     lv = Level()
@@ -440,7 +445,7 @@ def build_level(A, rel, AEs_stiffm, theta, nu_relax, nu_pro=0, testmesh=False):
     lv.Dinv_neg = build_Dinv_neg(lv.A)
     lv.roots = sas_poly_roots(nu_relax)
     lv.evals, lv.evects, lv.Ds = compute_vectors(rel, AEs_stiffm, theta, testmesh)
-    lv.tent, lv.mis_tent_interps, lv.mis_numcoarsedof, lv.mis_svals = contrib_mises(rel, lv.evects)
+    lv.tent, lv.mis_tent_interps, lv.mis_numcoarsedof, lv.mis_svals = contrib_mises(rel, lv.evects, extra=extra)
     lv.P = interp_smooth(lv.A, lv.tent, lv.Dinv_neg, nu_pro) if nu_pro > 0 else lv.tent.copy()
     lv.R = lv.P.T.tocsr()
     lv.Ac = (lv.R @ lv.A @ lv.P).tocsr()       # tg_coarse_matr == RAP, inc/tg.hpp:696-709
@@ -502,7 +507,7 @@ def nullspace_level(lv_last):
 
 
 def ml_produce_data(A, elem_to_dof, elmat, bdr, partitions, theta=0.003, nu_relax=3,
-                    nu_pro=0, testmesh=False, correct_nullspace=False):
+                    nu_pro=0, testmesh=False, correct_nullspace=False, extra_modes=None):
     """ml_produce_data + ml_produce_hierarchy_from_level (src/ml.cpp:379-472,:111-236).
     `partitions[k]` maps level-k elements to level-k AEs.  Exact coarsest solve."""
     A = sp.csr_matrix(A)
@@ -522,7 +527,8 @@ def ml_produce_data(A, elem_to_dof, elmat, bdr, partitions, theta=0.003, nu_rela
         stiff = pool.map(_stiff_task, range(rel.nparts), chunksize=2)
     else:
         stiff = [build_AE_stiffm_with_global(A, p, rel, elmat) for p in range(rel.nparts)]
-    lv = build_level(A, rel, stiff, theta, nu_relax, nu_pro, testmesh)
+    lv = build_level(A, rel, stiff, theta, nu_relax, nu_pro, testmesh,
+                     extra=None if extra_modes is None else np.asarray(extra_modes, dtype=float).reshape(ND, -1))
     H.levels.append(lv)
     for k in range(1, len(partitions)):
         prev = H.levels[-1]

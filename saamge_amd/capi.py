@@ -52,6 +52,8 @@ class Params(C.Structure):
         ("dist_min_local_rows", C.c_longlong),
         ("comm_stream_ordered", C.c_int),
         ("correct_nullspace", C.c_int),
+        ("extra_modes", C.c_void_p),
+        ("num_extra_modes", C.c_int),
     ]
 
 
@@ -114,7 +116,7 @@ def _ptr(a):
 
 def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, keep_debug=False,
                    coarse_rtol=1e-14, workspace_bytes=None, dist_min_local_rows=None,
-                   coarse_solver=None, nu_pro=0, correct_nullspace=False):
+                   coarse_solver=None, nu_pro=0, correct_nullspace=False, extra_modes=None):
     p = Params()
     load().saamge_amd_params_default(C.byref(p))
     p.num_coarsenings = num_coarsenings
@@ -130,6 +132,12 @@ def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, k
         p.workspace_bytes = int(workspace_bytes)
     if dist_min_local_rows is not None:
         p.dist_min_local_rows = int(dist_min_local_rows)
+    if extra_modes is not None:
+        em = np.asfortranarray(np.asarray(extra_modes, dtype=np.float64))   # n x q, column-major
+        em = em.reshape(em.shape[0], -1, order="F")
+        p._extra_keep = em                                                   # keep alive with the params
+        p.extra_modes = em.ctypes.data
+        p.num_extra_modes = em.shape[1]
     if coarse_solver is not None:
         p.coarse_solver = int(coarse_solver)   # 0 auto, 1 dense Cholesky, 2 inner PCG
     return p

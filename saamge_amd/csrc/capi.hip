@@ -54,6 +54,8 @@ void saamge_amd_params_default(saamge_amd_params *p) {
     p->dist_min_local_rows = 262144;
     p->comm_stream_ordered = 0;
     p->correct_nullspace = 0;
+    p->extra_modes = nullptr;
+    p->num_extra_modes = 0;
 }
 
 int saamge_amd_memcpy(void *dst, const void *src, long long bytes) {
@@ -98,6 +100,8 @@ int saamge_amd_ml_produce_data(int n, const int *rowptr, const int *col, const d
     p.dist_min_local_rows = params->dist_min_local_rows;
     p.comm_stream_ordered = params->comm_stream_ordered;
     p.correct_nullspace = params->correct_nullspace;
+    p.extra_modes = params->extra_modes;
+    p.num_extra_modes = params->num_extra_modes;
     SA_REQUIRE(p.world == 1 || (p.rank >= 0 && p.rank < p.world), "bad rank");
     Hierarchy *H = hierarchy_create(n, rowptr, col, val, NE, nde, elem_to_dof, elmat, bdr_dofs,
                                     partitions, nparts, p, (hipStream_t)stream);

@@ -45,6 +45,8 @@ struct Params {                 // MultilevelParameters (amg/inc/ml.hpp:59-114)
     long long dist_min_local_rows = 262144;
     int comm_stream_ordered = 0;  // callbacks enqueue on the hierarchy's stream (no host sync needed)
     int correct_nullspace = 0;    // extra scaling_P level under the coarsest spectral operator
+    const double *extra_modes = nullptr;  // level 0: n x num_extra_modes (column-major) appended to every MIS block
+    int num_extra_modes = 0;
 };
 
 struct Level {                  // tg_data_t + interp_data_t + agg_partitioning_relations_t
@@ -72,6 +74,7 @@ struct Level {                  // tg_data_t + interp_data_t + agg_partitioning_
     DBuf<int64_t> d_mis_u_off;
     // solve-phase work vectors
     DBuf<double> x, b, r, t0, t1;
+    DBuf<double> extra;                 // level 0: device copy / view of Params::extra_modes
     // row-partitioned solve: own rows [row_off[rank], row_off[rank+1]) (multiples of 64), halo
     // exchange lists of A's input vector (global indices, grouped by peer rank)
     struct Dist {

@@ -313,8 +313,10 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     L.mis_u_off.assign((size_t)nm + 1, 0);
     L.mis_s_off.assign((size_t)nm + 1, 0);
     int max_ctot = 0;
+    const int nextra = (lev == 0 && P.extra_modes) ? P.num_extra_modes : 0;
+    if (nextra) import_array(L.extra, P.extra_modes, (size_t)nextra * L.A.nrows, s);
     for (int m = 0; m < nm; ++m) {
-        int ctot = 0;
+        int ctot = nextra;
         for (int q = rel.mis_to_AE.I[m]; q < rel.mis_to_AE.I[m + 1]; ++q) ctot += L.ae_m[rel.mis_to_AE.J[q]];
         const int r = rel.mis_to_dof.row_size(m);
         g_off[m + 1] = g_off[m] + (int64_t)r * ctot;
@@ -348,6 +350,9 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         io.k = L.d_mis_k.p;
         io.ncols = d_ncols.p;
         io.avoid_ess = P.avoid_ess_bdr_dofs;
+        io.extra = nextra ? L.extra.p : nullptr;
+        io.nextra = nextra;
+        io.ND = L.A.nrows;
         mis_svd(s, L.drel, nm, max_ctot, io);
         { auto t_ = L.d_mis_k.to_host(s); L.mis_k.assign(t_.begin(), t_.end()); }
         { auto t_ = d_ncols.to_host(s); L.mis_ncols.assign(t_.begin(), t_.end()); }

@@ -20,6 +20,10 @@ struct MisSvdIO {
     int *k = nullptr;                   // [num_mises] kept vectors  (mis_numcoarsedof)
     int *ncols = nullptr;               // [num_mises] columns that entered the SVD
     int avoid_ess = 1;
+    // extra per-dof modes appended after the spectral columns (ExtendWithPolynomials / RBMs,
+    // amg/src/contrib.cpp:302-436): ND x nextra, column-major; level 0 only
+    const double *extra = nullptr;
+    int nextra = 0, ND = 0;
 };
 
 // ContribTent::SVDInsert on every MIS (amg/src/contrib.cpp:551-687): essential-boundary

@@ -83,6 +83,25 @@ __global__ __launch_bounds__(64) void mis_svd_kernel(
             ++c;
         }
     }
+    for (int q = 0; q < io.nextra; ++q) {   // appended modes, same filter / normalisation
+        const double *X = io.extra + (size_t)q * io.ND;
+        double *col = M + (size_t)c * sc;
+        double ss = 0.0;
+        int nz = 0;
+        for (int i = lane; i < r; i += 64) {
+            double x = X[dofs[i]];
+            if (io.avoid_ess && (flags[dofs[i]] & FLAG_ON_ESS_BORDER)) x = 0.0;
+            nz |= (x != 0.0);
+            ss = fma(x, x, ss);
+            col[i * sr] = x;
+        }
+        if (__ballot(nz) == 0ull) continue;
+        const double nrm = sqrt(wsum(ss));
+        if (nrm <= 1e-10) continue;
+        const double scl = 1.0 / nrm;
+        for (int i = lane; i < r; i += 64) col[i * sr] *= scl;
+        ++c;
+    }
     if (lane == 0) io.ncols[m] = c;
     if (c == 0) {
         if (lane == 0) io.k[m] = 0;

@@ -353,6 +353,57 @@ def test_corrected_nullspace_level_matches_oracle(levels):
     h.close()
 
 
+def _node_coords(n):
+    nx, ny, nz = n
+    iz, iy, ix = np.meshgrid(np.arange(nz + 1), np.arange(ny + 1), np.arange(nx + 1), indexing="ij")
+    return np.stack([ix.ravel() / nx, iy.ravel() / ny, iz.ravel() / nz], axis=1)
+
+
+@pytest.mark.parametrize("case", ["constants", "linears", "rigid_body_modes"])
+def test_extra_coarse_space_modes_match_oracle(case):
+    """ContribTent::ExtendWithPolynomials / ExtendWithRBMs (src/contrib.cpp:302-436): extra per-dof
+    modes appended to every MIS block before the SVD."""
+    capi, o = _capi(), _oracle()
+    if case == "rigid_body_modes":
+        n = (8, 6, 4)
+        prob = pr.elasticity3d_problem(n, blk=(4, 3, 2))
+        X = _node_coords(n)
+        nn = X.shape[0]
+        E = np.zeros((3 * nn, 6))
+        for d in range(3):
+            E[d::3, d] = 1.0                                   # translations
+        E[0::3, 3], E[1::3, 3] = X[:, 1], -X[:, 0]              # rotations (Hughes p. 88, as the reference)
+        E[1::3, 4], E[2::3, 4] = X[:, 2], -X[:, 1]
+        E[0::3, 5], E[2::3, 5] = -X[:, 2], X[:, 0]
+        theta = 1e-9                                           # spectral part: only the exact kernel
+    else:
+        n = (8, 8, 8)
+        prob = pr.poisson3d_problem(n, blk=(4, 4, 2), coef="checkerboard")
+        E = np.ones((prob.ND, 1)) if case == "constants" else np.concatenate([np.ones((prob.ND, 1)), _node_coords(n)], axis=1)
+        theta = 0.003
+    params = capi.default_params(num_coarsenings=1, theta=theta, keep_debug=True, coarse_rtol=1e-28, extra_modes=E)
+    h = capi.Hierarchy.from_problem(prob, params)
+    H = o.ml_produce_data(prob.A, prob.elem_to_dof, prob.elmat, prob.bdr, prob.partitions[:1],
+                          theta=theta, nu_relax=3, extra_modes=E)
+    olv = H.levels[0]
+    mises, k, ncols, flags = h.get_mis(0)
+    assert np.array_equal(k, olv.mis_numcoarsedof)            # coarse-space dimensions: exact
+    H0 = o.ml_produce_data(prob.A, prob.elem_to_dof, prob.elmat, prob.bdr, prob.partitions[:1],
+                           theta=theta, nu_relax=3)
+    assert olv.P.shape[1] > H0.levels[0].P.shape[1]           # the modes really enlarged the space
+    probe = np.sin(np.arange(prob.ND) * 0.37)
+    P = h.get_csr(0, "P")
+    assert np.allclose(_range_projection(sp.csr_matrix(P), probe),
+                       _range_projection(sp.csr_matrix(olv.P), probe), atol=1e-8)
+    b = np.cos(np.arange(prob.ND) * 0.13) * (~prob.ess)
+    x_gpu, x_ref = h.vcycle(b), o.vcycle(H, b)
+    assert np.linalg.norm(x_gpu - x_ref) <= 1e-8 * np.linalg.norm(x_ref)
+    x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-8)
+    xr, itr, convr, histr = o.solve(H, prob.b, rel_tol=1e-8)
+    assert conv and convr and it == itr
+    h.close()
+
+
 def test_smoother_matches_oracle():
     o = _oracle()
     prob = pr.poisson3d_problem((6, 6, 6), blk=(3, 3, 3))
