@@ -78,6 +78,11 @@ typedef struct saamge_amd_params {
      * level only, like the reference).  n x num_extra_modes, column-major, host or device. */
     const double *extra_modes;
     int num_extra_modes;
+    /* Element-free mode (tg_produce_data_algebraic / ExtractSubMatrices, src/tg.cpp:579-672,
+     * :862-886): elements are the dofs, partitions[0] maps DOFS to (non-overlapping) AEs, the AE
+     * matrices are principal submatrices of A made rowsum-free; pass NE = n, nde = 1,
+     * elem_to_dof = elmat = bdr_dofs = NULL. */
+    int algebraic;
 } saamge_amd_params;
 
 void saamge_amd_params_default(saamge_amd_params *p);

@@ -191,6 +191,35 @@ def build_AE_stiffm_with_global(A, part, rel, elmats):
     return out
 
 
+def build_AE_stiffm_algebraic(A, part, rel):
+    """ExtractSubMatrices (src/tg.cpp:579-672), the element-free mode: the principal submatrix of A
+    on the AE's dofs (non-zero entries), then every row with more than one stored entry gets its
+    row sum subtracted from the diagonal (constants in the kernel); a non-positive diagonal is
+    reset to 1; a single-dof AE is the 1 x 1 identity."""
+    dofs = rel.AE_to_dof.row(part)
+    n = dofs.size
+    if n == 1:
+        return np.ones((1, 1))
+    loc = rel.loc_in_AE[part]
+    out = np.zeros((n, n))
+    stored = np.zeros(n, dtype=np.int64)
+    indptr, indices, data = A.indptr, A.indices, A.data
+    for i in range(n):
+        g = int(dofs[i])
+        for k in range(indptr[g], indptr[g + 1]):
+            j = loc.get(int(indices[k]))
+            if j is None or data[k] == 0.0:
+                continue
+            out[i, j] = data[k]
+            stored[i] += 1
+    for i in range(n):
+        if stored[i] > 1:
+            out[i, i] += -float(np.sum(out[i, :]))
+        if out[i, i] <= 0.0:
+            out[i, i] = 1.0
+    return out
+
+
 def coarse_element_matrix(e, rel_f, rel_c, level_f):
     """ElementMatrixParallelCoarse::GetMatrix (src/elmat.cpp:105-195):
     P_loc^T * AEs_stiffm[e] * P_loc with P_loc built from mis_tent_interps."""
@@ -507,11 +536,17 @@ def nullspace_level(lv_last):
 
 
 def ml_produce_data(A, elem_to_dof, elmat, bdr, partitions, theta=0.003, nu_relax=3,
-                    nu_pro=0, testmesh=False, correct_nullspace=False, extra_modes=None):
+                    nu_pro=0, testmesh=False, correct_nullspace=False, extra_modes=None,
+                    algebraic=False):
     """ml_produce_data + ml_produce_hierarchy_from_level (src/ml.cpp:379-472,:111-236).
     `partitions[k]` maps level-k elements to level-k AEs.  Exact coarsest solve."""
     A = sp.csr_matrix(A)
     ND = A.shape[0]
+    if algebraic:
+        # tg_produce_data_algebraic (src/tg.cpp:862-886) on the tables of TestWindowSubMatrices /
+        # fem_create_partitioning_from_matrix: elements = dofs, partitions[0] maps dofs to AEs
+        elem_to_dof = np.arange(ND, dtype=np.int64).reshape(ND, 1)
+        bdr = None
     e2d = Table.from_fixed(elem_to_dof, ND)
     H = Hierarchy()
     H.levels = []
@@ -519,12 +554,14 @@ def ml_produce_data(A, elem_to_dof, elmat, bdr, partitions, theta=0.003, nu_rela
     rel = build_relations(e2d, partitions[0], nparts0, ND, bdr=bdr)
     global PARALLEL_MAP, _SHARED
     pool = None
-    if PARALLEL_CORES > 1:
+    if PARALLEL_CORES > 1 and not algebraic:
         import multiprocessing
         _SHARED = (A, rel, elmat)
         pool = multiprocessing.get_context("fork").Pool(PARALLEL_CORES)
         PARALLEL_MAP = lambda f, it: pool.map(f, it, chunksize=2)
         stiff = pool.map(_stiff_task, range(rel.nparts), chunksize=2)
+    elif algebraic:
+        stiff = [build_AE_stiffm_algebraic(A, p, rel) for p in range(rel.nparts)]
     else:
         stiff = [build_AE_stiffm_with_global(A, p, rel, elmat) for p in range(rel.nparts)]
     lv = build_level(A, rel, stiff, theta, nu_relax, nu_pro, testmesh,

@@ -54,6 +54,7 @@ class Params(C.Structure):
         ("correct_nullspace", C.c_int),
         ("extra_modes", C.c_void_p),
         ("num_extra_modes", C.c_int),
+        ("algebraic", C.c_int),
     ]
 
 
@@ -116,7 +117,7 @@ def _ptr(a):
 
 def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, keep_debug=False,
                    coarse_rtol=1e-14, workspace_bytes=None, dist_min_local_rows=None,
-                   coarse_solver=None, nu_pro=0, correct_nullspace=False, extra_modes=None):
+                   coarse_solver=None, nu_pro=0, correct_nullspace=False, extra_modes=None, algebraic=False):
     p = Params()
     load().saamge_amd_params_default(C.byref(p))
     p.num_coarsenings = num_coarsenings
@@ -126,6 +127,7 @@ def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, k
         p.nu_pro[i] = nu_pro
     p.testmesh = int(testmesh)
     p.correct_nullspace = int(correct_nullspace)
+    p.algebraic = int(algebraic)
     p.keep_debug = int(keep_debug)
     p.coarse_rtol = coarse_rtol
     if workspace_bytes is not None:
@@ -187,6 +189,20 @@ class Hierarchy(object):
         nparts = [int(p.max()) + 1 for p in parts]
         return cls(rowptr, col, val, A.shape[0], e2d, elmat, bdr, parts, nparts, params,
                    e2d.shape[0], e2d.shape[1], stream, group, dist_solve)
+
+    @classmethod
+    def from_matrix(cls, A, dof_partition, params, coarse_partitions=(), stream=0, group=None):
+        """Element-free (algebraic) mode: only the matrix and a map dof -> AE
+        (tg_produce_data_algebraic, amg/src/tg.cpp:862-886).  `params.algebraic` must be set."""
+        A = A.tocsr()
+        A.sort_indices()
+        rowptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
+        col = np.ascontiguousarray(A.indices, dtype=np.int32)
+        val = np.ascontiguousarray(A.data, dtype=np.float64)
+        parts = [np.ascontiguousarray(p, dtype=np.int32) for p in (dof_partition,) + tuple(coarse_partitions)]
+        nparts = [int(p.max()) + 1 for p in parts]
+        return cls(rowptr, col, val, A.shape[0], None, None, None, parts, nparts, params, A.shape[0], 1,
+                   stream, group)
 
     def close(self):
         if self.h:

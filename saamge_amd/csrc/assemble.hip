@@ -329,6 +329,49 @@ __global__ __launch_bounds__(AB_NT) void ae_build_kernel(
     }
 }
 
+// Element-free mode, ExtractSubMatrices (amg/src/tg.cpp:579-672): the principal submatrix of A
+// on the AE's dofs (non-zero entries only); rows with more than one stored entry get their row
+// sum subtracted from the diagonal, a non-positive diagonal becomes 1, a single-dof AE is [1].
+// One thread per local row (the AEs do not overlap in this mode: every dof is in exactly one AE).
+__global__ __launch_bounds__(ASM_NT) void ae_extract_kernel(
+    int ae0, const int *__restrict__ ns, const int64_t *__restrict__ moff, double *__restrict__ W,
+    const int *__restrict__ ae2d_I, const int *__restrict__ ae2d_J, const int *__restrict__ d2ae_I,
+    const int *__restrict__ d2ae_J, const int *__restrict__ dof_id_inAE, const int *__restrict__ Arow,
+    const int *__restrict__ Acol, const double *__restrict__ Aval) {
+    const int b = blockIdx.x, p = ae0 + b, n = ns[b];
+    double *Wm = W + moff[b];
+    const int tid = threadIdx.x;
+    const size_t nn = (size_t)n * n;
+    for (size_t idx = tid; idx < nn; idx += ASM_NT) Wm[idx] = 0.0;
+    __syncthreads();
+    if (n == 1) {
+        if (tid == 0) Wm[0] = 1.0;
+        return;
+    }
+    const int *aedofs = ae2d_J + ae2d_I[p];
+    for (int lr = tid; lr < n; lr += ASM_NT) {
+        const int g = aedofs[lr];
+        double rowsum = 0.0, diag = 0.0;
+        int stored = 0;
+        for (int k = Arow[g]; k < Arow[g + 1]; ++k) {
+            const int c = Acol[k];
+            const double v = Aval[k];
+            if (v == 0.0) continue;
+            int lc = -1;
+            for (int q = d2ae_I[c]; q < d2ae_I[c + 1]; ++q)
+                if (d2ae_J[q] == p) { lc = dof_id_inAE[q]; break; }
+            if (lc < 0) continue;
+            ++stored;
+            rowsum += v;
+            if (lc == lr) diag = v;
+            else Wm[(size_t)lc * n + lr] = v;     // entry (row lr, column lc), column-major
+        }
+        if (stored > 1) diag -= rowsum;
+        if (!(diag > 0.0)) diag = 1.0;
+        Wm[(size_t)lr * n + lr] = diag;
+    }
+}
+
 static int csr_max_row(hipStream_t s, const DCsr &A) {
     DBuf<int> m(1);
     m.zero(s);
@@ -341,6 +384,18 @@ static int csr_max_row(hipStream_t s, const DCsr &A) {
 void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevElmats &el, int ae0,
               EigBatch &batch, bool scale, double *Dout) {
     if (!batch.count) return;
+    if (A && el.algebraic) {
+        double bytes = 0.0;
+        for (int n : batch.h_n) bytes += 8.0 * (double)n * n;
+        profiler().begin(s);
+        hipLaunchKernelGGL(ae_extract_kernel, dim3(batch.count), dim3(ASM_NT), 0, s, ae0, batch.n.p, batch.moff.p,
+                           batch.W.p, rel.ae2d_I.p, rel.ae2d_J.p, rel.d2ae_I.p, rel.d2ae_J.p, rel.dof_id_inAE.p,
+                           A->rowptr.p, A->col.p, A->val.p);
+        SA_HIP_CHECK(hipGetLastError());
+        profiler().end(s, "ae_extract", bytes, 0.0);
+        if (scale) ae_scale(s, batch, Dout);
+        return;
+    }
     static const bool no_fused = std::getenv("SAAMGE_AMD_NO_FUSED_ASSEMBLY") != nullptr;
     size_t lds = 0;
     int RW = 0;

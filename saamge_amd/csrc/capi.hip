@@ -56,6 +56,7 @@ void saamge_amd_params_default(saamge_amd_params *p) {
     p->correct_nullspace = 0;
     p->extra_modes = nullptr;
     p->num_extra_modes = 0;
+    p->algebraic = 0;
 }
 
 int saamge_amd_memcpy(void *dst, const void *src, long long bytes) {
@@ -74,7 +75,7 @@ int saamge_amd_ml_produce_data(int n, const int *rowptr, const int *col, const d
                                const int *nparts, const saamge_amd_params *params, void *stream,
                                saamge_amd_hierarchy **out) {
     SA_API_BEGIN
-    SA_REQUIRE(out && params && rowptr && col && val && elem_to_dof && elmat && partitions && nparts,
+    SA_REQUIRE(out && params && rowptr && col && val && (params->algebraic || (elem_to_dof && elmat)) && partitions && nparts,
                "null argument");
     Params p;
     p.num_coarsenings = params->num_coarsenings;
@@ -102,6 +103,7 @@ int saamge_amd_ml_produce_data(int n, const int *rowptr, const int *col, const d
     p.correct_nullspace = params->correct_nullspace;
     p.extra_modes = params->extra_modes;
     p.num_extra_modes = params->num_extra_modes;
+    p.algebraic = params->algebraic;
     SA_REQUIRE(p.world == 1 || (p.rank >= 0 && p.rank < p.world), "bad rank");
     Hierarchy *H = hierarchy_create(n, rowptr, col, val, NE, nde, elem_to_dof, elmat, bdr_dofs,
                                     partitions, nparts, p, (hipStream_t)stream);

@@ -47,6 +47,7 @@ struct Params {                 // MultilevelParameters (amg/inc/ml.hpp:59-114)
     int correct_nullspace = 0;    // extra scaling_P level under the coarsest spectral operator
     const double *extra_modes = nullptr;  // level 0: n x num_extra_modes (column-major) appended to every MIS block
     int num_extra_modes = 0;
+    int algebraic = 0;            // element-free mode (tg_produce_data_algebraic): elements = dofs
 };
 
 struct Level {                  // tg_data_t + interp_data_t + agg_partitioning_relations_t
@@ -103,6 +104,7 @@ struct Hierarchy {              // ml_data_t
     // PCG scratch
     DBuf<double> pcg_r, pcg_z, pcg_d, pcg_q, scal, partials;
     int last_coarse_iters = 0;
+    DBuf<int> own_e2d;          // element-free mode: the generated identity elem_to_dof
 };
 
 // ml_produce_data (amg/src/ml.cpp:379-472).  All array arguments may be host or device

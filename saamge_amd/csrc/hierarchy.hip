@@ -66,6 +66,11 @@ static double *scratch_get(int slot, size_t need) {
 
 static void finish_csr(DCsr &A) { A.lanes_per_row = pick_lanes_per_row(A.nnz, A.nrows > 0 ? A.nrows : 1); }
 
+__global__ void iota_int_kernel(long n, int *p) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = (int)i;
+}
+
 __global__ void iota64_kernel(long n, int64_t scale, int64_t *p) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = i * scale;
@@ -827,12 +832,25 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
                             const signed char *bdr, const int *const *partitions,
                             const int *nparts, const Params &p, hipStream_t stream) {
     SA_REQUIRE(p.num_coarsenings >= 1 && p.num_coarsenings < MAX_LEVELS, "bad number of coarsenings");
+    // element-free mode: elements = dofs (identity elem_to_dof generated here), no element matrices
+    DBuf<int> iota_e2d;   // (moved into the hierarchy below: the device topology views it)
+    if (p.algebraic) {
+        NE = n;
+        nde = 1;
+        iota_e2d.alloc((size_t)n);
+        hipLaunchKernelGGL(iota_int_kernel, dim3(div_up(n, 256)), dim3(256), 0, stream, (long)n, iota_e2d.p);
+        SA_HIP_CHECK(hipGetLastError());
+        elem_to_dof = iota_e2d.p;
+        elmat = nullptr;
+        bdr = nullptr;
+    }
     SA_REQUIRE(n > 0 && NE > 0 && nde > 0, "empty problem");
     PhaseTimer tm_all(stream), tm0(stream);
     std::unique_ptr<Hierarchy> Hp(new Hierarchy);
     Hierarchy &H = *Hp;
     H.params = p;
     H.stream = stream;
+    H.own_e2d = std::move(iota_e2d);
     hipStream_t s = stream;
     H.scal.alloc(8);
     H.partials.alloc(1024);
@@ -854,8 +872,9 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
         hipLaunchKernelGGL(iota64_kernel, dim3(div_up((long)NE + 1, 256)), dim3(256), 0, s, (long)NE + 1,
                            (int64_t)nde * nde, L0.elmat.off.p);
         SA_HIP_CHECK(hipGetLastError());
-        import_array(L0.elmat.val, elmat, (size_t)NE * nde * nde, s);
+        if (!p.algebraic) import_array(L0.elmat.val, elmat, (size_t)NE * nde * nde, s);
         L0.elmat.nde = nde;
+        L0.elmat.algebraic = p.algebraic != 0;
     }
     // Level-0 topology inputs that are device-resident stay there (device build of the AE tables)
     static const bool host_topo = std::getenv("SAAMGE_AMD_HOST_TOPOLOGY") != nullptr;

@@ -160,3 +160,25 @@ def test_corrected_nullspace_level():
     assert np.allclose(proj, ones_c, atol=1e-10)
     x, it, conv, hist = o.solve(H, prob.b, rel_tol=1e-8)
     assert conv and np.linalg.norm(prob.A @ x - prob.b) <= 1e-6 * np.linalg.norm(prob.b)
+
+
+def test_algebraic_mode_on_the_reference_fixture():
+    """Element-free mode on amg/data/anisotropic.mat.00000 (the matrix of the reference's
+    `algebraic` ctest; its 12-iteration count depends on a METIS partition and is not pinned):
+    contiguous AEs of 128 dofs, theta = 0.01 -- every AE matrix has the constants in its kernel
+    and the preconditioned iteration converges."""
+    import scipy.sparse as sp
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "anisotropic_mat.npz"))
+    A = sp.csr_matrix((g["data"], g["indices"], g["indptr"]), shape=tuple(g["shape"]))[1:, 1:].tocsr()
+    n = A.shape[0]
+    part = (np.arange(n) // 128).astype(np.int32)
+    H = o.ml_produce_data(A, None, None, None, [part], theta=0.01, nu_relax=3, algebraic=True)
+    for Ai in H.levels[0].AEs_stiffm:
+        coupled = (Ai != 0.0).sum(axis=1) > 1                   # rows with a neighbour inside the AE
+        assert np.allclose((Ai @ np.ones(Ai.shape[0]))[coupled], 0.0, atol=1e-9 * np.abs(Ai).max())
+        assert (np.diag(Ai) > 0.0).all()
+    assert H.levels[0].rel.num_mises == H.levels[0].rel.nparts      # non-overlapping AEs: MIS == AE
+    b = np.ones(n)
+    x, it, conv, hist = o.solve(H, b, rel_tol=1e-6)
+    assert conv and it <= 100
+    assert np.linalg.norm(A @ x - b) <= 1e-4 * np.linalg.norm(b)
