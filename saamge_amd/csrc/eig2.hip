@@ -56,6 +56,20 @@ __device__ inline double rsum16(double v) {
     v += dpp_rot<0x121>(v);  // row_ror:1
     return v;
 }
+// v + v(lane ^ 16) and v + v(lane ^ 32) with the gfx950 row / half swaps (VALU) instead of
+// ds_bpermute round trips through the LDS crossbar
+__device__ inline double xsum16(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ inline double xsum32(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
 template <int NT>
 __device__ inline double bsum(double v, double *red) {
 #pragma unroll
@@ -904,8 +918,7 @@ __device__ inline void chase_step(const BandRef &B, int n, int s, int q, double 
             cv[k] = (r < L) ? B(i0 + r, j0 + c) : 0.0;
             w = fma(cv[k], vp[k], w);
         }
-        w += __shfl_xor(w, 16, 64);
-        w += __shfl_xor(w, 32, 64);
+        w = xsum32(xsum16(w));
         const double tw = tprev * w;
 #pragma unroll
         for (int k = 0; k < 4; ++k) cv[k] = fma(-tw, vp[k], cv[k]);   // C <- C H_prev
@@ -955,8 +968,7 @@ __device__ inline void chase_step(const BandRef &B, int n, int s, int q, double 
             dv[k] = (r < L && c < L) ? B.sym(i0 + r, i0 + c) : 0.0;
             p = fma(dv[k], vc[k], p);
         }
-        p += __shfl_xor(p, 16, 64);
-        p += __shfl_xor(p, 32, 64);
+        p = xsum32(xsum16(p));
         p *= tau;                                   // p_r
         const double pv = rsum16(p * vr);           // p and v are replicated in the four groups
         const double wr = fma(-0.5 * tau * pv, vr, p);   // w_r = p_r - tau/2 (p.v) v_r
