@@ -20,9 +20,9 @@ Prints ONE JSON line (rank 0).  Extra legs, outside the timed region:
 
 N > 1 (torchrun, one rank per GPU, RCCL): STRONG scaling on the same global problem -- the
 per-agglomerate spectral problems of every level (the dominant setup cost) are sharded over the
-ranks and their eigenvectors all-gathered in place; the PCG solve is row-partitioned on the large
-levels (halo exchange before every SpMV, all-reduced inner products and restricted residuals);
-topology, P and RAP are still replicated on every rank.
+ranks and their eigenvectors all-gathered in place, likewise the Galerkin product and the coarse
+element matrices; the PCG solve is row-partitioned on the large levels (halo exchange before every
+SpMV, all-reduced inner products and restricted residuals); topology, MIS SVD and P are replicated.
 value = dofs * steps / max-over-ranks time.
 """
 import argparse
@@ -188,9 +188,9 @@ def main():
                    "dofs": prob.n, "pcg_iterations": its, "converged": bool(conv),
                    "true_relative_residual": relres,
                    "level_dims": [i["n"] for i in infos] + [infos[-1]["ncoarse"]],
-                   "parallelism": ("%d ranks: per-AE spectral problems sharded + all-gather; levels %s "
-                                   "solved row-partitioned (halo exchange per SpMV, all-reduced dots); "
-                                   "topology/P/RAP and smaller levels replicated"
+                   "parallelism": ("%d ranks: per-AE spectral problems, RAP and coarse element matrices sharded + "
+                                   "all-gathered; levels %s solved row-partitioned (halo exchange per SpMV, "
+                                   "all-reduced dots); topology/MIS SVD/P and smaller levels replicated"
                                    % (world, [l for l, i in enumerate(infos) if i["row_partitioned"]]))
                    if world > 1 else "single GPU"},
     }

@@ -62,6 +62,7 @@ struct Level {                  // tg_data_t + interp_data_t + agg_partitioning_
     DevRelations drel;          // device mirror
     DevElmats elmat;            // element matrices of this level
     // interp_data_t
+    std::vector<int> ae_begin;          // [world+1] AE ownership ranges of the ranks (eigenproblems, coarse element matrices)
     std::vector<int> ae_m;              // eigenvectors per AE
     std::vector<int64_t> ae_xoff, ae_eoff;
     DBuf<double> evals, evecs;          // cut_evects_arr (packed)

@@ -166,6 +166,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         SA_REQUIRE(!(P.testmesh && lev == 0), "the mltest fixture is single-rank only");
     }
     const int ae_lo = ae_begin[world > 1 ? P.rank : 0], ae_hi = ae_begin[world > 1 ? P.rank + 1 : 1];
+    L.ae_begin = ae_begin;
     int64_t row0 = 0;
     for (int p = 0; p < ae_lo; ++p) row0 += sizes[p];
     // Optional chunk pipeline (SAAMGE_AMD_PIPELINE=1): dense -> band of chunk i on stream A beside
@@ -369,8 +370,16 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     build_P_R(s, L.drel, rel, L.mis_k, L.mis_u_off, L.d_mis_k.p, L.d_mis_coloff.p, L.d_mis_u_off.p,
               L.mis_U.p, L.P, L.R);
     if (P.nu_pro[lev] == 0) {
+        std::vector<long long> nnz_off;
         rap_mis(s, L.drel, rel, L.A, L.mis_k, L.mis_coloff, L.d_mis_k.p, L.d_mis_coloff.p,
-                L.d_mis_u_off.p, L.mis_U.p, L.Ac);
+                L.d_mis_u_off.p, L.mis_U.p, L.Ac, P.rank, world, world > 1 ? &nnz_off : nullptr);
+        if (world > 1 && L.Ac.nnz > 0) {   // every rank computed the row blocks of its MIS range
+            std::vector<long long> off((size_t)world + 1);
+            for (int r = 0; r <= world; ++r) off[r] = 4ll * nnz_off[r];
+            SA_REQUIRE(P.allgather(P.allgather_ctx, L.Ac.col.p, off.data()) == 0, "all-gather (Ac columns) failed");
+            for (int r = 0; r <= world; ++r) off[r] = 8ll * nnz_off[r];
+            SA_REQUIRE(P.allgather(P.allgather_ctx, L.Ac.val.p, off.data()) == 0, "all-gather (Ac values) failed");
+        }
     } else {
         // interp_smooth (amg/src/interp.cpp:172-229): P = prod_k (I + (1/tau_k) Dinv_neg A) P_tent with
         // tau_k = sin^2(k pi / (2 nu + 1)) (smpr_sa_poly_roots, amg/src/smpr.cpp:266-280); then
@@ -493,10 +502,15 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
     d_colpos.from_host(colpos, s);
     std::vector<int> sizes((size_t)nparts);
     for (int p = 0; p < nparts; ++p) sizes[p] = rel.AE_to_dof.row_size(p);
-    for (int ae0 = 0; ae0 < nparts;) {
+    // several ranks: each computes the coarse element matrices of its AE range (the ranges of
+    // the eigenproblems), then one in-place all-gather
+    const int world = H.params.world > 1 ? H.params.world : 1;
+    const int ae_lo = world > 1 ? L.ae_begin[H.params.rank] : 0;
+    const int ae_hi = world > 1 ? L.ae_begin[H.params.rank + 1] : nparts;
+    for (int ae0 = ae_lo; ae0 < ae_hi;) {
         size_t bytes = 0;
         int cnt = 0;
-        while (ae0 + cnt < nparts) {
+        while (ae0 + cnt < ae_hi) {
             const size_t n = (size_t)sizes[ae0 + cnt];
             const size_t add = 8 * (n * n + n * (EIG_NB + 8) + n * (size_t)e2d.row_size(ae0 + cnt));
             if (cnt > 0 && bytes + add > H.params.workspace_bytes) break;
@@ -515,6 +529,12 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
                       d_colpos.p, N.elmat.off.p, N.elmat.val.p, scratch, d_soff.p);
         SA_HIP_CHECK(hipStreamSynchronize(s));
         ae0 += cnt;
+    }
+    if (world > 1) {
+        std::vector<long long> off((size_t)world + 1);
+        for (int r = 0; r <= world; ++r) off[r] = 8ll * out_off[L.ae_begin[r]];
+        SA_REQUIRE(H.params.allgather(H.params.allgather_ctx, N.elmat.val.p, off.data()) == 0,
+                   "all-gather (coarse element matrices) failed");
     }
     return e2d;
 }

@@ -40,6 +40,7 @@ void build_P_R(hipStream_t s, const DevRelations &rel, const Relations &hrel,
 // Ac = P^T A P exploiting the MIS block structure of P (tg_coarse_matr, amg/inc/tg.hpp:696-709).
 void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, const DCsr &A,
              const std::vector<int> &h_k, const std::vector<int> &h_coloff, const int *d_k,
-             const int *d_coloff, const int64_t *d_u_off, const double *U, DCsr &Ac);
+             const int *d_coloff, const int64_t *d_u_off, const double *U, DCsr &Ac, int rank = 0,
+             int world = 1, std::vector<long long> *nnz_off = nullptr);
 
 }  // namespace saamge_amd

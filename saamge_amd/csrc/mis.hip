@@ -429,14 +429,14 @@ __global__ __launch_bounds__(RAP_NT) void rap_symbolic_kernel(
 }
 
 __global__ __launch_bounds__(RAP_NT) void rap_numeric_kernel(
-    const int *__restrict__ mis2d_I, const int *__restrict__ mis2d_J, const int *__restrict__ Arow,
+    int m_first, const int *__restrict__ mis2d_I, const int *__restrict__ mis2d_J, const int *__restrict__ Arow,
     const int *__restrict__ Acol, const double *__restrict__ Aval, const int *__restrict__ mises,
     const int *__restrict__ row_in_mis, const int *__restrict__ k, const int *__restrict__ coloff,
     const int64_t *__restrict__ u_off, const double *__restrict__ U,
     const int *__restrict__ nbr_ptr, const int *__restrict__ nbr, const int *__restrict__ crowptr,
     int *__restrict__ ccol, double *__restrict__ cval, int lds_doubles) {
     extern __shared__ __align__(16) double lds[];
-    const int m1 = blockIdx.x;
+    const int m1 = m_first + blockIdx.x;
     const int k1 = k[m1];
     if (k1 == 0) return;
     const int tid = threadIdx.x;
@@ -515,7 +515,8 @@ __global__ __launch_bounds__(RAP_NT) void rap_numeric_kernel(
 
 void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, const DCsr &A,
              const std::vector<int> &h_k, const std::vector<int> &h_coloff, const int *d_k,
-             const int *d_coloff, const int64_t *d_u_off, const double *U, DCsr &Ac) {
+             const int *d_coloff, const int64_t *d_u_off, const double *U, DCsr &Ac, int rank, int world,
+             std::vector<long long> *nnz_off) {
     const int nm = hrel.num_mises;
     int nc = 0;
     for (int m = 0; m < nm; ++m) nc += h_k[m];
@@ -574,10 +575,28 @@ void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, cons
     Ac.rowptr.from_host(crow, s);
     Ac.col.alloc((size_t)nnz);
     Ac.val.alloc((size_t)nnz);
-    hipLaunchKernelGGL(rap_numeric_kernel, dim3(nm), dim3(RAP_NT), lds_doubles * 8, s, rel.mis2d_I.p,
-                       rel.mis2d_J.p, A.rowptr.p, A.col.p, A.val.p, rel.mises.p, rel.dof_row_in_mis.p,
-                       d_k, d_coloff, d_u_off, U, nbr_ptr.p, nbr.p, Ac.rowptr.p, Ac.col.p, Ac.val.p,
-                       (int)lds_doubles);
+    // Several ranks: the MIS row blocks are split into `world` contiguous ranges balanced by their
+    // non-zeros; a rank computes its range only, the caller all-gathers col / val by nnz_off.
+    int m_lo = 0, m_hi = nm;
+    if (world > 1 && nnz_off) {
+        std::vector<int> mb((size_t)world + 1, nm);
+        mb[0] = 0;
+        int r = 0;
+        for (int m = 0; m < nm && r + 1 < world; ++m) {
+            const int64_t done = crow[(size_t)h_coloff[m + 1]];   // nnz of the rows of MISes 0..m
+            while (r + 1 < world && done >= nnz * (r + 1) / world) mb[++r] = m + 1;
+        }
+        mb[world] = nm;
+        nnz_off->assign((size_t)world + 1, 0);
+        for (int q = 0; q <= world; ++q) (*nnz_off)[q] = crow[(size_t)h_coloff[mb[q]]];
+        m_lo = mb[rank];
+        m_hi = mb[rank + 1];
+    }
+    if (m_hi > m_lo)
+        hipLaunchKernelGGL(rap_numeric_kernel, dim3(m_hi - m_lo), dim3(RAP_NT), lds_doubles * 8, s, m_lo,
+                           rel.mis2d_I.p, rel.mis2d_J.p, A.rowptr.p, A.col.p, A.val.p, rel.mises.p,
+                           rel.dof_row_in_mis.p, d_k, d_coloff, d_u_off, U, nbr_ptr.p, nbr.p, Ac.rowptr.p,
+                           Ac.col.p, Ac.val.p, (int)lds_doubles);
     SA_HIP_CHECK(hipGetLastError());
     SA_HIP_CHECK(hipStreamSynchronize(s));  // nbr buffers are freed on return
     profiler().end(s, "rap", 12.0 * (double)(A.nnz + nnz) + 4.0 * A.nrows, 0.0);

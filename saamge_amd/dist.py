@@ -173,8 +173,35 @@ class Group(object):
                 print("saamge_amd allreduce callback failed: %r" % (e,), file=sys.stderr)
                 return 4
 
+        plans = {}   # RCCL: (send ptr, recv ptr, sizes) -> prepared send/recv list (the library reuses its buffers)
+
         def alltoallv(ctx, send, soff, recv, roff):
             try:
+                if use_cuda:
+                    key = (int(send or 0), int(recv or 0), int(soff[world]), int(roff[world]))
+                    ops = plans.get(key)
+                    if ops is None:
+                        so = [int(soff[r]) for r in range(world + 1)]
+                        ro = [int(roff[r]) for r in range(world + 1)]
+                        st = self._wrap(send, so[world], torch.uint8) if so[world] else None
+                        rt = self._wrap(recv, ro[world], torch.uint8) if ro[world] else None
+                        ops = []
+                        for r in range(world):
+                            if r == rank:
+                                continue
+                            if so[r + 1] > so[r]:
+                                ops.append(dist.P2POp(dist.isend, st[so[r]:so[r + 1]], r))
+                            if ro[r + 1] > ro[r]:
+                                ops.append(dist.P2POp(dist.irecv, rt[ro[r]:ro[r + 1]], r))
+                        if len(plans) > 64:
+                            plans.clear()
+                        plans[key] = ops
+                    if ops:
+                        for w in dist.batch_isend_irecv(ops):
+                            w.wait()
+                    if not ordered:
+                        torch.cuda.current_stream().synchronize()
+                    return 0
                 so = [int(soff[r]) for r in range(world + 1)]
                 ro = [int(roff[r]) for r in range(world + 1)]
                 if use_cuda:
