@@ -45,7 +45,7 @@ KERNELS = {
     "eig_sbr_symm": ("sbr_symm_kernel", "hbm"),
     "eig_sbr_syr2k": ("sbr_syr2k_kernel", "hbm"),
     "eig_sbr_fused": ("sbr_fused_kernel", "hbm"),
-    "ae_build": ("ae_build_kernel<true, 8>", "hbm"),
+    "ae_build": ("ae_build_kernel<true, 8, true>", "hbm"),
     "eig_band_chase": ("band_chase_kernel", "mfma"),
     "eig_sbr_qr": ("sbr_qr_kernel<256, true>", "mfma"),
     "ae_assemble": ("ae_assemble_kernel", "hbm"),

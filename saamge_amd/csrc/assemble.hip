@@ -170,11 +170,82 @@ __global__ __launch_bounds__(256) void max_row_kernel(int n, const int *__restri
     if ((threadIdx.x & 63) == 0) atomicMax(out, len);
 }
 
+// Sparse rows of all AE matrices of a chunk, one thread per (AE, local row, slot of A's row):
+// full occupancy for the dependent gathers (dof -> AE-local index, flags, element lists) that
+// bound this step.  8-dof elements (dense elem_to_dof): the dof's <= 8 elements are examined with
+// independent vector loads and added in ascending element id (the reference's order).
+// Output: vals / cols at ((voff[b] + lr) * RW + k).
+__global__ __launch_bounds__(256) void ae_rows8_kernel(
+    int ae0, int RW, const int *__restrict__ ns, const int64_t *__restrict__ voff,
+    const int *__restrict__ ae2d_I, const int *__restrict__ ae2d_J, const int *__restrict__ d2ae_I,
+    const int *__restrict__ d2ae_J, const int *__restrict__ dof_id_inAE,
+    const signed char *__restrict__ flags, const int *__restrict__ d2e_I, const int *__restrict__ d2e_J,
+    const int *__restrict__ part, const int *__restrict__ e2d_J, const double *__restrict__ elval,
+    const int *__restrict__ Arow, const int *__restrict__ Acol, const double *__restrict__ Aval,
+    double *__restrict__ rvals, short *__restrict__ rcols) {
+    const int b = blockIdx.y, p = ae0 + b, n = ns[b];
+    const int it = blockIdx.x * 256 + threadIdx.x;
+    if (it >= n * RW) return;
+    const int lr = it / RW, k = it - lr * RW;
+    const int g = ae2d_J[ae2d_I[p] + lr];
+    const int a0 = Arow[g];
+    int lc = -1;
+    double v = 0.0;
+    if (k < Arow[g + 1] - a0) {
+        const int c = Acol[a0 + k];
+        for (int q = d2ae_I[c]; q < d2ae_I[c + 1]; ++q)
+            if (d2ae_J[q] == p) { lc = dof_id_inAE[q]; break; }
+        if (lc >= 0) {
+            const int fg = flags[g], fc = flags[c];
+            const bool assembled = (fg & 1) && (fc & 1) && (!((fg | fc) & 2) || c == g);
+            if (!assembled) {
+                v = Aval[a0 + k];               // copied from the global matrix (aggregates.cpp:930-934)
+            } else {                            // agg_assemble_value, aggregates.cpp:68-184
+                const int qb = d2e_I[g], cnt = d2e_I[g + 1] - qb;
+                int es[8], kk[8], jj[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int e = d2e_J[qb + min(q, cnt - 1)];
+                    const int4 lo = *(const int4 *)(e2d_J + (size_t)e * 8), hi = *(const int4 *)(e2d_J + (size_t)e * 8 + 4);
+                    es[q] = (q < cnt && part[e] == p) ? e : -1;
+                    kk[q] = (lo.x == g) ? 0 : (lo.y == g) ? 1 : (lo.z == g) ? 2 : (lo.w == g) ? 3 :
+                            (hi.x == g) ? 4 : (hi.y == g) ? 5 : (hi.z == g) ? 6 : 7;
+                    jj[q] = (lo.x == c) ? 0 : (lo.y == c) ? 1 : (lo.z == c) ? 2 : (lo.w == c) ? 3 :
+                            (hi.x == c) ? 4 : (hi.y == c) ? 5 : (hi.z == c) ? 6 : (hi.w == c) ? 7 : -1;
+                }
+                double m[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const bool on = es[q] >= 0 && jj[q] >= 0;
+                    m[q] = on ? elval[((size_t)max(es[q], 0) * 8 + kk[q]) * 8 + max(jj[q], 0)] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (es[q] >= 0 && jj[q] >= 0) v += m[q];
+                for (int q = 8; q < cnt; ++q) {   // (more than 8 elements at a dof: plain loop)
+                    const int e = d2e_J[qb + q];
+                    if (part[e] != p) continue;
+                    int k2 = -1, j2 = -1;
+                    for (int t = 0; t < 8; ++t) {
+                        const int dd = e2d_J[(size_t)e * 8 + t];
+                        if (dd == g && k2 < 0) k2 = t;
+                        if (dd == c && j2 < 0) j2 = t;
+                    }
+                    if (j2 >= 0) v += elval[((size_t)e * 8 + k2) * 8 + j2];
+                }
+            }
+        }
+    }
+    const size_t o = ((size_t)voff[b] + lr) * RW + k;
+    rvals[o] = v;
+    rcols[o] = (short)lc;
+}
+
 constexpr int AB_MAXE = 8;   // elements per dof kept in the LDS row tables (hexes: <= 8)
 
 // NDE > 0: every element has exactly NDE dofs (level 0: elem_to_dof is a dense NE x NDE array),
 // which turns the per-element searches into a few independent vector loads.
-template <bool SCALE, int NDE>
+template <bool SCALE, int NDE, bool PRE>
 __global__ __launch_bounds__(AB_NT) void ae_build_kernel(
     int ae0, int RW, const int *__restrict__ ns, const int64_t *__restrict__ moff,
     const int64_t *__restrict__ voff, double *__restrict__ W, double *__restrict__ dis_out,
@@ -184,7 +255,7 @@ __global__ __launch_bounds__(AB_NT) void ae_build_kernel(
     const int *__restrict__ d2e_I, const int *__restrict__ d2e_J, const int *__restrict__ part,
     const int *__restrict__ e2d_I, const int *__restrict__ e2d_J, const int64_t *__restrict__ eloff,
     const double *__restrict__ elval, const int *__restrict__ Arow, const int *__restrict__ Acol,
-    const double *__restrict__ Aval) {
+    const double *__restrict__ Aval, const double *__restrict__ rvals, const short *__restrict__ rcols) {
     extern __shared__ __align__(16) double lds[];
     __shared__ int anybig;
     const int b = blockIdx.x, p = ae0 + b, n = ns[b];
@@ -199,6 +270,14 @@ __global__ __launch_bounds__(AB_NT) void ae_build_kernel(
     short *cols = (short *)(colbuf + (size_t)NW * n);     // [n * RW] AE-local column or -1
     int *gdof = (int *)(cols + (((size_t)n * RW + 3) & ~(size_t)3));  // [n] global dof of each row
     const int *aedofs = ae2d_J + ae2d_I[p];
+    if (PRE) {   // sparse rows precomputed by ae_rows8_kernel: coalesced copy into LDS
+        const size_t base = (size_t)voff[b] * RW;
+        for (int it = tid; it < n * RW; it += AB_NT) {
+            vals[it] = rvals[base + it];
+            cols[it] = rcols[base + it];
+        }
+        __syncthreads();
+    } else {
     if (tid == 0) anybig = 0;
     for (int lr = tid; lr < n; lr += AB_NT) gdof[lr] = aedofs[lr];
     __syncthreads();
@@ -283,6 +362,7 @@ __global__ __launch_bounds__(AB_NT) void ae_build_kernel(
         cols[it] = (short)lc;
     }
     __syncthreads();
+    }
     // ---- 2. diagonal, 3. D and D^-1/2 ----
     for (int lr = tid; lr < n; lr += AB_NT) {
         double d = 0.0;
@@ -410,22 +490,39 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
         if (scale) ae_scale(s, batch, Dout);
         return;
     }
-    const bool nde8 = el.nde == 8;
+    const bool nde8 = el.nde == 8 && batch.count <= 65535;   // (grid.y of the rows kernel)
+    static DBuf<double> g_rvals;     // grow-only: sparse rows of the current chunk
+    static DBuf<short> g_rcols;
+    const double *rv = nullptr;
+    const short *rc = nullptr;
+    if (nde8) {
+        const size_t need = (size_t)batch.h_voff[batch.count] * RW + 64;
+        if (g_rvals.n < need) { g_rvals.alloc(need + need / 8); g_rcols.alloc(need + need / 8); }
+        profiler().begin(s);
+        hipLaunchKernelGGL(ae_rows8_kernel, dim3(div_up((long)batch.max_n * RW, 256), batch.count), dim3(256), 0, s,
+                           ae0, RW, batch.n.p, batch.voff.p, rel.ae2d_I.p, rel.ae2d_J.p, rel.d2ae_I.p,
+                           rel.d2ae_J.p, rel.dof_id_inAE.p, rel.flags.p, rel.d2e_I.p, rel.d2e_J.p, rel.part.p,
+                           rel.e2d_J.p, el.val.p, A->rowptr.p, A->col.p, A->val.p, g_rvals.p, g_rcols.p);
+        SA_HIP_CHECK(hipGetLastError());
+        profiler().end(s, "ae_rows", 0.0, 0.0);
+        rv = g_rvals.p;
+        rc = g_rcols.p;
+    }
     auto launch = [&](auto kern) {
         SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         hipLaunchKernelGGL(kern, dim3(batch.count), dim3(AB_NT), lds, s, ae0, RW, batch.n.p, batch.moff.p,
                            batch.voff.p, batch.W.p, batch.dis.p, Dout, rel.ae2d_I.p, rel.ae2d_J.p,
                            rel.d2ae_I.p, rel.d2ae_J.p, rel.dof_id_inAE.p, rel.flags.p, rel.d2e_I.p,
                            rel.d2e_J.p, rel.part.p, rel.e2d_I.p, rel.e2d_J.p, el.off.p, el.val.p,
-                           A->rowptr.p, A->col.p, A->val.p);
+                           A->rowptr.p, A->col.p, A->val.p, rv, rc);
     };
     double bytes = 0.0;
     for (int n : batch.h_n) bytes += 8.0 * (double)n * n;
     profiler().begin(s);
     if (scale) {
-        if (nde8) launch(ae_build_kernel<true, 8>); else launch(ae_build_kernel<true, 0>);
+        if (nde8) launch(ae_build_kernel<true, 8, true>); else launch(ae_build_kernel<true, 0, false>);
     } else {
-        if (nde8) launch(ae_build_kernel<false, 8>); else launch(ae_build_kernel<false, 0>);
+        if (nde8) launch(ae_build_kernel<false, 8, true>); else launch(ae_build_kernel<false, 0, false>);
     }
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "ae_build", bytes, 0.0);
