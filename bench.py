@@ -58,10 +58,10 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_problem(n, levels, dev, aniso=1.0):
+def build_problem(n, levels, dev, aniso=1.0, blk=(8, 8, 4)):
     from saamge_amd import problems
     cb = [(8, 8, 4)] * (levels - 2)
-    return problems.poisson3d_device(n, blk=(8, 8, 4), coarse_blk=cb, K=(1.0, 1.0, aniso), device=dev)
+    return problems.poisson3d_device(n, blk=blk, coarse_blk=cb, K=(1.0, 1.0, aniso), device=dev)
 
 
 def one_step(capi, prob, params, rel_tol=1e-8, group=None):
@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--levels", type=int, default=3)
     ap.add_argument("--theta", type=float, default=0.003)
     ap.add_argument("--aniso", type=float, default=1.0, help="K = diag(1, 1, aniso) (BASELINE config 4: 1000)")
+    ap.add_argument("--blk", type=str, default="8,8,4", help="elements per AE along x,y,z (experiments)")
     ap.add_argument("--correct-nullspace", action="store_true",
                     help="extra scaling_P level under the coarsest spectral operator (reference drivers' default)")
     ap.add_argument("--nu-pro", type=int, default=0, help="prolongator smoothing degree (0 = tentative, the reference default)")
@@ -139,7 +140,7 @@ def main():
     grp = Group(backend=os.environ.get("SAAMGE_AMD_DIST_BACKEND", "nccl"), device=dev)
     world, rank = grp.world, grp.rank
 
-    prob = build_problem(args.n, args.levels, dev, args.aniso)
+    prob = build_problem(args.n, args.levels, dev, args.aniso, tuple(int(v) for v in args.blk.split(",")))
     torch.cuda.synchronize()
     params = capi.default_params(num_coarsenings=args.levels - 1, theta=args.theta, nu_relax=3, nu_pro=args.nu_pro,
                                  correct_nullspace=args.correct_nullspace)

@@ -597,6 +597,8 @@ __global__ __launch_bounds__(256) void sbr_panel_update_kernel(int k0, const int
 }
 
 constexpr int SF_ROWS = 64;   // one row per lane: 2 x 16 row operands + 16 accumulators in VGPRs
+// PROD = false: the update alone (no accumulators: fewer VGPRs, one more wavefront per SIMD)
+template <bool PROD>
 __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__restrict__ ns,
                                                           const int64_t *__restrict__ moff,
                                                           const int64_t *__restrict__ voff,
@@ -608,7 +610,7 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
                                                           const int64_t *__restrict__ goff,
                                                           double *__restrict__ Gbuf,
                                                           double *__restrict__ trashbuf, int count,
-                                                          int tiles) {
+                                                          int tiles, int shift) {
     constexpr int SBP = SB + 1;
     __shared__ double red[4 * SB * SF_ROWS];   // 32 KiB: K-split reduction
     __shared__ double xs[SF_ROWS * SBP], vs2[SF_ROWS * SBP];
@@ -617,14 +619,16 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
     if (b >= count) return;
     const int n = ns[b];
     if (n - k0 - SB < 2) return;               // this matrix has no panel k0
-    const int np = n - k0 - 2 * SB;            // order of A22' (may be < 2: update only)
+    // shift = SB: look-ahead pipeline, the first SB columns / rows were handled by
+    // sbr_panel_update_kernel; shift = 0: the whole trailing matrix of panel k0
+    const int np = n - k0 - SB - shift;        // order of A22' (may be < 2: update only)
     if (np < 1) return;
     const int i0 = blk * SF_ROWS;
     if (i0 >= np) return;
-    const bool prod = np >= 2;                 // the next panel has reflectors
-    double *A22 = Wm + moff[b] + (size_t)(k0 + 2 * SB) * n + (k0 + 2 * SB);
-    const double *__restrict__ Z = Zbuf + voff[b] * SB + SB * SB;     // rows shifted by SB
-    const double *__restrict__ Vc = Vcur + voff[b] * SB + SB * SB;
+    const bool prod = PROD && np >= 2;         // the next panel has reflectors
+    double *A22 = Wm + moff[b] + (size_t)(k0 + SB + shift) * n + (k0 + SB + shift);
+    const double *__restrict__ Z = Zbuf + voff[b] * SB + shift * SB;   // rows shifted
+    const double *__restrict__ Vc = Vcur + voff[b] * SB + shift * SB;
     const double *__restrict__ Vn = Vnext + voff[b] * SB;
     double *X = Xbuf + voff[b] * SB;
     const int tid = threadIdx.x;
@@ -643,42 +647,53 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
         va[c] = -Vc[(size_t)iac * SB + c];
         xa[c] = 0.0;
     }
-    for (int l0 = S2_KC * w; l0 < np; l0 += 4 * S2_KC) {
-        const int kn = min(S2_KC, np - l0);   // wave-uniform
-        if (kn == S2_KC) {
-            double ta[S2_KC];
+    // Column groups of S2_KC; the A-tile of the NEXT group is requested before the current one is
+    // worked on (double-buffered in registers), so its HBM round trip is covered by 8 x 48 FMAs.
+    int l0 = S2_KC * w;
+    double ta[S2_KC], tn[S2_KC];
+    if (l0 + S2_KC <= np) {
 #pragma unroll
-            for (int k = 0; k < S2_KC; ++k) ta[k] = pa[(size_t)(l0 + k) * sa];
+        for (int k = 0; k < S2_KC; ++k) ta[k] = pa[(size_t)(l0 + k) * sa];
+    }
+    for (; l0 + S2_KC <= np; l0 += 4 * S2_KC) {
+        const int l1 = l0 + 4 * S2_KC;
+        const bool more = l1 + S2_KC <= np;    // wave-uniform
+        if (more) {
 #pragma unroll
-            for (int k = 0; k < S2_KC; ++k) {
-                const double *zl = Z + (size_t)(l0 + k) * SB;    // wave-uniform: scalar loads
-                const double *vl = Vc + (size_t)(l0 + k) * SB;
-#pragma unroll
-                for (int c = 0; c < SB; ++c) ta[k] = fma(za[c], vl[c], fma(va[c], zl[c], ta[k]));
-                if (prod) {
-                    const double *vn = Vn + (size_t)(l0 + k) * SB;
-#pragma unroll
-                    for (int j = 0; j < SB; ++j) xa[j] = fma(ta[k], vn[j], xa[j]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int k = 0; k < S2_KC; ++k) pa[(size_t)(l0 + k) * sa] = ta[k];
-        } else {
-            for (int k = 0; k < kn; ++k) {
-                double t0 = pa[(size_t)(l0 + k) * sa];
-                const double *zl = Z + (size_t)(l0 + k) * SB;
-                const double *vl = Vc + (size_t)(l0 + k) * SB;
-#pragma unroll
-                for (int c = 0; c < SB; ++c) t0 = fma(za[c], vl[c], fma(va[c], zl[c], t0));
-                if (prod) {
-                    const double *vn = Vn + (size_t)(l0 + k) * SB;
-#pragma unroll
-                    for (int j = 0; j < SB; ++j) xa[j] = fma(t0, vn[j], xa[j]);
-                }
-                pa[(size_t)(l0 + k) * sa] = t0;
-            }
+            for (int k = 0; k < S2_KC; ++k) tn[k] = pa[(size_t)(l1 + k) * sa];
         }
+#pragma unroll
+        for (int k = 0; k < S2_KC; ++k) {
+            const double *zl = Z + (size_t)(l0 + k) * SB;    // wave-uniform: scalar loads
+            const double *vl = Vc + (size_t)(l0 + k) * SB;
+#pragma unroll
+            for (int c = 0; c < SB; ++c) ta[k] = fma(za[c], vl[c], fma(va[c], zl[c], ta[k]));
+            if (prod) {
+                const double *vn = Vn + (size_t)(l0 + k) * SB;
+#pragma unroll
+                for (int j = 0; j < SB; ++j) xa[j] = fma(ta[k], vn[j], xa[j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k = 0; k < S2_KC; ++k) pa[(size_t)(l0 + k) * sa] = ta[k];
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < S2_KC; ++k) ta[k] = tn[k];
+        }
+    }
+    for (; l0 < np; ++l0) {                   // the last, partial group
+        double t0 = pa[(size_t)l0 * sa];
+        const double *zl = Z + (size_t)l0 * SB;
+        const double *vl = Vc + (size_t)l0 * SB;
+#pragma unroll
+        for (int c = 0; c < SB; ++c) t0 = fma(za[c], vl[c], fma(va[c], zl[c], t0));
+        if (prod) {
+            const double *vn = Vn + (size_t)l0 * SB;
+#pragma unroll
+            for (int j = 0; j < SB; ++j) xa[j] = fma(t0, vn[j], xa[j]);
+        }
+        pa[(size_t)l0 * sa] = t0;
     }
     if (!prod) return;   // block-uniform
     // ---- X = sum of the four column splits; partial G = V^T X of this 64-row block ----
@@ -1252,9 +1267,9 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
             if (prof) { profiler().end(s, "eig_sbr_symm", first ? sbytes : 0.0, 0.0); profiler().begin(s); }
             launch_z(k0, b.Vpk.p);
             if (prof) { profiler().end(s, "eig_sbr_z", 0.0, 0.0); profiler().begin(s); }
-            hipLaunchKernelGGL(sbr_syr2k_kernel, dim3(cnt8 * div_up(npmax, S2_ROWS)), dim3(S2_NT), 0, s, k0,
-                               b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.Xbuf.p, b.count,
-                               div_up(npmax, S2_ROWS));
+            hipLaunchKernelGGL(sbr_fused_kernel<false>, dim3(cnt8 * div_up(npmax, SF_ROWS)), dim3(S2_NT), 0, s,
+                               k0, b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.Vpk.p, b.Xbuf.p,
+                               b.goff.p, b.Gbuf.p, b.trash.p, b.count, div_up(npmax, SF_ROWS), 0);
             if (prof) profiler().end(s, "eig_sbr_syr2k", first ? ubytes : 0.0, 0.0);
             first = false;
         }
@@ -1292,9 +1307,9 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
 #undef SA_FUSED
             }
             else if (npn >= 1)
-                hipLaunchKernelGGL(sbr_fused_kernel, dim3(cnt8 * div_up(npn, SF_ROWS)), dim3(S2_NT), 0, s,
+                hipLaunchKernelGGL(sbr_fused_kernel<true>, dim3(cnt8 * div_up(npn, SF_ROWS)), dim3(S2_NT), 0, s,
                                    k0, b.n.p, b.moff.p, b.voff.p, b.W.p, Vcur, b.Zbuf.p, Vnext, b.Xbuf.p,
-                                   b.goff.p, b.Gbuf.p, b.trash.p, b.count, div_up(npn, SF_ROWS));
+                                   b.goff.p, b.Gbuf.p, b.trash.p, b.count, div_up(npn, SF_ROWS), SB);
             if (prof) { profiler().end(s, "eig_sbr_fused", first ? fbytes : 0.0, 0.0); profiler().begin(s); }
             if (has_next) launch_z(k0 + SB, Vnext);
             if (prof) profiler().end(s, "eig_sbr_z", 0.0, 0.0);
