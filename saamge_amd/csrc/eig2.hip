@@ -439,24 +439,39 @@ __global__ __launch_bounds__(SM_NT) void sbr_z_kernel(int k0, const int *__restr
         Ss[a * SB + c] = s;
     }
     __syncthreads();
+    // V rows in / Z rows out are row-major (16 contiguous doubles per row): staged through LDS so that
+    // the global accesses of the workgroup are one contiguous block instead of 128-B strided per lane
+    __shared__ double stage[SM_NT * (SB + 1)];
+    const int nr = min(SM_NT, np - r0);
+    for (int idx = tid; idx < nr * SB; idx += SM_NT) stage[(idx >> 4) * (SB + 1) + (idx & 15)] = Vp[(size_t)r0 * SB + idx];
+    __syncthreads();
     const int r = r0 + tid;
-    if (r >= np) return;
-    double x[SB], v[SB];
+    double x[SB], v[SB], z[SB];
+    if (r < np) {
 #pragma unroll
-    for (int j = 0; j < SB; ++j) {
-        x[j] = X[(size_t)j * n + r];
-        v[j] = Vp[(size_t)r * SB + j];
+        for (int j = 0; j < SB; ++j) {
+            x[j] = X[(size_t)j * n + r];
+            v[j] = stage[tid * (SB + 1) + j];
+        }
+#pragma unroll
+        for (int c = 0; c < SB; ++c) {
+            double y = 0.0, s = 0.0;
+#pragma unroll
+            for (int j = 0; j <= c; ++j) y = fma(x[j], Ts[c * SB + j], y);
+#pragma unroll
+            for (int a = 0; a < SB; ++a) s = fma(v[a], Ss[a * SB + c], s);
+            z[c] = fma(-0.5, s, y);
+        }
     }
+    __syncthreads();
+    if (r < np) {
 #pragma unroll
-    for (int c = 0; c < SB; ++c) {
-        double y = 0.0, s = 0.0;
-#pragma unroll
-        for (int j = 0; j <= c; ++j) y = fma(x[j], Ts[c * SB + j], y);
-#pragma unroll
-        for (int a = 0; a < SB; ++a) s = fma(v[a], Ss[a * SB + c], s);
-        Z[(size_t)r * SB + c] = fma(-0.5, s, y);
+        for (int c = 0; c < SB; ++c) stage[tid * (SB + 1) + c] = z[c];
     }
+    __syncthreads();
+    for (int idx = tid; idx < nr * SB; idx += SM_NT) Z[(size_t)r0 * SB + idx] = stage[(idx >> 4) * (SB + 1) + (idx & 15)];
 }
+
 
 // A22 -= Z V^T + V Z^T (both triangles: the mat-vec product reads full rows).  One workgroup
 // per (128-row strip, matrix).  Lane = two rows of the strip (lane, lane + 64): its Z/V rows stay
@@ -595,6 +610,7 @@ __global__ __launch_bounds__(256) void sbr_panel_update_kernel(int k0, const int
         A22[(size_t)c * n + r] = t;
     }
 }
+
 
 constexpr int SF_ROWS = 64;   // one row per lane: 2 x 16 row operands + 16 accumulators in VGPRs
 // PROD = false: the update alone (no accumulators: fewer VGPRs, one more wavefront per SIMD)
