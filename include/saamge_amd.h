@@ -108,6 +108,12 @@ int saamge_amd_ml_produce_data(int n, const int *rowptr, const int *col, const d
                                const signed char *bdr_dofs, const int *const *partitions,
                                const int *nparts, const saamge_amd_params *params, void *stream,
                                saamge_amd_hierarchy **out);
+/* adapt_update_operators(A, ml_data, mlp, resmooth_interp = true), src/adapt.cpp:188-219: the
+ * matrix values changed (same sparsity and topology): every interpolation is kept -- no local
+ * eigenproblem is solved again --, smoother diagonals, smoothed prolongators (nu_pro > 0), all
+ * Galerkin operators and the coarsest solver are rebuilt.  new_val: nnz(A) values in the order
+ * given at setup (host or device); NULL if the caller changed its device array in place. */
+int saamge_amd_update_operators(saamge_amd_hierarchy *h, const double *new_val);
 /* ml_free_data, inc/ml.hpp:196 */
 void saamge_amd_ml_free_data(saamge_amd_hierarchy *h);
 

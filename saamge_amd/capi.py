@@ -22,6 +22,7 @@ SYMBOLS = [
     "saamge_amd_get_mis", "saamge_amd_get_ae_eigens", "saamge_amd_get_mis_svd", "saamge_amd_spmv",
     "saamge_amd_lower_eigens_batched", "saamge_amd_profile_enable", "saamge_amd_profile_reset",
     "saamge_amd_profile_count", "saamge_amd_profile_get", "saamge_amd_memcpy",
+    "saamge_amd_update_operators",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong))
@@ -203,6 +204,12 @@ class Hierarchy(object):
         nparts = [int(p.max()) + 1 for p in parts]
         return cls(rowptr, col, val, A.shape[0], None, None, None, parts, nparts, params, A.shape[0], 1,
                    stream, group)
+
+    def update_operators(self, new_val=None):
+        """adapt_update_operators: new matrix values (same pattern), interpolations kept."""
+        if new_val is not None:
+            new_val = np.ascontiguousarray(new_val, dtype=np.float64) if not hasattr(new_val, "data_ptr") else new_val
+        _check(load().saamge_amd_update_operators(self.h, _ptr(new_val)))
 
     def close(self):
         if self.h:

@@ -111,6 +111,13 @@ int saamge_amd_ml_produce_data(int n, const int *rowptr, const int *col, const d
     SA_API_END
 }
 
+int saamge_amd_update_operators(saamge_amd_hierarchy *h, const double *new_val) {
+    SA_API_BEGIN
+    SA_REQUIRE(h, "null argument");
+    hierarchy_update_operators(*h->H, new_val);
+    SA_API_END
+}
+
 void saamge_amd_ml_free_data(saamge_amd_hierarchy *h) {
     if (!h) return;
     delete h->H;

@@ -115,6 +115,10 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
                             const signed char *bdr, const int *const *partitions,
                             const int *nparts, const Params &p, hipStream_t stream);
 
+// adapt_update_operators (amg/src/adapt.cpp:171-219): new matrix values (same pattern; host or
+// device pointer, nullptr = the level-0 values were changed in place), all interpolations kept.
+void hierarchy_update_operators(Hierarchy &h, const double *new_val);
+
 // VCycleSolver::Mult with iterative_mode = false (amg/src/solve.cpp:309-323): x = B b.
 void vcycle_apply(Hierarchy &h, int level, const double *b, double *x);
 // smpr_sym_poly (amg/src/smpr.cpp:213-234): x += M^-1 (b - A x)

@@ -84,6 +84,49 @@ __global__ void fill_kernel(long n, double *p, double v) {
 // ---------------------------------------------------------------------------------------
 // one coarsening: tg_init_data + tg_build_hierarchy + tg_update_coarse_operator
 // ---------------------------------------------------------------------------------------
+// P (smoothed when nu_pro > 0), R and Ac = R A P of level `lev` from its tentative prolongator
+// (tg_smooth_interp + tg_coarse_matr, amg/inc/tg.hpp:679-709).  `first`: P / R still hold the
+// tentative pair just built; otherwise (operator update) the stored tentative one is re-smoothed.
+static void level_galerkin(Hierarchy &H, int lev, bool first) {
+    Level &L = *H.levels[lev];
+    const Params &P = H.params;
+    const Relations &rel = L.rel;
+    hipStream_t s = H.stream;
+    const int world = P.world > 1 ? P.world : 1;
+    if (P.nu_pro[lev] == 0) {
+        std::vector<long long> nnz_off;
+        rap_mis(s, L.drel, rel, L.A, L.mis_k, L.mis_coloff, L.d_mis_k.p, L.d_mis_coloff.p,
+                L.d_mis_u_off.p, L.mis_U.p, L.Ac, P.rank, world, world > 1 ? &nnz_off : nullptr);
+        if (world > 1 && L.Ac.nnz > 0) {   // every rank computed the row blocks of its MIS range
+            std::vector<long long> off((size_t)world + 1);
+            for (int r = 0; r <= world; ++r) off[r] = 4ll * nnz_off[r];
+            SA_REQUIRE(P.allgather(P.allgather_ctx, L.Ac.col.p, off.data()) == 0, "all-gather (Ac columns) failed");
+            for (int r = 0; r <= world; ++r) off[r] = 8ll * nnz_off[r];
+            SA_REQUIRE(P.allgather(P.allgather_ctx, L.Ac.val.p, off.data()) == 0, "all-gather (Ac values) failed");
+        }
+    } else {
+        // interp_smooth (amg/src/interp.cpp:172-229): P = prod_k (I + (1/tau_k) Dinv_neg A) P_tent with
+        // tau_k = sin^2(k pi / (2 nu + 1)) (smpr_sa_poly_roots, amg/src/smpr.cpp:266-280); then
+        // R = P^T and Ac = R A P (mfem::RAP, amg/inc/tg.hpp:696-709) as general sparse products.
+        const int nu = P.nu_pro[lev];
+        if (first) L.Ptent = std::move(L.P);
+        DCsr tmp[2];
+        const DCsr *cur = &L.Ptent;
+        for (int k = 1; k <= nu; ++k) {
+            const double sn = std::sin((double)k * M_PI / (double)(2 * nu + 1));
+            DCsr &dst = tmp[k & 1];
+            dst = DCsr();
+            spgemm(s, L.A, *cur, cur, L.dinv_neg.p, 1.0 / (sn * sn), 1.0, dst);
+            cur = &dst;
+        }
+        L.P = std::move(tmp[nu & 1]);
+        csr_transpose(s, L.P, L.R);
+        DCsr AP;
+        spgemm(s, L.A, L.P, nullptr, nullptr, 1.0, 0.0, AP);
+        spgemm(s, L.R, AP, nullptr, nullptr, 1.0, 0.0, L.Ac);
+    }
+}
+
 struct DeviceInputs {   // level-0 inputs that already live on the device (see hierarchy_create)
     const int *e2d = nullptr, *part = nullptr;
     const signed char *bdr = nullptr;
@@ -369,38 +412,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     L.d_mis_coloff.from_host(L.mis_coloff, s);
     build_P_R(s, L.drel, rel, L.mis_k, L.mis_u_off, L.d_mis_k.p, L.d_mis_coloff.p, L.d_mis_u_off.p,
               L.mis_U.p, L.P, L.R);
-    if (P.nu_pro[lev] == 0) {
-        std::vector<long long> nnz_off;
-        rap_mis(s, L.drel, rel, L.A, L.mis_k, L.mis_coloff, L.d_mis_k.p, L.d_mis_coloff.p,
-                L.d_mis_u_off.p, L.mis_U.p, L.Ac, P.rank, world, world > 1 ? &nnz_off : nullptr);
-        if (world > 1 && L.Ac.nnz > 0) {   // every rank computed the row blocks of its MIS range
-            std::vector<long long> off((size_t)world + 1);
-            for (int r = 0; r <= world; ++r) off[r] = 4ll * nnz_off[r];
-            SA_REQUIRE(P.allgather(P.allgather_ctx, L.Ac.col.p, off.data()) == 0, "all-gather (Ac columns) failed");
-            for (int r = 0; r <= world; ++r) off[r] = 8ll * nnz_off[r];
-            SA_REQUIRE(P.allgather(P.allgather_ctx, L.Ac.val.p, off.data()) == 0, "all-gather (Ac values) failed");
-        }
-    } else {
-        // interp_smooth (amg/src/interp.cpp:172-229): P = prod_k (I + (1/tau_k) Dinv_neg A) P_tent with
-        // tau_k = sin^2(k pi / (2 nu + 1)) (smpr_sa_poly_roots, amg/src/smpr.cpp:266-280); then
-        // R = P^T and Ac = R A P (mfem::RAP, amg/inc/tg.hpp:696-709) as general sparse products.
-        const int nu = P.nu_pro[lev];
-        L.Ptent = std::move(L.P);
-        DCsr tmp[2];
-        const DCsr *cur = &L.Ptent;
-        for (int k = 1; k <= nu; ++k) {
-            const double sn = std::sin((double)k * M_PI / (double)(2 * nu + 1));
-            DCsr &dst = tmp[k & 1];
-            dst = DCsr();
-            spgemm(s, L.A, *cur, cur, L.dinv_neg.p, 1.0 / (sn * sn), 1.0, dst);
-            cur = &dst;
-        }
-        L.P = std::move(tmp[nu & 1]);
-        csr_transpose(s, L.P, L.R);
-        DCsr AP;
-        spgemm(s, L.A, L.P, nullptr, nullptr, 1.0, 0.0, AP);
-        spgemm(s, L.R, AP, nullptr, nullptr, 1.0, 0.0, L.Ac);
-    }
+    level_galerkin(H, lev, true);
     tm.lap("P, R, RAP", lev);
     if (!P.keep_debug) {
         L.evals.release();
@@ -956,6 +968,52 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
     }
     tm_all.lap("TOTAL ml_produce_data", 0);
     return Hp.release();
+}
+
+// adapt_update_operators (amg/src/adapt.cpp:171-219): the matrix changed (same sparsity, same
+// topology): keep every interpolation (the eigenproblems are NOT solved again), refresh the
+// smoother diagonals, re-smooth P where nu_pro > 0, rebuild all Galerkin operators and the coarsest
+// solver.
+void hierarchy_update_operators(Hierarchy &H, const double *new_val) {
+    hipStream_t s = H.stream;
+    const int nspec = H.params.num_coarsenings;
+    Level &L0 = *H.levels[0];
+    if (new_val && new_val != L0.A.val.p) {
+        if (is_device_ptr(new_val)) {
+            L0.A.val.view(const_cast<double *>(new_val), (size_t)L0.A.nnz);   // device arrays are used in place
+        } else {
+            if (!L0.A.val.owned) L0.A.val.alloc((size_t)L0.A.nnz);           // never write into the caller's array
+            SA_HIP_CHECK(hipMemcpyAsync(L0.A.val.p, new_val, sizeof(double) * (size_t)L0.A.nnz,
+                                        hipMemcpyHostToDevice, s));
+            SA_HIP_CHECK(hipStreamSynchronize(s));
+        }
+    }
+    for (int lev = 0; lev < nspec; ++lev) {
+        Level &L = *H.levels[lev];
+        build_sell(s, L.A);
+        {
+            DBuf<double> tmp((size_t)L.A.nrows);
+            build_dinv_neg(s, L.A, tmp.p, L.dinv_neg.p);
+            SA_HIP_CHECK(hipStreamSynchronize(s));
+        }
+        L.Ac = DCsr();
+        level_galerkin(H, lev, false);
+        if (lev + 1 < (int)H.levels.size()) H.levels[lev + 1]->A = std::move(L.Ac);
+    }
+    if (H.params.correct_nullspace) {   // the scaling_P level: same interpolation, new operators
+        Level &N = *H.levels.back();
+        build_sell(s, N.A);
+        DBuf<double> tmp((size_t)N.A.nrows);
+        build_dinv_neg(s, N.A, tmp.p, N.dinv_neg.p);
+        SA_HIP_CHECK(hipStreamSynchronize(s));
+        DCsr AP;
+        spgemm(s, N.A, N.P, nullptr, nullptr, 1.0, 0.0, AP);
+        N.Ac = DCsr();
+        spgemm(s, N.R, AP, nullptr, nullptr, 1.0, 0.0, N.Ac);
+    }
+    H.c_L.release();
+    setup_coarse_solver(H);
+    SA_HIP_CHECK(hipStreamSynchronize(s));
 }
 
 }  // namespace saamge_amd
