@@ -31,8 +31,7 @@ struct MultilevelParameters {
                          int nu_relax, double first_theta, double theta,
                          bool use_correct_nullspace = false, bool use_arpack = false) {
         saamge_amd_params_default(&p);
-        if (use_correct_nullspace)
-            throw std::invalid_argument("corrected null-space coarsest level is not part of this build");
+        p.correct_nullspace = use_correct_nullspace ? 1 : 0;   // CorrectNullspace on scaling_P (src/ml.cpp:225-236)
         (void)use_arpack;  // the direct (dense) eigensolver path is always taken
         p.num_coarsenings = coarsenings;
         nparts.assign(nparts_arr, nparts_arr + coarsenings);
@@ -43,6 +42,12 @@ struct MultilevelParameters {
         }
     }
     int get_num_coarsenings() const { return p.num_coarsenings; }
+    bool get_use_correct_nullspace() const { return p.correct_nullspace != 0; }
+    // polynomial / rigid-body coarse-space extension (ContribTent::ExtendWithPolynomials / RBMs): the
+    // modes are evaluated by the caller, n x count column-major
+    void set_extra_coarse_modes(const double *modes, int count) { p.extra_modes = modes; p.num_extra_modes = count; }
+    // element-free mode (tg_produce_data_algebraic): pass NE = n, nde = 1 and NULL element arrays
+    void set_algebraic(bool on) { p.algebraic = on ? 1 : 0; }
 };
 
 // Raw-array view of the reference's setup inputs (HypreParMatrix Ag, elem_to_dof Table,
@@ -71,6 +76,10 @@ inline ml_data_t *ml_produce_data(const ProblemArrays &a, const MultilevelParame
 }
 // ml_free_data (inc/ml.hpp:196)
 inline void ml_free_data(ml_data_t *h) { saamge_amd_ml_free_data(h); }
+// adapt_update_operators (inc/adapt.hpp, src/adapt.cpp:188-219): new matrix values, same pattern
+inline void adapt_update_operators(ml_data_t *h, const double *new_values) {
+    if (saamge_amd_update_operators(h, new_values)) throw std::runtime_error(saamge_amd_last_error());
+}
 
 // VCycleSolver (inc/solve.hpp:129-143): Mult zeroes x (iterative_mode = false).
 class VCycleSolver {
