@@ -1130,21 +1130,32 @@ __global__ __launch_bounds__(NT) void backtransform2_kernel(
         __syncthreads();
         for (int i = tid; i < n; i += NT) y[i] = Yj[i];
         __syncthreads();
-        // Q2: sweeps in reverse order
+        // Q2: sweeps in reverse order.  The reflector of the NEXT sweep (global memory) is requested
+        // before the current one is applied: otherwise every sweep pays a full memory round trip
+        // between two barriers (403 of them at n = 405).
+        double tau_n = 0.0, vr_n = 0.0;
+        if (n >= 3) {
+            const int s = n - 3;
+            if (grp < chase_steps(n, s)) {
+                tau_n = RT[cum[s] + grp];
+                vr_n = RV[(size_t)(cum[s] + grp) * SB + r];
+            }
+        }
         for (int s = n - 3; s >= 0; --s) {
             const int nst = chase_steps(n, s);
             const int base = cum[s];
+            const double tau_c = tau_n, vr_c = vr_n;
+            if (s > 0 && grp < chase_steps(n, s - 1)) {
+                tau_n = RT[cum[s - 1] + grp];
+                vr_n = RV[(size_t)(cum[s - 1] + grp) * SB + r];
+            }
             for (int q = grp; q < nst; q += NGRP) {
                 const int i0 = s + 1 + q * SB;
                 const bool act = (i0 + r < n);
-                const double tau = RT[base + q];
-                const double vr = act ? RV[(size_t)(base + q) * SB + r] : 0.0;
+                const double tau = (q == grp) ? tau_c : RT[base + q];
+                const double vr = act ? ((q == grp) ? vr_c : RV[(size_t)(base + q) * SB + r]) : 0.0;
                 const double yr = act ? y[i0 + r] : 0.0;
-                double dot = vr * yr;
-                dot += __shfl_xor(dot, 1, 64);
-                dot += __shfl_xor(dot, 2, 64);
-                dot += __shfl_xor(dot, 4, 64);
-                dot += __shfl_xor(dot, 8, 64);
+                const double dot = rsum16(vr * yr);
                 if (act && tau != 0.0) y[i0 + r] = fma(-tau * dot, vr, yr);
             }
             __syncthreads();
