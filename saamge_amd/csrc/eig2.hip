@@ -35,6 +35,28 @@ __device__ inline double gsum16(double v) {   // sum inside each 16-lane group
     return v;
 }
 
+// Reciprocal and square root to ~1 ulp from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~2^-24)
+// plus Newton steps: the IEEE-exact sequences cost 25-30 instructions each, and the reflector
+// construction sits on the serial critical path of the panel QR and of every chase step.
+// Arguments are O(1) entries of scaled matrices (no denormals, no overflow).
+__device__ inline double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ inline double fast_sqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    return fma(fma(-g, g, x), h, g);
+}
+
 __device__ inline double wsum64(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -45,8 +67,9 @@ __device__ inline double wsum64(double v) {
 template <int CTRL>
 __device__ inline double dpp_rot(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    // (row rotations read a valid lane everywhere: no "old" value, so no register to initialise)
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 __device__ inline double rsum16(double v) {
@@ -144,9 +167,9 @@ __global__ __launch_bounds__(NT) void sbr_qr_kernel(int k0, const int *__restric
         ss = bsum<NT>(ss, red);
         double tau = 0.0, beta = alpha, scale = 0.0;
         if (ss != 0.0) {
-            beta = -copysign(sqrt(fma(alpha, alpha, ss)), alpha);
-            tau = (beta - alpha) / beta;
-            scale = 1.0 / (alpha - beta);
+            beta = -copysign(fast_sqrt(fma(alpha, alpha, ss)), alpha);
+            tau = (beta - alpha) * fast_rcp(beta);
+            scale = fast_rcp(alpha - beta);
         }
         for (int i = c + 1 + tid; i < np; i += NT) pc[i] *= scale;
         if (tid == 0) pc[c] = beta;
@@ -244,9 +267,9 @@ __global__ __launch_bounds__(256) void sbr_qr_reg_kernel(int k0, const int *__re
         const double alpha = salpha;
         double tau = 0.0, beta = alpha, scale = 0.0;
         if (ss != 0.0) {
-            beta = -copysign(sqrt(fma(alpha, alpha, ss)), alpha);
-            tau = (beta - alpha) / beta;
-            scale = 1.0 / (alpha - beta);
+            beta = -copysign(fast_sqrt(fma(alpha, alpha, ss)), alpha);
+            tau = (beta - alpha) * fast_rcp(beta);
+            scale = fast_rcp(alpha - beta);
         }
         // v entries of my rows (v_c = 1 on row c, 0 above)
         double v0 = (r0 > c) ? p0[c] * scale : ((r0 == c) ? 1.0 : 0.0);
@@ -901,8 +924,9 @@ __device__ __host__ inline int chase_steps(int n, int s) { return (n - 1 - s + S
 
 struct BandRef {
     double *p;
-    __device__ inline double &operator()(int i, int j) const { return p[(size_t)j * LDB + (i - j)]; }
-    __device__ inline double sym(int i, int j) const { return i >= j ? p[(size_t)j * LDB + (i - j)] : p[(size_t)i * LDB + (j - i)]; }
+    // (int index: j * LDB + i - j < 2^31 for any admissible n)
+    __device__ inline double &operator()(int i, int j) const { return p[j * (LDB - 1) + i]; }
+    __device__ inline double sym(int i, int j) const { return i >= j ? p[j * (LDB - 1) + i] : p[i * (LDB - 1) + j]; }
 };
 
 __device__ inline void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
@@ -929,9 +953,9 @@ __device__ inline void chase_step(const BandRef &B, int n, int s, int q, double 
         const double alpha = sx[0];
         double beta = alpha, scale = 0.0;
         if (ss != 0.0 && L >= 2) {
-            beta = -copysign(sqrt(fma(alpha, alpha, ss)), alpha);
-            tau = (beta - alpha) / beta;
-            scale = 1.0 / (alpha - beta);
+            beta = -copysign(fast_sqrt(fma(alpha, alpha, ss)), alpha);
+            tau = (beta - alpha) * fast_rcp(beta);
+            scale = fast_rcp(alpha - beta);
         }
         vr = (r == 0) ? 1.0 : x * scale;
         if (r >= L) vr = 0.0;
@@ -961,9 +985,9 @@ __device__ inline void chase_step(const BandRef &B, int n, int s, int q, double 
         const double ss = rsum16((r >= 1 && r < L) ? x * x : 0.0);
         double beta = alpha, scale = 0.0;
         if (ss != 0.0 && L >= 2) {
-            beta = -copysign(sqrt(fma(alpha, alpha, ss)), alpha);
-            tau = (beta - alpha) / beta;
-            scale = 1.0 / (alpha - beta);
+            beta = -copysign(fast_sqrt(fma(alpha, alpha, ss)), alpha);
+            tau = (beta - alpha) * fast_rcp(beta);
+            scale = fast_rcp(alpha - beta);
         }
         vr = (r == 0) ? 1.0 : x * scale;
         if (r >= L) vr = 0.0;
@@ -1017,6 +1041,11 @@ __device__ inline void chase_step(const BandRef &B, int n, int s, int q, double 
     if (lane == 0) vprev[SB] = tau;
 }
 
+// IN_LDS: the band lives in LDS.  A compile-time switch, so that every band access is a 32-bit
+// ds_read / ds_write; with a run-time choice of the base pointer the accesses become FLAT
+// instructions with 64-bit address arithmetic (the kernel is bound by instruction issue:
+// ~400 vector instructions per chase step before this split).
+template <bool IN_LDS>
 __global__ __launch_bounds__(CH_NT) void band_chase_kernel(
     const int *__restrict__ ns, const int64_t *__restrict__ moff, const int64_t *__restrict__ voff,
     const int64_t *__restrict__ roff, const double *__restrict__ Wm, double *__restrict__ bandg,
@@ -1036,7 +1065,7 @@ __global__ __launch_bounds__(CH_NT) void band_chase_kernel(
     int *cum = (int *)(hand + CH_NW * HAND);
     double *bandl = (double *)(cum + ((n + 2 + 1) & ~1));
     BandRef B;
-    B.p = band_in_lds ? bandl : (bandg + vo * LDB);
+    B.p = IN_LDS ? bandl : (bandg + vo * LDB);
     // load the band (zero beyond it) -- A holds it in its lower triangle
     for (int idx = tid; idx < n * LDB; idx += CH_NT) {
         const int j = idx / LDB, t = idx % LDB;
@@ -1203,7 +1232,9 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
     if (!b.count) return;
     static bool attr = false;
     if (!attr) {
-        SA_HIP_CHECK(hipFuncSetAttribute((const void *)band_chase_kernel,
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)band_chase_kernel<true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)band_chase_kernel<false>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SA_HIP_CHECK(hipFuncSetAttribute((const void *)backtransform2_kernel<256>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1355,9 +1386,12 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
     double cflops = 0.0;
     for (int n : b.h_n) cflops += 6.0 * (double)n * n * SB;
     profiler().begin(s);
-    hipLaunchKernelGGL(band_chase_kernel, dim3(b.count), dim3(CH_NT), fixed + (in_lds ? band_bytes : 0) + 64,
-                       s, b.n.p, b.moff.p, b.voff.p, b.roff.p, b.W.p, b.bandg.p, in_lds, b.d.p, b.e.p,
-                       b.rv.p, b.rtau.p);
+    if (in_lds)
+        hipLaunchKernelGGL(band_chase_kernel<true>, dim3(b.count), dim3(CH_NT), fixed + band_bytes + 64, s, b.n.p,
+                           b.moff.p, b.voff.p, b.roff.p, b.W.p, b.bandg.p, in_lds, b.d.p, b.e.p, b.rv.p, b.rtau.p);
+    else
+        hipLaunchKernelGGL(band_chase_kernel<false>, dim3(b.count), dim3(CH_NT), fixed + 64, s, b.n.p, b.moff.p,
+                           b.voff.p, b.roff.p, b.W.p, b.bandg.p, in_lds, b.d.p, b.e.p, b.rv.p, b.rtau.p);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "eig_band_chase", 0.0, cflops);
 }
