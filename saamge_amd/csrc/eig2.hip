@@ -1060,10 +1060,12 @@ __global__ __launch_bounds__(CH_NT) void band_chase_kernel(
     double *RV = rv + roff[b] * SB;
     double *RT = rtau + roff[b];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // LDS: per-wave reflector hand-off [CH_NW][SB+1], cum[n+1] ints, then (optionally) the band
+    // LDS: per-wave reflector hand-off [CH_NW][HAND], cum[n+1] and start[n] ints, then
+    // (optionally) the band
     double *hand = lds;
     int *cum = (int *)(hand + CH_NW * HAND);
-    double *bandl = (double *)(cum + ((n + 2 + 1) & ~1));
+    int *start = cum + n + 1;
+    double *bandl = (double *)(cum + 2 * n + 2);
     BandRef B;
     B.p = IN_LDS ? bandl : (bandg + vo * LDB);
     // load the band (zero beyond it) -- A holds it in its lower triangle
@@ -1072,35 +1074,36 @@ __global__ __launch_bounds__(CH_NT) void band_chase_kernel(
         const int i = j + t;
         B.p[idx] = (t <= SB && i < n) ? A[(size_t)j * n + i] : 0.0;
     }
+    // Schedule: step q of sweep s runs at time start[s] + q, wavefront s mod CH_NW.  Sweep
+    // s + 1 must stay two steps behind sweep s (its block q overlaps blocks q, q + 1 of s), and
+    // a wavefront must have finished sweep s - CH_NW.  The sweeps get shorter, so the spacing
+    // drops to the minimum of 2 once CH_NW sweeps in flight cover a whole sweep.
     if (tid == 0) {
         int run = 0;
         for (int s = 0; s < n; ++s) {
             cum[s] = run;
             if (s <= n - 3) run += chase_steps(n, s);
+            int st = (s == 0) ? 0 : start[s - 1] + 2;
+            if (s >= CH_NW) st = max(st, start[s - CH_NW] + chase_steps(n, s - CH_NW));
+            start[s] = st;
         }
         cum[n] = run;
     }
     __syncthreads();
     if (n >= 3) {
         const int nsweeps = n - 2;
-        const int maxsteps = chase_steps(n, 0);
-        int G = (maxsteps + 1 + CH_NW - 1) / CH_NW;
-        if (G < 2) G = 2;
-        const int tend = (nsweeps - 1) * G + maxsteps;
+        const int tend = start[nsweeps - 1] + chase_steps(n, nsweeps - 1);
         double *myhand = hand + wave * HAND;
+        int s = wave;                               // the sweep this wavefront works on
+        int s_begin = 0, s_end = 0;
+        if (s < nsweeps) { s_begin = start[s]; s_end = s_begin + chase_steps(n, s); }
         for (int t = 0; t < tend; ++t) {
-            // the sweep of this wavefront that is active at time t (at most one)
-            int s = -1, q = 0;
-            {
-                // sweeps s = wave + k*CH_NW start at time G*s
-                const int smax = min(nsweeps - 1, t / G);
-                if (smax >= wave) {
-                    const int sc = smax - ((smax - wave) % CH_NW);  // largest s <= smax, s == wave mod NW
-                    const int qq = t - G * sc;
-                    if (qq < chase_steps(n, sc)) { s = sc; q = qq; }
-                }
+            if (s < nsweeps && t >= s_end) {
+                s += CH_NW;
+                if (s < nsweeps) { s_begin = start[s]; s_end = s_begin + chase_steps(n, s); }
             }
-            if (s >= 0) {
+            if (s < nsweeps && t >= s_begin) {
+                const int q = t - s_begin;
                 const int rid = cum[s] + q;
                 chase_step(B, n, s, q, myhand, RV + (size_t)rid * SB, RT + rid, lane);
             }
@@ -1250,7 +1253,7 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
     for (int i = 0; i < b.count; ++i) b.h_roff[i + 1] = b.h_roff[i] + chase_reflector_count(b.h_n[i]);
     const size_t nrefl = (size_t)b.h_roff[b.count];
     const int nmax0 = b.max_n;
-    const size_t fixed0 = sizeof(double) * (CH_NW * HAND) + sizeof(int) * ((size_t)nmax0 + 4);
+    const size_t fixed0 = sizeof(double) * (CH_NW * HAND) + sizeof(int) * (2 * (size_t)nmax0 + 4);
     const bool in_lds0 = fixed0 + sizeof(double) * (size_t)nmax0 * LDB + 64 <= 160 * 1024;
     b.h_goff.assign((size_t)b.count + 1, 0);
     for (int i = 0; i < b.count; ++i)
@@ -1380,7 +1383,7 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
     }
     if (!(phases & 2)) return;
     // ---- stage 2 ----
-    const size_t fixed = sizeof(double) * (CH_NW * HAND) + sizeof(int) * ((size_t)nmax + 4);
+    const size_t fixed = sizeof(double) * (CH_NW * HAND) + sizeof(int) * (2 * (size_t)nmax + 4);
     const size_t band_bytes = sizeof(double) * (size_t)nmax * LDB;
     const int in_lds = (fixed + band_bytes + 64 <= 160 * 1024) ? 1 : 0;
     double cflops = 0.0;
