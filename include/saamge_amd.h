@@ -81,8 +81,14 @@ typedef struct saamge_amd_params {
     /* Element-free mode (tg_produce_data_algebraic / ExtractSubMatrices, src/tg.cpp:579-672,
      * :862-886): elements are the dofs, partitions[0] maps DOFS to (non-overlapping) AEs, the AE
      * matrices are principal submatrices of A made rowsum-free; pass NE = n, nde = 1,
-     * elem_to_dof = elmat = bdr_dofs = NULL. */
+     * elem_to_dof = elmat = bdr_dofs = NULL.  1 = ExtractSubMatrices; 2 = WindowSubMatrices
+     * (src/tg.cpp:741-858, `use_window`): A_TT + A_TX E, outside neighbours replaced by the
+     * row-weighted average of the inside ones. */
     int algebraic;
+    /* MultilevelParameters::smooth_drop_tol (inc/ml.hpp:93-113; interp_smooth -> AltThreshold,
+     * src/interp.cpp:89-229): entries of the SMOOTHED prolongator (nu_pro > 0) with
+     * |value| <= tol are dropped before R = P^T and Ac = RAP.  0 = keep everything. */
+    double smooth_drop_tol;
 } saamge_amd_params;
 
 void saamge_amd_params_default(saamge_amd_params *p);

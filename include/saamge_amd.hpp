@@ -47,7 +47,9 @@ struct MultilevelParameters {
     // modes are evaluated by the caller, n x count column-major
     void set_extra_coarse_modes(const double *modes, int count) { p.extra_modes = modes; p.num_extra_modes = count; }
     // element-free mode (tg_produce_data_algebraic): pass NE = n, nde = 1 and NULL element arrays
-    void set_algebraic(bool on) { p.algebraic = on ? 1 : 0; }
+    void set_algebraic(bool on, bool use_window = false) { p.algebraic = on ? (use_window ? 2 : 1) : 0; }
+    double get_smooth_drop_tol() const { return p.smooth_drop_tol; }
+    void set_smooth_drop_tol(double tol) { p.smooth_drop_tol = tol; }
 };
 
 // Raw-array view of the reference's setup inputs (HypreParMatrix Ag, elem_to_dof Table,

@@ -220,6 +220,46 @@ def build_AE_stiffm_algebraic(A, part, rel):
     return out
 
 
+def build_AE_stiffm_window(A, part, rel):
+    """WindowSubMatrices (src/tg.cpp:741-858): A_TT + A_TX E for the AE's dof set T and its
+    outside neighbours X, with the extension E[x, i] = a_ix / sum_{k in T} a_xk (every outside
+    value is replaced by that weighted average of the inside ones); a single-dof AE is [1]."""
+    dofs = rel.AE_to_dof.row(part)
+    n = dofs.size
+    if n == 1:
+        return np.ones((1, 1))
+    loc = rel.loc_in_AE[part]
+    indptr, indices, data = A.indptr, A.indices, A.data
+    denom, xnum = {}, {}
+    for i in range(n):
+        g = int(dofs[i])
+        for k in range(indptr[g], indptr[g + 1]):
+            x = int(indices[k])
+            if x in denom or x in loc:
+                continue
+            value = 0.0
+            for kk in range(indptr[x], indptr[x + 1]):
+                if int(indices[kk]) in loc:
+                    value += data[kk]
+            assert abs(value) > 0.0
+            denom[x] = value
+            xnum[x] = len(xnum)
+    nx = len(xnum)
+    ext = np.zeros((nx, n))
+    ATX = np.zeros((n, nx))
+    ATT = np.zeros((n, n))
+    for i in range(n):
+        g = int(dofs[i])
+        for k in range(indptr[g], indptr[g + 1]):
+            x = int(indices[k])
+            if x in denom:
+                ATX[i, xnum[x]] += data[k]
+                ext[xnum[x], i] += data[k] / denom[x]
+            else:
+                ATT[i, loc[x]] += data[k]
+    return ATT + (ATX @ ext if nx else 0.0)
+
+
 def coarse_element_matrix(e, rel_f, rel_c, level_f):
     """ElementMatrixParallelCoarse::GetMatrix (src/elmat.cpp:105-195):
     P_loc^T * AEs_stiffm[e] * P_loc with P_loc built from mis_tent_interps."""
@@ -447,13 +487,18 @@ def compute_poly(A, b, x, roots, Dinv_neg):
     return x
 
 
-def interp_smooth(A, tent, Dinv_neg, nu_pro):
-    """interp_smooth (src/interp.cpp:172-229): P = prod_k (I + (1/tau_k) Dinv_neg A) tent."""
+def interp_smooth(A, tent, Dinv_neg, nu_pro, drop_tol=0.0):
+    """interp_smooth (src/interp.cpp:172-229): P = prod_k (I + (1/tau_k) Dinv_neg A) tent, then
+    AltThreshold (src/interp.cpp:89-170): only entries with fabs(v) > drop_tol are kept."""
     P = tent.copy()
     S = sp.diags(Dinv_neg) @ A
     for tau in sa_poly_roots(nu_pro):
         P = P + (1.0 / tau) * (S @ P)
-    return P.tocsr()
+    P = P.tocsr()
+    if drop_tol != 0.0:
+        P.data[np.abs(P.data) <= drop_tol] = 0.0
+        P.eliminate_zeros()
+    return P
 
 
 # ---------------------------------------------------------------------------
@@ -464,7 +509,8 @@ class Level(object):
     pass
 
 
-def build_level(A, rel, AEs_stiffm, theta, nu_relax, nu_pro=0, testmesh=False, extra=None):
+def build_level(A, rel, AEs_stiffm, theta, nu_relax, nu_pro=0, testmesh=False, extra=None,
+                drop_tol=0.0):
     """tg_init_data + tg_build_hierarchy + tg_update_coarse_operator
     (src/tg.cpp:402-430, :502-540, :979-1014)."""
     lv = Level()
@@ -475,7 +521,7 @@ def build_level(A, rel, AEs_stiffm, theta, nu_relax, nu_pro=0, testmesh=False, e
     lv.roots = sas_poly_roots(nu_relax)
     lv.evals, lv.evects, lv.Ds = compute_vectors(rel, AEs_stiffm, theta, testmesh)
     lv.tent, lv.mis_tent_interps, lv.mis_numcoarsedof, lv.mis_svals = contrib_mises(rel, lv.evects, extra=extra)
-    lv.P = interp_smooth(lv.A, lv.tent, lv.Dinv_neg, nu_pro) if nu_pro > 0 else lv.tent.copy()
+    lv.P = interp_smooth(lv.A, lv.tent, lv.Dinv_neg, nu_pro, drop_tol) if nu_pro > 0 else lv.tent.copy()
     lv.R = lv.P.T.tocsr()
     lv.Ac = (lv.R @ lv.A @ lv.P).tocsr()       # tg_coarse_matr == RAP, inc/tg.hpp:696-709
     return lv
@@ -537,7 +583,7 @@ def nullspace_level(lv_last):
 
 def ml_produce_data(A, elem_to_dof, elmat, bdr, partitions, theta=0.003, nu_relax=3,
                     nu_pro=0, testmesh=False, correct_nullspace=False, extra_modes=None,
-                    algebraic=False):
+                    algebraic=False, smooth_drop_tol=0.0):
     """ml_produce_data + ml_produce_hierarchy_from_level (src/ml.cpp:379-472,:111-236).
     `partitions[k]` maps level-k elements to level-k AEs.  Exact coarsest solve."""
     A = sp.csr_matrix(A)
@@ -561,11 +607,13 @@ def ml_produce_data(A, elem_to_dof, elmat, bdr, partitions, theta=0.003, nu_rela
         PARALLEL_MAP = lambda f, it: pool.map(f, it, chunksize=2)
         stiff = pool.map(_stiff_task, range(rel.nparts), chunksize=2)
     elif algebraic:
-        stiff = [build_AE_stiffm_algebraic(A, p, rel) for p in range(rel.nparts)]
+        build = build_AE_stiffm_window if algebraic == "window" else build_AE_stiffm_algebraic
+        stiff = [build(A, p, rel) for p in range(rel.nparts)]
     else:
         stiff = [build_AE_stiffm_with_global(A, p, rel, elmat) for p in range(rel.nparts)]
     lv = build_level(A, rel, stiff, theta, nu_relax, nu_pro, testmesh,
-                     extra=None if extra_modes is None else np.asarray(extra_modes, dtype=float).reshape(ND, -1))
+                     extra=None if extra_modes is None else np.asarray(extra_modes, dtype=float).reshape(ND, -1),
+                     drop_tol=smooth_drop_tol)
     H.levels.append(lv)
     for k in range(1, len(partitions)):
         prev = H.levels[-1]
@@ -573,7 +621,7 @@ def ml_produce_data(A, elem_to_dof, elmat, bdr, partitions, theta=0.003, nu_rela
         rel_c = coarse_relations(prev.rel, prev, partitions[k], nparts)
         cel = [coarse_element_matrix(e, prev.rel, rel_c, prev) for e in range(prev.rel.nparts)]
         stiff = [build_AE_stiffm(p, rel_c, cel) for p in range(rel_c.nparts)]
-        lv = build_level(prev.Ac, rel_c, stiff, theta, nu_relax, nu_pro, False)
+        lv = build_level(prev.Ac, rel_c, stiff, theta, nu_relax, nu_pro, False, drop_tol=smooth_drop_tol)
         lv.coarse_elmats = cel
         H.levels.append(lv)
     if pool is not None:

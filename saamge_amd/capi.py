@@ -56,6 +56,7 @@ class Params(C.Structure):
         ("extra_modes", C.c_void_p),
         ("num_extra_modes", C.c_int),
         ("algebraic", C.c_int),
+        ("smooth_drop_tol", C.c_double),
     ]
 
 
@@ -118,7 +119,8 @@ def _ptr(a):
 
 def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, keep_debug=False,
                    coarse_rtol=1e-14, workspace_bytes=None, dist_min_local_rows=None,
-                   coarse_solver=None, nu_pro=0, correct_nullspace=False, extra_modes=None, algebraic=False):
+                   coarse_solver=None, nu_pro=0, correct_nullspace=False, extra_modes=None, algebraic=False,
+                   smooth_drop_tol=0.0):
     p = Params()
     load().saamge_amd_params_default(C.byref(p))
     p.num_coarsenings = num_coarsenings
@@ -128,7 +130,8 @@ def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, k
         p.nu_pro[i] = nu_pro
     p.testmesh = int(testmesh)
     p.correct_nullspace = int(correct_nullspace)
-    p.algebraic = int(algebraic)
+    p.algebraic = 2 if algebraic == "window" else int(bool(algebraic))
+    p.smooth_drop_tol = float(smooth_drop_tol)
     p.keep_debug = int(keep_debug)
     p.coarse_rtol = coarse_rtol
     if workspace_bytes is not None:

@@ -12,7 +12,8 @@ struct DevElmats {
     DBuf<int64_t> off;  // [NE+1]
     DBuf<double> val;
     int nde = 0;        // > 0: every element has exactly nde dofs and e2d_J / val are dense arrays
-    bool algebraic = false;  // element-free mode: the AE matrices are extracted from A (no element matrices)
+    int algebraic = 0;       // element-free mode: the AE matrices come from A (no element matrices);
+                             // 1 = ExtractSubMatrices, 2 = WindowSubMatrices
 };
 
 // Dense AE matrices for the AEs [ae0, ae0+count) into batch.W (column-major, ld = n_i).

@@ -452,6 +452,53 @@ __global__ __launch_bounds__(ASM_NT) void ae_extract_kernel(
     }
 }
 
+// Element-free mode, window variant (WindowSubMatrices, amg/src/tg.cpp:741-858): W = A_TT + A_TX E
+// with E[x, l] = a_lx / sum_{k in T} a_xk for the outside neighbours x of the AE's dof set T, i.e.
+// W[i, l] = a_il + sum_x a_ix a_xl / denom_x (A symmetric).  One thread per local row i: it alone
+// writes row i of the dense image, walking the rows of its outside neighbours twice (denominator,
+// then update) -- no atomics, fixed summation order.
+__global__ __launch_bounds__(ASM_NT) void ae_window_kernel(
+    int ae0, const int *__restrict__ ns, const int64_t *__restrict__ moff, double *__restrict__ W,
+    const int *__restrict__ ae2d_I, const int *__restrict__ ae2d_J, const int *__restrict__ d2ae_I,
+    const int *__restrict__ d2ae_J, const int *__restrict__ dof_id_inAE, const int *__restrict__ Arow,
+    const int *__restrict__ Acol, const double *__restrict__ Aval) {
+    const int b = blockIdx.x, p = ae0 + b, n = ns[b];
+    double *Wm = W + moff[b];
+    const int tid = threadIdx.x;
+    const size_t nn = (size_t)n * n;
+    for (size_t idx = tid; idx < nn; idx += ASM_NT) Wm[idx] = 0.0;
+    __syncthreads();
+    if (n == 1) {
+        if (tid == 0) Wm[0] = 1.0;
+        return;
+    }
+    auto local_id = [&](int c) {
+        for (int q = d2ae_I[c]; q < d2ae_I[c + 1]; ++q)
+            if (d2ae_J[q] == p) return dof_id_inAE[q];
+        return -1;
+    };
+    const int *aedofs = ae2d_J + ae2d_I[p];
+    for (int lr = tid; lr < n; lr += ASM_NT) {
+        const int g = aedofs[lr];
+        for (int k = Arow[g]; k < Arow[g + 1]; ++k) {
+            const int c = Acol[k];
+            const double v = Aval[k];
+            const int lc = local_id(c);
+            if (lc >= 0) {
+                Wm[(size_t)lc * n + lr] += v;
+                continue;
+            }
+            double denom = 0.0;
+            for (int kk = Arow[c]; kk < Arow[c + 1]; ++kk)
+                if (local_id(Acol[kk]) >= 0) denom += Aval[kk];
+            for (int kk = Arow[c]; kk < Arow[c + 1]; ++kk) {
+                const int ll = local_id(Acol[kk]);
+                if (ll >= 0) Wm[(size_t)ll * n + lr] += v * (Aval[kk] / denom);
+            }
+        }
+    }
+}
+
 static int csr_max_row(hipStream_t s, const DCsr &A) {
     DBuf<int> m(1);
     m.zero(s);
@@ -468,9 +515,9 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
         double bytes = 0.0;
         for (int n : batch.h_n) bytes += 8.0 * (double)n * n;
         profiler().begin(s);
-        hipLaunchKernelGGL(ae_extract_kernel, dim3(batch.count), dim3(ASM_NT), 0, s, ae0, batch.n.p, batch.moff.p,
-                           batch.W.p, rel.ae2d_I.p, rel.ae2d_J.p, rel.d2ae_I.p, rel.d2ae_J.p, rel.dof_id_inAE.p,
-                           A->rowptr.p, A->col.p, A->val.p);
+        hipLaunchKernelGGL(el.algebraic == 2 ? ae_window_kernel : ae_extract_kernel, dim3(batch.count),
+                           dim3(ASM_NT), 0, s, ae0, batch.n.p, batch.moff.p, batch.W.p, rel.ae2d_I.p, rel.ae2d_J.p,
+                           rel.d2ae_I.p, rel.d2ae_J.p, rel.dof_id_inAE.p, A->rowptr.p, A->col.p, A->val.p);
         SA_HIP_CHECK(hipGetLastError());
         profiler().end(s, "ae_extract", bytes, 0.0);
         if (scale) ae_scale(s, batch, Dout);

@@ -119,7 +119,10 @@ static void level_galerkin(Hierarchy &H, int lev, bool first) {
             spgemm(s, L.A, *cur, cur, L.dinv_neg.p, 1.0 / (sn * sn), 1.0, dst);
             cur = &dst;
         }
-        L.P = std::move(tmp[nu & 1]);
+        if (P.smooth_drop_tol != 0.0)   // AltThreshold (amg/src/interp.cpp:219-227)
+            csr_threshold(s, tmp[nu & 1], P.smooth_drop_tol, L.P);
+        else
+            L.P = std::move(tmp[nu & 1]);
         csr_transpose(s, L.P, L.R);
         DCsr AP;
         spgemm(s, L.A, L.P, nullptr, nullptr, 1.0, 0.0, AP);
@@ -906,7 +909,7 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
         SA_HIP_CHECK(hipGetLastError());
         if (!p.algebraic) import_array(L0.elmat.val, elmat, (size_t)NE * nde * nde, s);
         L0.elmat.nde = nde;
-        L0.elmat.algebraic = p.algebraic != 0;
+        L0.elmat.algebraic = p.algebraic;
     }
     // Level-0 topology inputs that are device-resident stay there (device build of the AE tables)
     static const bool host_topo = std::getenv("SAAMGE_AMD_HOST_TOPOLOGY") != nullptr;

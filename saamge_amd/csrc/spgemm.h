@@ -10,5 +10,7 @@ void spgemm(hipStream_t s, const DCsr &A, const DCsr &B, const DCsr *E, const do
             double beta, DCsr &C);
 // R = P^T, rows sorted by column
 void csr_transpose(hipStream_t s, const DCsr &P, DCsr &R);
+// C = entries of A with |v| > tol, order kept (AltThreshold, amg/src/interp.cpp:89-170)
+void csr_threshold(hipStream_t s, const DCsr &A, double tol, DCsr &C);
 
 }  // namespace saamge_amd

@@ -358,4 +358,58 @@ void csr_transpose(hipStream_t s, const DCsr &P, DCsr &R) {
     R.lanes_per_row = pick_lanes_per_row(R.nnz, R.nrows);
 }
 
+// ---------------------------------------------------------------------------------------
+// thresholding (AltThreshold, amg/src/interp.cpp:89-170): keep entries with |v| > tol
+// ---------------------------------------------------------------------------------------
+// One wavefront per row; the kept entries stay in their order (ballot + prefix popcount).
+template <bool FILL>
+__global__ __launch_bounds__(256) void threshold_kernel(int nrows, double tol, const int *__restrict__ rowptr,
+                                                        const int *__restrict__ col, const double *__restrict__ val,
+                                                        int *__restrict__ cnt, const int *__restrict__ orow,
+                                                        int *__restrict__ ocol, double *__restrict__ oval) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= nrows) return;
+    const int b = rowptr[row], e = rowptr[row + 1];
+    int kept = 0;
+    for (int p0 = b; p0 < e; p0 += 64) {
+        const int p = p0 + lane;
+        const double v = (p < e) ? val[p] : 0.0;
+        const bool keep = (p < e) && (fabs(v) > tol);
+        const unsigned long long m = __ballot(keep);
+        if (FILL && keep) {
+            const int dst = orow[row] + kept + __popcll(m & ((1ull << lane) - 1ull));
+            ocol[dst] = col[p];
+            oval[dst] = v;
+        }
+        kept += __popcll(m);
+    }
+    if (!FILL && lane == 0) cnt[row] = kept;
+}
+
+void csr_threshold(hipStream_t s, const DCsr &A, double tol, DCsr &C) {
+    C.nrows = A.nrows;
+    C.ncols = A.ncols;
+    C.has_sell = false;
+    C.max_row = -1;
+    C.rowptr.alloc((size_t)A.nrows + 1);
+    DBuf<int> cnt((size_t)A.nrows + 1);
+    const dim3 grid(div_up(A.nrows, 4));
+    if (A.nrows > 0)
+        hipLaunchKernelGGL((threshold_kernel<false>), grid, dim3(256), 0, s, A.nrows, tol, A.rowptr.p, A.col.p,
+                           A.val.p, cnt.p, nullptr, nullptr, nullptr);
+    exclusive_scan_int(s, A.nrows, cnt.p, C.rowptr.p);
+    int nnz = 0;
+    SA_HIP_CHECK(hipMemcpyAsync(&nnz, C.rowptr.p + A.nrows, sizeof(int), hipMemcpyDeviceToHost, s));
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    C.nnz = nnz;
+    C.col.alloc((size_t)nnz + 1);
+    C.val.alloc((size_t)nnz + 1);
+    if (A.nrows > 0)
+        hipLaunchKernelGGL((threshold_kernel<true>), grid, dim3(256), 0, s, A.nrows, tol, A.rowptr.p, A.col.p,
+                           A.val.p, nullptr, C.rowptr.p, C.col.p, C.val.p);
+    SA_HIP_CHECK(hipGetLastError());
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    C.lanes_per_row = pick_lanes_per_row(C.nnz, C.nrows);
+}
+
 }  // namespace saamge_amd

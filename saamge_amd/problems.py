@@ -216,6 +216,57 @@ def mltest_problem(order=1, levels=2):
                              ess_sides=("left",), partition=parts)
 
 
+def quad_elasticity_matrix(hx, hy, lam=1.0, mu=1.0):
+    """8 x 8 stiffness of isotropic plane elasticity (lambda div u div v + 2 mu eps(u):eps(v),
+    MFEM's ElasticityIntegrator form) on an hx x hy bilinear rectangle, 2x2 Gauss (exact),
+    vertex order (v00, v10, v11, v01), dofs 2*vertex + component."""
+    g = np.array([-1.0, 1.0]) / np.sqrt(3.0)
+    sgn = np.array([[-1, -1], [1, -1], [1, 1], [-1, 1]], dtype=float)
+    C = np.array([[lam + 2 * mu, lam, 0.0], [lam, lam + 2 * mu, 0.0], [0.0, 0.0, mu]])
+    Ke = np.zeros((8, 8))
+    detJ = hx * hy / 4.0
+    for xi in g:
+        for eta in g:
+            B = np.zeros((3, 8))
+            for a in range(4):
+                dx = sgn[a, 0] * (1.0 + sgn[a, 1] * eta) / 4.0 * (2.0 / hx)
+                dy = sgn[a, 1] * (1.0 + sgn[a, 0] * xi) / 4.0 * (2.0 / hy)
+                B[0, 2 * a] = dx
+                B[1, 2 * a + 1] = dy
+                B[2, 2 * a], B[2, 2 * a + 1] = dy, dx
+            Ke += detJ * (B.T @ C @ B)
+    return 0.5 * (Ke + Ke.T)
+
+
+def mltest_elasticity_problem(levels=2):
+    """The reference's ctest `elasticity` (amg/CMakeLists.txt:226-233): mltest.mesh, two
+    displacement components per vertex, constant coefficient (lambda = mu = 1,
+    `ElasticityIntegrator(q, 1.0, 1.0)`, amg/test/mltest/mltest.cpp:581), clamped on
+    attribute 4 (x = 0), ZERO right-hand side (the driver starts PCG from a random vector,
+    mltest.cpp:752-758), the fixture's AE maps."""
+    nx, ny = 4, 3
+    hx, hy = 1.0 / nx, 1.0 / ny
+    nvx, nvy = nx + 1, ny + 1
+    NV, NE = nvx * nvy, nx * ny
+    ND = 2 * NV
+    ex, ey = np.meshgrid(np.arange(nx), np.arange(ny), indexing="xy")
+    ex, ey = ex.ravel(), ey.ravel()
+    vid = lambda i, j: j * nvx + i
+    e2v = np.stack([vid(ex, ey), vid(ex + 1, ey), vid(ex + 1, ey + 1), vid(ex, ey + 1)], axis=1)
+    elem_to_dof = (2 * e2v[:, :, None] + np.arange(2)[None, None, :]).reshape(NE, 8).astype(np.int32)
+    Kref = quad_elasticity_matrix(hx, hy)
+    elmat = np.ascontiguousarray(np.broadcast_to(Kref, (NE, 8, 8)))
+    A0 = _assemble(ND, elem_to_dof, elmat)
+    ess = np.repeat((np.arange(NV) % nvx) == 0, 2)
+    A, b = _eliminate(A0, np.zeros(ND), ess)
+    bdr = (np.where(ess, AGG_ON_ESS_DOMAIN_BORDER_FLAG, 0) | AGG_OWNED_FLAG).astype(np.int8)
+    parts = [MLTEST_PARTITION.copy()]
+    if levels >= 3:
+        parts.append(MLTEST_COARSE_PARTITION.copy())
+    return Problem(A=A, b=b, elem_to_dof=elem_to_dof, elmat=elmat, bdr=bdr, ess=ess,
+                   partitions=parts, dims=(nx, ny), order=1, Kref=Kref)
+
+
 # --------------------------------------------------------------------------
 # structured 3-D hexahedral Poisson (BASELINE.md configs 2-4)
 # --------------------------------------------------------------------------

@@ -217,6 +217,22 @@ def test_mltest_fixture_matches_oracle(order, levels):
     h.close()
 
 
+def test_mltest_elasticity_fixture_matches_oracle():
+    """The reference's ctest `elasticity` (amg/CMakeLists.txt:226-233): mltest.mesh, two
+    displacement components, zero right-hand side, random start (3 iterations)."""
+    o = _oracle()
+    prob = pr.mltest_elasticity_problem()
+    h, H = _build_pair(prob, 1, testmesh=True)
+    _compare_level(h, H, 0, 0.003, strict=False, degenerate=True)
+    x0 = np.random.default_rng(0).uniform(-1.0, 1.0, prob.ND)
+    x, it, conv, hist = h.pcg(prob.b, x=x0.copy(), rel_tol=1e-6, zero_guess=False)
+    xr, itr, convr, histr = o.solve(H, prob.b, x0=x0, rel_tol=1e-6)
+    assert conv and convr and it == itr == 3
+    assert np.allclose(hist, histr, rtol=1e-6)
+    assert np.allclose(x, xr, atol=1e-9 * np.abs(x0).max())
+    h.close()
+
+
 @pytest.mark.parametrize("n,blk,cblk,K", [
     ((8, 8, 8), (4, 4, 2), None, (1, 1, 1)),
     ((8, 8, 8), (4, 4, 4), [(2, 2, 1)], (1, 1, 1)),
@@ -317,6 +333,38 @@ def test_smoothed_prolongator_matches_oracle(nu_pro, levels):
     h.close()
 
 
+def test_smooth_drop_tol_matches_oracle():
+    """MultilevelParameters::smooth_drop_tol (AltThreshold, amg/src/interp.cpp:89-229): entries of the
+    smoothed prolongator with |v| <= tol are dropped before R and Ac are formed."""
+    capi, o = _capi(), _oracle()
+    prob = pr.poisson3d_problem((8, 8, 8), blk=(4, 4, 2), coef="checkerboard")
+    tol = 0.02
+    params = capi.default_params(num_coarsenings=1, keep_debug=True, coarse_rtol=1e-28, nu_pro=1,
+                                 smooth_drop_tol=tol)
+    h = capi.Hierarchy.from_problem(prob, params)
+    H = o.ml_produce_data(prob.A, prob.elem_to_dof, prob.elmat, prob.bdr, prob.partitions[:1],
+                          theta=0.003, nu_relax=3, nu_pro=1, smooth_drop_tol=tol)
+    H0 = o.ml_produce_data(prob.A, prob.elem_to_dof, prob.elmat, prob.bdr, prob.partitions[:1],
+                           theta=0.003, nu_relax=3, nu_pro=1)
+    P, R, Ac, A = (h.get_csr(0, w) for w in ("P", "R", "Ac", "A"))
+    Po = H.levels[0].P.copy()
+    Po.sort_indices()
+    assert Po.nnz < H0.levels[0].P.nnz                   # the tolerance really drops entries
+    assert np.abs(P.data).min() > tol
+    assert P.nnz == Po.nnz and np.array_equal(P.indptr, Po.indptr) and np.array_equal(P.indices, Po.indices)
+    assert np.allclose(np.abs(P.data), np.abs(Po.data), atol=1e-10)      # columns are sign-ambiguous
+    assert abs(P - R.T).max() == 0.0
+    ref = (P.T @ A @ P).toarray()
+    assert np.allclose(Ac.toarray(), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    b = np.cos(np.arange(prob.ND) * 0.13) * (~prob.ess)
+    x_gpu, x_ref = h.vcycle(b), o.vcycle(H, b)
+    assert np.linalg.norm(x_gpu - x_ref) <= 1e-9 * np.linalg.norm(x_ref)
+    x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-8)
+    xr, itr, convr, histr = o.solve(H, prob.b, rel_tol=1e-8)
+    assert conv and convr and it == itr
+    h.close()
+
+
 @pytest.mark.parametrize("levels", [2, 3])
 def test_corrected_nullspace_level_matches_oracle(levels):
     """CorrectNullspace (src/solve.cpp:52-164) = one more two-grid level on
@@ -414,12 +462,19 @@ def _anisotropic_fixture():
     return A[1:, 1:].tocsr()
 
 
-@pytest.mark.parametrize("case", ["anisotropic_fixture", "poisson"])
+@pytest.mark.parametrize("case", ["anisotropic_fixture", "poisson", "laplace2d_window"])
 def test_algebraic_mode_matches_oracle(case):
     """element-free mode (ExtractSubMatrices, src/tg.cpp:579-672): elements =
-    dofs, non-overlapping AEs, rowsum-free principal submatrices as local matrices."""
+    dofs, non-overlapping AEs, rowsum-free principal submatrices as local matrices; `_window`:
+    the WindowSubMatrices variant (src/tg.cpp:741-858), A_TT + A_TX E."""
     capi, o = _capi(), _oracle()
-    if case == "poisson":
+    mode = "window" if case.endswith("_window") else True
+    if case == "laplace2d_window":
+        T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(24, 24))
+        A = (sp.kron(sp.identity(24), T) + sp.kron(T, sp.identity(24))).tocsr()
+        part = (np.arange(A.shape[0]) // 48).astype(np.int32)
+        theta = 0.02
+    elif case == "poisson":
         A = pr.poisson3d_problem((8, 8, 8), blk=(4, 4, 2)).A.tocsr()
         part = (np.arange(A.shape[0]) // 60).astype(np.int32)
         theta = 0.01
@@ -429,9 +484,9 @@ def test_algebraic_mode_matches_oracle(case):
         theta = 0.01
     n = A.shape[0]
     b = np.ones(n)
-    params = capi.default_params(num_coarsenings=1, theta=theta, keep_debug=True, coarse_rtol=1e-28, algebraic=True)
+    params = capi.default_params(num_coarsenings=1, theta=theta, keep_debug=True, coarse_rtol=1e-28, algebraic=mode)
     h = capi.Hierarchy.from_matrix(A, part, params)
-    H = o.ml_produce_data(A, None, None, None, [part], theta=theta, nu_relax=3, algebraic=True)
+    H = o.ml_produce_data(A, None, None, None, [part], theta=theta, nu_relax=3, algebraic=mode)
     olv = H.levels[0]
     m, ev, X, Ds = h.get_ae_eigens(0)
     assert [int(v) for v in m] == [e.shape[1] for e in olv.evects]

@@ -33,6 +33,22 @@ def test_kat_mltest2_q2_4_iterations():
     assert conv and it == 4
 
 
+def test_kat_elasticity_3_iterations():
+    """amg/CMakeLists.txt:226-233: `mltest --elasticity --constant-coefficient --zero-rhs`
+    -> "Outer PCG converged in 3 iterations."  The driver's start vector is
+    `HypreParVector::Randomize(0)` (uniform in [-1, 1], hypre's generator: unpinned), so the
+    count is checked for several seeds."""
+    prob = pr.mltest_elasticity_problem()
+    H = o.ml_produce_data(prob.A, prob.elem_to_dof, prob.elmat, prob.bdr, prob.partitions,
+                          theta=0.003, nu_relax=3, testmesh=True)
+    assert H.levels[0].A.shape[0] == 40
+    for seed in range(6):
+        x0 = np.random.default_rng(seed).uniform(-1.0, 1.0, prob.ND)
+        x, it, conv, hist = o.solve(H, prob.b, x0=x0, rel_tol=1e-6)
+        assert conv and it == 3
+        assert np.abs(x[~prob.ess]).max() <= 1e-3     # the solution of A x = 0 with x_ess kept
+
+
 def test_kat_mltest_bracketed_by_coarse_solver():
     """amg/CMakeLists.txt:191-196: `mltest` -> 3 iterations with ONE BoomerAMG V-cycle as the
     coarsest solver (third-party, unpinned).  With an exact coarsest solve the count is 2;
@@ -160,6 +176,41 @@ def test_corrected_nullspace_level():
     assert np.allclose(proj, ones_c, atol=1e-10)
     x, it, conv, hist = o.solve(H, prob.b, rel_tol=1e-8)
     assert conv and np.linalg.norm(prob.A @ x - prob.b) <= 1e-6 * np.linalg.norm(prob.b)
+
+
+def _window_test_matrix():
+    """The 9 x 9 matrix and the dof -> AE map of TestWindowSubMatrices (amg/src/tg.cpp:674-739)."""
+    import scipy.sparse as sp
+    rows = {0: {0: 2, 1: -1, 3: -1}, 1: {0: -1, 1: 3, 2: -1, 5: -1}, 2: {1: -1, 2: 2, 4: -1},
+            3: {0: -1, 3: 3, 5: -1, 6: -1}, 4: {2: -1, 4: 3, 5: -1, 8: -1},
+            5: {1: -1, 3: -1, 4: -1, 5: 4, 7: -1}, 6: {3: -1, 6: 2, 7: -1},
+            7: {5: -1, 6: -1, 7: 3, 8: -1}, 8: {4: -1, 7: -1, 8: 2}}
+    A = sp.lil_matrix((9, 9))
+    for i, r in rows.items():
+        for j, v in r.items():
+            A[i, j] = float(v)
+    return A.tocsr(), np.array([0] * 5 + [1] * 4, dtype=np.int32)
+
+
+def test_window_submatrices_on_the_reference_test_matrix():
+    """WindowSubMatrices (amg/src/tg.cpp:741-858) on the matrix of the reference's own
+    TestWindowSubMatrices: A_TT + A_TX E.  Entries checked by hand: the outside neighbours of
+    T = {0..4} are 5 (denominator -3), 6 and 8 (-1 each)."""
+    A, part = _window_test_matrix()
+    H = o.ml_produce_data(A, None, None, None, [part], theta=0.01, nu_relax=3, algebraic="window")
+    W0, W1 = H.levels[0].AEs_stiffm
+    assert W0.shape == (5, 5) and W1.shape == (4, 4)
+    assert np.isclose(W0[1, 1], 3.0 - 1.0 / 3.0) and np.isclose(W0[3, 3], 3.0 - 1.0 / 3.0 - 1.0)
+    assert np.isclose(W0[1, 3], -1.0 / 3.0) and np.isclose(W0[4, 4], 3.0 - 1.0 / 3.0 - 1.0)
+    assert W0[0, 0] == 2.0 and W0[0, 1] == -1.0
+    for W in (W0, W1):
+        assert np.allclose(W, W.T) and np.allclose(W @ np.ones(W.shape[0]), 0.0, atol=1e-14)
+        assert np.linalg.eigvalsh(W).min() > -1e-14
+    # (the test matrix is a singular Neumann Laplacian: no solve.)  The window matrices keep the
+    # constants in their kernels, so the coarse space reproduces the constant vector.
+    P = H.levels[0].P.toarray()
+    one = np.ones(9)
+    assert np.allclose(P @ np.linalg.lstsq(P, one, rcond=None)[0], one, atol=1e-12)
 
 
 def test_algebraic_mode_on_the_reference_fixture():
