@@ -89,6 +89,12 @@ typedef struct saamge_amd_params {
      * src/interp.cpp:89-229): entries of the SMOOTHED prolongator (nu_pro > 0) with
      * |value| <= tol are dropped before R = P^T and Ac = RAP.  0 = keep everything. */
     double smooth_drop_tol;
+    /* MultilevelParameters::do_aggregates (inc/ml.hpp; src/ml.cpp:149): on the LAST coarsening the
+     * minimal intersection sets are replaced by one aggregate per AE; dofs shared by several AEs
+     * are distributed greedily by strength of connection (agg_construct_aggregate_mises,
+     * src/aggregates.cpp:324-487; Arbitrator::suggest, src/arbitrator.cpp:93-204).  Lower
+     * operator complexity on the coarsest level. */
+    int do_aggregates;
 } saamge_amd_params;
 
 void saamge_amd_params_default(saamge_amd_params *p);

@@ -48,6 +48,8 @@ struct MultilevelParameters {
     void set_extra_coarse_modes(const double *modes, int count) { p.extra_modes = modes; p.num_extra_modes = count; }
     // element-free mode (tg_produce_data_algebraic): pass NE = n, nde = 1 and NULL element arrays
     void set_algebraic(bool on, bool use_window = false) { p.algebraic = on ? (use_window ? 2 : 1) : 0; }
+    bool get_do_aggregates() const { return p.do_aggregates != 0; }
+    void set_do_aggregates(bool on) { p.do_aggregates = on ? 1 : 0; }
     double get_smooth_drop_tol() const { return p.smooth_drop_tol; }
     void set_smooth_drop_tol(double tol) { p.smooth_drop_tol = tol; }
 };

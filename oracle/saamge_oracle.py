@@ -122,9 +122,55 @@ def construct_mises(dof_to_AE):
     return mises, Table.from_rows(rows, ND)
 
 
-def build_relations(elem_to_dof, partitioning, nparts, ND, bdr=None):
+def construct_aggregate_mises(A, dof_to_AE, nparts):
+    """agg_construct_aggregate_mises (src/aggregates.cpp:324-487) + Arbitrator::suggest
+    (src/arbitrator.cpp:93-204), one rank: on the LAST coarsening the "MISes" are aggregates,
+    one per AE.  Dofs of a single AE go to it; the others are distributed greedily in ascending
+    dof order: to the aggregate of the already distributed neighbour with the strongest
+    connection |a_ij| / sqrt(a_ii a_jj) among the aggregates whose AE contains the dof (first
+    maximum in stored -- here ascending column -- order), else to the smallest of its AEs' aggregates
+    (first minimum in dof_to_AE order).  Returns mises[dof], mis_to_dof and mises_size."""
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    ND = dof_to_AE.nrows
+    indptr, indices, data = A.indptr, A.indices, A.data
+    diag = A.diagonal()
+    mises = np.full(ND, -2, dtype=np.int64)
+    size = np.zeros(nparts, dtype=np.int64)
+    for i in range(ND):
+        row = dof_to_AE.row(i)
+        if row.size == 1:
+            mises[i] = row[0]
+            size[row[0]] += 1
+    for i in range(ND):
+        if mises[i] != -2:
+            continue
+        parts = dof_to_AE.row(i)
+        agg, max_stren = -1, -1.0
+        if indptr[i + 1] - indptr[i] > 1:
+            for k in range(indptr[i], indptr[i + 1]):
+                nb = int(indices[k])
+                if nb != i and mises[nb] >= 0 and mises[nb] in parts:
+                    strength = abs(data[k]) / np.sqrt(diag[i] * diag[nb])
+                    if strength > max_stren:
+                        max_stren, agg = strength, int(mises[nb])
+        if max_stren < 0.0:
+            agg = int(parts[0])
+            for p in parts[1:]:
+                if size[agg] > size[p]:
+                    agg = int(p)
+        mises[i] = agg
+        size[agg] += 1
+    rows = [[] for _ in range(nparts)]
+    for i in range(ND):
+        rows[mises[i]].append(i)
+    return mises, Table.from_rows(rows, ND), size
+
+
+def build_relations(elem_to_dof, partitioning, nparts, ND, bdr=None, aggregates_A=None):
     """agg_create_partitioning_tables (src/aggregates.cpp:1357-1443) and
-    agg_produce_mises / agg_construct_mises_parallel (:712-853) on one rank."""
+    agg_produce_mises / agg_construct_mises_parallel (:712-853) on one rank.  `aggregates_A`
+    (the level matrix): `do_aggregates`, aggregates with arbitration instead of MISes."""
     r = Relations()
     r.ND = ND
     r.nparts = int(nparts)
@@ -140,10 +186,15 @@ def build_relations(elem_to_dof, partitioning, nparts, ND, bdr=None):
     # dof_id_inAE / agg_map_id_glob_to_AE (:1202-1244): local index of dof in AE
     r.loc_in_AE = [dict((int(d), j) for j, d in enumerate(r.AE_to_dof.row(p)))
                    for p in range(nparts)]
-    r.mises, r.mis_to_dof = construct_mises(r.dof_to_AE)
-    r.num_mises = r.mis_to_dof.nrows
-    r.mises_size = np.diff(r.mis_to_dof.I)
-    r.mis_to_AE = table_mult(r.mis_to_dof, r.dof_to_AE)         # :776
+    if aggregates_A is not None:
+        r.mises, r.mis_to_dof, r.mises_size = construct_aggregate_mises(aggregates_A, r.dof_to_AE, r.nparts)
+        r.num_mises = r.nparts
+        r.mis_to_AE = Table(np.arange(r.nparts + 1), np.arange(r.nparts), r.nparts)   # :770-771
+    else:
+        r.mises, r.mis_to_dof = construct_mises(r.dof_to_AE)
+        r.num_mises = r.mis_to_dof.nrows
+        r.mises_size = np.diff(r.mis_to_dof.I)
+        r.mis_to_AE = table_mult(r.mis_to_dof, r.dof_to_AE)     # :776
     r.AE_to_mis = table_transpose(r.mis_to_AE)                  # :777
     # agg_construct_agg_flags (:198-216)
     flags = np.zeros(ND, dtype=np.int64) if bdr is None else np.asarray(bdr, dtype=np.int64).copy()
@@ -527,7 +578,7 @@ def build_level(A, rel, AEs_stiffm, theta, nu_relax, nu_pro=0, testmesh=False, e
     return lv
 
 
-def coarse_relations(rel_f, level_f, partitioning, nparts):
+def coarse_relations(rel_f, level_f, partitioning, nparts, aggregates_A=None):
     """agg_create_partitioning_coarse + agg_build_coarse_Dof_TrueDof +
     agg_create_rels_except_elem_coarse (src/aggregates.cpp:1610-1832,:1481-1602):
     coarse elements = fine AEs; coarse dofs numbered MIS by MIS; elem_to_dof =
@@ -537,7 +588,7 @@ def coarse_relations(rel_f, level_f, partitioning, nparts):
     T = level_f.tent.tocsr()
     finedof_to_dof = Table(T.indptr, T.indices, nc)
     elem_to_dof = table_mult(rel_f.AE_to_dof, finedof_to_dof)
-    rel_c = build_relations(elem_to_dof, partitioning, nparts, nc, bdr=None)
+    rel_c = build_relations(elem_to_dof, partitioning, nparts, nc, bdr=None, aggregates_A=aggregates_A)
     rel_c.mis_coarsedofoffsets = offs
     return rel_c
 
@@ -583,9 +634,10 @@ def nullspace_level(lv_last):
 
 def ml_produce_data(A, elem_to_dof, elmat, bdr, partitions, theta=0.003, nu_relax=3,
                     nu_pro=0, testmesh=False, correct_nullspace=False, extra_modes=None,
-                    algebraic=False, smooth_drop_tol=0.0):
+                    algebraic=False, smooth_drop_tol=0.0, do_aggregates=False):
     """ml_produce_data + ml_produce_hierarchy_from_level (src/ml.cpp:379-472,:111-236).
-    `partitions[k]` maps level-k elements to level-k AEs.  Exact coarsest solve."""
+    `partitions[k]` maps level-k elements to level-k AEs.  Exact coarsest solve.
+    `do_aggregates`: aggregates instead of MISes on the LAST coarsening (src/ml.cpp:149)."""
     A = sp.csr_matrix(A)
     ND = A.shape[0]
     if algebraic:
@@ -597,7 +649,9 @@ def ml_produce_data(A, elem_to_dof, elmat, bdr, partitions, theta=0.003, nu_rela
     H = Hierarchy()
     H.levels = []
     nparts0 = int(np.max(partitions[0])) + 1
-    rel = build_relations(e2d, partitions[0], nparts0, ND, bdr=bdr)
+    last = len(partitions) - 1
+    rel = build_relations(e2d, partitions[0], nparts0, ND, bdr=bdr,
+                          aggregates_A=A if (do_aggregates and last == 0) else None)
     global PARALLEL_MAP, _SHARED
     pool = None
     if PARALLEL_CORES > 1 and not algebraic:
@@ -618,7 +672,8 @@ def ml_produce_data(A, elem_to_dof, elmat, bdr, partitions, theta=0.003, nu_rela
     for k in range(1, len(partitions)):
         prev = H.levels[-1]
         nparts = int(np.max(partitions[k])) + 1
-        rel_c = coarse_relations(prev.rel, prev, partitions[k], nparts)
+        rel_c = coarse_relations(prev.rel, prev, partitions[k], nparts,
+                                 aggregates_A=prev.Ac if (do_aggregates and k == last) else None)
         cel = [coarse_element_matrix(e, prev.rel, rel_c, prev) for e in range(prev.rel.nparts)]
         stiff = [build_AE_stiffm(p, rel_c, cel) for p in range(rel_c.nparts)]
         lv = build_level(prev.Ac, rel_c, stiff, theta, nu_relax, nu_pro, False, drop_tol=smooth_drop_tol)

@@ -57,6 +57,7 @@ class Params(C.Structure):
         ("num_extra_modes", C.c_int),
         ("algebraic", C.c_int),
         ("smooth_drop_tol", C.c_double),
+        ("do_aggregates", C.c_int),
     ]
 
 
@@ -120,7 +121,7 @@ def _ptr(a):
 def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, keep_debug=False,
                    coarse_rtol=1e-14, workspace_bytes=None, dist_min_local_rows=None,
                    coarse_solver=None, nu_pro=0, correct_nullspace=False, extra_modes=None, algebraic=False,
-                   smooth_drop_tol=0.0):
+                   smooth_drop_tol=0.0, do_aggregates=False):
     p = Params()
     load().saamge_amd_params_default(C.byref(p))
     p.num_coarsenings = num_coarsenings
@@ -132,6 +133,7 @@ def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, k
     p.correct_nullspace = int(correct_nullspace)
     p.algebraic = 2 if algebraic == "window" else int(bool(algebraic))
     p.smooth_drop_tol = float(smooth_drop_tol)
+    p.do_aggregates = int(do_aggregates)
     p.keep_debug = int(keep_debug)
     p.coarse_rtol = coarse_rtol
     if workspace_bytes is not None:

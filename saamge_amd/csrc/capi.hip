@@ -58,6 +58,7 @@ void saamge_amd_params_default(saamge_amd_params *p) {
     p->num_extra_modes = 0;
     p->algebraic = 0;
     p->smooth_drop_tol = 0.0;
+    p->do_aggregates = 0;
 }
 
 int saamge_amd_memcpy(void *dst, const void *src, long long bytes) {
@@ -106,6 +107,7 @@ int saamge_amd_ml_produce_data(int n, const int *rowptr, const int *col, const d
     p.num_extra_modes = params->num_extra_modes;
     p.algebraic = params->algebraic;
     p.smooth_drop_tol = params->smooth_drop_tol;
+    p.do_aggregates = params->do_aggregates;
     SA_REQUIRE(p.world == 1 || (p.rank >= 0 && p.rank < p.world), "bad rank");
     Hierarchy *H = hierarchy_create(n, rowptr, col, val, NE, nde, elem_to_dof, elmat, bdr_dofs,
                                     partitions, nparts, p, (hipStream_t)stream);

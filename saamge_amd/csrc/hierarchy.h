@@ -48,6 +48,7 @@ struct Params {                 // MultilevelParameters (amg/inc/ml.hpp:59-114)
     const double *extra_modes = nullptr;  // level 0: n x num_extra_modes (column-major) appended to every MIS block
     int num_extra_modes = 0;
     double smooth_drop_tol = 0.0; // |entries| <= tol of the smoothed P are dropped (AltThreshold)
+    int do_aggregates = 0;        // aggregates with arbitration instead of MISes on the last coarsening
     int algebraic = 0;            // element-free mode (tg_produce_data_algebraic): elements = dofs
 };
 

@@ -169,9 +169,23 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         tm.lap("upload topology", lev);
     }
     // the MIS tables are built on a host thread while the GPU solves the local eigenproblems
+    // (do_aggregates, amg/src/ml.cpp:149: aggregates with arbitration on the LAST coarsening; the
+    // greedy arbitration reads the level matrix on the host)
+    HostCsr aggA;
+    const bool aggregates = P.do_aggregates && lev == P.num_coarsenings - 1;
+    if (aggregates) {
+        aggA.nrows = L.A.nrows;
+        aggA.rowptr.resize((size_t)L.A.nrows + 1);
+        aggA.col.resize((size_t)L.A.nnz);
+        aggA.val.resize((size_t)L.A.nnz);
+        SA_HIP_CHECK(hipMemcpyAsync(aggA.rowptr.data(), L.A.rowptr.p, sizeof(int) * ((size_t)L.A.nrows + 1), hipMemcpyDeviceToHost, s));
+        SA_HIP_CHECK(hipMemcpyAsync(aggA.col.data(), L.A.col.p, sizeof(int) * (size_t)L.A.nnz, hipMemcpyDeviceToHost, s));
+        SA_HIP_CHECK(hipMemcpyAsync(aggA.val.data(), L.A.val.p, sizeof(double) * (size_t)L.A.nnz, hipMemcpyDeviceToHost, s));
+        SA_HIP_CHECK(hipStreamSynchronize(s));
+    }
     std::exception_ptr mis_err;
     std::thread mis_thread([&]() {
-        try { build_relations_mis(L.rel); } catch (...) { mis_err = std::current_exception(); }
+        try { build_relations_mis(L.rel, aggregates ? &aggA : nullptr); } catch (...) { mis_err = std::current_exception(); }
     });
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{mis_thread};
     const Relations &rel = L.rel;

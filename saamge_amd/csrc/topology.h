@@ -43,7 +43,15 @@ struct Relations {
 // AE matrices (which only need the first half).
 void build_relations_ae(Relations &r, Table &&elem_to_dof, const hvec<int> &partitioning,
                         int nparts, int ND, const signed char *bdr);
-void build_relations_mis(Relations &r);
+// `aggregates_A` (host copy of the level matrix): do_aggregates on the last coarsening --
+// aggregates with arbitration instead of MISes (agg_construct_aggregate_mises,
+// amg/src/aggregates.cpp:324-487; Arbitrator::suggest, amg/src/arbitrator.cpp:93-204).
+struct HostCsr {
+    int nrows = 0;
+    std::vector<int> rowptr, col;
+    std::vector<double> val;
+};
+void build_relations_mis(Relations &r, const HostCsr *aggregates_A = nullptr);
 
 struct DevRelations {
     DBuf<int> e2d_I, e2d_J, elem_ldof, part;

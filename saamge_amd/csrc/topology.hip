@@ -330,7 +330,52 @@ void build_relations_ae(Relations &r, Table &&elem_to_dof, const hvec<int> &part
 
 // Part 2 (MIS tables): independent of the device work on the AE matrices, so the caller runs
 // it on a host thread while the GPU solves the local eigenproblems.
-void build_relations_mis(Relations &r) {
+// agg_construct_aggregate_mises (amg/src/aggregates.cpp:324-487) + Arbitrator::suggest
+// (amg/src/arbitrator.cpp:93-204): the greedy distribution is sequential by construction (every
+// decision sees the earlier ones), so it runs on one host thread over the rows of the interface
+// dofs only.  Ties: first maximum in the stored column order of A's row.
+static void arbitrate_aggregates(Relations &r, const HostCsr &A) {
+    const int ND = r.ND, nparts = r.nparts;
+    SA_REQUIRE(A.nrows == ND, "aggregates: level matrix / dof count mismatch");
+    r.mises.assign((size_t)ND, -2);
+    std::vector<int> size((size_t)nparts, 0);
+    std::vector<double> diag((size_t)ND, 0.0);
+    parallel_for(ND, [&](int64_t b, int64_t e, int) {
+        for (int64_t i = b; i < e; ++i)
+            for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+                if (A.col[k] == (int)i) diag[(size_t)i] = A.val[k];
+    });
+    for (int i = 0; i < ND; ++i)
+        if (r.dof_to_AE.row_size(i) == 1) {
+            const int p = r.dof_to_AE.row(i)[0];
+            r.mises[(size_t)i] = p;
+            ++size[(size_t)p];
+        }
+    for (int i = 0; i < ND; ++i) {
+        if (r.mises[(size_t)i] != -2) continue;
+        const int *parts = r.dof_to_AE.row(i);
+        const int np = r.dof_to_AE.row_size(i);
+        int agg = -1;
+        double max_stren = -1.0;
+        if (A.rowptr[i + 1] - A.rowptr[i] > 1)
+            for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) {
+                const int nb = A.col[k];
+                const int a = r.mises[(size_t)nb];
+                if (nb == i || a < 0 || std::find(parts, parts + np, a) == parts + np) continue;
+                const double strength = std::fabs(A.val[k]) / std::sqrt(diag[(size_t)i] * diag[(size_t)nb]);
+                if (strength > max_stren) { max_stren = strength; agg = a; }
+            }
+        if (max_stren < 0.0) {
+            agg = parts[0];
+            for (int j = 1; j < np; ++j)
+                if (size[(size_t)agg] > size[(size_t)parts[j]]) agg = parts[j];
+        }
+        r.mises[(size_t)i] = agg;
+        ++size[(size_t)agg];
+    }
+}
+
+void build_relations_mis(Relations &r, const HostCsr *aggregates_A) {
     const bool timing = std::getenv("SAAMGE_AMD_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -341,6 +386,14 @@ void build_relations_mis(Relations &r) {
         t_last = t;
     };
     const int ND = r.ND, nparts = r.nparts;
+    const bool aggregates = aggregates_A != nullptr;
+    std::vector<int> reps;
+    if (aggregates) {
+        // ---- last coarsening with do_aggregates: one "MIS" per AE, mis_to_AE = identity ----
+        arbitrate_aggregates(r, *aggregates_A);
+        r.num_mises = nparts;
+        lap("aggregates (arbitration)");
+    } else {
     // ---- MISes: groups of dofs with identical AE lists, numbered by first appearance ----
     // group representative = smallest dof of the group
     std::vector<int> rep_of((size_t)ND, -1);        // dof -> representative dof
@@ -400,7 +453,6 @@ void build_relations_mis(Relations &r) {
         for (auto &x : th) x.join();
     }
     // MIS ids = rank of the representative among all representatives (first appearance order)
-    std::vector<int> reps;
     for (int i = 0; i < ND; ++i)
         if (rep_of[i] == i) reps.push_back(i);
     r.num_mises = (int)reps.size();
@@ -410,9 +462,8 @@ void build_relations_mis(Relations &r) {
     parallel_for(ND, [&](int64_t b, int64_t e, int) {
         for (int64_t i = b; i < e; ++i) r.mises[(size_t)i] = mis_of_rep[rep_of[(size_t)i]];
     });
-    mis_of_rep.clear();
-    mis_of_rep.shrink_to_fit();
     lap("MIS ids");
+    }
     // mis_to_dof: dofs of each MIS ascending
     r.mis_to_dof.ncols = ND;
     counting_sort_rows(ND, r.num_mises, [&](int64_t i) { return r.mises[(size_t)i]; }, r.mis_to_dof.I,
@@ -428,12 +479,15 @@ void build_relations_mis(Relations &r) {
     r.mis_to_AE.ncols = nparts;
     r.mis_to_AE.I.assign((size_t)r.num_mises + 1, 0);
     for (int m = 0; m < r.num_mises; ++m)
-        r.mis_to_AE.I[m + 1] = r.mis_to_AE.I[m] + r.dof_to_AE.row_size(reps[m]);
+        r.mis_to_AE.I[m + 1] = r.mis_to_AE.I[m] + (aggregates ? 1 : r.dof_to_AE.row_size(reps[m]));
     r.mis_to_AE.J.resize((size_t)r.mis_to_AE.I[r.num_mises]);
     parallel_for(r.num_mises, [&](int64_t mb, int64_t me, int) {
         for (int64_t m = mb; m < me; ++m)
-            std::copy(r.dof_to_AE.row(reps[m]), r.dof_to_AE.row(reps[m]) + r.dof_to_AE.row_size(reps[m]),
-                      r.mis_to_AE.J.begin() + r.mis_to_AE.I[m]);
+            if (aggregates)
+                r.mis_to_AE.J[(size_t)m] = (int)m;     // IdentityTable, aggregates.cpp:770-771
+            else
+                std::copy(r.dof_to_AE.row(reps[m]), r.dof_to_AE.row(reps[m]) + r.dof_to_AE.row_size(reps[m]),
+                          r.mis_to_AE.J.begin() + r.mis_to_AE.I[m]);
     }, 64);
     // AE_to_mis = transpose (ascending MIS ids == the "sorted" order of elmat.cpp:121-123);
     // ae_pair keeps, for each (AE, mis) entry, the id of the (mis, AE) pair
@@ -472,7 +526,13 @@ void build_relations_mis(Relations &r) {
                 for (int k = 0; k < sz; ++k) {
                     const int dof = r.mis_to_dof.J[(size_t)r.mis_to_dof.I[m] + k];
                     // every dof of the MIS has the same AE list: the t-th AE of the dof's row
-                    dst[k] = r.dof_id_inAE[(size_t)r.dof_to_AE.I[dof] + t];
+                    // (aggregates: the position of AE m in the dof's row)
+                    int tt = t;
+                    if (aggregates) {
+                        const int *row = r.dof_to_AE.row(dof);
+                        tt = (int)(std::find(row, row + r.dof_to_AE.row_size(dof), (int)m) - row);
+                    }
+                    dst[k] = r.dof_id_inAE[(size_t)r.dof_to_AE.I[dof] + tt];
                 }
             }
         }

@@ -365,6 +365,51 @@ def test_smooth_drop_tol_matches_oracle():
     h.close()
 
 
+@pytest.mark.parametrize("levels,coef", [(2, None), (3, "checkerboard")])
+def test_aggregates_with_arbitration_match_oracle(levels, coef):
+    """`do_aggregates` -- on the last coarsening one aggregate per AE instead of
+    the MISes, interface dofs distributed by Arbitrator::suggest (amg/src/aggregates.cpp:324-487,
+    amg/src/arbitrator.cpp:93-204).  Integer tables bit-exact."""
+    capi, o = _capi(), _oracle()
+    cblk = [(2, 2, 2)] if levels == 3 else None
+    prob = pr.poisson3d_problem((8, 8, 8), blk=(4, 4, 2), coarse_blk=cblk, coef=coef)
+    nco = levels - 1
+    params = capi.default_params(num_coarsenings=nco, keep_debug=True, coarse_rtol=1e-28, do_aggregates=True)
+    h = capi.Hierarchy.from_problem(prob, params)
+    H = o.ml_produce_data(prob.A, prob.elem_to_dof, prob.elmat, prob.bdr, prob.partitions[:nco],
+                          theta=0.003, nu_relax=3, do_aggregates=True)
+    rel = H.levels[-1].rel
+    assert rel.num_mises == rel.nparts and np.array_equal(rel.mis_to_AE.J, np.arange(rel.nparts))
+    mises, k, ncols, flags = h.get_mis(nco - 1)
+    if levels == 2:
+        assert np.array_equal(mises, rel.mises)             # the arbitration itself
+        _compare_level(h, H, 0, 0.003, strict=False)
+    else:
+        # On a coarse level the strengths |a_ij| / sqrt(a_ii a_jj) come from a Galerkin matrix whose
+        # basis is sign/rotation-ambiguous and whose exactly tied connections are decided by
+        # round-off: the greedy choice is only pinned up to those ties.  Every dof must sit in one
+        # of its own AEs and the single-AE dofs in theirs.
+        _compare_level(h, H, 0, 0.003, strict=False)
+        I, J = h.get_table(nco - 1, "dof_to_AE")
+        for d in range(len(mises)):
+            assert mises[d] in J[I[d]:I[d + 1]]
+        single = np.diff(I) == 1
+        assert np.array_equal(mises[single], rel.mises[single])
+        assert np.mean(mises == rel.mises) > 0.8
+        assert h.level_info(nco - 1)["num_mises"] == rel.nparts
+    H_mis = o.ml_produce_data(prob.A, prob.elem_to_dof, prob.elmat, prob.bdr, prob.partitions[:nco],
+                              theta=0.003, nu_relax=3)
+    assert H.levels[-1].Ac.shape[0] < H_mis.levels[-1].Ac.shape[0]     # fewer coarse dofs than with MISes
+    b = np.cos(np.arange(prob.ND) * 0.13) * (~prob.ess)
+    x_gpu, x_ref = h.vcycle(b), o.vcycle(H, b)
+    assert np.linalg.norm(x_gpu - x_ref) <= (1e-9 if levels == 2 else 0.2) * np.linalg.norm(x_ref)
+    x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-8)
+    xr, itr, convr, histr = o.solve(H, prob.b, rel_tol=1e-8)
+    assert conv and convr and abs(it - itr) <= (0 if levels == 2 else 2)
+    assert np.linalg.norm(prob.A @ x - prob.b) <= 1e-6 * np.linalg.norm(prob.b)
+    h.close()
+
+
 @pytest.mark.parametrize("levels", [2, 3])
 def test_corrected_nullspace_level_matches_oracle(levels):
     """CorrectNullspace (src/solve.cpp:52-164) = one more two-grid level on

@@ -178,6 +178,44 @@ def test_corrected_nullspace_level():
     assert conv and np.linalg.norm(prob.A @ x - prob.b) <= 1e-6 * np.linalg.norm(prob.b)
 
 
+def test_aggregates_with_arbitration():
+    """do_aggregates (amg/src/aggregates.cpp:324-487, amg/src/arbitrator.cpp:93-204) on the
+    mltest fixture: one aggregate per AE; every dof lands in exactly one of ITS AEs; the dofs
+    of a single AE stay there; a shared dof follows its strongest already-distributed neighbour."""
+    prob = pr.mltest_problem(order=1, levels=2)
+    H = o.ml_produce_data(prob.A, prob.elem_to_dof, prob.elmat, prob.bdr, prob.partitions,
+                          theta=0.003, nu_relax=3, testmesh=True, do_aggregates=True)
+    rel = H.levels[0].rel
+    assert rel.num_mises == rel.nparts == 4
+    assert np.array_equal(np.sort(np.concatenate([rel.mis_to_dof.row(m) for m in range(4)])), np.arange(20))
+    A = prob.A.tocsr()
+    d = A.diagonal()
+    for i in range(20):
+        aes = rel.dof_to_AE.row(i)
+        assert rel.mises[i] in aes
+        if aes.size == 1:
+            continue
+        # replay the greedy rule for dof i against the final assignment of the EARLIER decisions:
+        # neighbours that were already distributed when i was visited = single-AE dofs and
+        # shared dofs with a smaller index
+        best, arg = -1.0, None
+        for k in range(A.indptr[i], A.indptr[i + 1]):
+            j = A.indices[k]
+            known = rel.dof_to_AE.row(j).size == 1 or j < i
+            if j != i and known and rel.mises[j] in aes:
+                sgth = abs(A.data[k]) / np.sqrt(d[i] * d[j])
+                if sgth > best:
+                    best, arg = sgth, rel.mises[j]
+        if arg is not None:
+            assert rel.mises[i] == arg
+    x, it, conv, hist = o.solve(H, prob.b, rel_tol=1e-6)
+    assert conv and it <= 6
+    # fewer coarse dofs than with minimal intersection sets
+    H2 = o.ml_produce_data(prob.A, prob.elem_to_dof, prob.elmat, prob.bdr, prob.partitions,
+                           theta=0.003, nu_relax=3, testmesh=True)
+    assert H.levels[0].Ac.shape[0] < H2.levels[0].Ac.shape[0]
+
+
 def _window_test_matrix():
     """The 9 x 9 matrix and the dof -> AE map of TestWindowSubMatrices (amg/src/tg.cpp:674-739)."""
     import scipy.sparse as sp
