@@ -336,6 +336,95 @@ def poisson3d_problem(n, blk=(8, 8, 4), K=(1.0, 1.0, 1.0), coarse_blk=None,
                    bdr=bdr, ess=ess, partitions=parts, dims=n, order=1, Kref=Kref, coefs=c)
 
 
+def _lagrange_1d_mixed(order):
+    """C[i, j] = int_0^1 phi_i'(x) phi_j(x) dx for the equispaced Lagrange basis of _lagrange_1d."""
+    nodes = np.linspace(0.0, 1.0, order + 1)
+    xg, wg = np.polynomial.legendre.leggauss(order + 2)
+    xg, wg = 0.5 * (xg + 1.0), 0.5 * wg
+    n = order + 1
+    phi = np.ones((n, xg.size))
+    dphi = np.zeros((n, xg.size))
+    for i in range(n):
+        for j in range(n):
+            if j != i:
+                phi[i] *= (xg - nodes[j]) / (nodes[i] - nodes[j])
+        for k in range(n):
+            if k == i:
+                continue
+            t = np.ones_like(xg) / (nodes[i] - nodes[k])
+            for j in range(n):
+                if j != i and j != k:
+                    t *= (xg - nodes[j]) / (nodes[i] - nodes[j])
+            dphi[i] += t
+    return (dphi * wg) @ phi.T
+
+
+def hex_elasticity_matrix_tensor(h, order, lam=1.0, mu=1.0):
+    """Stiffness of isotropic linear elasticity (lambda div u div v + 2 mu eps(u):eps(v)) on an
+    h[0] x h[1] x h[2] box with tensor-product Lagrange elements of the given order (order 2:
+    the 27-node hex, 81 dofs, of BASELINE config 5), exact Gauss integration.  Local numbering:
+    node = (iz * n1 + iy) * n1 + ix, dof = 3 * node + component."""
+    M1, K1, _ = _lagrange_1d(order)
+    C1 = _lagrange_1d_mixed(order)
+    n1 = order + 1
+    nn = n1 ** 3
+    # 1-D factors per direction for "derivative on i / on j / on both / on none"
+    f = [{"00": M1 * hd, "11": K1 / hd, "10": C1, "01": C1.T} for hd in h]
+
+    def integral(da, db):
+        """int d_a phi_i d_b phi_j over the box, node-by-node (z slowest)."""
+        key = []
+        for d in range(3):
+            key.append(("1" if d == da else "0") + ("1" if d == db else "0"))
+        return np.kron(f[2][key[2]], np.kron(f[1][key[1]], f[0][key[0]]))
+
+    G = [[integral(a, b) for b in range(3)] for a in range(3)]
+    lap = G[0][0] + G[1][1] + G[2][2]
+    Ke = np.zeros((3 * nn, 3 * nn))
+    for a in range(3):
+        for b in range(3):
+            blk = lam * G[a][b] + mu * G[b][a]
+            if a == b:
+                blk = blk + mu * lap
+            Ke[a::3, b::3] = blk
+    return 0.5 * (Ke + Ke.T)
+
+
+def elasticity3d_q2_problem(n, blk=(2, 2, 2), lam=1.0, mu=1.0, order=2):
+    """BASELINE config 5 in small: unit cube of n hexes with tensor-product elements of `order`
+    (2: 27 nodes, 81 dofs per element), 3 displacement components per node (byVDIM), clamped
+    on x = 0, body force (0, 0, -1), AEs = blocks of blk elements."""
+    if np.isscalar(n):
+        n = (int(n),) * 3
+    nx, ny, nz = n
+    h = (1.0 / nx, 1.0 / ny, 1.0 / nz)
+    n1 = order + 1
+    gx, gy, gz = order * nx + 1, order * ny + 1, order * nz + 1
+    NV = gx * gy * gz
+    ND, NE = 3 * NV, nx * ny * nz
+    ez, ey, ex = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    ex, ey, ez = ex.ravel(), ey.ravel(), ez.ravel()
+    nid = lambda i, j, k: (k * gy + j) * gx + i
+    loc = [(a, b_, c) for c in range(n1) for b_ in range(n1) for a in range(n1)]
+    e2n = np.stack([nid(order * ex + a, order * ey + b_, order * ez + c) for (a, b_, c) in loc], axis=1)
+    nde = 3 * len(loc)
+    elem_to_dof = (3 * e2n[:, :, None] + np.arange(3)[None, None, :]).reshape(NE, nde).astype(np.int32)
+    Kref = hex_elasticity_matrix_tensor(h, order, lam, mu)
+    elmat = np.ascontiguousarray(np.broadcast_to(Kref, (NE, nde, nde)))
+    A0 = _assemble(ND, elem_to_dof, elmat)
+    _, _, L1 = _lagrange_1d(order)
+    load = -h[0] * h[1] * h[2] * np.kron(L1, np.kron(L1, L1))
+    b0 = np.zeros(ND)
+    np.add.at(b0, elem_to_dof[:, 2::3].ravel(), np.tile(load, NE))
+    ix = np.arange(NV) % gx
+    ess = np.repeat(ix == 0, 3)
+    A, b = _eliminate(A0, b0, ess)
+    bdr = (np.where(ess, AGG_ON_ESS_DOMAIN_BORDER_FLAG, 0) | AGG_OWNED_FLAG).astype(np.int8)
+    part0, nb = block_partition(n, blk)
+    return Problem(A=A, b=b, elem_to_dof=elem_to_dof, elmat=elmat, bdr=bdr, ess=ess,
+                   partitions=[part0], dims=n, order=order, Kref=Kref, coefs=np.ones(NE))
+
+
 # --------------------------------------------------------------------------
 # device-resident generator (torch is plumbing: it only allocates/fills HBM)
 # --------------------------------------------------------------------------

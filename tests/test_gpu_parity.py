@@ -81,6 +81,31 @@ def test_batched_lower_eigens_vs_lapack(seed):
         assert np.allclose(_proj(X, D), _proj(Xr, D), atol=PROJ_TOL)
 
 
+def test_batched_lower_eigens_large_agglomerates():
+    """Agglomerate sizes of the headline configs (405 = 8x8x4 Q1, 729 = 8^3 Q1) and beyond the
+    LDS-resident band (n > ~1150: band and bulge in global memory; 2187 = the 4^3 Q2 elasticity
+    agglomerate of BASELINE config 5)."""
+    capi, o = _capi(), _oracle()
+    rng = np.random.default_rng(5)
+    mats, diags = [], []
+    for n in [405, 729, 1300, 2187]:
+        G = sp.random(n, n, density=8.0 / n, random_state=rng).toarray()
+        W = np.abs(G + G.T)
+        L = np.diag(W.sum(axis=1)) - W + 1e-4 * np.diag(rng.random(n))
+        mats.append(L)
+        diags.append(o.snd_D_from_dense(L))
+    theta = 0.01
+    res = capi.lower_eigens_batched(mats, diags, -1.0, theta)
+    for L, D, (w, X) in zip(mats, diags, res):
+        wr, Xr = o.lower_eigens_dense(L, D, theta)
+        assert len(w) == len(wr) and len(w) >= 1
+        assert np.allclose(w, wr, rtol=0, atol=EIG_TOL)
+        assert np.allclose(X.T @ (D[:, None] * X), np.eye(len(w)), atol=1e-10)
+        R = L @ X - (D[:, None] * X) * w[None, :]
+        assert np.abs(R).max() <= 1e-10 * max(1.0, np.abs(L).max())
+        assert np.allclose(_proj(X, D), _proj(Xr, D), atol=PROJ_TOL)
+
+
 def test_batched_eigens_degenerate_and_split():
     """Degenerate clusters (block-diagonal copies) and splitting tridiagonals."""
     capi, o = _capi(), _oracle()
@@ -294,6 +319,27 @@ def test_elasticity3d_matches_oracle(levels):
     x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-8)
     xr, itr, convr, histr = o.solve(H, prob.b, rel_tol=1e-8)
     assert conv and convr and abs(it - itr) <= (0 if levels == 2 else 1)
+    assert np.linalg.norm(prob.A @ x - prob.b) <= 1e-6 * np.linalg.norm(prob.b)
+    h.close()
+
+
+def test_q2_elasticity3d_matches_oracle():
+    """BASELINE config 5's element type in small: 27-node hexes with 3 displacement components
+    (81 x 81 element matrices, 525-dof agglomerates), six rigid-body modes per free agglomerate.
+    (2 x 3 elements across, so that the bending modes of the clamped agglomerate are not a
+    degenerate pair of which "at least one" would pick an arbitrary member.)"""
+    o = _oracle()
+    prob = pr.elasticity3d_q2_problem((4, 2, 3), blk=(2, 2, 3))
+    h, H = _build_pair(prob, 1)
+    _compare_level(h, H, 0, 0.003, strict=False, degenerate=True)
+    m, ev, X, Ds = h.get_ae_eigens(0)
+    assert m.tolist() == [H.levels[0].evects[i].shape[1] for i in range(2)] and m[1] >= 6
+    b = np.cos(np.arange(prob.ND) * 0.13) * (~prob.ess)
+    x_gpu, x_ref = h.vcycle(b), o.vcycle(H, b)
+    assert np.linalg.norm(x_gpu - x_ref) <= 1e-8 * np.linalg.norm(x_ref)
+    x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-8)
+    xr, itr, convr, histr = o.solve(H, prob.b, rel_tol=1e-8)
+    assert conv and convr and it == itr
     assert np.linalg.norm(prob.A @ x - prob.b) <= 1e-6 * np.linalg.norm(prob.b)
     h.close()
 
