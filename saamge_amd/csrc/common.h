@@ -166,6 +166,10 @@ struct DCsr {
     int64_t sell_size = 0;
     DBuf<int> sell_ptr, sell_col;
     DBuf<double> sell_val;
+    // coded slices: <= 64 distinct offsets col - row -> sell_tab[64 s + code], one byte per entry
+    // in sell_code (four consecutive entries of a row per word); sell_ntab[s] = -1: plain slice
+    DBuf<int> sell_ntab, sell_tab;
+    DBuf<unsigned> sell_code;
 };
 
 inline int pick_lanes_per_row(int64_t nnz, int nrows) {
