@@ -43,8 +43,8 @@ KERNELS = {
     "spmv": ("sell_spmv_kernel<0>", "hbm"),
     "spmv_residual": ("sell_spmv_kernel<1>", "hbm"),
     "eig_sbr_symm": ("sbr_symm_kernel", "hbm"),
-    "eig_sbr_syr2k": ("sbr_fused_kernel<false>", "hbm"),
-    "eig_sbr_fused": ("sbr_fused_kernel<true>", "hbm"),
+    "eig_sbr_syr2k": ("sbr_fused_kernel<false, 1>", "hbm"),
+    "eig_sbr_fused": ("sbr_fused_kernel<true, 2>", "hbm"),
     "ae_build": ("ae_build_kernel<true, 8, true>", "hbm"),
     "eig_band_chase": ("band_chase_kernel", "mfma"),
     "eig_sbr_qr": ("sbr_qr_kernel<256, true>", "mfma"),

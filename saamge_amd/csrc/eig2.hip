@@ -635,9 +635,12 @@ __global__ __launch_bounds__(256) void sbr_panel_update_kernel(int k0, const int
 }
 
 
-constexpr int SF_ROWS = 64;   // one row per lane: 2 x 16 row operands + 16 accumulators in VGPRs
-// PROD = false: the update alone (no accumulators: fewer VGPRs, one more wavefront per SIMD)
-template <bool PROD>
+constexpr int SF_ROWS = 64;   // rows per lane-row: 2 x 16 row operands + 16 accumulators in VGPRs
+// PROD = false: the update alone (no accumulators: fewer VGPRs, one more wavefront per SIMD).
+// RPL = rows per lane (strip of 64 RPL rows): every column operand fetched through the scalar cache
+// feeds RPL FMAs.  The kernel is bound by that operand delivery (~17 TFLOP/s with one FMA per
+// fetched scalar, both on the 405-row and on the 2 600-row agglomerates), not by HBM.
+template <bool PROD, int RPL>
 __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__restrict__ ns,
                                                           const int64_t *__restrict__ moff,
                                                           const int64_t *__restrict__ voff,
@@ -651,6 +654,7 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
                                                           double *__restrict__ trashbuf, int count,
                                                           int tiles, int shift) {
     constexpr int SBP = SB + 1;
+    constexpr int KC = (RPL == 1) ? S2_KC : 4;   // columns per step (VGPR budget: 2 RPL KC tile values)
     __shared__ double red[4 * SB * SF_ROWS];   // 32 KiB: K-split reduction
     __shared__ double xs[SF_ROWS * SBP], vs2[SF_ROWS * SBP];
     int b, blk;
@@ -662,7 +666,7 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
     // sbr_panel_update_kernel; shift = 0: the whole trailing matrix of panel k0
     const int np = n - k0 - SB - shift;        // order of A22' (may be < 2: update only)
     if (np < 1) return;
-    const int i0 = blk * SF_ROWS;
+    const int i0 = blk * (SF_ROWS * RPL);
     if (i0 >= np) return;
     const bool prod = PROD && np >= 2;         // the next panel has reflectors
     double *A22 = Wm + moff[b] + (size_t)(k0 + SB + shift) * n + (k0 + SB + shift);
@@ -673,89 +677,119 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ia = i0 + lane;
-    const bool oka = ia < np;
-    double *pa = oka ? A22 + ia : trashbuf + lane;          // rows past the end: see sbr_syr2k_kernel
-    const size_t sa = oka ? (size_t)n : 0;
-    const int iac = min(ia, np - 1);
-    double za[SB], va[SB];   // negated row operands
-    double xa[SB];
+    double *pa[RPL];
+    size_t sa[RPL];
+    double za[RPL][SB], va[RPL][SB];   // negated row operands
+    double xa[RPL][SB];
 #pragma unroll
-    for (int c = 0; c < SB; ++c) {
-        za[c] = -Z[(size_t)iac * SB + c];
-        va[c] = -Vc[(size_t)iac * SB + c];
-        xa[c] = 0.0;
-    }
-    // Column groups of S2_KC; the A-tile of the NEXT group is requested before the current one is
-    // worked on (double-buffered in registers), so its HBM round trip is covered by 8 x 48 FMAs.
-    int l0 = S2_KC * w;
-    double ta[S2_KC], tn[S2_KC];
-    if (l0 + S2_KC <= np) {
+    for (int r = 0; r < RPL; ++r) {
+        const int ia = i0 + SF_ROWS * r + lane;
+        const bool oka = ia < np;
+        pa[r] = oka ? A22 + ia : trashbuf + lane;          // rows past the end: see sbr_syr2k_kernel
+        sa[r] = oka ? (size_t)n : 0;
+        const int iac = min(ia, np - 1);
 #pragma unroll
-        for (int k = 0; k < S2_KC; ++k) ta[k] = pa[(size_t)(l0 + k) * sa];
+        for (int c = 0; c < SB; ++c) {
+            za[r][c] = -Z[(size_t)iac * SB + c];
+            va[r][c] = -Vc[(size_t)iac * SB + c];
+            xa[r][c] = 0.0;
+        }
     }
-    for (; l0 + S2_KC <= np; l0 += 4 * S2_KC) {
-        const int l1 = l0 + 4 * S2_KC;
-        const bool more = l1 + S2_KC <= np;    // wave-uniform
+    // Column groups of KC; the A-tile of the NEXT group is requested before the current one is
+    // worked on (double-buffered in registers), so its HBM round trip is covered by KC x 48 RPL FMAs.
+    int l0 = KC * w;
+    double ta[RPL][KC], tn[RPL][KC];
+    if (l0 + KC <= np) {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r)
+#pragma unroll
+            for (int k = 0; k < KC; ++k) ta[r][k] = pa[r][(size_t)(l0 + k) * sa[r]];
+    }
+    for (; l0 + KC <= np; l0 += 4 * KC) {
+        const int l1 = l0 + 4 * KC;
+        const bool more = l1 + KC <= np;    // wave-uniform
         if (more) {
 #pragma unroll
-            for (int k = 0; k < S2_KC; ++k) tn[k] = pa[(size_t)(l1 + k) * sa];
+            for (int r = 0; r < RPL; ++r)
+#pragma unroll
+                for (int k = 0; k < KC; ++k) tn[r][k] = pa[r][(size_t)(l1 + k) * sa[r]];
         }
 #pragma unroll
-        for (int k = 0; k < S2_KC; ++k) {
+        for (int k = 0; k < KC; ++k) {
             const double *zl = Z + (size_t)(l0 + k) * SB;    // wave-uniform: scalar loads
             const double *vl = Vc + (size_t)(l0 + k) * SB;
 #pragma unroll
-            for (int c = 0; c < SB; ++c) ta[k] = fma(za[c], vl[c], fma(va[c], zl[c], ta[k]));
+            for (int c = 0; c < SB; ++c)
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) ta[r][k] = fma(za[r][c], vl[c], fma(va[r][c], zl[c], ta[r][k]));
             if (prod) {
                 const double *vn = Vn + (size_t)(l0 + k) * SB;
 #pragma unroll
-                for (int j = 0; j < SB; ++j) xa[j] = fma(ta[k], vn[j], xa[j]);
+                for (int j = 0; j < SB; ++j)
+#pragma unroll
+                    for (int r = 0; r < RPL; ++r) xa[r][j] = fma(ta[r][k], vn[j], xa[r][j]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int k = 0; k < S2_KC; ++k) pa[(size_t)(l0 + k) * sa] = ta[k];
+        for (int r = 0; r < RPL; ++r)
+#pragma unroll
+            for (int k = 0; k < KC; ++k) pa[r][(size_t)(l0 + k) * sa[r]] = ta[r][k];
         if (more) {
 #pragma unroll
-            for (int k = 0; k < S2_KC; ++k) ta[k] = tn[k];
+            for (int r = 0; r < RPL; ++r)
+#pragma unroll
+                for (int k = 0; k < KC; ++k) ta[r][k] = tn[r][k];
         }
     }
     for (; l0 < np; ++l0) {                   // the last, partial group
-        double t0 = pa[(size_t)l0 * sa];
+        double t0[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) t0[r] = pa[r][(size_t)l0 * sa[r]];
         const double *zl = Z + (size_t)l0 * SB;
         const double *vl = Vc + (size_t)l0 * SB;
 #pragma unroll
-        for (int c = 0; c < SB; ++c) t0 = fma(za[c], vl[c], fma(va[c], zl[c], t0));
+        for (int c = 0; c < SB; ++c)
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) t0[r] = fma(za[r][c], vl[c], fma(va[r][c], zl[c], t0[r]));
         if (prod) {
             const double *vn = Vn + (size_t)l0 * SB;
 #pragma unroll
-            for (int j = 0; j < SB; ++j) xa[j] = fma(t0, vn[j], xa[j]);
+            for (int j = 0; j < SB; ++j)
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) xa[r][j] = fma(t0[r], vn[j], xa[r][j]);
         }
-        pa[(size_t)l0 * sa] = t0;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) pa[r][(size_t)l0 * sa[r]] = t0[r];
     }
     if (!prod) return;   // block-uniform
-    // ---- X = sum of the four column splits; partial G = V^T X of this 64-row block ----
+    // ---- X = sum of the four column splits; partial G = V^T X of each 64-row block ----
 #pragma unroll
-    for (int j = 0; j < SB; ++j) red[(w * SB + j) * SF_ROWS + lane] = xa[j];
-    __syncthreads();
-    for (int idx = tid; idx < SF_ROWS * SB; idx += S2_NT) {
-        const int rr = idx & (SF_ROWS - 1), j = idx >> 6;
-        double s = 0.0;
-        if (i0 + rr < np) {
-            s = (red[(0 * SB + j) * SF_ROWS + rr] + red[(1 * SB + j) * SF_ROWS + rr]) +
-                (red[(2 * SB + j) * SF_ROWS + rr] + red[(3 * SB + j) * SF_ROWS + rr]);
-            X[(size_t)j * n + i0 + rr] = s;
+    for (int r = 0; r < RPL; ++r) {
+        const int ib = i0 + SF_ROWS * r;           // first row of this 64-row block
+        if (ib >= np) break;                       // block-uniform
+        if (r) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SB; ++j) red[(w * SB + j) * SF_ROWS + lane] = xa[r][j];
+        __syncthreads();
+        for (int idx = tid; idx < SF_ROWS * SB; idx += S2_NT) {
+            const int rr = idx & (SF_ROWS - 1), j = idx >> 6;
+            double s = 0.0;
+            if (ib + rr < np) {
+                s = (red[(0 * SB + j) * SF_ROWS + rr] + red[(1 * SB + j) * SF_ROWS + rr]) +
+                    (red[(2 * SB + j) * SF_ROWS + rr] + red[(3 * SB + j) * SF_ROWS + rr]);
+                X[(size_t)j * n + ib + rr] = s;
+            }
+            xs[rr * SBP + j] = s;
+            vs2[rr * SBP + j] = (ib + rr < np) ? Vn[(size_t)(ib + rr) * SB + j] : 0.0;
         }
-        xs[rr * SBP + j] = s;
-        vs2[rr * SBP + j] = (i0 + rr < np) ? Vn[(size_t)(i0 + rr) * SB + j] : 0.0;
-    }
-    __syncthreads();
-    {
-        const int a = tid >> 4, c = tid & 15;
-        double s = 0.0;
-        for (int rr = 0; rr < SF_ROWS; ++rr) s = fma(vs2[rr * SBP + a], xs[rr * SBP + c], s);
-        Gbuf[goff[b] + (size_t)blk * (SB * SB) + tid] = s;
+        __syncthreads();
+        {
+            const int a = tid >> 4, c = tid & 15;
+            double s = 0.0;
+            for (int rr = 0; rr < SF_ROWS; ++rr) s = fma(vs2[rr * SBP + a], xs[rr * SBP + c], s);
+            Gbuf[goff[b] + (size_t)(blk * RPL + r) * (SB * SB) + tid] = s;
+        }
     }
 }
 
@@ -1289,6 +1323,11 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
         return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
     }();
     const bool fused = fused_mode != 0;
+    // rows per lane of the fused kernel (SAAMGE_AMD_EIG_RPL = 1 | 2)
+    static const int rpl = []() {
+        const char *e = std::getenv("SAAMGE_AMD_EIG_RPL");
+        return (e && e[0] == '1') ? 1 : 2;
+    }();
     if (phases & 1) {
     if (!prof) profiler().begin(s);
     const int cnt8 = 8 * div_up(b.count, 8);
@@ -1328,7 +1367,7 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
             if (prof) { profiler().end(s, "eig_sbr_symm", first ? sbytes : 0.0, 0.0); profiler().begin(s); }
             launch_z(k0, b.Vpk.p);
             if (prof) { profiler().end(s, "eig_sbr_z", 0.0, 0.0); profiler().begin(s); }
-            hipLaunchKernelGGL(sbr_fused_kernel<false>, dim3(cnt8 * div_up(npmax, SF_ROWS)), dim3(S2_NT), 0, s,
+            hipLaunchKernelGGL((sbr_fused_kernel<false, 1>), dim3(cnt8 * div_up(npmax, SF_ROWS)), dim3(S2_NT), 0, s,
                                k0, b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.Vpk.p, b.Xbuf.p,
                                b.goff.p, b.Gbuf.p, b.trash.p, b.count, div_up(npmax, SF_ROWS), 0);
             if (prof) profiler().end(s, "eig_sbr_syr2k", first ? ubytes : 0.0, 0.0);
@@ -1367,8 +1406,14 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
                 if (rg == 1) SA_FUSED(1); else if (rg == 2) SA_FUSED(2); else SA_FUSED(4);
 #undef SA_FUSED
             }
+            // two rows per lane are ~10 % faster per row slot but pad the strip count to 128 rows
+            else if (npn >= 1 && rpl == 2 &&
+                     (double)div_up(npn, 2 * SF_ROWS) * (2 * SF_ROWS) < 1.10 * (double)div_up(npn, SF_ROWS) * SF_ROWS)
+                hipLaunchKernelGGL((sbr_fused_kernel<true, 2>), dim3(cnt8 * div_up(npn, 2 * SF_ROWS)), dim3(S2_NT), 0, s,
+                                   k0, b.n.p, b.moff.p, b.voff.p, b.W.p, Vcur, b.Zbuf.p, Vnext, b.Xbuf.p,
+                                   b.goff.p, b.Gbuf.p, b.trash.p, b.count, div_up(npn, 2 * SF_ROWS), SB);
             else if (npn >= 1)
-                hipLaunchKernelGGL(sbr_fused_kernel<true>, dim3(cnt8 * div_up(npn, SF_ROWS)), dim3(S2_NT), 0, s,
+                hipLaunchKernelGGL((sbr_fused_kernel<true, 1>), dim3(cnt8 * div_up(npn, SF_ROWS)), dim3(S2_NT), 0, s,
                                    k0, b.n.p, b.moff.p, b.voff.p, b.W.p, Vcur, b.Zbuf.p, Vnext, b.Xbuf.p,
                                    b.goff.p, b.Gbuf.p, b.trash.p, b.count, div_up(npn, SF_ROWS), SB);
             if (prof) { profiler().end(s, "eig_sbr_fused", first ? fbytes : 0.0, 0.0); profiler().begin(s); }
