@@ -1407,8 +1407,11 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
 #undef SA_FUSED
             }
             // two rows per lane are ~10 % faster per row slot but pad the strip count to 128 rows
-            else if (npn >= 1 && rpl == 2 &&
-                     (double)div_up(npn, 2 * SF_ROWS) * (2 * SF_ROWS) < 1.10 * (double)div_up(npn, SF_ROWS) * SF_ROWS)
+            const bool two_rows = rpl == 2 && fused_mode != 2 &&
+                (double)div_up(npn, 2 * SF_ROWS) * (2 * SF_ROWS) < 1.10 * (double)div_up(npn, SF_ROWS) * SF_ROWS;
+            if (fused_mode == 2) {
+                // (launched above)
+            } else if (npn >= 1 && two_rows)
                 hipLaunchKernelGGL((sbr_fused_kernel<true, 2>), dim3(cnt8 * div_up(npn, 2 * SF_ROWS)), dim3(S2_NT), 0, s,
                                    k0, b.n.p, b.moff.p, b.voff.p, b.W.p, Vcur, b.Zbuf.p, Vnext, b.Xbuf.p,
                                    b.goff.p, b.Gbuf.p, b.trash.p, b.count, div_up(npn, 2 * SF_ROWS), SB);
@@ -1416,7 +1419,16 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
                 hipLaunchKernelGGL((sbr_fused_kernel<true, 1>), dim3(cnt8 * div_up(npn, SF_ROWS)), dim3(S2_NT), 0, s,
                                    k0, b.n.p, b.moff.p, b.voff.p, b.W.p, Vcur, b.Zbuf.p, Vnext, b.Xbuf.p,
                                    b.goff.p, b.Gbuf.p, b.trash.p, b.count, div_up(npn, SF_ROWS), SB);
-            if (prof) { profiler().end(s, "eig_sbr_fused", first ? fbytes : 0.0, 0.0); profiler().begin(s); }
+            if (prof) {
+                // (one label per kernel symbol, bytes of THIS launch: 16 np'^2 per matrix)
+                double lb = 0.0;
+                for (int n : b.h_n) {
+                    const double q = (double)n - k0 - 2 * SB;
+                    if (n - k0 - SB >= 2 && q >= 1.0) lb += 16.0 * q * q;
+                }
+                profiler().end(s, two_rows ? "eig_sbr_fused" : "eig_sbr_fused1", lb, 0.0);
+                profiler().begin(s);
+            }
             if (has_next) launch_z(k0 + SB, Vnext);
             if (prof) profiler().end(s, "eig_sbr_z", 0.0, 0.0);
             std::swap(Vcur, Vnext);
