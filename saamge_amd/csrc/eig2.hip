@@ -950,8 +950,6 @@ __global__ __launch_bounds__(256) void sbr_fused_mfma_kernel(int k0, const int *
 // ---------------------------------------------------------------------------------------
 // stage 2: bulge chasing
 // ---------------------------------------------------------------------------------------
-constexpr int CH_NT = 1024;
-constexpr int CH_NW = CH_NT / 64;
 
 // number of chase steps of sweep s
 __device__ __host__ inline int chase_steps(int n, int s) { return (n - 1 - s + SB - 1) / SB; }
@@ -967,13 +965,24 @@ __device__ inline void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CS
 
 constexpr int HAND = 4 * SB + 2;  // per-wave LDS scratch: vprev[SB], tau, pad, sv[SB], sw[SB], sx[SB]
 
-// One chase step of sweep s (q-th block), executed by one wavefront.  Lane l: r = l & 15 is
-// the row inside the SB x SB block, cq = l >> 4 selects 4 of its 16 columns.  Vectors that
-// every lane needs (v, w, first column) go through a wave-private LDS scratch instead of
-// cross-lane permutes; the 16-lane sums use DPP row rotations.
+// One chase step of sweep s (q-th block), executed by 16 NCQ lanes (a "slot": NCQ = 4: a whole
+// wavefront; NCQ = 2: half of one, the two halves work on different sweeps).  Lane l of the slot:
+// r = l & 15 is the row inside the SB x SB block, cq = l >> 4 selects SB / NCQ of its 16 columns.
+// Vectors that every lane needs (v, w, first column) go through a slot-private LDS scratch
+// instead of cross-lane permutes; the 16-lane sums use DPP row rotations.  s, q (and everything
+// derived from them) are per-slot values; a slot is active or idle as a whole, so the DPP rows and
+// the permlane swaps below never mix active and idle lanes.
+template <int NCQ>
 __device__ inline void chase_step(const BandRef &B, int n, int s, int q, double *hand,
                                   double *refl_v, double *refl_tau, int lane) {
-    const int r = lane & 15, cq = lane >> 4;
+    constexpr int CPL = SB / NCQ;               // columns per lane
+    const int sl = lane & (16 * NCQ - 1);       // lane inside the slot
+    const int r = sl & 15, cq = sl >> 4;
+    auto rowsum = [](double v) {                // sum over the NCQ column groups of a row
+        if (NCQ == 4) return xsum32(xsum16(v));
+        if (NCQ == 2) return xsum16(v);
+        return v;
+    };
     double *vprev = hand, *sv = hand + SB + 2, *sw = sv + SB, *sx = sw + SB;
     const int i0 = s + 1 + q * SB;              // first row of I_q
     const int L = min(SB, n - i0);              // |I_q| >= 1
@@ -982,7 +991,7 @@ __device__ inline void chase_step(const BandRef &B, int n, int s, int q, double 
         // eliminate column s below its first sub-diagonal entry
         const double x = (r < L) ? B(i0 + r, s) : 0.0;
         const double ss = rsum16((r >= 1) ? x * x : 0.0);   // every 16-lane group holds the column
-        if (lane == 0) sx[0] = x;
+        if (sl == 0) sx[0] = x;
         wave_lds_fence();
         const double alpha = sx[0];
         double beta = alpha, scale = 0.0;
@@ -997,20 +1006,20 @@ __device__ inline void chase_step(const BandRef &B, int n, int s, int q, double 
     } else {
         const int j0 = i0 - SB;                  // I_{q-1} = [j0, j0 + SB)
         const double tprev = vprev[SB];
-        // C(r, c) = A[i0 + r, j0 + c], 4 columns per lane
-        double cv[4], vp[4];
+        // C(r, c) = A[i0 + r, j0 + c], CPL columns per lane
+        double cv[CPL], vp[CPL];
         double w = 0.0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = 4 * cq + k;
+        for (int k = 0; k < CPL; ++k) {
+            const int c = CPL * cq + k;
             vp[k] = vprev[c];
             cv[k] = (r < L) ? B(i0 + r, j0 + c) : 0.0;
             w = fma(cv[k], vp[k], w);
         }
-        w = xsum32(xsum16(w));
+        w = rowsum(w);
         const double tw = tprev * w;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) cv[k] = fma(-tw, vp[k], cv[k]);   // C <- C H_prev
+        for (int k = 0; k < CPL; ++k) cv[k] = fma(-tw, vp[k], cv[k]);   // C <- C H_prev
         // new reflector from the first column of C (held by the cq == 0 lanes)
         if (cq == 0) sx[r] = cv[0];
         wave_lds_fence();
@@ -1028,7 +1037,7 @@ __device__ inline void chase_step(const BandRef &B, int n, int s, int q, double 
         if (tau != 0.0) {
             // C <- H C : z_c = sum_r v_r C(r, c)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < CPL; ++k) {
                 const double z = rsum16(vr * cv[k]);
                 cv[k] = fma(-tau * z, vr, cv[k]);
             }
@@ -1036,7 +1045,7 @@ __device__ inline void chase_step(const BandRef &B, int n, int s, int q, double 
         }
         if (r < L) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) B(i0 + r, j0 + 4 * cq + k) = cv[k];
+            for (int k = 0; k < CPL; ++k) B(i0 + r, j0 + CPL * cq + k) = cv[k];
         }
     }
     // publish v: next step of this sweep, the D update below, and the back-transformation
@@ -1044,48 +1053,48 @@ __device__ inline void chase_step(const BandRef &B, int n, int s, int q, double 
         sv[r] = vr;
         refl_v[r] = vr;
     }
-    if (lane == 0) *refl_tau = tau;
+    if (sl == 0) *refl_tau = tau;
     wave_lds_fence();
     // two-sided update of the diagonal block D = A[I_q, I_q] (lower part stored)
     if (tau != 0.0) {
-        double dv[4], vc[4];
+        double dv[CPL], vc[CPL];
         double p = 0.0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = 4 * cq + k;
+        for (int k = 0; k < CPL; ++k) {
+            const int c = CPL * cq + k;
             vc[k] = sv[c];
             dv[k] = (r < L && c < L) ? B.sym(i0 + r, i0 + c) : 0.0;
             p = fma(dv[k], vc[k], p);
         }
-        p = xsum32(xsum16(p));
+        p = rowsum(p);
         p *= tau;                                   // p_r
-        const double pv = rsum16(p * vr);           // p and v are replicated in the four groups
+        const double pv = rsum16(p * vr);           // p and v are replicated in the column groups
         const double wr = fma(-0.5 * tau * pv, vr, p);   // w_r = p_r - tau/2 (p.v) v_r
         if (cq == 0) sw[r] = wr;
         wave_lds_fence();
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = 4 * cq + k;
+        for (int k = 0; k < CPL; ++k) {
+            const int c = CPL * cq + k;
             const double wc = sw[c];
             if (r < L && c <= r) B(i0 + r, i0 + c) = dv[k] - vr * wc - wr * vc[k];
         }
     }
-    // hand the reflector to the next step (same wavefront)
+    // hand the reflector to the next step (same slot)
     if (cq == 0) vprev[r] = vr;
-    if (lane == 0) vprev[SB] = tau;
+    if (sl == 0) vprev[SB] = tau;
 }
 
 // IN_LDS: the band lives in LDS.  A compile-time switch, so that every band access is a 32-bit
 // ds_read / ds_write; with a run-time choice of the base pointer the accesses become FLAT
-// instructions with 64-bit address arithmetic (the kernel is bound by instruction issue:
-// ~400 vector instructions per chase step before this split).
-template <bool IN_LDS>
-__global__ __launch_bounds__(CH_NT) void band_chase_kernel(
+// instructions with 64-bit address arithmetic.  NT threads = NT / (16 NCQ) slots, one sweep each.
+template <bool IN_LDS, int NCQ, int NT>
+__global__ __launch_bounds__(NT) void band_chase_kernel(
     const int *__restrict__ ns, const int64_t *__restrict__ moff, const int64_t *__restrict__ voff,
     const int64_t *__restrict__ roff, const double *__restrict__ Wm, double *__restrict__ bandg,
     int band_in_lds, double *__restrict__ dd, double *__restrict__ ee, double *__restrict__ rv,
     double *__restrict__ rtau) {
     extern __shared__ __align__(16) double lds[];
+    constexpr int NSLOT = NT / (16 * NCQ);
     const int b = blockIdx.x;
     const int n = ns[b];
     const double *A = Wm + moff[b];
@@ -1093,32 +1102,33 @@ __global__ __launch_bounds__(CH_NT) void band_chase_kernel(
     double *d = dd + vo, *e = ee + vo;
     double *RV = rv + roff[b] * SB;
     double *RT = rtau + roff[b];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // LDS: per-wave reflector hand-off [CH_NW][HAND], cum[n+1] and start[n] ints, then
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int slot = tid / (16 * NCQ);
+    // LDS: per-slot reflector hand-off [NSLOT][HAND], cum[n+1] and start[n] ints, then
     // (optionally) the band
     double *hand = lds;
-    int *cum = (int *)(hand + CH_NW * HAND);
+    int *cum = (int *)(hand + NSLOT * HAND);
     int *start = cum + n + 1;
     double *bandl = (double *)(cum + 2 * n + 2);
     BandRef B;
     B.p = IN_LDS ? bandl : (bandg + vo * LDB);
     // load the band (zero beyond it) -- A holds it in its lower triangle
-    for (int idx = tid; idx < n * LDB; idx += CH_NT) {
+    for (int idx = tid; idx < n * LDB; idx += NT) {
         const int j = idx / LDB, t = idx % LDB;
         const int i = j + t;
         B.p[idx] = (t <= SB && i < n) ? A[(size_t)j * n + i] : 0.0;
     }
-    // Schedule: step q of sweep s runs at time start[s] + q, wavefront s mod CH_NW.  Sweep
-    // s + 1 must stay two steps behind sweep s (its block q overlaps blocks q, q + 1 of s), and
-    // a wavefront must have finished sweep s - CH_NW.  The sweeps get shorter, so the spacing
-    // drops to the minimum of 2 once CH_NW sweeps in flight cover a whole sweep.
+    // Schedule: step q of sweep s runs at time start[s] + q on slot s mod NSLOT.  Sweep s + 1 must
+    // stay two steps behind sweep s (its block q overlaps blocks q, q + 1 of s), and a slot must
+    // have finished sweep s - NSLOT.  The sweeps get shorter, so the spacing drops to the minimum
+    // of 2 once NSLOT sweeps in flight cover a whole sweep.
     if (tid == 0) {
         int run = 0;
         for (int s = 0; s < n; ++s) {
             cum[s] = run;
             if (s <= n - 3) run += chase_steps(n, s);
             int st = (s == 0) ? 0 : start[s - 1] + 2;
-            if (s >= CH_NW) st = max(st, start[s - CH_NW] + chase_steps(n, s - CH_NW));
+            if (s >= NSLOT) st = max(st, start[s - NSLOT] + chase_steps(n, s - NSLOT));
             start[s] = st;
         }
         cum[n] = run;
@@ -1127,24 +1137,24 @@ __global__ __launch_bounds__(CH_NT) void band_chase_kernel(
     if (n >= 3) {
         const int nsweeps = n - 2;
         const int tend = start[nsweeps - 1] + chase_steps(n, nsweeps - 1);
-        double *myhand = hand + wave * HAND;
-        int s = wave;                               // the sweep this wavefront works on
+        double *myhand = hand + slot * HAND;
+        int s = slot;                               // the sweep this slot works on
         int s_begin = 0, s_end = 0;
         if (s < nsweeps) { s_begin = start[s]; s_end = s_begin + chase_steps(n, s); }
         for (int t = 0; t < tend; ++t) {
             if (s < nsweeps && t >= s_end) {
-                s += CH_NW;
+                s += NSLOT;
                 if (s < nsweeps) { s_begin = start[s]; s_end = s_begin + chase_steps(n, s); }
             }
             if (s < nsweeps && t >= s_begin) {
                 const int q = t - s_begin;
                 const int rid = cum[s] + q;
-                chase_step(B, n, s, q, myhand, RV + (size_t)rid * SB, RT + rid, lane);
+                chase_step<NCQ>(B, n, s, q, myhand, RV + (size_t)rid * SB, RT + rid, lane);
             }
             __syncthreads();
         }
     }
-    for (int i = tid; i < n; i += CH_NT) {
+    for (int i = tid; i < n; i += NT) {
         d[i] = B(i, i);
         e[i] = (i + 1 < n) ? B(i + 1, i) : 0.0;
     }
@@ -1265,14 +1275,43 @@ int64_t chase_reflector_count(int n) {
     return r;
 }
 
+// Lanes per chase step and threads per matrix (SAAMGE_AMD_CHASE="ncq,nt" overrides; ncq = 4 | 2
+// column groups of 16 lanes per step, nt / (16 ncq) sweeps in flight).  Measured at 128^3
+// (n = 405, 8 192 matrices): 64 lanes per step 42.9 ms, 32 lanes 70.2 ms, 16 lanes 96 ms, and
+// 32 slots instead of 16 do not help the 2 600-row level-1 matrices either (80 vs 60 ms): a step
+// is a chain of ~180 dependent operations (LDS round trips, 64-bit DPP sums, the reflector's
+// rsq / rcp), and spreading a step over more lanes shortens that chain -- fewer lanes per step
+// save instructions but the kernel is bound by the chain, not by issue slots.
+struct ChaseConfig {
+    int ncq, nt;
+    int slots() const { return nt / (16 * ncq); }
+};
+static ChaseConfig chase_config(int nmax) {
+    static const ChaseConfig forced = []() {
+        ChaseConfig c{0, 0};
+        const char *e = std::getenv("SAAMGE_AMD_CHASE");
+        if (e && std::sscanf(e, "%d,%d", &c.ncq, &c.nt) == 2) {
+            const bool ok = (c.ncq == 4 && c.nt == 1024) || (c.ncq == 2 && (c.nt == 512 || c.nt == 1024));
+            if (!ok) c = ChaseConfig{0, 0};
+        }
+        return c;
+    }();
+    if (forced.ncq) return forced;
+    // a sweep of n rows keeps ~n / 32 sweeps in flight at the minimum spacing of two steps
+    return ChaseConfig{4, 1024};
+}
+
 void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
     if (!b.count) return;
     static bool attr = false;
     if (!attr) {
-        SA_HIP_CHECK(hipFuncSetAttribute((const void *)band_chase_kernel<true>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        SA_HIP_CHECK(hipFuncSetAttribute((const void *)band_chase_kernel<false>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define SA_CHASE_ATTR(L, Q, T)                                                              \
+    SA_HIP_CHECK(hipFuncSetAttribute((const void *)band_chase_kernel<L, Q, T>,                 \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+        SA_CHASE_ATTR(true, 4, 1024); SA_CHASE_ATTR(false, 4, 1024);
+        SA_CHASE_ATTR(true, 2, 512); SA_CHASE_ATTR(false, 2, 512);
+        SA_CHASE_ATTR(true, 2, 1024); SA_CHASE_ATTR(false, 2, 1024);
+#undef SA_CHASE_ATTR
         SA_HIP_CHECK(hipFuncSetAttribute((const void *)backtransform2_kernel<256>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SA_HIP_CHECK(hipFuncSetAttribute((const void *)backtransform2_kernel<1024>,
@@ -1287,7 +1326,7 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
     for (int i = 0; i < b.count; ++i) b.h_roff[i + 1] = b.h_roff[i] + chase_reflector_count(b.h_n[i]);
     const size_t nrefl = (size_t)b.h_roff[b.count];
     const int nmax0 = b.max_n;
-    const size_t fixed0 = sizeof(double) * (CH_NW * HAND) + sizeof(int) * (2 * (size_t)nmax0 + 4);
+    const size_t fixed0 = sizeof(double) * (chase_config(nmax0).slots() * HAND) + sizeof(int) * (2 * (size_t)nmax0 + 4);
     const bool in_lds0 = fixed0 + sizeof(double) * (size_t)nmax0 * LDB + 64 <= 160 * 1024;
     b.h_goff.assign((size_t)b.count + 1, 0);
     for (int i = 0; i < b.count; ++i)
@@ -1440,18 +1479,26 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
     }
     if (!(phases & 2)) return;
     // ---- stage 2 ----
-    const size_t fixed = sizeof(double) * (CH_NW * HAND) + sizeof(int) * (2 * (size_t)nmax + 4);
+    const ChaseConfig cc = chase_config(nmax);
+    const size_t fixed = sizeof(double) * (cc.slots() * HAND) + sizeof(int) * (2 * (size_t)nmax + 4);
     const size_t band_bytes = sizeof(double) * (size_t)nmax * LDB;
     const int in_lds = (fixed + band_bytes + 64 <= 160 * 1024) ? 1 : 0;
     double cflops = 0.0;
     for (int n : b.h_n) cflops += 6.0 * (double)n * n * SB;
     profiler().begin(s);
-    if (in_lds)
-        hipLaunchKernelGGL(band_chase_kernel<true>, dim3(b.count), dim3(CH_NT), fixed + band_bytes + 64, s, b.n.p,
-                           b.moff.p, b.voff.p, b.roff.p, b.W.p, b.bandg.p, in_lds, b.d.p, b.e.p, b.rv.p, b.rtau.p);
-    else
-        hipLaunchKernelGGL(band_chase_kernel<false>, dim3(b.count), dim3(CH_NT), fixed + 64, s, b.n.p, b.moff.p,
-                           b.voff.p, b.roff.p, b.W.p, b.bandg.p, in_lds, b.d.p, b.e.p, b.rv.p, b.rtau.p);
+#define SA_CHASE(Q, T)                                                                                          \
+    if (cc.ncq == Q && cc.nt == T) {                                                                            \
+        if (in_lds)                                                                                             \
+            hipLaunchKernelGGL((band_chase_kernel<true, Q, T>), dim3(b.count), dim3(T), fixed + band_bytes + 64, s, \
+                               b.n.p, b.moff.p, b.voff.p, b.roff.p, b.W.p, b.bandg.p, in_lds, b.d.p, b.e.p,     \
+                               b.rv.p, b.rtau.p);                                                               \
+        else                                                                                                    \
+            hipLaunchKernelGGL((band_chase_kernel<false, Q, T>), dim3(b.count), dim3(T), fixed + 64, s, b.n.p,  \
+                               b.moff.p, b.voff.p, b.roff.p, b.W.p, b.bandg.p, in_lds, b.d.p, b.e.p, b.rv.p,    \
+                               b.rtau.p);                                                                       \
+    }
+    SA_CHASE(4, 1024) SA_CHASE(2, 512) SA_CHASE(2, 1024)
+#undef SA_CHASE
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "eig_band_chase", 0.0, cflops);
 }
