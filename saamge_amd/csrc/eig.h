@@ -22,7 +22,8 @@ struct EigBatch {
     DBuf<double> panel;     // [sum n_i * EIG_NB] W-panel of the blocked reduction
     DBuf<double> d, e, tau; // [sum n_i] tridiagonal + reflector scalars
     DBuf<double> dis;       // [sum n_i] D^-1/2 (row scaling applied to the vectors)
-    DBuf<int> m, j0;        // [count] number of wanted pairs, index of the first
+    DBuf<int> m, j0;        // [count] number of wanted pairs, index of the first (-1: nothing in (vl, vu], smallest pair)
+    double vl = 0.0, vu = 0.0;   // the window eig_count was called with (eig_vectors selects per decoupled block)
     // two-stage reduction (eig2.hip)
     bool two_stage = false;
     DBuf<double> Tfac;      // [sum n_i * SB] compact-WY T factors, one SB x SB block per panel

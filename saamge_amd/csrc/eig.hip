@@ -22,6 +22,7 @@ namespace saamge_amd {
 
 constexpr int TRI_NT = 1024;  // threads per workgroup in phase 1 (16 wavefronts)
 constexpr int VEC_NT = 256;   // threads per workgroup in phase 3
+constexpr int VEC_MAXB = 254; // decoupled blocks of one tridiagonal handled separately (more: one last block)
 
 __device__ inline double wave_sum(double v) {
 #pragma unroll
@@ -252,6 +253,11 @@ __device__ inline int sturm_count(int n, const double *d, const double *e, doubl
     return cnt;
 }
 
+// dstebz's splitting criterion: e_i^2 <= ulp^2 |d_i d_{i+1}| + safmin decouples the tridiagonal
+__device__ inline bool negligible_offdiag(double di, double dn, double ei) {
+    return fabs(di * dn) * (DBL_EPSILON * DBL_EPSILON) + DBL_MIN > ei * ei;
+}
+
 __global__ __launch_bounds__(64) void count_kernel(const int *__restrict__ ns,
                                                    const int64_t *__restrict__ voff,
                                                    const double *__restrict__ dd,
@@ -275,6 +281,9 @@ __global__ __launch_bounds__(64) void count_kernel(const int *__restrict__ ns,
     for (int o = 32; o > 0; o >>= 1) emax = fmax(emax, __shfl_xor(emax, o, 64));
     __syncthreads();
     const double pivmin = DBL_MIN * fmax(1.0, emax);
+    for (int i = lane; i + 1 < n; i += 64)      // the splits of dstebz, as in eigvec_kernel
+        if (negligible_offdiag(d[i], d[i + 1], e[i])) e[i] = 0.0;
+    __syncthreads();
     int cnt = 0;
     if (lane < 2) cnt = sturm_count(n, d, e, lane == 0 ? vl : vu, pivmin);
     const int cl = __shfl(cnt, 0, 64), cu = __shfl(cnt, 1, 64);
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(64) void count_kernel(const int *__restrict__ ns,
         int m = cu - cl, j0 = cl;
         if (m <= 0) {  // "atleast_one": the single smallest eigenpair (range 'I', il=iu=1)
             m = 1;
-            j0 = 0;
+            j0 = -1;   // flag for eigvec_kernel
         }
         m_out[b] = m;
         j0_out[b] = j0;
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
     const double *__restrict__ Wm, const double *__restrict__ dd, const double *__restrict__ ee,
     const double *__restrict__ tt, const double *__restrict__ dis, const int *__restrict__ ms,
     const int *__restrict__ j0s, const int64_t *__restrict__ eoff, const int64_t *__restrict__ xoff,
-    double *__restrict__ evals, double *__restrict__ evecs, int do_backtransform) {
+    double *__restrict__ evals, double *__restrict__ evecs, int do_backtransform, double vl, double vu) {
     constexpr int NT = VEC_NT;
     constexpr int NW = NT / 64;
     extern __shared__ __align__(16) double lds[];
@@ -323,7 +332,12 @@ __global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
     double *ld2 = lc + n;   // [n] LU super 2
     double *z = ld2 + n;    // [n]
     double *red = z + n;    // [8]
-    int *pin = (int *)(red + 8);  // [n]
+    int *iscr = (int *)(red + 8);                         // [8]
+    unsigned short *oblk = (unsigned short *)(iscr + 8);  // [n] block of each output slot
+    unsigned short *bstart = oblk + n;                    // [VEC_MAXB + 2] first row of each block
+    unsigned short *bslot = bstart + VEC_MAXB + 2;        // [VEC_MAXB + 2] first output slot of each block
+    unsigned short *bclo = bslot + VEC_MAXB + 2;          // [VEC_MAXB + 2] local index of its first wanted pair
+    unsigned char *pin = (unsigned char *)(bclo + VEC_MAXB + 2);   // [n] LU row interchanges
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     double emax = 0.0, gl = DBL_MAX, gu = -DBL_MAX, onenrm = 0.0;
@@ -331,6 +345,13 @@ __global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
         d[i] = dd[vo + i];
         e[i] = ee[vo + i];
     }
+    __syncthreads();
+    // Splits (dstebz): a negligible off-diagonal decouples the matrix into blocks; eigenvalues and
+    // eigenvectors are computed block by block (dstebz order 'B' + dstein), which is what keeps
+    // inverse iteration well defined when decoupled blocks share eigenvalues (e.g. an agglomerate
+    // made of identical disconnected pieces: one 30-fold eigenvalue, 30 blocks).
+    for (int i = tid; i + 1 < n; i += NT)
+        if (negligible_offdiag(d[i], d[i + 1], e[i])) e[i] = 0.0;
     __syncthreads();
     for (int i = tid; i < n; i += NT) {
         const double el = (i > 0) ? fabs(e[i - 1]) : 0.0, er = (i < n - 1) ? fabs(e[i]) : 0.0;
@@ -361,16 +382,77 @@ __global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
     gl -= 2.1 * tnorm * ulp * n + 2.1 * pivmin;
     gu += 2.1 * tnorm * ulp * n + 2.1 * pivmin;
 
-    // ---- A: eigenvalues j0 .. j0+m-1 by 64-way multisection, one wavefront each ----
-    for (int jj = wave; jj < m; jj += NW) {
-        const int want = j0 + jj;  // count(lo) <= want < count(hi)
+    // ---- blocks and the wanted local index range of each ----
+    if (tid == 0) iscr[2] = 0;
+    __syncthreads();
+    for (int i = tid; i + 1 < n; i += NT)
+        if (e[i] == 0.0) iscr[2] = 1;        // (benign race: every writer stores the same value)
+    __syncthreads();
+    const int any_split = iscr[2];
+    if (tid == 0) {
+        int nb = 0;
+        bstart[0] = 0;
+        if (any_split)
+            for (int i = 0; i + 1 < n; ++i)
+                if (e[i] == 0.0 && nb < VEC_MAXB - 1) bstart[++nb] = (unsigned short)(i + 1);   // (beyond VEC_MAXB: one last block)
+        ++nb;
+        bstart[nb] = (unsigned short)n;
+        iscr[0] = nb;
+        if (nb == 1) {      // the usual case: the window of the whole matrix is the one of count_kernel
+            bclo[0] = (unsigned short)max(j0, 0);
+            bslot[0] = (unsigned short)m;
+        }
+    }
+    __syncthreads();
+    const int nb = iscr[0];
+    const bool smallest_only = j0 < 0;      // nothing in (vl, vu]: the smallest eigenpair of the matrix
+    if (wave == 0 && nb > 1) {
+        // counts of every block at vl / vu (lane pairs: block = lane >> 1)
+        for (int b0 = 0; b0 < nb; b0 += 32) {
+            const int bq = b0 + (lane >> 1);
+            int c = 0;
+            if (bq < nb && !smallest_only) {
+                const int bs = bstart[bq], len = bstart[bq + 1] - bs;
+                c = sturm_count(len, d + bs, e + bs, (lane & 1) ? vu : vl, pivmin);
+            }
+            const int cu = __shfl_down(c, 1, 64);
+            if (bq < nb && !(lane & 1)) {
+                bclo[bq] = (unsigned short)c;
+                bslot[bq] = (unsigned short)(smallest_only ? 1 : max(cu - c, 0));   // count for now
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {      // exclusive scan of the per-block counts -> first output slot
+        int run = 0;
+        for (int bq = 0; bq < nb; ++bq) {
+            const int c = bslot[bq];
+            bslot[bq] = (unsigned short)run;
+            run += c;
+        }
+        bslot[nb] = (unsigned short)run;
+        iscr[1] = run;
+    }
+    __syncthreads();
+    // number of (block, local index) candidates: m in window mode, one per block otherwise
+    const int ncand = smallest_only ? nb : min(iscr[1], m);
+    for (int bq = tid; bq < nb; bq += NT)
+        for (int sl = bslot[bq]; sl < bslot[bq + 1] && sl < n; ++sl) oblk[sl] = (unsigned short)bq;
+    __syncthreads();
+
+    // ---- A: the wanted eigenvalues of every block by 64-way multisection, one wavefront each ----
+    // (smallest-only mode: the smallest eigenvalue of every block goes to z[], the minimum wins)
+    for (int sl = wave; sl < ncand; sl += NW) {
+        const int bq = oblk[sl];
+        const int bs = bstart[bq], len = bstart[bq + 1] - bs;
+        const int want = smallest_only ? 0 : bclo[bq] + (sl - bslot[bq]);  // count(lo) <= want < count(hi)
         double lo = gl, hi = gu;
         for (int it = 0; it < 40; ++it) {
             const double width = hi - lo;
             const double tol = fmax(2.0 * ulp * fmax(fabs(lo), fabs(hi)), pivmin);
             if (width <= tol) break;
             const double x = lo + width * ((double)(lane + 1) / 65.0);
-            const int c = sturm_count(n, d, e, x, pivmin);
+            const int c = sturm_count(len, d + bs, e + bs, x, pivmin);
             const unsigned long long ge = __ballot(c >= want + 1);
             double nlo = lo, nhi = hi;
             if (ge == 0ull) {
@@ -384,64 +466,81 @@ __global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
             lo = nlo;
             hi = nhi;
         }
-        if (lane == 0) lam[jj] = 0.5 * (lo + hi);
+        if (lane == 0) {
+            if (smallest_only) z[sl] = 0.5 * (lo + hi);
+            else lam[sl] = 0.5 * (lo + hi);
+        }
     }
     __syncthreads();
+    if (smallest_only) {
+        if (tid == 0) {
+            int best = 0;
+            for (int bq = 1; bq < nb; ++bq)
+                if (z[bq] < z[best]) best = bq;
+            lam[0] = z[best];
+            oblk[0] = (unsigned short)best;
+            bclo[best] = 0;
+            bslot[best] = 0;
+        }
+        __syncthreads();
+    }
+    const int mout = smallest_only ? 1 : ncand;    // == m
 
-    // ---- B: inverse iteration (dstein), vectors stored in Y (unit 2-norm) ----
+    // ---- B: inverse iteration (dstein) block by block, vectors stored in Y (unit 2-norm) ----
     const double eps = ulp;
     const double ortol = 1e-3 * onenrm;
-    const double dtpcrt = sqrt(0.1 / (double)n);
     double xjm = 0.0;
     int gpind = 0;
-    for (int jj = 0; jj < m; ++jj) {
+    for (int jj = 0; jj < mout; ++jj) {
+        const int bq = oblk[jj];
+        const int bs = bstart[bq], nl = bstart[bq + 1] - bs;     // block rows [bs, bs + nl)
+        const bool first_in_block = smallest_only || jj == bslot[bq];
+        const double *db = d + bs, *eb = e + bs;
+        const double dtpcrt = sqrt(0.1 / (double)nl);
         double xj = lam[jj];
-        if (jj > 0) {
+        if (!first_in_block) {
             const double pertol = 10.0 * fabs(eps * xj);
             if (xj - xjm < pertol) xj = xjm + pertol;
         }
         double *Yj = Y + (size_t)jj * n;
-        if (n == 1) {
-            if (tid == 0) Yj[0] = 1.0;
+        for (int i = tid; i < n; i += NT) Yj[i] = 0.0;
+        if (nl == 1) {
+            if (tid == 0) Yj[bs] = 1.0;
             xjm = xj;
             __syncthreads();
             continue;
         }
-        for (int i = tid; i < n; i += NT) z[i] = unit_rand((unsigned)i, (unsigned)(jj + 1));
+        for (int i = tid; i < nl; i += NT) z[i] = unit_rand((unsigned)(bs + i), (unsigned)(jj + 1));
         // dlagtf: LU of T - xj I with partial pivoting (sequential, thread 0)
         if (tid == 0) {
-            for (int i = 0; i < n; ++i) {
-                la[i] = d[i] - xj;
-                if (i < n - 1) { lb[i] = e[i]; lc[i] = e[i]; }
+            for (int i = 0; i < nl; ++i) {
+                la[i] = db[i] - xj;
+                if (i < nl - 1) { lb[i] = eb[i]; lc[i] = eb[i]; }
             }
-            pin[n - 1] = 0;
-            const double tl = eps;
             double scale1 = fabs(la[0]) + fabs(lb[0]);
-            for (int k = 0; k < n - 1; ++k) {
+            for (int k = 0; k < nl - 1; ++k) {
                 double scale2 = fabs(lc[k]) + fabs(la[k + 1]);
-                if (k < n - 2) scale2 += fabs(lb[k + 1]);
+                if (k < nl - 2) scale2 += fabs(lb[k + 1]);
                 const double piv1 = (la[k] == 0.0) ? 0.0 : fabs(la[k]) / scale1;
-                double piv2;
                 if (lc[k] == 0.0) {
                     pin[k] = 0;
-                    piv2 = 0.0;
                     scale1 = scale2;
-                    if (k < n - 2) ld2[k] = 0.0;
+                    if (k < nl - 2) ld2[k] = 0.0;
                 } else {
-                    piv2 = fabs(lc[k]) / scale2;
+                    const double piv2 = fabs(lc[k]) / scale2;
                     if (piv2 <= piv1) {
                         pin[k] = 0;
                         scale1 = scale2;
                         lc[k] = lc[k] / la[k];
                         la[k + 1] -= lc[k] * lb[k];
-                        if (k < n - 2) ld2[k] = 0.0;
+                        if (k < nl - 2) ld2[k] = 0.0;
                     } else {
                         pin[k] = 1;
                         const double mult = la[k] / lc[k];
                         la[k] = lc[k];
                         const double temp = la[k + 1];
                         la[k + 1] = lb[k] - mult * temp;
-                        if (k < n - 2) {
+                        if (k < nl - 2) {
                             ld2[k] = lb[k + 1];
                             lb[k + 1] = -mult * ld2[k];
                         }
@@ -449,17 +548,15 @@ __global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
                         lc[k] = mult;
                     }
                 }
-                if (fmax(piv1, piv2) <= tl && pin[n - 1] == 0) pin[n - 1] = k + 1;
             }
-            if (fabs(la[n - 1]) <= scale1 * tl && pin[n - 1] == 0) pin[n - 1] = n;
         }
         __syncthreads();
         // dlagts tolerance
         double tolp = 0.0;
-        for (int i = tid; i < n; i += NT) {
+        for (int i = tid; i < nl; i += NT) {
             double t = fabs(la[i]);
-            if (i < n - 1) t = fmax(t, fabs(lb[i]));
-            if (i < n - 2) t = fmax(t, fabs(ld2[i]));
+            if (i < nl - 1) t = fmax(t, fabs(lb[i]));
+            if (i < nl - 2) t = fmax(t, fabs(ld2[i]));
             tolp = fmax(tolp, t);
         }
         {
@@ -473,13 +570,13 @@ __global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
             tolp *= eps;
             if (tolp == 0.0) tolp = eps;
         }
-        if (jj > 0 && fabs(xj - xjm) > ortol) gpind = jj;
-        if (jj == 0) gpind = 0;
+        if (first_in_block) gpind = jj;
+        else if (fabs(xj - xjm) > ortol) gpind = jj;
         int nrmchk = 0;
         for (int its = 0; its < 5; ++its) {
             // scale the right-hand side
             double zmax = 0.0;
-            for (int i = tid; i < n; i += NT) zmax = fmax(zmax, fabs(z[i]));
+            for (int i = tid; i < nl; i += NT) zmax = fmax(zmax, fabs(z[i]));
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) zmax = fmax(zmax, __shfl_xor(zmax, o, 64));
             __syncthreads();
@@ -487,12 +584,12 @@ __global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
             __syncthreads();
             zmax = red[0];
             for (int w2 = 1; w2 < NW; ++w2) zmax = fmax(zmax, red[w2]);
-            const double scl = (double)n * onenrm * fmax(eps, fabs(la[n - 1])) / zmax;
-            for (int i = tid; i < n; i += NT) z[i] *= scl;
+            const double scl = (double)nl * onenrm * fmax(eps, fabs(la[nl - 1])) / zmax;
+            for (int i = tid; i < nl; i += NT) z[i] *= scl;
             __syncthreads();
             // dlagts job = -1 (sequential, thread 0)
             if (tid == 0) {
-                for (int k = 1; k < n; ++k) {
+                for (int k = 1; k < nl; ++k) {
                     if (pin[k - 1] == 0) {
                         z[k] -= lc[k - 1] * z[k - 1];
                     } else {
@@ -502,10 +599,10 @@ __global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
                     }
                 }
                 const double sfmin = DBL_MIN, bignum = 1.0 / DBL_MIN;
-                for (int k = n - 1; k >= 0; --k) {
+                for (int k = nl - 1; k >= 0; --k) {
                     double temp;
-                    if (k <= n - 3) temp = z[k] - lb[k] * z[k + 1] - ld2[k] * z[k + 2];
-                    else if (k == n - 2) temp = z[k] - lb[k] * z[k + 1];
+                    if (k <= nl - 3) temp = z[k] - lb[k] * z[k + 1] - ld2[k] * z[k + 2];
+                    else if (k == nl - 2) temp = z[k] - lb[k] * z[k + 1];
                     else temp = z[k];
                     double ak = la[k];
                     double pert = copysign(tolp, ak);
@@ -533,17 +630,17 @@ __global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
                 }
             }
             __syncthreads();
-            // re-orthogonalise against the cluster (modified Gram-Schmidt)
+            // re-orthogonalise against the cluster (modified Gram-Schmidt; same block)
             for (int g = gpind; g < jj; ++g) {
-                const double *Yg = Y + (size_t)g * n;
+                const double *Yg = Y + (size_t)g * n + bs;
                 double s = 0.0;
-                for (int i = tid; i < n; i += NT) s = fma(z[i], Yg[i], s);
+                for (int i = tid; i < nl; i += NT) s = fma(z[i], Yg[i], s);
                 s = block_sum<NT>(s, red);
-                for (int i = tid; i < n; i += NT) z[i] = fma(-s, Yg[i], z[i]);
+                for (int i = tid; i < nl; i += NT) z[i] = fma(-s, Yg[i], z[i]);
                 __syncthreads();
             }
             double nrm = 0.0;
-            for (int i = tid; i < n; i += NT) nrm = fmax(nrm, fabs(z[i]));
+            for (int i = tid; i < nl; i += NT) nrm = fmax(nrm, fabs(z[i]));
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) nrm = fmax(nrm, __shfl_xor(nrm, o, 64));
             __syncthreads();
@@ -557,8 +654,8 @@ __global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
         }
         // normalise: unit 2-norm, largest component positive
         double s2 = 0.0, amax = 0.0;
-        int imax = n;
-        for (int i = tid; i < n; i += NT) {
+        int imax = nl;
+        for (int i = tid; i < nl; i += NT) {
             s2 = fma(z[i], z[i], s2);
             if (fabs(z[i]) > amax) { amax = fabs(z[i]); imax = i; }
         }
@@ -572,20 +669,40 @@ __global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
         __syncthreads();
         gm = red[0];
         for (int w2 = 1; w2 < NW; ++w2) gm = fmax(gm, red[w2]);
-        int cand = (amax == gm) ? imax : n;
+        int cand = (amax == gm) ? imax : nl;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
         __syncthreads();
-        if (lane == 0) pin[wave] = cand;  // pin is free now
+        if (lane == 0) iscr[wave] = cand;
         __syncthreads();
-        cand = pin[0];
-        for (int w2 = 1; w2 < NW; ++w2) cand = min(cand, pin[w2]);
+        cand = iscr[0];
+        for (int w2 = 1; w2 < NW; ++w2) cand = min(cand, iscr[w2]);
         double sc = 1.0 / sqrt(s2);
         if (z[cand] < 0.0) sc = -sc;
         __syncthreads();
-        for (int i = tid; i < n; i += NT) Yj[i] = z[i] * sc;
+        for (int i = tid; i < nl; i += NT) Yj[bs + i] = z[i] * sc;
         xjm = xj;
         __syncthreads();
+    }
+    // ---- ascending eigenvalues across the blocks (dsyevx's final selection sort, pairs move together) ----
+    if (nb > 1 && mout > 1) {
+        for (int i = 0; i < mout - 1; ++i) {
+            int k = i;
+            double lk = lam[i];
+            for (int j = i + 1; j < mout; ++j)
+                if (lam[j] < lk) { k = j; lk = lam[j]; }
+            __syncthreads();               // everyone has read lam before it changes
+            if (k != i) {
+                double *Yi = Y + (size_t)i * n, *Yk = Y + (size_t)k * n;
+                for (int r = tid; r < n; r += NT) {
+                    const double t = Yi[r];
+                    Yi[r] = Yk[r];
+                    Yk[r] = t;
+                }
+                if (tid == 0) { lam[k] = lam[i]; lam[i] = lk; }
+            }
+            __syncthreads();
+        }
     }
 
     if (!do_backtransform) return;  // two-stage path: eig2.hip applies Q1 Q2 and the row scaling
@@ -703,7 +820,10 @@ void eig_batch_two_stage_buffers(EigBatch &b, size_t nrefl, bool need_bandg, hip
 }
 
 static size_t tri_lds_bytes(int n) { return sizeof(double) * (2 * (size_t)n + TRI_NT + 2 * EIG_NB + TRI_NT / 64); }
-static size_t vec_lds_bytes(int n) { return sizeof(double) * (7 * (size_t)n + 8) + sizeof(int) * ((size_t)n + 8); }
+static size_t vec_lds_bytes(int n) {
+    return sizeof(double) * (7 * (size_t)n + 8) + sizeof(int) * 8 + sizeof(unsigned short) * ((size_t)n + 3 * (VEC_MAXB + 2)) +
+           (size_t)n + 64;
+}
 constexpr size_t LDS_MAX = 160 * 1024;
 
 size_t eig_workspace_bytes(int n) {
@@ -761,6 +881,8 @@ void eig_count(hipStream_t s, EigBatch &b, double vl, double vu) {
                        b.e.p, vl, vu, b.m.p, b.j0.p);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "eig_count", 0.0, 0.0);
+    b.vl = vl;
+    b.vu = vu;
     { auto t_ = b.m.to_host(s); b.h_m.assign(t_.begin(), t_.end()); }
 }
 
@@ -774,7 +896,7 @@ void eig_vectors(hipStream_t s, EigBatch &b, const int64_t *eoff, const int64_t 
     profiler().begin(s);
     hipLaunchKernelGGL(eigvec_kernel, dim3(b.count), dim3(VEC_NT), lds, s, b.n.p, b.moff.p,
                        b.voff.p, b.W.p, b.d.p, b.e.p, b.tau.p, b.dis.p, b.m.p, b.j0.p, eoff, xoff,
-                       evals, evecs, b.two_stage ? 0 : 1);
+                       evals, evecs, b.two_stage ? 0 : 1, b.vl, b.vu);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "eig_vectors", 0.0, flops);
     if (b.two_stage) eig_backtransform_two_stage(s, b, xoff, evecs);

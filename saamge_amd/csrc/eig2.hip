@@ -987,6 +987,15 @@ __device__ inline void chase_step(const BandRef &B, int n, int s, int q, double 
     const int i0 = s + 1 + q * SB;              // first row of I_q
     const int L = min(SB, n - i0);              // |I_q| >= 1
     double vr = 0.0, tau = 0.0;                 // new reflector (entry r), built below
+    // The diagonal block D = A[I_q, I_q] is not touched before its own update at the end of the
+    // step: request it now, so that its LDS round trip overlaps the work on C (the step is a
+    // chain of dependent operations; every exposed round trip counts).
+    double dv[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int c = CPL * cq + k;
+        dv[k] = (r < L && c < L) ? B.sym(i0 + r, i0 + c) : 0.0;
+    }
     if (q == 0) {
         // eliminate column s below its first sub-diagonal entry
         const double x = (r < L) ? B(i0 + r, s) : 0.0;
@@ -1057,13 +1066,11 @@ __device__ inline void chase_step(const BandRef &B, int n, int s, int q, double 
     wave_lds_fence();
     // two-sided update of the diagonal block D = A[I_q, I_q] (lower part stored)
     if (tau != 0.0) {
-        double dv[CPL], vc[CPL];
+        double vc[CPL];
         double p = 0.0;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
-            const int c = CPL * cq + k;
-            vc[k] = sv[c];
-            dv[k] = (r < L && c < L) ? B.sym(i0 + r, i0 + c) : 0.0;
+            vc[k] = sv[CPL * cq + k];
             p = fma(dv[k], vc[k], p);
         }
         p = rowsum(p);
@@ -1342,14 +1349,14 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
     const bool prof = profiler().enabled;
     // algorithmic bytes of the product / update / fused kernels (trailing matrix read once by
     // the product; read + written once by the update, also when the next product rides on it)
-    double sbytes = 0.0, ubytes = 0.0, fbytes = 0.0;
+    double sbytes = 0.0, ubytes = 0.0;
     if (prof) {
         for (int n : b.h_n)
             for (int k0 = 0; n - k0 - SB >= 2; k0 += SB) {
                 const double np = n - k0 - SB, npn = std::max(0.0, np - SB);
                 sbytes += 8.0 * np * np;
                 ubytes += 16.0 * np * np;
-                fbytes += 16.0 * npn * npn;
+                (void)npn;
             }
     }
     // SAAMGE_AMD_EIG_FUSED: 0 = separate product / update kernels, 1 (default) = fused, vector

@@ -127,6 +127,29 @@ def test_batched_eigens_degenerate_and_split():
     assert len(w) == 1 and np.allclose(w, wr, atol=1e-12)
 
 
+def test_batched_eigens_many_identical_blocks():
+    """An agglomerate made of 32 identical disconnected pieces (randomly permuted): 32-fold
+    eigenvalues.  The tridiagonal decouples into blocks sharing their spectra; eigenvectors are
+    computed block by block like dstebz + dstein do (one undivided inverse iteration loses
+    directions of such a cluster)."""
+    capi, o = _capi(), _oracle()
+    rng = np.random.default_rng(11)
+    Bk = np.array([[2.0, -1, 0, -1], [-1, 2, -1, 0], [0, -1, 2, -1], [-1, 0, -1, 2.0]]) + np.diag([0.0, 0.01, 0.02, 0.05])
+    L = np.kron(np.eye(32), Bk)
+    perm = rng.permutation(128)
+    L = L[np.ix_(perm, perm)]
+    D = o.snd_D_from_dense(L)
+    for theta in (0.02, 0.6):
+        (w, X), = capi.lower_eigens_batched([L], [D], -1.0, theta)
+        wr, Xr = o.lower_eigens_dense(L, D, theta)
+        assert len(w) == len(wr) and len(w) % 32 == 0
+        assert np.allclose(w, wr, atol=EIG_TOL) and np.all(np.diff(w) >= -1e-14)
+        assert np.allclose(X.T @ (D[:, None] * X), np.eye(len(w)), atol=1e-10)
+        R = L @ X - (D[:, None] * X) * w[None, :]
+        assert np.abs(R).max() <= 1e-10
+        assert np.allclose(_proj(X, D), _proj(Xr, D), atol=PROJ_TOL)
+
+
 def _range_projection(P, probe):
     """Orthogonal projection of `probe` onto range(P) (basis independent)."""
     G = (P.T @ P).toarray()
