@@ -224,20 +224,22 @@ __global__ __launch_bounds__(NT) void sbr_qr_kernel(int k0, const int *__restric
 }
 
 // Register-resident panel QR for np <= 512: thread t owns panel rows t and t + 256 (2 x SB
-// doubles in VGPRs).  Per column: one block reduction for the norm and ONE fused multi-dot
-// (the 15 products v_c . P(:, j)) -- 16-lane partial sums by DPP row rotations, the rest through
-// a small LDS buffer -- instead of one pass over LDS/global per column pair.
+// doubles in VGPRs).  Per column c ONE reduction round gives everything the column needs: the 16
+// raw products G_j = sum_{i > c} P(i, c) P(i, j) -- for j = c the squared norm below the diagonal,
+// for j > c the dots of the updates, for j < c (those columns hold V) the z of the T factor --
+// because the reflector is v = e_c + scale P(c+1:, c) with scale known only after the norm:
+// v . P(:, j) = P(c, j) + scale G_j.  Two barriers per column (partials -> G), the T column is a
+// 16 x 16 product spread over the workgroup instead of a serial chain on 16 threads.
 __global__ __launch_bounds__(256) void sbr_qr_reg_kernel(int k0, const int *__restrict__ ns,
                                                          const int64_t *__restrict__ moff,
                                                          const int64_t *__restrict__ voff,
                                                          double *__restrict__ Wm,
                                                          double *__restrict__ Tfac,
                                                          double *__restrict__ Vpk) {
-    __shared__ double red[4];
-    __shared__ double part[SB * 16];   // [j][row-of-16]
-    __shared__ double dots[SB];        // w_j (j > c) / z_j (j < c)
+    __shared__ double part[SB * 128];     // [j][pair of lanes]: partial products
+    __shared__ double Gs[2][SB];          // G_j, double-buffered by column parity
+    __shared__ double rowc[2][SB];        // row c of the panel, same
     __shared__ double Ts[SB * SB];
-    __shared__ double salpha;
     const int b = blockIdx.x;
     const int n = ns[b];
     const int np = n - k0 - SB;
@@ -255,16 +257,35 @@ __global__ __launch_bounds__(256) void sbr_qr_reg_kernel(int k0, const int *__re
     }
     for (int i = tid; i < SB * SB; i += 256) Ts[i] = 0.0;
     const int nref = min(SB, np - 1);
+    const int gj = tid >> 4, gk = tid & 15;      // reduction role: column gj, sixteenth gk
 #pragma unroll
     for (int c = 0; c < SB; ++c) {
         if (c < nref) {   // uniform: the loop stays fully unrolled, the panel stays in registers
-        // ---- Householder vector of column c ----
-        double ss = 0.0;
-        if (r0 > c) ss = p0[c] * p0[c];
-        ss = fma(p1[c], p1[c], ss);          // rows >= 256 > c; zero beyond np
-        if (tid == c) salpha = p0[c];
-        ss = bsum<256>(ss, red);             // contains the barriers that publish salpha
-        const double alpha = salpha;
+        const int pb = c & 1;
+        // ---- A: raw products of column c with every column over the rows below c ----
+        const double a0 = (r0 > c) ? p0[c] : 0.0;
+#pragma unroll
+        for (int j = 0; j < SB; ++j) {
+            double sj = fma(p1[c], p1[j], a0 * p0[j]);
+            sj += dpp_rot<0xB1>(sj);                 // quad_perm [1,0,3,2]: neighbouring lane
+            if (!(tid & 1)) part[j * 128 + (tid >> 1)] = sj;
+        }
+        if (r0 == c) {
+#pragma unroll
+            for (int j = 0; j < SB; ++j) rowc[pb][j] = p0[j];
+        }
+        __syncthreads();
+        // ---- B: G_j ----
+        {
+            const double *pp = part + gj * 128 + gk * 8;
+            double g = ((pp[0] + pp[1]) + (pp[2] + pp[3])) + ((pp[4] + pp[5]) + (pp[6] + pp[7]));
+            g = rsum16(g);
+            if (gk == 0) Gs[pb][gj] = g;
+        }
+        __syncthreads();
+        // ---- C: reflector, update of the columns to the right, column c of T ----
+        const double ss = Gs[pb][c];
+        const double alpha = rowc[pb][c];
         double tau = 0.0, beta = alpha, scale = 0.0;
         if (ss != 0.0) {
             beta = -copysign(fast_sqrt(fma(alpha, alpha, ss)), alpha);
@@ -272,53 +293,31 @@ __global__ __launch_bounds__(256) void sbr_qr_reg_kernel(int k0, const int *__re
             scale = fast_rcp(alpha - beta);
         }
         // v entries of my rows (v_c = 1 on row c, 0 above)
-        double v0 = (r0 > c) ? p0[c] * scale : ((r0 == c) ? 1.0 : 0.0);
-        double v1 = p1[c] * scale;
+        const double v0 = (r0 > c) ? p0[c] * scale : ((r0 == c) ? 1.0 : 0.0);
+        const double v1 = p1[c] * scale;
         if (r0 > c) p0[c] = v0;
         if (r0 == c) p0[c] = beta;
         p1[c] = v1;
         if (tau != 0.0) {
-            // ---- all dots v . P(:, j), j != c, at once ----
-#pragma unroll
-            for (int j = 0; j < SB; ++j) {
-                if (j == c) continue;
-                // for j < c the column holds V(:, j): rows <= j are not part of it (R entries)
-                double a0 = p0[j];
-                if (j < c && r0 <= j) a0 = (r0 == j) ? 1.0 : 0.0;
-                double s = fma(v1, p1[j], v0 * a0);
-                s = rsum16(s);
-                if ((tid & 15) == 0) part[j * 16 + (tid >> 4)] = s;
-            }
-            __syncthreads();
-            if (tid < SB) {
-                double s = 0.0;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) s += part[tid * 16 + q];
-                dots[tid] = s;
-            }
-            __syncthreads();
-            // ---- apply H_c to the columns right of c ----
 #pragma unroll
             for (int j = 0; j < SB; ++j) {
                 if (j <= c) continue;
-                const double tw = tau * dots[j];
+                const double tw = tau * fma(scale, Gs[pb][j], rowc[pb][j]);   // tau (v . P(:, j))
                 p0[j] = fma(-tw, v0, p0[j]);
                 p1[j] = fma(-tw, v1, p1[j]);
             }
         }
-        if (tid <= c) {  // T(0:c, c) = -tau T(0:c,0:c) z ; T(c,c) = tau
+        // T(0:c, c) = -tau T(0:c, 0:c) z, T(c, c) = tau (dlarft, forward columnwise); z_j = V(:, j) . v
+        {
+            const int i = gj, j = gk;
             double t = 0.0;
-            if (tid == c) {
-                t = tau;
-            } else if (tau != 0.0) {
-                for (int j = tid; j < c; ++j) t = fma(Ts[j * SB + tid], dots[j], t);
-                t = -tau * t;
-            }
-            Ts[c * SB + tid] = t;
+            if (tau != 0.0 && j >= i && j < c) t = Ts[j * SB + i] * fma(scale, Gs[pb][j], rowc[pb][j]);
+            t = rsum16(t);
+            if (j == 0 && i <= c) Ts[c * SB + i] = (i == c) ? tau : -tau * t;
         }
-        __syncthreads();
         }
     }
+    __syncthreads();
     for (int i = tid; i < SB * SB; i += 256) T[i] = Ts[i];
     double *Vp = Vpk + voff[b] * SB;
 #pragma unroll
