@@ -31,6 +31,16 @@ void ae_scale(hipStream_t s, EigBatch &batch, double *Dout);
 void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevElmats &el, int ae0,
               EigBatch &batch, bool scale, double *Dout);
 
+// Fine level, 8-dof elements: the sparse rows of the AE matrices of a chunk (RW slots per row at
+// rv / rc[(batch.voff[b] + row) * RW + slot], column -1 = empty).  false: not applicable.
+bool ae_sparse_rows(hipStream_t s, const DevRelations &rel, const DCsr &A, const DevElmats &el, int ae0,
+                    const EigBatch &batch, int &RW, const double *&rv, const short *&rc);
+// E_e from those rows (no dense AE matrix)
+void coarse_elmats_sparse(hipStream_t s, const DevRelations &rel, int ae0, const EigBatch &batch, int RW,
+                          const double *rv, const short *rc, const int *mis_k, const int64_t *mis_u_off,
+                          const double *mis_u, const int *colpos_ptr, const int *colpos, const int64_t *out_off,
+                          double *out, double *scratch, const int64_t *scratch_off);
+
 // Coarse element matrices E_e = P_loc^T A_e P_loc for AEs [ae0, ae0+count)
 // (ElementMatrixParallelCoarse::GetMatrix, amg/src/elmat.cpp:105-195).  batch.W must hold
 // the *unscaled* AE matrices.  Output row-major at out[out_off[e]], k_e x k_e.

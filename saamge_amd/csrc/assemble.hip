@@ -508,6 +508,33 @@ static int csr_max_row(hipStream_t s, const DCsr &A) {
     return m.to_host(s)[0];
 }
 
+// sparse rows of the AE matrices of one chunk (RW slots per row) into a grow-only buffer
+static void launch_rows8(hipStream_t s, const DevRelations &rel, const DCsr &A, const DevElmats &el, int ae0,
+                         const EigBatch &batch, int RW, const double *&rv, const short *&rc) {
+    static DBuf<double> g_rvals;
+    static DBuf<short> g_rcols;
+    const size_t need = (size_t)batch.h_voff[batch.count] * RW + 64;
+    if (g_rvals.n < need) { g_rvals.alloc(need + need / 8); g_rcols.alloc(need + need / 8); }
+    profiler().begin(s);
+    hipLaunchKernelGGL(ae_rows8_kernel, dim3(div_up((long)batch.max_n * RW, 256), batch.count), dim3(256), 0, s,
+                       ae0, RW, batch.n.p, batch.voff.p, rel.ae2d_I.p, rel.ae2d_J.p, rel.d2ae_I.p,
+                       rel.d2ae_J.p, rel.dof_id_inAE.p, rel.flags.p, rel.d2e_I.p, rel.d2e_J.p, rel.part.p,
+                       rel.e2d_J.p, el.val.p, A.rowptr.p, A.col.p, A.val.p, g_rvals.p, g_rcols.p);
+    SA_HIP_CHECK(hipGetLastError());
+    profiler().end(s, "ae_rows", 0.0, 0.0);
+    rv = g_rvals.p;
+    rc = g_rcols.p;
+}
+
+bool ae_sparse_rows(hipStream_t s, const DevRelations &rel, const DCsr &A, const DevElmats &el, int ae0,
+                    const EigBatch &batch, int &RW, const double *&rv, const short *&rc) {
+    if (!batch.count || el.algebraic || el.nde != 8 || batch.count > 65535 || batch.max_n > 32767) return false;
+    if (A.max_row < 0) A.max_row = csr_max_row(s, A);
+    RW = A.max_row;
+    launch_rows8(s, rel, A, el, ae0, batch, RW, rv, rc);
+    return true;
+}
+
 void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevElmats &el, int ae0,
               EigBatch &batch, bool scale, double *Dout) {
     if (!batch.count) return;
@@ -538,23 +565,9 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
         return;
     }
     const bool nde8 = el.nde == 8 && batch.count <= 65535;   // (grid.y of the rows kernel)
-    static DBuf<double> g_rvals;     // grow-only: sparse rows of the current chunk
-    static DBuf<short> g_rcols;
     const double *rv = nullptr;
     const short *rc = nullptr;
-    if (nde8) {
-        const size_t need = (size_t)batch.h_voff[batch.count] * RW + 64;
-        if (g_rvals.n < need) { g_rvals.alloc(need + need / 8); g_rcols.alloc(need + need / 8); }
-        profiler().begin(s);
-        hipLaunchKernelGGL(ae_rows8_kernel, dim3(div_up((long)batch.max_n * RW, 256), batch.count), dim3(256), 0, s,
-                           ae0, RW, batch.n.p, batch.voff.p, rel.ae2d_I.p, rel.ae2d_J.p, rel.d2ae_I.p,
-                           rel.d2ae_J.p, rel.dof_id_inAE.p, rel.flags.p, rel.d2e_I.p, rel.d2e_J.p, rel.part.p,
-                           rel.e2d_J.p, el.val.p, A->rowptr.p, A->col.p, A->val.p, g_rvals.p, g_rcols.p);
-        SA_HIP_CHECK(hipGetLastError());
-        profiler().end(s, "ae_rows", 0.0, 0.0);
-        rv = g_rvals.p;
-        rc = g_rcols.p;
-    }
+    if (nde8) launch_rows8(s, rel, *A, el, ae0, batch, RW, rv, rc);
     auto launch = [&](auto kern) {
         SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         hipLaunchKernelGGL(kern, dim3(batch.count), dim3(AB_NT), lds, s, ae0, RW, batch.n.p, batch.moff.p,
@@ -624,6 +637,106 @@ __global__ __launch_bounds__(ASM_NT) void coarse_elmat_kernel(
             E[(size_t)cp[v] * ke + col] = sum;
         }
     }
+}
+
+// The same from the SPARSE rows of A_e (fine level: ~27 entries per row instead of the dense
+// n x n image -- neither written nor read): T = A_e P_loc row by row (thread = row, entries
+// scattered into the k columns of the entry's MIS; no other thread touches the row), then
+// E = P_loc^T T as above.
+__global__ __launch_bounds__(ASM_NT) void coarse_elmat_sparse_kernel(
+    int ae0, int RW, const int *__restrict__ ns, const int64_t *__restrict__ voff,
+    const double *__restrict__ rvals, const short *__restrict__ rcols, const int *__restrict__ ae2mis_I,
+    const int *__restrict__ ae2mis_J, const int *__restrict__ ae_pair,
+    const int64_t *__restrict__ pair_loc_off, const int *__restrict__ pair_loc,
+    const int *__restrict__ mis2d_I, const int *__restrict__ mis_k,
+    const int64_t *__restrict__ mis_u_off, const double *__restrict__ mis_u,
+    const int *__restrict__ colpos_ptr, const int *__restrict__ colpos,
+    const int64_t *__restrict__ out_off, double *__restrict__ out,
+    double *__restrict__ scratch, const int64_t *__restrict__ scratch_off) {
+    extern __shared__ __align__(16) short dof_tq[];   // [2 n]: MIS slot of the AE and row in that MIS, per local dof
+    constexpr int MAXT = 64;                          // MISes of one AE kept in LDS (27 for a box of hexes)
+    __shared__ int tk[MAXT], tr[MAXT], tcp[MAXT];
+    __shared__ long long tu[MAXT];
+    const int b = blockIdx.x, e = ae0 + b, n = ns[b];
+    double *T = scratch + scratch_off[b];
+    double *E = out + out_off[e];
+    const int ke = (int)(sqrt((double)(out_off[e + 1] - out_off[e])) + 0.5);
+    const int tid = threadIdx.x;
+    const int mb = ae2mis_I[e], me = ae2mis_I[e + 1];
+    short *dof_t = dof_tq, *dof_q = dof_tq + n;
+    for (int t = mb + tid; t < me && t - mb < MAXT; t += ASM_NT) {
+        const int mis = ae2mis_J[t];
+        tk[t - mb] = mis_k[mis];
+        tr[t - mb] = mis2d_I[mis + 1] - mis2d_I[mis];
+        tu[t - mb] = mis_u_off[mis];
+        tcp[t - mb] = colpos_ptr[t];
+    }
+    for (int t = mb; t < me; ++t) {
+        const int mis = ae2mis_J[t];
+        const int r = mis2d_I[mis + 1] - mis2d_I[mis];
+        const int *loc = pair_loc + pair_loc_off[ae_pair[t]];
+        for (int q = tid; q < r; q += ASM_NT) {
+            dof_t[loc[q]] = (short)(t - mb);
+            dof_q[loc[q]] = (short)q;
+        }
+    }
+    for (size_t idx = tid; idx < (size_t)n * ke; idx += ASM_NT) T[idx] = 0.0;
+    __syncthreads();
+    const size_t rbase = (size_t)voff[b] * RW;
+    const bool cached = me - mb <= MAXT;
+    for (int i = tid; i < n; i += ASM_NT) {
+        const short *rc_i = rcols + rbase + (size_t)i * RW;
+        const double *rv_i = rvals + rbase + (size_t)i * RW;
+        for (int k = 0; k < RW; ++k) {
+            const int c = rc_i[k];
+            if (c < 0) continue;
+            const double v = rv_i[k];
+            const int tl = dof_t[c], q = dof_q[c];
+            int km, r, cpo;
+            long long uo;
+            if (cached) {
+                km = tk[tl]; r = tr[tl]; uo = tu[tl]; cpo = tcp[tl];
+            } else {
+                const int mis = ae2mis_J[mb + tl];
+                km = mis_k[mis]; r = mis2d_I[mis + 1] - mis2d_I[mis]; uo = mis_u_off[mis]; cpo = colpos_ptr[mb + tl];
+            }
+            const double *U = mis_u + uo + q;
+            const int *cp = colpos + cpo;
+            for (int w = 0; w < km; ++w) {
+                double *dst = T + (size_t)cp[w] * n + i;
+                *dst = fma(v, U[(size_t)w * r], *dst);
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = mb; t < me; ++t) {
+        const int mis = ae2mis_J[t], k = mis_k[mis];
+        if (k == 0) continue;
+        const int r = mis2d_I[mis + 1] - mis2d_I[mis];
+        const int *loc = pair_loc + pair_loc_off[ae_pair[t]];
+        const double *U = mis_u + mis_u_off[mis];
+        const int *cp = colpos + colpos_ptr[t];
+        for (int idx = tid; idx < k * ke; idx += ASM_NT) {
+            const int col = idx % ke, v = idx / ke;
+            double sum = 0.0;
+            for (int q = 0; q < r; ++q) sum = fma(U[(size_t)v * r + q], T[(size_t)col * n + loc[q]], sum);
+            E[(size_t)cp[v] * ke + col] = sum;
+        }
+    }
+}
+
+void coarse_elmats_sparse(hipStream_t s, const DevRelations &rel, int ae0, const EigBatch &batch, int RW,
+                          const double *rv, const short *rc, const int *mis_k, const int64_t *mis_u_off,
+                          const double *mis_u, const int *colpos_ptr, const int *colpos, const int64_t *out_off,
+                          double *out, double *scratch, const int64_t *scratch_off) {
+    if (!batch.count) return;
+    profiler().begin(s);
+    hipLaunchKernelGGL(coarse_elmat_sparse_kernel, dim3(batch.count), dim3(ASM_NT), 4 * (size_t)batch.max_n + 16, s,
+                       ae0, RW, batch.n.p, batch.voff.p, rv, rc, rel.ae2mis_I.p, rel.ae2mis_J.p, rel.ae_pair.p,
+                       rel.pair_loc_off.p, rel.pair_loc.p, rel.mis2d_I.p, mis_k, mis_u_off, mis_u, colpos_ptr,
+                       colpos, out_off, out, scratch, scratch_off);
+    SA_HIP_CHECK(hipGetLastError());
+    profiler().end(s, "coarse_elmats", 0.0, 0.0);
 }
 
 void coarse_elmats(hipStream_t s, const DevRelations &rel, int ae0, const EigBatch &batch,

@@ -548,14 +548,24 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
         }
         EigBatch batch;
         eig_batch_alloc(batch, std::vector<int>(sizes.begin() + ae0, sizes.begin() + ae0 + cnt), s);
-        ae_build(s, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch, false, nullptr);
         std::vector<int64_t> soff((size_t)cnt + 1, 0);
         for (int i = 0; i < cnt; ++i) soff[i + 1] = soff[i] + (int64_t)sizes[ae0 + i] * e2d.row_size(ae0 + i);
         DBuf<int64_t> d_soff;
         d_soff.from_host(soff, s);
         double *scratch = scratch_get(0, (size_t)soff[cnt] + 1);
-        coarse_elmats(s, L.drel, ae0, batch, L.d_mis_k.p, L.d_mis_u_off.p, L.mis_U.p, d_colpos_ptr.p,
-                      d_colpos.p, N.elmat.off.p, N.elmat.val.p, scratch, d_soff.p);
+        int RW = 0;
+        const double *rv = nullptr;
+        const short *rc = nullptr;
+        static const bool dense_only = std::getenv("SAAMGE_AMD_COARSE_ELMAT_DENSE") != nullptr;
+        if (lev == 0 && !dense_only && ae_sparse_rows(s, L.drel, L.A, L.elmat, ae0, batch, RW, rv, rc)) {
+            // fine level: straight from the sparse rows of the AE matrices
+            coarse_elmats_sparse(s, L.drel, ae0, batch, RW, rv, rc, L.d_mis_k.p, L.d_mis_u_off.p, L.mis_U.p,
+                                 d_colpos_ptr.p, d_colpos.p, N.elmat.off.p, N.elmat.val.p, scratch, d_soff.p);
+        } else {
+            ae_build(s, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch, false, nullptr);
+            coarse_elmats(s, L.drel, ae0, batch, L.d_mis_k.p, L.d_mis_u_off.p, L.mis_U.p, d_colpos_ptr.p,
+                          d_colpos.p, N.elmat.off.p, N.elmat.val.p, scratch, d_soff.p);
+        }
         SA_HIP_CHECK(hipStreamSynchronize(s));
         ae0 += cnt;
     }
