@@ -445,12 +445,26 @@ __global__ __launch_bounds__(RAP_NT) void rap_numeric_kernel(
     const int r1 = mis2d_I[m1 + 1] - mis2d_I[m1];
     const int *dofs = mis2d_J + mis2d_I[m1];
     const double *U1 = U + u_off[m1];
-    // LDS: pos[nn+1] (ints), acc[k1*ncol], T[RC*ncol]
-    int *pos = (int *)lds;
-    const int pos_d = (nn + 2 + 1) / 2;
+    // LDS: per neighbour MIS its id, k, row count, offset of its basis and first local column
+    // (the row loop below is a chain of dependent gathers: everything that can come from LDS does),
+    // then acc[k1*ncol], T[RC*ncol]
+    const int pos_d = 3 * nn + 2;
+    long long *uo = (long long *)lds;         // [nn]
+    int *pos = (int *)(uo + nn);              // [nn + 1]
+    int *nbl = pos + nn + 1;                  // [nn]
+    int *kk = nbl + nn;                       // [nn]
+    int *rr = kk + nn;                        // [nn]
+    for (int t = tid; t < nn; t += RAP_NT) {
+        const int m2 = nb[t];
+        nbl[t] = m2;
+        kk[t] = k[m2];
+        rr[t] = mis2d_I[m2 + 1] - mis2d_I[m2];
+        uo[t] = u_off[m2];
+    }
+    __syncthreads();
     if (tid == 0) {
         int run = 0;
-        for (int t = 0; t < nn; ++t) { pos[t] = run; run += k[nb[t]]; }
+        for (int t = 0; t < nn; ++t) { pos[t] = run; run += kk[t]; }
         pos[nn] = run;
     }
     __syncthreads();
@@ -468,7 +482,7 @@ __global__ __launch_bounds__(RAP_NT) void rap_numeric_kernel(
         const int v1 = idx / ncol, cc = idx % ncol;
         int lo = 0, hi = nn;  // neighbour owning local column cc
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pos[mid] <= cc) lo = mid; else hi = mid; }
-        ccol[crowptr[coloff[m1] + v1] + cc] = coloff[nb[lo]] + (cc - pos[lo]);
+        ccol[crowptr[coloff[m1] + v1] + cc] = coloff[nbl[lo]] + (cc - pos[lo]);
     }
     for (int v0 = 0; v0 < k1; v0 += KC) {
         const int kc = min(KC, k1 - v0);
@@ -485,12 +499,12 @@ __global__ __launch_bounds__(RAP_NT) void rap_numeric_kernel(
                 for (int q = Arow[g]; q < Arow[g + 1]; ++q) {
                     const int j = Acol[q];
                     const int m2 = mises[j];
-                    const int k2 = k[m2];
-                    if (k2 == 0) continue;
-                    int lo = 0, hi = nn;
-                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (nb[mid] <= m2) lo = mid; else hi = mid; }
-                    const int r2 = mis2d_I[m2 + 1] - mis2d_I[m2];
-                    const double *U2 = U + u_off[m2] + row_in_mis[j];
+                    int lo = 0, hi = nn;      // (the neighbour list holds exactly the MISes with k > 0)
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (nbl[mid] <= m2) lo = mid; else hi = mid; }
+                    if (nn == 0 || nbl[lo] != m2) continue;
+                    const int k2 = kk[lo];
+                    const int r2 = rr[lo];
+                    const double *U2 = U + uo[lo] + row_in_mis[j];
                     const double a = Aval[q];
                     double *dst = Trow + pos[lo];
                     for (int v = 0; v < k2; ++v) dst[v] = fma(a, U2[(size_t)v * r2], dst[v]);
@@ -545,7 +559,7 @@ void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, cons
     // row pointers of Ac and LDS sizing
     std::vector<int> crow((size_t)nc + 1, 0);
     int64_t nnz = 0;
-    size_t need_max = 0;
+    size_t need_max = 0, small_max = 0;
     for (int m = 0; m < nm; ++m) {
         if (h_k[m] == 0) continue;
         int ncol = 0;
@@ -555,15 +569,19 @@ void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, cons
             nnz += ncol;
         }
         // all k rows of the block + 1 row of T if that fits 160 KiB, else 2 rows (multi-pass)
-        size_t need = (size_t)(h_cnt[m] + 3) / 2 + (size_t)(h_k[m] + 1) * ncol;
+        size_t need = (size_t)(3 * h_cnt[m] + 2) + (size_t)(h_k[m] + 1) * ncol;
         const size_t cap = 160 * 1024 / 8;
-        if (need > cap) need = std::max((size_t)(h_cnt[m] + 3) / 2 + 2 * (size_t)ncol, std::min(need, cap));
+        if (need > cap) need = std::max((size_t)(3 * h_cnt[m] + 2) + 2 * (size_t)ncol, std::min(need, cap));
         if (need > need_max) need_max = need;
+        small_max = std::max(small_max, (size_t)(3 * h_cnt[m] + 2) + (size_t)(h_k[m] + 8) * ncol);
     }
     SA_REQUIRE(nnz < (int64_t)1 << 31, "coarse operator too large for 32-bit indices");
     for (int i = 0; i < nc; ++i) crow[i + 1] += crow[i];
-    size_t lds_doubles = 8192;  // 64 KiB default: several workgroups per CU
-    if (need_max > lds_doubles) lds_doubles = need_max;
+    // Blocks that fit 64 KiB in one pass get by with the k output rows + >= 8 rows of T per chunk of
+    // MIS rows (16 KiB floor): the kernel is bound by the latency of its dependent gathers, and
+    // the smaller footprint puts 8 workgroups instead of 2 on a CU.  Wider blocks keep what they need.
+    size_t lds_doubles = std::max((size_t)2048, small_max);
+    if (need_max > 8192) lds_doubles = need_max;
     SA_REQUIRE(lds_doubles * 8 <= 160 * 1024, "RAP: MIS block too wide for LDS");
     static bool attr = false;
     if (!attr) {
