@@ -200,7 +200,10 @@ def main():
     if rank == 0 and not args.no_roofline:
         capi.profile(True)
         capi.profile_reset()
-        h, x, its2, conv2, hist2 = one_step(capi, prob, params)
+        # (single-rank parameters: `params` now carries the group's callbacks)
+        params1 = capi.default_params(num_coarsenings=args.levels - 1, theta=args.theta, nu_relax=3,
+                                      nu_pro=args.nu_pro, correct_nullspace=args.correct_nullspace)
+        h, x, its2, conv2, hist2 = one_step(capi, prob, params1)
         h.close()
         capi.profile(False)
         stats = sorted(capi.profile_stats(), key=lambda s: -s["ms"])
