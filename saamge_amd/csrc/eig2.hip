@@ -2,15 +2,16 @@
 //
 //   stage 1  dense -> band (bandwidth SB):  per panel of SB columns, batched over all matrices
 //            of the chunk (grid.y = matrix):
-//              sbr_qr_kernel     Householder QR of the block below the band, compact WY (V, T)
-//              sbr_symm_kernel   X = A22 V        tall-skinny product, A22 streamed ONCE per panel
-//              sbr_small_kernel  Y = X T, S = T^T V^T Y, Z = Y - V S / 2
-//              sbr_syr2k_kernel  A22 -= Z V^T + V Z^T   64x64 tiles, 4x4 register micro-tiles
-//            HBM traffic 24 n'^2 B per panel  ->  8 n^3 / SB bytes per matrix instead of the
-//            one-stage 8 n^3 / 3 (x3 with its rank-2 update): bandwidth-bound at 4 flop/byte.
+//              sbr_qr_*          Householder QR of the block below the band, compact WY (V, T)
+//              sbr_symm_kernel   X = A22 V        (first panel only) tall-skinny product
+//              sbr_z_kernel      Y = X T, S = T^T V^T Y, Z = Y - V S / 2
+//              sbr_panel_update / sbr_fused_kernel   A22 -= Z V^T + V Z^T with the NEXT panel's
+//                                product X' = A22' V' riding on the same pass (look-ahead)
+//            HBM traffic 16 n'^2 B per panel  ->  16 n^3 / (3 SB) bytes per matrix instead of the
+//            one-stage 8 n^3 / 3.
 //   stage 2  band -> tridiagonal by bulge chasing, one workgroup per matrix, band resident in
 //            LDS (n*2*SB doubles) when it fits; the 16 wavefronts run 16 sweeps at once in a
-//            lock-step software pipeline (sweep s does its q-th chase step at time G*s + q).
+//            lock-step software pipeline (sweep s does its q-th chase step at time start[s] + q).
 //   back-transformation  y = Q1 Q2 z : the chase reflectors (length <= SB) are applied per
 //            sweep by 16-lane groups, the panel reflectors through their compact WY form.
 //
@@ -495,98 +496,8 @@ __global__ __launch_bounds__(SM_NT) void sbr_z_kernel(int k0, const int *__restr
 }
 
 
-// A22 -= Z V^T + V Z^T (both triangles: the mat-vec product reads full rows).  One workgroup
-// per (128-row strip, matrix).  Lane = two rows of the strip (lane, lane + 64): its Z/V rows stay
-// in registers for the whole strip and every A22 access is a 512-B coalesced wave access.
-// Wavefront w owns columns 8 w .. 8 w + 7 of each 32-column tile: the column operands
-// Z(l, :), V(l, :) are wave-uniform and arrive through the scalar cache as SGPR operands of the
-// FMAs -- no LDS at all.
 constexpr int S2_NT = 256;
-constexpr int S2_ROWS = 128;
 constexpr int S2_KC = 8;   // columns per wavefront per step (bounded by the SGPR budget)
-
-__global__ __launch_bounds__(S2_NT) void sbr_syr2k_kernel(int k0, const int *__restrict__ ns,
-                                                          const int64_t *__restrict__ moff,
-                                                          const int64_t *__restrict__ voff,
-                                                          double *__restrict__ Wm,
-                                                          const double *__restrict__ Vpk,
-                                                          const double *__restrict__ Zbuf,
-                                                          double *__restrict__ Xbuf, int count,
-                                                          int tiles) {
-    int b, blk;
-    xcd_decode(tiles, b, blk);
-    if (b >= count) return;
-    const int n = ns[b];
-    const int np = n - k0 - SB;
-    if (np < 2) return;
-    const int i0 = blk * S2_ROWS;
-    if (i0 >= np) return;
-    double *A22 = Wm + moff[b] + (size_t)(k0 + SB) * n + (k0 + SB);
-    const double *__restrict__ Z = Zbuf + voff[b] * SB;
-    const double *__restrict__ Vp = Vpk + voff[b] * SB;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // Rows past the end of the matrix (last strip) are redirected to per-lane trash slots in the
-    // already consumed X buffer (n * SB >= 128 doubles) with column stride 0: loads and stores
-    // stay unconditional (conditional stores make the compiler sink the arithmetic into the
-    // store branches and reload the scalar operands there).
-    const int ia = i0 + lane, ib = i0 + lane + 64;
-    const bool oka = ia < np, okb = ib < np;
-    double *trash = Xbuf + voff[b] * SB;
-    double *pa = oka ? A22 + ia : trash + lane;
-    double *pb = okb ? A22 + ib : trash + 64 + lane;
-    const size_t sa = oka ? (size_t)n : 0, sb = okb ? (size_t)n : 0;
-    const int iac = min(ia, np - 1), ibc = min(ib, np - 1);
-    double za[SB], va[SB], zb[SB], vb[SB];   // negated row operands
-#pragma unroll
-    for (int c = 0; c < SB; ++c) {
-        za[c] = -Z[(size_t)iac * SB + c];
-        va[c] = -Vp[(size_t)iac * SB + c];
-        zb[c] = -Z[(size_t)ibc * SB + c];
-        vb[c] = -Vp[(size_t)ibc * SB + c];
-    }
-    for (int l0 = S2_KC * w; l0 < np; l0 += 4 * S2_KC) {
-        const int kn = min(S2_KC, np - l0);   // wave-uniform
-        if (kn == S2_KC) {
-            double ta[S2_KC], tb[S2_KC];
-#pragma unroll
-            for (int k = 0; k < S2_KC; ++k) {
-                ta[k] = pa[(size_t)(l0 + k) * sa];
-                tb[k] = pb[(size_t)(l0 + k) * sb];
-            }
-#pragma unroll
-            for (int k = 0; k < S2_KC; ++k) {
-                const double *zl = Z + (size_t)(l0 + k) * SB;    // wave-uniform: scalar loads
-                const double *vl = Vp + (size_t)(l0 + k) * SB;
-#pragma unroll
-                for (int c = 0; c < SB; ++c) {
-                    ta[k] = fma(za[c], vl[c], fma(va[c], zl[c], ta[k]));
-                    tb[k] = fma(zb[c], vl[c], fma(vb[c], zl[c], tb[k]));
-                }
-                // the scheduler must not hoist the scalar loads of all columns (64 SGPRs each)
-                if (k & 1) __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int k = 0; k < S2_KC; ++k) {
-                pa[(size_t)(l0 + k) * sa] = ta[k];
-                pb[(size_t)(l0 + k) * sb] = tb[k];
-            }
-        } else {
-            for (int k = 0; k < kn; ++k) {
-                double t0 = pa[(size_t)(l0 + k) * sa], t1 = pb[(size_t)(l0 + k) * sb];
-                const double *zl = Z + (size_t)(l0 + k) * SB;
-                const double *vl = Vp + (size_t)(l0 + k) * SB;
-#pragma unroll
-                for (int c = 0; c < SB; ++c) {
-                    t0 = fma(za[c], vl[c], fma(va[c], zl[c], t0));
-                    t1 = fma(zb[c], vl[c], fma(vb[c], zl[c], t1));
-                }
-                pa[(size_t)(l0 + k) * sa] = t0;
-                pb[(size_t)(l0 + k) * sb] = t1;
-            }
-        }
-    }
-}
 
 // ---- look-ahead variant: the product of the NEXT panel is fused into the update -------------
 // Per panel p (V_p, T_p, Z_p known):
@@ -684,7 +595,10 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
     for (int r = 0; r < RPL; ++r) {
         const int ia = i0 + SF_ROWS * r + lane;
         const bool oka = ia < np;
-        pa[r] = oka ? A22 + ia : trashbuf + lane;          // rows past the end: see sbr_syr2k_kernel
+        // rows past the end of the matrix: the lane keeps computing (a predicated store would make
+        // the compiler sink the arithmetic into the branch and spill) but reads and writes a
+        // private trash slot with stride 0
+        pa[r] = oka ? A22 + ia : trashbuf + lane;
         sa[r] = oka ? (size_t)n : 0;
         const int iac = min(ia, np - 1);
 #pragma unroll
