@@ -52,6 +52,12 @@ struct Params {                 // MultilevelParameters (amg/inc/ml.hpp:59-114)
     int algebraic = 0;            // element-free mode (tg_produce_data_algebraic): elements = dofs
 };
 
+struct NextPrep {               // host half of the next level's inputs (prepare_next_host)
+    bool ready = false;
+    Table e2d;                  // coarse elem_to_dof
+    std::vector<int> colpos_ptr, colpos;
+};
+
 struct Level {                  // tg_data_t + interp_data_t + agg_partitioning_relations_t
     DCsr A;                     // level operator (level 0: the user's matrix, viewed or copied)
     DCsr P, R, Ac;              // interp, restr, coarse operator
@@ -61,6 +67,7 @@ struct Level {                  // tg_data_t + interp_data_t + agg_partitioning_
     double theta = 0.0;
     int nu_relax = 3;
     Relations rel;              // host topology
+    NextPrep next_prep;         // filled beside the Galerkin product, consumed by prepare_next_level
     DevRelations drel;          // device mirror
     DevElmats elmat;            // element matrices of this level
     // interp_data_t

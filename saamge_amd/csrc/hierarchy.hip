@@ -136,6 +136,9 @@ struct DeviceInputs {   // level-0 inputs that already live on the device (see h
     int NE = 0, nde = 0;
 };
 
+static void prepare_next_host(const Level &L, const int *p_rowptr_dev, const double *p_val_dev, int p_nrows,
+                              int64_t p_nnz, hipStream_t s, NextPrep &out);
+
 static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &part, int nparts,
                         const signed char *bdr_host, const DeviceInputs *din = nullptr) {
     Level &L = *H.levels[lev];
@@ -429,7 +432,27 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     L.d_mis_coloff.from_host(L.mis_coloff, s);
     build_P_R(s, L.drel, rel, L.mis_k, L.mis_u_off, L.d_mis_k.p, L.d_mis_coloff.p, L.d_mis_u_off.p,
               L.mis_U.p, L.P, L.R);
+    // the host half of the next level's inputs runs beside the Galerkin product (own thread, own
+    // stream); with a smoothed prolongator level_galerkin moves P, so it is done afterwards
+    std::exception_ptr prep_err;
+    std::thread prep_thread;
+    struct PrepJoiner { std::thread &t; ~PrepJoiner() { if (t.joinable()) t.join(); } } prep_joiner{prep_thread};
+    if (lev + 1 < P.num_coarsenings && P.nu_pro[lev] == 0) {
+        static hipStream_t side = nullptr;
+        if (!side) SA_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        SA_HIP_CHECK(hipStreamSynchronize(s));       // P is complete
+        const int *prp = L.P.rowptr.p;
+        const double *pvl = L.P.val.p;
+        const int pnr = L.P.nrows;
+        const int64_t pnz = L.P.nnz;
+        hipStream_t sd = side;
+        prep_thread = std::thread([&L, &prep_err, prp, pvl, pnr, pnz, sd]() {
+            try { prepare_next_host(L, prp, pvl, pnr, pnz, sd, L.next_prep); } catch (...) { prep_err = std::current_exception(); }
+        });
+    }
     level_galerkin(H, lev, true);
+    if (prep_thread.joinable()) prep_thread.join();
+    if (prep_err) std::rethrow_exception(prep_err);
     tm.lap("P, R, RAP", lev);
     if (!P.keep_debug) {
         L.evals.release();
@@ -445,36 +468,41 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
 // next level's inputs: coarse elements = AEs, coarse element matrices = P_loc^T A_e P_loc
 // (agg_create_partitioning_coarse / elmat_parallel)
 // ---------------------------------------------------------------------------------------
-static Table prepare_next_level(Hierarchy &H, int lev) {
-    Level &L = *H.levels[lev];
-    hipStream_t s = H.stream;
+// Host half of the next level's inputs (everything that needs only the topology, the MIS sizes
+// and the numerically non-zero pattern of the tentative prolongator).  Runs on its own thread
+// and stream beside the Galerkin product when the prolongator is not smoothed.
+static void prepare_next_host(const Level &L, const int *p_rowptr_dev, const double *p_val_dev, int p_nrows,
+                              int64_t p_nnz, hipStream_t s, NextPrep &out) {
     const Relations &rel = L.rel;
     const int nparts = rel.nparts;
     // coarse elem_to_dof = AE_to_dof x pattern(P_tent), first-encounter order
     // (agg_create_rels_except_elem_coarse, amg/src/aggregates.cpp:1510-1514).  The pattern is
     // the *numerically non-zero* entries of P_tent (contrib_tent_insert_simple drops exact
     // zeros, amg/src/contrib.cpp:186-187), so P's values are inspected on the host.
-    Table e2d;
+    Table &e2d = out.e2d;
     e2d.ncols = L.mis_coloff.back();
     e2d.I.assign((size_t)nparts + 1, 0);
-    // (always the TENTATIVE prolongator: the coarse elements are built from mis_tent_interps)
-    const DCsr &PT = L.Ptent.nrows ? L.Ptent : L.P;
-    auto p_rowptr = PT.rowptr.to_host(s);
-    auto p_val = PT.val.to_host(s);
+    hvec<int> p_rowptr((size_t)p_nrows + 1);
+    hvec<double> p_val((size_t)p_nnz + 1);
+    SA_HIP_CHECK(hipMemcpyAsync(p_rowptr.data(), p_rowptr_dev, sizeof(int) * ((size_t)p_nrows + 1), hipMemcpyDeviceToHost, s));
+    if (p_nnz) SA_HIP_CHECK(hipMemcpyAsync(p_val.data(), p_val_dev, sizeof(double) * (size_t)p_nnz, hipMemcpyDeviceToHost, s));
+    SA_HIP_CHECK(hipStreamSynchronize(s));
     // colpos: for every (AE, MIS) incidence (aligned with AE_to_mis.J) the position of each of
     // the MIS's coarse dofs in the coarse element's dof list
-    std::vector<int> colpos_ptr(rel.AE_to_mis.J.size() + 1, 0);
+    std::vector<int> &colpos_ptr = out.colpos_ptr;
+    colpos_ptr.assign(rel.AE_to_mis.J.size() + 1, 0);
     for (int e = 0; e < nparts; ++e)
         for (int t = rel.AE_to_mis.I[e]; t < rel.AE_to_mis.I[e + 1]; ++t)
             colpos_ptr[(size_t)t + 1] = colpos_ptr[t] + L.mis_k[rel.AE_to_mis.J[t]];
-    std::vector<int> colpos((size_t)colpos_ptr.back(), -1);
+    std::vector<int> &colpos = out.colpos;
+    colpos.assign((size_t)colpos_ptr.back(), -1);
     // two passes over the AEs (count, then fill), both split over host threads
     {
         int T = (int)std::thread::hardware_concurrency();
         if (T < 1) T = 1;
         if (T > 16) T = 16;
         if (nparts < 64) T = 1;
-        auto walk = [&](int e, std::vector<int> &stamp, int *out, bool fill) -> int {
+        auto walk = [&](int e, std::vector<int> &stamp, int *dst, bool fill) -> int {
             int run = 0;
             const int *misrow = rel.AE_to_mis.row(e);
             const int nmis = rel.AE_to_mis.row_size(e);
@@ -491,7 +519,7 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
                     stamp[cd] = e;
                     if (fill) {
                         colpos[(size_t)colpos_ptr[t] + v] = run;
-                        out[run] = cd;
+                        dst[run] = cd;
                     }
                     ++run;
                 }
@@ -516,6 +544,23 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
             }
         }
     }
+    out.ready = true;
+}
+
+static Table prepare_next_level(Hierarchy &H, int lev) {
+    Level &L = *H.levels[lev];
+    hipStream_t s = H.stream;
+    const Relations &rel = L.rel;
+    const int nparts = rel.nparts;
+    if (!L.next_prep.ready) {
+        // (always the TENTATIVE prolongator: the coarse elements are built from mis_tent_interps)
+        const DCsr &PT = L.Ptent.nrows ? L.Ptent : L.P;
+        prepare_next_host(L, PT.rowptr.p, PT.val.p, PT.nrows, PT.nnz, s, L.next_prep);
+    }
+    Table e2d = std::move(L.next_prep.e2d);
+    const std::vector<int> colpos_ptr = std::move(L.next_prep.colpos_ptr);
+    const std::vector<int> colpos = std::move(L.next_prep.colpos);
+    L.next_prep = NextPrep();
     for (int v : colpos) SA_REQUIRE(v >= 0, "coarse dof with an all-zero prolongator column in an AE");
     // coarse element matrices
     Level &N = *H.levels[lev + 1];
