@@ -94,9 +94,16 @@ __global__ __launch_bounds__(ASM_NT) void ae_scale_kernel(const int *__restrict_
     const int b = blockIdx.x, n = ns[b];
     double *Wm = W + moff[b];
     const int64_t vo = voff[b];
-    double *dg = lds, *dis = lds + n, *part = lds + 2 * n;  // part[4][64]
+    // sqrt(a_rr / a_jj) = sqrt(a_rr) * (1 / sqrt(a_jj)): the two factors once per row instead of a
+    // square root and a division per matrix entry (which made this pass compute-bound)
+    double *dg = lds, *dis = lds + n, *part = lds + 2 * n;  // dg[i] = sqrt(a_ii); part[4][64]
+    double *idg = part + 256;                                // 1 / sqrt(a_ii)
     const int tid = threadIdx.x;
-    for (int i = tid; i < n; i += ASM_NT) dg[i] = Wm[(size_t)i * n + i];
+    for (int i = tid; i < n; i += ASM_NT) {
+        const double sq = sqrt(Wm[(size_t)i * n + i]);
+        dg[i] = sq;
+        idg[i] = 1.0 / sq;
+    }
     __syncthreads();
     const int rr = tid & 63, g = tid >> 6;
     for (int r0 = 0; r0 < n; r0 += 64) {
@@ -111,13 +118,9 @@ __global__ __launch_bounds__(ASM_NT) void ae_scale_kernel(const int *__restrict_
 #pragma unroll
                 for (int u = 0; u < 8; ++u) a[u] = Wm[(size_t)(j + u) * n + r];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (a[u] != 0.0) sum += fabs(a[u]) * sqrt(dr / dg[j + u]);
+                for (int u = 0; u < 8; ++u) sum = fma(fabs(a[u]), dr * idg[j + u], sum);
             }
-            for (; j < ce; ++j) {
-                const double a = Wm[(size_t)j * n + r];
-                if (a != 0.0) sum += fabs(a) * sqrt(dr / dg[j]);
-            }
+            for (; j < ce; ++j) sum = fma(fabs(Wm[(size_t)j * n + r]), dr * idg[j], sum);
         }
         part[g * 64 + rr] = sum;
         __syncthreads();
@@ -137,13 +140,77 @@ __global__ __launch_bounds__(ASM_NT) void ae_scale_kernel(const int *__restrict_
     }
 }
 
+// The same for FEW LARGE agglomerates (coarse levels: 256 matrices of 2 600 rows): one workgroup
+// per matrix cannot keep HBM busy, so the row sums and the scaling are spread over
+// (matrix, 64-row block) and (matrix, column) grids.
+__global__ __launch_bounds__(256) void ae_rowsum_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
+                                                        const int64_t *__restrict__ voff, const double *__restrict__ W,
+                                                        double *__restrict__ dis_out, double *__restrict__ D_out) {
+    __shared__ double part[4 * 64];
+    const int b = blockIdx.y, n = ns[b];
+    const int r0 = blockIdx.x * 64;
+    if (r0 >= n) return;
+    const double *Wm = W + moff[b];
+    const int64_t vo = voff[b];
+    const int rr = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int r = r0 + rr;
+    double sum = 0.0;
+    if (r < n) {
+        const double dr = sqrt(Wm[(size_t)r * n + r]);
+        const int cb = (int)(((long)n * g) / 4), ce = (int)(((long)n * (g + 1)) / 4);
+        int j = cb;
+        for (; j + 4 <= ce; j += 4) {
+            double a[4], dj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = Wm[(size_t)(j + u) * n + r]; dj[u] = Wm[(size_t)(j + u) * n + (j + u)]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sum = fma(fabs(a[u]), dr / sqrt(dj[u]), sum);
+        }
+        for (; j < ce; ++j) sum = fma(fabs(Wm[(size_t)j * n + r]), dr / sqrt(Wm[(size_t)j * n + j]), sum);
+    }
+    part[g * 64 + rr] = sum;
+    __syncthreads();
+    if (g == 0 && r < n) {
+        const double s4 = (part[rr] + part[64 + rr]) + (part[128 + rr] + part[192 + rr]);
+        dis_out[vo + r] = 1.0 / sqrt(s4);
+        if (D_out) D_out[vo + r] = s4;
+    }
+}
+__global__ __launch_bounds__(256) void ae_apply_scale_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
+                                                             const int64_t *__restrict__ voff, double *__restrict__ W,
+                                                             const double *__restrict__ dis) {
+    const int b = blockIdx.y, n = ns[b];
+    const int j = blockIdx.x;
+    if (j >= n) return;
+    double *col = W + moff[b] + (size_t)j * n;
+    const double *d = dis + voff[b];
+    const double dj = d[j];
+    for (int r = threadIdx.x; r < n; r += 256) col[r] = d[r] * col[r] * dj;
+}
+
 void ae_scale(hipStream_t s, EigBatch &batch, double *Dout) {
     if (!batch.count) return;
     double bytes = 0.0;
     for (int n : batch.h_n) bytes += 24.0 * (double)n * n;
+    if (batch.count <= 2048 && batch.max_n >= 1024) {
+        profiler().begin(s);
+        hipLaunchKernelGGL(ae_rowsum_kernel, dim3(div_up(batch.max_n, 64), batch.count), dim3(256), 0, s, batch.n.p,
+                           batch.moff.p, batch.voff.p, batch.W.p, batch.dis.p, Dout);
+        hipLaunchKernelGGL(ae_apply_scale_kernel, dim3(batch.max_n, batch.count), dim3(256), 0, s, batch.n.p,
+                           batch.moff.p, batch.voff.p, batch.W.p, batch.dis.p);
+        SA_HIP_CHECK(hipGetLastError());
+        profiler().end(s, "ae_scale", bytes, 0.0);
+        return;
+    }
+    const size_t lds = (3 * (size_t)batch.max_n + 256) * sizeof(double);
+    SA_REQUIRE(lds <= 160 * 1024, "agglomerate too large for the scaling kernel");
+    static bool attr = false;
+    if (!attr) {
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)ae_scale_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
     profiler().begin(s);
-    hipLaunchKernelGGL(ae_scale_kernel, dim3(batch.count), dim3(ASM_NT),
-                       (2 * (size_t)batch.max_n + 256) * sizeof(double), s, batch.n.p, batch.moff.p,
+    hipLaunchKernelGGL(ae_scale_kernel, dim3(batch.count), dim3(ASM_NT), lds, s, batch.n.p, batch.moff.p,
                        batch.voff.p, batch.W.p, batch.dis.p, Dout);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "ae_scale", bytes, 0.0);
