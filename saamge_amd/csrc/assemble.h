@@ -28,13 +28,21 @@ void ae_scale(hipStream_t s, EigBatch &batch, double *Dout);
 
 // ae_assemble (+ ae_scale when `scale`): on the fine level, when the sparse rows of one AE fit in
 // LDS, as ONE fused kernel that writes the dense image once (see assemble.hip).
+// `rows` (optional): where the chunk's first row sits among the rows of all agglomerates of the level
+// and how many there are -- the sparse rows are then kept for the rest of the hierarchy build
+// (ae_rows_new_build() starts a new one) and not recomputed by later passes over the same AEs.
+struct RowsSpan {
+    int64_t first = 0, total = 0;
+};
+void ae_rows_new_build();
 void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevElmats &el, int ae0,
-              EigBatch &batch, bool scale, double *Dout);
+              EigBatch &batch, bool scale, double *Dout, const RowsSpan *rows = nullptr);
 
 // Fine level, 8-dof elements: the sparse rows of the AE matrices of a chunk (RW slots per row at
 // rv / rc[(batch.voff[b] + row) * RW + slot], column -1 = empty).  false: not applicable.
 bool ae_sparse_rows(hipStream_t s, const DevRelations &rel, const DCsr &A, const DevElmats &el, int ae0,
-                    const EigBatch &batch, int &RW, const double *&rv, const short *&rc);
+                    const EigBatch &batch, int &RW, const double *&rv, const short *&rc,
+                    const RowsSpan *rows = nullptr);
 // E_e from those rows (no dense AE matrix)
 void coarse_elmats_sparse(hipStream_t s, const DevRelations &rel, int ae0, const EigBatch &batch, int RW,
                           const double *rv, const short *rc, const int *mis_k, const int64_t *mis_u_off,

@@ -234,7 +234,8 @@ __global__ __launch_bounds__(256) void max_row_kernel(int n, const int *__restri
     int len = (i < n) ? rowptr[i + 1] - rowptr[i] : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_xor(len, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, len);
+    // (one contended address: only the few wavefronts that raise the maximum touch it)
+    if ((threadIdx.x & 63) == 0 && len > *(volatile int *)out) atomicMax(out, len);
 }
 
 // Sparse rows of all AE matrices of a chunk, one thread per (AE, local row, slot of A's row):
@@ -575,35 +576,71 @@ static int csr_max_row(hipStream_t s, const DCsr &A) {
     return m.to_host(s)[0];
 }
 
-// sparse rows of the AE matrices of one chunk (RW slots per row) into a grow-only buffer
+// Sparse rows of the AE matrices of one chunk (RW slots per row).  With `rows` (position of the
+// chunk's first row among the rows of ALL agglomerates of the level, and their total) the rows
+// are kept for the whole hierarchy build in a grow-only buffer: the eigenproblem pass computes
+// them once and the pass that builds the coarse element matrices reads them again.
+struct RowsCache {
+    int gen = -1;                 // hierarchy build the contents belong to
+    const void *key = nullptr;    // the level matrix
+    int RW = 0;
+    int lo = 0, hi = 0;           // AEs [lo, hi) are present
+    DBuf<double> vals;
+    DBuf<short> cols;
+};
+static RowsCache g_rows;
+static int g_rows_gen = 0;
+void ae_rows_new_build() { ++g_rows_gen; }
+
 static void launch_rows8(hipStream_t s, const DevRelations &rel, const DCsr &A, const DevElmats &el, int ae0,
-                         const EigBatch &batch, int RW, const double *&rv, const short *&rc) {
+                         const EigBatch &batch, int RW, const double *&rv, const short *&rc,
+                         const RowsSpan *rows = nullptr) {
     static DBuf<double> g_rvals;
     static DBuf<short> g_rcols;
-    const size_t need = (size_t)batch.h_voff[batch.count] * RW + 64;
-    if (g_rvals.n < need) { g_rvals.alloc(need + need / 8); g_rcols.alloc(need + need / 8); }
+    double *dv;
+    short *dc;
+    if (rows) {
+        RowsCache &c = g_rows;
+        const size_t need = (size_t)rows->total * RW + 64;
+        if (c.gen != g_rows_gen || c.key != (const void *)A.val.p || c.RW != RW || c.vals.n < need) {
+            if (c.vals.n < need) { c.vals.alloc(need); c.cols.alloc(need); }
+            c.gen = g_rows_gen; c.key = A.val.p; c.RW = RW; c.lo = c.hi = 0;
+        }
+        dv = c.vals.p + (size_t)rows->first * RW;
+        dc = c.cols.p + (size_t)rows->first * RW;
+        rv = dv;
+        rc = dc;
+        if (ae0 >= c.lo && ae0 + batch.count <= c.hi) return;          // computed earlier in this build
+        if (c.lo == c.hi) { c.lo = ae0; c.hi = ae0 + batch.count; }
+        else if (ae0 == c.hi) c.hi += batch.count;                      // the passes walk the AEs in order
+    } else {
+        const size_t need = (size_t)batch.h_voff[batch.count] * RW + 64;
+        if (g_rvals.n < need) { g_rvals.alloc(need + need / 8); g_rcols.alloc(need + need / 8); }
+        dv = g_rvals.p;
+        dc = g_rcols.p;
+    }
     profiler().begin(s);
     hipLaunchKernelGGL(ae_rows8_kernel, dim3(div_up((long)batch.max_n * RW, 256), batch.count), dim3(256), 0, s,
                        ae0, RW, batch.n.p, batch.voff.p, rel.ae2d_I.p, rel.ae2d_J.p, rel.d2ae_I.p,
                        rel.d2ae_J.p, rel.dof_id_inAE.p, rel.flags.p, rel.d2e_I.p, rel.d2e_J.p, rel.part.p,
-                       rel.e2d_J.p, el.val.p, A.rowptr.p, A.col.p, A.val.p, g_rvals.p, g_rcols.p);
+                       rel.e2d_J.p, el.val.p, A.rowptr.p, A.col.p, A.val.p, dv, dc);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "ae_rows", 0.0, 0.0);
-    rv = g_rvals.p;
-    rc = g_rcols.p;
+    rv = dv;
+    rc = dc;
 }
 
 bool ae_sparse_rows(hipStream_t s, const DevRelations &rel, const DCsr &A, const DevElmats &el, int ae0,
-                    const EigBatch &batch, int &RW, const double *&rv, const short *&rc) {
+                    const EigBatch &batch, int &RW, const double *&rv, const short *&rc, const RowsSpan *rows) {
     if (!batch.count || el.algebraic || el.nde != 8 || batch.count > 65535 || batch.max_n > 32767) return false;
     if (A.max_row < 0) A.max_row = csr_max_row(s, A);
     RW = A.max_row;
-    launch_rows8(s, rel, A, el, ae0, batch, RW, rv, rc);
+    launch_rows8(s, rel, A, el, ae0, batch, RW, rv, rc, rows);
     return true;
 }
 
 void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevElmats &el, int ae0,
-              EigBatch &batch, bool scale, double *Dout) {
+              EigBatch &batch, bool scale, double *Dout, const RowsSpan *rows) {
     if (!batch.count) return;
     if (A && el.algebraic) {
         double bytes = 0.0;
@@ -634,7 +671,7 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
     const bool nde8 = el.nde == 8 && batch.count <= 65535;   // (grid.y of the rows kernel)
     const double *rv = nullptr;
     const short *rc = nullptr;
-    if (nde8) launch_rows8(s, rel, *A, el, ae0, batch, RW, rv, rc);
+    if (nde8) launch_rows8(s, rel, *A, el, ae0, batch, RW, rv, rc, rows);
     auto launch = [&](auto kern) {
         SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         hipLaunchKernelGGL(kern, dim3(batch.count), dim3(AB_NT), lds, s, ae0, RW, batch.n.p, batch.moff.p,

@@ -203,6 +203,10 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     L.roots = sas_poly_roots(L.nu_relax);
 
     // ---- local spectral problems, chunked over AEs (interp_compute_vectors) ----
+    // (the sparse rows of the fine AE matrices are kept for the coarse element matrices of the next
+    // level when there is one: ~10 bytes per stored entry of the overlapping AE rows)
+    const bool keep_rows = lev == 0 && lev + 1 < P.num_coarsenings &&
+                           (double)L.rel.AE_to_dof.I[nparts] * 30.0 * 10.0 < 32e9;
     std::vector<int> sizes((size_t)nparts);
     for (int p = 0; p < nparts; ++p) sizes[p] = rel.AE_to_dof.row_size(p);
     L.ae_m.assign((size_t)nparts, 0);
@@ -297,8 +301,9 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         EigBatch &batch = batches[slot];
         batch = EigBatch();
         eig_batch_alloc(batch, std::vector<int>(sizes.begin() + ae0, sizes.begin() + ae0 + cnt), qa, slot);
+        const RowsSpan span{(int64_t)L.rel.AE_to_dof.I[ae0], (int64_t)L.rel.AE_to_dof.I[nparts]};
         ae_build(qa, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch, true,
-                 P.keep_debug ? L.ae_D.p + row0 : nullptr);
+                 P.keep_debug ? L.ae_D.p + row0 : nullptr, keep_rows ? &span : nullptr);
         eig_tridiagonalize(qa, batch, 1);
         if (pipelined) SA_HIP_CHECK(hipEventRecord(ev_band[slot], qa));
         pend_ae0[slot] = ae0;
@@ -602,7 +607,8 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
         const double *rv = nullptr;
         const short *rc = nullptr;
         static const bool dense_only = std::getenv("SAAMGE_AMD_COARSE_ELMAT_DENSE") != nullptr;
-        if (lev == 0 && !dense_only && ae_sparse_rows(s, L.drel, L.A, L.elmat, ae0, batch, RW, rv, rc)) {
+        const RowsSpan span{(int64_t)rel.AE_to_dof.I[ae0], (int64_t)rel.AE_to_dof.I[nparts]};
+        if (lev == 0 && !dense_only && ae_sparse_rows(s, L.drel, L.A, L.elmat, ae0, batch, RW, rv, rc, &span)) {
             // fine level: straight from the sparse rows of the AE matrices
             coarse_elmats_sparse(s, L.drel, ae0, batch, RW, rv, rc, L.d_mis_k.p, L.d_mis_u_off.p, L.mis_U.p,
                                  d_colpos_ptr.p, d_colpos.p, N.elmat.off.p, N.elmat.val.p, scratch, d_soff.p);
@@ -936,6 +942,7 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
                             const signed char *bdr, const int *const *partitions,
                             const int *nparts, const Params &p, hipStream_t stream) {
     SA_REQUIRE(p.num_coarsenings >= 1 && p.num_coarsenings < MAX_LEVELS, "bad number of coarsenings");
+    ae_rows_new_build();     // nothing cached from an earlier hierarchy is reused
     // element-free mode: elements = dofs (identity elem_to_dof generated here), no element matrices
     DBuf<int> iota_e2d;   // (moved into the hierarchy below: the device topology views it)
     if (p.algebraic) {
