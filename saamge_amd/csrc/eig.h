@@ -35,6 +35,11 @@ struct EigBatch {
     DBuf<int64_t> roff;     // [count+1] reflector offsets
     DBuf<double> Gbuf;      // per (matrix, 64-row block) partial V^T X (SB x SB each)
     DBuf<int64_t> goff;
+    // symmetric fused update (SAAMGE_AMD_EIG_FUSED=3): per matrix the 64 x SB partial products of
+    // the tiles below the diagonal, tile (I, J) at xpoff[b] + I (I - 1) / 2 + J
+    DBuf<double> Xpart;
+    DBuf<int64_t> xpoff;
+    std::vector<int64_t> h_xpoff;
     std::vector<int64_t> h_roff, h_goff;
     std::vector<int> h_n, h_m;
     std::vector<int64_t> h_moff, h_voff;

@@ -742,9 +742,9 @@ static bool use_one_stage() {
 // multi-GB buffers costs 0.1-0.4 s each on this platform; the arena is allocated once per
 // process and reused by every chunk / level / hierarchy).  Single stream, sequential use.
 struct EigArena {
-    DBuf<double> W, panel, d, e, tau, dis, Tfac, Xbuf, Zbuf, Vpk, Vpk2, trash, rv, rtau, bandg, Gbuf;
+    DBuf<double> W, panel, d, e, tau, dis, Tfac, Xbuf, Zbuf, Vpk, Vpk2, trash, rv, rtau, bandg, Gbuf, Xpart;
     DBuf<int> n, m, j0;
-    DBuf<int64_t> moff, voff, roff, goff;
+    DBuf<int64_t> moff, voff, roff, goff, xpoff;
 };
 static int g_slot = 0;   // workspace of the batch being set up (single host thread)
 static EigArena &arena() {
@@ -817,6 +817,12 @@ void eig_batch_two_stage_buffers(EigBatch &b, size_t nrefl, bool need_bandg, hip
     arena_view(b.rv, a.rv, nrefl * EIG_SB + EIG_SB);
     arena_view(b.rtau, a.rtau, nrefl + 1);
     if (need_bandg) arena_view(b.bandg, a.bandg, rows * 2 * EIG_SB);
+    if (!b.h_xpoff.empty()) {
+        arena_view(b.xpoff, a.xpoff, (size_t)b.count + 1);
+        arena_view(b.Xpart, a.Xpart, (size_t)b.h_xpoff[b.count] * 64 * EIG_SB + 64);
+        SA_HIP_CHECK(hipMemcpyAsync(b.xpoff.p, b.h_xpoff.data(), 8 * ((size_t)b.count + 1), hipMemcpyHostToDevice, s));
+        SA_HIP_CHECK(hipStreamSynchronize(s));
+    }
 }
 
 static size_t tri_lds_bytes(int n) { return sizeof(double) * (2 * (size_t)n + TRI_NT + 2 * EIG_NB + TRI_NT / 64); }

@@ -706,6 +706,183 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
     }
 }
 
+// ---- symmetric variant (SAAMGE_AMD_EIG_FUSED=3) ----------------------------------------------
+// Only the tiles on and below the diagonal of A22' are read, updated and written: the strip of
+// 64 rows I walks its tiles J <= I.  A tile below the diagonal is used twice, for the rows of I
+// (as above) and -- transposed through LDS, so that the lane again owns the output row and the
+// operand V'(r, :) is wave-uniform -- for the rows of J: X(J) += A'(I, J)^T V'(I).  Those
+// contributions go to a per-tile partial buffer and are summed (with the partial V'^T X) by
+// sbr_xsum_kernel.  The diagonal tile is completed from its lower triangle through LDS; the
+// upper triangle of the matrix is never read again.  32 + 16 + 16 FMAs per element of the lower
+// half instead of 2 x 48 for the pair, half the matrix traffic plus 12 % for the partials.
+// Parity-green; measured at 256^3: level 1 (n = 2 600) 487 ms against 534 ms for the one-row
+// kernel and 464 ms for the two-row one, level 0 (n = 405, 7 strips: triangular imbalance and two
+// barriers per tile) 665 ms against 551 / 514 ms -- a third fewer FMAs and scalar operands buy 9 %
+// where they buy anything, so it stays opt-in (requesting the next tile before the transposed
+// product made it slower: 570 ms on level 1).
+constexpr int TP = 65;   // LDS tile pitch (conflict-free both ways)
+__global__ __launch_bounds__(S2_NT) void sbr_fused_sym_kernel(int k0, const int *__restrict__ ns,
+                                                              const int64_t *__restrict__ moff,
+                                                              const int64_t *__restrict__ voff,
+                                                              double *__restrict__ Wm,
+                                                              const double *__restrict__ Vcur,
+                                                              const double *__restrict__ Zbuf,
+                                                              const double *__restrict__ Vnext,
+                                                              double *__restrict__ Xbuf,
+                                                              const int64_t *__restrict__ xpoff,
+                                                              double *__restrict__ Xpart,
+                                                              double *__restrict__ trashbuf, int count,
+                                                              int tiles, int shift) {
+    __shared__ double tileT[64 * TP];          // tile (c, r) at c * TP + r; the epilogue reuses it
+    int b, blk;
+    xcd_decode(tiles, b, blk);
+    if (b >= count) return;
+    const int n = ns[b];
+    if (n - k0 - SB < 2) return;
+    const int np = n - k0 - SB - shift;
+    if (np < 1) return;
+    const bool prod = np >= 2;                 // np == 1: the last diagonal entry is only updated
+    const int I = tiles - 1 - blk;             // long strips first
+    const int i0 = I * 64;
+    if (i0 >= np) return;
+    double *A22 = Wm + moff[b] + (size_t)(k0 + SB + shift) * n + (k0 + SB + shift);
+    const double *__restrict__ Z = Zbuf + voff[b] * SB + shift * SB;
+    const double *__restrict__ Vc = Vcur + voff[b] * SB + shift * SB;
+    const double *__restrict__ Vn = Vnext + voff[b] * SB;
+    double *X = Xbuf + voff[b] * SB;
+    double *Xp = Xpart + (size_t)(xpoff[b] + (int64_t)I * (I - 1) / 2) * (64 * SB);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ia = i0 + lane;
+    const bool oka = ia < np;
+    double *pa = oka ? A22 + ia : trashbuf + lane;
+    const size_t sa = oka ? (size_t)n : 0;
+    const int iac = min(ia, np - 1);
+    const int rmax = min(64, np - i0);         // rows of this strip inside the matrix
+    double za[SB], va[SB], xa[SB];
+#pragma unroll
+    for (int c = 0; c < SB; ++c) {
+        za[c] = -Z[(size_t)iac * SB + c];
+        va[c] = -Vc[(size_t)iac * SB + c];
+        xa[c] = 0.0;
+    }
+    const int c0 = 16 * w;                               // this wavefront's columns of a tile
+    const int ncd = max(0, min(16, rmax - c0));          // ... of the diagonal tile
+    for (int J = 0; J <= I; ++J) {
+        const int j0 = J * 64;
+        const bool diag = J == I;
+        const int nc = diag ? ncd : 16;
+        double ta[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) ta[k] = (k < nc) ? pa[(size_t)(j0 + c0 + k) * sa] : 0.0;
+        if (diag) {
+            // entries above the diagonal of the tile come from the lower triangle
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tileT[(c0 + k) * TP + lane] = ta[k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (c0 + k > lane && k < nc) ta[k] = tileT[lane * TP + c0 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k < nc) {    // wave-uniform
+                const double *zl = Z + (size_t)(j0 + c0 + k) * SB;
+                const double *vl = Vc + (size_t)(j0 + c0 + k) * SB;
+                const double *vn = Vn + (size_t)(j0 + c0 + k) * SB;
+#pragma unroll
+                for (int c = 0; c < SB; ++c) ta[k] = fma(za[c], vl[c], fma(va[c], zl[c], ta[k]));
+                if (prod) {
+#pragma unroll
+                    for (int j = 0; j < SB; ++j) xa[j] = fma(ta[k], vn[j], xa[j]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (k < nc) pa[(size_t)(j0 + c0 + k) * sa] = ta[k];
+        if (!diag) {
+            // rows of J: X(J) += A'(I, J)^T V'(I), lane = column of the tile, wavefront w does 4 of the SB outputs
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tileT[(c0 + k) * TP + lane] = ta[k];
+            __syncthreads();
+            double xt[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int r = 0; r < rmax; ++r) {
+                const double a = tileT[lane * TP + r];
+                const double *vn = Vn + (size_t)(i0 + r) * SB + 4 * w;   // wave-uniform
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xt[q] = fma(a, vn[q], xt[q]);
+            }
+            double *dst = Xp + (size_t)J * (64 * SB);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[(4 * w + q) * 64 + lane] = xt[q];
+            __syncthreads();       // the tile buffer is rewritten by the next tile
+        }
+    }
+    if (!prod) return;     // block-uniform
+    // ---- direct part of X(I): sum of the four column splits ----
+    __syncthreads();
+    double *red = tileT;           // 4 * SB * 64 doubles
+#pragma unroll
+    for (int j = 0; j < SB; ++j) red[(w * SB + j) * 64 + lane] = xa[j];
+    __syncthreads();
+    for (int idx = tid; idx < 64 * SB; idx += S2_NT) {
+        const int rr = idx & 63, j = idx >> 6;
+        if (i0 + rr < np)
+            X[(size_t)j * n + i0 + rr] = (red[(0 * SB + j) * 64 + rr] + red[(1 * SB + j) * 64 + rr]) +
+                                         (red[(2 * SB + j) * 64 + rr] + red[(3 * SB + j) * 64 + rr]);
+    }
+}
+
+// X(J) += the partial products of the tiles below J's diagonal tile; partial G = V'^T X of the block
+__global__ __launch_bounds__(256) void sbr_xsum_kernel(int k0, const int *__restrict__ ns,
+                                                       const int64_t *__restrict__ voff,
+                                                       const double *__restrict__ Vnext,
+                                                       double *__restrict__ Xbuf,
+                                                       const int64_t *__restrict__ xpoff,
+                                                       const double *__restrict__ Xpart,
+                                                       const int64_t *__restrict__ goff,
+                                                       double *__restrict__ Gbuf, int count, int tiles,
+                                                       int shift) {
+    constexpr int SBP = SB + 1;
+    __shared__ double xs[64 * SBP], vs2[64 * SBP];
+    int b, J;
+    xcd_decode(tiles, b, J);
+    if (b >= count) return;
+    const int n = ns[b];
+    if (n - k0 - SB < 2) return;
+    const int np = n - k0 - SB - shift;
+    if (np < 2) return;
+    const int j0 = J * 64;
+    if (j0 >= np) return;
+    const int T = (np + 63) / 64;
+    const double *__restrict__ Vn = Vnext + voff[b] * SB;
+    double *X = Xbuf + voff[b] * SB;
+    const double *Xp = Xpart + (size_t)xpoff[b] * (64 * SB);
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 64 * SB; idx += 256) {
+        const int rr = idx & 63, j = idx >> 6;
+        double s = 0.0;
+        if (j0 + rr < np) {
+            s = X[(size_t)j * n + j0 + rr];
+            for (int I = J + 1; I < T; ++I)
+                s += Xp[(size_t)((int64_t)I * (I - 1) / 2 + J) * (64 * SB) + j * 64 + rr];
+            X[(size_t)j * n + j0 + rr] = s;
+        }
+        xs[rr * SBP + j] = s;
+        vs2[rr * SBP + j] = (j0 + rr < np) ? Vn[(size_t)(j0 + rr) * SB + j] : 0.0;
+    }
+    __syncthreads();
+    {
+        const int a = tid >> 4, c = tid & 15;
+        double s = 0.0;
+        for (int rr = 0; rr < 64; ++rr) s = fma(vs2[rr * SBP + a], xs[rr * SBP + c], s);
+        Gbuf[goff[b] + (size_t)J * (SB * SB) + tid] = s;
+    }
+}
+
 // ---- the same fused update + product on the matrix cores ------------------------------------
 // v_mfma_f64_16x16x4_f64 (D = A(16x4) B(4x16) + C; A: row = lane & 15, k = lane >> 4; B: col =
 // lane & 15, k = lane >> 4; C/D register r: col = lane & 15, row = (lane >> 4) + 4 r).
@@ -1248,6 +1425,18 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
     const int nmax0 = b.max_n;
     const size_t fixed0 = sizeof(double) * (chase_config(nmax0).slots() * HAND) + sizeof(int) * (2 * (size_t)nmax0 + 4);
     const bool in_lds0 = fixed0 + sizeof(double) * (size_t)nmax0 * LDB + 64 <= 160 * 1024;
+    static const int fused_mode = []() {
+        const char *e = std::getenv("SAAMGE_AMD_EIG_FUSED");
+        return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;
+    }();
+    b.h_xpoff.clear();
+    if (fused_mode == 3) {      // symmetric update: room for the partial products of the tiles below the diagonal
+        b.h_xpoff.assign((size_t)b.count + 1, 0);
+        for (int i = 0; i < b.count; ++i) {
+            const int64_t T0 = std::max(0, (b.h_n[i] - 2 * SB + 63) / 64);
+            b.h_xpoff[i + 1] = b.h_xpoff[i] + T0 * (T0 - 1) / 2;
+        }
+    }
     b.h_goff.assign((size_t)b.count + 1, 0);
     for (int i = 0; i < b.count; ++i)
         b.h_goff[i + 1] = b.h_goff[i] + (int64_t)((b.h_n[i] + 63) / 64) * SB * SB;
@@ -1277,10 +1466,6 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
     // (256^3, profiles/r01_*): 1 is the fastest; fp64 MFMA (tools/fma64_bench.hip: 46 TFLOP/s
     // sustained vs 69 for v_fma_f64) buys nothing here because none of the variants is bound by
     // FMA issue or by HBM bytes -- they are bound by operand delivery (scalar-load latency).
-    static const int fused_mode = []() {
-        const char *e = std::getenv("SAAMGE_AMD_EIG_FUSED");
-        return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
-    }();
     const bool fused = fused_mode != 0;
     // rows per lane of the fused kernel (SAAMGE_AMD_EIG_RPL = 1 | 2)
     static const int rpl = []() {
@@ -1370,6 +1555,13 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
                 (double)div_up(npn, 2 * SF_ROWS) * (2 * SF_ROWS) < 1.10 * (double)div_up(npn, SF_ROWS) * SF_ROWS;
             if (fused_mode == 2) {
                 // (launched above)
+            } else if (fused_mode == 3 && npn >= 1) {
+                hipLaunchKernelGGL(sbr_fused_sym_kernel, dim3(cnt8 * div_up(npn, SF_ROWS)), dim3(S2_NT), 0, s, k0,
+                                   b.n.p, b.moff.p, b.voff.p, b.W.p, Vcur, b.Zbuf.p, Vnext, b.Xbuf.p, b.xpoff.p,
+                                   b.Xpart.p, b.trash.p, b.count, div_up(npn, SF_ROWS), SB);
+                hipLaunchKernelGGL(sbr_xsum_kernel, dim3(cnt8 * div_up(npn, SF_ROWS)), dim3(256), 0, s, k0, b.n.p,
+                                   b.voff.p, Vnext, b.Xbuf.p, b.xpoff.p, b.Xpart.p, b.goff.p, b.Gbuf.p, b.count,
+                                   div_up(npn, SF_ROWS), SB);
             } else if (npn >= 1 && two_rows)
                 hipLaunchKernelGGL((sbr_fused_kernel<true, 2>), dim3(cnt8 * div_up(npn, 2 * SF_ROWS)), dim3(S2_NT), 0, s,
                                    k0, b.n.p, b.moff.p, b.voff.p, b.W.p, Vcur, b.Zbuf.p, Vnext, b.Xbuf.p,

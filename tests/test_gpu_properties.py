@@ -147,7 +147,7 @@ def test_edge_cases():
 
 
 def test_one_stage_and_two_stage_eigensolvers_agree():
-    """SAAMGE_AMD_EIG=onestage selects the one-stage blocked Householder kernel; both paths must
+    """SAAMGE_AMD_EIG=onestage selects the one-stage blocked Householder kernel; every path must
     give the same hierarchy (coarse dims) and PCG history."""
     code = (
         "import sys, json; sys.path.insert(0, %r)\n"
@@ -157,15 +157,20 @@ def test_one_stage_and_two_stage_eigensolvers_agree():
         "h = capi.Hierarchy.from_problem(prob, capi.default_params(coarse_rtol=1e-28))\n"
         "x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-8)\n"
         "print(json.dumps({'nc': h.level_info(0)['ncoarse'], 'it': it, 'hist': list(hist)}))\n" % ROOT)
+    import json
     outs = []
-    for mode in ("onestage", "twostage"):
-        env = dict(os.environ, SAAMGE_AMD_EIG=mode)
+    # one-stage kernel, and the variants of the band reduction kept behind SAAMGE_AMD_EIG_FUSED
+    # (0 separate product / update, 1 fused (default), 2 fused on fp64 MFMA, 3 symmetric: lower tiles only)
+    variants = [{"SAAMGE_AMD_EIG": "onestage"}] + [{"SAAMGE_AMD_EIG": "twostage", "SAAMGE_AMD_EIG_FUSED": m}
+                                                   for m in ("1", "0", "2", "3")]
+    for extra in variants:
+        env = dict(os.environ, **extra)
         o = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert o.returncode == 0, o.stderr[-2000:]
-        import json
         outs.append(json.loads(o.stdout.strip().splitlines()[-1]))
-    assert outs[0]["nc"] == outs[1]["nc"] and outs[0]["it"] == outs[1]["it"]
-    assert np.allclose(outs[0]["hist"], outs[1]["hist"], rtol=1e-8)
+    for other in outs[1:]:
+        assert outs[0]["nc"] == other["nc"] and outs[0]["it"] == other["it"]
+        assert np.allclose(outs[0]["hist"], other["hist"], rtol=1e-8)
 
 
 @pytest.mark.parametrize("case", ["poisson3d", "mltest1", "mltest2", "random_partition"])
