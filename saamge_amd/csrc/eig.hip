@@ -240,13 +240,22 @@ __global__ __launch_bounds__(TRI_NT) void tridiag_kernel(const int *__restrict__
 // ---------------------------------------------------------------------------------------
 // Sturm sequence (dlaebz pivot rule): number of eigenvalues <= x
 // ---------------------------------------------------------------------------------------
+// 1 / q from the hardware seed + two Newton steps (<= 1 ulp): the Sturm recurrence is one long
+// chain of dependent divisions, and the IEEE-exact sequence is twice as long.  |q| >= pivmin.
+__device__ inline double chain_rcp(double q) {
+    double r = __builtin_amdgcn_rcp(q);
+    r = fma(fma(-q, r, 1.0), r, r);
+    r = fma(fma(-q, r, 1.0), r, r);
+    return r;
+}
+
 __device__ inline int sturm_count(int n, const double *d, const double *e, double x, double pivmin) {
     double q = d[0] - x;
     if (fabs(q) < pivmin) q = -pivmin;
     int cnt = (q <= 0.0) ? 1 : 0;
     for (int i = 1; i < n; ++i) {
         const double ei = e[i - 1];
-        q = d[i] - (ei * ei) / q - x;
+        q = d[i] - (ei * ei) * chain_rcp(q) - x;
         if (fabs(q) < pivmin) q = -pivmin;
         cnt += (q <= 0.0) ? 1 : 0;
     }
@@ -521,22 +530,22 @@ __global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
             for (int k = 0; k < nl - 1; ++k) {
                 double scale2 = fabs(lc[k]) + fabs(la[k + 1]);
                 if (k < nl - 2) scale2 += fabs(lb[k + 1]);
-                const double piv1 = (la[k] == 0.0) ? 0.0 : fabs(la[k]) / scale1;
+                const double piv1 = (la[k] == 0.0) ? 0.0 : fabs(la[k]) * chain_rcp(scale1);
                 if (lc[k] == 0.0) {
                     pin[k] = 0;
                     scale1 = scale2;
                     if (k < nl - 2) ld2[k] = 0.0;
                 } else {
-                    const double piv2 = fabs(lc[k]) / scale2;
+                    const double piv2 = fabs(lc[k]) * chain_rcp(scale2);
                     if (piv2 <= piv1) {
                         pin[k] = 0;
                         scale1 = scale2;
-                        lc[k] = lc[k] / la[k];
+                        lc[k] = lc[k] * chain_rcp(la[k]);
                         la[k + 1] -= lc[k] * lb[k];
                         if (k < nl - 2) ld2[k] = 0.0;
                     } else {
                         pin[k] = 1;
-                        const double mult = la[k] / lc[k];
+                        const double mult = la[k] * chain_rcp(lc[k]);
                         la[k] = lc[k];
                         const double temp = la[k + 1];
                         la[k + 1] = lb[k] - mult * temp;
@@ -626,7 +635,7 @@ __global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
                         }
                         break;
                     }
-                    z[k] = temp / ak;
+                    z[k] = temp * chain_rcp(ak);
                 }
             }
             __syncthreads();
