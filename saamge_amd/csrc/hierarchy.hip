@@ -186,9 +186,16 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         SA_HIP_CHECK(hipMemcpyAsync(aggA.val.data(), L.A.val.p, sizeof(double) * (size_t)L.A.nnz, hipMemcpyDeviceToHost, s));
         SA_HIP_CHECK(hipStreamSynchronize(s));
     }
+    // (the tables go to the device from the same thread, on a side stream, while the eigensolver runs)
+    static hipStream_t mis_stream = nullptr;
+    if (!mis_stream) SA_HIP_CHECK(hipStreamCreateWithFlags(&mis_stream, hipStreamNonBlocking));
     std::exception_ptr mis_err;
     std::thread mis_thread([&]() {
-        try { build_relations_mis(L.rel, aggregates ? &aggA : nullptr); } catch (...) { mis_err = std::current_exception(); }
+        try {
+            build_relations_mis(L.rel, aggregates ? &aggA : nullptr);
+            upload_relations_mis(L.drel, L.rel, mis_stream);
+            SA_HIP_CHECK(hipStreamSynchronize(mis_stream));
+        } catch (...) { mis_err = std::current_exception(); }
     });
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{mis_thread};
     const Relations &rel = L.rel;
@@ -380,8 +387,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     // ---- MIS stage (ContribTent::contrib_mises) ----
     mis_thread.join();
     if (mis_err) std::rethrow_exception(mis_err);
-    upload_relations_mis(L.drel, L.rel, s);
-    tm.lap("MIS tables (join + upload)", lev);
+    tm.lap("MIS tables (join)", lev);
     const int nm = rel.num_mises;
     std::vector<int64_t> g_off((size_t)nm + 1, 0);
     L.mis_u_off.assign((size_t)nm + 1, 0);
