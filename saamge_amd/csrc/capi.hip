@@ -390,6 +390,15 @@ int saamge_amd_lower_eigens_batched(int count, const int *n, const double *A, co
                        b.voff.p, b.W.p, dD.p, b.dis.p);
     eig_tridiagonalize(s, b);
     eig_count(s, b, vl, vu);
+    if (b.ss_failed) {     // few-eigenpairs path gave up: the dense path on a fresh copy
+        b.dense_only = true;
+        b.subspace = b.ss_failed = false;
+        SA_HIP_CHECK(hipMemcpyAsync(b.W.p, A, 8 * (size_t)b.h_moff[count], hipMemcpyDefault, s));
+        hipLaunchKernelGGL(apply_dscale_kernel, dim3(count), dim3(256), 0, s, count, b.n.p, b.moff.p,
+                           b.voff.p, b.W.p, dD.p, b.dis.p);
+        eig_tridiagonalize(s, b);
+        eig_count(s, b, vl, vu);
+    }
     std::vector<int64_t> eoff((size_t)count + 1, 0), xoff((size_t)count + 1, 0);
     for (int i = 0; i < count; ++i) {
         eoff[i + 1] = eoff[i] + b.h_m[i];

@@ -41,6 +41,10 @@ struct EigBatch {
     DBuf<int64_t> xpoff;
     std::vector<int64_t> h_xpoff;
     std::vector<int64_t> h_roff, h_goff;
+    // few-eigenpairs path (SAAMGE_AMD_EIG=subspace): Ritz values of the accepted block; `dense_only`
+    // forces the dense path for this batch (fallback after a failed subspace attempt)
+    DBuf<double> ss_mu;
+    bool subspace = false, dense_only = false, ss_failed = false;
     std::vector<int> h_n, h_m;
     std::vector<int64_t> h_moff, h_voff;
 };
@@ -59,6 +63,12 @@ bool eig_uses_two_stage();
 void eig_backtransform_two_stage(hipStream_t s, EigBatch &b, const int64_t *xoff, double *evecs);
 int64_t chase_reflector_count(int n);
 void eig_batch_two_stage_buffers(EigBatch &b, size_t nrefl, bool need_bandg, hipStream_t s);
+// few-eigenpairs path (eig2.hip), see there
+bool eig_use_subspace();
+bool eig_subspace_factor(hipStream_t s, EigBatch &b);
+bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu);
+void eig_subspace_vectors(hipStream_t s, EigBatch &b, const int64_t *eoff, const int64_t *xoff, double *evals,
+                          double *evecs);
 void eig_arena_release();   // frees the persistent workspace
 // bytes of device workspace one matrix of size n needs (for chunk sizing)
 size_t eig_workspace_bytes(int n);

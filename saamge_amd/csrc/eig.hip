@@ -846,8 +846,28 @@ size_t eig_workspace_bytes(int n) {
     return 8 * (nn * nn + nn * (EIG_NB + 8) + nn * nn / 2 + nn * (3 * EIG_SB + 2 * EIG_SB) + 64);
 }
 
+bool eig_use_subspace() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = std::getenv("SAAMGE_AMD_EIG");
+        v = (e && std::string(e) == "subspace") ? 1 : 0;
+    }
+    return v == 1;
+}
+
 void eig_tridiagonalize(hipStream_t s, EigBatch &b, int phases) {
     if (!b.count) return;
+    // (SAAMGE_AMD_SS_MIN_N: smallest agglomerate size of a batch that takes the few-eigenpairs path)
+    static const int ss_min_n = []() { const char *e = std::getenv("SAAMGE_AMD_SS_MIN_N"); return e ? std::atoi(e) : 1024; }();
+    if (eig_use_subspace() && !b.dense_only && b.max_n >= ss_min_n) {
+        // few-eigenpairs path: "phase 1" is the Cholesky factorisation, phase 2 has nothing to do
+        if (phases & 1) {
+            b.subspace = true;
+            b.ss_failed = !eig_subspace_factor(s, b);
+        }
+        return;
+    }
+    b.subspace = false;
     static bool attr0 = false;
     if (!attr0) {
         SA_HIP_CHECK(hipFuncSetAttribute((const void *)eigvec_kernel,
@@ -889,6 +909,12 @@ void eig_tridiagonalize(hipStream_t s, EigBatch &b, int phases) {
 
 void eig_count(hipStream_t s, EigBatch &b, double vl, double vu) {
     if (!b.count) return;
+    if (b.subspace) {
+        // (vl = -1 < every eigenvalue of the semidefinite C: the window is lambda <= vu)
+        if (!b.ss_failed) b.ss_failed = !eig_subspace_iterate(s, b, vu);
+        if (b.ss_failed) b.h_m.assign((size_t)b.count, 1);     // the caller redoes the batch densely
+        return;
+    }
     const size_t lds = sizeof(double) * 2 * (size_t)b.max_n;
     SA_REQUIRE(lds <= LDS_MAX, "agglomerate too large for the Sturm kernel");
     profiler().begin(s);
@@ -904,6 +930,11 @@ void eig_count(hipStream_t s, EigBatch &b, double vl, double vu) {
 void eig_vectors(hipStream_t s, EigBatch &b, const int64_t *eoff, const int64_t *xoff,
                  double *evals, double *evecs) {
     if (!b.count) return;
+    if (b.subspace) {
+        SA_REQUIRE(!b.ss_failed, "subspace eigensolver failed and was not redone densely");
+        eig_subspace_vectors(s, b, eoff, xoff, evals, evecs);
+        return;
+    }
     const size_t lds = vec_lds_bytes(b.max_n);
     SA_REQUIRE(lds <= LDS_MAX, "agglomerate too large for the LDS-resident inverse iteration");
     double flops = 0.0;

@@ -28,6 +28,12 @@ namespace saamge_amd {
 constexpr int SB = EIG_SB;      // band width
 constexpr int LDB = 2 * SB;     // band storage: distances 0 .. 2*SB-1 (band + bulge)
 
+__device__ inline double unit_rand_ss(unsigned a, unsigned b) {  // deterministic uniform(-1,1)
+    unsigned h = a * 2654435761u ^ (b + 0x9e3779b9u + (a << 6) + (a >> 2));
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return ((double)h + 0.5) * (2.0 / 4294967296.0) - 1.0;
+}
+
 __device__ inline double gsum16(double v) {   // sum inside each 16-lane group
     v += __shfl_xor(v, 1, 64);
     v += __shfl_xor(v, 2, 64);
@@ -550,7 +556,9 @@ constexpr int SF_ROWS = 64;   // rows per lane-row: 2 x 16 row operands + 16 acc
 // RPL = rows per lane (strip of 64 RPL rows): every column operand fetched through the scalar cache
 // feeds RPL FMAs.  The kernel is bound by that operand delivery (~17 TFLOP/s with one FMA per
 // fetched scalar, both on the 405-row and on the 2 600-row agglomerates), not by HBM.
-template <bool PROD, int RPL>
+// TERMS = 1: A22' -= V V^T only (the trailing update of the Cholesky factorisation of the
+// few-eigenpairs path: half the FMAs and scalar operands, Z is not read).
+template <bool PROD, int RPL, int TERMS = 2>
 __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__restrict__ ns,
                                                           const int64_t *__restrict__ moff,
                                                           const int64_t *__restrict__ voff,
@@ -578,6 +586,9 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
     if (np < 1) return;
     const int i0 = blk * (SF_ROWS * RPL);
     if (i0 >= np) return;
+    // TERMS == 1 (Cholesky): only the columns up to the end of this strip's diagonal tile -- the
+    // factorisation never reads the upper triangle of the trailing matrix
+    const int ncols = (TERMS == 1) ? min(np, i0 + SF_ROWS * RPL) : np;
     const bool prod = PROD && np >= 2;         // the next panel has reflectors
     double *A22 = Wm + moff[b] + (size_t)(k0 + SB + shift) * n + (k0 + SB + shift);
     const double *__restrict__ Z = Zbuf + voff[b] * SB + shift * SB;   // rows shifted
@@ -603,7 +614,7 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
         const int iac = min(ia, np - 1);
 #pragma unroll
         for (int c = 0; c < SB; ++c) {
-            za[r][c] = -Z[(size_t)iac * SB + c];
+            za[r][c] = (TERMS == 2) ? -Z[(size_t)iac * SB + c] : 0.0;
             va[r][c] = -Vc[(size_t)iac * SB + c];
             xa[r][c] = 0.0;
         }
@@ -612,15 +623,15 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
     // worked on (double-buffered in registers), so its HBM round trip is covered by KC x 48 RPL FMAs.
     int l0 = KC * w;
     double ta[RPL][KC], tn[RPL][KC];
-    if (l0 + KC <= np) {
+    if (l0 + KC <= ncols) {
 #pragma unroll
         for (int r = 0; r < RPL; ++r)
 #pragma unroll
             for (int k = 0; k < KC; ++k) ta[r][k] = pa[r][(size_t)(l0 + k) * sa[r]];
     }
-    for (; l0 + KC <= np; l0 += 4 * KC) {
+    for (; l0 + KC <= ncols; l0 += 4 * KC) {
         const int l1 = l0 + 4 * KC;
-        const bool more = l1 + KC <= np;    // wave-uniform
+        const bool more = l1 + KC <= ncols;    // wave-uniform
         if (more) {
 #pragma unroll
             for (int r = 0; r < RPL; ++r)
@@ -634,7 +645,8 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
 #pragma unroll
             for (int c = 0; c < SB; ++c)
 #pragma unroll
-                for (int r = 0; r < RPL; ++r) ta[r][k] = fma(za[r][c], vl[c], fma(va[r][c], zl[c], ta[r][k]));
+                for (int r = 0; r < RPL; ++r)
+                    ta[r][k] = (TERMS == 2) ? fma(za[r][c], vl[c], fma(va[r][c], zl[c], ta[r][k])) : fma(va[r][c], vl[c], ta[r][k]);
             if (prod) {
                 const double *vn = Vn + (size_t)(l0 + k) * SB;
 #pragma unroll
@@ -655,7 +667,7 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
                 for (int k = 0; k < KC; ++k) ta[r][k] = tn[r][k];
         }
     }
-    for (; l0 < np; ++l0) {                   // the last, partial group
+    for (; l0 < ncols; ++l0) {                // the last, partial group
         double t0[RPL];
 #pragma unroll
         for (int r = 0; r < RPL; ++r) t0[r] = pa[r][(size_t)l0 * sa[r]];
@@ -664,7 +676,8 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
 #pragma unroll
         for (int c = 0; c < SB; ++c)
 #pragma unroll
-            for (int r = 0; r < RPL; ++r) t0[r] = fma(za[r][c], vl[c], fma(va[r][c], zl[c], t0[r]));
+            for (int r = 0; r < RPL; ++r)
+                t0[r] = (TERMS == 2) ? fma(za[r][c], vl[c], fma(va[r][c], zl[c], t0[r])) : fma(va[r][c], vl[c], t0[r]);
         if (prod) {
             const double *vn = Vn + (size_t)l0 * SB;
 #pragma unroll
@@ -1632,6 +1645,476 @@ void eig_backtransform_two_stage(hipStream_t s, EigBatch &b, const int64_t *xoff
                            b.m.p, xoff, evecs);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "eig_backtransform", 0.0, flops);
+}
+
+
+// =========================================================================================
+// Few-eigenpairs path (SAAMGE_AMD_EIG=subspace, opt-in): the agglomerates want one or two
+// eigenpairs and the dense reduction pays 2 n^3 flops for them.  Here: C - sigma I = L L^T
+// (sigma < 0, C is positive semidefinite; n^3/3 FMAs through the SAME rank-16 update kernel as
+// the band reduction, with Z = L21 / 2, V = L21), then shift-invert subspace iteration on a block
+// of SS_B vectors with a Rayleigh-Ritz step per iteration that needs only the solves:
+//   Z = (C - sigma)^-1 X,  M = Z^T X (= Z^T (C - sigma) Z),  G = Z^T Z,  M c = mu G c,
+//   X <- Z c,  lambda = sigma + mu.
+// A pair is accepted when its inverse residual || Z_j - X_j / mu_j || bounds the residual of C
+// below SS_TOL; the count is certified by the first unwanted pair having converged above vu.
+// Anything that does not fit (more than SS_B - 2 wanted pairs, no convergence, a non-positive
+// pivot) makes the caller fall back to the dense path on a re-assembled matrix.
+// =========================================================================================
+constexpr int SS_B = 8;
+constexpr double SS_SIGMA = -1e-3;
+constexpr double SS_TOL = 1e-12;
+
+__global__ __launch_bounds__(256) void ss_shift_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
+                                                       double *__restrict__ W, double sigma) {
+    const int b = blockIdx.x, n = ns[b];
+    double *A = W + moff[b];
+    for (int i = threadIdx.x; i < n; i += 256) A[(size_t)i * n + i] -= sigma;
+}
+
+// Cholesky of the SB x SB diagonal block at k0 and L21 = A21 L11^-T below it.  L goes to the lower
+// triangle, its transpose to the upper one (the solves then stream columns both ways), and the
+// packed row-major copies V = L21, Z = L21 / 2 feed the trailing update.
+template <int NT>
+__global__ __launch_bounds__(NT) void chol_panel_kernel(int k0, const int *__restrict__ ns,
+                                                         const int64_t *__restrict__ moff,
+                                                         const int64_t *__restrict__ voff, double *__restrict__ W,
+                                                         double *__restrict__ Vpk, double *__restrict__ Zbuf,
+                                                         int *__restrict__ info) {
+    __shared__ double Ld[SB][SB + 1];
+    const int b = blockIdx.x, n = ns[b];
+    if (k0 >= n) return;
+    double *A = W + moff[b];
+    const int nb = min(SB, n - k0);
+    const int tid = threadIdx.x;
+    if (tid < SB * SB) {
+        const int i = tid >> 4, j = tid & 15;
+        Ld[i][j] = (i < nb && j <= i) ? A[(size_t)(k0 + j) * n + (k0 + i)] : ((i == j) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    // right-looking Cholesky of the block in LDS, one column per step (three barriers each)
+    __shared__ int bad;
+    if (tid == 0) bad = 0;
+    for (int j = 0; j < SB; ++j) {
+        __syncthreads();
+        if (tid == 0) {
+            double d = Ld[j][j];
+            if (!(d > 0.0)) { bad = 1; d = 1.0; }
+            Ld[j][j] = sqrt(d);
+        }
+        __syncthreads();
+        if (tid > j && tid < SB) Ld[tid][j] /= Ld[j][j];
+        __syncthreads();
+        if (tid < SB * SB) {
+            const int i = tid >> 4, c = tid & 15;
+            if (i > j && c > j && c <= i) Ld[i][c] -= Ld[i][j] * Ld[c][j];
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && bad) info[b] = 1;
+    // the diagonal block is kept as its INVERSE (lower part L11^-1, upper part its transpose): the
+    // solves then apply it as a small matrix product instead of a serial substitution
+    __shared__ double Li[SB][SB + 1];
+    if (tid < SB) {
+        const int j = tid;                       // column j of L11^-1 by forward substitution
+        for (int i = 0; i < SB; ++i) {
+            double t = (i == j) ? 1.0 : 0.0;
+            for (int q = j; q < i; ++q) t -= Ld[i][q] * Li[q][j];
+            Li[i][j] = (i >= j) ? t / Ld[i][i] : 0.0;
+        }
+    }
+    __syncthreads();
+    if (tid < SB * SB) {
+        const int i = tid >> 4, j = tid & 15;
+        if (i < nb && j <= i) {
+            A[(size_t)(k0 + j) * n + (k0 + i)] = Li[i][j];
+            A[(size_t)(k0 + i) * n + (k0 + j)] = Li[i][j];
+        }
+    }
+    if (nb < SB) return;
+    double *Vp = Vpk + voff[b] * SB;
+    for (int r = k0 + SB + tid; r < n; r += NT) {
+        double x[SB];
+#pragma unroll
+        for (int c = 0; c < SB; ++c) x[c] = A[(size_t)(k0 + c) * n + r];
+        double y[SB];                // row of L21 = x L11^-T: y_c = sum_{j <= c} x_j (L11^-1)(c, j)
+#pragma unroll
+        for (int c = 0; c < SB; ++c) {
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j <= c; ++j) t = fma(x[j], Li[c][j], t);
+            y[c] = t;
+        }
+        const size_t pr = (size_t)(r - k0 - SB) * SB;
+#pragma unroll
+        for (int c = 0; c < SB; ++c) {
+            A[(size_t)(k0 + c) * n + r] = y[c];
+            A[(size_t)r * n + (k0 + c)] = y[c];
+            Vp[pr + c] = y[c];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ss_init_kernel(const int *__restrict__ ns, const int64_t *__restrict__ voff,
+                                                      double *__restrict__ X) {
+    const int b = blockIdx.x, n = ns[b];
+    double *Xb = X + voff[b] * SB;
+    for (int idx = threadIdx.x; idx < n * SS_B; idx += 256)
+        Xb[idx] = unit_rand_ss((unsigned)idx, (unsigned)(b + 1));
+}
+
+// X <- T^-1 X for the lower (UPPER = false: L y = x) or the upper (UPPER = true: L^T z = y) factor,
+// SS_B right-hand sides, rows x SS_B row-major.  Right-looking by blocks of SB: the solved block
+// is eliminated from the remaining rows with coalesced column reads (the upper triangle holds L^T).
+template <bool UPPER, int NT>
+__global__ __launch_bounds__(NT) void ss_trsolve_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
+                                                         const int64_t *__restrict__ voff,
+                                                         const double *__restrict__ W, double *__restrict__ X) {
+    __shared__ double Td[SB][SB + 1];
+    __shared__ double ys[SB][SS_B];
+    __shared__ double xs[2][SB][SS_B];       // right-hand side rows of the current / next block
+    const int b = blockIdx.x, n = ns[b];
+    const double *A = W + moff[b];
+    double *Xb = X + voff[b] * SB;
+    const int tid = threadIdx.x;
+    const int nblk = (n + SB - 1) / SB;
+    const int ti = (tid >> 4) & 15, tj = tid & 15;
+    auto load_td = [&](int k0) {             // T11^-1 of the block at k0 (stored inverted), 0 outside its triangle
+        const int nb = min(SB, n - k0);
+        double v = 0.0;
+        if (ti < nb && tj < nb && (UPPER ? tj >= ti : tj <= ti)) v = A[(size_t)(k0 + tj) * n + (k0 + ti)];
+        return v;
+    };
+    {
+        const int k0 = UPPER ? (nblk - 1) * SB : 0;
+        const int nb = min(SB, n - k0);
+        if (tid < SB * SS_B) {
+            const int c = tid >> 3, jj = tid & 7;
+            xs[0][c][jj] = (c < nb) ? Xb[(size_t)(k0 + c) * SS_B + jj] : 0.0;
+        }
+    }
+    double td_next = load_td(UPPER ? (nblk - 1) * SB : 0);
+    for (int bb = 0; bb < nblk; ++bb) {
+        const int k0 = UPPER ? (nblk - 1 - bb) * SB : bb * SB;
+        const int nb = min(SB, n - k0);
+        const int cur = bb & 1;
+        if (tid < SB * SB) Td[ti][tj] = td_next;
+        __syncthreads();
+        if (tid < SB * SS_B) {      // y = T11^-1 x
+            const int c = tid >> 3, jj = tid & 7;
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < SB; ++i) t = fma(Td[c][i], xs[cur][i][jj], t);
+            ys[c][jj] = (c < nb) ? t : 0.0;
+            if (c < nb) Xb[(size_t)(k0 + c) * SS_B + jj] = t;
+        }
+        // the next block's inverse is requested now; its rows of the right-hand side are caught in LDS by
+        // the threads that update them below
+        const int kn = UPPER ? k0 - SB : k0 + SB;
+        if (bb + 1 < nblk) td_next = load_td(kn);
+        __syncthreads();
+        const int r_lo = UPPER ? 0 : k0 + nb, r_hi = UPPER ? k0 : n;
+        for (int r = r_lo + tid; r < r_hi; r += NT) {
+            double acc[SS_B];
+#pragma unroll
+            for (int j = 0; j < SS_B; ++j) acc[j] = Xb[(size_t)r * SS_B + j];
+            for (int c = 0; c < nb; ++c) {
+                const double t = A[(size_t)(k0 + c) * n + r];     // T(r, k0 + c): column k0 + c, row r
+#pragma unroll
+                for (int j = 0; j < SS_B; ++j) acc[j] = fma(-t, ys[c][j], acc[j]);
+            }
+            const bool in_next = (r >= kn && r < kn + SB);
+#pragma unroll
+            for (int j = 0; j < SS_B; ++j) {
+                Xb[(size_t)r * SS_B + j] = acc[j];
+                if (in_next) xs[cur ^ 1][r - kn][j] = acc[j];
+            }
+        }
+        if (bb + 1 < nblk) {        // rows of the next block beyond the matrix (partial last block of the forward solve)
+            if (tid < SB * SS_B) {
+                const int c = tid >> 3, jj = tid & 7;
+                if (kn + c >= n) xs[cur ^ 1][c][jj] = 0.0;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Rayleigh-Ritz on span(Z) from M = Z^T X and G = Z^T Z, inverse residuals of the previous pairs,
+// X <- Z C.  state[b]: bit 0 = converged (the wanted pairs and the first unwanted one), count in
+// bits 8.., bit 1 = failure (too many wanted pairs / breakdown).  mu[b][SS_B] ascending.
+__global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, const int64_t *__restrict__ voff,
+                                                    double *__restrict__ X, const double *__restrict__ Z,
+                                                    double *__restrict__ mu, int *__restrict__ state, int iter,
+                                                    double sigma, double vu) {
+    __shared__ double part[32][2 * SS_B][SS_B];     // [row group][M rows | G rows][column j]
+    __shared__ double Ms[SS_B][SS_B], Gs[SS_B][SS_B], Cs[SS_B][SS_B], res2[SS_B], mus[SS_B], mu_old[SS_B];
+    const int b = blockIdx.x, n = ns[b];
+    double *Xb = X + voff[b] * SB;
+    const double *Zb = Z + voff[b] * SB;
+    const int tid = threadIdx.x;
+    const int j = tid & 7, grp = tid >> 3;          // column j, row group (32 of them)
+    if (tid < SS_B) mu_old[tid] = (iter > 0) ? mu[(size_t)b * SS_B + tid] : 1.0;
+    __syncthreads();
+    {
+        double am[SS_B], ag[SS_B], rs = 0.0;
+#pragma unroll
+        for (int i = 0; i < SS_B; ++i) { am[i] = 0.0; ag[i] = 0.0; }
+        const double th = 1.0 / mu_old[j];
+        for (int r = grp; r < n; r += 32) {
+            const double xj = Xb[(size_t)r * SS_B + j], zj = Zb[(size_t)r * SS_B + j];
+#pragma unroll
+            for (int i = 0; i < SS_B; ++i) {
+                const double zi = Zb[(size_t)r * SS_B + i];
+                am[i] = fma(zi, xj, am[i]);
+                ag[i] = fma(zi, zj, ag[i]);
+            }
+            const double d = zj - th * xj;
+            rs = fma(d, d, rs);
+        }
+#pragma unroll
+        for (int i = 0; i < SS_B; ++i) { part[grp][i][j] = am[i]; part[grp][SS_B + i][j] = ag[i]; }
+        __syncthreads();
+        if (tid < 2 * SS_B * SS_B) {
+            const int i = tid >> 3, jj = tid & 7;
+            double sum = 0.0;
+            for (int g = 0; g < 32; ++g) sum += part[g][i][jj];
+            if (i < SS_B) Ms[i][jj] = sum; else Gs[i - SS_B][jj] = sum;
+        }
+        __syncthreads();
+        part[grp][0][j] = rs;
+        __syncthreads();
+        if (tid < SS_B) {
+            double sum = 0.0;
+            for (int g = 0; g < 32; ++g) sum += part[g][0][tid];
+            res2[tid] = sum;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int st = 0;
+        // convergence of the PREVIOUS pairs (X, mu_old): || C x - lambda x || <= || C - sigma || mu || z - x / mu ||
+        if (iter > 0) {
+            int k = 0;
+            for (int q = 0; q < SS_B; ++q) if (sigma + mu_old[q] <= vu) ++k;
+            if (k > SS_B - 2) st |= 2;
+            else {
+                // residual bounds of the wanted pairs; the first unwanted one only has to be pinned
+                // above the window (an eigenvalue lies within the bound of its Ritz value)
+                bool ok = true;
+                for (int q = 0; q < max(k, 1); ++q) ok = ok && (2.5 * mu_old[q] * sqrt(res2[q]) <= SS_TOL);
+                if (k >= 1) ok = ok && (2.5 * mu_old[k] * sqrt(res2[k]) < 0.5 * (sigma + mu_old[k] - vu));
+                if (ok) st |= 1 | (max(k, 1) << 8);
+            }
+        }
+        if (!(st & 1)) {
+            // G = R^T R, S = R^-T (M sym) R^-1, Jacobi, C = R^-1 V
+            __shared__ double R[SS_B][SS_B + 1], S[SS_B][SS_B + 1], V[SS_B][SS_B + 1];   // (LDS, not scratch)
+            bool ok = true;
+            for (int c = 0; c < SS_B; ++c)
+                for (int r2 = 0; r2 < SS_B; ++r2) { R[r2][c] = 0.0; V[r2][c] = (r2 == c) ? 1.0 : 0.0; }
+            for (int c = 0; c < SS_B; ++c) {      // upper Cholesky factor, row by row
+                double d = Gs[c][c];
+                for (int q = 0; q < c; ++q) d -= R[q][c] * R[q][c];
+                if (!(d > 0.0)) { ok = false; d = 1.0; }
+                d = sqrt(d);
+                R[c][c] = d;
+                for (int c2 = c + 1; c2 < SS_B; ++c2) {
+                    double t = 0.5 * (Gs[c][c2] + Gs[c2][c]);
+                    for (int q = 0; q < c; ++q) t -= R[q][c] * R[q][c2];
+                    R[c][c2] = t / d;
+                }
+            }
+            // T1 = R^-T Msym  (solve R^T T1 = Msym), S = T1 R^-1 (solve S R = T1)
+            for (int c = 0; c < SS_B; ++c)
+                for (int r2 = 0; r2 < SS_B; ++r2) {
+                    double t = 0.5 * (Ms[r2][c] + Ms[c][r2]);
+                    for (int q = 0; q < r2; ++q) t -= R[q][r2] * S[q][c];
+                    S[r2][c] = t / R[r2][r2];
+                }
+            for (int r2 = 0; r2 < SS_B; ++r2)
+                for (int c = 0; c < SS_B; ++c) {
+                    double t = S[r2][c];
+                    for (int q = 0; q < c; ++q) t -= S[r2][q] * R[q][c];
+                    S[r2][c] = t / R[c][c];
+                }
+            for (int r2 = 0; r2 < SS_B; ++r2)
+                for (int c = r2 + 1; c < SS_B; ++c) { const double t = 0.5 * (S[r2][c] + S[c][r2]); S[r2][c] = t; S[c][r2] = t; }
+            for (int sweep = 0; sweep < 12; ++sweep) {
+                double off = 0.0;
+                for (int p2 = 0; p2 < SS_B; ++p2)
+                    for (int q = p2 + 1; q < SS_B; ++q) off += S[p2][q] * S[p2][q];
+                double dg = 0.0;
+                for (int p2 = 0; p2 < SS_B; ++p2) dg += S[p2][p2] * S[p2][p2];
+                if (off <= 1e-34 * dg) break;
+                for (int p2 = 0; p2 < SS_B; ++p2)
+                    for (int q = p2 + 1; q < SS_B; ++q) {
+                        if (S[p2][q] == 0.0) continue;
+                        const double tau = (S[q][q] - S[p2][p2]) / (2.0 * S[p2][q]);
+                        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        const double cc = 1.0 / sqrt(1.0 + t * t), sn = t * cc;
+                        for (int k2 = 0; k2 < SS_B; ++k2) {
+                            const double a = S[k2][p2], bq = S[k2][q];
+                            S[k2][p2] = cc * a - sn * bq;
+                            S[k2][q] = sn * a + cc * bq;
+                        }
+                        for (int k2 = 0; k2 < SS_B; ++k2) {
+                            const double a = S[p2][k2], bq = S[q][k2];
+                            S[p2][k2] = cc * a - sn * bq;
+                            S[q][k2] = sn * a + cc * bq;
+                        }
+                        for (int k2 = 0; k2 < SS_B; ++k2) {
+                            const double a = V[k2][p2], bq = V[k2][q];
+                            V[k2][p2] = cc * a - sn * bq;
+                            V[k2][q] = sn * a + cc * bq;
+                        }
+                    }
+            }
+            int order[SS_B];
+            for (int q = 0; q < SS_B; ++q) order[q] = q;
+            for (int a2 = 0; a2 < SS_B; ++a2)
+                for (int b2 = a2 + 1; b2 < SS_B; ++b2)
+                    if (S[order[b2]][order[b2]] < S[order[a2]][order[a2]]) { const int t = order[a2]; order[a2] = order[b2]; order[b2] = t; }
+            for (int q = 0; q < SS_B; ++q) {
+                const int src = order[q];
+                mus[q] = S[src][src];
+                if (!(mus[q] > 0.0)) ok = false;
+                // column q of C = R^-1 V(:, src)
+                for (int r2 = SS_B - 1; r2 >= 0; --r2) {
+                    double t = V[r2][src];
+                    for (int c2 = r2 + 1; c2 < SS_B; ++c2) t -= R[r2][c2] * Cs[c2][q];
+                    Cs[r2][q] = t / R[r2][r2];
+                }
+            }
+            if (!ok) st |= 2;
+        }
+        state[b] = st;
+        Ms[0][0] = (double)st;
+    }
+    __syncthreads();
+    const int st = (int)Ms[0][0];
+    if (st & 3) return;            // converged (X, mu stay the accepted pairs) or failed
+    if (tid < SS_B) mu[(size_t)b * SS_B + tid] = mus[tid];
+    for (int r = tid; r < n; r += 256) {
+        double z[SS_B], x[SS_B];
+#pragma unroll
+        for (int i = 0; i < SS_B; ++i) z[i] = Zb[(size_t)r * SS_B + i];
+#pragma unroll
+        for (int q = 0; q < SS_B; ++q) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < SS_B; ++i) t = fma(z[i], Cs[i][q], t);
+            x[q] = t;
+        }
+#pragma unroll
+        for (int q = 0; q < SS_B; ++q) Xb[(size_t)r * SS_B + q] = x[q];
+    }
+}
+
+__global__ __launch_bounds__(256) void ss_output_kernel(const int *__restrict__ ns, const int64_t *__restrict__ voff,
+                                                        const double *__restrict__ X, const double *__restrict__ mu,
+                                                        const double *__restrict__ dis, const int *__restrict__ ms,
+                                                        const int64_t *__restrict__ eoff, const int64_t *__restrict__ xoff,
+                                                        double *__restrict__ evals, double *__restrict__ evecs,
+                                                        double sigma) {
+    const int b = blockIdx.x, n = ns[b], m = ms[b];
+    const double *Xb = X + voff[b] * SB;
+    for (int q = threadIdx.x; q < m; q += 256) evals[eoff[b] + q] = sigma + mu[(size_t)b * SS_B + q];
+    for (int idx = threadIdx.x; idx < n * m; idx += 256) {
+        const int r = idx % n, q = idx / n;
+        evecs[xoff[b] + (size_t)q * n + r] = dis[voff[b] + r] * Xb[(size_t)r * SS_B + q];
+    }
+}
+
+// C - sigma I = L L^T for every matrix of the batch (in place, L below / L^T above the diagonal).
+// Returns false when a pivot was not positive.
+bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
+    const int nmax = b.max_n;
+    b.h_xpoff.clear();
+    b.h_goff.assign((size_t)b.count + 1, 0);
+    b.h_roff.assign((size_t)b.count + 1, 0);
+    eig_batch_two_stage_buffers(b, 1, false, s);
+    DBuf<int> info((size_t)b.count);
+    info.zero(s);
+    hipLaunchKernelGGL(ss_shift_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, SS_SIGMA);
+    const int cnt8 = 8 * div_up(b.count, 8);
+    profiler().begin(s);
+    for (int k0 = 0; k0 < nmax; k0 += SB) {
+        if (nmax > 768)
+            hipLaunchKernelGGL((chol_panel_kernel<1024>), dim3(b.count), dim3(1024), 0, s, k0, b.n.p, b.moff.p, b.voff.p,
+                               b.W.p, b.Vpk.p, b.Zbuf.p, info.p);
+        else
+            hipLaunchKernelGGL((chol_panel_kernel<256>), dim3(b.count), dim3(256), 0, s, k0, b.n.p, b.moff.p, b.voff.p,
+                               b.W.p, b.Vpk.p, b.Zbuf.p, info.p);
+        const int np = nmax - k0 - SB;
+        if (np >= 1) {
+            if (np > 192)
+                hipLaunchKernelGGL((sbr_fused_kernel<false, 2, 1>), dim3(cnt8 * div_up(np, 2 * SF_ROWS)), dim3(S2_NT), 0, s, k0,
+                                   b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
+                                   b.Gbuf.p, b.trash.p, b.count, div_up(np, 2 * SF_ROWS), 0);
+            else
+                hipLaunchKernelGGL((sbr_fused_kernel<false, 1, 1>), dim3(cnt8 * div_up(np, SF_ROWS)), dim3(S2_NT), 0, s, k0,
+                                   b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
+                                   b.Gbuf.p, b.trash.p, b.count, div_up(np, SF_ROWS), 0);
+        }
+    }
+    SA_HIP_CHECK(hipGetLastError());
+    profiler().end(s, "eig_ss_cholesky", 0.0, 0.0);
+    auto h = info.to_host(s);
+    for (int v : h) if (v) return false;
+    return true;
+}
+
+// Subspace iteration; fills b.h_m / b.m.  Returns false when some matrix needs the dense path.
+bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
+    DBuf<int> state((size_t)b.count);
+    state.zero(s);
+    double *X = b.Xbuf.p, *Z = b.Vpk2.p, *mu = b.d.p;     // d: rows >= SS_B per matrix is checked by the caller
+    DBuf<double> mubuf((size_t)b.count * SS_B);
+    mu = mubuf.p;
+    profiler().begin(s);
+    hipLaunchKernelGGL(ss_init_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, X);
+    bool done = false, failed = false;
+    std::vector<int> hstate;
+    for (int iter = 0; iter < 80 && !done; ++iter) {
+        SA_HIP_CHECK(hipMemcpyAsync(Z, X, sizeof(double) * (size_t)b.h_voff[b.count] * SB, hipMemcpyDeviceToDevice, s));
+        if (false) {      // (1024 threads per matrix measured slower on the 2 600-row level: 17 vs 7 ms per solve)
+            hipLaunchKernelGGL((ss_trsolve_kernel<false, 1024>), dim3(b.count), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z);
+            hipLaunchKernelGGL((ss_trsolve_kernel<true, 1024>), dim3(b.count), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z);
+        } else {
+            hipLaunchKernelGGL((ss_trsolve_kernel<false, 256>), dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z);
+            hipLaunchKernelGGL((ss_trsolve_kernel<true, 256>), dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z);
+        }
+        hipLaunchKernelGGL(ss_rr_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, X, Z, mu, state.p, iter,
+                           SS_SIGMA, vu);
+        if (iter >= 3 && (iter % 2) == 1) {
+            auto t = state.to_host(s);
+            hstate.assign(t.begin(), t.end());
+            done = true;
+            for (int v : hstate) {
+                if (v & 2) failed = true;
+                if (!(v & 3)) done = false;
+            }
+            if (failed) break;
+        }
+    }
+    SA_HIP_CHECK(hipGetLastError());
+    profiler().end(s, "eig_ss_iterate", 0.0, 0.0);
+    if (failed || !done) return false;
+    b.h_m.assign((size_t)b.count, 1);
+    for (int i = 0; i < b.count; ++i) b.h_m[i] = hstate[i] >> 8;
+    b.m.from_host(b.h_m, s);
+    b.ss_mu = std::move(mubuf);
+    return true;
+}
+
+void eig_subspace_vectors(hipStream_t s, EigBatch &b, const int64_t *eoff, const int64_t *xoff, double *evals,
+                          double *evecs) {
+    profiler().begin(s);
+    hipLaunchKernelGGL(ss_output_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, b.Xbuf.p, b.ss_mu.p, b.dis.p,
+                       b.m.p, eoff, xoff, evals, evecs, SS_SIGMA);
+    SA_HIP_CHECK(hipGetLastError());
+    profiler().end(s, "eig_ss_output", 0.0, 0.0);
 }
 
 }  // namespace saamge_amd

@@ -270,12 +270,22 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     }
     EigBatch batches[2];
     int pend_ae0[2] = {0, 0}, pend_cnt[2] = {0, 0};
+    int64_t pend_row0[2] = {0, 0};
     auto post = [&](int slot) {   // band -> tridiagonal, counts, eigenvectors of the chunk in `slot`
         EigBatch &batch = batches[slot];
         const int ae0 = pend_ae0[slot], cnt = pend_cnt[slot];
         if (pipelined) SA_HIP_CHECK(hipStreamWaitEvent(qb, ev_band[slot], 0));
         eig_tridiagonalize(qb, batch, 2);
         eig_count(qb, batch, -1.0, L.theta);
+        if (batch.ss_failed) {   // few-eigenpairs path gave up on this chunk: dense path on re-assembled matrices
+            batch.dense_only = true;
+            batch.subspace = batch.ss_failed = false;
+            const RowsSpan span{(int64_t)L.rel.AE_to_dof.I[ae0], (int64_t)L.rel.AE_to_dof.I[nparts]};
+            ae_build(qb, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch, true,
+                     P.keep_debug ? L.ae_D.p + pend_row0[slot] : nullptr, keep_rows ? &span : nullptr);
+            eig_tridiagonalize(qb, batch, 3);
+            eig_count(qb, batch, -1.0, L.theta);
+        }
         chunks.emplace_back();
         Chunk &c = chunks.back();
         c.ae0 = ae0;
@@ -315,6 +325,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         if (pipelined) SA_HIP_CHECK(hipEventRecord(ev_band[slot], qa));
         pend_ae0[slot] = ae0;
         pend_cnt[slot] = cnt;
+        pend_row0[slot] = row0;
         if (prev >= 0) post(prev);
         prev = slot;
         row0 += batch.h_voff[cnt];

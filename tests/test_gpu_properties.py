@@ -163,6 +163,8 @@ def test_one_stage_and_two_stage_eigensolvers_agree():
     # (0 separate product / update, 1 fused (default), 2 fused on fp64 MFMA, 3 symmetric: lower tiles only)
     variants = [{"SAAMGE_AMD_EIG": "onestage"}] + [{"SAAMGE_AMD_EIG": "twostage", "SAAMGE_AMD_EIG_FUSED": m}
                                                    for m in ("1", "0", "2", "3")]
+    # the few-eigenpairs path (Cholesky + shift-invert subspace iteration) on every agglomerate size
+    variants.append({"SAAMGE_AMD_EIG": "subspace", "SAAMGE_AMD_SS_MIN_N": "0"})
     for extra in variants:
         env = dict(os.environ, **extra)
         o = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
