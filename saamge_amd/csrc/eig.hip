@@ -846,11 +846,15 @@ size_t eig_workspace_bytes(int n) {
     return 8 * (nn * nn + nn * (EIG_NB + 8) + nn * nn / 2 + nn * (3 * EIG_SB + 2 * EIG_SB) + 64);
 }
 
+// The few-eigenpairs path (eig2.hip) is taken by default for batches of LARGE agglomerates
+// (SAAMGE_AMD_SS_MIN_N, default 1024: the coarse levels), where it is measured faster than the
+// dense reduction; SAAMGE_AMD_EIG=twostage / onestage / dense switches it off, =subspace (with
+// SAAMGE_AMD_SS_MIN_N=0) forces it everywhere.
 bool eig_use_subspace() {
     static int v = -1;
     if (v < 0) {
         const char *e = std::getenv("SAAMGE_AMD_EIG");
-        v = (e && std::string(e) == "subspace") ? 1 : 0;
+        v = (!e || std::string(e) == "subspace") ? 1 : 0;
     }
     return v == 1;
 }

@@ -2078,7 +2078,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     std::vector<int> hstate;
     for (int iter = 0; iter < 80 && !done; ++iter) {
         SA_HIP_CHECK(hipMemcpyAsync(Z, X, sizeof(double) * (size_t)b.h_voff[b.count] * SB, hipMemcpyDeviceToDevice, s));
-        if (false) {      // (1024 threads per matrix measured slower on the 2 600-row level: 17 vs 7 ms per solve)
+        if (b.max_n > 768) {
             hipLaunchKernelGGL((ss_trsolve_kernel<false, 1024>), dim3(b.count), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z);
             hipLaunchKernelGGL((ss_trsolve_kernel<true, 1024>), dim3(b.count), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z);
         } else {
