@@ -1840,6 +1840,71 @@ __global__ __launch_bounds__(NT) void ss_trsolve_kernel(const int *__restrict__ 
     }
 }
 
+// Both solves in one launch with the right-hand sides resident in LDS (row pitch 9 doubles:
+// conflict-free for lanes = rows): the factor is then the only global traffic, read once per
+// triangle.  For agglomerates up to ~2 000 rows.
+constexpr int XLP = SS_B + 1;
+__global__ __launch_bounds__(256) void ss_solve_lds_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
+                                                           const int64_t *__restrict__ voff,
+                                                           const double *__restrict__ W, const double *__restrict__ X,
+                                                           double *__restrict__ Zout) {
+    extern __shared__ __align__(16) double xl[];      // [n][XLP]
+    __shared__ double Td[SB][SB + 1];
+    __shared__ double ys[SB][SS_B];
+    const int b = blockIdx.x, n = ns[b];
+    const double *A = W + moff[b];
+    const double *Xb = X + voff[b] * SB;
+    double *Zb = Zout + voff[b] * SB;
+    const int tid = threadIdx.x;
+    const int nblk = (n + SB - 1) / SB;
+    const int ti = tid >> 4, tj = tid & 15;
+    for (int idx = tid; idx < n * SS_B; idx += 256) xl[(idx >> 3) * XLP + (idx & 7)] = Xb[idx];
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool upper = pass == 1;
+        auto load_td = [&](int k0) {
+            const int nb = min(SB, n - k0);
+            double v = 0.0;
+            if (ti < nb && tj < nb && (upper ? tj >= ti : tj <= ti)) v = A[(size_t)(k0 + tj) * n + (k0 + ti)];
+            return v;
+        };
+        double td_next = load_td(upper ? (nblk - 1) * SB : 0);
+        for (int bb = 0; bb < nblk; ++bb) {
+            const int k0 = upper ? (nblk - 1 - bb) * SB : bb * SB;
+            const int nb = min(SB, n - k0);
+            Td[ti][tj] = td_next;
+            __syncthreads();
+            if (tid < SB * SS_B) {      // y = T11^-1 x (the stored block is the inverse)
+                const int c = tid >> 3, jj = tid & 7;
+                double t = 0.0;
+#pragma unroll
+                for (int i = 0; i < SB; ++i) t = fma(Td[c][i], (i < nb) ? xl[(k0 + i) * XLP + jj] : 0.0, t);
+                ys[c][jj] = (c < nb) ? t : 0.0;
+            }
+            if (bb + 1 < nblk) td_next = load_td(upper ? k0 - SB : k0 + SB);
+            __syncthreads();
+            if (tid < SB * SS_B) {
+                const int c = tid >> 3, jj = tid & 7;
+                if (c < nb) xl[(k0 + c) * XLP + jj] = ys[c][jj];
+            }
+            const int r_lo = upper ? 0 : k0 + nb, r_hi = upper ? k0 : n;
+            for (int r = r_lo + tid; r < r_hi; r += 256) {
+                double acc[SS_B];
+#pragma unroll
+                for (int j = 0; j < SS_B; ++j) acc[j] = xl[r * XLP + j];
+                for (int c = 0; c < nb; ++c) {
+                    const double t = A[(size_t)(k0 + c) * n + r];
+#pragma unroll
+                    for (int j = 0; j < SS_B; ++j) acc[j] = fma(-t, ys[c][j], acc[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < SS_B; ++j) xl[r * XLP + j] = acc[j];
+            }
+            __syncthreads();
+        }
+    }
+    for (int idx = tid; idx < n * SS_B; idx += 256) Zb[idx] = xl[(idx >> 3) * XLP + (idx & 7)];
+}
+
 // Rayleigh-Ritz on span(Z) from M = Z^T X and G = Z^T Z, inverse residuals of the previous pairs,
 // X <- Z C.  state[b]: bit 0 = converged (the wanted pairs and the first unwanted one), count in
 // bits 8.., bit 1 = failure (too many wanted pairs / breakdown).  mu[b][SS_B] ascending.
@@ -1891,6 +1956,9 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
         }
         __syncthreads();
     }
+    __shared__ double R[SS_B][SS_B + 1], S[SS_B][SS_B + 1], V[SS_B][SS_B + 1];
+    __shared__ double rot_c[4], rot_s[4];
+    __shared__ int sh_st, sh_ok;
     if (tid == 0) {
         int st = 0;
         // convergence of the PREVIOUS pairs (X, mu_old): || C x - lambda x || <= || C - sigma || mu || z - x / mu ||
@@ -1907,16 +1975,16 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
                 if (ok) st |= 1 | (max(k, 1) << 8);
             }
         }
-        if (!(st & 1)) {
-            // G = R^T R, S = R^-T (M sym) R^-1, Jacobi, C = R^-1 V
-            __shared__ double R[SS_B][SS_B + 1], S[SS_B][SS_B + 1], V[SS_B][SS_B + 1];   // (LDS, not scratch)
-            bool ok = true;
+        sh_st = st;
+        sh_ok = 1;
+        if (!(st & 3)) {
+            // G = R^T R (upper factor, row by row): the only serial piece (~100 flops)
             for (int c = 0; c < SS_B; ++c)
-                for (int r2 = 0; r2 < SS_B; ++r2) { R[r2][c] = 0.0; V[r2][c] = (r2 == c) ? 1.0 : 0.0; }
-            for (int c = 0; c < SS_B; ++c) {      // upper Cholesky factor, row by row
+                for (int r2 = 0; r2 < SS_B; ++r2) R[r2][c] = 0.0;
+            for (int c = 0; c < SS_B; ++c) {
                 double d = Gs[c][c];
                 for (int q = 0; q < c; ++q) d -= R[q][c] * R[q][c];
-                if (!(d > 0.0)) { ok = false; d = 1.0; }
+                if (!(d > 0.0)) { sh_ok = 0; d = 1.0; }
                 d = sqrt(d);
                 R[c][c] = d;
                 for (int c2 = c + 1; c2 < SS_B; ++c2) {
@@ -1925,69 +1993,109 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
                     R[c][c2] = t / d;
                 }
             }
-            // T1 = R^-T Msym  (solve R^T T1 = Msym), S = T1 R^-1 (solve S R = T1)
-            for (int c = 0; c < SS_B; ++c)
-                for (int r2 = 0; r2 < SS_B; ++r2) {
-                    double t = 0.5 * (Ms[r2][c] + Ms[c][r2]);
-                    for (int q = 0; q < r2; ++q) t -= R[q][r2] * S[q][c];
-                    S[r2][c] = t / R[r2][r2];
-                }
-            for (int r2 = 0; r2 < SS_B; ++r2)
-                for (int c = 0; c < SS_B; ++c) {
-                    double t = S[r2][c];
-                    for (int q = 0; q < c; ++q) t -= S[r2][q] * R[q][c];
-                    S[r2][c] = t / R[c][c];
-                }
-            for (int r2 = 0; r2 < SS_B; ++r2)
-                for (int c = r2 + 1; c < SS_B; ++c) { const double t = 0.5 * (S[r2][c] + S[c][r2]); S[r2][c] = t; S[c][r2] = t; }
-            for (int sweep = 0; sweep < 12; ++sweep) {
-                double off = 0.0;
-                for (int p2 = 0; p2 < SS_B; ++p2)
-                    for (int q = p2 + 1; q < SS_B; ++q) off += S[p2][q] * S[p2][q];
-                double dg = 0.0;
-                for (int p2 = 0; p2 < SS_B; ++p2) dg += S[p2][p2] * S[p2][p2];
-                if (off <= 1e-34 * dg) break;
-                for (int p2 = 0; p2 < SS_B; ++p2)
-                    for (int q = p2 + 1; q < SS_B; ++q) {
-                        if (S[p2][q] == 0.0) continue;
-                        const double tau = (S[q][q] - S[p2][p2]) / (2.0 * S[p2][q]);
-                        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                        const double cc = 1.0 / sqrt(1.0 + t * t), sn = t * cc;
-                        for (int k2 = 0; k2 < SS_B; ++k2) {
-                            const double a = S[k2][p2], bq = S[k2][q];
-                            S[k2][p2] = cc * a - sn * bq;
-                            S[k2][q] = sn * a + cc * bq;
-                        }
-                        for (int k2 = 0; k2 < SS_B; ++k2) {
-                            const double a = S[p2][k2], bq = S[q][k2];
-                            S[p2][k2] = cc * a - sn * bq;
-                            S[q][k2] = sn * a + cc * bq;
-                        }
-                        for (int k2 = 0; k2 < SS_B; ++k2) {
-                            const double a = V[k2][p2], bq = V[k2][q];
-                            V[k2][p2] = cc * a - sn * bq;
-                            V[k2][q] = sn * a + cc * bq;
-                        }
-                    }
+        }
+    }
+    __syncthreads();
+    if (!(sh_st & 3) && tid < 64) {
+        // ---- S = R^-T Msym R^-1 and its eigen-decomposition by parallel-order Jacobi, one wavefront ----
+        const int lr = tid >> 3, lc = tid & 7;
+        auto wsync = []() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+        V[lr][lc] = (lr == lc) ? 1.0 : 0.0;
+        if (tid < SS_B) {                     // column c of T1 = R^-T Msym: forward substitution
+            const int c = tid;
+            for (int r2 = 0; r2 < SS_B; ++r2) {
+                double t = 0.5 * (Ms[r2][c] + Ms[c][r2]);
+                for (int q = 0; q < r2; ++q) t -= R[q][r2] * S[q][c];
+                S[r2][c] = t / R[r2][r2];
             }
+        }
+        wsync();
+        if (tid < SS_B) {                     // row r of S = T1 R^-1
+            const int r2 = tid;
+            for (int c = 0; c < SS_B; ++c) {
+                double t = S[r2][c];
+                for (int q = 0; q < c; ++q) t -= S[r2][q] * R[q][c];
+                S[r2][c] = t / R[c][c];
+            }
+        }
+        wsync();
+        {
+            const double t = 0.5 * (S[lr][lc] + S[lc][lr]);
+            wsync();
+            S[lr][lc] = t;
+        }
+        wsync();
+        for (int sweep = 0; sweep < 12; ++sweep) {
+            double off = (lr != lc) ? S[lr][lc] * S[lr][lc] : 0.0, dg = (lr == lc) ? S[lr][lc] * S[lr][lc] : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o, 64); dg += __shfl_xor(dg, o, 64); }
+            if (off <= 1e-34 * dg) break;
+            for (int step = 0; step < 7; ++step) {
+                // round-robin pairing of 8 players: player 7 fixed, the others rotate
+                auto player = [&](int slot) { return slot == 7 ? 7 : (slot + step) % 7; };
+                if (tid < 4) {
+                    int p2 = player(tid), q2 = player(7 - tid);
+                    if (p2 > q2) { const int t = p2; p2 = q2; q2 = t; }
+                    double cc = 1.0, sn = 0.0;
+                    const double apq = S[p2][q2];
+                    if (apq != 0.0) {
+                        const double tau = (S[q2][q2] - S[p2][p2]) / (2.0 * apq);
+                        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        cc = 1.0 / sqrt(1.0 + t * t);
+                        sn = t * cc;
+                    }
+                    rot_c[tid] = cc;
+                    rot_s[tid] = sn;
+                }
+                wsync();
+                const int m2 = tid & 3, k2 = (tid >> 2) & 7;      // pair m2, row / column k2; lanes 0..31 S, 32..63 V
+                int p2 = player(m2), q2 = player(7 - m2);
+                if (p2 > q2) { const int t = p2; p2 = q2; q2 = t; }
+                const double cc = rot_c[m2], sn = rot_s[m2];
+                {   // columns p, q of S (lanes < 32) and of V (lanes >= 32)
+                    double (*Mx)[SS_B + 1] = (tid < 32) ? S : V;
+                    const double a = Mx[k2][p2], bq = Mx[k2][q2];
+                    wsync();
+                    Mx[k2][p2] = cc * a - sn * bq;
+                    Mx[k2][q2] = sn * a + cc * bq;
+                }
+                wsync();
+                if (tid < 32) {   // rows p, q of S
+                    const double a = S[p2][k2], bq = S[q2][k2];
+                    S[p2][k2] = cc * a - sn * bq;
+                    S[q2][k2] = sn * a + cc * bq;
+                }
+                wsync();
+            }
+        }
+        wsync();
+        if (tid == 0) {
             int order[SS_B];
             for (int q = 0; q < SS_B; ++q) order[q] = q;
             for (int a2 = 0; a2 < SS_B; ++a2)
                 for (int b2 = a2 + 1; b2 < SS_B; ++b2)
                     if (S[order[b2]][order[b2]] < S[order[a2]][order[a2]]) { const int t = order[a2]; order[a2] = order[b2]; order[b2] = t; }
             for (int q = 0; q < SS_B; ++q) {
-                const int src = order[q];
-                mus[q] = S[src][src];
-                if (!(mus[q] > 0.0)) ok = false;
-                // column q of C = R^-1 V(:, src)
-                for (int r2 = SS_B - 1; r2 >= 0; --r2) {
-                    double t = V[r2][src];
-                    for (int c2 = r2 + 1; c2 < SS_B; ++c2) t -= R[r2][c2] * Cs[c2][q];
-                    Cs[r2][q] = t / R[r2][r2];
-                }
+                mus[q] = S[order[q]][order[q]];
+                if (!(mus[q] > 0.0)) sh_ok = 0;
+                rot_c[0] = 0.0;
+                res2[q] = (double)order[q];      // (res2 is free now: source column of output q)
             }
-            if (!ok) st |= 2;
         }
+        wsync();
+        if (tid < SS_B) {      // column q of C = R^-1 V(:, src)
+            const int q = tid, src = (int)res2[q];
+            for (int r2 = SS_B - 1; r2 >= 0; --r2) {
+                double t = V[r2][src];
+                for (int c2 = r2 + 1; c2 < SS_B; ++c2) t -= R[r2][c2] * Cs[c2][q];
+                Cs[r2][q] = t / R[r2][r2];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int st = sh_st;
+        if (!(st & 3) && !sh_ok) st |= 2;
         state[b] = st;
         Ms[0][0] = (double)st;
     }
@@ -2077,6 +2185,15 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     bool done = false, failed = false;
     std::vector<int> hstate;
     for (int iter = 0; iter < 80 && !done; ++iter) {
+        const size_t xl_bytes = sizeof(double) * (size_t)b.max_n * XLP + 64;
+        if (b.max_n <= 1280) {
+            static bool attr = false;
+            if (!attr) {
+                SA_HIP_CHECK(hipFuncSetAttribute((const void *)ss_solve_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                attr = true;
+            }
+            hipLaunchKernelGGL(ss_solve_lds_kernel, dim3(b.count), dim3(256), xl_bytes, s, b.n.p, b.moff.p, b.voff.p, b.W.p, X, Z);
+        } else {
         SA_HIP_CHECK(hipMemcpyAsync(Z, X, sizeof(double) * (size_t)b.h_voff[b.count] * SB, hipMemcpyDeviceToDevice, s));
         if (b.max_n > 768) {
             hipLaunchKernelGGL((ss_trsolve_kernel<false, 1024>), dim3(b.count), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z);
@@ -2084,6 +2201,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         } else {
             hipLaunchKernelGGL((ss_trsolve_kernel<false, 256>), dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z);
             hipLaunchKernelGGL((ss_trsolve_kernel<true, 256>), dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z);
+        }
         }
         hipLaunchKernelGGL(ss_rr_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, X, Z, mu, state.p, iter,
                            SS_SIGMA, vu);
