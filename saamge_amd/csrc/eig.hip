@@ -846,10 +846,11 @@ size_t eig_workspace_bytes(int n) {
     return 8 * (nn * nn + nn * (EIG_NB + 8) + nn * nn / 2 + nn * (3 * EIG_SB + 2 * EIG_SB) + 64);
 }
 
-// The few-eigenpairs path (eig2.hip) is taken by default for batches of LARGE agglomerates
-// (SAAMGE_AMD_SS_MIN_N, default 1024: the coarse levels), where it is measured faster than the
-// dense reduction; SAAMGE_AMD_EIG=twostage / onestage / dense switches it off, =subspace (with
-// SAAMGE_AMD_SS_MIN_N=0) forces it everywhere.
+// The few-eigenpairs path (eig2.hip) is the default for batches whose largest agglomerate has at
+// least SAAMGE_AMD_SS_MIN_N (64) rows -- measured faster than the dense reduction on the 405-row and
+// on the 2 600-row agglomerates of the headline problem; a batch it cannot handle (more than six
+// wanted pairs, no convergence) is redone by the dense path.  SAAMGE_AMD_EIG=twostage / onestage /
+// dense switches it off.
 bool eig_use_subspace() {
     static int v = -1;
     if (v < 0) {
@@ -862,7 +863,7 @@ bool eig_use_subspace() {
 void eig_tridiagonalize(hipStream_t s, EigBatch &b, int phases) {
     if (!b.count) return;
     // (SAAMGE_AMD_SS_MIN_N: smallest agglomerate size of a batch that takes the few-eigenpairs path)
-    static const int ss_min_n = []() { const char *e = std::getenv("SAAMGE_AMD_SS_MIN_N"); return e ? std::atoi(e) : 1024; }();
+    static const int ss_min_n = []() { const char *e = std::getenv("SAAMGE_AMD_SS_MIN_N"); return e ? std::atoi(e) : 64; }();
     if (eig_use_subspace() && !b.dense_only && b.max_n >= ss_min_n) {
         // few-eigenpairs path: "phase 1" is the Cholesky factorisation, phase 2 has nothing to do
         if (phases & 1) {

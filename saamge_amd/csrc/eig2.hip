@@ -1760,7 +1760,7 @@ __global__ __launch_bounds__(256) void ss_init_kernel(const int *__restrict__ ns
     const int b = blockIdx.x, n = ns[b];
     double *Xb = X + voff[b] * SB;
     for (int idx = threadIdx.x; idx < n * SS_B; idx += 256)
-        Xb[idx] = unit_rand_ss((unsigned)idx, (unsigned)(b + 1));
+        Xb[idx] = unit_rand_ss((unsigned)idx, (unsigned)n);     // (no dependence on the batch: same vectors on any rank / chunking)
 }
 
 // X <- T^-1 X for the lower (UPPER = false: L y = x) or the upper (UPPER = true: L^T z = y) factor,
