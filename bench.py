@@ -46,6 +46,11 @@ KERNELS = {
     "eig_sbr_syr2k": ("sbr_fused_kernel<false, 1>", "hbm"),
     "eig_sbr_fused": ("sbr_fused_kernel<true, 2>", "hbm"),
     "eig_sbr_fused1": ("sbr_fused_kernel<true, 1>", "hbm"),
+    "eig_ss_solve": ("ss_solve_lds_kernel", "hbm"),
+    "eig_ss_update": ("sbr_fused_kernel<false, 2, 1>", "hbm"),
+    "eig_ss_update1": ("sbr_fused_kernel<false, 1, 1>", "hbm"),
+    "eig_ss_panel": ("chol_panel_kernel<256>", "hbm"),
+    "eig_ss_rr": ("ss_rr_kernel", "hbm"),
     "ae_build": ("ae_build_kernel<true, 8, true>", "hbm"),
     "eig_band_chase": ("band_chase_kernel", "mfma"),
     "eig_sbr_qr": ("sbr_qr_kernel<256, true>", "mfma"),

@@ -1769,11 +1769,13 @@ __global__ __launch_bounds__(256) void ss_init_kernel(const int *__restrict__ ns
 template <bool UPPER, int NT>
 __global__ __launch_bounds__(NT) void ss_trsolve_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
                                                          const int64_t *__restrict__ voff,
-                                                         const double *__restrict__ W, double *__restrict__ X) {
+                                                         const double *__restrict__ W, double *__restrict__ X,
+                                                         const int *__restrict__ state) {
     __shared__ double Td[SB][SB + 1];
     __shared__ double ys[SB][SS_B];
     __shared__ double xs[2][SB][SS_B];       // right-hand side rows of the current / next block
     const int b = blockIdx.x, n = ns[b];
+    if (state[b] & 3) return;
     const double *A = W + moff[b];
     double *Xb = X + voff[b] * SB;
     const int tid = threadIdx.x;
@@ -1847,11 +1849,12 @@ constexpr int XLP = SS_B + 1;
 __global__ __launch_bounds__(256) void ss_solve_lds_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
                                                            const int64_t *__restrict__ voff,
                                                            const double *__restrict__ W, const double *__restrict__ X,
-                                                           double *__restrict__ Zout) {
+                                                           double *__restrict__ Zout, const int *__restrict__ state) {
     extern __shared__ __align__(16) double xl[];      // [n][XLP]
     __shared__ double Td[SB][SB + 1];
     __shared__ double ys[SB][SS_B];
     const int b = blockIdx.x, n = ns[b];
+    if (state[b] & 3) return;                         // accepted (or given up) in an earlier iteration
     const double *A = W + moff[b];
     const double *Xb = X + voff[b] * SB;
     double *Zb = Zout + voff[b] * SB;
@@ -1915,6 +1918,7 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
     __shared__ double part[32][2 * SS_B][SS_B];     // [row group][M rows | G rows][column j]
     __shared__ double Ms[SS_B][SS_B], Gs[SS_B][SS_B], Cs[SS_B][SS_B], res2[SS_B], mus[SS_B], mu_old[SS_B];
     const int b = blockIdx.x, n = ns[b];
+    if (state[b] & 3) return;                       // accepted earlier: X, mu stay as they are
     double *Xb = X + voff[b] * SB;
     const double *Zb = Z + voff[b] * SB;
     const int tid = threadIdx.x;
@@ -2146,16 +2150,24 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
     info.zero(s);
     hipLaunchKernelGGL(ss_shift_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, SS_SIGMA);
     const int cnt8 = 8 * div_up(b.count, 8);
-    profiler().begin(s);
+    const bool prof = profiler().enabled;
+    if (!prof) profiler().begin(s);
     for (int k0 = 0; k0 < nmax; k0 += SB) {
+        if (prof) profiler().begin(s);
         if (nmax > 768)
             hipLaunchKernelGGL((chol_panel_kernel<1024>), dim3(b.count), dim3(1024), 0, s, k0, b.n.p, b.moff.p, b.voff.p,
                                b.W.p, b.Vpk.p, b.Zbuf.p, info.p);
         else
             hipLaunchKernelGGL((chol_panel_kernel<256>), dim3(b.count), dim3(256), 0, s, k0, b.n.p, b.moff.p, b.voff.p,
                                b.W.p, b.Vpk.p, b.Zbuf.p, info.p);
+        if (prof) profiler().end(s, "eig_ss_panel", 0.0, 0.0);
         const int np = nmax - k0 - SB;
         if (np >= 1) {
+            double ub = 0.0;
+            if (prof) {      // lower tiles of the trailing matrices, read and written once
+                for (int n : b.h_n) { const double q = (double)n - k0 - SB; if (q >= 1.0) ub += 8.0 * q * q; }
+                profiler().begin(s);
+            }
             if (np > 192)
                 hipLaunchKernelGGL((sbr_fused_kernel<false, 2, 1>), dim3(cnt8 * div_up(np, 2 * SF_ROWS)), dim3(S2_NT), 0, s, k0,
                                    b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
@@ -2164,10 +2176,11 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
                 hipLaunchKernelGGL((sbr_fused_kernel<false, 1, 1>), dim3(cnt8 * div_up(np, SF_ROWS)), dim3(S2_NT), 0, s, k0,
                                    b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
                                    b.Gbuf.p, b.trash.p, b.count, div_up(np, SF_ROWS), 0);
+            if (prof) profiler().end(s, np > 192 ? "eig_ss_update" : "eig_ss_update1", ub, 0.0);
         }
     }
     SA_HIP_CHECK(hipGetLastError());
-    profiler().end(s, "eig_ss_cholesky", 0.0, 0.0);
+    if (!prof) profiler().end(s, "eig_ss_cholesky", 0.0, 0.0);
     auto h = info.to_host(s);
     for (int v : h) if (v) return false;
     return true;
@@ -2180,11 +2193,15 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     double *X = b.Xbuf.p, *Z = b.Vpk2.p, *mu = b.d.p;     // d: rows >= SS_B per matrix is checked by the caller
     DBuf<double> mubuf((size_t)b.count * SS_B);
     mu = mubuf.p;
-    profiler().begin(s);
+    const bool prof = profiler().enabled;
+    double sbytes = 0.0;       // the factor once per triangle + the right-hand sides in and out
+    for (int n : b.h_n) sbytes += 8.0 * (double)n * n + 2.0 * 8.0 * SS_B * n;
+    if (!prof) profiler().begin(s);
     hipLaunchKernelGGL(ss_init_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, X);
     bool done = false, failed = false;
     std::vector<int> hstate;
     for (int iter = 0; iter < 80 && !done; ++iter) {
+        if (prof) profiler().begin(s);
         const size_t xl_bytes = sizeof(double) * (size_t)b.max_n * XLP + 64;
         if (b.max_n <= 1280) {
             static bool attr = false;
@@ -2192,19 +2209,21 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
                 SA_HIP_CHECK(hipFuncSetAttribute((const void *)ss_solve_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
                 attr = true;
             }
-            hipLaunchKernelGGL(ss_solve_lds_kernel, dim3(b.count), dim3(256), xl_bytes, s, b.n.p, b.moff.p, b.voff.p, b.W.p, X, Z);
+            hipLaunchKernelGGL(ss_solve_lds_kernel, dim3(b.count), dim3(256), xl_bytes, s, b.n.p, b.moff.p, b.voff.p, b.W.p, X, Z, state.p);
         } else {
         SA_HIP_CHECK(hipMemcpyAsync(Z, X, sizeof(double) * (size_t)b.h_voff[b.count] * SB, hipMemcpyDeviceToDevice, s));
         if (b.max_n > 768) {
-            hipLaunchKernelGGL((ss_trsolve_kernel<false, 1024>), dim3(b.count), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z);
-            hipLaunchKernelGGL((ss_trsolve_kernel<true, 1024>), dim3(b.count), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z);
+            hipLaunchKernelGGL((ss_trsolve_kernel<false, 1024>), dim3(b.count), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p);
+            hipLaunchKernelGGL((ss_trsolve_kernel<true, 1024>), dim3(b.count), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p);
         } else {
-            hipLaunchKernelGGL((ss_trsolve_kernel<false, 256>), dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z);
-            hipLaunchKernelGGL((ss_trsolve_kernel<true, 256>), dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z);
+            hipLaunchKernelGGL((ss_trsolve_kernel<false, 256>), dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p);
+            hipLaunchKernelGGL((ss_trsolve_kernel<true, 256>), dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p);
         }
         }
+        if (prof) { profiler().end(s, b.max_n <= 1280 ? "eig_ss_solve" : "eig_ss_solve_g", sbytes, 0.0); profiler().begin(s); }
         hipLaunchKernelGGL(ss_rr_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, X, Z, mu, state.p, iter,
                            SS_SIGMA, vu);
+        if (prof) profiler().end(s, "eig_ss_rr", 0.0, 0.0);
         if (iter >= 3 && (iter % 2) == 1) {
             auto t = state.to_host(s);
             hstate.assign(t.begin(), t.end());
@@ -2217,7 +2236,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         }
     }
     SA_HIP_CHECK(hipGetLastError());
-    profiler().end(s, "eig_ss_iterate", 0.0, 0.0);
+    if (!prof) profiler().end(s, "eig_ss_iterate", 0.0, 0.0);
     if (failed || !done) return false;
     b.h_m.assign((size_t)b.count, 1);
     for (int i = 0; i < b.count; ++i) b.h_m[i] = hstate[i] >> 8;
