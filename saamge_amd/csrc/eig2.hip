@@ -1846,7 +1846,8 @@ __global__ __launch_bounds__(NT) void ss_trsolve_kernel(const int *__restrict__ 
 // conflict-free for lanes = rows): the factor is then the only global traffic, read once per
 // triangle.  For agglomerates up to ~2 000 rows.
 constexpr int XLP = SS_B + 1;
-__global__ __launch_bounds__(256) void ss_solve_lds_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
+template <int NT>
+__global__ __launch_bounds__(NT) void ss_solve_lds_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
                                                            const int64_t *__restrict__ voff,
                                                            const double *__restrict__ W, const double *__restrict__ X,
                                                            double *__restrict__ Zout, const int *__restrict__ state) {
@@ -1860,8 +1861,8 @@ __global__ __launch_bounds__(256) void ss_solve_lds_kernel(const int *__restrict
     double *Zb = Zout + voff[b] * SB;
     const int tid = threadIdx.x;
     const int nblk = (n + SB - 1) / SB;
-    const int ti = tid >> 4, tj = tid & 15;
-    for (int idx = tid; idx < n * SS_B; idx += 256) xl[(idx >> 3) * XLP + (idx & 7)] = Xb[idx];
+    const int ti = (tid >> 4) & 15, tj = tid & 15;
+    for (int idx = tid; idx < n * SS_B; idx += NT) xl[(idx >> 3) * XLP + (idx & 7)] = Xb[idx];
     for (int pass = 0; pass < 2; ++pass) {
         const bool upper = pass == 1;
         auto load_td = [&](int k0) {
@@ -1874,7 +1875,7 @@ __global__ __launch_bounds__(256) void ss_solve_lds_kernel(const int *__restrict
         for (int bb = 0; bb < nblk; ++bb) {
             const int k0 = upper ? (nblk - 1 - bb) * SB : bb * SB;
             const int nb = min(SB, n - k0);
-            Td[ti][tj] = td_next;
+            if (tid < SB * SB) Td[ti][tj] = td_next;
             __syncthreads();
             if (tid < SB * SS_B) {      // y = T11^-1 x (the stored block is the inverse)
                 const int c = tid >> 3, jj = tid & 7;
@@ -1890,14 +1891,18 @@ __global__ __launch_bounds__(256) void ss_solve_lds_kernel(const int *__restrict
                 if (c < nb) xl[(k0 + c) * XLP + jj] = ys[c][jj];
             }
             const int r_lo = upper ? 0 : k0 + nb, r_hi = upper ? k0 : n;
-            for (int r = r_lo + tid; r < r_hi; r += 256) {
+            for (int r = r_lo + tid; r < r_hi; r += NT) {
                 double acc[SS_B];
 #pragma unroll
                 for (int j = 0; j < SS_B; ++j) acc[j] = xl[r * XLP + j];
-                for (int c = 0; c < nb; ++c) {
-                    const double t = A[(size_t)(k0 + c) * n + r];
+                const double *ap = A + (size_t)k0 * n + r;
+#pragma unroll 1
+                for (int c = 0; c < SB; c += 4) {     // four factor entries in flight (ys is zero past the block)
+                    const double t0 = ap[(size_t)min(c, nb - 1) * n], t1 = ap[(size_t)min(c + 1, nb - 1) * n];
+                    const double t2 = ap[(size_t)min(c + 2, nb - 1) * n], t3 = ap[(size_t)min(c + 3, nb - 1) * n];
 #pragma unroll
-                    for (int j = 0; j < SS_B; ++j) acc[j] = fma(-t, ys[c][j], acc[j]);
+                    for (int j = 0; j < SS_B; ++j)
+                        acc[j] = fma(-t3, ys[c + 3][j], fma(-t2, ys[c + 2][j], fma(-t1, ys[c + 1][j], fma(-t0, ys[c][j], acc[j]))));
                 }
 #pragma unroll
                 for (int j = 0; j < SS_B; ++j) xl[r * XLP + j] = acc[j];
@@ -1905,7 +1910,7 @@ __global__ __launch_bounds__(256) void ss_solve_lds_kernel(const int *__restrict
             __syncthreads();
         }
     }
-    for (int idx = tid; idx < n * SS_B; idx += 256) Zb[idx] = xl[(idx >> 3) * XLP + (idx & 7)];
+    for (int idx = tid; idx < n * SS_B; idx += NT) Zb[idx] = xl[(idx >> 3) * XLP + (idx & 7)];
 }
 
 // Rayleigh-Ritz on span(Z) from M = Z^T X and G = Z^T Z, inverse residuals of the previous pairs,
@@ -2206,10 +2211,10 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         if (b.max_n <= 1280) {
             static bool attr = false;
             if (!attr) {
-                SA_HIP_CHECK(hipFuncSetAttribute((const void *)ss_solve_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                SA_HIP_CHECK(hipFuncSetAttribute((const void *)ss_solve_lds_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
                 attr = true;
             }
-            hipLaunchKernelGGL(ss_solve_lds_kernel, dim3(b.count), dim3(256), xl_bytes, s, b.n.p, b.moff.p, b.voff.p, b.W.p, X, Z, state.p);
+            hipLaunchKernelGGL((ss_solve_lds_kernel<512>), dim3(b.count), dim3(512), xl_bytes, s, b.n.p, b.moff.p, b.voff.p, b.W.p, X, Z, state.p);
         } else {
         SA_HIP_CHECK(hipMemcpyAsync(Z, X, sizeof(double) * (size_t)b.h_voff[b.count] * SB, hipMemcpyDeviceToDevice, s));
         if (b.max_n > 768) {
