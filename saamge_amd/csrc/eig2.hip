@@ -1692,23 +1692,29 @@ __global__ __launch_bounds__(NT) void chol_panel_kernel(int k0, const int *__res
         Ld[i][j] = (i < nb && j <= i) ? A[(size_t)(k0 + j) * n + (k0 + i)] : ((i == j) ? 1.0 : 0.0);
     }
     __syncthreads();
-    // right-looking Cholesky of the block in LDS, one column per step (three barriers each)
+    // right-looking Cholesky of the block in LDS by ONE wavefront (wave-level synchronisation only;
+    // the other wavefronts wait at a single barrier)
     __shared__ int bad;
-    if (tid == 0) bad = 0;
-    for (int j = 0; j < SB; ++j) {
-        __syncthreads();
-        if (tid == 0) {
-            double d = Ld[j][j];
-            if (!(d > 0.0)) { bad = 1; d = 1.0; }
-            Ld[j][j] = sqrt(d);
+    if (tid < 64) {
+        auto wsync = []() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+        int isbad = 0;
+        for (int j = 0; j < SB; ++j) {
+            wsync();
+            const double dj = Ld[j][j];
+            const double d = (dj > 0.0) ? sqrt(dj) : 1.0;
+            if (!(dj > 0.0)) isbad = 1;
+            wsync();
+            if (tid == j) Ld[j][j] = d;
+            if (tid > j && tid < SB) Ld[tid][j] /= d;
+            wsync();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int idx = tid + 64 * e, i = idx >> 4, c = idx & 15;
+                if (i > j && c > j && c <= i) Ld[i][c] -= Ld[i][j] * Ld[c][j];
+            }
         }
-        __syncthreads();
-        if (tid > j && tid < SB) Ld[tid][j] /= Ld[j][j];
-        __syncthreads();
-        if (tid < SB * SB) {
-            const int i = tid >> 4, c = tid & 15;
-            if (i > j && c > j && c <= i) Ld[i][c] -= Ld[i][j] * Ld[c][j];
-        }
+        wsync();
+        if (tid == 0) bad = isbad;
     }
     __syncthreads();
     if (tid == 0 && bad) info[b] = 1;
