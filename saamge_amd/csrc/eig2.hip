@@ -521,13 +521,13 @@ __global__ __launch_bounds__(256) void sbr_panel_update_kernel(int k0, const int
                                                                double *__restrict__ Wm,
                                                                const double *__restrict__ Vpk,
                                                                const double *__restrict__ Zbuf, int count,
-                                                               int tiles) {
+                                                               int tiles, int min_np = 2) {
     int b, blk;
     xcd_decode(tiles, b, blk);
     if (b >= count) return;
     const int n = ns[b];
     const int np = n - k0 - SB;
-    if (np < 2) return;
+    if (np < min_np) return;       // (band reduction: a trailing matrix of order 1 has no reflector; Cholesky: 1)
     const int r = blk * 256 + threadIdx.x;
     if (r >= np) return;
     double *A22 = Wm + moff[b] + (size_t)(k0 + SB) * n + (k0 + SB);
@@ -557,7 +557,9 @@ constexpr int SF_ROWS = 64;   // rows per lane-row: 2 x 16 row operands + 16 acc
 // feeds RPL FMAs.  The kernel is bound by that operand delivery (~17 TFLOP/s with one FMA per
 // fetched scalar, both on the 405-row and on the 2 600-row agglomerates), not by HBM.
 // TERMS = 1: A22' -= V V^T only (the trailing update of the Cholesky factorisation of the
-// few-eigenpairs path: half the FMAs and scalar operands, Z is not read).
+// few-eigenpairs path: half the FMAs and scalar operands, Z is not read).  TERMS = 3: A22' -= V V^T +
+// Z Z^T with V = the (row-shifted) factor panel k and Z = panel k + 1 (not shifted): two panels in one
+// pass over the trailing matrix.  Both only on the tiles on and below the diagonal.
 template <bool PROD, int RPL, int TERMS = 2>
 __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__restrict__ ns,
                                                           const int64_t *__restrict__ moff,
@@ -588,10 +590,10 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
     if (i0 >= np) return;
     // TERMS == 1 (Cholesky): only the columns up to the end of this strip's diagonal tile -- the
     // factorisation never reads the upper triangle of the trailing matrix
-    const int ncols = (TERMS == 1) ? min(np, i0 + SF_ROWS * RPL) : np;
+    const int ncols = (TERMS != 2) ? min(np, i0 + SF_ROWS * RPL) : np;
     const bool prod = PROD && np >= 2;         // the next panel has reflectors
     double *A22 = Wm + moff[b] + (size_t)(k0 + SB + shift) * n + (k0 + SB + shift);
-    const double *__restrict__ Z = Zbuf + voff[b] * SB + shift * SB;   // rows shifted
+    const double *__restrict__ Z = Zbuf + voff[b] * SB + (TERMS == 3 ? 0 : shift * SB);   // rows shifted
     const double *__restrict__ Vc = Vcur + voff[b] * SB + shift * SB;
     const double *__restrict__ Vn = Vnext + voff[b] * SB;
     double *X = Xbuf + voff[b] * SB;
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
         const int iac = min(ia, np - 1);
 #pragma unroll
         for (int c = 0; c < SB; ++c) {
-            za[r][c] = (TERMS == 2) ? -Z[(size_t)iac * SB + c] : 0.0;
+            za[r][c] = (TERMS != 1) ? -Z[(size_t)iac * SB + c] : 0.0;
             va[r][c] = -Vc[(size_t)iac * SB + c];
             xa[r][c] = 0.0;
         }
@@ -646,7 +648,9 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
             for (int c = 0; c < SB; ++c)
 #pragma unroll
                 for (int r = 0; r < RPL; ++r)
-                    ta[r][k] = (TERMS == 2) ? fma(za[r][c], vl[c], fma(va[r][c], zl[c], ta[r][k])) : fma(va[r][c], vl[c], ta[r][k]);
+                    ta[r][k] = (TERMS == 2) ? fma(za[r][c], vl[c], fma(va[r][c], zl[c], ta[r][k]))
+                             : (TERMS == 3) ? fma(za[r][c], zl[c], fma(va[r][c], vl[c], ta[r][k]))
+                                            : fma(va[r][c], vl[c], ta[r][k]);
             if (prod) {
                 const double *vn = Vn + (size_t)(l0 + k) * SB;
 #pragma unroll
@@ -677,7 +681,9 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
         for (int c = 0; c < SB; ++c)
 #pragma unroll
             for (int r = 0; r < RPL; ++r)
-                t0[r] = (TERMS == 2) ? fma(za[r][c], vl[c], fma(va[r][c], zl[c], t0[r])) : fma(va[r][c], vl[c], t0[r]);
+                t0[r] = (TERMS == 2) ? fma(za[r][c], vl[c], fma(va[r][c], zl[c], t0[r]))
+                      : (TERMS == 3) ? fma(za[r][c], zl[c], fma(va[r][c], vl[c], t0[r]))
+                                     : fma(va[r][c], vl[c], t0[r]);
         if (prod) {
             const double *vn = Vn + (size_t)l0 * SB;
 #pragma unroll
@@ -1738,7 +1744,7 @@ __global__ __launch_bounds__(NT) void chol_panel_kernel(int k0, const int *__res
         }
     }
     if (nb < SB) return;
-    double *Vp = Vpk + voff[b] * SB;
+    double *Vp = Vpk + voff[b] * SB, *Zp = Zbuf ? Zbuf + voff[b] * SB : nullptr;
     for (int r = k0 + SB + tid; r < n; r += NT) {
         double x[SB];
 #pragma unroll
@@ -1757,6 +1763,7 @@ __global__ __launch_bounds__(NT) void chol_panel_kernel(int k0, const int *__res
             A[(size_t)(k0 + c) * n + r] = y[c];
             A[(size_t)r * n + (k0 + c)] = y[c];
             Vp[pr + c] = y[c];
+            if (Zp) Zp[pr + c] = 0.5 * y[c];
         }
     }
 }
@@ -2167,30 +2174,43 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
     const int cnt8 = 8 * div_up(b.count, 8);
     const bool prof = profiler().enabled;
     if (!prof) profiler().begin(s);
-    for (int k0 = 0; k0 < nmax; k0 += SB) {
+    auto panel = [&](int k0, double *Vout, double *Zout) {
         if (prof) profiler().begin(s);
         if (nmax > 768)
             hipLaunchKernelGGL((chol_panel_kernel<1024>), dim3(b.count), dim3(1024), 0, s, k0, b.n.p, b.moff.p, b.voff.p,
-                               b.W.p, b.Vpk.p, b.Zbuf.p, info.p);
+                               b.W.p, Vout, Zout, info.p);
         else
             hipLaunchKernelGGL((chol_panel_kernel<256>), dim3(b.count), dim3(256), 0, s, k0, b.n.p, b.moff.p, b.voff.p,
-                               b.W.p, b.Vpk.p, b.Zbuf.p, info.p);
+                               b.W.p, Vout, Zout, info.p);
         if (prof) profiler().end(s, "eig_ss_panel", 0.0, 0.0);
-        const int np = nmax - k0 - SB;
+    };
+    // Two panels per pass over the trailing matrix: panel k, its update of the next SB columns only,
+    // panel k + 1, then A22(2 SB:, 2 SB:) -= L_k L_k^T + L_{k+1} L_{k+1}^T in one read + write of the
+    // lower tiles.
+    for (int k0 = 0; k0 < nmax; k0 += 2 * SB) {
+        panel(k0, b.Vpk.p, b.Zbuf.p);
+        const int np1 = nmax - k0 - SB;          // order of the trailing matrix after panel k
+        if (np1 < 1) break;
+        if (prof) profiler().begin(s);
+        hipLaunchKernelGGL(sbr_panel_update_kernel, dim3(cnt8 * div_up(np1, 256)), dim3(256), 0, s, k0, b.n.p, b.moff.p,
+                           b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.count, div_up(np1, 256), 1);
+        if (prof) profiler().end(s, "eig_ss_panel", 0.0, 0.0);
+        panel(k0 + SB, b.Vpk2.p, nullptr);
+        const int np = np1 - SB;                  // ... after panel k + 1
         if (np >= 1) {
             double ub = 0.0;
             if (prof) {      // lower tiles of the trailing matrices, read and written once
-                for (int n : b.h_n) { const double q = (double)n - k0 - SB; if (q >= 1.0) ub += 8.0 * q * q; }
+                for (int n : b.h_n) { const double q = (double)n - k0 - 2 * SB; if (q >= 1.0) ub += 8.0 * q * q; }
                 profiler().begin(s);
             }
             if (np > 192)
-                hipLaunchKernelGGL((sbr_fused_kernel<false, 2, 1>), dim3(cnt8 * div_up(np, 2 * SF_ROWS)), dim3(S2_NT), 0, s, k0,
-                                   b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
-                                   b.Gbuf.p, b.trash.p, b.count, div_up(np, 2 * SF_ROWS), 0);
+                hipLaunchKernelGGL((sbr_fused_kernel<false, 2, 3>), dim3(cnt8 * div_up(np, 2 * SF_ROWS)), dim3(S2_NT), 0, s, k0,
+                                   b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Vpk2.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
+                                   b.Gbuf.p, b.trash.p, b.count, div_up(np, 2 * SF_ROWS), SB);
             else
-                hipLaunchKernelGGL((sbr_fused_kernel<false, 1, 1>), dim3(cnt8 * div_up(np, SF_ROWS)), dim3(S2_NT), 0, s, k0,
-                                   b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
-                                   b.Gbuf.p, b.trash.p, b.count, div_up(np, SF_ROWS), 0);
+                hipLaunchKernelGGL((sbr_fused_kernel<false, 1, 3>), dim3(cnt8 * div_up(np, SF_ROWS)), dim3(S2_NT), 0, s, k0,
+                                   b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Vpk2.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
+                                   b.Gbuf.p, b.trash.p, b.count, div_up(np, SF_ROWS), SB);
             if (prof) profiler().end(s, np > 192 ? "eig_ss_update" : "eig_ss_update1", ub, 0.0);
         }
     }
