@@ -1728,12 +1728,17 @@ __global__ __launch_bounds__(NT) void chol_panel_kernel(int k0, const int *__res
     // solves then apply it as a small matrix product instead of a serial substitution
     __shared__ double Li[SB][SB + 1];
     if (tid < SB) {
-        const int j = tid;                       // column j of L11^-1 by forward substitution
+        const int j = tid;                       // column j of L11^-1 by forward substitution, held in registers
+        double x[SB];
+#pragma unroll
         for (int i = 0; i < SB; ++i) {
             double t = (i == j) ? 1.0 : 0.0;
-            for (int q = j; q < i; ++q) t -= Ld[i][q] * Li[q][j];
-            Li[i][j] = (i >= j) ? t / Ld[i][i] : 0.0;
+#pragma unroll
+            for (int q = 0; q < i; ++q) t = fma(-Ld[i][q], x[q], t);     // (x[q] = 0 above the diagonal)
+            x[i] = (i >= j) ? t / Ld[i][i] : 0.0;
         }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) Li[i][j] = x[i];
     }
     __syncthreads();
     if (tid < SB * SB) {
