@@ -1773,12 +1773,16 @@ __global__ __launch_bounds__(NT) void chol_panel_kernel(int k0, const int *__res
     }
 }
 
+// Start block: column 0 = D^1/2 1 (the exact null vector of C for an agglomerate without essential
+// rows -- most of them -- and a smooth first guess otherwise), the rest pseudo-random.  No
+// dependence on the batch: the same vectors on any rank / chunking.
 __global__ __launch_bounds__(256) void ss_init_kernel(const int *__restrict__ ns, const int64_t *__restrict__ voff,
-                                                      double *__restrict__ X) {
+                                                      const double *__restrict__ dis, double *__restrict__ X) {
     const int b = blockIdx.x, n = ns[b];
     double *Xb = X + voff[b] * SB;
+    const double *db = dis + voff[b];
     for (int idx = threadIdx.x; idx < n * SS_B; idx += 256)
-        Xb[idx] = unit_rand_ss((unsigned)idx, (unsigned)n);     // (no dependence on the batch: same vectors on any rank / chunking)
+        Xb[idx] = ((idx & 7) == 0) ? 1.0 / db[idx >> 3] : unit_rand_ss((unsigned)idx, (unsigned)n);
 }
 
 // X <- T^-1 X for the lower (UPPER = false: L y = x) or the upper (UPPER = true: L^T z = y) factor,
@@ -1919,12 +1923,14 @@ __global__ __launch_bounds__(NT) void ss_solve_lds_kernel(const int *__restrict_
                 for (int j = 0; j < SS_B; ++j) acc[j] = xl[r * XLP + j];
                 const double *ap = A + (size_t)k0 * n + r;
 #pragma unroll 1
-                for (int c = 0; c < SB; c += 4) {     // four factor entries in flight (ys is zero past the block)
-                    const double t0 = ap[(size_t)min(c, nb - 1) * n], t1 = ap[(size_t)min(c + 1, nb - 1) * n];
-                    const double t2 = ap[(size_t)min(c + 2, nb - 1) * n], t3 = ap[(size_t)min(c + 3, nb - 1) * n];
+                for (int c = 0; c < SB; c += 8) {     // eight factor entries in flight (ys is zero past the block)
+                    double t[8];
 #pragma unroll
-                    for (int j = 0; j < SS_B; ++j)
-                        acc[j] = fma(-t3, ys[c + 3][j], fma(-t2, ys[c + 2][j], fma(-t1, ys[c + 1][j], fma(-t0, ys[c][j], acc[j]))));
+                    for (int u = 0; u < 8; ++u) t[u] = ap[(size_t)min(c + u, nb - 1) * n];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int j = 0; j < SS_B; ++j) acc[j] = fma(-t[u], ys[c + u][j], acc[j]);
                 }
 #pragma unroll
                 for (int j = 0; j < SS_B; ++j) xl[r * XLP + j] = acc[j];
@@ -2237,7 +2243,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     double sbytes = 0.0;       // the factor once per triangle + the right-hand sides in and out
     for (int n : b.h_n) sbytes += 8.0 * (double)n * n + 2.0 * 8.0 * SS_B * n;
     if (!prof) profiler().begin(s);
-    hipLaunchKernelGGL(ss_init_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, X);
+    hipLaunchKernelGGL(ss_init_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, b.dis.p, X);
     bool done = false, failed = false;
     std::vector<int> hstate;
     for (int iter = 0; iter < 80 && !done; ++iter) {
@@ -2268,10 +2274,14 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
             auto t = state.to_host(s);
             hstate.assign(t.begin(), t.end());
             done = true;
+            int nconv = 0;
             for (int v : hstate) {
                 if (v & 2) failed = true;
                 if (!(v & 3)) done = false;
+                else ++nconv;
             }
+            static const bool dbg = std::getenv("SAAMGE_AMD_SS_DEBUG") != nullptr;
+            if (dbg) std::fprintf(stderr, "subspace: iteration %d, %d of %d matrices accepted (n max %d)\n", iter, nconv, b.count, b.max_n);
             if (failed) break;
         }
     }
