@@ -44,6 +44,9 @@ struct EigBatch {
     // few-eigenpairs path (SAAMGE_AMD_EIG=subspace): Ritz values of the accepted block; `dense_only`
     // forces the dense path for this batch (fallback after a failed subspace attempt)
     DBuf<double> ss_mu;
+    DBuf<int> bw;           // [count] half bandwidths (banded Cholesky), host copy; empty = full matrices
+    std::vector<int> h_bw;
+    int ss_bwmax = 0;
     bool subspace = false, dense_only = false, ss_failed = false;
     std::vector<int> h_n, h_m;
     std::vector<int64_t> h_moff, h_voff;

@@ -521,7 +521,8 @@ __global__ __launch_bounds__(256) void sbr_panel_update_kernel(int k0, const int
                                                                double *__restrict__ Wm,
                                                                const double *__restrict__ Vpk,
                                                                const double *__restrict__ Zbuf, int count,
-                                                               int tiles, int min_np = 2) {
+                                                               int tiles, int min_np = 2,
+                                                               const int *__restrict__ bws = nullptr) {
     int b, blk;
     xcd_decode(tiles, b, blk);
     if (b >= count) return;
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(256) void sbr_panel_update_kernel(int k0, const int
     const int np = n - k0 - SB;
     if (np < min_np) return;       // (band reduction: a trailing matrix of order 1 has no reflector; Cholesky: 1)
     const int r = blk * 256 + threadIdx.x;
-    if (r >= np) return;
+    if (r >= (bws ? min(np, bws[b]) : np)) return;      // (banded Cholesky: the panel is zero below the band)
     double *A22 = Wm + moff[b] + (size_t)(k0 + SB) * n + (k0 + SB);
     const double *__restrict__ Z = Zbuf + voff[b] * SB;
     const double *__restrict__ Vp = Vpk + voff[b] * SB;
@@ -572,7 +573,8 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
                                                           const int64_t *__restrict__ goff,
                                                           double *__restrict__ Gbuf,
                                                           double *__restrict__ trashbuf, int count,
-                                                          int tiles, int shift) {
+                                                          int tiles, int shift,
+                                                          const int *__restrict__ bws = nullptr) {
     constexpr int SBP = SB + 1;
     constexpr int KC = (RPL == 1) ? S2_KC : 4;   // columns per step (VGPR budget: 2 RPL KC tile values)
     __shared__ double red[4 * SB * SF_ROWS];   // 32 KiB: K-split reduction
@@ -584,7 +586,8 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
     if (n - k0 - SB < 2) return;               // this matrix has no panel k0
     // shift = SB: look-ahead pipeline, the first SB columns / rows were handled by
     // sbr_panel_update_kernel; shift = 0: the whole trailing matrix of panel k0
-    const int np = n - k0 - SB - shift;        // order of A22' (may be < 2: update only)
+    int np = n - k0 - SB - shift;              // order of A22' (may be < 2: update only)
+    if (TERMS != 2 && bws) np = min(np, bws[b]);   // banded Cholesky: the panels are zero below the band
     if (np < 1) return;
     const int i0 = blk * (SF_ROWS * RPL);
     if (i0 >= np) return;
@@ -1678,6 +1681,31 @@ __global__ __launch_bounds__(256) void ss_shift_kernel(const int *__restrict__ n
     for (int i = threadIdx.x; i < n; i += 256) A[(size_t)i * n + i] -= sigma;
 }
 
+// Half bandwidth of every matrix: bw = max (i - j) over the non-zero entries below the diagonal.
+// The agglomerate-local numbering of a mesh keeps it far below n (405-row box agglomerates of the
+// 256^3 workload: 91); Cholesky fill stays inside the band, so the factorisation and the solves
+// skip everything outside it -- exactly the entries a dense factorisation would carry as zeros.
+__global__ __launch_bounds__(256) void ss_band_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
+                                                      const double *__restrict__ W, int *__restrict__ bws) {
+    __shared__ int wmax[4];
+    const int b = blockIdx.x, n = ns[b];
+    const double *A = W + moff[b];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int bw = 0;
+    for (int j = w; j < n; j += 4) {           // one wavefront per column, bottom up, until the first non-zero
+        const double *col = A + (size_t)j * n;
+        for (int r1 = n; r1 > j + 1 + bw; r1 -= 64) {
+            const int r = r1 - 64 + lane;
+            const bool nz = r > j + bw && col[r] != 0.0;
+            const unsigned long long m = __ballot(nz);
+            if (m) { bw = max(bw, r1 - 64 + 63 - __builtin_clzll(m) - j); break; }
+        }
+    }
+    if (lane == 0) wmax[w] = bw;
+    __syncthreads();
+    if (tid == 0) bws[b] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+}
+
 // Cholesky of the SB x SB diagonal block at k0 and L21 = A21 L11^-T below it.  L goes to the lower
 // triangle, its transpose to the upper one (the solves then stream columns both ways), and the
 // packed row-major copies V = L21, Z = L21 / 2 feed the trailing update.
@@ -1686,10 +1714,14 @@ __global__ __launch_bounds__(NT) void chol_panel_kernel(int k0, const int *__res
                                                          const int64_t *__restrict__ moff,
                                                          const int64_t *__restrict__ voff, double *__restrict__ W,
                                                          double *__restrict__ Vpk, double *__restrict__ Zbuf,
-                                                         int *__restrict__ info) {
+                                                         int *__restrict__ info, const int *__restrict__ bws,
+                                                         int rext) {
     __shared__ double Ld[SB][SB + 1];
     const int b = blockIdx.x, n = ns[b];
     if (k0 >= n) return;
+    // rows below the band are zero and stay zero; `rext` more rows are still written (as zeros) to the
+    // packed panel for the two-panel update that reads them
+    const int rend = bws ? min(n, k0 + SB + bws[b] + rext) : n;
     double *A = W + moff[b];
     const int nb = min(SB, n - k0);
     const int tid = threadIdx.x;
@@ -1750,7 +1782,7 @@ __global__ __launch_bounds__(NT) void chol_panel_kernel(int k0, const int *__res
     }
     if (nb < SB) return;
     double *Vp = Vpk + voff[b] * SB, *Zp = Zbuf ? Zbuf + voff[b] * SB : nullptr;
-    for (int r = k0 + SB + tid; r < n; r += NT) {
+    for (int r = k0 + SB + tid; r < rend; r += NT) {
         double x[SB];
 #pragma unroll
         for (int c = 0; c < SB; ++c) x[c] = A[(size_t)(k0 + c) * n + r];
@@ -1792,12 +1824,15 @@ template <bool UPPER, int NT>
 __global__ __launch_bounds__(NT) void ss_trsolve_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
                                                          const int64_t *__restrict__ voff,
                                                          const double *__restrict__ W, double *__restrict__ X,
-                                                         const int *__restrict__ state) {
+                                                         const int *__restrict__ state, const int *__restrict__ bws) {
     __shared__ double Td[SB][SB + 1];
     __shared__ double ys[SB][SS_B];
     __shared__ double xs[2][SB][SS_B];       // right-hand side rows of the current / next block
     const int b = blockIdx.x, n = ns[b];
     if (state[b] & 3) return;
+    // the factor is zero beyond this distance from the diagonal (at least SB: the rows of the next
+    // block are caught in LDS by the threads that update them)
+    const int bw = bws ? max(bws[b], SB) : n;
     const double *A = W + moff[b];
     double *Xb = X + voff[b] * SB;
     const int tid = threadIdx.x;
@@ -1837,7 +1872,7 @@ __global__ __launch_bounds__(NT) void ss_trsolve_kernel(const int *__restrict__ 
         const int kn = UPPER ? k0 - SB : k0 + SB;
         if (bb + 1 < nblk) td_next = load_td(kn);
         __syncthreads();
-        const int r_lo = UPPER ? 0 : k0 + nb, r_hi = UPPER ? k0 : n;
+        const int r_lo = UPPER ? max(0, k0 - bw) : k0 + nb, r_hi = UPPER ? k0 : min(n, k0 + nb + bw);
         for (int r = r_lo + tid; r < r_hi; r += NT) {
             double acc[SS_B];
 #pragma unroll
@@ -1872,16 +1907,18 @@ __global__ __launch_bounds__(NT) void ss_trsolve_kernel(const int *__restrict__ 
 // conflict-free for lanes = rows): the factor is then the only global traffic, read once per
 // triangle.  For agglomerates up to ~2 000 rows.
 constexpr int XLP = SS_B + 1;
-template <int NT>
+template <int NT, int MODE>
 __global__ __launch_bounds__(NT) void ss_solve_lds_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
                                                            const int64_t *__restrict__ voff,
                                                            const double *__restrict__ W, const double *__restrict__ X,
-                                                           double *__restrict__ Zout, const int *__restrict__ state) {
+                                                           double *__restrict__ Zout, const int *__restrict__ state,
+                                                           const int *__restrict__ bws) {
     extern __shared__ __align__(16) double xl[];      // [n][XLP]
     __shared__ double Td[SB][SB + 1];
     __shared__ double ys[SB][SS_B];
     const int b = blockIdx.x, n = ns[b];
     if (state[b] & 3) return;                         // accepted (or given up) in an earlier iteration
+    const int bw = bws ? bws[b] : n;                  // the factor is zero beyond this distance from the diagonal
     const double *A = W + moff[b];
     const double *Xb = X + voff[b] * SB;
     double *Zb = Zout + voff[b] * SB;
@@ -1916,21 +1953,44 @@ __global__ __launch_bounds__(NT) void ss_solve_lds_kernel(const int *__restrict_
                 const int c = tid >> 3, jj = tid & 7;
                 if (c < nb) xl[(k0 + c) * XLP + jj] = ys[c][jj];
             }
-            const int r_lo = upper ? 0 : k0 + nb, r_hi = upper ? k0 : n;
+            const int r_lo = upper ? max(0, k0 - bw) : k0 + nb, r_hi = upper ? k0 : min(n, k0 + nb + bw);
             for (int r = r_lo + tid; r < r_hi; r += NT) {
                 double acc[SS_B];
 #pragma unroll
                 for (int j = 0; j < SS_B; ++j) acc[j] = xl[r * XLP + j];
-                const double *ap = A + (size_t)k0 * n + r;
+                if (MODE == 0) {
+                    const double *ap = A + (size_t)k0 * n + r;
 #pragma unroll 1
-                for (int c = 0; c < SB; c += 8) {     // eight factor entries in flight (ys is zero past the block)
-                    double t[8];
+                    for (int c = 0; c < SB; c += 8) {     // eight factor entries in flight (ys is zero past the block)
+                        double t[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = ap[(size_t)min(c + u, nb - 1) * n];
+                        for (int u = 0; u < 8; ++u) t[u] = ap[(size_t)min(c + u, nb - 1) * n];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
+                        for (int u = 0; u < 8; ++u)
 #pragma unroll
-                        for (int j = 0; j < SS_B; ++j) acc[j] = fma(-t[u], ys[c + u][j], acc[j]);
+                            for (int j = 0; j < SS_B; ++j) acc[j] = fma(-t[u], ys[c + u][j], acc[j]);
+                    }
+                } else if (MODE == 1) {                   // the whole block row in flight
+                    const double *ap = A + (size_t)k0 * n + r;
+                    double t[SB];
+#pragma unroll
+                    for (int u = 0; u < SB; ++u) t[u] = ap[(size_t)min(u, nb - 1) * n];
+#pragma unroll
+                    for (int u = 0; u < SB; ++u)
+#pragma unroll
+                        for (int j = 0; j < SS_B; ++j) acc[j] = fma(-t[u], ys[u][j], acc[j]);
+                } else {
+                    // the same entries from the other triangle (it holds the transpose): SB consecutive
+                    // doubles per row.  Past a partial last block (backward pass only) the reads run into the
+                    // next column of the matrix -- finite values that meet the zeros of ys.
+                    const double *ap = A + (size_t)r * n + k0;
+                    double t[SB];
+#pragma unroll
+                    for (int u = 0; u < SB; ++u) t[u] = ap[u];
+#pragma unroll
+                    for (int u = 0; u < SB; ++u)
+#pragma unroll
+                        for (int j = 0; j < SS_B; ++j) acc[j] = fma(-t[u], ys[u][j], acc[j]);
                 }
 #pragma unroll
                 for (int j = 0; j < SS_B; ++j) xl[r * XLP + j] = acc[j];
@@ -2182,46 +2242,71 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
     DBuf<int> info((size_t)b.count);
     info.zero(s);
     hipLaunchKernelGGL(ss_shift_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, SS_SIGMA);
+    // banded factorisation (SAAMGE_AMD_SS_BAND=0: treat every matrix as full)
+    static const bool use_band = [] { const char *e = std::getenv("SAAMGE_AMD_SS_BAND"); return !(e && e[0] == '0'); }();
+    const int *bws = nullptr;
+    int bwmax = nmax;
+    b.h_bw.clear();
+    if (use_band) {
+        if (b.bw.n < (size_t)b.count) b.bw.alloc((size_t)b.count);
+        profiler().begin(s);
+        hipLaunchKernelGGL(ss_band_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, b.bw.p);
+        profiler().end(s, "eig_ss_band", 0.0, 0.0);
+        b.h_bw.resize((size_t)b.count);
+        SA_HIP_CHECK(hipMemcpyAsync(b.h_bw.data(), b.bw.p, sizeof(int) * (size_t)b.count, hipMemcpyDeviceToHost, s));
+        SA_HIP_CHECK(hipStreamSynchronize(s));
+        bwmax = 0;
+        for (int v : b.h_bw) bwmax = std::max(bwmax, v);
+        bws = b.bw.p;
+    }
+    b.ss_bwmax = bwmax;
     const int cnt8 = 8 * div_up(b.count, 8);
     const bool prof = profiler().enabled;
     if (!prof) profiler().begin(s);
-    auto panel = [&](int k0, double *Vout, double *Zout) {
+    auto panel = [&](int k0, double *Vout, double *Zout, int rext) {
         if (prof) profiler().begin(s);
-        if (nmax > 768)
+        if (std::min(nmax, bwmax + 2 * SB) > 768)
             hipLaunchKernelGGL((chol_panel_kernel<1024>), dim3(b.count), dim3(1024), 0, s, k0, b.n.p, b.moff.p, b.voff.p,
-                               b.W.p, Vout, Zout, info.p);
+                               b.W.p, Vout, Zout, info.p, bws, rext);
         else
             hipLaunchKernelGGL((chol_panel_kernel<256>), dim3(b.count), dim3(256), 0, s, k0, b.n.p, b.moff.p, b.voff.p,
-                               b.W.p, Vout, Zout, info.p);
+                               b.W.p, Vout, Zout, info.p, bws, rext);
         if (prof) profiler().end(s, "eig_ss_panel", 0.0, 0.0);
     };
     // Two panels per pass over the trailing matrix: panel k, its update of the next SB columns only,
     // panel k + 1, then A22(2 SB:, 2 SB:) -= L_k L_k^T + L_{k+1} L_{k+1}^T in one read + write of the
     // lower tiles.
     for (int k0 = 0; k0 < nmax; k0 += 2 * SB) {
-        panel(k0, b.Vpk.p, b.Zbuf.p);
-        const int np1 = nmax - k0 - SB;          // order of the trailing matrix after panel k
-        if (np1 < 1) break;
-        if (prof) profiler().begin(s);
-        hipLaunchKernelGGL(sbr_panel_update_kernel, dim3(cnt8 * div_up(np1, 256)), dim3(256), 0, s, k0, b.n.p, b.moff.p,
-                           b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.count, div_up(np1, 256), 1);
-        if (prof) profiler().end(s, "eig_ss_panel", 0.0, 0.0);
-        panel(k0 + SB, b.Vpk2.p, nullptr);
-        const int np = np1 - SB;                  // ... after panel k + 1
+        panel(k0, b.Vpk.p, b.Zbuf.p, SB);
+        const int np1f = nmax - k0 - SB;         // order of the trailing matrix after panel k
+        if (np1f < 1) break;
+        const int np1 = std::min(np1f, bwmax);   // ... of its part inside the band
+        if (np1 >= 1) {
+            if (prof) profiler().begin(s);
+            hipLaunchKernelGGL(sbr_panel_update_kernel, dim3(cnt8 * div_up(np1, 256)), dim3(256), 0, s, k0, b.n.p, b.moff.p,
+                               b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.count, div_up(np1, 256), 1, bws);
+            if (prof) profiler().end(s, "eig_ss_panel", 0.0, 0.0);
+        }
+        panel(k0 + SB, b.Vpk2.p, nullptr, 0);
+        const int np = std::min(np1f - SB, bwmax);    // ... after panel k + 1
         if (np >= 1) {
             double ub = 0.0;
-            if (prof) {      // lower tiles of the trailing matrices, read and written once
-                for (int n : b.h_n) { const double q = (double)n - k0 - 2 * SB; if (q >= 1.0) ub += 8.0 * q * q; }
+            if (prof) {      // lower tiles of the trailing matrices (inside the band), read and written once
+                for (size_t i = 0; i < b.h_n.size(); ++i) {
+                    double q = (double)b.h_n[i] - k0 - 2 * SB;
+                    if (!b.h_bw.empty()) q = std::min(q, (double)b.h_bw[i]);
+                    if (q >= 1.0) ub += 8.0 * q * q;
+                }
                 profiler().begin(s);
             }
             if (np > 192)
                 hipLaunchKernelGGL((sbr_fused_kernel<false, 2, 3>), dim3(cnt8 * div_up(np, 2 * SF_ROWS)), dim3(S2_NT), 0, s, k0,
                                    b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Vpk2.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
-                                   b.Gbuf.p, b.trash.p, b.count, div_up(np, 2 * SF_ROWS), SB);
+                                   b.Gbuf.p, b.trash.p, b.count, div_up(np, 2 * SF_ROWS), SB, bws);
             else
                 hipLaunchKernelGGL((sbr_fused_kernel<false, 1, 3>), dim3(cnt8 * div_up(np, SF_ROWS)), dim3(S2_NT), 0, s, k0,
                                    b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Vpk2.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
-                                   b.Gbuf.p, b.trash.p, b.count, div_up(np, SF_ROWS), SB);
+                                   b.Gbuf.p, b.trash.p, b.count, div_up(np, SF_ROWS), SB, bws);
             if (prof) profiler().end(s, np > 192 ? "eig_ss_update" : "eig_ss_update1", ub, 0.0);
         }
     }
@@ -2241,7 +2326,11 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     mu = mubuf.p;
     const bool prof = profiler().enabled;
     double sbytes = 0.0;       // the factor once per triangle + the right-hand sides in and out
-    for (int n : b.h_n) sbytes += 8.0 * (double)n * n + 2.0 * 8.0 * SS_B * n;
+    const int *bws = b.h_bw.empty() ? nullptr : b.bw.p;
+    for (size_t i = 0; i < b.h_n.size(); ++i) {
+        const double n = b.h_n[i], w = b.h_bw.empty() ? n : std::min(n, (double)b.h_bw[i] + SB);
+        sbytes += 8.0 * n * (2.0 * w - w * w / n) + 2.0 * 8.0 * SS_B * n;     // band of both triangles
+    }
     if (!prof) profiler().begin(s);
     hipLaunchKernelGGL(ss_init_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, b.dis.p, X);
     bool done = false, failed = false;
@@ -2250,20 +2339,25 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         if (prof) profiler().begin(s);
         const size_t xl_bytes = sizeof(double) * (size_t)b.max_n * XLP + 64;
         if (b.max_n <= 1280) {
-            static bool attr = false;
-            if (!attr) {
-                SA_HIP_CHECK(hipFuncSetAttribute((const void *)ss_solve_lds_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-                attr = true;
-            }
-            hipLaunchKernelGGL((ss_solve_lds_kernel<512>), dim3(b.count), dim3(512), xl_bytes, s, b.n.p, b.moff.p, b.voff.p, b.W.p, X, Z, state.p);
+            static const int mode = [] { const char *e = std::getenv("SAAMGE_AMD_SS_SOLVE"); return e ? std::atoi(e) : 0; }();
+            static const int snt = [] { const char *e = std::getenv("SAAMGE_AMD_SS_SOLVE_NT"); return e ? std::atoi(e) : 0; }();
+            const int rows = std::min(b.max_n, b.ss_bwmax + SB);     // rows a block step updates
+            const int nt = snt ? snt : (rows <= 128 ? 128 : rows <= 256 ? 256 : 512);
+            auto go = [&](auto kern) {
+                SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                hipLaunchKernelGGL(kern, dim3(b.count), dim3(nt), xl_bytes, s, b.n.p, b.moff.p, b.voff.p, b.W.p, X, Z, state.p, bws);
+            };
+            if (nt == 128) { if (mode == 0) go(ss_solve_lds_kernel<128, 0>); else if (mode == 1) go(ss_solve_lds_kernel<128, 1>); else go(ss_solve_lds_kernel<128, 2>); }
+            else if (nt == 256) { if (mode == 0) go(ss_solve_lds_kernel<256, 0>); else if (mode == 1) go(ss_solve_lds_kernel<256, 1>); else go(ss_solve_lds_kernel<256, 2>); }
+            else { if (mode == 0) go(ss_solve_lds_kernel<512, 0>); else if (mode == 1) go(ss_solve_lds_kernel<512, 1>); else go(ss_solve_lds_kernel<512, 2>); }
         } else {
         SA_HIP_CHECK(hipMemcpyAsync(Z, X, sizeof(double) * (size_t)b.h_voff[b.count] * SB, hipMemcpyDeviceToDevice, s));
         if (b.max_n > 768) {
-            hipLaunchKernelGGL((ss_trsolve_kernel<false, 1024>), dim3(b.count), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p);
-            hipLaunchKernelGGL((ss_trsolve_kernel<true, 1024>), dim3(b.count), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p);
+            hipLaunchKernelGGL((ss_trsolve_kernel<false, 1024>), dim3(b.count), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws);
+            hipLaunchKernelGGL((ss_trsolve_kernel<true, 1024>), dim3(b.count), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws);
         } else {
-            hipLaunchKernelGGL((ss_trsolve_kernel<false, 256>), dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p);
-            hipLaunchKernelGGL((ss_trsolve_kernel<true, 256>), dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p);
+            hipLaunchKernelGGL((ss_trsolve_kernel<false, 256>), dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws);
+            hipLaunchKernelGGL((ss_trsolve_kernel<true, 256>), dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws);
         }
         }
         if (prof) { profiler().end(s, b.max_n <= 1280 ? "eig_ss_solve" : "eig_ss_solve_g", sbytes, 0.0); profiler().begin(s); }
