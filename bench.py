@@ -46,7 +46,7 @@ KERNELS = {
     "eig_sbr_syr2k": ("sbr_fused_kernel<false, 1>", "hbm"),
     "eig_sbr_fused": ("sbr_fused_kernel<true, 2>", "hbm"),
     "eig_sbr_fused1": ("sbr_fused_kernel<true, 1>", "hbm"),
-    "eig_ss_solve": ("ss_solve_lds_kernel<128, 0>", "hbm"),
+    "eig_ss_solve": ("ss_solve_lds_kernel<256, 0>", "hbm"),
     "eig_ss_update": ("sbr_fused_kernel<false, 2, 3>", "hbm"),
     "eig_ss_update1": ("sbr_fused_kernel<false, 1, 3>", "hbm"),
     "eig_ss_panel": ("chol_panel_kernel<256>", "hbm"),

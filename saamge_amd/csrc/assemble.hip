@@ -323,7 +323,8 @@ __global__ __launch_bounds__(AB_NT) void ae_build_kernel(
     const int *__restrict__ d2e_I, const int *__restrict__ d2e_J, const int *__restrict__ part,
     const int *__restrict__ e2d_I, const int *__restrict__ e2d_J, const int64_t *__restrict__ eloff,
     const double *__restrict__ elval, const int *__restrict__ Arow, const int *__restrict__ Acol,
-    const double *__restrict__ Aval, const double *__restrict__ rvals, const short *__restrict__ rcols) {
+    const double *__restrict__ Aval, const double *__restrict__ rvals, const short *__restrict__ rcols,
+    const short *__restrict__ perm) {
     extern __shared__ __align__(16) double lds[];
     __shared__ int anybig;
     const int b = blockIdx.x, p = ae0 + b, n = ns[b];
@@ -456,23 +457,25 @@ __global__ __launch_bounds__(AB_NT) void ae_build_kernel(
         __syncthreads();
     }
     // ---- 4. dense image: wavefront w writes columns w, w + NW, ... ----
+    // (perm: row / column r of the agglomerate goes to position perm[r] of the dense matrix)
     double *Wm = W + moff[b];
     double *cb = colbuf + (size_t)wave * n;
+    const short *pm = perm ? perm + voff[b] : nullptr;
     for (int r = lane; r < n; r += 64) cb[r] = 0.0;
     for (int j = wave; j < n; j += NW) {
         const double dj = SCALE ? dis[j] : 1.0;
         for (int k = lane; k < RW; k += 64) {
             const int lc = cols[j * RW + k];
-            if (lc >= 0) cb[lc] = SCALE ? dj * vals[j * RW + k] * dis[lc] : vals[j * RW + k];
+            if (lc >= 0) cb[pm ? pm[lc] : lc] = SCALE ? dj * vals[j * RW + k] * dis[lc] : vals[j * RW + k];
         }
         // (wave-private LDS: program order within the wavefront is enough)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        double *col = Wm + (size_t)j * n;
+        double *col = Wm + (size_t)(pm ? pm[j] : j) * n;
         for (int r = lane; r < n; r += 64) col[r] = cb[r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         for (int k = lane; k < RW; k += 64) {
             const int lc = cols[j * RW + k];
-            if (lc >= 0) cb[lc] = 0.0;
+            if (lc >= 0) cb[pm ? pm[lc] : lc] = 0.0;
         }
     }
 }
@@ -639,9 +642,27 @@ bool ae_sparse_rows(hipStream_t s, const DevRelations &rel, const DCsr &A, const
     return true;
 }
 
+// perm[r] = rank of the global dof of local row r among the agglomerate's dofs
+__global__ __launch_bounds__(256) void ae_perm_kernel(int ae0, const int *__restrict__ ns, const int64_t *__restrict__ voff,
+                                                      const int *__restrict__ ae2d_I, const int *__restrict__ ae2d_J,
+                                                      short *__restrict__ perm) {
+    extern __shared__ int gd[];
+    const int b = blockIdx.x, n = ns[b];
+    const int *aedofs = ae2d_J + ae2d_I[ae0 + b];
+    for (int r = threadIdx.x; r < n; r += 256) gd[r] = aedofs[r];
+    __syncthreads();
+    for (int r = threadIdx.x; r < n; r += 256) {
+        const int g = gd[r];
+        int rank = 0;
+        for (int k = 0; k < n; ++k) rank += gd[k] < g;
+        perm[voff[b] + r] = (short)rank;
+    }
+}
+
 void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevElmats &el, int ae0,
               EigBatch &batch, bool scale, double *Dout, const RowsSpan *rows) {
     if (!batch.count) return;
+    batch.has_perm = false;
     if (A && el.algebraic) {
         double bytes = 0.0;
         for (int n : batch.h_n) bytes += 8.0 * (double)n * n;
@@ -668,6 +689,16 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
         if (scale) ae_scale(s, batch, Dout);
         return;
     }
+    // rows ordered by global dof number for the banded factorisation of the few-eigenpairs path
+    static const bool use_perm = [] { const char *e = std::getenv("SAAMGE_AMD_SS_PERM"); return !(e && e[0] == '0'); }();
+    if (use_perm && scale && eig_batch_takes_subspace(batch) && batch.max_n <= 16384) {
+        const size_t rows_total = (size_t)batch.h_voff[batch.count];
+        if (batch.perm.n < rows_total) batch.perm.alloc(rows_total);
+        hipLaunchKernelGGL(ae_perm_kernel, dim3(batch.count), dim3(256), sizeof(int) * (size_t)batch.max_n, s, ae0,
+                           batch.n.p, batch.voff.p, rel.ae2d_I.p, rel.ae2d_J.p, batch.perm.p);
+        batch.has_perm = true;
+    }
+    const short *pm = batch.has_perm ? batch.perm.p : nullptr;
     const bool nde8 = el.nde == 8 && batch.count <= 65535;   // (grid.y of the rows kernel)
     const double *rv = nullptr;
     const short *rc = nullptr;
@@ -678,7 +709,7 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
                            batch.voff.p, batch.W.p, batch.dis.p, Dout, rel.ae2d_I.p, rel.ae2d_J.p,
                            rel.d2ae_I.p, rel.d2ae_J.p, rel.dof_id_inAE.p, rel.flags.p, rel.d2e_I.p,
                            rel.d2e_J.p, rel.part.p, rel.e2d_I.p, rel.e2d_J.p, el.off.p, el.val.p,
-                           A->rowptr.p, A->col.p, A->val.p, rv, rc);
+                           A->rowptr.p, A->col.p, A->val.p, rv, rc, pm);
     };
     double bytes = 0.0;
     for (int n : batch.h_n) bytes += 8.0 * (double)n * n;

@@ -44,6 +44,11 @@ struct EigBatch {
     // few-eigenpairs path (SAAMGE_AMD_EIG=subspace): Ritz values of the accepted block; `dense_only`
     // forces the dense path for this batch (fallback after a failed subspace attempt)
     DBuf<double> ss_mu;
+    // [sum n_i] position of agglomerate-local row r in the matrix as assembled (rows ordered by global
+    // dof number: a far narrower band than the first-encounter order of the tables); has_perm = false:
+    // identity.  Only the fused assembly sets it, and only for batches that take this path.
+    DBuf<short> perm;
+    bool has_perm = false;
     DBuf<int> bw;           // [count] half bandwidths (banded Cholesky), host copy; empty = full matrices
     std::vector<int> h_bw;
     int ss_bwmax = 0;
@@ -68,6 +73,7 @@ int64_t chase_reflector_count(int n);
 void eig_batch_two_stage_buffers(EigBatch &b, size_t nrefl, bool need_bandg, hipStream_t s);
 // few-eigenpairs path (eig2.hip), see there
 bool eig_use_subspace();
+bool eig_batch_takes_subspace(const EigBatch &b);   // what eig_tridiagonalize will decide for this batch
 bool eig_subspace_factor(hipStream_t s, EigBatch &b);
 bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu);
 void eig_subspace_vectors(hipStream_t s, EigBatch &b, const int64_t *eoff, const int64_t *xoff, double *evals,

@@ -778,6 +778,7 @@ void eig_batch_alloc(EigBatch &b, const std::vector<int> &sizes, hipStream_t s, 
     b.slot = g_slot = slot & 1;
     b.count = (int)sizes.size();
     b.h_n = sizes;
+    b.has_perm = false;
     b.h_moff.assign(b.count + 1, 0);
     b.h_voff.assign(b.count + 1, 0);
     b.max_n = 0;
@@ -860,11 +861,15 @@ bool eig_use_subspace() {
     return v == 1;
 }
 
-void eig_tridiagonalize(hipStream_t s, EigBatch &b, int phases) {
-    if (!b.count) return;
+bool eig_batch_takes_subspace(const EigBatch &b) {
     // (SAAMGE_AMD_SS_MIN_N: smallest agglomerate size of a batch that takes the few-eigenpairs path)
     static const int ss_min_n = []() { const char *e = std::getenv("SAAMGE_AMD_SS_MIN_N"); return e ? std::atoi(e) : 64; }();
-    if (eig_use_subspace() && !b.dense_only && b.max_n >= ss_min_n) {
+    return eig_use_subspace() && !b.dense_only && b.max_n >= ss_min_n;
+}
+
+void eig_tridiagonalize(hipStream_t s, EigBatch &b, int phases) {
+    if (!b.count) return;
+    if (eig_batch_takes_subspace(b)) {
         // few-eigenpairs path: "phase 1" is the Cholesky factorisation, phase 2 has nothing to do
         if (phases & 1) {
             b.subspace = true;
