@@ -46,10 +46,12 @@ KERNELS = {
     "eig_sbr_syr2k": ("sbr_fused_kernel<false, 1>", "hbm"),
     "eig_sbr_fused": ("sbr_fused_kernel<true, 2>", "hbm"),
     "eig_sbr_fused1": ("sbr_fused_kernel<true, 1>", "hbm"),
-    "eig_ss_solve": ("ss_solve_lds_kernel<256, 0>", "hbm"),
+    "eig_ss_solve": ("ss_solve_lds_pf_kernel<128>", "hbm"),
+    "eig_ss_chol_lds": ("chol_band_lds_kernel", "hbm"),
+    "eig_ss_solve_g": ("ss_trsolve_kernel<false, 1024>", "hbm"),
     "eig_ss_update": ("sbr_fused_kernel<false, 2, 3>", "hbm"),
     "eig_ss_update1": ("sbr_fused_kernel<false, 1, 3>", "hbm"),
-    "eig_ss_panel": ("chol_panel_kernel<256>", "hbm"),
+    "eig_ss_panel": ("chol_panel_kernel<1024>", "hbm"),
     "eig_ss_rr": ("ss_rr_kernel", "hbm"),
     "ae_build": ("ae_build_kernel<true, 8, true>", "hbm"),
     "eig_band_chase": ("band_chase_kernel", "mfma"),

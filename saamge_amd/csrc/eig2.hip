@@ -2162,6 +2162,118 @@ __global__ __launch_bounds__(NT) void ss_solve_lds_kernel(const int *__restrict_
     for (int idx = tid; idx < n * SS_B; idx += NT) Zb[idx] = xl[(idx >> 3) * XLP + (idx & 7)];
 }
 
+// The same for narrow bands (at most NT = 128 rows below a block): the kernel above is bound by the
+// bytes it keeps in flight (measured: 0.44 ms per launch with the factor loads removed against 4 ms
+// with them), so here the factor entries and the diagonal block of a step are requested more than
+// two steps ahead: three rotating register buffers, each refilled as soon as its step has used it
+// (the step loop is unrolled by three: no copy waits for a load) and the workgroup is two wavefronts, which lets five of them share a CU.
+template <int NT>
+__global__ __launch_bounds__(NT) void ss_solve_lds_pf_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
+                                                              const int64_t *__restrict__ voff,
+                                                              const double *__restrict__ W, const double *__restrict__ X,
+                                                              double *__restrict__ Zout, const int *__restrict__ state,
+                                                              const int *__restrict__ bws) {
+    static_assert(NT == 128, "two diagonal-block entries per thread");
+    extern __shared__ __align__(16) double xl[];      // [n][XLP]
+    __shared__ double Td[SB][SB + 1];
+    __shared__ double ys[SB][SS_B];
+    const int b = blockIdx.x, n = ns[b];
+    if (state[b] & 3) return;
+    const int bw = bws ? bws[b] : n;
+    const double *A = W + moff[b];
+    const double *Xb = X + voff[b] * SB;
+    double *Zb = Zout + voff[b] * SB;
+    const int tid = threadIdx.x;
+    const int nblk = (n + SB - 1) / SB, nstep = 2 * nblk;
+    for (int idx = tid; idx < n * SS_B; idx += NT) xl[(idx >> 3) * XLP + (idx & 7)] = Xb[idx];
+    auto step_k0 = [&](int st) { return st < nblk ? st * SB : (nstep - 1 - st) * SB; };
+    // buf[0 .. SB): factor entries of this thread's row, buf[SB], buf[SB + 1]: its two entries of the block inverse
+    auto prefetch = [&](int st, double (&buf)[SB + 2]) {
+        if (st >= nstep) return;
+        const bool upper = st >= nblk;
+        const int k0 = step_k0(st), nb = min(SB, n - k0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ti = (tid >> 4) + 8 * h, tj = tid & 15;
+            double v = 0.0;
+            if (ti < nb && tj < nb && (upper ? tj >= ti : tj <= ti)) v = A[(size_t)(k0 + tj) * n + (k0 + ti)];
+            buf[SB + h] = v;
+        }
+        const int r_lo = upper ? max(0, k0 - bw) : k0 + nb, r_hi = upper ? k0 : min(n, k0 + nb + bw);
+        const int r = r_lo + tid;
+        if (r < r_hi) {
+            const double *ap = A + (size_t)k0 * n + r;
+#pragma unroll
+            for (int c = 0; c < SB; ++c) buf[c] = ap[(size_t)min(c, nb - 1) * n];
+        }
+    };
+    auto step = [&](int st, double (&cur)[SB + 2]) {
+        if (st >= nstep) return;                         // (block-uniform)
+        const bool upper = st >= nblk;
+        const int k0 = step_k0(st), nb = min(SB, n - k0);
+        Td[tid >> 4][tid & 15] = cur[SB];
+        Td[(tid >> 4) + 8][tid & 15] = cur[SB + 1];
+        __syncthreads();
+        {                           // y = T11^-1 x (the stored block is the inverse)
+            const int c = tid >> 3, jj = tid & 7;
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < SB; ++i) t = fma(Td[c][i], (i < nb) ? xl[(k0 + i) * XLP + jj] : 0.0, t);
+            ys[c][jj] = (c < nb) ? t : 0.0;
+        }
+        __syncthreads();
+        {
+            const int c = tid >> 3, jj = tid & 7;
+            if (c < nb) xl[(k0 + c) * XLP + jj] = ys[c][jj];
+        }
+        const int r_lo = upper ? max(0, k0 - bw) : k0 + nb, r_hi = upper ? k0 : min(n, k0 + nb + bw);
+        int r = r_lo + tid;
+        if (r < r_hi) {
+            double acc[SS_B];
+#pragma unroll
+            for (int j = 0; j < SS_B; ++j) acc[j] = xl[r * XLP + j];
+#pragma unroll
+            for (int u = 0; u < SB; ++u)
+#pragma unroll
+                for (int j = 0; j < SS_B; ++j) acc[j] = fma(-cur[u], ys[u][j], acc[j]);
+#pragma unroll
+            for (int j = 0; j < SS_B; ++j) xl[r * XLP + j] = acc[j];
+        }
+        for (r += NT; r < r_hi; r += NT) {               // (not reached when the host picked this kernel)
+            double acc[SS_B];
+#pragma unroll
+            for (int j = 0; j < SS_B; ++j) acc[j] = xl[r * XLP + j];
+            const double *ap = A + (size_t)k0 * n + r;
+#pragma unroll 1
+            for (int c = 0; c < SB; c += 8) {
+                double t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = ap[(size_t)min(c + u, nb - 1) * n];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int j = 0; j < SS_B; ++j) acc[j] = fma(-t[u], ys[c + u][j], acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < SS_B; ++j) xl[r * XLP + j] = acc[j];
+        }
+        prefetch(st + 3, cur);                           // this buffer is free again
+        __syncthreads();
+    };
+    double t0[SB + 2], t1[SB + 2], t2[SB + 2];
+#pragma unroll
+    for (int c = 0; c < SB + 2; ++c) t0[c] = t1[c] = t2[c] = 0.0;
+    prefetch(0, t0);
+    prefetch(1, t1);
+    prefetch(2, t2);
+    for (int st = 0; st < nstep; st += 3) {
+        step(st, t0);
+        step(st + 1, t1);
+        step(st + 2, t2);
+    }
+    for (int idx = tid; idx < n * SS_B; idx += NT) Zb[idx] = xl[(idx >> 3) * XLP + (idx & 7)];
+}
+
 // Rayleigh-Ritz on span(Z) from M = Z^T X and G = Z^T Z, inverse residuals of the previous pairs,
 // X <- Z C.  state[b]: bit 0 = converged (the wanted pairs and the first unwanted one), count in
 // bits 8.., bit 1 = failure (too many wanted pairs / breakdown).  mu[b][SS_B] ascending.
@@ -2525,15 +2637,17 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         if (prof) profiler().begin(s);
         const size_t xl_bytes = sizeof(double) * (size_t)b.max_n * XLP + 64;
         if (b.max_n <= 1280) {
-            static const int mode = [] { const char *e = std::getenv("SAAMGE_AMD_SS_SOLVE"); return e ? std::atoi(e) : 0; }();
+            // SAAMGE_AMD_SS_SOLVE: 3 (default) deep-prefetch kernel for narrow bands, 0 / 1 / 2 variants of the plain one
+            static const int mode = [] { const char *e = std::getenv("SAAMGE_AMD_SS_SOLVE"); return e ? std::atoi(e) : 3; }();
             static const int snt = [] { const char *e = std::getenv("SAAMGE_AMD_SS_SOLVE_NT"); return e ? std::atoi(e) : 0; }();
             const int rows = std::min(b.max_n, b.ss_bwmax + SB);     // rows a block step updates
-            const int nt = (snt == 256 || snt == 512) ? snt : (rows <= 256 ? 256 : 512);   // (>= SB * SB threads: the block loads)
+            int nt = (snt == 256 || snt == 512) ? snt : (rows <= 256 ? 256 : 512);   // (>= SB * SB threads: the block loads)
             auto go = [&](auto kern) {
                 SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
                 hipLaunchKernelGGL(kern, dim3(b.count), dim3(nt), xl_bytes, s, b.n.p, b.moff.p, b.voff.p, b.W.p, X, Z, state.p, bws);
             };
-            if (nt == 256) { if (mode == 0) go(ss_solve_lds_kernel<256, 0>); else if (mode == 1) go(ss_solve_lds_kernel<256, 1>); else go(ss_solve_lds_kernel<256, 2>); }
+            if (mode == 3 && rows <= 128) { nt = 128; go(ss_solve_lds_pf_kernel<128>); }
+            else if (nt == 256) { if (mode == 0) go(ss_solve_lds_kernel<256, 0>); else if (mode == 1) go(ss_solve_lds_kernel<256, 1>); else go(ss_solve_lds_kernel<256, 2>); }
             else { if (mode == 0) go(ss_solve_lds_kernel<512, 0>); else if (mode == 1) go(ss_solve_lds_kernel<512, 1>); else go(ss_solve_lds_kernel<512, 2>); }
         } else {
         SA_HIP_CHECK(hipMemcpyAsync(Z, X, sizeof(double) * (size_t)b.h_voff[b.count] * SB, hipMemcpyDeviceToDevice, s));
