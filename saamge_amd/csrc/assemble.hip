@@ -18,7 +18,8 @@ __global__ __launch_bounds__(ASM_NT) void ae_assemble_kernel(
     const int *__restrict__ d2e_J, const int *__restrict__ part, const int *__restrict__ e2d_I,
     const int *__restrict__ e2d_J, const int *__restrict__ elem_ldof,
     const int64_t *__restrict__ eloff, const double *__restrict__ elval, int has_A,
-    const int *__restrict__ Arow, const int *__restrict__ Acol, const double *__restrict__ Aval) {
+    const int *__restrict__ Arow, const int *__restrict__ Acol, const double *__restrict__ Aval,
+    const int64_t *__restrict__ voff, const short *__restrict__ perm) {
     const int b = blockIdx.x, p = ae0 + b, n = ns[b];
     double *Wm = W + moff[b];
     const int tid = threadIdx.x;
@@ -26,8 +27,10 @@ __global__ __launch_bounds__(ASM_NT) void ae_assemble_kernel(
     for (size_t idx = tid; idx < nn; idx += ASM_NT) Wm[idx] = 0.0;
     __syncthreads();
     const int *aedofs = ae2d_J + ae2d_I[p];
-    for (int lr = tid; lr < n; lr += ASM_NT) {
-        const int g = aedofs[lr];
+    const short *pm = perm ? perm + voff[b] : nullptr;    // position of an agglomerate row in the matrix
+    for (int lr0 = tid; lr0 < n; lr0 += ASM_NT) {
+        const int g = aedofs[lr0];
+        const int lr = pm ? pm[lr0] : lr0;
         const int fg = has_A ? flags[g] : 0;
         if (has_A) {
             // entries copied from the global matrix (aggregates.cpp:930-934)
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(ASM_NT) void ae_assemble_kernel(
                 const bool assembled = (fg & 1) && (fc & 1) && (!((fg | fc) & 2) || c == g);
                 if (!assembled) {
                     const double v = Aval[k];
-                    if (v != 0.0) Wm[(size_t)dof_id_inAE[idx] * n + lr] = v;
+                    if (v != 0.0) Wm[(size_t)(pm ? pm[dof_id_inAE[idx]] : dof_id_inAE[idx]) * n + lr] = v;
                 }
             }
         }
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(ASM_NT) void ae_assemble_kernel(
                     const int fc = flags[c];
                     assembled = (fg & 1) && (fc & 1) && (!((fg | fc) & 2) || c == g);
                 }
-                if (assembled) Wm[(size_t)elem_ldof[eb + jj] * n + lr] += M[jj];
+                if (assembled) Wm[(size_t)(pm ? pm[elem_ldof[eb + jj]] : elem_ldof[eb + jj]) * n + lr] += M[jj];
             }
         }
     }
@@ -77,7 +80,7 @@ void ae_assemble(hipStream_t s, const DevRelations &rel, const DCsr *A, const De
                        rel.d2ae_J.p, rel.dof_id_inAE.p, rel.flags.p, rel.d2e_I.p, rel.d2e_J.p,
                        rel.part.p, rel.e2d_I.p, rel.e2d_J.p, rel.elem_ldof.p, el.off.p, el.val.p,
                        A ? 1 : 0, A ? A->rowptr.p : nullptr, A ? A->col.p : nullptr,
-                       A ? A->val.p : nullptr);
+                       A ? A->val.p : nullptr, batch.voff.p, batch.has_perm ? batch.perm.p : nullptr);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "ae_assemble", bytes, 0.0);
 }
@@ -145,7 +148,8 @@ __global__ __launch_bounds__(ASM_NT) void ae_scale_kernel(const int *__restrict_
 // (matrix, 64-row block) and (matrix, column) grids.
 __global__ __launch_bounds__(256) void ae_rowsum_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
                                                         const int64_t *__restrict__ voff, const double *__restrict__ W,
-                                                        double *__restrict__ dis_out, double *__restrict__ D_out) {
+                                                        double *__restrict__ dis_out, double *__restrict__ D_out,
+                                                        const short *__restrict__ iperm) {
     __shared__ double part[4 * 64];
     const int b = blockIdx.y, n = ns[b];
     const int r0 = blockIdx.x * 64;
@@ -172,20 +176,23 @@ __global__ __launch_bounds__(256) void ae_rowsum_kernel(const int *__restrict__ 
     __syncthreads();
     if (g == 0 && r < n) {
         const double s4 = (part[rr] + part[64 + rr]) + (part[128 + rr] + part[192 + rr]);
-        dis_out[vo + r] = 1.0 / sqrt(s4);
-        if (D_out) D_out[vo + r] = s4;
+        const int ro = iperm ? iperm[vo + r] : r;       // (the scalings are stored in agglomerate order)
+        dis_out[vo + ro] = 1.0 / sqrt(s4);
+        if (D_out) D_out[vo + ro] = s4;
     }
 }
 __global__ __launch_bounds__(256) void ae_apply_scale_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
                                                              const int64_t *__restrict__ voff, double *__restrict__ W,
-                                                             const double *__restrict__ dis) {
+                                                             const double *__restrict__ dis,
+                                                             const short *__restrict__ iperm) {
     const int b = blockIdx.y, n = ns[b];
     const int j = blockIdx.x;
     if (j >= n) return;
     double *col = W + moff[b] + (size_t)j * n;
     const double *d = dis + voff[b];
-    const double dj = d[j];
-    for (int r = threadIdx.x; r < n; r += 256) col[r] = d[r] * col[r] * dj;
+    const short *ip = iperm ? iperm + voff[b] : nullptr;
+    const double dj = d[ip ? ip[j] : j];
+    for (int r = threadIdx.x; r < n; r += 256) col[r] = d[ip ? ip[r] : r] * col[r] * dj;
 }
 
 void ae_scale(hipStream_t s, EigBatch &batch, double *Dout) {
@@ -194,10 +201,11 @@ void ae_scale(hipStream_t s, EigBatch &batch, double *Dout) {
     for (int n : batch.h_n) bytes += 24.0 * (double)n * n;
     if (batch.count <= 2048 && batch.max_n >= 1024) {
         profiler().begin(s);
+        const short *ip = batch.has_perm ? batch.iperm.p : nullptr;
         hipLaunchKernelGGL(ae_rowsum_kernel, dim3(div_up(batch.max_n, 64), batch.count), dim3(256), 0, s, batch.n.p,
-                           batch.moff.p, batch.voff.p, batch.W.p, batch.dis.p, Dout);
+                           batch.moff.p, batch.voff.p, batch.W.p, batch.dis.p, Dout, ip);
         hipLaunchKernelGGL(ae_apply_scale_kernel, dim3(batch.max_n, batch.count), dim3(256), 0, s, batch.n.p,
-                           batch.moff.p, batch.voff.p, batch.W.p, batch.dis.p);
+                           batch.moff.p, batch.voff.p, batch.W.p, batch.dis.p, ip);
         SA_HIP_CHECK(hipGetLastError());
         profiler().end(s, "ae_scale", bytes, 0.0);
         return;
@@ -645,7 +653,7 @@ bool ae_sparse_rows(hipStream_t s, const DevRelations &rel, const DCsr &A, const
 // perm[r] = rank of the global dof of local row r among the agglomerate's dofs
 __global__ __launch_bounds__(256) void ae_perm_kernel(int ae0, const int *__restrict__ ns, const int64_t *__restrict__ voff,
                                                       const int *__restrict__ ae2d_I, const int *__restrict__ ae2d_J,
-                                                      short *__restrict__ perm) {
+                                                      short *__restrict__ perm, short *__restrict__ iperm) {
     extern __shared__ int gd[];
     const int b = blockIdx.x, n = ns[b];
     const int *aedofs = ae2d_J + ae2d_I[ae0 + b];
@@ -656,6 +664,7 @@ __global__ __launch_bounds__(256) void ae_perm_kernel(int ae0, const int *__rest
         int rank = 0;
         for (int k = 0; k < n; ++k) rank += gd[k] < g;
         perm[voff[b] + r] = (short)rank;
+        iperm[voff[b] + rank] = (short)r;
     }
 }
 
@@ -678,6 +687,17 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
     static const bool no_fused = std::getenv("SAAMGE_AMD_NO_FUSED_ASSEMBLY") != nullptr;
     size_t lds = 0;
     int RW = 0;
+    // rows ordered by global dof number for the banded factorisation of the few-eigenpairs path (the
+    // fused kernel below, or the plain assembly followed by the two-kernel scaling)
+    static const bool use_perm = [] { const char *e = std::getenv("SAAMGE_AMD_SS_PERM"); return !(e && e[0] == '0'); }();
+    const bool split_scale = batch.count <= 2048 && batch.max_n >= 1024;      // (what ae_scale will pick)
+    if (use_perm && scale && eig_batch_takes_subspace(batch) && batch.max_n <= 16384 && ((A && !no_fused) || split_scale)) {
+        const size_t rows_total = (size_t)batch.h_voff[batch.count];
+        if (batch.perm.n < rows_total) { batch.perm.alloc(rows_total); batch.iperm.alloc(rows_total); }
+        hipLaunchKernelGGL(ae_perm_kernel, dim3(batch.count), dim3(256), sizeof(int) * (size_t)batch.max_n, s, ae0,
+                           batch.n.p, batch.voff.p, rel.ae2d_I.p, rel.ae2d_J.p, batch.perm.p, batch.iperm.p);
+        batch.has_perm = true;
+    }
     if (A && !no_fused) {
         if (A->max_row < 0) A->max_row = csr_max_row(s, *A);
         RW = A->max_row;
@@ -685,18 +705,10 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
         lds = 8 * (n * RW + 2 * n + (AB_NT / 64) * n) + 2 * n * RW + 4 * n + 64;
     }
     if (!A || no_fused || lds > 160 * 1024 - 256 || batch.max_n > 32767) {
+        if (!split_scale) batch.has_perm = false;       // (the one-kernel scaling works in agglomerate order)
         ae_assemble(s, rel, A, el, ae0, batch);
         if (scale) ae_scale(s, batch, Dout);
         return;
-    }
-    // rows ordered by global dof number for the banded factorisation of the few-eigenpairs path
-    static const bool use_perm = [] { const char *e = std::getenv("SAAMGE_AMD_SS_PERM"); return !(e && e[0] == '0'); }();
-    if (use_perm && scale && eig_batch_takes_subspace(batch) && batch.max_n <= 16384) {
-        const size_t rows_total = (size_t)batch.h_voff[batch.count];
-        if (batch.perm.n < rows_total) batch.perm.alloc(rows_total);
-        hipLaunchKernelGGL(ae_perm_kernel, dim3(batch.count), dim3(256), sizeof(int) * (size_t)batch.max_n, s, ae0,
-                           batch.n.p, batch.voff.p, rel.ae2d_I.p, rel.ae2d_J.p, batch.perm.p);
-        batch.has_perm = true;
     }
     const short *pm = batch.has_perm ? batch.perm.p : nullptr;
     const bool nde8 = el.nde == 8 && batch.count <= 65535;   // (grid.y of the rows kernel)

@@ -47,7 +47,7 @@ struct EigBatch {
     // [sum n_i] position of agglomerate-local row r in the matrix as assembled (rows ordered by global
     // dof number: a far narrower band than the first-encounter order of the tables); has_perm = false:
     // identity.  Only the fused assembly sets it, and only for batches that take this path.
-    DBuf<short> perm;
+    DBuf<short> perm, iperm;      // (iperm: row of the agglomerate at a position of the matrix)
     bool has_perm = false;
     DBuf<int> bw;           // [count] half bandwidths (banded Cholesky), host copy; empty = full matrices
     std::vector<int> h_bw;
