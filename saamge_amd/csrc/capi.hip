@@ -1,4 +1,5 @@
 // extern "C" boundary (include/saamge_amd.h).  Exceptions stop here.
+#include <cstdlib>
 #include "../../include/saamge_amd.h"
 
 #include <string>
@@ -44,6 +45,10 @@ void saamge_amd_params_default(saamge_amd_params *p) {
     p->coarse_rtol = 1e-14;
     p->coarse_max_iter = 2000;
     p->workspace_bytes = (long long)32 << 30;
+    if (const char *e = std::getenv("SAAMGE_AMD_WORKSPACE_GB")) {     // default chunk size of the AE eigenproblems
+        const long long gb = std::atoll(e);
+        if (gb >= 1 && gb <= 256) p->workspace_bytes = gb << 30;
+    }
     p->keep_debug = 0;
     p->rank = 0;
     p->world = 1;

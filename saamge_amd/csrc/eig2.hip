@@ -2281,7 +2281,7 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
                                                     double *__restrict__ X, const double *__restrict__ Z,
                                                     double *__restrict__ mu, int *__restrict__ state, int iter,
                                                     double sigma, double vu) {
-    __shared__ double part[32][2 * SS_B][SS_B];     // [row group][M rows | G rows][column j]
+    __shared__ double part[4][2 * SS_B + 1][SS_B];  // [wavefront][M rows | G rows | residual][column j]
     __shared__ double Ms[SS_B][SS_B], Gs[SS_B][SS_B], Cs[SS_B][SS_B], res2[SS_B], mus[SS_B], mu_old[SS_B];
     const int b = blockIdx.x, n = ns[b];
     if (state[b] & 3) return;                       // accepted earlier: X, mu stay as they are
@@ -2307,22 +2307,25 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
             const double d = zj - th * xj;
             rs = fma(d, d, rs);
         }
+        // the 8 row groups of a wavefront are summed in registers (lane bits 3..5), the 4 wavefronts in LDS:
+        // a small footprint lets 8 workgroups share a CU, which is what hides the serial part below
 #pragma unroll
-        for (int i = 0; i < SS_B; ++i) { part[grp][i][j] = am[i]; part[grp][SS_B + i][j] = ag[i]; }
-        __syncthreads();
-        if (tid < 2 * SS_B * SS_B) {
-            const int i = tid >> 3, jj = tid & 7;
-            double sum = 0.0;
-            for (int g = 0; g < 32; ++g) sum += part[g][i][jj];
-            if (i < SS_B) Ms[i][jj] = sum; else Gs[i - SS_B][jj] = sum;
+        for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+            for (int i = 0; i < SS_B; ++i) { am[i] += __shfl_xor(am[i], o, 64); ag[i] += __shfl_xor(ag[i], o, 64); }
+            rs += __shfl_xor(rs, o, 64);
+        }
+        if ((tid & 63) < SS_B) {
+            const int w = tid >> 6;
+#pragma unroll
+            for (int i = 0; i < SS_B; ++i) { part[w][i][j] = am[i]; part[w][SS_B + i][j] = ag[i]; }
+            part[w][2 * SS_B][j] = rs;
         }
         __syncthreads();
-        part[grp][0][j] = rs;
-        __syncthreads();
-        if (tid < SS_B) {
-            double sum = 0.0;
-            for (int g = 0; g < 32; ++g) sum += part[g][0][tid];
-            res2[tid] = sum;
+        if (tid < (2 * SS_B + 1) * SS_B) {
+            const int i = tid >> 3, jj = tid & 7;
+            const double sum = (part[0][i][jj] + part[1][i][jj]) + (part[2][i][jj] + part[3][i][jj]);
+            if (i < SS_B) Ms[i][jj] = sum; else if (i < 2 * SS_B) Gs[i - SS_B][jj] = sum; else res2[jj] = sum;
         }
         __syncthreads();
     }
