@@ -64,6 +64,13 @@ __device__ inline double fast_sqrt(double x) {
     return fma(fma(-g, g, x), h, g);
 }
 
+__device__ inline double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    return y;
+}
+
 __device__ inline double wsum64(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -2296,16 +2303,30 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
 #pragma unroll
         for (int i = 0; i < SS_B; ++i) { am[i] = 0.0; ag[i] = 0.0; }
         const double th = 1.0 / mu_old[j];
-        for (int r = grp; r < n; r += 32) {
-            const double xj = Xb[(size_t)r * SS_B + j], zj = Zb[(size_t)r * SS_B + j];
+        // four rows per trip: their loads are independent (the loop is otherwise one HBM round trip per row)
+        for (int r0 = grp; r0 < n; r0 += 128) {
+            double xj[4], zjv[4], zr[4][SS_B];
 #pragma unroll
-            for (int i = 0; i < SS_B; ++i) {
-                const double zi = Zb[(size_t)r * SS_B + i];
-                am[i] = fma(zi, xj, am[i]);
-                ag[i] = fma(zi, zj, ag[i]);
+            for (int u = 0; u < 4; ++u) {
+                const int r = min(r0 + 32 * u, n - 1);
+                xj[u] = Xb[(size_t)r * SS_B + j];
+                zjv[u] = Zb[(size_t)r * SS_B + j];
+#pragma unroll
+                for (int i = 0; i < SS_B; ++i) zr[u][i] = Zb[(size_t)r * SS_B + i];
             }
-            const double d = zj - th * xj;
-            rs = fma(d, d, rs);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (r0 + 32 * u < n) {
+                    const double zj = zjv[u];
+#pragma unroll
+                    for (int i = 0; i < SS_B; ++i) {
+                        am[i] = fma(zr[u][i], xj[u], am[i]);
+                        ag[i] = fma(zr[u][i], zj, ag[i]);
+                    }
+                    const double d = zj - th * xj[u];
+                    rs = fma(d, d, rs);
+                }
+            }
         }
         // the 8 row groups of a wavefront are summed in registers (lane bits 3..5), the 4 wavefronts in LDS:
         // a small footprint lets 8 workgroups share a CU, which is what hides the serial part below
@@ -2330,7 +2351,7 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
         __syncthreads();
     }
     __shared__ double R[SS_B][SS_B + 1], S[SS_B][SS_B + 1], V[SS_B][SS_B + 1];
-    __shared__ double rot_c[4], rot_s[4];
+    __shared__ double rot_c[4], rot_s[4], rdi[SS_B];     // (rdi: reciprocal diagonal of R)
     __shared__ int sh_st, sh_ok;
     if (tid == 0) {
         int st = 0;
@@ -2358,12 +2379,13 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
                 double d = Gs[c][c];
                 for (int q = 0; q < c; ++q) d -= R[q][c] * R[q][c];
                 if (!(d > 0.0)) { sh_ok = 0; d = 1.0; }
-                d = sqrt(d);
-                R[c][c] = d;
+                const double ri = fast_rsqrt(d);      // (division and square-root chains: hardware seed + Newton)
+                R[c][c] = d * ri;
+                rdi[c] = ri;
                 for (int c2 = c + 1; c2 < SS_B; ++c2) {
                     double t = 0.5 * (Gs[c][c2] + Gs[c2][c]);
                     for (int q = 0; q < c; ++q) t -= R[q][c] * R[q][c2];
-                    R[c][c2] = t / d;
+                    R[c][c2] = t * ri;
                 }
             }
         }
@@ -2379,7 +2401,7 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
             for (int r2 = 0; r2 < SS_B; ++r2) {
                 double t = 0.5 * (Ms[r2][c] + Ms[c][r2]);
                 for (int q = 0; q < r2; ++q) t -= R[q][r2] * S[q][c];
-                S[r2][c] = t / R[r2][r2];
+                S[r2][c] = t * rdi[r2];
             }
         }
         wsync();
@@ -2388,7 +2410,7 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
             for (int c = 0; c < SS_B; ++c) {
                 double t = S[r2][c];
                 for (int q = 0; q < c; ++q) t -= S[r2][q] * R[q][c];
-                S[r2][c] = t / R[c][c];
+                S[r2][c] = t * rdi[c];
             }
         }
         wsync();
@@ -2412,9 +2434,11 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
                     double cc = 1.0, sn = 0.0;
                     const double apq = S[p2][q2];
                     if (apq != 0.0) {
-                        const double tau = (S[q2][q2] - S[p2][p2]) / (2.0 * apq);
-                        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                        cc = 1.0 / sqrt(1.0 + t * t);
+                        // t = sign(tau) / (|tau| + sqrt(1 + tau^2)), tau = d / (2 apq), without the division by apq
+                        const double d = S[q2][q2] - S[p2][p2];
+                        const double den = fabs(d) + fast_sqrt(fma(d, d, 4.0 * apq * apq));
+                        const double t = ((d >= 0.0) == (apq >= 0.0) ? 2.0 : -2.0) * fabs(apq) * fast_rcp(den);
+                        cc = fast_rsqrt(fma(t, t, 1.0));
                         sn = t * cc;
                     }
                     rot_c[tid] = cc;
@@ -2461,7 +2485,7 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
             for (int r2 = SS_B - 1; r2 >= 0; --r2) {
                 double t = V[r2][src];
                 for (int c2 = r2 + 1; c2 < SS_B; ++c2) t -= R[r2][c2] * Cs[c2][q];
-                Cs[r2][q] = t / R[r2][r2];
+                Cs[r2][q] = t * rdi[r2];
             }
         }
     }
