@@ -1765,6 +1765,7 @@ __device__ inline int chol16_inverse_wave(double (*Ld)[SB + 1], double (*Li)[SB 
 #pragma unroll
             for (int q = 0; q < i; ++q) t = fma(-Ld[i][q], x[q], t);     // (x[q] = 0 above the diagonal)
             x[i] = (i >= j) ? t * rd[i] : 0.0;
+            __builtin_amdgcn_sched_barrier(0);      // (keeps the 120 LDS operands from being hoisted into registers at once)
         }
 #pragma unroll
         for (int i = 0; i < SB; ++i) Li[i][j] = x[i];
@@ -1850,12 +1851,19 @@ __global__ __launch_bounds__(NT) void chol_panel_kernel(int k0, const int *__res
 // register tiles, and the next SB rows of the band are fetched (from the upper triangle: it still
 // holds the original entries, column i rows i - bw .. i are contiguous).  The band is read once and
 // written once; nothing else touches HBM.
-constexpr int BC_WIN = 128, BC_P = BC_WIN + 1, BC_MAXBW = BC_WIN - SB, BC_NT = 256;
-constexpr int BC_PT = BC_MAXBW + 4;      // pitch of the transposed panel (rows padded to the 4-row tiles)
-constexpr size_t BC_LDS = sizeof(double) * ((size_t)BC_WIN * BC_P + (size_t)SB * BC_PT + 2 * SB * (SB + 1)) + 64;
+// The window size is a template parameter: 128 (bands up to 112, one workgroup per CU), 80 (up to 64,
+// two per CU) and 68 (up to 52, three per CU) -- the kernel is a chain of short dependent stages, so
+// the resident workgroups of other matrices are what fills the CU.
+constexpr int BC_NT = 256;
+constexpr size_t bc_lds_bytes(int win) {
+    return sizeof(double) * ((size_t)win * (win + 1) + (size_t)SB * (win - SB + 4) + 2 * SB * (SB + 1)) + 64;
+}
+template <int BC_WIN>
 __global__ __launch_bounds__(BC_NT) void chol_band_lds_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
                                                               double *__restrict__ W, const int *__restrict__ bws,
                                                               int *__restrict__ info) {
+    constexpr int BC_P = BC_WIN + 1, BC_MAXBW = BC_WIN - SB;
+    constexpr int BC_PT = BC_MAXBW + 4;      // pitch of the transposed panel (rows padded to the 4-row tiles)
     extern __shared__ __align__(16) double bc_lds[];
     double *S = bc_lds;                                  // [BC_WIN][BC_P]
     double *Lp = S + BC_WIN * BC_P;                      // [SB][BC_PT]: L21^T of the current block (16-byte aligned rows)
@@ -1866,7 +1874,7 @@ __global__ __launch_bounds__(BC_NT) void chol_band_lds_kernel(const int *__restr
     if (bw > BC_MAXBW) return;                           // (the host only launches this when every matrix fits)
     double *A = W + moff[b];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    auto sl = [&](int i, int j) -> double & { return S[(i & (BC_WIN - 1)) * BC_P + (j & (BC_WIN - 1))]; };
+    auto sl = [&](int i, int j) -> double & { return S[(i % BC_WIN) * BC_P + (j % BC_WIN)]; };     // (i, j >= 0)
     auto fetch_rows = [&](int i0, int i1) {              // rows [i0, i1) of the band, from the upper triangle
         for (int i = i0 + w; i < min(i1, n); i += BC_NT / 64)
             for (int jj = lane; jj <= bw; jj += 64) {
@@ -1925,6 +1933,7 @@ __global__ __launch_bounds__(BC_NT) void chol_band_lds_kernel(const int *__restr
                 Lp[c * BC_PT + tid] = t;
                 A[(size_t)(k0 + c) * n + r] = t;
                 A[(size_t)r * n + (k0 + c)] = t;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
@@ -1941,8 +1950,8 @@ __global__ __launch_bounds__(BC_NT) void chol_band_lds_kernel(const int *__restr
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[a][c] = 0.0;
             const double *pi = Lp + 4 * ti, *pj = Lp + 4 * tj;
-#pragma unroll
-            for (int c = 0; c < SB; ++c) {
+#pragma unroll 2
+            for (int c = 0; c < SB; ++c) {        // (not fully unrolled: the scheduler would hoist all 64 operand loads, 300 VGPRs)
                 const double2 i01 = *(const double2 *)(pi + c * BC_PT), i23 = *(const double2 *)(pi + c * BC_PT + 2);
                 const double2 j01 = *(const double2 *)(pj + c * BC_PT), j23 = *(const double2 *)(pj + c * BC_PT + 2);
                 const double ai[4] = {i01.x, i01.y, i23.x, i23.y}, aj[4] = {j01.x, j01.y, j23.x, j23.y};
@@ -2568,16 +2577,17 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
         std::fprintf(stderr, "subspace: %d matrices, n max %d, half bandwidth %d .. %d\n", b.count, nmax, b.h_bw.empty() ? nmax : bwmin, bwmax);
     }
     static const bool use_lds = [] { const char *e = std::getenv("SAAMGE_AMD_SS_BAND_LDS"); return !(e && e[0] == '0'); }();
-    if (bws && use_lds && bwmax <= BC_MAXBW) {       // the band fits the LDS window: one launch
-        static bool attr = false;
-        if (!attr) {
-            SA_HIP_CHECK(hipFuncSetAttribute((const void *)chol_band_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BC_LDS));
-            attr = true;
-        }
+    if (bws && use_lds && bwmax <= 128 - SB) {       // the band fits the LDS window: one launch
         double cb = 0.0;      // the band read once, the factor written to both triangles
         for (size_t i = 0; i < b.h_n.size(); ++i) cb += 3.0 * 8.0 * (double)b.h_n[i] * (std::min(b.h_bw[i], b.h_n[i] - 1) + 1);
         profiler().begin(s);
-        hipLaunchKernelGGL(chol_band_lds_kernel, dim3(b.count), dim3(BC_NT), BC_LDS, s, b.n.p, b.moff.p, b.W.p, bws, info.p);
+        auto go = [&](auto kern, int win) {
+            SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bc_lds_bytes(win)));
+            hipLaunchKernelGGL(kern, dim3(b.count), dim3(BC_NT), bc_lds_bytes(win), s, b.n.p, b.moff.p, b.W.p, bws, info.p);
+        };
+        if (bwmax <= 68 - SB) go(chol_band_lds_kernel<68>, 68);
+        else if (bwmax <= 80 - SB) go(chol_band_lds_kernel<80>, 80);
+        else go(chol_band_lds_kernel<128>, 128);
         SA_HIP_CHECK(hipGetLastError());
         profiler().end(s, "eig_ss_chol_lds", cb, 0.0);
         auto h = info.to_host(s);
