@@ -2312,11 +2312,11 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
 #pragma unroll
         for (int i = 0; i < SS_B; ++i) { am[i] = 0.0; ag[i] = 0.0; }
         const double th = 1.0 / mu_old[j];
-        // four rows per trip: their loads are independent (the loop is otherwise one HBM round trip per row)
-        for (int r0 = grp; r0 < n; r0 += 128) {
-            double xj[4], zjv[4], zr[4][SS_B];
+                // two rows per trip: their loads are independent (four would cost a resident workgroup: 164 VGPRs)
+        for (int r0 = grp; r0 < n; r0 += 64) {
+            double xj[2], zjv[2], zr[2][SS_B];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 2; ++u) {
                 const int r = min(r0 + 32 * u, n - 1);
                 xj[u] = Xb[(size_t)r * SS_B + j];
                 zjv[u] = Zb[(size_t)r * SS_B + j];
@@ -2324,7 +2324,7 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
                 for (int i = 0; i < SS_B; ++i) zr[u][i] = Zb[(size_t)r * SS_B + i];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 2; ++u) {
                 if (r0 + 32 * u < n) {
                     const double zj = zjv[u];
 #pragma unroll
@@ -2509,19 +2509,17 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
     const int st = (int)Ms[0][0];
     if (st & 3) return;            // converged (X, mu stay the accepted pairs) or failed
     if (tid < SS_B) mu[(size_t)b * SS_B + tid] = mus[tid];
-    for (int r = tid; r < n; r += 256) {
-        double z[SS_B], x[SS_B];
+    {   // X = Z C: one output entry per thread and trip (its column of C in 8 registers, coalesced stores)
+        const int q = tid & 7;
+        double cq[SS_B];
 #pragma unroll
-        for (int i = 0; i < SS_B; ++i) z[i] = Zb[(size_t)r * SS_B + i];
-#pragma unroll
-        for (int q = 0; q < SS_B; ++q) {
+        for (int i = 0; i < SS_B; ++i) cq[i] = Cs[i][q];
+        for (int r = tid >> 3; r < n; r += 32) {
             double t = 0.0;
 #pragma unroll
-            for (int i = 0; i < SS_B; ++i) t = fma(z[i], Cs[i][q], t);
-            x[q] = t;
+            for (int i = 0; i < SS_B; ++i) t = fma(Zb[(size_t)r * SS_B + i], cq[i], t);
+            Xb[(size_t)r * SS_B + q] = t;
         }
-#pragma unroll
-        for (int q = 0; q < SS_B; ++q) Xb[(size_t)r * SS_B + q] = x[q];
     }
 }
 
