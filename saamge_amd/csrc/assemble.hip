@@ -332,7 +332,7 @@ __global__ __launch_bounds__(AB_NT) void ae_build_kernel(
     const int *__restrict__ e2d_I, const int *__restrict__ e2d_J, const int64_t *__restrict__ eloff,
     const double *__restrict__ elval, const int *__restrict__ Arow, const int *__restrict__ Acol,
     const double *__restrict__ Aval, const double *__restrict__ rvals, const short *__restrict__ rcols,
-    const short *__restrict__ perm) {
+    const short *__restrict__ perm, int *__restrict__ bw_out) {
     extern __shared__ __align__(16) double lds[];
     __shared__ int anybig;
     const int b = blockIdx.x, p = ae0 + b, n = ns[b];
@@ -470,21 +470,33 @@ __global__ __launch_bounds__(AB_NT) void ae_build_kernel(
     double *cb = colbuf + (size_t)wave * n;
     const short *pm = perm ? perm + voff[b] : nullptr;
     for (int r = lane; r < n; r += 64) cb[r] = 0.0;
+    int mybw = 0;          // half bandwidth of the matrix as written (for the banded factorisation)
     for (int j = wave; j < n; j += NW) {
         const double dj = SCALE ? dis[j] : 1.0;
+        const int pj = pm ? pm[j] : j;
         for (int k = lane; k < RW; k += 64) {
             const int lc = cols[j * RW + k];
-            if (lc >= 0) cb[pm ? pm[lc] : lc] = SCALE ? dj * vals[j * RW + k] * dis[lc] : vals[j * RW + k];
+            if (lc >= 0) {
+                const int pc = pm ? pm[lc] : lc;
+                const double v = SCALE ? dj * vals[j * RW + k] * dis[lc] : vals[j * RW + k];
+                cb[pc] = v;
+                if (v != 0.0) mybw = max(mybw, abs(pc - pj));
+            }
         }
         // (wave-private LDS: program order within the wavefront is enough)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        double *col = Wm + (size_t)(pm ? pm[j] : j) * n;
+        double *col = Wm + (size_t)pj * n;
         for (int r = lane; r < n; r += 64) col[r] = cb[r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         for (int k = lane; k < RW; k += 64) {
             const int lc = cols[j * RW + k];
             if (lc >= 0) cb[pm ? pm[lc] : lc] = 0.0;
         }
+    }
+    if (bw_out) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mybw = max(mybw, __shfl_xor(mybw, o, 64));
+        if (lane == 0 && mybw > 0) atomicMax(bw_out + b, mybw);
     }
 }
 
@@ -730,6 +742,7 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
               EigBatch &batch, bool scale, double *Dout, const RowsSpan *rows) {
     if (!batch.count) return;
     batch.has_perm = false;
+    batch.has_bw = false;
     if (A && el.algebraic) {
         double bytes = 0.0;
         for (int n : batch.h_n) bytes += 8.0 * (double)n * n;
@@ -770,6 +783,13 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
         return;
     }
     const short *pm = batch.has_perm ? batch.perm.p : nullptr;
+    int *bwp = nullptr;           // half bandwidths straight from the sparse rows (scaled matrices of the few-eigenpairs path)
+    if (scale && eig_batch_takes_subspace(batch)) {
+        if (batch.bw.n < (size_t)batch.count) batch.bw.alloc((size_t)batch.count);
+        SA_HIP_CHECK(hipMemsetAsync(batch.bw.p, 0, sizeof(int) * (size_t)batch.count, s));
+        bwp = batch.bw.p;
+        batch.has_bw = true;
+    }
     const bool nde8 = el.nde == 8 && batch.count <= 65535;   // (grid.y of the rows kernel)
     const double *rv = nullptr;
     const short *rc = nullptr;
@@ -780,7 +800,7 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
                            batch.voff.p, batch.W.p, batch.dis.p, Dout, rel.ae2d_I.p, rel.ae2d_J.p,
                            rel.d2ae_I.p, rel.d2ae_J.p, rel.dof_id_inAE.p, rel.flags.p, rel.d2e_I.p,
                            rel.d2e_J.p, rel.part.p, rel.e2d_I.p, rel.e2d_J.p, el.off.p, el.val.p,
-                           A->rowptr.p, A->col.p, A->val.p, rv, rc, pm);
+                           A->rowptr.p, A->col.p, A->val.p, rv, rc, pm, bwp);
     };
     double bytes = 0.0;
     for (int n : batch.h_n) bytes += 8.0 * (double)n * n;

@@ -49,6 +49,7 @@ struct EigBatch {
     // identity.  Only the fused assembly sets it, and only for batches that take this path.
     DBuf<short> perm, iperm;      // (iperm: row of the agglomerate at a position of the matrix)
     bool has_perm = false;
+    bool has_bw = false;    // bw was filled by the assembly (from the sparse rows): no scan of the dense matrices
     DBuf<int> bw;           // [count] half bandwidths (banded Cholesky), host copy; empty = full matrices
     std::vector<int> h_bw;
     int ss_bwmax = 0;

@@ -779,6 +779,7 @@ void eig_batch_alloc(EigBatch &b, const std::vector<int> &sizes, hipStream_t s, 
     b.count = (int)sizes.size();
     b.h_n = sizes;
     b.has_perm = false;
+    b.has_bw = false;
     b.h_moff.assign(b.count + 1, 0);
     b.h_voff.assign(b.count + 1, 0);
     b.max_n = 0;

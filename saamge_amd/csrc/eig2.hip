@@ -2557,10 +2557,12 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
     int bwmax = nmax;
     b.h_bw.clear();
     if (use_band) {
-        if (b.bw.n < (size_t)b.count) b.bw.alloc((size_t)b.count);
-        profiler().begin(s);
-        hipLaunchKernelGGL(ss_band_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, b.bw.p);
-        profiler().end(s, "eig_ss_band", 0.0, 0.0);
+        if (!b.has_bw) {          // (the fused assembly has already measured them on the sparse rows)
+            if (b.bw.n < (size_t)b.count) b.bw.alloc((size_t)b.count);
+            profiler().begin(s);
+            hipLaunchKernelGGL(ss_band_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, b.bw.p);
+            profiler().end(s, "eig_ss_band", 0.0, 0.0);
+        }
         b.h_bw.resize((size_t)b.count);
         SA_HIP_CHECK(hipMemcpyAsync(b.h_bw.data(), b.bw.p, sizeof(int) * (size_t)b.count, hipMemcpyDeviceToHost, s));
         SA_HIP_CHECK(hipStreamSynchronize(s));
