@@ -1699,7 +1699,8 @@ __global__ __launch_bounds__(256) void ss_band_kernel(const int *__restrict__ ns
     const double *A = W + moff[b];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     int bw = 0;
-    for (int j = w; j < n; j += 4) {           // one wavefront per column, bottom up, until the first non-zero
+    // one wavefront per column, bottom up, until the first non-zero; gridDim.y workgroups share a matrix
+    for (int j = blockIdx.y * 4 + w; j < n; j += 4 * gridDim.y) {
         const double *col = A + (size_t)j * n;
         for (int r1 = n; r1 > j + 1 + bw; r1 -= 64) {
             const int r = r1 - 64 + lane;
@@ -1710,7 +1711,7 @@ __global__ __launch_bounds__(256) void ss_band_kernel(const int *__restrict__ ns
     }
     if (lane == 0) wmax[w] = bw;
     __syncthreads();
-    if (tid == 0) bws[b] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    if (tid == 0) atomicMax(bws + b, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));    // (zeroed by the host)
 }
 
 __device__ inline double readlane_f64(double v, int src) {       // src: wave-uniform
@@ -1727,7 +1728,7 @@ __device__ inline double readlane_f64(double v, int src) {       // src: wave-un
 // the reciprocal pivots.  Returns non-zero when a pivot was not positive.
 __device__ inline int chol16_inverse_wave(double (*Ld)[SB + 1], double (*Li)[SB + 1], int lane) {
     const int li = lane & (SB - 1);
-    double a[SB], rd[SB];
+    double a[SB];
 #pragma unroll
     for (int c = 0; c < SB; ++c) a[c] = Ld[li][c];
     int isbad = 0;
@@ -1742,7 +1743,7 @@ __device__ inline int chol16_inverse_wave(double (*Ld)[SB + 1], double (*Li)[SB 
             r = r * fma(-0.5 * dj * r, r, 1.5);
             r = r * fma(-0.5 * dj * r, r, 1.5);
         }
-        rd[j] = r;
+        if (lane == 0) Li[0][j] = r;                // reciprocal pivots: parked in row 0 of Li until the inverse is written
         a[j] *= r;                                  // column j of L on the lanes i >= j (lane j: sqrt(dj))
 #pragma unroll
         for (int c = j + 1; c < SB; ++c) {
@@ -1764,7 +1765,7 @@ __device__ inline int chol16_inverse_wave(double (*Ld)[SB + 1], double (*Li)[SB 
             double t = (i == j) ? 1.0 : 0.0;
 #pragma unroll
             for (int q = 0; q < i; ++q) t = fma(-Ld[i][q], x[q], t);     // (x[q] = 0 above the diagonal)
-            x[i] = (i >= j) ? t * rd[i] : 0.0;
+            x[i] = (i >= j) ? t * Li[0][i] : 0.0;
             __builtin_amdgcn_sched_barrier(0);      // (keeps the 120 LDS operands from being hoisted into registers at once)
         }
 #pragma unroll
@@ -1823,21 +1824,18 @@ __global__ __launch_bounds__(NT) void chol_panel_kernel(int k0, const int *__res
         double x[SB];
 #pragma unroll
         for (int c = 0; c < SB; ++c) x[c] = A[(size_t)(k0 + c) * n + r];
-        double y[SB];                // row of L21 = x L11^-T: y_c = sum_{j <= c} x_j (L11^-1)(c, j)
-#pragma unroll
+        const size_t pr = (size_t)(r - k0 - SB) * SB;
+        // row of L21 = x L11^-T: y_c = sum_j x_j (L11^-1)(c, j) (zero above the diagonal); two columns per
+        // trip so that the 256 LDS operands are not all hoisted into registers
+#pragma unroll 2
         for (int c = 0; c < SB; ++c) {
             double t = 0.0;
 #pragma unroll
-            for (int j = 0; j <= c; ++j) t = fma(x[j], Li[c][j], t);
-            y[c] = t;
-        }
-        const size_t pr = (size_t)(r - k0 - SB) * SB;
-#pragma unroll
-        for (int c = 0; c < SB; ++c) {
-            A[(size_t)(k0 + c) * n + r] = y[c];
-            A[(size_t)r * n + (k0 + c)] = y[c];
-            Vp[pr + c] = y[c];
-            if (Zp) Zp[pr + c] = 0.5 * y[c];
+            for (int j = 0; j < SB; ++j) t = fma(x[j], Li[c][j], t);
+            A[(size_t)(k0 + c) * n + r] = t;
+            A[(size_t)r * n + (k0 + c)] = t;
+            Vp[pr + c] = t;
+            if (Zp) Zp[pr + c] = 0.5 * t;
         }
     }
 }
@@ -2560,7 +2558,9 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
         if (!b.has_bw) {          // (the fused assembly has already measured them on the sparse rows)
             if (b.bw.n < (size_t)b.count) b.bw.alloc((size_t)b.count);
             profiler().begin(s);
-            hipLaunchKernelGGL(ss_band_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, b.bw.p);
+            SA_HIP_CHECK(hipMemsetAsync(b.bw.p, 0, sizeof(int) * (size_t)b.count, s));
+            const int ny = std::max(1, std::min(32, std::min(nmax / 64, 4096 / std::max(1, b.count))));
+            hipLaunchKernelGGL(ss_band_kernel, dim3(b.count, ny), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, b.bw.p);
             profiler().end(s, "eig_ss_band", 0.0, 0.0);
         }
         b.h_bw.resize((size_t)b.count);
