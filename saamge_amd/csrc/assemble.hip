@@ -332,9 +332,9 @@ __global__ __launch_bounds__(AB_NT) void ae_build_kernel(
     const int *__restrict__ e2d_I, const int *__restrict__ e2d_J, const int64_t *__restrict__ eloff,
     const double *__restrict__ elval, const int *__restrict__ Arow, const int *__restrict__ Acol,
     const double *__restrict__ Aval, const double *__restrict__ rvals, const short *__restrict__ rcols,
-    const short *__restrict__ perm, int *__restrict__ bw_out) {
+    const short *__restrict__ perm, int *__restrict__ bw_out, int band_only) {
     extern __shared__ __align__(16) double lds[];
-    __shared__ int anybig;
+    __shared__ int anybig, sbw;
     const int b = blockIdx.x, p = ae0 + b, n = ns[b];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = AB_NT / 64;
@@ -470,6 +470,24 @@ __global__ __launch_bounds__(AB_NT) void ae_build_kernel(
     double *cb = colbuf + (size_t)wave * n;
     const short *pm = perm ? perm + voff[b] : nullptr;
     for (int r = lane; r < n; r += 64) cb[r] = 0.0;
+    // band_only: the consumer is the banded factorisation, which never reads further than bw + 2 SB
+    // from the diagonal (bw = half bandwidth of the stored entries) -- only that part of every column is
+    // written (a fifth of the 87 GB of dense images on the headline problem's fine level)
+    int wb = n;
+    if (band_only) {
+        if (tid == 0) sbw = 0;
+        __syncthreads();
+        int m = 0;
+        for (int it = tid; it < n * RW; it += AB_NT) {
+            const int lc = cols[it];
+            if (lc >= 0 && vals[it] != 0.0) m = max(m, abs((pm ? pm[lc] : lc) - (pm ? pm[it / RW] : it / RW)));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+        if (lane == 0) atomicMax(&sbw, m);
+        __syncthreads();
+        wb = sbw + 32;
+    }
     int mybw = 0;          // half bandwidth of the matrix as written (for the banded factorisation)
     for (int j = wave; j < n; j += NW) {
         const double dj = SCALE ? dis[j] : 1.0;
@@ -486,7 +504,7 @@ __global__ __launch_bounds__(AB_NT) void ae_build_kernel(
         // (wave-private LDS: program order within the wavefront is enough)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         double *col = Wm + (size_t)pj * n;
-        for (int r = lane; r < n; r += 64) col[r] = cb[r];
+        for (int r = max(0, pj - wb) + lane; r < min(n, pj + wb + 1); r += 64) col[r] = cb[r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         for (int k = lane; k < RW; k += 64) {
             const int lc = cols[j * RW + k];
@@ -790,6 +808,8 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
         bwp = batch.bw.p;
         batch.has_bw = true;
     }
+    static const bool band_write = [] { const char *e = std::getenv("SAAMGE_AMD_SS_BAND_WRITE"); return !(e && e[0] == '0'); }();
+    const int band_only = (bwp && band_write && eig_ss_band_enabled()) ? 1 : 0;
     const bool nde8 = el.nde == 8 && batch.count <= 65535;   // (grid.y of the rows kernel)
     const double *rv = nullptr;
     const short *rc = nullptr;
@@ -800,7 +820,7 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
                            batch.voff.p, batch.W.p, batch.dis.p, Dout, rel.ae2d_I.p, rel.ae2d_J.p,
                            rel.d2ae_I.p, rel.d2ae_J.p, rel.dof_id_inAE.p, rel.flags.p, rel.d2e_I.p,
                            rel.d2e_J.p, rel.part.p, rel.e2d_I.p, rel.e2d_J.p, el.off.p, el.val.p,
-                           A->rowptr.p, A->col.p, A->val.p, rv, rc, pm, bwp);
+                           A->rowptr.p, A->col.p, A->val.p, rv, rc, pm, bwp, band_only);
     };
     double bytes = 0.0;
     for (int n : batch.h_n) bytes += 8.0 * (double)n * n;

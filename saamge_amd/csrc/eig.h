@@ -74,6 +74,7 @@ int64_t chase_reflector_count(int n);
 void eig_batch_two_stage_buffers(EigBatch &b, size_t nrefl, bool need_bandg, hipStream_t s);
 // few-eigenpairs path (eig2.hip), see there
 bool eig_use_subspace();
+bool eig_ss_band_enabled();                          // banded factorisation on (SAAMGE_AMD_SS_BAND != 0)
 bool eig_batch_takes_subspace(const EigBatch &b);   // what eig_tridiagonalize will decide for this batch
 bool eig_subspace_factor(hipStream_t s, EigBatch &b);
 bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu);

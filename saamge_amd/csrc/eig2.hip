@@ -2538,6 +2538,11 @@ __global__ __launch_bounds__(256) void ss_output_kernel(const int *__restrict__ 
     }
 }
 
+bool eig_ss_band_enabled() {
+    static const bool v = [] { const char *e = std::getenv("SAAMGE_AMD_SS_BAND"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
 // C - sigma I = L L^T for every matrix of the batch (in place, L below / L^T above the diagonal).
 // Returns false when a pivot was not positive.
 bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
@@ -2550,7 +2555,7 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
     info.zero(s);
     hipLaunchKernelGGL(ss_shift_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, SS_SIGMA);
     // banded factorisation (SAAMGE_AMD_SS_BAND=0: treat every matrix as full)
-    static const bool use_band = [] { const char *e = std::getenv("SAAMGE_AMD_SS_BAND"); return !(e && e[0] == '0'); }();
+    const bool use_band = eig_ss_band_enabled();
     const int *bws = nullptr;
     int bwmax = nmax;
     b.h_bw.clear();
