@@ -150,6 +150,45 @@ def test_batched_eigens_many_identical_blocks():
         assert np.allclose(_proj(X, D), _proj(Xr, D), atol=PROJ_TOL)
 
 
+def test_batched_eigens_banded_matrices_take_the_few_eigenpairs_path():
+    """Banded agglomerate matrices (graph Laplacians of band graphs, half bandwidths 1 .. n - 1) through the
+    banded Cholesky + shift-invert path: the band fits the LDS window (first batch: windows 68 / 80 / 128
+    are picked by the widest band of a batch) or goes through HBM (second batch).  STRICT turns the silent
+    dense fallback into an error, so this passes only on the path it names."""
+    capi, o = _capi(), _oracle()
+    rng = np.random.default_rng(23)
+
+    def band_laplacian(n, bw):
+        W = np.zeros((n, n))
+        for d in range(1, bw + 1):
+            w = rng.uniform(0.5, 1.5, size=n - d)
+            W += np.diag(-w, d) + np.diag(-w, -d)
+        L = W + np.diag(-W.sum(axis=1))
+        return L + np.diag(1e-4 * rng.uniform(0.5, 1.0, size=n))     # SPD, one eigenvalue near zero
+
+    old = os.environ.get("SAAMGE_AMD_SS_STRICT")
+    os.environ["SAAMGE_AMD_SS_STRICT"] = "1"
+    try:
+        for shapes in ([(70, 1), (96, 5), (130, 17), (64, 40)], [(200, 52)], [(150, 60), (90, 3)], [(300, 100), (77, 2)],
+                       [(300, 120), (257, 256), (80, 4)]):
+            mats = [band_laplacian(n, bw) for n, bw in shapes]
+            Ds = [o.snd_D_from_dense(L) for L in mats]
+            theta = 2e-3
+            res = capi.lower_eigens_batched(mats, Ds, -1.0, theta)
+            for L, D, (w, X) in zip(mats, Ds, res):
+                wr, Xr = o.lower_eigens_dense(L, D, theta)
+                assert len(w) == len(wr) and 1 <= len(w) <= 6
+                assert np.allclose(w, wr, atol=EIG_TOL)
+                R = L @ X - (D[:, None] * X) * w[None, :]
+                assert np.abs(R).max() <= 1e-10
+                assert np.allclose(_proj(X, D), _proj(Xr, D), atol=PROJ_TOL)
+    finally:
+        if old is None:
+            del os.environ["SAAMGE_AMD_SS_STRICT"]
+        else:
+            os.environ["SAAMGE_AMD_SS_STRICT"] = old
+
+
 def _range_projection(P, probe):
     """Orthogonal projection of `probe` onto range(P) (basis independent)."""
     G = (P.T @ P).toarray()
