@@ -18,7 +18,9 @@ Prints ONE JSON line (rank 0).  Extra legs, outside the timed region:
   * cpu_baseline: the CPU oracle (numpy + LAPACK dsygvx/dgesvd, 1 thread) on a bounded
     sample of the same workload, timed on this box's host cores.
 
-N > 1 (torchrun, one rank per GPU, RCCL): STRONG scaling on the same global problem -- the
+N > 1: `python bench.py --gpus N` starts N fresh rank processes itself (one per GPU, before this
+process touches the GPU; under torchrun / the driver's torch.distributed.run the ranks already exist
+and WORLD_SIZE must equal --gpus).  STRONG scaling on the same global problem -- the
 per-agglomerate spectral problems of every level (the dominant setup cost) are sharded over the
 ranks and their eigenvectors all-gathered in place, likewise the Galerkin product and the coarse
 element matrices; the PCG solve is row-partitioned on the large levels (halo exchange before every
@@ -121,6 +123,31 @@ def pmc_traffic(symbol, n, levels):
     return (2.0 * k["fetch_bytes_raw"] + k["write_bytes"]) / k["launches"]
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: N child processes, one per GPU, started before
+    this process imports torch or touches the GPU (a process that initialised the GPU must never be
+    re-executed).  Rank 0's JSON line is relayed; any failing rank fails the run."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, WORLD_SIZE=str(n), RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        log("bench.py: rank exit codes %s" % rcs)
+        sys.exit(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +164,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus, sys.argv[1:])
 
     import torch
     from saamge_amd import capi
@@ -147,6 +176,9 @@ def main():
     dev = "cuda:%d" % local_dev
     grp = Group(backend=os.environ.get("SAAMGE_AMD_DIST_BACKEND", "nccl"), device=dev)
     world, rank = grp.world, grp.rank
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with `python bench.py --gpus N` or "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
 
     prob = build_problem(args.n, args.levels, dev, args.aniso, tuple(int(v) for v in args.blk.split(",")))
     torch.cuda.synchronize()
@@ -184,7 +216,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak",
+        "scaling": "strong",     # the same global problem at every N (BASELINE config 3: "256^3 ... 1 -> 8 MI355X")
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -207,10 +239,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         capi.profile(True)
         capi.profile_reset()
-        # (single-rank parameters: `params` now carries the group's callbacks)
-        params1 = capi.default_params(num_coarsenings=args.levels - 1, theta=args.theta, nu_relax=3,
-                                      nu_pro=args.nu_pro, correct_nullspace=args.correct_nullspace)
-        h, x, its2, conv2, hist2 = one_step(capi, prob, params1)
+        h, x, its2, conv2, hist2 = one_step(capi, prob, params)      # (single rank: no group)
         h.close()
         capi.profile(False)
         stats = sorted(capi.profile_stats(), key=lambda s: -s["ms"])

@@ -95,6 +95,12 @@ typedef struct saamge_amd_params {
      * src/aggregates.cpp:324-487; Arbitrator::suggest, src/arbitrator.cpp:93-204).  Lower
      * operator complexity on the coarsest level. */
     int do_aggregates;
+    /* Local eigensolver (Eigensolver::SolveDirect -> dsygvx, src/spectral.cpp:124-237,
+     * src/xpacks.cpp:222-314).  0 (default): few-eigenpairs path -- banded Cholesky + shift-invert
+     * subspace iteration, the count #{lambda <= theta} certified by the inertia of C - theta I,
+     * any batch that fails certification redone by the dense path; 1: dense path only (dsygvx's
+     * own algorithm: reduction to tridiagonal form, Sturm counts, inverse iteration). */
+    int eigensolver;
 } saamge_amd_params;
 
 void saamge_amd_params_default(saamge_amd_params *p);
@@ -177,6 +183,14 @@ int saamge_amd_spmv(int nrows, int ncols, const int *rowptr, const int *col, con
  * (first m[i] columns), D-orthonormal. */
 int saamge_amd_lower_eigens_batched(int count, const int *n, const double *A, const double *D,
                                     double vl, double vu, int *m, double *evals, double *evecs);
+
+/* The certificate of the few-eigenpairs path on its own: neg[i] = number of eigenvalues of
+ * A_i x = lambda D_i x below vu, from the inertia of D^-1/2 A D^-1/2 - vu I (banded L S L^T without
+ * pivoting; Sylvester) -- what dsygvx obtains from dstebz's Sturm counts (src/xpacks.cpp:226-268).
+ * -1: a pivot was too small for the count to be trusted (the setup then takes the dense path).
+ * Same packing as saamge_amd_lower_eigens_batched. */
+int saamge_amd_inertia_batched(int count, const int *n, const double *A, const double *D, double vu,
+                               int *neg);
 
 /* ---- per-kernel timing for bench.py's roofline leg (HIP events around every launch) ---- */
 void saamge_amd_profile_enable(int on);

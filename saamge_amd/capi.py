@@ -22,7 +22,7 @@ SYMBOLS = [
     "saamge_amd_get_mis", "saamge_amd_get_ae_eigens", "saamge_amd_get_mis_svd", "saamge_amd_spmv",
     "saamge_amd_lower_eigens_batched", "saamge_amd_profile_enable", "saamge_amd_profile_reset",
     "saamge_amd_profile_count", "saamge_amd_profile_get", "saamge_amd_memcpy",
-    "saamge_amd_update_operators",
+    "saamge_amd_update_operators", "saamge_amd_inertia_batched",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong))
@@ -58,6 +58,7 @@ class Params(C.Structure):
         ("algebraic", C.c_int),
         ("smooth_drop_tol", C.c_double),
         ("do_aggregates", C.c_int),
+        ("eigensolver", C.c_int),
     ]
 
 
@@ -121,7 +122,7 @@ def _ptr(a):
 def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, keep_debug=False,
                    coarse_rtol=1e-14, workspace_bytes=None, dist_min_local_rows=None,
                    coarse_solver=None, nu_pro=0, correct_nullspace=False, extra_modes=None, algebraic=False,
-                   smooth_drop_tol=0.0, do_aggregates=False):
+                   smooth_drop_tol=0.0, do_aggregates=False, eigensolver=0):
     p = Params()
     load().saamge_amd_params_default(C.byref(p))
     p.num_coarsenings = num_coarsenings
@@ -134,6 +135,7 @@ def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, k
     p.algebraic = 2 if algebraic == "window" else int(bool(algebraic))
     p.smooth_drop_tol = float(smooth_drop_tol)
     p.do_aggregates = int(do_aggregates)
+    p.eigensolver = {"subspace": 0, "dense": 1}.get(eigensolver, eigensolver)
     p.keep_debug = int(keep_debug)
     p.coarse_rtol = coarse_rtol
     if workspace_bytes is not None:
@@ -159,6 +161,9 @@ class Hierarchy(object):
                  params, NE, nde, stream=0, group=None, dist_solve=True):
         lib = load()
         self._keep = (A_rowptr, A_col, A_val, elem_to_dof, elmat, bdr, partitions)
+        caller_params = params
+        params = Params.from_buffer_copy(params)      # the caller's struct is never modified
+        self._keep_params = caller_params             # (keeps extra_modes alive)
         if group is not None and group.world > 1:
             # distributed setup: this rank solves the eigenproblems of its AE range only;
             # distributed solve: large levels are applied by row blocks with halo exchange
@@ -371,6 +376,17 @@ def lower_eigens_batched(mats, diags, vl, vu):
         vo += ni
         mo += ni * ni
     return out
+
+
+def inertia_batched(mats, diags, vu):
+    """Number of eigenvalues of A_i x = lambda D_i x below vu per matrix (-1: not certifiable)."""
+    count = len(mats)
+    n = np.array([m.shape[0] for m in mats], dtype=np.int32)
+    A = np.concatenate([np.asfortranarray(m).ravel(order="F") for m in mats])
+    D = np.concatenate([np.asarray(d, dtype=np.float64) for d in diags])
+    neg = np.zeros(count, dtype=np.int32)
+    _check(load().saamge_amd_inertia_batched(C.c_int(count), _ptr(n), _ptr(A), _ptr(D), C.c_double(vu), _ptr(neg)))
+    return neg
 
 
 def profile(enable=True):

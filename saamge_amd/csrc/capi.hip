@@ -27,6 +27,12 @@ static std::string g_last_error;
     }                                                \
     return 0;
 
+// every call on a hierarchy must come from a thread whose current HIP device is the one the
+// hierarchy was built on (HIP's current device is per host thread)
+static void require_device(const Hierarchy &H) {
+    SA_REQUIRE(current_device() == H.device, "the calling thread's current HIP device is not the hierarchy's device");
+}
+
 extern "C" {
 
 const char *saamge_amd_last_error(void) { return g_last_error.c_str(); }
@@ -64,6 +70,7 @@ void saamge_amd_params_default(saamge_amd_params *p) {
     p->algebraic = 0;
     p->smooth_drop_tol = 0.0;
     p->do_aggregates = 0;
+    p->eigensolver = 0;
 }
 
 int saamge_amd_memcpy(void *dst, const void *src, long long bytes) {
@@ -113,6 +120,8 @@ int saamge_amd_ml_produce_data(int n, const int *rowptr, const int *col, const d
     p.algebraic = params->algebraic;
     p.smooth_drop_tol = params->smooth_drop_tol;
     p.do_aggregates = params->do_aggregates;
+    p.eigensolver = params->eigensolver;
+    SA_REQUIRE(p.eigensolver == 0 || p.eigensolver == 1, "bad eigensolver selector");
     SA_REQUIRE(p.world == 1 || (p.rank >= 0 && p.rank < p.world), "bad rank");
     Hierarchy *H = hierarchy_create(n, rowptr, col, val, NE, nde, elem_to_dof, elmat, bdr_dofs,
                                     partitions, nparts, p, (hipStream_t)stream);
@@ -123,6 +132,7 @@ int saamge_amd_ml_produce_data(int n, const int *rowptr, const int *col, const d
 int saamge_amd_update_operators(saamge_amd_hierarchy *h, const double *new_val) {
     SA_API_BEGIN
     SA_REQUIRE(h, "null argument");
+    require_device(*h->H);
     hierarchy_update_operators(*h->H, new_val);
     SA_API_END
 }
@@ -165,6 +175,7 @@ int saamge_amd_vcycle_mult(saamge_amd_hierarchy *h, const double *b, double *x) 
     SA_API_BEGIN
     SA_REQUIRE(h && b && x, "null argument");
     Hierarchy &H = *h->H;
+    require_device(H);
     const size_t n = (size_t)H.levels[0]->A.nrows;
     VecIn vb(b, n, H.stream);
     VecOut vx(x, n, H.stream, false);
@@ -177,6 +188,7 @@ int saamge_amd_smoother(saamge_amd_hierarchy *h, int level, const double *b, dou
     SA_API_BEGIN
     SA_REQUIRE(h && b && x, "null argument");
     Hierarchy &H = *h->H;
+    require_device(H);
     SA_REQUIRE(level >= 0 && level < (int)H.levels.size(), "bad level");
     const size_t n = (size_t)H.levels[level]->A.nrows;
     VecIn vb(b, n, H.stream);
@@ -192,6 +204,7 @@ int saamge_amd_pcg(saamge_amd_hierarchy *h, const double *b, double *x, double r
     SA_API_BEGIN
     SA_REQUIRE(h && b && x && iters, "null argument");
     Hierarchy &H = *h->H;
+    require_device(H);
     const size_t n = (size_t)H.levels[0]->A.nrows;
     VecIn vb(b, n, H.stream);
     VecOut vx(x, n, H.stream, !zero_guess);
@@ -388,6 +401,7 @@ int saamge_amd_lower_eigens_batched(int count, const int *n, const double *A, co
     std::vector<int> sizes(n, n + count);
     EigBatch b;
     eig_batch_alloc(b, sizes, s);
+    b.set_window(vu);
     SA_HIP_CHECK(hipMemcpyAsync(b.W.p, A, 8 * (size_t)b.h_moff[count], hipMemcpyDefault, s));
     DBuf<double> dD;
     dD.assign(D, (size_t)b.h_voff[count], s);
@@ -421,6 +435,25 @@ int saamge_amd_lower_eigens_batched(int count, const int *n, const double *A, co
         std::copy(hev.begin() + eoff[i], hev.begin() + eoff[i + 1], evals + b.h_voff[i]);
         std::copy(hxv.begin() + xoff[i], hxv.begin() + xoff[i + 1], evecs + b.h_moff[i]);
     }
+    SA_API_END
+}
+
+int saamge_amd_inertia_batched(int count, const int *n, const double *A, const double *D, double vu, int *neg) {
+    SA_API_BEGIN
+    SA_REQUIRE(count >= 0 && n && A && D && neg, "bad argument");
+    hipStream_t s = 0;
+    std::vector<int> sizes(n, n + count);
+    EigBatch b;
+    eig_batch_alloc(b, sizes, s);
+    b.set_window(vu);
+    SA_HIP_CHECK(hipMemcpyAsync(b.W.p, A, 8 * (size_t)b.h_moff[count], hipMemcpyDefault, s));
+    DBuf<double> dD;
+    dD.assign(D, (size_t)b.h_voff[count], s);
+    hipLaunchKernelGGL(apply_dscale_kernel, dim3(count), dim3(256), 0, s, count, b.n.p, b.moff.p,
+                       b.voff.p, b.W.p, dD.p, b.dis.p);
+    (void)eig_subspace_factor(s, b);      // (the inertia pass runs ahead of the Cholesky factorisation)
+    SA_REQUIRE((int)b.h_inertia.size() == count, "the inertia pass is switched off");
+    std::copy(b.h_inertia.begin(), b.h_inertia.end(), neg);
     SA_API_END
 }
 

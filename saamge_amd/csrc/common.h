@@ -34,6 +34,20 @@ struct Error : std::runtime_error {
                                              std::to_string(__LINE__) + " " + (msg));   \
     } while (0)
 
+// ---- device affinity of helper threads -------------------------------------------------
+// HIP's current device is a per-host-thread property and defaults to device 0.  One process
+// drives one GPU (rank r on device LOCAL_RANK), so every helper thread that may touch HIP
+// (hipMalloc, copies, pinned allocations, launches) adopts the device of the thread that
+// spawned it, and the helper streams are kept per device.
+inline int current_device() {
+    int d = 0;
+    SA_HIP_CHECK(hipGetDevice(&d));
+    return d;
+}
+inline void adopt_device(int dev) { SA_HIP_CHECK(hipSetDevice(dev)); }
+// non-blocking helper stream number `slot` of the calling thread's current device
+hipStream_t side_stream(int slot);
+
 // ---- pinned host memory: pooled allocator for the big host-side tables -----------------
 // Pageable <-> device copies run at a few GB/s; page-locked ones at PCIe speed.  hipHostMalloc
 // itself is slow (it pins pages), so freed blocks are kept in a size-class pool and reused

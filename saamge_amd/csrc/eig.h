@@ -53,6 +53,13 @@ struct EigBatch {
     DBuf<int> bw;           // [count] half bandwidths (banded Cholesky), host copy; empty = full matrices
     std::vector<int> h_bw;
     int ss_bwmax = 0;
+    // certified count: the upper end of the window must be known when the matrices are factored
+    // (set_window before eig_tridiagonalize); h_inertia[i] = #{eigenvalues of C_i < vu} from the
+    // inertia of C_i - vu I, -1 = not trustworthy (tiny pivot)
+    bool has_window = false;
+    double window_vu = 0.0;
+    std::vector<int> h_inertia;
+    void set_window(double vu_) { has_window = true; window_vu = vu_; }
     bool subspace = false, dense_only = false, ss_failed = false;
     std::vector<int> h_n, h_m;
     std::vector<int64_t> h_moff, h_voff;
@@ -81,6 +88,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu);
 void eig_subspace_vectors(hipStream_t s, EigBatch &b, const int64_t *eoff, const int64_t *xoff, double *evals,
                           double *evecs);
 void eig_arena_release();   // frees the persistent workspace
+double *eig_arena_bandsave(const EigBatch &b, size_t doubles);   // persistent scratch of the inertia pass
 // bytes of device workspace one matrix of size n needs (for chunk sizing)
 size_t eig_workspace_bytes(int n);
 // Phase 2: count eigenvalues in (vl, vu] (Sturm); fills b.m / b.j0 and the host copy b.h_m

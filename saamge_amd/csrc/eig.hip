@@ -316,15 +316,21 @@ __device__ inline double unit_rand(unsigned a, unsigned b) {  // deterministic u
     return ((double)h + 0.5) * (2.0 / 4294967296.0) - 1.0;
 }
 
+// GWS: the per-matrix work arrays (tridiagonal, LU factors, iterate: ~58 n bytes) live in a global
+// workspace instead of LDS -- agglomerates beyond ~2 900 rows, where they no longer fit 160 KiB
+// (same code through generic pointers; the workgroup barriers order the accesses).
+template <bool GWS>
 __global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
     const int *__restrict__ ns, const int64_t *__restrict__ moff, const int64_t *__restrict__ voff,
     const double *__restrict__ Wm, const double *__restrict__ dd, const double *__restrict__ ee,
     const double *__restrict__ tt, const double *__restrict__ dis, const int *__restrict__ ms,
     const int *__restrict__ j0s, const int64_t *__restrict__ eoff, const int64_t *__restrict__ xoff,
-    double *__restrict__ evals, double *__restrict__ evecs, int do_backtransform, double vl, double vu) {
+    double *__restrict__ evals, double *__restrict__ evecs, int do_backtransform, double vl, double vu,
+    double *__restrict__ gws, int64_t gws_stride) {
     constexpr int NT = VEC_NT;
     constexpr int NW = NT / 64;
-    extern __shared__ __align__(16) double lds[];
+    extern __shared__ __align__(16) double lds_[];
+    double *lds = GWS ? gws + (size_t)blockIdx.x * gws_stride : lds_;
     const int bi = blockIdx.x;
     const int n = ns[bi];
     const int m = ms[bi], j0 = j0s[bi];
@@ -751,7 +757,7 @@ static bool use_one_stage() {
 // multi-GB buffers costs 0.1-0.4 s each on this platform; the arena is allocated once per
 // process and reused by every chunk / level / hierarchy).  Single stream, sequential use.
 struct EigArena {
-    DBuf<double> W, panel, d, e, tau, dis, Tfac, Xbuf, Zbuf, Vpk, Vpk2, trash, rv, rtau, bandg, Gbuf, Xpart;
+    DBuf<double> W, panel, d, e, tau, dis, Tfac, Xbuf, Zbuf, Vpk, Vpk2, trash, rv, rtau, bandg, Gbuf, Xpart, bandsave;
     DBuf<int> n, m, j0;
     DBuf<int64_t> moff, voff, roff, goff, xpoff;
 };
@@ -773,6 +779,12 @@ void eig_arena_release() {
     g_slot = 0;
 }
 bool eig_uses_two_stage() { return !use_one_stage(); }
+double *eig_arena_bandsave(const EigBatch &b, size_t doubles) {
+    g_slot = b.slot;
+    EigArena &a = arena();
+    if (a.bandsave.n < doubles) a.bandsave.alloc(doubles + doubles / 8 + 64);
+    return a.bandsave.p;
+}
 
 void eig_batch_alloc(EigBatch &b, const std::vector<int> &sizes, hipStream_t s, int slot) {
     b.slot = g_slot = slot & 1;
@@ -881,7 +893,7 @@ void eig_tridiagonalize(hipStream_t s, EigBatch &b, int phases) {
     b.subspace = false;
     static bool attr0 = false;
     if (!attr0) {
-        SA_HIP_CHECK(hipFuncSetAttribute((const void *)eigvec_kernel,
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)eigvec_kernel<false>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
         SA_HIP_CHECK(hipFuncSetAttribute((const void *)count_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
@@ -900,7 +912,7 @@ void eig_tridiagonalize(hipStream_t s, EigBatch &b, int phases) {
     if (!attr_set) {
         SA_HIP_CHECK(hipFuncSetAttribute((const void *)tridiag_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
-        SA_HIP_CHECK(hipFuncSetAttribute((const void *)eigvec_kernel,
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)eigvec_kernel<false>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
         SA_HIP_CHECK(hipFuncSetAttribute((const void *)count_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
@@ -947,16 +959,26 @@ void eig_vectors(hipStream_t s, EigBatch &b, const int64_t *eoff, const int64_t 
         return;
     }
     const size_t lds = vec_lds_bytes(b.max_n);
-    SA_REQUIRE(lds <= LDS_MAX, "agglomerate too large for the LDS-resident inverse iteration");
     double flops = 0.0;
     for (int i = 0; i < b.count; ++i) flops += 2.0 * (double)b.h_n[i] * b.h_n[i] * b.h_m[i];
+    DBuf<double> gws;
+    if (lds > LDS_MAX) {      // work arrays in global memory
+        SA_REQUIRE(b.max_n < 65536, "agglomerate too large for the inverse iteration's 16-bit block tables");
+        gws.alloc((size_t)b.count * (lds / 8 + 2));
+    }
     profiler().begin(s);
-    hipLaunchKernelGGL(eigvec_kernel, dim3(b.count), dim3(VEC_NT), lds, s, b.n.p, b.moff.p,
-                       b.voff.p, b.W.p, b.d.p, b.e.p, b.tau.p, b.dis.p, b.m.p, b.j0.p, eoff, xoff,
-                       evals, evecs, b.two_stage ? 0 : 1, b.vl, b.vu);
+    if (lds > LDS_MAX)
+        hipLaunchKernelGGL(eigvec_kernel<true>, dim3(b.count), dim3(VEC_NT), 64, s, b.n.p, b.moff.p,
+                           b.voff.p, b.W.p, b.d.p, b.e.p, b.tau.p, b.dis.p, b.m.p, b.j0.p, eoff, xoff,
+                           evals, evecs, b.two_stage ? 0 : 1, b.vl, b.vu, gws.p, (int64_t)(lds / 8 + 2));
+    else
+        hipLaunchKernelGGL(eigvec_kernel<false>, dim3(b.count), dim3(VEC_NT), lds, s, b.n.p, b.moff.p,
+                           b.voff.p, b.W.p, b.d.p, b.e.p, b.tau.p, b.dis.p, b.m.p, b.j0.p, eoff, xoff,
+                           evals, evecs, b.two_stage ? 0 : 1, b.vl, b.vu, (double *)nullptr, (int64_t)0);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "eig_vectors", 0.0, flops);
     if (b.two_stage) eig_backtransform_two_stage(s, b, xoff, evecs);
+    if (gws.p) SA_HIP_CHECK(hipStreamSynchronize(s));     // (the workspace is released on return)
 }
 
 }  // namespace saamge_amd

@@ -581,7 +581,11 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
                                                           double *__restrict__ Gbuf,
                                                           double *__restrict__ trashbuf, int count,
                                                           int tiles, int shift,
-                                                          const int *__restrict__ bws = nullptr) {
+                                                          const int *__restrict__ bws = nullptr,
+                                                          const double *__restrict__ VrowCur = nullptr,
+                                                          const double *__restrict__ ZrowBuf = nullptr) {
+    // (VrowCur / ZrowBuf, TERMS = 3 only: the ROW operands come from these panels instead of Vcur / Zbuf --
+    // the signed factorisation C - theta I = L S L^T updates with (L S) L^T)
     constexpr int SBP = SB + 1;
     constexpr int KC = (RPL == 1) ? S2_KC : 4;   // columns per step (VGPR budget: 2 RPL KC tile values)
     __shared__ double red[4 * SB * SF_ROWS];   // 32 KiB: K-split reduction
@@ -606,6 +610,8 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
     const double *__restrict__ Z = Zbuf + voff[b] * SB + (TERMS == 3 ? 0 : shift * SB);   // rows shifted
     const double *__restrict__ Vc = Vcur + voff[b] * SB + shift * SB;
     const double *__restrict__ Vn = Vnext + voff[b] * SB;
+    const double *__restrict__ Zr = (TERMS == 3 && ZrowBuf) ? ZrowBuf + voff[b] * SB : Z;
+    const double *__restrict__ Vr = (TERMS == 3 && VrowCur) ? VrowCur + voff[b] * SB + shift * SB : Vc;
     double *X = Xbuf + voff[b] * SB;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -626,8 +632,8 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
         const int iac = min(ia, np - 1);
 #pragma unroll
         for (int c = 0; c < SB; ++c) {
-            za[r][c] = (TERMS != 1) ? -Z[(size_t)iac * SB + c] : 0.0;
-            va[r][c] = -Vc[(size_t)iac * SB + c];
+            za[r][c] = (TERMS != 1) ? -Zr[(size_t)iac * SB + c] : 0.0;
+            va[r][c] = -Vr[(size_t)iac * SB + c];
             xa[r][c] = 0.0;
         }
     }
@@ -1726,29 +1732,46 @@ __device__ inline double readlane_f64(double v, int src) {       // src: wave-un
 // the others through readlane (no LDS round trips, no barriers), 1 / sqrt(pivot) by rsq + Newton.
 // Then L goes to Ld once and lane j builds column j of the inverse by forward substitution with
 // the reciprocal pivots.  Returns non-zero when a pivot was not positive.
-__device__ inline int chol16_inverse_wave(double (*Ld)[SB + 1], double (*Li)[SB + 1], int lane) {
+// SIGNED: the block may be indefinite -- A = L S L^T with S = diag(+-1) (LDL^T without pivoting,
+// |pivot|^1/2 folded into L): sg[j] receives the sign of pivot j, the return value is the number
+// of negative pivots, or -1 when a pivot is too small for the count to be trusted (the inertia of
+// C - theta I certifies the number of eigenvalues below theta; a pivot below SS_PIV_TINY means
+// theta sits on an eigenvalue of a leading block to within round-off growth: the caller falls
+// back to the dense path, whose Sturm count has no such restriction).
+constexpr double SS_PIV_TINY = 1e-7;
+template <bool SIGNED>
+__device__ inline int chol16_inverse_wave(double (*Ld)[SB + 1], double (*Li)[SB + 1], int lane, double *sg = nullptr) {
     const int li = lane & (SB - 1);
     double a[SB];
 #pragma unroll
     for (int c = 0; c < SB; ++c) a[c] = Ld[li][c];
-    int isbad = 0;
+    int isbad = 0, nneg = 0;
 #pragma unroll
     for (int j = 0; j < SB; ++j) {
         const double dj = readlane_f64(a[j], j);
-        const bool ok = dj > 0.0;
+        const double ad = SIGNED ? fabs(dj) : dj;
+        const bool ok = SIGNED ? (ad > SS_PIV_TINY) : (dj > 0.0);
         isbad |= !ok;
         double r = 1.0;
         if (ok) {                                   // (wave-uniform)
-            r = __builtin_amdgcn_rsq(dj);
-            r = r * fma(-0.5 * dj * r, r, 1.5);
-            r = r * fma(-0.5 * dj * r, r, 1.5);
+            r = __builtin_amdgcn_rsq(ad);
+            r = r * fma(-0.5 * ad * r, r, 1.5);
+            r = r * fma(-0.5 * ad * r, r, 1.5);
         }
         if (lane == 0) Li[0][j] = r;                // reciprocal pivots: parked in row 0 of Li until the inverse is written
+        double sj = 1.0;
+        if (SIGNED) {
+            sj = (dj < 0.0) ? -1.0 : 1.0;
+            nneg += (dj < 0.0) ? 1 : 0;
+            if (lane == 0) sg[j] = sj;
+            r *= sj;                                // L(i, j) = s_j A(i, j) / |d_j|^1/2, L(j, j) = |d_j|^1/2
+        }
         a[j] *= r;                                  // column j of L on the lanes i >= j (lane j: sqrt(dj))
+        const double ajs = SIGNED ? sj * a[j] : a[j];
 #pragma unroll
         for (int c = j + 1; c < SB; ++c) {
             const double lcj = readlane_f64(a[j], c);
-            a[c] = fma(-a[j], lcj, a[c]);           // meaningful on the lanes i >= c
+            a[c] = fma(-ajs, lcj, a[c]);            // meaningful on the lanes i >= c
         }
     }
     if (lane < SB) {
@@ -1771,19 +1794,26 @@ __device__ inline int chol16_inverse_wave(double (*Ld)[SB + 1], double (*Li)[SB 
 #pragma unroll
         for (int i = 0; i < SB; ++i) Li[i][j] = x[i];
     }
+    if (SIGNED) return isbad ? -1 : nneg;
     return isbad;
 }
 
 // Cholesky of the SB x SB diagonal block at k0 and L21 = A21 L11^-T below it.  L goes to the lower
 // triangle, its transpose to the upper one (the solves then stream columns both ways), and the
 // packed row-major copies V = L21, Z = L21 / 2 feed the trailing update.
-template <int NT>
+// SIGNED: the same walk for the indefinite C - theta I = L S L^T (inertia count of the wide-band
+// matrices): the packed copies are V = L21, Z = L21 S / 2 (so that Z V^T + V Z^T = L21 S L21^T in
+// the next-columns update) and Sout = L21 S (row operands of the trailing update); the matrix keeps
+// only what later panels read (nothing of the factor is written back); neg[b] accumulates the
+// negative pivots, info[b] = 1 marks a pivot too small to trust the count.
+template <int NT, bool SIGNED = false>
 __global__ __launch_bounds__(NT) void chol_panel_kernel(int k0, const int *__restrict__ ns,
                                                          const int64_t *__restrict__ moff,
                                                          const int64_t *__restrict__ voff, double *__restrict__ W,
                                                          double *__restrict__ Vpk, double *__restrict__ Zbuf,
                                                          int *__restrict__ info, const int *__restrict__ bws,
-                                                         int rext) {
+                                                         int rext, double *__restrict__ Sout = nullptr,
+                                                         int *__restrict__ neg = nullptr) {
     __shared__ double Ld[SB][SB + 1];
     const int b = blockIdx.x, n = ns[b];
     if (k0 >= n) return;
@@ -1798,28 +1828,32 @@ __global__ __launch_bounds__(NT) void chol_panel_kernel(int k0, const int *__res
         Ld[i][j] = (i < nb && j <= i) ? A[(size_t)(k0 + j) * n + (k0 + i)] : ((i == j) ? 1.0 : 0.0);
     }
     __syncthreads();
-    // right-looking Cholesky of the block in LDS by ONE wavefront (wave-level synchronisation only;
-    // the other wavefronts wait at a single barrier)
     // Cholesky of the block and its INVERSE by ONE wavefront (the diagonal block is kept as L11^-1,
     // lower part, and its transpose: the solves then apply it as a small matrix product instead of
-    // a serial substitution)
+    // a serial substitution); the other wavefronts wait at a single barrier
     __shared__ int bad;
     __shared__ double Li[SB][SB + 1];
+    __shared__ double sg[SB];
     if (tid < 64) {
-        const int isbad = chol16_inverse_wave(Ld, Li, tid);
-        if (tid == 0) bad = isbad;
+        const int r = chol16_inverse_wave<SIGNED>(Ld, Li, tid, sg);
+        if (tid == 0) bad = r;
     }
     __syncthreads();
-    if (tid == 0 && bad) info[b] = 1;
-    if (tid < SB * SB) {
-        const int i = tid >> 4, j = tid & 15;
-        if (i < nb && j <= i) {
-            A[(size_t)(k0 + j) * n + (k0 + i)] = Li[i][j];
-            A[(size_t)(k0 + i) * n + (k0 + j)] = Li[i][j];
+    if (SIGNED) {
+        if (tid == 0) { if (bad < 0) info[b] = 1; else neg[b] += bad; }
+    } else {
+        if (tid == 0 && bad) info[b] = 1;
+        if (tid < SB * SB) {
+            const int i = tid >> 4, j = tid & 15;
+            if (i < nb && j <= i) {
+                A[(size_t)(k0 + j) * n + (k0 + i)] = Li[i][j];
+                A[(size_t)(k0 + i) * n + (k0 + j)] = Li[i][j];
+            }
         }
     }
     if (nb < SB) return;
     double *Vp = Vpk + voff[b] * SB, *Zp = Zbuf ? Zbuf + voff[b] * SB : nullptr;
+    double *Sp = (SIGNED && Sout) ? Sout + voff[b] * SB : nullptr;
     for (int r = k0 + SB + tid; r < rend; r += NT) {
         double x[SB];
 #pragma unroll
@@ -1832,10 +1866,38 @@ __global__ __launch_bounds__(NT) void chol_panel_kernel(int k0, const int *__res
             double t = 0.0;
 #pragma unroll
             for (int j = 0; j < SB; ++j) t = fma(x[j], Li[c][j], t);
-            A[(size_t)(k0 + c) * n + r] = t;
-            A[(size_t)r * n + (k0 + c)] = t;
-            Vp[pr + c] = t;
-            if (Zp) Zp[pr + c] = 0.5 * t;
+            if (SIGNED) {
+                const double ts = t;                 // = (L21 S)(r, c)
+                t *= sg[c];
+                Vp[pr + c] = t;
+                if (Zp) Zp[pr + c] = 0.5 * ts;
+                if (Sp) Sp[pr + c] = ts;
+            } else {
+                A[(size_t)(k0 + c) * n + r] = t;
+                A[(size_t)r * n + (k0 + c)] = t;
+                Vp[pr + c] = t;
+                if (Zp) Zp[pr + c] = 0.5 * t;
+            }
+        }
+    }
+}
+
+
+// full band |i - j| <= bw of every column, packed (column j of matrix b at soff[b] + j (2 bw + 1)):
+// saved before / restored after the in-place inertia factorisation of the wide-band matrices
+template <bool RESTORE>
+__global__ __launch_bounds__(256) void band_copy_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
+                                                        double *__restrict__ W, const int *__restrict__ bws,
+                                                        const int64_t *__restrict__ soff, double *__restrict__ save) {
+    const int b = blockIdx.x, n = ns[b], bw = bws[b], w2 = 2 * bw + 1;
+    double *A = W + moff[b];
+    double *S = save + soff[b];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int j = blockIdx.y * 4 + wv; j < n; j += 4 * gridDim.y) {
+        const int lo = max(0, j - bw), hi = min(n - 1, j + bw);
+        for (int i = lo + lane; i <= hi; i += 64) {
+            if (RESTORE) A[(size_t)j * n + i] = S[(size_t)j * w2 + (i - j + bw)];
+            else S[(size_t)j * w2 + (i - j + bw)] = A[(size_t)j * n + i];
         }
     }
 }
@@ -1854,12 +1916,17 @@ __global__ __launch_bounds__(NT) void chol_panel_kernel(int k0, const int *__res
 // the resident workgroups of other matrices are what fills the CU.
 constexpr int BC_NT = 256;
 constexpr size_t bc_lds_bytes(int win) {
-    return sizeof(double) * ((size_t)win * (win + 1) + (size_t)SB * (win - SB + 4) + 2 * SB * (SB + 1)) + 64;
+    return sizeof(double) * ((size_t)win * (win + 1) + (size_t)SB * (win - SB + 4) + 2 * SB * (SB + 1) + SB) + 64;
 }
-template <int BC_WIN>
+// INERTIA = true: nothing is written back.  The same window walk factors C - shift I = L S L^T
+// (S = diag(+-1), no pivoting) and info[b] receives the number of negative pivots = the number of
+// eigenvalues of C below `shift` (Sylvester), or -1 when a pivot was too small to trust the count.
+// This is what makes the few-eigenpairs path's count as rigorous as dsygvx's bisection
+// (dstebz Sturm counts, amg/src/xpacks.cpp:226-268).
+template <int BC_WIN, bool INERTIA = false>
 __global__ __launch_bounds__(BC_NT) void chol_band_lds_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
                                                               double *__restrict__ W, const int *__restrict__ bws,
-                                                              int *__restrict__ info) {
+                                                              int *__restrict__ info, double shift = 0.0) {
     constexpr int BC_P = BC_WIN + 1, BC_MAXBW = BC_WIN - SB;
     constexpr int BC_PT = BC_MAXBW + 4;      // pitch of the transposed panel (rows padded to the 4-row tiles)
     extern __shared__ __align__(16) double bc_lds[];
@@ -1868,6 +1935,7 @@ __global__ __launch_bounds__(BC_NT) void chol_band_lds_kernel(const int *__restr
     double (*Ld)[SB + 1] = (double (*)[SB + 1])(Lp + SB * BC_PT);
     double (*Li)[SB + 1] = Ld + SB;
     int *bad = (int *)(Li + SB);
+    double *sg = (double *)(bad + 2);                    // INERTIA: signs of the current block's pivots
     const int b = blockIdx.x, n = ns[b], bw = bws[b];
     if (bw > BC_MAXBW) return;                           // (the host only launches this when every matrix fits)
     double *A = W + moff[b];
@@ -1877,10 +1945,10 @@ __global__ __launch_bounds__(BC_NT) void chol_band_lds_kernel(const int *__restr
         for (int i = i0 + w; i < min(i1, n); i += BC_NT / 64)
             for (int jj = lane; jj <= bw; jj += 64) {
                 const int j = i - bw + jj;
-                if (j >= 0) sl(i, j) = A[(size_t)i * n + j];
+                if (j >= 0) sl(i, j) = A[(size_t)i * n + j] - ((INERTIA && j == i) ? shift : 0.0);
             }
     };
-    if (tid == 0) *bad = 0;
+    if (tid == 0) { bad[0] = 0; bad[1] = 0; }
     fetch_rows(0, SB + bw);
     __syncthreads();
     for (int k0 = 0; k0 < n; k0 += SB) {
@@ -1891,11 +1959,12 @@ __global__ __launch_bounds__(BC_NT) void chol_band_lds_kernel(const int *__restr
         }
         __syncthreads();
         if (tid < 64) {        // Cholesky of the block and its inverse by one wavefront
-            const int isbad = chol16_inverse_wave(Ld, Li, tid);
-            if (tid == 0 && isbad) *bad = 1;
+            const int r = chol16_inverse_wave<INERTIA>(Ld, Li, tid, sg);
+            if (INERTIA) { if (tid == 0) { if (r < 0) *bad = 1; else bad[1] += r; } }
+            else if (tid == 0 && r) *bad = 1;
         }
         __syncthreads();
-        if (tid < SB * SB) {
+        if (!INERTIA && tid < SB * SB) {
             const int i = tid >> 4, j = tid & 15;
             if (i < nb && j <= i) {
                 A[(size_t)(k0 + j) * n + (k0 + i)] = Li[i][j];
@@ -1912,7 +1981,7 @@ __global__ __launch_bounds__(BC_NT) void chol_band_lds_kernel(const int *__restr
         for (int u = 0; u < NPF; ++u) {
             const int idx = tid + u * BC_NT, ii = idx / bw1, jj = idx - ii * bw1;
             const int i = f0 + ii, j = i - bw + jj;
-            pf[u] = (ii < SB && i < n && j >= 0) ? A[(size_t)i * n + j] : 0.0;
+            pf[u] = (ii < SB && i < n && j >= 0) ? A[(size_t)i * n + j] - ((INERTIA && j == i) ? shift : 0.0) : 0.0;
         }
         if (tid >= m && tid < m + 4) {               // the 4-row tiles read up to 3 rows past the panel
 #pragma unroll
@@ -1928,9 +1997,12 @@ __global__ __launch_bounds__(BC_NT) void chol_band_lds_kernel(const int *__restr
                 double t = 0.0;
 #pragma unroll
                 for (int j = 0; j <= c; ++j) t = fma(x[j], Li[c][j], t);
+                if (INERTIA) t *= sg[c];              // L21 = A21 L11^-T S
                 Lp[c * BC_PT + tid] = t;
-                A[(size_t)(k0 + c) * n + r] = t;
-                A[(size_t)r * n + (k0 + c)] = t;
+                if (!INERTIA) {
+                    A[(size_t)(k0 + c) * n + r] = t;
+                    A[(size_t)r * n + (k0 + c)] = t;
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -1952,7 +2024,13 @@ __global__ __launch_bounds__(BC_NT) void chol_band_lds_kernel(const int *__restr
             for (int c = 0; c < SB; ++c) {        // (not fully unrolled: the scheduler would hoist all 64 operand loads, 300 VGPRs)
                 const double2 i01 = *(const double2 *)(pi + c * BC_PT), i23 = *(const double2 *)(pi + c * BC_PT + 2);
                 const double2 j01 = *(const double2 *)(pj + c * BC_PT), j23 = *(const double2 *)(pj + c * BC_PT + 2);
-                const double ai[4] = {i01.x, i01.y, i23.x, i23.y}, aj[4] = {j01.x, j01.y, j23.x, j23.y};
+                double ai[4] = {i01.x, i01.y, i23.x, i23.y};
+                const double aj[4] = {j01.x, j01.y, j23.x, j23.y};
+                if (INERTIA) {                         // window -= L21 S L21^T
+                    const double sc = sg[c];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) ai[a] *= sc;
+                }
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -1973,7 +2051,8 @@ __global__ __launch_bounds__(BC_NT) void chol_band_lds_kernel(const int *__restr
         }
         __syncthreads();
     }
-    if (tid == 0 && *bad) info[b] = 1;
+    if (INERTIA) { if (tid == 0) info[b] = *bad ? -1 : bad[1]; }
+    else if (tid == 0 && *bad) info[b] = 1;
 }
 
 // Start block: column 0 = D^1/2 1 (the exact null vector of C for an agglomerate without essential
@@ -2373,7 +2452,7 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
                 bool ok = true;
                 for (int q = 0; q < max(k, 1); ++q) ok = ok && (2.5 * mu_old[q] * sqrt(res2[q]) <= SS_TOL);
                 if (k >= 1) ok = ok && (2.5 * mu_old[k] * sqrt(res2[k]) < 0.5 * (sigma + mu_old[k] - vu));
-                if (ok) st |= 1 | (max(k, 1) << 8);
+                if (ok) st |= 1 | (k << 4) | (max(k, 1) << 8);      // bits 4..7: Ritz values inside the window
             }
         }
         sh_st = st;
@@ -2551,9 +2630,9 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
     b.h_goff.assign((size_t)b.count + 1, 0);
     b.h_roff.assign((size_t)b.count + 1, 0);
     eig_batch_two_stage_buffers(b, 1, false, s);
+    SA_REQUIRE(b.has_window, "few-eigenpairs path: the eigenvalue window must be set before the factorisation");
     DBuf<int> info((size_t)b.count);
     info.zero(s);
-    hipLaunchKernelGGL(ss_shift_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, SS_SIGMA);
     // banded factorisation (SAAMGE_AMD_SS_BAND=0: treat every matrix as full)
     const bool use_band = eig_ss_band_enabled();
     const int *bws = nullptr;
@@ -2574,6 +2653,10 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
         bwmax = 0;
         for (int v : b.h_bw) bwmax = std::max(bwmax, v);
         bws = b.bw.p;
+    } else {                      // full matrices: bandwidth n - 1 (the inertia pass wants explicit widths)
+        std::vector<int> full((size_t)b.count);
+        for (int i = 0; i < b.count; ++i) full[i] = b.h_n[i] - 1;
+        b.bw.from_host(full, s);
     }
     b.ss_bwmax = bwmax;
     if (std::getenv("SAAMGE_AMD_SS_DEBUG")) {
@@ -2582,74 +2665,139 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
         std::fprintf(stderr, "subspace: %d matrices, n max %d, half bandwidth %d .. %d\n", b.count, nmax, b.h_bw.empty() ? nmax : bwmin, bwmax);
     }
     static const bool use_lds = [] { const char *e = std::getenv("SAAMGE_AMD_SS_BAND_LDS"); return !(e && e[0] == '0'); }();
-    if (bws && use_lds && bwmax <= 128 - SB) {       // the band fits the LDS window: one launch
-        double cb = 0.0;      // the band read once, the factor written to both triangles
-        for (size_t i = 0; i < b.h_n.size(); ++i) cb += 3.0 * 8.0 * (double)b.h_n[i] * (std::min(b.h_bw[i], b.h_n[i] - 1) + 1);
+    const bool lds_path = bws && use_lds && bwmax <= 128 - SB;      // the band fits the LDS window: one launch
+    double cb = 0.0;      // the band read once, the factor written to both triangles
+    if (lds_path)
+        for (size_t i = 0; i < b.h_n.size(); ++i) cb += 8.0 * (double)b.h_n[i] * (std::min(b.h_bw[i], b.h_n[i] - 1) + 1);
+    const int cnt8 = 8 * div_up(b.count, 8);
+    const bool prof = profiler().enabled;
+    // Blocked right-looking factorisation of every matrix in place, two panels per pass over the trailing
+    // matrix: panel k, its update of the next SB columns only, panel k + 1, then A22(2 SB:, 2 SB:) -=
+    // L_k L_k^T + L_{k+1} L_{k+1}^T in one read + write of the lower tiles.  sgn: C - theta I = L S L^T
+    // (inertia count; the factor is not kept), neg receives the negative pivots.
+    auto factor_generic = [&](bool sgn, int *neg) {
+        const int *gbw = bws ? bws : (sgn ? b.bw.p : nullptr);
+        auto panel = [&](int k0, double *Vout, double *Zout, int rext, double *Sout) {
+            if (prof) profiler().begin(s);
+            const bool big = std::min(nmax, bwmax + 2 * SB) > 768;
+            if (sgn) {
+                if (big) hipLaunchKernelGGL((chol_panel_kernel<1024, true>), dim3(b.count), dim3(1024), 0, s, k0, b.n.p, b.moff.p,
+                                            b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, Sout, neg);
+                else hipLaunchKernelGGL((chol_panel_kernel<256, true>), dim3(b.count), dim3(256), 0, s, k0, b.n.p, b.moff.p,
+                                        b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, Sout, neg);
+            } else {
+                if (big) hipLaunchKernelGGL((chol_panel_kernel<1024, false>), dim3(b.count), dim3(1024), 0, s, k0, b.n.p, b.moff.p,
+                                            b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, (double *)nullptr, (int *)nullptr);
+                else hipLaunchKernelGGL((chol_panel_kernel<256, false>), dim3(b.count), dim3(256), 0, s, k0, b.n.p, b.moff.p,
+                                        b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, (double *)nullptr, (int *)nullptr);
+            }
+            if (prof) profiler().end(s, sgn ? "eig_ss_inertia_panel" : "eig_ss_panel", 0.0, 0.0);
+        };
+        const double *vrow = sgn ? b.Xbuf.p : nullptr, *zrow = sgn ? b.Tfac.p : nullptr;
+        for (int k0 = 0; k0 < nmax; k0 += 2 * SB) {
+            panel(k0, b.Vpk.p, b.Zbuf.p, SB, b.Xbuf.p);
+            const int np1f = nmax - k0 - SB;         // order of the trailing matrix after panel k
+            if (np1f < 1) break;
+            const int np1 = std::min(np1f, bwmax);   // ... of its part inside the band
+            if (np1 >= 1) {
+                if (prof) profiler().begin(s);
+                hipLaunchKernelGGL(sbr_panel_update_kernel, dim3(cnt8 * div_up(np1, 256)), dim3(256), 0, s, k0, b.n.p, b.moff.p,
+                                   b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.count, div_up(np1, 256), 1, gbw);
+                if (prof) profiler().end(s, sgn ? "eig_ss_inertia_panel" : "eig_ss_panel", 0.0, 0.0);
+            }
+            panel(k0 + SB, b.Vpk2.p, nullptr, 0, b.Tfac.p);
+            const int np = std::min(np1f - SB, bwmax);    // ... after panel k + 1
+            if (np >= 1) {
+                double ub = 0.0;
+                if (prof) {      // lower tiles of the trailing matrices (inside the band), read and written once
+                    for (size_t i = 0; i < b.h_n.size(); ++i) {
+                        double q = (double)b.h_n[i] - k0 - 2 * SB;
+                        if (!b.h_bw.empty()) q = std::min(q, (double)b.h_bw[i]);
+                        if (q >= 1.0) ub += 8.0 * q * q;
+                    }
+                    profiler().begin(s);
+                }
+                if (np > 192)
+                    hipLaunchKernelGGL((sbr_fused_kernel<false, 2, 3>), dim3(cnt8 * div_up(np, 2 * SF_ROWS)), dim3(S2_NT), 0, s, k0,
+                                       b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Vpk2.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
+                                       b.Gbuf.p, b.trash.p, b.count, div_up(np, 2 * SF_ROWS), SB, gbw, vrow, zrow);
+                else
+                    hipLaunchKernelGGL((sbr_fused_kernel<false, 1, 3>), dim3(cnt8 * div_up(np, SF_ROWS)), dim3(S2_NT), 0, s, k0,
+                                       b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Vpk2.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
+                                       b.Gbuf.p, b.trash.p, b.count, div_up(np, SF_ROWS), SB, gbw, vrow, zrow);
+                if (prof) profiler().end(s, sgn ? "eig_ss_inertia_update" : (np > 192 ? "eig_ss_update" : "eig_ss_update1"), ub, 0.0);
+            }
+        }
+        SA_HIP_CHECK(hipGetLastError());
+    };
+
+    // ---- certified count: inertia of C - vu I, before the matrices are shifted and overwritten ----
+    // (dsygvx counts by bisection, amg/src/xpacks.cpp:226-268; a subspace iteration alone cannot prove
+    // that no eigenvalue below vu is missing from its block)
+    static const bool certify = [] { const char *e = std::getenv("SAAMGE_AMD_SS_CERTIFY"); return !(e && e[0] == '0'); }();
+    b.h_inertia.clear();
+    if (certify) {
+        DBuf<int> neg((size_t)b.count);
+        neg.zero(s);
+        if (lds_path) {
+            profiler().begin(s);
+            auto go = [&](auto kern, int win) {
+                SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bc_lds_bytes(win)));
+                hipLaunchKernelGGL(kern, dim3(b.count), dim3(BC_NT), bc_lds_bytes(win), s, b.n.p, b.moff.p, b.W.p, bws, neg.p,
+                                   b.window_vu);
+            };
+            if (bwmax <= 68 - SB) go(chol_band_lds_kernel<68, true>, 68);
+            else if (bwmax <= 80 - SB) go(chol_band_lds_kernel<80, true>, 80);
+            else go(chol_band_lds_kernel<128, true>, 128);
+            SA_HIP_CHECK(hipGetLastError());
+            profiler().end(s, "eig_ss_inertia_lds", cb, 0.0);
+            auto h = neg.to_host(s);
+            b.h_inertia.assign(h.begin(), h.end());
+        } else {
+            // in place on the matrices: the band is saved, C - vu I factored, the band restored
+            if (!prof) profiler().begin(s);
+            std::vector<int64_t> soff((size_t)b.count + 1, 0);
+            for (int i = 0; i < b.count; ++i) {
+                const int64_t w = std::min(b.h_bw.empty() ? b.h_n[i] - 1 : b.h_bw[i], b.h_n[i] - 1);
+                soff[(size_t)i + 1] = soff[i] + (int64_t)b.h_n[i] * (2 * w + 1);
+            }
+            DBuf<int64_t> d_soff;
+            d_soff.from_host(soff, s);
+            double *save = eig_arena_bandsave(b, (size_t)soff[b.count] + 1);
+            const int ny = std::max(1, std::min(64, 8192 / std::max(1, b.count)));
+            hipLaunchKernelGGL(band_copy_kernel<false>, dim3(b.count, ny), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, b.bw.p, d_soff.p, save);
+            hipLaunchKernelGGL(ss_shift_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, b.window_vu);
+            factor_generic(true, neg.p);
+            hipLaunchKernelGGL(band_copy_kernel<true>, dim3(b.count, ny), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, b.bw.p, d_soff.p, save);
+            SA_HIP_CHECK(hipGetLastError());
+            if (!prof) profiler().end(s, "eig_ss_inertia", 0.0, 0.0);
+            auto h = neg.to_host(s);
+            auto hi = info.to_host(s);
+            b.h_inertia.assign(h.begin(), h.end());
+            for (int i = 0; i < b.count; ++i) if (hi[i]) b.h_inertia[i] = -1;
+            info.zero(s);
+        }
+    }
+
+    // ---- C - sigma I = L L^T ----
+    hipLaunchKernelGGL(ss_shift_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, SS_SIGMA);
+    if (lds_path) {
         profiler().begin(s);
         auto go = [&](auto kern, int win) {
             SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bc_lds_bytes(win)));
-            hipLaunchKernelGGL(kern, dim3(b.count), dim3(BC_NT), bc_lds_bytes(win), s, b.n.p, b.moff.p, b.W.p, bws, info.p);
+            hipLaunchKernelGGL(kern, dim3(b.count), dim3(BC_NT), bc_lds_bytes(win), s, b.n.p, b.moff.p, b.W.p, bws, info.p, 0.0);
         };
-        if (bwmax <= 68 - SB) go(chol_band_lds_kernel<68>, 68);
-        else if (bwmax <= 80 - SB) go(chol_band_lds_kernel<80>, 80);
-        else go(chol_band_lds_kernel<128>, 128);
+        if (bwmax <= 68 - SB) go(chol_band_lds_kernel<68, false>, 68);
+        else if (bwmax <= 80 - SB) go(chol_band_lds_kernel<80, false>, 80);
+        else go(chol_band_lds_kernel<128, false>, 128);
         SA_HIP_CHECK(hipGetLastError());
-        profiler().end(s, "eig_ss_chol_lds", cb, 0.0);
+        profiler().end(s, "eig_ss_chol_lds", 3.0 * cb, 0.0);
         auto h = info.to_host(s);
         for (int v : h) if (v) return false;
         return true;
     }
-    const int cnt8 = 8 * div_up(b.count, 8);
-    const bool prof = profiler().enabled;
     if (!prof) profiler().begin(s);
-    auto panel = [&](int k0, double *Vout, double *Zout, int rext) {
-        if (prof) profiler().begin(s);
-        if (std::min(nmax, bwmax + 2 * SB) > 768)
-            hipLaunchKernelGGL((chol_panel_kernel<1024>), dim3(b.count), dim3(1024), 0, s, k0, b.n.p, b.moff.p, b.voff.p,
-                               b.W.p, Vout, Zout, info.p, bws, rext);
-        else
-            hipLaunchKernelGGL((chol_panel_kernel<256>), dim3(b.count), dim3(256), 0, s, k0, b.n.p, b.moff.p, b.voff.p,
-                               b.W.p, Vout, Zout, info.p, bws, rext);
-        if (prof) profiler().end(s, "eig_ss_panel", 0.0, 0.0);
-    };
-    // Two panels per pass over the trailing matrix: panel k, its update of the next SB columns only,
-    // panel k + 1, then A22(2 SB:, 2 SB:) -= L_k L_k^T + L_{k+1} L_{k+1}^T in one read + write of the
-    // lower tiles.
-    for (int k0 = 0; k0 < nmax; k0 += 2 * SB) {
-        panel(k0, b.Vpk.p, b.Zbuf.p, SB);
-        const int np1f = nmax - k0 - SB;         // order of the trailing matrix after panel k
-        if (np1f < 1) break;
-        const int np1 = std::min(np1f, bwmax);   // ... of its part inside the band
-        if (np1 >= 1) {
-            if (prof) profiler().begin(s);
-            hipLaunchKernelGGL(sbr_panel_update_kernel, dim3(cnt8 * div_up(np1, 256)), dim3(256), 0, s, k0, b.n.p, b.moff.p,
-                               b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.count, div_up(np1, 256), 1, bws);
-            if (prof) profiler().end(s, "eig_ss_panel", 0.0, 0.0);
-        }
-        panel(k0 + SB, b.Vpk2.p, nullptr, 0);
-        const int np = std::min(np1f - SB, bwmax);    // ... after panel k + 1
-        if (np >= 1) {
-            double ub = 0.0;
-            if (prof) {      // lower tiles of the trailing matrices (inside the band), read and written once
-                for (size_t i = 0; i < b.h_n.size(); ++i) {
-                    double q = (double)b.h_n[i] - k0 - 2 * SB;
-                    if (!b.h_bw.empty()) q = std::min(q, (double)b.h_bw[i]);
-                    if (q >= 1.0) ub += 8.0 * q * q;
-                }
-                profiler().begin(s);
-            }
-            if (np > 192)
-                hipLaunchKernelGGL((sbr_fused_kernel<false, 2, 3>), dim3(cnt8 * div_up(np, 2 * SF_ROWS)), dim3(S2_NT), 0, s, k0,
-                                   b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Vpk2.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
-                                   b.Gbuf.p, b.trash.p, b.count, div_up(np, 2 * SF_ROWS), SB, bws);
-            else
-                hipLaunchKernelGGL((sbr_fused_kernel<false, 1, 3>), dim3(cnt8 * div_up(np, SF_ROWS)), dim3(S2_NT), 0, s, k0,
-                                   b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Vpk2.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
-                                   b.Gbuf.p, b.trash.p, b.count, div_up(np, SF_ROWS), SB, bws);
-            if (prof) profiler().end(s, np > 192 ? "eig_ss_update" : "eig_ss_update1", ub, 0.0);
-        }
-    }
-    SA_HIP_CHECK(hipGetLastError());
+    factor_generic(false, nullptr);
     if (!prof) profiler().end(s, "eig_ss_cholesky", 0.0, 0.0);
     auto h = info.to_host(s);
     for (int v : h) if (v) return false;
@@ -2726,6 +2874,24 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         // (SAAMGE_AMD_SS_STRICT: the tests of this path must not pass on the dense fallback)
         SA_REQUIRE(!std::getenv("SAAMGE_AMD_SS_STRICT"), "few-eigenpairs path gave up on a batch (strict mode)");
         return false;
+    }
+    // certification: the number of Ritz values inside the window must be the number of eigenvalues
+    // below vu (inertia of C - vu I); anything else sends the batch to the dense path
+    if (!b.h_inertia.empty()) {
+        int bad = 0, unsure = 0;
+        for (int i = 0; i < b.count; ++i) {
+            const int k = (hstate[i] >> 4) & 15;
+            if (b.h_inertia[i] < 0) ++unsure;
+            else if (b.h_inertia[i] != k) ++bad;
+        }
+        static const bool dbg = std::getenv("SAAMGE_AMD_SS_DEBUG") != nullptr;
+        if (dbg || bad || unsure)
+            std::fprintf(stderr, "saamge_amd: few-eigenpairs batch of %d: %d counts contradicted by the inertia, %d uncertified\n",
+                         b.count, bad, unsure);
+        if (bad || unsure) {
+            SA_REQUIRE(!std::getenv("SAAMGE_AMD_SS_STRICT"), "few-eigenpairs path: count not certified (strict mode)");
+            return false;
+        }
     }
     b.h_m.assign((size_t)b.count, 1);
     for (int i = 0; i < b.count; ++i) b.h_m[i] = hstate[i] >> 8;

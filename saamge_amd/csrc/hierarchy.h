@@ -50,6 +50,7 @@ struct Params {                 // MultilevelParameters (amg/inc/ml.hpp:59-114)
     double smooth_drop_tol = 0.0; // |entries| <= tol of the smoothed P are dropped (AltThreshold)
     int do_aggregates = 0;        // aggregates with arbitration instead of MISes on the last coarsening
     int algebraic = 0;            // element-free mode (tg_produce_data_algebraic): elements = dofs
+    int eigensolver = 0;          // 0 few-eigenpairs path (certified count, dense fallback), 1 dense path only
 };
 
 struct NextPrep {               // host half of the next level's inputs (prepare_next_host)
@@ -105,6 +106,7 @@ struct KernelTiming { double setup_ms = 0, solve_ms = 0; };
 struct Hierarchy {              // ml_data_t
     Params params;
     hipStream_t stream = 0;
+    int device = 0;             // the GPU this hierarchy lives on (current device of the creating thread)
     std::vector<std::unique_ptr<Level>> levels;
     // coarsest solver
     int coarse_kind = 2;        // 1 dense Cholesky, 2 inner PCG

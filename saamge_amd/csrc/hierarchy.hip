@@ -187,11 +187,12 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         SA_HIP_CHECK(hipStreamSynchronize(s));
     }
     // (the tables go to the device from the same thread, on a side stream, while the eigensolver runs)
-    static hipStream_t mis_stream = nullptr;
-    if (!mis_stream) SA_HIP_CHECK(hipStreamCreateWithFlags(&mis_stream, hipStreamNonBlocking));
+    hipStream_t mis_stream = side_stream(0);
+    const int dev = current_device();
     std::exception_ptr mis_err;
     std::thread mis_thread([&]() {
         try {
+            adopt_device(dev);   // the worker allocates and copies: same GPU as the caller
             build_relations_mis(L.rel, aggregates ? &aggA : nullptr);
             upload_relations_mis(L.drel, L.rel, mis_stream);
             SA_HIP_CHECK(hipStreamSynchronize(mis_stream));
@@ -243,38 +244,17 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     L.ae_begin = ae_begin;
     int64_t row0 = 0;
     for (int p = 0; p < ae_lo; ++p) row0 += sizes[p];
-    // Optional chunk pipeline (SAAMGE_AMD_PIPELINE=1): dense -> band of chunk i on stream A beside
-    // the bulge chasing / Sturm counts / inverse iteration / back-transformation of chunk i-1 on
-    // stream B, two persistent workspaces alternating; the streams are internal and non-blocking
-    // (the caller's stream may be the null stream, which would serialise them).  Measured on
-    // MI355X: no gain (256^3: 3.48 s vs 3.29 s sequential, 128^3: equal) -- the two kernel families
-    // do not co-schedule profitably and the smaller chunks cost more than the overlap returns --
-    // so it is off by default.
-    static hipStream_t sA = nullptr, sB = nullptr;
-    static hipEvent_t ev_band[2] = {nullptr, nullptr};
-    static const bool want_pipe = std::getenv("SAAMGE_AMD_PIPELINE") != nullptr;
-    const bool pipelined = want_pipe && eig_uses_two_stage() && !profiler().enabled && !tm.on;
-    if (pipelined && !sA) {
-        SA_HIP_CHECK(hipStreamCreateWithFlags(&sA, hipStreamNonBlocking));
-        SA_HIP_CHECK(hipStreamCreateWithFlags(&sB, hipStreamNonBlocking));
-        SA_HIP_CHECK(hipEventCreateWithFlags(&ev_band[0], hipEventDisableTiming));
-        SA_HIP_CHECK(hipEventCreateWithFlags(&ev_band[1], hipEventDisableTiming));
-    }
-    hipStream_t qa = pipelined ? sA : s, qb = pipelined ? sB : s;
+    // (a two-stream pipeline over the chunks -- band reduction of chunk i beside the chase of chunk
+    // i-1 -- was measured without gain on MI355X, 256^3: 3.48 s vs 3.29 s, and removed)
+    hipStream_t qa = s, qb = s;
     SA_HIP_CHECK(hipStreamSynchronize(s));
-    size_t chunk_bytes = P.workspace_bytes;
-    if (pipelined) {   // at least ~4 chunks when there is enough work to overlap
-        size_t total = 0;
-        for (int p = ae_lo; p < ae_hi; ++p) total += eig_workspace_bytes(sizes[p]);
-        if (total > ((size_t)4 << 30)) chunk_bytes = std::min(chunk_bytes, std::max(total / 4 + 1, (size_t)2 << 30));
-    }
+    const size_t chunk_bytes = P.workspace_bytes;
     EigBatch batches[2];
     int pend_ae0[2] = {0, 0}, pend_cnt[2] = {0, 0};
     int64_t pend_row0[2] = {0, 0};
     auto post = [&](int slot) {   // band -> tridiagonal, counts, eigenvectors of the chunk in `slot`
         EigBatch &batch = batches[slot];
         const int ae0 = pend_ae0[slot], cnt = pend_cnt[slot];
-        if (pipelined) SA_HIP_CHECK(hipStreamWaitEvent(qb, ev_band[slot], 0));
         eig_tridiagonalize(qb, batch, 2);
         eig_count(qb, batch, -1.0, L.theta);
         if (batch.ss_failed) {   // few-eigenpairs path gave up on this chunk: dense path on re-assembled matrices
@@ -318,11 +298,12 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         EigBatch &batch = batches[slot];
         batch = EigBatch();
         eig_batch_alloc(batch, std::vector<int>(sizes.begin() + ae0, sizes.begin() + ae0 + cnt), qa, slot);
+        batch.dense_only = P.eigensolver == 1;
+        batch.set_window(L.theta);
         const RowsSpan span{(int64_t)L.rel.AE_to_dof.I[ae0], (int64_t)L.rel.AE_to_dof.I[nparts]};
         ae_build(qa, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch, true,
                  P.keep_debug ? L.ae_D.p + row0 : nullptr, keep_rows ? &span : nullptr);
         eig_tridiagonalize(qa, batch, 1);
-        if (pipelined) SA_HIP_CHECK(hipEventRecord(ev_band[slot], qa));
         pend_ae0[slot] = ae0;
         pend_cnt[slot] = cnt;
         pend_row0[slot] = row0;
@@ -332,10 +313,6 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         ae0 += cnt;
     }
     if (prev >= 0) post(prev);
-    if (pipelined) {
-        SA_HIP_CHECK(hipStreamSynchronize(qa));
-        SA_HIP_CHECK(hipStreamSynchronize(qb));
-    }
     tm.lap("local eigenproblems", lev);
     if (world > 1) {   // exchange the number of eigenvectors per AE
         DBuf<int> d_m;
@@ -460,16 +437,18 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     std::thread prep_thread;
     struct PrepJoiner { std::thread &t; ~PrepJoiner() { if (t.joinable()) t.join(); } } prep_joiner{prep_thread};
     if (lev + 1 < P.num_coarsenings && P.nu_pro[lev] == 0) {
-        static hipStream_t side = nullptr;
-        if (!side) SA_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        hipStream_t side = side_stream(1);
         SA_HIP_CHECK(hipStreamSynchronize(s));       // P is complete
         const int *prp = L.P.rowptr.p;
         const double *pvl = L.P.val.p;
         const int pnr = L.P.nrows;
         const int64_t pnz = L.P.nnz;
         hipStream_t sd = side;
-        prep_thread = std::thread([&L, &prep_err, prp, pvl, pnr, pnz, sd]() {
-            try { prepare_next_host(L, prp, pvl, pnr, pnz, sd, L.next_prep); } catch (...) { prep_err = std::current_exception(); }
+        prep_thread = std::thread([&L, &prep_err, prp, pvl, pnr, pnz, sd, dev]() {
+            try {
+                adopt_device(dev);
+                prepare_next_host(L, prp, pvl, pnr, pnz, sd, L.next_prep);
+            } catch (...) { prep_err = std::current_exception(); }
         });
     }
     level_galerkin(H, lev, true);
@@ -548,10 +527,12 @@ static void prepare_next_host(const Level &L, const int *p_rowptr_dev, const dou
             }
             return run;
         };
+        const int dev = current_device();
         for (int pass = 0; pass < 2; ++pass) {
             std::vector<std::thread> th;
             for (int t = 0; t < T; ++t)
                 th.emplace_back([&, t, pass]() {
+                    (void)hipSetDevice(dev);
                     std::vector<int> stamp((size_t)e2d.ncols, -1);
                     const int eb = (int)((int64_t)nparts * t / T), ee = (int)((int64_t)nparts * (t + 1) / T);
                     for (int e = eb; e < ee; ++e) {
@@ -978,6 +959,7 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
     Hierarchy &H = *Hp;
     H.params = p;
     H.stream = stream;
+    H.device = current_device();
     H.own_e2d = std::move(iota_e2d);
     hipStream_t s = stream;
     H.scal.alloc(8);

@@ -47,7 +47,7 @@ void *pinned_alloc(size_t bytes) {
         }
     }
     void *p = nullptr;
-    if (hipHostMalloc(&p, c, hipHostMallocDefault) != hipSuccess || !p) {
+    if (hipHostMalloc(&p, c, hipHostMallocPortable) != hipSuccess || !p) {
         (void)hipGetLastError();
         throw std::bad_alloc();
     }
@@ -91,11 +91,28 @@ static void parallel_for(int64_t n, const std::function<void(int64_t, int64_t, i
         return;
     }
     std::vector<std::thread> th;
+    const int dev = current_device();   // pinned allocations inside fn: see adopt_device
     for (int t = 0; t < T; ++t) {
         const int64_t b = n * t / T, e = n * (t + 1) / T;
-        th.emplace_back([=, &fn]() { fn(b, e, t); });
+        th.emplace_back([=, &fn]() {
+            (void)hipSetDevice(dev);
+            fn(b, e, t);
+        });
     }
     for (auto &x : th) x.join();
+}
+
+hipStream_t side_stream(int slot) {
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, hipStream_t> streams;
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = streams.find(std::make_pair(dev, slot));
+    if (it != streams.end()) return it->second;
+    hipStream_t s = nullptr;
+    SA_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    streams[std::make_pair(dev, slot)] = s;
+    return s;
 }
 
 Table table_transpose(const Table &T) {

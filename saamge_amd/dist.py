@@ -15,6 +15,16 @@ library's device buffers, enqueued on the library's stream)."""
 import os
 
 
+def _fail_fast(what, e):
+    """A collective callback failed on this rank: the C side would throw here while the peers block in the
+    next collective.  End the process instead, so that the launcher sees a non-zero exit and the peers'
+    collectives time out / abort."""
+    import sys
+    print("saamge_amd %s callback failed on rank %s: %r -- aborting this rank" % (what, os.environ.get("RANK", "0"), e),
+          file=sys.stderr, flush=True)
+    os._exit(17)
+
+
 class Group(object):
     def __init__(self, backend=None, device=None, host_buffers=False):
         self.host_buffers = bool(host_buffers)
@@ -26,7 +36,9 @@ class Group(object):
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            kw = {}
+            import datetime
+            # (a rank that dies inside a collective must not leave its peers waiting forever)
+            kw = {"timeout": datetime.timedelta(seconds=int(os.environ.get("SAAMGE_AMD_DIST_TIMEOUT", "600")))}
             if backend == "nccl" and device is not None:
                 import torch
                 kw["device_id"] = torch.device(device)
@@ -109,8 +121,7 @@ class Group(object):
                     torch.cuda.synchronize()
                 return 0
             except Exception as e:  # never let an exception cross the C boundary
-                import sys
-                print("saamge_amd allgather callback failed: %r" % (e,), file=sys.stderr)
+                _fail_fast("allgather", e)
                 return 4
 
         return capi.ALLGATHER_FN(cb)
@@ -170,7 +181,7 @@ class Group(object):
                 dist.all_reduce(t)
                 return memcpy(buf, t.data_ptr(), 8 * count)
             except Exception as e:
-                print("saamge_amd allreduce callback failed: %r" % (e,), file=sys.stderr)
+                _fail_fast("allreduce", e)
                 return 4
 
         plans = {}   # RCCL: (send ptr, recv ptr, sizes) -> prepared send/recv list (the library reuses its buffers)
@@ -178,11 +189,11 @@ class Group(object):
         def alltoallv(ctx, send, soff, recv, roff):
             try:
                 if use_cuda:
-                    key = (int(send or 0), int(recv or 0), int(soff[world]), int(roff[world]))
+                    so = tuple(int(soff[r]) for r in range(world + 1))
+                    ro = tuple(int(roff[r]) for r in range(world + 1))
+                    key = (int(send or 0), int(recv or 0), so, ro)     # (the full per-peer layout, not only the totals)
                     ops = plans.get(key)
                     if ops is None:
-                        so = [int(soff[r]) for r in range(world + 1)]
-                        ro = [int(roff[r]) for r in range(world + 1)]
                         st = self._wrap(send, so[world], torch.uint8) if so[world] else None
                         rt = self._wrap(recv, ro[world], torch.uint8) if ro[world] else None
                         ops = []
@@ -232,7 +243,7 @@ class Group(object):
                     return memcpy(recv, rt.data_ptr(), ro[world])
                 return 0
             except Exception as e:
-                print("saamge_amd alltoallv callback failed: %r" % (e,), file=sys.stderr)
+                _fail_fast("alltoallv", e)
                 return 4
 
         return capi.ALLREDUCE_FN(allreduce), capi.ALLTOALLV_FN(alltoallv)

@@ -316,6 +316,11 @@ def poisson3d_problem(n, blk=(8, 8, 4), K=(1.0, 1.0, 1.0), coarse_blk=None,
     Kref = hex_element_matrix(h, K)
     if coef == "checkerboard":
         c = checkerboard_coef((ex + 0.5) * h[0], (ey + 0.5) * h[1], (ez + 0.5) * h[2])
+    elif coef == "skew":
+        # smooth coefficient without any mirror / permutation symmetry: no two agglomerates are
+        # congruent and no local eigenspace is degenerate (parity tests at tight tolerances)
+        cx, cy, cz = (ex + 0.5) * h[0], (ey + 0.5) * h[1], (ez + 0.5) * h[2]
+        c = np.exp(0.7 * cx + 0.4 * cy - 0.3 * cz) * (1.0 + 0.3 * np.sin(5.0 * cx + 3.0 * cy + 7.0 * cz))
     else:
         c = np.ones(NE)
     elmat = c[:, None, None] * Kref[None, :, :]

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/scale_*.npz: oracle answers at the HEADLINE agglomerate shapes.
+
+The small fixtures of make_golden.py stop at a few thousand dofs.  These run the CPU oracle
+(numpy + LAPACK dsygvx / dgesvd; one process per core over the agglomerates) on 3-level
+hierarchies with the bench's 8x8x4-element AEs and 8x8x4-AE coarse blocks, so that level-1
+agglomerates are the ~2 600-row kind, and store what `north_star` wants identical:
+
+    level_dims, m_i per AE, k per MIS, PCG iteration count and (B r,r) history to 1e-8,
+
+plus, per MIS, the two singular values that decide the cut sigma > 1e-10 sigma_0
+(src/xpacks.cpp:591-620): the smallest kept and the largest dropped ratio sigma / sigma_0.
+A ratio within a decade of 1e-10 names a MIS whose k is round-off dependent.
+
+    python tests/golden/make_golden_scale.py [case ...]      (cases: see CASES; default all)
+
+Run time on 8 cores: 64x64x32 ~1 min, 96x96x64 ~4 min, 128^3 ~15 min (about 25 GB of RAM).
+"""
+import os
+import sys
+import time
+
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import saamge_oracle as o  # noqa: E402
+from saamge_amd import problems as pr  # noqa: E402
+
+# name -> (elements per side, coefficient, theta)
+CASES = {
+    "scale_64x64x32": ((64, 64, 32), None, 0.003),
+    "scale_64x64x32_skew": ((64, 64, 32), "skew", 0.003),     # no mirror symmetry: no degenerate eigenspaces
+    "scale_96x96x64": ((96, 96, 64), None, 0.003),
+    "scale_128": ((128, 128, 128), None, 0.003),
+}
+
+
+def cut_ratios(lv):
+    nm = len(lv.mis_svals)
+    kept = np.full(nm, np.inf)
+    dropped = np.zeros(nm)
+    for m, s in enumerate(lv.mis_svals):
+        if s is None or len(s) == 0:
+            continue
+        k = int(lv.mis_numcoarsedof[m])
+        kept[m] = s[k - 1] / s[0]
+        if k < len(s):
+            dropped[m] = s[k] / s[0]
+    return kept, dropped
+
+
+def run(name):
+    n, coef, theta = CASES[name]
+    prob = pr.poisson3d_problem(n, blk=(8, 8, 4), coarse_blk=[(8, 8, 4)], coef=coef)
+    o.PARALLEL_CORES = max(1, min(len(os.sched_getaffinity(0)), 16))
+    t0 = time.perf_counter()
+    H = o.ml_produce_data(prob.A, prob.elem_to_dof, prob.elmat, prob.bdr, prob.partitions,
+                          theta=theta, nu_relax=3)
+    t1 = time.perf_counter()
+    x, it, conv, hist = o.solve(H, prob.b, rel_tol=1e-8)
+    t2 = time.perf_counter()
+    out = {"dims": np.array(n, dtype=np.int32), "theta": np.array([theta]),
+           "level_dims": np.array([lv.A.shape[0] for lv in H.levels] + [H.levels[-1].Ac.shape[0]], dtype=np.int64),
+           "pcg_iters": np.array([it], dtype=np.int32), "pcg_hist": np.array(hist),
+           "x_norm": np.array([np.linalg.norm(x)]),
+           "relres": np.array([np.linalg.norm(prob.b - prob.A @ x) / np.linalg.norm(prob.b)])}
+    for l, lv in enumerate(H.levels):
+        out["l%d_ae_m" % l] = np.array([z.shape[1] for z in lv.evects], dtype=np.int16)
+        out["l%d_mis_k" % l] = lv.mis_numcoarsedof.astype(np.int16)
+        out["l%d_evals_max_kept" % l] = np.array([w[-1] for w in lv.evals])
+        kept, dropped = cut_ratios(lv)
+        out["l%d_sv_min_kept" % l] = kept
+        out["l%d_sv_max_dropped" % l] = dropped
+        out["l%d_Ac_trace" % l] = np.array([lv.Ac.diagonal().sum()])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    near = []
+    for l, lv in enumerate(H.levels):
+        kept, dropped = cut_ratios(lv)
+        near.append(int(np.sum((kept < 1e-9) | (dropped > 1e-11))))
+    print("%s: dims %s, %d its, setup %.1f s, solve %.1f s, MISes with a singular value within a decade of the cut: %s"
+          % (name, out["level_dims"].tolist(), it, t1 - t0, t2 - t1, near), flush=True)
+
+
+if __name__ == "__main__":
+    for c in (sys.argv[1:] or list(CASES)):
+        run(c)
