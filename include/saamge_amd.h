@@ -36,7 +36,7 @@ typedef struct saamge_amd_params {
     int nu_pro[SAAMGE_AMD_MAX_LEVELS];        /* prolongator smoothing degree (interp_smooth, src/interp.cpp:172-229); 0 = tentative */
     int avoid_ess_bdr_dofs;                   /* src/ml.cpp:64, always true in the reference */
     int testmesh;                             /* mltest fixture: ones-vector on AE 0, src/interp.cpp:510-524 */
-    int coarse_solver;                        /* 0 auto (dense Cholesky up to 1024 rows, else inner PCG), 1 dense Cholesky, 2 inner PCG */
+    int coarse_solver;                        /* 0 auto (explicit dense inverse up to 8192 rows, else inner PCG), 1 dense inverse, 2 inner PCG */
     double coarse_rtol;                       /* inner PCG tolerance on (B r, r), un-squared */
     int coarse_max_iter;
     long long workspace_bytes;                /* dense AE matrices are processed in chunks of this size (default 32 GiB) */

@@ -1,12 +1,13 @@
-// Dense Cholesky coarsest solver (see dense.hip).
+// Dense direct coarsest solver: explicit inverse by block Gauss-Jordan (see dense.hip).
 #pragma once
 #include "common.h"
 
 namespace saamge_amd {
 
-// L (n x n, column-major, lower) = chol(A).  Returns false when a pivot is not positive.
-bool dense_cholesky_factor(hipStream_t s, const DCsr &A, DBuf<double> &L);
-// x = L^-T L^-1 b ; `work` holds 2 n doubles; b and x may alias
-void dense_cholesky_solve(hipStream_t s, int n, const double *L, const double *b, double *x, double *work);
+// X (n x n, column-major, symmetric) = A^-1 for an SPD operator.  Returns false when a pivot is not
+// positive (semi-definite operator): the caller falls back to the inner PCG.
+bool dense_inverse_spd(hipStream_t s, const DCsr &A, DBuf<double> &X);
+// y = X b, or y += X b ; b and y must not alias
+void dense_symv(hipStream_t s, int n, const double *X, const double *b, double *y, bool add);
 
 }  // namespace saamge_amd

@@ -59,6 +59,7 @@ struct EigBatch {
     bool has_window = false;
     double window_vu = 0.0;
     std::vector<int> h_inertia;
+    DBuf<int> inertia;      // device copy (the iteration accepts a matrix when its Ritz count reaches it)
     void set_window(double vu_) { has_window = true; window_vu = vu_; }
     bool subspace = false, dense_only = false, ss_failed = false;
     std::vector<int> h_n, h_m;

@@ -1915,8 +1915,8 @@ __global__ __launch_bounds__(256) void band_copy_kernel(const int *__restrict__ 
 // two per CU) and 68 (up to 52, three per CU) -- the kernel is a chain of short dependent stages, so
 // the resident workgroups of other matrices are what fills the CU.
 constexpr int BC_NT = 256;
-constexpr size_t bc_lds_bytes(int win) {
-    return sizeof(double) * ((size_t)win * (win + 1) + (size_t)SB * (win - SB + 4) + 2 * SB * (SB + 1) + SB) + 64;
+constexpr size_t bc_lds_bytes(int win) {      // window rows x (band + 1) columns, L21^T, the two block buffers, signs
+    return sizeof(double) * ((size_t)win * (win - SB + 1) + (size_t)SB * (win - SB + 4) + 2 * SB * (SB + 1) + SB) + 64;
 }
 // INERTIA = true: nothing is written back.  The same window walk factors C - shift I = L S L^T
 // (S = diag(+-1), no pivoting) and info[b] receives the number of negative pivots = the number of
@@ -1927,7 +1927,9 @@ template <int BC_WIN, bool INERTIA = false>
 __global__ __launch_bounds__(BC_NT) void chol_band_lds_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
                                                               double *__restrict__ W, const int *__restrict__ bws,
                                                               int *__restrict__ info, double shift = 0.0) {
-    constexpr int BC_P = BC_WIN + 1, BC_MAXBW = BC_WIN - SB;
+    // the window is kept band-packed: row i holds columns i - BC_MAXBW .. i (only the lower band is ever
+    // touched), 53 instead of 69 doubles per row at BC_WIN = 68 -- four workgroups per CU instead of three
+    constexpr int BC_MAXBW = BC_WIN - SB, BC_P = BC_MAXBW + 1;
     constexpr int BC_PT = BC_MAXBW + 4;      // pitch of the transposed panel (rows padded to the 4-row tiles)
     extern __shared__ __align__(16) double bc_lds[];
     double *S = bc_lds;                                  // [BC_WIN][BC_P]
@@ -1939,8 +1941,9 @@ __global__ __launch_bounds__(BC_NT) void chol_band_lds_kernel(const int *__restr
     const int b = blockIdx.x, n = ns[b], bw = bws[b];
     if (bw > BC_MAXBW) return;                           // (the host only launches this when every matrix fits)
     double *A = W + moff[b];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    auto sl = [&](int i, int j) -> double & { return S[(i % BC_WIN) * BC_P + (j % BC_WIN)]; };     // (i, j >= 0)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    auto sl = [&](int i, int j) -> double & { return S[(i % BC_WIN) * BC_P + (j - i + BC_MAXBW)]; };     // (0 <= i - j <= BC_MAXBW)
     auto fetch_rows = [&](int i0, int i1) {              // rows [i0, i1) of the band, from the upper triangle
         for (int i = i0 + w; i < min(i1, n); i += BC_NT / 64)
             for (int jj = lane; jj <= bw; jj += 64) {
@@ -2078,11 +2081,12 @@ template <bool UPPER, int NT>
 __global__ __launch_bounds__(NT) void ss_trsolve_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
                                                          const int64_t *__restrict__ voff,
                                                          const double *__restrict__ W, double *__restrict__ X,
-                                                         const int *__restrict__ state, const int *__restrict__ bws) {
+                                                         const int *__restrict__ state, const int *__restrict__ bws,
+        const int *__restrict__ active = nullptr) {
     __shared__ double Td[SB][SB + 1];
     __shared__ double ys[SB][SS_B];
     __shared__ double xs[2][SB][SS_B];       // right-hand side rows of the current / next block
-    const int b = blockIdx.x, n = ns[b];
+    const int b = active ? active[blockIdx.x] : (int)blockIdx.x, n = ns[b];     // (active: the matrices still iterating)
     if (state[b] & 3) return;
     // the factor is zero beyond this distance from the diagonal (at least SB: the rows of the next
     // block are caught in LDS by the threads that update them)
@@ -2166,11 +2170,12 @@ __global__ __launch_bounds__(NT) void ss_solve_lds_kernel(const int *__restrict_
                                                            const int64_t *__restrict__ voff,
                                                            const double *__restrict__ W, const double *__restrict__ X,
                                                            double *__restrict__ Zout, const int *__restrict__ state,
-                                                           const int *__restrict__ bws) {
+                                                           const int *__restrict__ bws,
+        const int *__restrict__ active = nullptr) {
     extern __shared__ __align__(16) double xl[];      // [n][XLP]
     __shared__ double Td[SB][SB + 1];
     __shared__ double ys[SB][SS_B];
-    const int b = blockIdx.x, n = ns[b];
+    const int b = active ? active[blockIdx.x] : (int)blockIdx.x, n = ns[b];     // (active: the matrices still iterating)
     if (state[b] & 3) return;                         // accepted (or given up) in an earlier iteration
     const int bw = bws ? bws[b] : n;                  // the factor is zero beyond this distance from the diagonal
     const double *A = W + moff[b];
@@ -2265,12 +2270,13 @@ __global__ __launch_bounds__(NT) void ss_solve_lds_pf_kernel(const int *__restri
                                                               const int64_t *__restrict__ voff,
                                                               const double *__restrict__ W, const double *__restrict__ X,
                                                               double *__restrict__ Zout, const int *__restrict__ state,
-                                                              const int *__restrict__ bws) {
+                                                              const int *__restrict__ bws,
+        const int *__restrict__ active = nullptr) {
     static_assert(NT == 128, "two diagonal-block entries per thread");
     extern __shared__ __align__(16) double xl[];      // [n][XLP]
     __shared__ double Td[SB][SB + 1];
     __shared__ double ys[SB][SS_B];
-    const int b = blockIdx.x, n = ns[b];
+    const int b = active ? active[blockIdx.x] : (int)blockIdx.x, n = ns[b];     // (active: the matrices still iterating)
     if (state[b] & 3) return;
     const int bw = bws ? bws[b] : n;
     const double *A = W + moff[b];
@@ -2373,10 +2379,12 @@ __global__ __launch_bounds__(NT) void ss_solve_lds_pf_kernel(const int *__restri
 __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, const int64_t *__restrict__ voff,
                                                     double *__restrict__ X, const double *__restrict__ Z,
                                                     double *__restrict__ mu, int *__restrict__ state, int iter,
-                                                    double sigma, double vu) {
+                                                    double sigma, double vu, const int *__restrict__ inertia,
+                                                    double *__restrict__ dbg = nullptr,
+        const int *__restrict__ active = nullptr) {
     __shared__ double part[4][2 * SS_B + 1][SS_B];  // [wavefront][M rows | G rows | residual][column j]
     __shared__ double Ms[SS_B][SS_B], Gs[SS_B][SS_B], Cs[SS_B][SS_B], res2[SS_B], mus[SS_B], mu_old[SS_B];
-    const int b = blockIdx.x, n = ns[b];
+    const int b = active ? active[blockIdx.x] : (int)blockIdx.x, n = ns[b];     // (active: the matrices still iterating)
     if (state[b] & 3) return;                       // accepted earlier: X, mu stay as they are
     double *Xb = X + voff[b] * SB;
     const double *Zb = Z + voff[b] * SB;
@@ -2445,14 +2453,24 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
         if (iter > 0) {
             int k = 0;
             for (int q = 0; q < SS_B; ++q) if (sigma + mu_old[q] <= vu) ++k;
-            if (k > SS_B - 2) st |= 2;
-            else {
-                // residual bounds of the wanted pairs; the first unwanted one only has to be pinned
-                // above the window (an eigenvalue lies within the bound of its Ritz value)
+            if (dbg)        // (SAAMGE_AMD_SS_DEBUG: residual bounds and Ritz values of the previous pairs)
+                for (int q = 0; q < SS_B; ++q) { dbg[(size_t)b * 2 * SS_B + q] = 2.5 * mu_old[q] * sqrt(res2[q]); dbg[(size_t)b * 2 * SS_B + SS_B + q] = sigma + mu_old[q]; }
+            const int cert = inertia ? inertia[b] : -2;      // certified #{lambda < vu}; -1: not certifiable, -2: none
+            if (k > SS_B - 2 || cert > SS_B - 2 || cert == -1) st |= 2;
+            else if (cert >= 0) {
+                // Ritz values approach the eigenvalues from above, so the number inside the window grows to the
+                // certified count: accept once it is reached and those pairs have converged (count 0: the
+                // smallest pair alone, the reference's "at least one" rule)
+                bool ok = k == cert;
+                for (int q = 0; q < max(k, 1); ++q) ok = ok && (2.5 * mu_old[q] * sqrt(res2[q]) <= SS_TOL);
+                if (ok) st |= 1 | (k << 4) | (max(k, 1) << 8);
+            } else {
+                // no certificate (SAAMGE_AMD_SS_CERTIFY=0): residual bounds of the wanted pairs; the first unwanted
+                // one has to be pinned above the window (an eigenvalue lies within the bound of its Ritz value)
                 bool ok = true;
                 for (int q = 0; q < max(k, 1); ++q) ok = ok && (2.5 * mu_old[q] * sqrt(res2[q]) <= SS_TOL);
                 if (k >= 1) ok = ok && (2.5 * mu_old[k] * sqrt(res2[k]) < 0.5 * (sigma + mu_old[k] - vu));
-                if (ok) st |= 1 | (k << 4) | (max(k, 1) << 8);      // bits 4..7: Ritz values inside the window
+                if (ok) st |= 1 | (k << 4) | (max(k, 1) << 8);
             }
         }
         sh_st = st;
@@ -2779,6 +2797,7 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
         }
     }
 
+    if (!b.h_inertia.empty()) b.inertia.from_host(b.h_inertia, s);
     // ---- C - sigma I = L L^T ----
     hipLaunchKernelGGL(ss_shift_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, SS_SIGMA);
     if (lds_path) {
@@ -2812,17 +2831,21 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     DBuf<double> mubuf((size_t)b.count * SS_B);
     mu = mubuf.p;
     const bool prof = profiler().enabled;
-    double sbytes = 0.0;       // the factor once per triangle + the right-hand sides in and out
     const int *bws = b.h_bw.empty() ? nullptr : b.bw.p;
-    for (size_t i = 0; i < b.h_n.size(); ++i) {
-        const double n = b.h_n[i], w = b.h_bw.empty() ? n : std::min(n, (double)b.h_bw[i] + SB);
-        sbytes += 8.0 * n * (2.0 * w - w * w / n) + 2.0 * 8.0 * SS_B * n;     // band of both triangles
-    }
     if (!prof) profiler().begin(s);
     hipLaunchKernelGGL(ss_init_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, b.dis.p,
                        b.has_perm ? b.perm.p : nullptr, X);
     bool done = false, failed = false;
     std::vector<int> hstate;
+    // Only the matrices that are still iterating are launched, through a dense index list: accepted ones
+    // would exit at once, but the survivors (agglomerates on the domain boundary: every 64th id, runs of 64)
+    // would then sit on a few CUs -- block ids map to XCDs and CUs round-robin -- and a launch with 6 % of
+    // the matrices active took as long as a full one.
+    std::vector<int> h_active((size_t)b.count);
+    for (int i = 0; i < b.count; ++i) h_active[i] = i;
+    DBuf<int> active;
+    active.from_host(h_active, s);
+    int nact = b.count;
     for (int iter = 0; iter < 80 && !done; ++iter) {
         if (prof) profiler().begin(s);
         const size_t xl_bytes = sizeof(double) * (size_t)b.max_n * XLP + 64;
@@ -2834,7 +2857,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
             int nt = (snt == 256 || snt == 512) ? snt : (rows <= 256 ? 256 : 512);   // (>= SB * SB threads: the block loads)
             auto go = [&](auto kern) {
                 SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-                hipLaunchKernelGGL(kern, dim3(b.count), dim3(nt), xl_bytes, s, b.n.p, b.moff.p, b.voff.p, b.W.p, X, Z, state.p, bws);
+                hipLaunchKernelGGL(kern, dim3(nact), dim3(nt), xl_bytes, s, b.n.p, b.moff.p, b.voff.p, b.W.p, X, Z, state.p, bws, active.p);
             };
             if (mode == 3 && rows <= 128) { nt = 128; go(ss_solve_lds_pf_kernel<128>); }
             else if (nt == 256) { if (mode == 0) go(ss_solve_lds_kernel<256, 0>); else if (mode == 1) go(ss_solve_lds_kernel<256, 1>); else go(ss_solve_lds_kernel<256, 2>); }
@@ -2842,18 +2865,39 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         } else {
         SA_HIP_CHECK(hipMemcpyAsync(Z, X, sizeof(double) * (size_t)b.h_voff[b.count] * SB, hipMemcpyDeviceToDevice, s));
         if (b.max_n > 768) {
-            hipLaunchKernelGGL((ss_trsolve_kernel<false, 1024>), dim3(b.count), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws);
-            hipLaunchKernelGGL((ss_trsolve_kernel<true, 1024>), dim3(b.count), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws);
+            hipLaunchKernelGGL((ss_trsolve_kernel<false, 1024>), dim3(nact), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
+            hipLaunchKernelGGL((ss_trsolve_kernel<true, 1024>), dim3(nact), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
         } else {
-            hipLaunchKernelGGL((ss_trsolve_kernel<false, 256>), dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws);
-            hipLaunchKernelGGL((ss_trsolve_kernel<true, 256>), dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws);
+            hipLaunchKernelGGL((ss_trsolve_kernel<false, 256>), dim3(nact), dim3(256), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
+            hipLaunchKernelGGL((ss_trsolve_kernel<true, 256>), dim3(nact), dim3(256), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
         }
         }
-        if (prof) { profiler().end(s, b.max_n <= 1280 ? "eig_ss_solve" : "eig_ss_solve_g", sbytes, 0.0); profiler().begin(s); }
-        hipLaunchKernelGGL(ss_rr_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, X, Z, mu, state.p, iter,
-                           SS_SIGMA, vu);
+        if (prof) {
+            double ab = 0.0;      // the factor once per triangle + the right-hand sides, ACTIVE matrices only
+            for (int i : h_active) {
+                const double n = b.h_n[i], w = b.h_bw.empty() ? n : std::min(n, (double)b.h_bw[i] + SB);
+                ab += 8.0 * n * (2.0 * w - w * w / n) + 2.0 * 8.0 * SS_B * n;
+            }
+            profiler().end(s, b.max_n <= 1280 ? "eig_ss_solve" : "eig_ss_solve_g", ab, 0.0);
+            profiler().begin(s);
+        }
+        static const bool dbg_on = std::getenv("SAAMGE_AMD_SS_DEBUG") != nullptr;
+        DBuf<double> dbgbuf;
+        if (dbg_on) dbgbuf.alloc((size_t)b.count * 2 * SS_B);
+        hipLaunchKernelGGL(ss_rr_kernel, dim3(nact), dim3(256), 0, s, b.n.p, b.voff.p, X, Z, mu, state.p, iter,
+                           SS_SIGMA, vu, b.h_inertia.empty() ? (const int *)nullptr : b.inertia.p, dbgbuf.p, active.p);
+        if (dbg_on && iter > 0) {
+            auto hd = dbgbuf.to_host(s);
+            const int show = std::min(b.count, 3);
+            for (int i = 0; i < show; ++i) {
+                const int mi = (int)((int64_t)i * (b.count - 1) / std::max(1, show - 1));
+                std::fprintf(stderr, "  iter %d matrix %d (n %d): bounds %.2e %.2e %.2e | lambda %.6e %.6e %.6e | inertia %d\n", iter, mi, b.h_n[mi],
+                             hd[(size_t)mi * 16], hd[(size_t)mi * 16 + 1], hd[(size_t)mi * 16 + 2], hd[(size_t)mi * 16 + 8],
+                             hd[(size_t)mi * 16 + 9], hd[(size_t)mi * 16 + 10], b.h_inertia.empty() ? -2 : b.h_inertia[mi]);
+            }
+        }
         if (prof) profiler().end(s, "eig_ss_rr", 0.0, 0.0);
-        if (iter >= 3 && (iter % 2) == 1) {
+        if (iter >= 1) {      // (one small read-back per iteration: a launch costs ~1 ms here)
             auto t = state.to_host(s);
             hstate.assign(t.begin(), t.end());
             done = true;
@@ -2866,6 +2910,11 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
             static const bool dbg = std::getenv("SAAMGE_AMD_SS_DEBUG") != nullptr;
             if (dbg) std::fprintf(stderr, "subspace: iteration %d, %d of %d matrices accepted (n max %d)\n", iter, nconv, b.count, b.max_n);
             if (failed) break;
+            h_active.clear();
+            for (int i = 0; i < b.count; ++i)
+                if (!(hstate[i] & 3)) h_active.push_back(i);
+            nact = (int)h_active.size();
+            if (nact) SA_HIP_CHECK(hipMemcpyAsync(active.p, h_active.data(), sizeof(int) * (size_t)nact, hipMemcpyHostToDevice, s));
         }
     }
     SA_HIP_CHECK(hipGetLastError());

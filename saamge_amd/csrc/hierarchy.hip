@@ -648,20 +648,16 @@ static void setup_coarse_solver(Hierarchy &H) {
         SA_HIP_CHECK(hipStreamSynchronize(s));
     }
     H.c_roots = sas_poly_roots(H.levels.back()->nu_relax);
-    // Dense Cholesky (the reference's serial `--coarse-direct`, amg/src/tg.cpp:979-1014) when the
-    // coarsest operator is small enough (coarse_solver 0 = auto: n <= 1024 -- measured at n = 3317:
-    // factor 48 ms + 2.4 ms per solve against ~1 ms per solve for the inner PCG --, 1 = always);
-    // a non-positive pivot (semi-definite operator) falls back to the inner PCG.
+    // Dense direct solve (the reference's serial `--coarse-direct`, amg/src/tg.cpp:979-1014) as an explicit
+    // inverse when the coarsest operator is small enough (coarse_solver 0 = auto: n <= 8192, i.e. up to 512 MiB;
+    // 1 = always): at n = 3317 the inverse costs a few ms once and 20 us per V-cycle, the inner PCG ~2.4 ms per
+    // V-cycle.  A non-positive pivot (semi-definite operator) falls back to the inner PCG.
     const int want = H.params.coarse_solver;
     static const long dense_max = std::getenv("SAAMGE_AMD_COARSE_DENSE_MAX")
-                                      ? atol(std::getenv("SAAMGE_AMD_COARSE_DENSE_MAX")) : 1024;
+                                      ? atol(std::getenv("SAAMGE_AMD_COARSE_DENSE_MAX")) : 8192;
     if (n && (want == 1 || (want == 0 && (long)n <= dense_max)) && n <= 16384) {
-        if (dense_cholesky_factor(s, Ac, H.c_L)) {
-            H.coarse_kind = 1;
-            H.c_work.alloc(2 * n);
-        } else {
-            H.c_L.release();
-        }
+        if (dense_inverse_spd(s, Ac, H.c_L)) H.coarse_kind = 1;
+        else H.c_L.release();
     }
 }
 
@@ -779,7 +775,12 @@ static void coarse_solve(Hierarchy &H, const double *rc, double *xc) {
     const DCsr &Ac = coarsest_op(H);
     if (Ac.nrows == 0) return;
     if (H.coarse_kind == 1) {
-        dense_cholesky_solve(H.stream, Ac.nrows, H.c_L.p, rc, xc, H.c_work.p);
+        // x = X b and one step of iterative refinement, x += X (b - Ac x): the elimination's round-off
+        // (~cond(Ac) eps) is pushed to the level of the residual evaluation
+        const int n = Ac.nrows;
+        dense_symv(H.stream, n, H.c_L.p, rc, xc, false);
+        spmv_residual(H.stream, Ac, xc, rc, H.c_r.p);
+        dense_symv(H.stream, n, H.c_L.p, H.c_r.p, xc, true);
         H.last_coarse_iters = 0;
         return;
     }
