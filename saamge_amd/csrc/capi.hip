@@ -372,6 +372,8 @@ int saamge_amd_spmv(int nrows, int ncols, const int *rowptr, const int *col, con
     import_array(A.col, col, (size_t)A.nnz, s);
     import_array(A.val, val, (size_t)A.nnz, s);
     A.lanes_per_row = pick_lanes_per_row(A.nnz, nrows > 0 ? nrows : 1);
+    // SAAMGE_AMD_SPMV_SELL=1 (tests): through the SELL-64 copy and its coded slices, the format of the level operators
+    if (nrows == ncols && std::getenv("SAAMGE_AMD_SPMV_SELL")) build_sell(s, A);
     VecIn vx(x, (size_t)ncols, s);
     VecOut vy(y, (size_t)nrows, s, false);
     spmv(s, A, vx.p, vy.p);

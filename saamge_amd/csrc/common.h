@@ -182,8 +182,10 @@ struct DCsr {
     DBuf<double> sell_val;
     // coded slices: <= 64 distinct offsets col - row -> sell_tab[64 s + code], one byte per entry
     // in sell_code (four consecutive entries of a row per word); sell_ntab[s] = -1: plain slice
+    // pair-coded slices (sell_ntab >= 256): <= 64 distinct (offset, VALUE) pairs, sell_vtab holds the values
     DBuf<int> sell_ntab, sell_tab;
     DBuf<unsigned> sell_code;
+    DBuf<double> sell_vtab;
 };
 
 inline int pick_lanes_per_row(int64_t nnz, int nrows) {

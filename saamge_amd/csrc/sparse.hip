@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void sell_spmv_kernel(int nrows, int row0, con
                                                         double *__restrict__ y,
                                                         const double *__restrict__ b,
                                                         const double *__restrict__ dinv, double scale,
-                                                        const double *__restrict__ xrow) {
+                                                        const double *__restrict__ xrow,
+                                                        const double *__restrict__ vtab) {
     const long row = (long)blockIdx.x * 256 + threadIdx.x;
     const int slice = (int)(row >> 6), lane = threadIdx.x & 63;
     if ((long)slice * 64 >= nrows) return;
@@ -71,7 +72,35 @@ __global__ __launch_bounds__(256) void sell_spmv_kernel(int nrows, int row0, con
     double s0 = 0.0, s1 = 0.0;
     int k = 0;
     const int gslice = (row0 >> 6) + slice;
-    if (ntab[gslice] >= 0) {
+    const int nt = ntab[gslice];
+    if (nt >= 256) {
+        // pair-coded slice: the byte indexes a table of (offset, VALUE) pairs -- at most 64 distinct ones in
+        // the slice, which is every slice of a constant-coefficient stencil matrix (the whole fine level of the
+        // headline problem).  Neither columns nor values are streamed: 1 byte per stored entry instead of 12.
+        const int np = nt - 256;
+        const int mytab = (lane < np) ? tab[(size_t)gslice * 64 + lane] : 0;
+        const double myval = (lane < np) ? vtab[(size_t)gslice * 64 + lane] : 0.0;
+        const int grow = row0 + (int)row;
+        const unsigned *wp = codes + ((size_t)(beg >> 2) + (size_t)gslice * 64 + lane);
+        for (; k + 4 <= w; k += 4) {
+            const unsigned cw = __builtin_nontemporal_load(wp + 16 * k);
+            const int i0 = (int)(cw & 255u), i1 = (int)((cw >> 8) & 255u), i2 = (int)((cw >> 16) & 255u), i3 = (int)(cw >> 24);
+            const int c0 = grow + __shfl(mytab, i0), c1 = grow + __shfl(mytab, i1);
+            const int c2 = grow + __shfl(mytab, i2), c3 = grow + __shfl(mytab, i3);
+            const double v0 = __shfl(myval, i0), v1 = __shfl(myval, i1), v2 = __shfl(myval, i2), v3 = __shfl(myval, i3);
+            s0 = fma(v0, x[c0], s0);
+            s1 = fma(v1, x[c1], s1);
+            s0 = fma(v2, x[c2], s0);
+            s1 = fma(v3, x[c3], s1);
+        }
+        if (k < w) {
+            unsigned cw = __builtin_nontemporal_load(wp + 16 * k);
+            for (; k < w; ++k, cw >>= 8) {
+                const int i0 = (int)(cw & 255u);
+                s0 = fma(__shfl(myval, i0), x[grow + __shfl(mytab, i0)], s0);
+            }
+        }
+    } else if (nt >= 0) {
         const int mytab = tab[(size_t)gslice * 64 + lane];
         const int grow = row0 + (int)row;                  // global row: columns are row + offset
         const unsigned *wp = codes + ((size_t)(beg >> 2) + (size_t)gslice * 64 + lane);
@@ -145,45 +174,63 @@ __global__ __launch_bounds__(256) void sell_fill_kernel(int nrows, const int *__
     }
 }
 
-// Offset tables and byte codes of the coded slices (see sell_spmv_kernel): one wavefront per
-// slice collects the distinct offsets col - row in first-appearance order, one table entry per
-// lane; a slice with more than 64 of them keeps its 4-byte columns (ntab = -1).  The codes of
-// four consecutive entries of a row share one 32-bit word at
-// codes[sptr/4 + 64 slice + 64 (k / 4) + lane].
+// Tables and byte codes of the coded slices (see sell_spmv_kernel): one wavefront per slice.  First
+// the distinct (offset, value) PAIRS are collected in first-appearance order, one table entry per lane
+// (ntab = 256 + count: neither columns nor values are streamed for such a slice); a slice with more than
+// 64 pairs falls back to the distinct offsets col - row alone (ntab = count, values streamed), and one with
+// more than 64 offsets keeps its 4-byte columns (ntab = -1).  The codes of four consecutive entries of a
+// row share one 32-bit word at codes[sptr/4 + 64 slice + 64 (k / 4) + lane].
 __global__ __launch_bounds__(256) void sell_code_kernel(int nslices, const int *__restrict__ sptr,
-                                                        const int *__restrict__ scol, int *__restrict__ ntab,
-                                                        int *__restrict__ tab, unsigned *__restrict__ codes) {
+                                                        const int *__restrict__ scol, const double *__restrict__ sval,
+                                                        int *__restrict__ ntab, int *__restrict__ tab,
+                                                        double *__restrict__ vtab, unsigned *__restrict__ codes,
+                                                        int with_values) {
     const int slice = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (slice >= nslices) return;
     const int beg = sptr[slice], w = (sptr[slice + 1] - beg) >> 6;
     const int row = slice * 64 + lane;
     unsigned *wp = codes + ((size_t)(beg >> 2) + (size_t)slice * 64 + lane);
-    int mytab = 0, nt = 0;
-    unsigned cw = 0;
-    bool ok = true;
-    for (int k = 0; k < w && ok; ++k) {
-        const int delta = scol[beg + 64 * k + lane] - row;
-        int code = -1;
-        for (int t = 0; t < nt; ++t)
-            if (__shfl(mytab, t) == delta) code = t;
-        unsigned long long pending = __ballot(code < 0);
-        while (pending) {
-            const int leader = __ffsll((long long)pending) - 1;
-            const int d = __shfl(delta, leader);
-            if (nt == 64) { ok = false; break; }
-            if (lane == nt) mytab = d;
-            if (code < 0 && delta == d) code = nt;
-            ++nt;
-            pending = __ballot(code < 0);
+    for (int pass = with_values ? 0 : 1; pass < 2; ++pass) {
+        const bool pairs = pass == 0;
+        int mytab = 0, nt = 0;
+        long long myval = 0;
+        unsigned cw = 0;
+        bool ok = true;
+        for (int k = 0; k < w && ok; ++k) {
+            const int delta = scol[beg + 64 * k + lane] - row;
+            const long long vb = pairs ? __double_as_longlong(sval[beg + 64 * k + lane]) : 0;
+            int code = -1;
+            for (int t = 0; t < nt; ++t) {
+                // (both shuffles outside the condition: a cross-lane read under a divergent branch returns
+                // nothing from the lanes that did not take it)
+                const int tt = __shfl(mytab, t);
+                const long long tv = __shfl(myval, t);
+                if (tt == delta && tv == vb) code = t;
+            }
+            unsigned long long pending = __ballot(code < 0);
+            while (pending) {
+                const int leader = __ffsll((long long)pending) - 1;
+                const int d = __shfl(delta, leader);
+                const long long dv = __shfl(vb, leader);
+                if (nt == 64) { ok = false; break; }
+                if (lane == nt) { mytab = d; myval = dv; }
+                if (code < 0 && delta == d && vb == dv) code = nt;
+                ++nt;
+                pending = __ballot(code < 0);
+            }
+            cw |= (unsigned)(code & 255) << (8 * (k & 3));
+            if ((k & 3) == 3 || k == w - 1) {
+                wp[16 * (k & ~3)] = cw;
+                cw = 0;
+            }
         }
-        cw |= (unsigned)(code & 255) << (8 * (k & 3));
-        if ((k & 3) == 3 || k == w - 1) {
-            wp[16 * (k & ~3)] = cw;
-            cw = 0;
+        if (ok || !pairs) {
+            tab[(size_t)slice * 64 + lane] = mytab;
+            if (pairs) vtab[(size_t)slice * 64 + lane] = __longlong_as_double(myval);
+            if (lane == 0) ntab[slice] = ok ? (pairs ? 256 + nt : nt) : -1;
+            return;
         }
     }
-    tab[(size_t)slice * 64 + lane] = mytab;
-    if (lane == 0) ntab[slice] = ok ? nt : -1;
 }
 
 void exclusive_scan_int(hipStream_t s, int n, const int *in, int *out);  // mis.hip
@@ -212,11 +259,15 @@ void build_sell(hipStream_t s, DCsr &A) {
     A.sell_ntab.alloc((size_t)A.nslices);
     A.sell_tab.alloc((size_t)A.nslices * 64);
     A.sell_code.alloc((size_t)total / 4 + (size_t)A.nslices * 64 + 64);
+    A.sell_vtab.alloc((size_t)A.nslices * 64);
+    // (SAAMGE_AMD_SELL_CODES=1: offset codes only, values always streamed)
+    static const bool no_vals = std::getenv("SAAMGE_AMD_SELL_CODES") && std::atoi(std::getenv("SAAMGE_AMD_SELL_CODES")) == 1;
     if (no_codes)
         SA_HIP_CHECK(hipMemsetAsync(A.sell_ntab.p, 0xff, sizeof(int) * (size_t)A.nslices, s));
     else
         hipLaunchKernelGGL(sell_code_kernel, dim3(div_up(A.nslices, 4)), dim3(256), 0, s, A.nslices, A.sell_ptr.p,
-                           A.sell_col.p, A.sell_ntab.p, A.sell_tab.p, A.sell_code.p);
+                           A.sell_col.p, A.sell_val.p, A.sell_ntab.p, A.sell_tab.p, A.sell_vtab.p, A.sell_code.p,
+                           no_vals ? 0 : 1);
     SA_HIP_CHECK(hipGetLastError());
     A.has_sell = true;
 }
@@ -238,7 +289,7 @@ static void launch_spmv(hipStream_t s, const DCsr &A, RowRange rr, const double 
         const int grid = div_up((long)div_up(nrows, 64) * 64, 256);
         hipLaunchKernelGGL((sell_spmv_kernel<MODE>), dim3(grid), dim3(256), 0, s, nrows, row0,
                            A.sell_ptr.p + row0 / 64, A.sell_col.p, A.sell_val.p, A.sell_ntab.p, A.sell_tab.p,
-                           A.sell_code.p, x, y, b, dinv, scale, xrow);
+                           A.sell_code.p, x, y, b, dinv, scale, xrow, A.sell_vtab.p);
         SA_HIP_CHECK(hipGetLastError());
         return;
     }

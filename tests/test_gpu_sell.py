@@ -1,0 +1,60 @@
+"""The SELL-64 SpMV of the level operators against scipy, in each of its three slice formats: pair-coded
+(<= 64 distinct (offset, value) pairs per slice: constant-coefficient stencils), offset-coded (<= 64
+distinct column offsets, values streamed: variable-coefficient stencils) and plain.  Bit-level claim:
+the coded formats are lossless, so all three give the same sums in the same order."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_CODE = r"""
+import sys, numpy as np, scipy.sparse as sp
+sys.path.insert(0, %r)
+from saamge_amd import capi, problems as pr
+rng = np.random.default_rng(3)
+mats = {
+  "stencil_const_short_rows": pr.poisson3d_problem((8, 8, 8), blk=(4, 4, 2)).A.tocsr(),     # boundary rows shorter than the slice: padded entries
+  "stencil_const": pr.poisson3d_problem((20, 12, 9), blk=(4, 4, 3)).A.tocsr(),
+  "stencil_skew": pr.poisson3d_problem((12, 12, 12), blk=(4, 4, 4), coef="skew").A.tocsr(),
+  "random": sp.random(1000, 1000, density=0.02, random_state=rng, format="csr"),
+  "tiny": sp.csr_matrix(np.array([[2.0, -1.0, 0.0], [-1.0, 2.0, -1.0], [0.0, -1.0, 2.0]])),
+}
+out = {}
+for name, A in mats.items():
+    A = A.tocsr(); A.sort_indices()
+    x = rng.standard_normal(A.shape[1])
+    y = capi.spmv(A, x)
+    ref = A @ x
+    err = np.abs(y - ref).max() / (np.abs(A) @ np.abs(x)).max()
+    print("RESULT", name, repr(float(err)), y.tobytes().hex()[:64])
+"""
+
+
+def _run(codes):
+    env = dict(os.environ, SAAMGE_AMD_SPMV_SELL="1")
+    if codes is not None:
+        env["SAAMGE_AMD_SELL_CODES"] = str(codes)
+    o = subprocess.run([sys.executable, "-c", _CODE % ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert o.returncode == 0, o.stdout + o.stderr
+    res = {}
+    for line in o.stdout.splitlines():
+        if line.startswith("RESULT"):
+            _, name, err, digest = line.split()
+            res[name] = (float(err), digest)
+    return res
+
+
+def test_sell_formats_match_scipy_and_each_other():
+    full = _run(None)          # pair codes where possible
+    offs = _run(1)             # offset codes only
+    plain = _run(0)            # no codes
+    assert set(full) == set(offs) == set(plain) and len(full) == 5
+    for name in full:
+        for res in (full, offs, plain):
+            assert res[name][0] <= 1e-15, (name, res[name])
+        assert full[name][1] == offs[name][1] == plain[name][1], name      # identical bits
