@@ -15,8 +15,10 @@ Prints ONE JSON line (rank 0).  Extra legs, outside the timed region:
     time.  `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes of this
     same command (profiles/r01_pmc_traffic.json, produced by tools/pmc_traffic.py; FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for gfx950, calibrated on pcg_update_xr).
-  * cpu_baseline: the CPU oracle (numpy + LAPACK dsygvx/dgesvd, 1 thread) on a bounded
-    sample of the same workload, timed on this box's host cores.
+  * cpu_baseline: the CPU restatement (oracle/cpu_ref.cpp: threaded C++, LAPACK dsygvx/dgesvd, one
+    agglomerate per core) on a bounded sample of the same workload, timed on this box's host cores;
+    the GPU path is then run on the same sample and must give the same level dimensions, iteration
+    count and (B r,r) history.
 
 N > 1: `python bench.py --gpus N` starts N fresh rank processes itself (one per GPU, before this
 process touches the GPU; under torchrun / the driver's torch.distributed.run the ranks already exist
@@ -84,9 +86,9 @@ def one_step(capi, prob, params, rel_tol=1e-8, group=None):
 
 
 def cpu_baseline(n_sample, levels):
-    """Oracle setup+solve on a bounded sample: the same discretisation and AE shape on a smaller
-    box, reported per dof.  Runs in a GPU-free child process (oracle/baseline_worker.py) with the
-    per-AE eigenproblems spread over the host cores, one LAPACK thread per process."""
+    """The CPU restatement (oracle/cpu_ref.cpp: threaded C++, LAPACK dsygvx / dgesvd, one agglomerate per
+    core like the reference's one-MPI-rank-per-core runs) on a bounded sample: the same discretisation, AE
+    shape and coarse blocks on a smaller box, reported per dof.  Runs in a GPU-free child process."""
     import subprocess
     try:
         cores = len(os.sched_getaffinity(0))
@@ -99,13 +101,35 @@ def cpu_baseline(n_sample, levels):
     if out.returncode != 0:
         raise RuntimeError("cpu_baseline worker failed: " + out.stderr.decode()[-2000:])
     r = json.loads(out.stdout.decode().strip().splitlines()[-1])
-    return {"value": r["dofs"] / (r["setup_s"] + r["solve_s"]), "unit": "DoF/s", "cores": r["cores"],
-            "kind": "port",
-            "sample": "oracle (numpy + LAPACK dsygvx/dgesvd; per-AE eigenproblems on %d processes, 1 LAPACK "
-                      "thread each; the rest serial) on 3-D Poisson %s (%d dofs), %d-level, 8x8x4-element AEs: "
-                      "setup %.2f s, solve %.2f s, %d PCG its"
-                      % (r["cores"], "x".join(str(v) for v in n_sample), r["dofs"], levels, r["setup_s"],
-                         r["solve_s"], r["iters"])}
+    return r, {"value": r["dofs"] / (r["setup_s"] + r["solve_s"]), "unit": "DoF/s", "cores": r["cores"],
+               "kind": "port",
+               "sample": "oracle/cpu_ref.cpp (C++ restatement of the reference's setup + solve: LAPACK dsygvx / dgesvd per "
+                         "agglomerate / MIS on %d threads, one agglomerate per core; threaded SpMV / RAP) on 3-D Poisson %s "
+                         "(%d dofs), %d-level, 8x8x4-element AEs, %s-AE coarse blocks (the GPU run's shapes): setup %.2f s, "
+                         "solve %.2f s, %d PCG its, level dims %s"
+                         % (r["cores"], "x".join(str(v) for v in n_sample), r["dofs"], levels,
+                            "x".join(str(v) for v in r["coarse_blk"]), r["setup_s"], r["solve_s"], r["iters"], r["level_dims"])}
+
+
+def gpu_check_on_sample(capi, n_sample, levels, dev, theta, cpu):
+    """The GPU path on the cpu_baseline sample: level dimensions and iteration count must equal the CPU
+    restatement's, the (B r,r) history must agree to 1e-8 (the oracle's answer is already in hand)."""
+    import numpy as np
+    import torch
+    prob = build_problem(n_sample, levels, dev)
+    params = capi.default_params(num_coarsenings=levels - 1, theta=theta, nu_relax=3)
+    h, x, its, conv, hist = one_step(capi, prob, params)
+    infos = [h.level_info(l) for l in range(levels - 1)]
+    dims = [i["n"] for i in infos] + [infos[-1]["ncoarse"]]
+    h.close()
+    ch = np.array(cpu["hist"])
+    dev_hist = float(np.max(np.abs(hist - ch) / ch)) if len(hist) == len(ch) else float("inf")
+    ok = dims == cpu["level_dims"] and its == cpu["iters"] and dev_hist <= 1e-8
+    res = {"level_dims_gpu": dims, "level_dims_cpu": cpu["level_dims"], "pcg_iterations_gpu": its,
+           "pcg_iterations_cpu": cpu["iters"], "max_rel_history_deviation": dev_hist, "identical": bool(ok)}
+    if not ok:
+        raise SystemExit("bench.py: the GPU path and the CPU restatement disagree on the sample: %s" % json.dumps(res))
+    return res
 
 
 def pmc_traffic(symbol, n, levels):
@@ -269,7 +293,10 @@ def main():
                            "GBps": round(s["bytes"] / max(s["ms"], 1e-9) / 1e6, 1)}
                           for s in stats[:10]]
     if rank == 0 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline((96, 96, 64), args.levels)   # ~10 s on the GPU box's 16 cores
+        sample = (96, 96, 64)       # ~15 s on the GPU box's 16 cores
+        cpu_raw, res["cpu_baseline"] = cpu_baseline(sample, args.levels)
+        if args.aniso == 1.0 and args.nu_pro == 0 and not args.correct_nullspace and args.blk == "8,8,4":
+            res["cpu_baseline"]["gpu_check"] = gpu_check_on_sample(capi, sample, args.levels, dev, args.theta, cpu_raw)
     if rank == 0:
         print(json.dumps(res), flush=True)
     grp.close()
