@@ -138,6 +138,16 @@ void saamge_amd_ml_free_data(saamge_amd_hierarchy *h);
 /* VCycleSolver::Mult with iterative_mode = false (inc/solve.hpp:129-143,
  * src/solve.cpp:309-323 -> tg_cycle_atb src/tg.cpp:91-132): x = B b */
 int saamge_amd_vcycle_mult(saamge_amd_hierarchy *h, const double *b, double *x);
+/* VCycleSolver::Mult for either iterative_mode (src/solve.cpp:309-323): iterative_mode != 0 keeps the
+ * caller's x as the start vector, x <- x + B (b - A x) (the cycle is a stationary linear iteration, so this
+ * equals tg_cycle_atb started from x). */
+int saamge_amd_vcycle(saamge_amd_hierarchy *h, const double *b, double *x, int iterative_mode);
+/* tg_data_t::coarse_solver (inc/tg_data.hpp:71; assigned by callers, e.g. test/algebraic/algebraic.cpp:282-283;
+ * invoked as coarse_solver.Mult(RESC, XC) with XC pre-zeroed, src/tg.cpp:110-126): replaces the library's
+ * coarsest solve by a host callback, xc = solve(rc) on `n` = coarsest dimension host doubles; return 0 on
+ * success.  NULL restores the built-in solver. */
+typedef int (*saamge_amd_coarse_solve_fn)(void *ctx, int n, const double *rc_host, double *xc_host);
+int saamge_amd_set_coarse_solver(saamge_amd_hierarchy *h, saamge_amd_coarse_solve_fn fn, void *ctx);
 /* smpr_sym_poly on one level (inc/smpr.hpp:59-60, src/smpr.cpp:213-234): x += M^-1 (b - A x) */
 int saamge_amd_smoother(saamge_amd_hierarchy *h, int level, const double *b, double *x);
 /* Outer Krylov loop: MFEM CGSolver as driven by test/mltest/mltest.cpp:773-781

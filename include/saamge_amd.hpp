@@ -2,14 +2,16 @@
 // implemented as thin adaptors over the C ABI (saamge_amd.h).
 //
 // Two layers:
-//   1. namespace saamge_amd::api  -- always available, raw arrays, same names / argument
-//      meaning / error behaviour (negative iteration count on failure, inc/tg.hpp:291-293)
-//      as the reference's free functions: ml_produce_data, ml_free_data, tg_cycle_atb's
-//      entry VCycleSolver::Mult, smpr_sym_poly, kalchev_pcg.
-//   2. namespace saamge (only when SAAMGE_AMD_WITH_MFEM is defined, i.e. where <mfem.hpp> and
-//      hypre exist -- not in the build container): VCycleSolver / SpectralAMGSolver-shaped
-//      mfem::Solver subclasses so that amg/test drivers link unchanged.  It converts
-//      HypreParMatrix / mfem::Vector to raw pointers (zero copy on the host, one upload).
+//   1. namespace saamge_amd::api (this file) -- always available, raw arrays, same names / argument
+//      order / error behaviour (negative iteration count on failure, inc/tg.hpp:291-293) as the
+//      reference's free functions: MultilevelParameters, ml_produce_data, ml_free_data,
+//      VCycleSolver::Mult, smpr_sym_poly, kalchev_pcg, adapt_update_operators.
+//   2. namespace saamge (saamge_amd_mfem.hpp, included from here when SAAMGE_AMD_WITH_MFEM is
+//      defined, i.e. where <mfem.hpp> and hypre exist -- not in the build container): the
+//      reference's own types and entry points -- agg_partitioning_relations_t,
+//      ElementMatrixProvider, MultilevelParameters, tg_data_t, ml_data_t, ml_produce_data,
+//      tg_produce_data, VCycleSolver, SpectralAMGSolver, kalchev_pcg -- so that an amg/test driver
+//      compiles and links against this library for the setup + solve path.
 #ifndef SAAMGE_AMD_HPP
 #define SAAMGE_AMD_HPP
 
@@ -22,36 +24,68 @@
 namespace saamge_amd {
 namespace api {
 
-// == MultilevelParameters (inc/ml.hpp:59-114): constructor argument order follows
-// src/ml.cpp:54-91 where it applies.
-struct MultilevelParameters {
-    saamge_amd_params p;
-    std::vector<int> nparts;
-    MultilevelParameters(int coarsenings, const int *nparts_arr, int first_nu_pro, int nu_pro,
-                         int nu_relax, double first_theta, double theta,
-                         bool use_correct_nullspace = false, bool use_arpack = false) {
+// == MultilevelParameters (inc/ml.hpp:59-114): the reference's 11-argument constructor
+// (inc/ml.hpp:66-70, src/ml.cpp:54-91), same argument order and getters.
+class MultilevelParameters {
+public:
+    MultilevelParameters(int coarsenings, int *nparts_arr, int first_nu_pro, int nu_pro, int nu_relax,
+                         double first_theta, double theta, int polynomial_coarse_space,
+                         bool use_correct_nullspace, bool use_arpack, bool do_aggregates)
+        : nparts_(nparts_arr, nparts_arr + coarsenings), polynomial_coarse_space_(coarsenings, polynomial_coarse_space),
+          use_arpack_(use_arpack), use_double_cycle_(false), coarse_direct_(false) {
+        if (coarsenings < 1 || coarsenings >= SAAMGE_AMD_MAX_LEVELS)
+            throw std::invalid_argument("MultilevelParameters: 1 <= coarsenings < SAAMGE_AMD_MAX_LEVELS");
         saamge_amd_params_default(&p);
-        p.correct_nullspace = use_correct_nullspace ? 1 : 0;   // CorrectNullspace on scaling_P (src/ml.cpp:225-236)
-        (void)use_arpack;  // the direct (dense) eigensolver path is always taken
         p.num_coarsenings = coarsenings;
-        nparts.assign(nparts_arr, nparts_arr + coarsenings);
-        for (int i = 0; i < coarsenings && i < SAAMGE_AMD_MAX_LEVELS; ++i) {
+        for (int i = 0; i < coarsenings; ++i) {
             p.theta[i] = i ? theta : first_theta;
             p.nu_pro[i] = i ? nu_pro : first_nu_pro;
             p.nu_relax[i] = nu_relax;
         }
+        p.correct_nullspace = use_correct_nullspace ? 1 : 0;   // CorrectNullspace on scaling_P (src/ml.cpp:225-236)
+        p.do_aggregates = do_aggregates ? 1 : 0;               // src/ml.cpp:149
+        p.avoid_ess_bdr_dofs = 1;                              // src/ml.cpp:64
+        // use_arpack: the reference switches to ARPACK above ARPACK_SIZE_THRESHOLD (inc/interp.hpp:104);
+        // this library always solves the local problems with its own batched eigensolver (same pairs).
+        // polynomial_coarse_space >= 0 asks for ExtendWithPolynomials / ExtendWithRBMs: the modes need the
+        // dof coordinates, so they are passed already evaluated through set_extra_coarse_modes(); a
+        // non-negative order without modes is refused at ml_produce_data.
     }
     int get_num_coarsenings() const { return p.num_coarsenings; }
+    int get_nu_pro(int j) const { return p.nu_pro[j]; }
+    int get_nu_relax(int j) const { return p.nu_relax[j]; }
+    double get_theta(int j) const { return p.theta[j]; }
+    bool get_smooth_interp(int j) const { return p.nu_pro[j] > 0; }
+    int get_polynomial_coarse_space(int j) const { return polynomial_coarse_space_[j]; }
     bool get_use_correct_nullspace() const { return p.correct_nullspace != 0; }
-    // polynomial / rigid-body coarse-space extension (ContribTent::ExtendWithPolynomials / RBMs): the
-    // modes are evaluated by the caller, n x count column-major
+    bool get_use_arpack() const { return use_arpack_; }
+    bool get_do_aggregates() const { return p.do_aggregates != 0; }
+    int get_nparts(int j) const { return nparts_[j]; }
+    bool get_avoid_ess_bdr_dofs() const { return p.avoid_ess_bdr_dofs != 0; }
+    bool get_use_double_cycle() const { return use_double_cycle_; }
+    double get_smooth_drop_tol() const { return p.smooth_drop_tol; }
+    void set_polynomial_coarse_space(int j, int val) { polynomial_coarse_space_[j] = val; }
+    void set_use_double_cycle(bool use) {
+        if (use) throw std::invalid_argument("MultilevelParameters: the double cycle is outside the hot path (SURVEY section 2)");
+        use_double_cycle_ = use;
+    }
+    bool get_coarse_direct() const { return coarse_direct_; }
+    void set_coarse_direct(bool cd) { coarse_direct_ = cd; p.coarse_solver = cd ? 1 : 0; }
+    void set_smooth_drop_tol(double tol) { p.smooth_drop_tol = tol; }
+    // ---- additions of this library ----
+    // polynomial / rigid-body coarse-space extension: modes evaluated by the caller, n x count column-major
     void set_extra_coarse_modes(const double *modes, int count) { p.extra_modes = modes; p.num_extra_modes = count; }
     // element-free mode (tg_produce_data_algebraic): pass NE = n, nde = 1 and NULL element arrays
     void set_algebraic(bool on, bool use_window = false) { p.algebraic = on ? (use_window ? 2 : 1) : 0; }
-    bool get_do_aggregates() const { return p.do_aggregates != 0; }
     void set_do_aggregates(bool on) { p.do_aggregates = on ? 1 : 0; }
-    double get_smooth_drop_tol() const { return p.smooth_drop_tol; }
-    void set_smooth_drop_tol(double tol) { p.smooth_drop_tol = tol; }
+    void set_eigensolver(int which) { p.eigensolver = which; }      // 0 few-eigenpairs (certified), 1 dense
+
+    saamge_amd_params p;
+    const int *nparts_data() const { return nparts_.data(); }
+
+private:
+    std::vector<int> nparts_, polynomial_coarse_space_;
+    bool use_arpack_, use_double_cycle_, coarse_direct_;
 };
 
 // Raw-array view of the reference's setup inputs (HypreParMatrix Ag, elem_to_dof Table,
@@ -70,11 +104,15 @@ struct ProblemArrays {
 typedef saamge_amd_hierarchy ml_data_t;  // inc/ml.hpp:118-120
 
 // ml_produce_data (inc/ml.hpp:192-194)
-inline ml_data_t *ml_produce_data(const ProblemArrays &a, const MultilevelParameters &mlp,
-                                  void *stream = nullptr) {
+inline ml_data_t *ml_produce_data(const ProblemArrays &a, const MultilevelParameters &mlp, void *stream = nullptr) {
+    for (int j = 0; j < mlp.get_num_coarsenings(); ++j)
+        if (mlp.get_polynomial_coarse_space(j) >= 0 && mlp.p.num_extra_modes == 0)
+            throw std::invalid_argument("polynomial_coarse_space >= 0: pass the evaluated modes with set_extra_coarse_modes()");
+    if ((int)a.partitions.size() < mlp.get_num_coarsenings())
+        throw std::invalid_argument("ml_produce_data: one partition array per coarsening is required");
     ml_data_t *h = nullptr;
-    if (saamge_amd_ml_produce_data(a.n, a.rowptr, a.col, a.val, a.NE, a.nde, a.elem_to_dof, a.elmat,
-                                   a.bdr_dofs, a.partitions.data(), mlp.nparts.data(), &mlp.p, stream, &h))
+    if (saamge_amd_ml_produce_data(a.n, a.rowptr, a.col, a.val, a.NE, a.nde, a.elem_to_dof, a.elmat, a.bdr_dofs,
+                                   a.partitions.data(), mlp.nparts_data(), &mlp.p, stream, &h))
         throw std::runtime_error(saamge_amd_last_error());
     return h;
 }
@@ -85,15 +123,14 @@ inline void adapt_update_operators(ml_data_t *h, const double *new_values) {
     if (saamge_amd_update_operators(h, new_values)) throw std::runtime_error(saamge_amd_last_error());
 }
 
-// VCycleSolver (inc/solve.hpp:129-143): Mult zeroes x (iterative_mode = false).
+// VCycleSolver (inc/solve.hpp:129-143, src/solve.cpp:309-323): Mult zeroes x unless iterative_mode.
 class VCycleSolver {
     ml_data_t *h_;
+    bool iterative_mode_;
 public:
-    explicit VCycleSolver(ml_data_t *h, bool iterative_mode = false) : h_(h) {
-        if (iterative_mode) throw std::invalid_argument("VCycleSolver: iterative_mode is not supported");
-    }
+    explicit VCycleSolver(ml_data_t *h, bool iterative_mode = false) : h_(h), iterative_mode_(iterative_mode) {}
     void Mult(const double *b, double *x) const {
-        if (saamge_amd_vcycle_mult(h_, b, x)) throw std::runtime_error(saamge_amd_last_error());
+        if (saamge_amd_vcycle(h_, b, x, iterative_mode_ ? 1 : 0)) throw std::runtime_error(saamge_amd_last_error());
     }
 };
 
@@ -102,14 +139,20 @@ inline void smpr_sym_poly(ml_data_t *h, int level, const double *b, double *x) {
     if (saamge_amd_smoother(h, level, b, x)) throw std::runtime_error(saamge_amd_last_error());
 }
 
-// kalchev_pcg (inc/mfem_addons.hpp:276): returns the iteration count, negative when the
-// loop did not converge (src/mfem_addons.cpp:226-231).
-inline int kalchev_pcg(ml_data_t *h, const double *b, double *x, int max_num_iter, double rtol,
-                       double atol, bool zero_guess = true) {
+// kalchev_pcg (inc/mfem_addons.hpp:276, src/mfem_addons.cpp:106-248) with B = the hierarchy's V-cycle:
+// iterates from the caller's x; stops when (B r, r) < max(RTOLERANCE (B r0, r0), ATOLERANCE);
+// returns the iteration count, its negative when the loop did not converge, -1 when the start vector
+// already satisfies the criterion (:150-162).  zero_rhs (the reference's A-norm stopping rule for b = 0,
+// :142-148, :205) is not implemented: refused.
+inline int kalchev_pcg(ml_data_t *h, const double *b, double *x, int print_iter = 0, int max_num_iter = 1000,
+                       double RTOLERANCE = 10e-12, double ATOLERANCE = 10e-24, bool zero_rhs = false) {
+    if (zero_rhs) throw std::invalid_argument("kalchev_pcg: zero_rhs (A-norm stopping rule) is not supported");
+    (void)print_iter;
     int iters = 0, conv = 0;
-    if (saamge_amd_pcg(h, b, x, rtol, atol, max_num_iter, /*squared_tol=*/0, zero_guess ? 1 : 0,
-                       &iters, &conv, nullptr))
+    if (saamge_amd_pcg(h, b, x, RTOLERANCE, ATOLERANCE, max_num_iter, /*squared_tol=*/0, /*zero_guess=*/0, &iters, &conv,
+                       nullptr))
         throw std::runtime_error(saamge_amd_last_error());
+    if (conv && iters == 0) return -1;
     return conv ? iters : -iters;
 }
 
@@ -117,49 +160,6 @@ inline int kalchev_pcg(ml_data_t *h, const double *b, double *x, int max_num_ite
 }  // namespace saamge_amd
 
 #ifdef SAAMGE_AMD_WITH_MFEM
-// ---------------------------------------------------------------------------------------
-// MFEM-facing adaptors (compiled only where MFEM + hypre headers exist).
-// ---------------------------------------------------------------------------------------
-#include <mfem.hpp>
-
-namespace saamge {
-
-// Drop-in for saamge::VCycleSolver (inc/solve.hpp:129-143) on top of a hierarchy produced by
-// saamge_amd::api::ml_produce_data.  Serial (one rank) HypreParMatrix only in this round.
-class VCycleSolver : public mfem::Solver {
-    saamge_amd_hierarchy *h_;
-public:
-    VCycleSolver(saamge_amd_hierarchy *h, bool iterative_mode_)
-        : mfem::Solver(0, iterative_mode_), h_(h) {
-        if (iterative_mode_) mfem::mfem_error("VCycleSolver: iterative_mode is not supported");
-    }
-    virtual void SetOperator(const mfem::Operator &op) {
-        if (!dynamic_cast<const mfem::HypreParMatrix *>(&op))
-            mfem::mfem_error("VCycleSolver::SetOperator : not HypreParMatrix!");  // src/solve.cpp:301-307
-        height = width = op.Height();
-    }
-    virtual void Mult(const mfem::Vector &b, mfem::Vector &x) const {
-        if (saamge_amd_vcycle_mult(h_, b.GetData(), x.GetData())) mfem::mfem_error(saamge_amd_last_error());
-    }
-};
-
-// Raw views of the reference's setup objects; see INTEGRATION.md for the full recipe.
-inline saamge_amd::api::ProblemArrays view_problem(mfem::SparseMatrix &Al, const mfem::Table &elem_to_dof,
-                                                   const double *elmats, int nde,
-                                                   const signed char *bdr_dofs) {
-    saamge_amd::api::ProblemArrays a;
-    a.n = Al.Height();
-    a.rowptr = Al.GetI();
-    a.col = Al.GetJ();
-    a.val = Al.GetData();
-    a.NE = elem_to_dof.Size();
-    a.nde = nde;
-    a.elem_to_dof = elem_to_dof.GetJ();
-    a.elmat = elmats;
-    a.bdr_dofs = bdr_dofs;
-    return a;
-}
-
-}  // namespace saamge
-#endif  // SAAMGE_AMD_WITH_MFEM
+#include "saamge_amd_mfem.hpp"
+#endif
 #endif  // SAAMGE_AMD_HPP

@@ -1,0 +1,523 @@
+// saamge_amd_mfem.hpp -- the reference's own C++ entry points for the setup + solve hot path, in
+// namespace saamge, as thin adaptors over the C ABI (saamge_amd.h).  Compiled only where MFEM + hypre
+// headers exist (SAAMGE_AMD_WITH_MFEM; not in the build container -- tests/test_cxx_boundary.py compiles it
+// against tests/mfem_stub/, a declaration-only stand-in for the handful of MFEM types used here).
+//
+// A driver written against <saamge.hpp> (amg/test/mltest/mltest.cpp:667-793 is the model) keeps its
+// call sequence:
+//     agg_part_rels = agg_create_partitioning_fine(A, NE, elem_to_dof, elem_to_elem, partitioning,
+//                                                  bdr_dofs, nparts, dof_truedof, do_aggregates);
+//     emp = new ElementMatrixStandardGeometric(*agg_part_rels, Al, a);
+//     MultilevelParameters mlp(coarsenings, nparts, first_nu_pro, nu_pro, nu_relax, first_theta, theta,
+//                              polynomial_coarse, correct_nulspace, use_arpack, do_aggregates);
+//     ml_data = ml_produce_data(*Ag, agg_part_rels, emp, mlp);
+//     level = levels_list_get_level(ml_data->levels_list, 0);
+//     Bprec = new VCycleSolver(level->tg_data, false);  Bprec->SetOperator(*Ag);
+//     CGSolver ... SetPreconditioner(*Bprec) ... Mult(b, x);
+//     ml_free_data(ml_data);  agg_free_partitioning(agg_part_rels);
+// What differs from the reference, by design: the topology tables, the local spectral problems, P, RAP
+// and the V-cycle live on the GPU; agg_partitioning_relations_t therefore carries the INPUTS of
+// agg_create_partitioning_fine (partitioning, elem_to_dof, flags) and the tables are fetched from the
+// hierarchy on request (agg_fetch_tables).  Coarse partitions (METIS in the reference,
+// src/part.cpp:170-183 -- third party) come from a hook, ml_set_coarse_partitioner(); the default cuts
+// the coarse elements into contiguous index ranges.  One MPI rank per GPU: the HypreParMatrix must be
+// the rank's whole matrix (serial hypre layout); multi-GPU runs go through the C ABI's rank / world
+// parameters.
+#ifndef SAAMGE_AMD_MFEM_HPP
+#define SAAMGE_AMD_MFEM_HPP
+
+#include <mfem.hpp>
+
+#include <cmath>
+#include <functional>
+#include <vector>
+
+#include "saamge_amd.hpp"
+
+namespace saamge {
+
+typedef char agg_dof_status_t;                       // inc/aggregates.hpp:115
+constexpr agg_dof_status_t AGG_BETWEEN_AES_FLAG = 0x01, AGG_ON_ESS_DOMAIN_BORDER_FLAG = 0x02,
+                           AGG_ON_PROC_IFACE_FLAG = 0x04, AGG_OWNED_FLAG = 0x08;     // :102-105
+
+// == agg_partitioning_relations_t (inc/aggregates.hpp:120-179), the fields drivers read.
+struct agg_partitioning_relations_t {
+    int ND = 0;                       // dofs
+    int nparts = 0;                   // AEs
+    int *partitioning = nullptr;      // element -> AE (owned, like the reference: src/aggregates.cpp:1834-1870)
+    mfem::Table *elem_to_dof = nullptr, *elem_to_elem = nullptr;      // owned
+    agg_dof_status_t *agg_flags = nullptr;                            // owned copy of bdr_dofs (BETWEEN added by agg_fetch_tables)
+    // filled by agg_fetch_tables() from a built hierarchy (NULL before):
+    mfem::Table *AE_to_dof = nullptr, *dof_to_AE = nullptr, *mis_to_dof = nullptr, *mis_to_AE = nullptr,
+                *AE_to_mis = nullptr;
+    int num_mises = 0;
+    int *mises = nullptr;
+    bool testmesh = false;
+    bool do_aggregates = false;
+    int NE = 0;
+};
+
+// agg_create_partitioning_fine (inc/aggregates.hpp:385-390, src/aggregates.cpp:1316-1355): takes ownership
+// of elem_to_dof, elem_to_elem and partitioning.  `partitioning` must be given (the reference calls METIS
+// when it is NULL -- third party, not reproduced); *nparts is the number of AEs.
+inline agg_partitioning_relations_t *agg_create_partitioning_fine(
+    mfem::HypreParMatrix &A, int NE, mfem::Table *elem_to_dof, mfem::Table *elem_to_elem, int *partitioning,
+    const agg_dof_status_t *bdr_dofs, int *nparts, mfem::HypreParMatrix *dof_truedof, bool do_aggregates,
+    bool testmesh = false) {
+    if (!partitioning) mfem::mfem_error("agg_create_partitioning_fine: a partitioning array is required (METIS is not part of this library)");
+    (void)dof_truedof;
+    agg_partitioning_relations_t *r = new agg_partitioning_relations_t;
+    r->ND = A.Height();
+    r->NE = NE;
+    r->nparts = *nparts;
+    r->partitioning = partitioning;
+    r->elem_to_dof = elem_to_dof;
+    r->elem_to_elem = elem_to_elem;
+    r->agg_flags = new agg_dof_status_t[r->ND];
+    for (int i = 0; i < r->ND; ++i) r->agg_flags[i] = bdr_dofs ? bdr_dofs[i] : AGG_OWNED_FLAG;
+    r->testmesh = testmesh;
+    r->do_aggregates = do_aggregates;
+    return r;
+}
+inline void agg_free_partitioning(agg_partitioning_relations_t *r) {     // src/aggregates.cpp:1834-1870
+    if (!r) return;
+    delete[] r->partitioning;
+    delete r->elem_to_dof;
+    delete r->elem_to_elem;
+    delete[] r->agg_flags;
+    delete r->AE_to_dof; delete r->dof_to_AE; delete r->mis_to_dof; delete r->mis_to_AE; delete r->AE_to_mis;
+    delete[] r->mises;
+    delete r;
+}
+
+// == ElementMatrixProvider (inc/elmat.hpp:53-78)
+class ElementMatrixProvider {
+public:
+    ElementMatrixProvider(const agg_partitioning_relations_t &agg_part_rels_) : agg_part_rels(agg_part_rels_), is_geometric(false) {}
+    virtual ~ElementMatrixProvider() {}
+    virtual mfem::Matrix *GetMatrix(int elno, bool &free_matr) const = 0;
+    // (the AE matrices are assembled on the GPU from the element matrices: a provider's BuildAEStiff is never called)
+    virtual mfem::SparseMatrix *BuildAEStiff(int elno) const { (void)elno; return nullptr; }
+    bool IsGeometric() { return is_geometric; }
+protected:
+    const agg_partitioning_relations_t &agg_part_rels;
+    bool is_geometric;
+};
+// == ElementMatrixStandardGeometric (inc/elmat.hpp:80-100, src/elmat.cpp:46-88): element matrices from the
+// bilinear form (no boundary conditions imposed: bdr_cond_imposed = true means the caller's global matrix has them)
+class ElementMatrixStandardGeometric : public ElementMatrixProvider {
+public:
+    ElementMatrixStandardGeometric(const agg_partitioning_relations_t &agg_part_rels_,
+                                   mfem::SparseMatrix *assembled_processor_matrix, mfem::ParBilinearForm *form_)
+        : ElementMatrixProvider(agg_part_rels_), assembled(assembled_processor_matrix), form(form_) { is_geometric = true; }
+    virtual mfem::Matrix *GetMatrix(int elno, bool &free_matr) const {
+        mfem::DenseMatrix *m = new mfem::DenseMatrix;
+        form->ComputeElementMatrix(elno, *m);
+        free_matr = true;
+        return m;
+    }
+private:
+    mfem::SparseMatrix *assembled;
+    mfem::ParBilinearForm *form;
+};
+
+// == MultilevelParameters (inc/ml.hpp:59-114): the same class as saamge_amd::api::MultilevelParameters
+// (11-argument constructor of inc/ml.hpp:66-70, getters / setters of :80-101)
+typedef saamge_amd::api::MultilevelParameters MultilevelParameters;
+
+// == smoother plug (inc/smpr.hpp:59-60) and polynomial smoother data (inc/smpr.hpp:89-108)
+typedef void (*smpr_ft)(mfem::HypreParMatrix &A, const mfem::Vector &b, mfem::Vector &x, void *data);
+struct smpr_poly_data_t {
+    saamge_amd_hierarchy *h;     // the hierarchy that owns D^-1 and the roots
+    int level;
+};
+// smpr_sym_poly (inc/smpr.hpp, src/smpr.cpp:213-234): x += M^-1 (b - A x) with the level's SAS polynomial
+inline void smpr_sym_poly(mfem::HypreParMatrix &A, const mfem::Vector &b, mfem::Vector &x, void *data) {
+    (void)A;
+    smpr_poly_data_t *d = (smpr_poly_data_t *)data;
+    if (saamge_amd_smoother(d->h, d->level, b.GetData(), x.GetData())) mfem::mfem_error(saamge_amd_last_error());
+}
+
+struct interp_data_t;       // (opaque here: the per-AE eigenpairs live on the GPU; saamge_amd_get_ae_eigens exports them)
+
+// == tg_data_t (inc/tg_data.hpp:47-83).  Ac / interp / restr are host copies for inspection; the GPU owns the
+// operators the cycle uses.  coarse_solver may be assigned by the caller (test/algebraic/algebraic.cpp:282-283):
+// VCycleSolver::Mult then routes the coarsest solve through it.
+struct tg_data_t {
+    interp_data_t *interp_data = nullptr;
+    mfem::HypreParMatrix *Ac = nullptr, *interp = nullptr, *restr = nullptr;
+    mfem::SparseMatrix *ltent_interp = nullptr;
+    mfem::HypreParMatrix *tent_interp = nullptr, *scaling_P = nullptr;
+    bool smooth_interp = false;
+    double theta = 0.0;
+    smpr_ft pre_smoother = smpr_sym_poly, post_smoother = smpr_sym_poly;
+    mfem::Solver *coarse_solver = nullptr;
+    smpr_poly_data_t *poly_data = nullptr;
+    bool use_w_cycle = false;
+    int polynomial_coarse_space = -1;
+    bool doing_spectral = true;
+    int tag = 0;
+    ElementMatrixProvider *elem_data = nullptr;
+    // ---- this library ----
+    saamge_amd_hierarchy *h = nullptr;     // shared by the tg_data of every level of one ml_data_t
+    int level = 0;
+    bool owns_h = false;
+    mfem::SparseMatrix *Ac_diag = nullptr, *interp_diag = nullptr, *restr_diag = nullptr;
+    HYPRE_Int row_starts[2][2];
+};
+
+// == levels (inc/levels.hpp:47-64)
+struct levels_level_t {
+    levels_level_t *finer = nullptr;
+    agg_partitioning_relations_t *agg_part_rels = nullptr;
+    tg_data_t *tg_data = nullptr;
+    levels_level_t *coarser = nullptr;
+};
+struct levels_list_t {
+    int num_levels = 0;
+    levels_level_t *finest = nullptr, *coarsest = nullptr;
+};
+inline levels_level_t *levels_list_get_level(const levels_list_t &l, int num) {     // inc/levels.hpp
+    levels_level_t *p = l.finest;
+    for (int i = 0; i < num && p; ++i) p = p->coarser;
+    return p;
+}
+struct ml_data_t {         // inc/ml.hpp:118-120
+    levels_list_t levels_list;
+};
+
+// Coarse partitions: partition(level k >= 1, number of level-k elements = AEs of level k-1, number of parts,
+// elem_to_elem of level k, out[n_elem]).  Default: contiguous index ranges.  Plug METIS here to reproduce the
+// reference's partitions (src/aggregates.cpp:1797-1804).
+typedef std::function<void(int level, int n_elem, int nparts, const mfem::Table &elem_to_elem, int *partition)> ml_partitioner_t;
+inline ml_partitioner_t &ml_coarse_partitioner() {
+    static ml_partitioner_t p = [](int, int n_elem, int nparts, const mfem::Table &, int *out) {
+        for (int e = 0; e < n_elem; ++e) out[e] = (int)((long long)e * nparts / n_elem);
+    };
+    return p;
+}
+inline void ml_set_coarse_partitioner(const ml_partitioner_t &p) { ml_coarse_partitioner() = p; }
+
+namespace detail {
+
+struct HostCsr {
+    std::vector<int> I, J;
+    std::vector<double> V;
+};
+// the rank's matrix as sorted CSR (hypre keeps the diagonal entry first in each row: src/mbox.cpp:1664-1667)
+inline HostCsr csr_of(mfem::HypreParMatrix &A) {
+    mfem::SparseMatrix diag;
+    A.GetDiag(diag);
+    const int n = diag.Height();
+    const int *I = diag.GetI(), *J = diag.GetJ();
+    const double *V = diag.GetData();
+    HostCsr c;
+    c.I.assign(I, I + n + 1);
+    c.J.resize((size_t)I[n]);
+    c.V.resize((size_t)I[n]);
+    std::vector<std::pair<int, double> > row;
+    for (int i = 0; i < n; ++i) {
+        row.clear();
+        for (int k = I[i]; k < I[i + 1]; ++k) row.push_back(std::make_pair(J[k], V[k]));
+        std::sort(row.begin(), row.end());
+        for (int k = I[i]; k < I[i + 1]; ++k) { c.J[(size_t)k] = row[(size_t)(k - I[i])].first; c.V[(size_t)k] = row[(size_t)(k - I[i])].second; }
+    }
+    return c;
+}
+inline mfem::Table *table_from(const saamge_amd_hierarchy *h, int level, int which) {
+    int nrows = 0;
+    long long nconn = 0;
+    if (saamge_amd_get_table(h, level, which, &nrows, &nconn, nullptr, nullptr)) mfem::mfem_error(saamge_amd_last_error());
+    std::vector<int> I((size_t)nrows + 1), J((size_t)nconn);
+    if (saamge_amd_get_table(h, level, which, nullptr, nullptr, I.data(), J.data())) mfem::mfem_error(saamge_amd_last_error());
+    mfem::Table *t = new mfem::Table;
+    t->SetDims(nrows, (int)nconn);
+    std::copy(I.begin(), I.end(), t->GetI());
+    std::copy(J.begin(), J.end(), t->GetJ());
+    return t;
+}
+// host copies of the level's operators as HypreParMatrix (one rank)
+inline void fetch_operators(tg_data_t &tg, MPI_Comm comm) {
+    long long info[16];
+    if (saamge_amd_level_info(tg.h, tg.level, info)) mfem::mfem_error(saamge_amd_last_error());
+    const int n = (int)info[0], nc = (int)info[4];
+    struct Sel { int which, rows, cols; long long nnz; mfem::SparseMatrix **diag; mfem::HypreParMatrix **par; };
+    Sel sel[3] = {{1, n, nc, info[5], &tg.interp_diag, &tg.interp},
+                  {2, nc, n, info[5], &tg.restr_diag, &tg.restr},
+                  {3, nc, nc, info[6], &tg.Ac_diag, &tg.Ac}};
+    tg.row_starts[0][0] = 0; tg.row_starts[0][1] = n;
+    tg.row_starts[1][0] = 0; tg.row_starts[1][1] = nc;
+    for (int q = 0; q < 3; ++q) {
+        int *I = new int[sel[q].rows + 1];
+        int *J = new int[sel[q].nnz];
+        double *V = new double[sel[q].nnz];
+        if (saamge_amd_get_csr(tg.h, tg.level, sel[q].which, I, J, V)) mfem::mfem_error(saamge_amd_last_error());
+        *sel[q].diag = new mfem::SparseMatrix(I, J, V, sel[q].rows, sel[q].cols);      // takes ownership of the arrays
+        HYPRE_Int *rs = sel[q].rows == n ? tg.row_starts[0] : tg.row_starts[1];
+        HYPRE_Int *cs = sel[q].cols == n ? tg.row_starts[0] : tg.row_starts[1];
+        *sel[q].par = new mfem::HypreParMatrix(comm, sel[q].rows, sel[q].cols, rs, cs, *sel[q].diag);
+    }
+}
+inline int coarse_solver_trampoline(void *ctx, int n, const double *rc, double *xc) {
+    mfem::Solver *s = *(mfem::Solver **)ctx;
+    mfem::Vector R(const_cast<double *>(rc), n), X(xc, n);
+    X = 0.0;                        // "XC pre-zeroed", src/tg.cpp:110-126
+    s->Mult(R, X);
+    return 0;
+}
+
+}  // namespace detail
+
+// ml_produce_data (inc/ml.hpp:192-194, src/ml.cpp:379-472).  Takes ownership of the provider (freed by
+// ml_free_data, like tg_free_data does in the reference, src/tg.cpp:946); agg_part_rels stays the caller's.
+// GetMatrix is called once per element.
+inline ml_data_t *ml_produce_data(mfem::HypreParMatrix &Ag, agg_partitioning_relations_t *agg_part_rels,
+                                  ElementMatrixProvider *elem_data_finest, const MultilevelParameters &mlp) {
+    const int nco = mlp.get_num_coarsenings();
+    agg_partitioning_relations_t &r = *agg_part_rels;
+    detail::HostCsr A = detail::csr_of(Ag);
+    const int n = Ag.Height(), NE = r.NE;
+    // element matrices, raw (row-major nde x nde per element); uniform element size required by the batched assembly
+    const int nde = r.elem_to_dof->RowSize(0);
+    std::vector<double> elmat((size_t)NE * nde * nde);
+    for (int e = 0; e < NE; ++e) {
+        if (r.elem_to_dof->RowSize(e) != nde) mfem::mfem_error("ml_produce_data: elements with different numbers of dofs are not supported");
+        bool free_matr = false;
+        mfem::Matrix *m = elem_data_finest->GetMatrix(e, free_matr);
+        for (int a = 0; a < nde; ++a)
+            for (int b = 0; b < nde; ++b) elmat[((size_t)e * nde + a) * nde + b] = m->Elem(a, b);
+        if (free_matr) delete m;
+    }
+    // partitions of every coarsening: level 0 from agg_part_rels, coarser ones from the partitioner hook on the
+    // AE adjacency graph elem_to_elem_{k+1} = AE_to_elem x elem_to_elem x elem_to_AE (src/aggregates.cpp:1768-1771)
+    std::vector<std::vector<int> > parts((size_t)nco);
+    std::vector<const int *> part_ptrs((size_t)nco);
+    parts[0].assign(r.partitioning, r.partitioning + NE);
+    mfem::Table *e2e = r.elem_to_elem;
+    std::vector<mfem::Table *> owned;
+    for (int k = 1; k < nco; ++k) {
+        const int n_el_prev = (int)parts[(size_t)k - 1].size(), n_el = mlp.get_nparts(k - 1);
+        mfem::Table e2AE;                                  // element -> AE of level k-1
+        e2AE.MakeI(n_el_prev);
+        for (int e = 0; e < n_el_prev; ++e) e2AE.AddAColumnInRow(e);
+        e2AE.MakeJ();
+        for (int e = 0; e < n_el_prev; ++e) e2AE.AddConnection(e, parts[(size_t)k - 1][(size_t)e]);
+        e2AE.ShiftUpI();
+        mfem::Table *AE2e = mfem::Transpose(e2AE);
+        mfem::Table *next = nullptr;
+        if (e2e) {
+            mfem::Table *t = mfem::Mult(*AE2e, *e2e);
+            next = mfem::Mult(*t, e2AE);
+            delete t;
+        } else {
+            next = new mfem::Table;
+        }
+        delete AE2e;
+        owned.push_back(next);
+        parts[(size_t)k].resize((size_t)n_el);
+        ml_coarse_partitioner()(k, n_el, mlp.get_nparts(k), *next, parts[(size_t)k].data());
+        e2e = next;
+    }
+    for (size_t i = 0; i < owned.size(); ++i) delete owned[i];
+    for (int k = 0; k < nco; ++k) part_ptrs[(size_t)k] = parts[(size_t)k].data();
+    std::vector<signed char> bdr((size_t)n);
+    for (int i = 0; i < n; ++i) bdr[(size_t)i] = (signed char)r.agg_flags[i];
+    saamge_amd_params p = mlp.p;
+    p.testmesh = r.testmesh ? 1 : 0;
+    std::vector<int> nparts((size_t)nco);
+    for (int k = 0; k < nco; ++k) nparts[(size_t)k] = mlp.get_nparts(k);
+    saamge_amd_hierarchy *h = nullptr;
+    if (saamge_amd_ml_produce_data(n, A.I.data(), A.J.data(), A.V.data(), NE, nde, r.elem_to_dof->GetJ(), elmat.data(),
+                                   bdr.data(), part_ptrs.data(), nparts.data(), &p, nullptr, &h))
+        mfem::mfem_error(saamge_amd_last_error());
+    // the list of levels (ml_produce_hierarchy_from_level, src/ml.cpp:111-236)
+    ml_data_t *ml = new ml_data_t;
+    levels_level_t *prev = nullptr;
+    for (int k = 0; k < nco; ++k) {
+        levels_level_t *lv = new levels_level_t;
+        tg_data_t *tg = new tg_data_t;
+        tg->h = h;
+        tg->level = k;
+        tg->owns_h = (k == 0);
+        tg->theta = mlp.get_theta(k);
+        tg->smooth_interp = mlp.get_smooth_interp(k);
+        tg->polynomial_coarse_space = mlp.get_polynomial_coarse_space(k);
+        tg->poly_data = new smpr_poly_data_t;
+        tg->poly_data->h = h;
+        tg->poly_data->level = k;
+        tg->elem_data = (k == 0) ? elem_data_finest : nullptr;
+        detail::fetch_operators(*tg, Ag.GetComm());
+        lv->tg_data = tg;
+        lv->agg_part_rels = (k == 0) ? agg_part_rels : nullptr;
+        lv->finer = prev;
+        if (prev) prev->coarser = lv; else ml->levels_list.finest = lv;
+        prev = lv;
+    }
+    ml->levels_list.coarsest = prev;
+    ml->levels_list.num_levels = nco;
+    return ml;
+}
+
+inline void tg_free_data(tg_data_t *tg) {           // inc/tg.hpp:576, src/tg.cpp:930-950
+    if (!tg) return;
+    delete tg->Ac; delete tg->interp; delete tg->restr;
+    delete tg->Ac_diag; delete tg->interp_diag; delete tg->restr_diag;
+    delete tg->poly_data;
+    delete tg->elem_data;
+    if (tg->owns_h) saamge_amd_ml_free_data(tg->h);
+    delete tg;
+}
+inline void ml_free_data(ml_data_t *ml) {           // inc/ml.hpp:196
+    if (!ml) return;
+    levels_level_t *lv = ml->levels_list.coarsest;  // (the finest level owns the hierarchy: freed last)
+    while (lv) {
+        levels_level_t *f = lv->finer;
+        tg_free_data(lv->tg_data);
+        delete lv;
+        lv = f;
+    }
+    delete ml;
+}
+
+// tg_produce_data (inc/tg.hpp:565-570): the two-level method = one coarsening
+inline tg_data_t *tg_produce_data(mfem::HypreParMatrix &Ag, const agg_partitioning_relations_t &agg_part_rels, int nu_pro,
+                                  int nu_relax, ElementMatrixProvider *elem_data_finest, double theta, bool smooth_interp,
+                                  int polynomial_coarse_arg, bool use_arpack, bool avoid_ess_bdr_dofs) {
+    (void)avoid_ess_bdr_dofs;       // always true in the reference (src/ml.cpp:64)
+    int nparts = agg_part_rels.nparts;
+    MultilevelParameters mlp(1, &nparts, smooth_interp ? nu_pro : 0, nu_pro, nu_relax, theta, theta, polynomial_coarse_arg,
+                             false, use_arpack, agg_part_rels.do_aggregates);
+    ml_data_t *ml = ml_produce_data(Ag, const_cast<agg_partitioning_relations_t *>(&agg_part_rels), elem_data_finest, mlp);
+    tg_data_t *tg = ml->levels_list.finest->tg_data;
+    delete ml->levels_list.finest;
+    delete ml;
+    return tg;
+}
+// tg_update_coarse_operator (inc/tg.hpp:610-612): the matrix values changed, interpolation kept
+inline void tg_update_coarse_operator(mfem::HypreParMatrix &A, tg_data_t *tg_data, bool perform_solve_init, bool coarse_direct) {
+    (void)perform_solve_init; (void)coarse_direct;
+    detail::HostCsr c = detail::csr_of(A);
+    if (saamge_amd_update_operators(tg_data->h, c.V.data())) mfem::mfem_error(saamge_amd_last_error());
+}
+
+// Tables built on the GPU, on request (agg_partitioning_relations_t fields of inc/aggregates.hpp:120-179)
+inline void agg_fetch_tables(agg_partitioning_relations_t &r, const ml_data_t &ml) {
+    const saamge_amd_hierarchy *h = ml.levels_list.finest->tg_data->h;
+    r.AE_to_dof = detail::table_from(h, 0, 0);
+    r.dof_to_AE = detail::table_from(h, 0, 1);
+    r.mis_to_dof = detail::table_from(h, 0, 2);
+    r.mis_to_AE = detail::table_from(h, 0, 3);
+    r.AE_to_mis = detail::table_from(h, 0, 4);
+    r.num_mises = r.mis_to_dof->Size();
+    r.mises = new int[r.ND];
+    std::vector<signed char> flags((size_t)r.ND);
+    if (saamge_amd_get_mis(h, 0, r.mises, nullptr, nullptr, flags.data())) mfem::mfem_error(saamge_amd_last_error());
+    for (int i = 0; i < r.ND; ++i) r.agg_flags[i] = (agg_dof_status_t)flags[(size_t)i];
+}
+inline void ml_get_dims(const ml_data_t &ml, mfem::Array<int> &dims) {      // inc/ml.hpp (ml_get_dims)
+    const saamge_amd_hierarchy *h = ml.levels_list.finest->tg_data->h;
+    const int nl = ml.levels_list.num_levels;
+    dims.SetSize(nl + 1);
+    for (int l = 0; l < nl; ++l) {
+        long long info[16];
+        if (saamge_amd_level_info(h, l, info)) mfem::mfem_error(saamge_amd_last_error());
+        dims[l] = (int)info[0];
+        dims[l + 1] = (int)info[4];
+    }
+}
+
+// == VCycleSolver (inc/solve.hpp:129-143, src/solve.cpp:290-323)
+class VCycleSolver : public mfem::Solver {
+public:
+    VCycleSolver(tg_data_t *tg_data_in, bool iterative_mode_)
+        : mfem::Solver(tg_data_in->restr->Width(), iterative_mode_), tg_data(tg_data_in), A(NULL), plugged(NULL) {
+        if (tg_data->level != 0) mfem::mfem_error("VCycleSolver: only the finest level's tg_data can be cycled from outside");
+    }
+    virtual ~VCycleSolver() {}
+    virtual void SetOperator(const mfem::Operator &op) {
+        A = const_cast<mfem::HypreParMatrix *>(dynamic_cast<const mfem::HypreParMatrix *>(&op));
+        if (A == NULL) mfem::mfem_error("VCycleSolver::SetOperator : not HypreParMatrix!");     // src/solve.cpp:301-307
+    }
+    virtual void Mult(const mfem::Vector &b, mfem::Vector &x) const {
+        // a coarse_solver assigned by the caller takes over the coarsest solve (tg_data_t::coarse_solver plug)
+        if (tg_data->coarse_solver != plugged) {
+            plugged = tg_data->coarse_solver;
+            if (saamge_amd_set_coarse_solver(tg_data->h, plugged ? detail::coarse_solver_trampoline : nullptr,
+                                             (void *)&tg_data->coarse_solver))
+                mfem::mfem_error(saamge_amd_last_error());
+        }
+        if (saamge_amd_vcycle(tg_data->h, b.GetData(), x.GetData(), iterative_mode ? 1 : 0)) mfem::mfem_error(saamge_amd_last_error());
+    }
+    // the PCG loop of kalchev_pcg on the GPU with this cycle as the preconditioner
+    int pcg(const double *b, double *x, int print_iter, int max_num_iter, double RTOLERANCE, double ATOLERANCE,
+            bool zero_rhs) const {
+        try {
+            return saamge_amd::api::kalchev_pcg(tg_data->h, b, x, print_iter, max_num_iter, RTOLERANCE, ATOLERANCE, zero_rhs);
+        } catch (const std::exception &e) {
+            mfem::mfem_error(e.what());
+        }
+        return 0;
+    }
+private:
+    tg_data_t *tg_data;
+    mfem::HypreParMatrix *A;
+    mutable mfem::Solver *plugged;
+};
+
+// == SpectralAMGSolver (inc/solve.hpp:149-177, src/solve.cpp:167-230).  The reference derives the partition
+// with METIS from the mesh (fem_create_partitioning -- third party, out of the hot path); here the element
+// partition is an argument.  polynomial_coarse = -1: corrected null-space level, like the reference.
+class SpectralAMGSolver : public mfem::Solver {
+public:
+    SpectralAMGSolver(mfem::HypreParMatrix &Ag, mfem::ParBilinearForm &aform, mfem::SparseMatrix &Alocal,
+                      const agg_dof_status_t *bdr_dofs, mfem::Table *elem_to_dof, mfem::Table *elem_to_elem,
+                      int *partitioning, int nparts0, int elems_per_agg, int num_levels, int nu_pro, int nu_relax,
+                      double theta, int polynomial_coarse, bool coarse_direct)
+        : mfem::Solver(Ag.Height(), false), Ag_(Ag) {
+        nparts_arr_ = new int[num_levels - 1];
+        nparts_arr_[0] = nparts0;
+        for (int i = 1; i < num_levels - 1; ++i) {
+            nparts_arr_[i] = (int)std::floor((double)nparts_arr_[i - 1] / (double)elems_per_agg + 0.5);
+            if (nparts_arr_[i] < 1) nparts_arr_[i] = 1;
+        }
+        agg_part_rels_ = agg_create_partitioning_fine(Ag, elem_to_dof->Size(), elem_to_dof, elem_to_elem, partitioning,
+                                                      bdr_dofs, nparts_arr_, nullptr, false);
+        ElementMatrixProvider *emp = new ElementMatrixStandardGeometric(*agg_part_rels_, &Alocal, &aform);
+        const bool correct_nulspace = (polynomial_coarse == -1);
+        MultilevelParameters mlp(num_levels - 1, nparts_arr_, nu_pro, nu_pro, nu_relax, theta, theta, polynomial_coarse,
+                                 correct_nulspace, true, false);
+        if (coarse_direct) mlp.set_coarse_direct(true);
+        ml_data_ = ml_produce_data(Ag_, agg_part_rels_, emp, mlp);
+        v_cycle_ = new VCycleSolver(levels_list_get_level(ml_data_->levels_list, 0)->tg_data, false);
+        v_cycle_->SetOperator(Ag_);
+    }
+    ~SpectralAMGSolver() {
+        delete[] nparts_arr_;
+        delete v_cycle_;
+        ml_free_data(ml_data_);
+        agg_free_partitioning(agg_part_rels_);
+    }
+    void SetOperator(const mfem::Operator &op) { (void)op; }       // "implemented in constructor", src/solve.cpp:219-223
+    void Mult(const mfem::Vector &x, mfem::Vector &y) const { v_cycle_->Mult(x, y); }
+private:
+    mfem::HypreParMatrix &Ag_;
+    int *nparts_arr_;
+    agg_partitioning_relations_t *agg_part_rels_;
+    ml_data_t *ml_data_;
+    VCycleSolver *v_cycle_;
+};
+
+// kalchev_pcg (inc/mfem_addons.hpp:276, src/mfem_addons.cpp:106-248) for B = a VCycleSolver of this library:
+// the loop runs on the GPU (device vectors, one scalar read-back per iteration); any other preconditioner
+// belongs in MFEM's own CGSolver.
+inline int kalchev_pcg(const mfem::HypreParMatrix &A, const mfem::Operator &B, const mfem::HypreParVector &b,
+                       mfem::HypreParVector &x, int print_iter, int max_num_iter, double RTOLERANCE, double ATOLERANCE,
+                       bool zero_rhs) {
+    (void)A;
+    const VCycleSolver *vc = dynamic_cast<const VCycleSolver *>(&B);
+    if (!vc) mfem::mfem_error("kalchev_pcg: B must be a saamge::VCycleSolver of this library");
+    return vc->pcg(b.GetData(), x.GetData(), print_iter, max_num_iter, RTOLERANCE, ATOLERANCE, zero_rhs);
+}
+
+}  // namespace saamge
+#endif  // SAAMGE_AMD_MFEM_HPP

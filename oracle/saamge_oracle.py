@@ -717,6 +717,23 @@ def vcycle(H, b, level=0):
     return x
 
 
+def vcycle_iterative(H, b, x0, coarse=None):
+    """VCycleSolver::Mult with iterative_mode = true (src/solve.cpp:309-323): tg_cycle_atb (src/tg.cpp:91-132)
+    started from the caller's x on the finest level; coarser levels start from zero as always.
+    `coarse`: replacement for the coarsest solve (tg_data_t::coarse_solver plug)."""
+    lv = H.levels[0]
+    x = x0.copy()
+    compute_poly(lv.A, b, x, lv.roots, lv.Dinv_neg)
+    rc = lv.R @ (b - lv.A @ x)
+    if len(H.levels) > 1:
+        xc = vcycle(H, rc, 1)
+    else:
+        xc = coarse(rc) if coarse is not None else coarse_solve(H, rc)
+    x += lv.P @ xc
+    compute_poly(lv.A, b, x, lv.roots, lv.Dinv_neg)
+    return x
+
+
 def pcg(A, prec, b, x0=None, rel_tol=1e-6, abs_tol=0.0, max_iter=1000, squared_tol=True):
     """MFEM CGSolver::Mult as driven by amg/test/mltest/mltest.cpp:773-781
     (``SetRelTol(1e-6)``, "MFEM squares this") -- the same loop as kalchev_pcg

@@ -22,11 +22,13 @@ SYMBOLS = [
     "saamge_amd_get_mis", "saamge_amd_get_ae_eigens", "saamge_amd_get_mis_svd", "saamge_amd_spmv",
     "saamge_amd_lower_eigens_batched", "saamge_amd_profile_enable", "saamge_amd_profile_reset",
     "saamge_amd_profile_count", "saamge_amd_profile_get", "saamge_amd_memcpy",
-    "saamge_amd_update_operators", "saamge_amd_inertia_batched",
+    "saamge_amd_update_operators", "saamge_amd_inertia_batched", "saamge_amd_vcycle",
+    "saamge_amd_set_coarse_solver",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong))
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_longlong)
+COARSE_SOLVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double))
 ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p,
                            C.POINTER(C.c_longlong))
 
@@ -238,6 +240,31 @@ class Hierarchy(object):
             x = np.zeros_like(b)
         _check(load().saamge_amd_vcycle_mult(self.h, _ptr(b), _ptr(x)))
         return x
+
+    def vcycle_iterative(self, b, x):
+        """VCycleSolver::Mult with iterative_mode = true: x <- x + B (b - A x)."""
+        _check(load().saamge_amd_vcycle(self.h, _ptr(b), _ptr(x), C.c_int(1)))
+        return x
+
+    def set_coarse_solver(self, fn):
+        """tg_data_t::coarse_solver plug: fn(rc: ndarray) -> xc: ndarray on the host, or None for the built-in solver."""
+        if fn is None:
+            self._coarse_cb = None
+            _check(load().saamge_amd_set_coarse_solver(self.h, None, None))
+            return
+
+        def tramp(ctx, n, rc, xc):
+            try:
+                r = np.ctypeslib.as_array(rc, shape=(n,))
+                out = np.ctypeslib.as_array(xc, shape=(n,))
+                out[:] = fn(r.copy())
+                return 0
+            except Exception as e:
+                import sys
+                print("coarse solver callback failed: %r" % (e,), file=sys.stderr)
+                return 1
+        self._coarse_cb = COARSE_SOLVE_FN(tramp)
+        _check(load().saamge_amd_set_coarse_solver(self.h, self._coarse_cb, None))
 
     def smoother(self, level, b, x):
         _check(load().saamge_amd_smoother(self.h, C.c_int(level), _ptr(b), _ptr(x)))

@@ -184,6 +184,33 @@ int saamge_amd_vcycle_mult(saamge_amd_hierarchy *h, const double *b, double *x) 
     SA_API_END
 }
 
+int saamge_amd_vcycle(saamge_amd_hierarchy *h, const double *b, double *x, int iterative_mode) {
+    if (!iterative_mode) return saamge_amd_vcycle_mult(h, b, x);
+    SA_API_BEGIN
+    SA_REQUIRE(h && b && x, "null argument");
+    Hierarchy &H = *h->H;
+    require_device(H);
+    Level &L0 = *H.levels[0];
+    SA_REQUIRE(!L0.dist.on, "iterative_mode is not available on a row-partitioned hierarchy");
+    const size_t n = (size_t)L0.A.nrows;
+    VecIn vb(b, n, H.stream);
+    VecOut vx(x, n, H.stream, true);
+    // x <- x + B (b - A x)
+    spmv_residual(H.stream, L0.A, vx.p, vb.p, H.pcg_r.p);
+    vcycle_apply(H, 0, H.pcg_r.p, H.pcg_z.p);
+    vec_axpy(H.stream, (int)n, 1.0, H.pcg_z.p, vx.p);
+    vx.finish();
+    SA_API_END
+}
+
+int saamge_amd_set_coarse_solver(saamge_amd_hierarchy *h, saamge_amd_coarse_solve_fn fn, void *ctx) {
+    SA_API_BEGIN
+    SA_REQUIRE(h, "null argument");
+    h->H->user_coarse_solve = fn;
+    h->H->user_coarse_ctx = ctx;
+    SA_API_END
+}
+
 int saamge_amd_smoother(saamge_amd_hierarchy *h, int level, const double *b, double *x) {
     SA_API_BEGIN
     SA_REQUIRE(h && b && x, "null argument");

@@ -116,6 +116,9 @@ struct Hierarchy {              // ml_data_t
     // PCG scratch
     DBuf<double> pcg_r, pcg_z, pcg_d, pcg_q, scal, partials;
     int last_coarse_iters = 0;
+    // tg_data_t::coarse_solver plug: host callback replacing the built-in coarsest solve
+    int (*user_coarse_solve)(void *ctx, int n, const double *rc_host, double *xc_host) = nullptr;
+    void *user_coarse_ctx = nullptr;
     DBuf<int> own_e2d;          // element-free mode: the generated identity elem_to_dof
 };
 

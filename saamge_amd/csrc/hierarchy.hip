@@ -774,6 +774,17 @@ static int pcg_loop(Hierarchy &H, const DCsr &A, const std::function<void(const 
 static void coarse_solve(Hierarchy &H, const double *rc, double *xc) {
     const DCsr &Ac = coarsest_op(H);
     if (Ac.nrows == 0) return;
+    if (H.user_coarse_solve) {      // tg_data_t::coarse_solver assigned by the caller (host solver)
+        const size_t n = (size_t)Ac.nrows;
+        hvec<double> hr(n), hx(n, 0.0);
+        SA_HIP_CHECK(hipMemcpyAsync(hr.data(), rc, 8 * n, hipMemcpyDeviceToHost, H.stream));
+        SA_HIP_CHECK(hipStreamSynchronize(H.stream));
+        SA_REQUIRE(H.user_coarse_solve(H.user_coarse_ctx, (int)n, hr.data(), hx.data()) == 0, "user coarse solver failed");
+        SA_HIP_CHECK(hipMemcpyAsync(xc, hx.data(), 8 * n, hipMemcpyHostToDevice, H.stream));
+        SA_HIP_CHECK(hipStreamSynchronize(H.stream));
+        H.last_coarse_iters = 0;
+        return;
+    }
     if (H.coarse_kind == 1) {
         // x = X b and one step of iterative refinement, x += X (b - Ac x): the elimination's round-off
         // (~cond(Ac) eps) is pushed to the level of the residual evaluation

@@ -1,0 +1,46 @@
+// TEST: the call sequence of an amg/test driver (amg/test/mltest/mltest.cpp:667-793, test/algebraic/algebraic.cpp:282-283)
+// against include/saamge_amd.hpp with SAAMGE_AMD_WITH_MFEM, compiled (not linked) against tests/mfem_stub.
+#include "saamge_amd.hpp"
+
+using namespace mfem;
+using namespace saamge;
+
+int mock_driver(HypreParMatrix *Ag, SparseMatrix *Al, ParBilinearForm *a, Table *elem_to_dof, Table *elem_to_elem,
+                int *partitioning, const agg_dof_status_t *bdr_dofs, HypreParVector *bg, HypreParVector *pxg,
+                Solver *my_coarse_solver, int num_levels, int elems_per_agg) {
+    int *nparts_arr = new int[num_levels - 1];
+    nparts_arr[0] = elem_to_dof->Size() / elems_per_agg;
+    for (int i = 1; i < num_levels - 1; ++i) nparts_arr[i] = nparts_arr[i - 1] / elems_per_agg;
+    agg_partitioning_relations_t *agg_part_rels = agg_create_partitioning_fine(
+        *Ag, elem_to_dof->Size(), elem_to_dof, elem_to_elem, partitioning, bdr_dofs, nparts_arr, NULL, false);
+    ElementMatrixProvider *emp = new ElementMatrixStandardGeometric(*agg_part_rels, Al, a);
+    const int first_nu_pro = 0, nu_pro = 0, nu_relax = 3, polynomial_coarse = -1;
+    const double first_theta = 0.003, theta = 0.003;
+    const bool correct_nulspace = true, direct_eigensolver = true, do_aggregates = false;
+    MultilevelParameters mlp(num_levels - 1, nparts_arr, first_nu_pro, nu_pro, nu_relax, first_theta, theta, polynomial_coarse,
+                             correct_nulspace, !direct_eigensolver, do_aggregates);      // the reference's 11 arguments
+    mlp.set_coarse_direct(true);
+    mlp.set_smooth_drop_tol(0.0);
+    ml_data_t *ml_data = ml_produce_data(*Ag, agg_part_rels, emp, mlp);
+    levels_level_t *level = levels_list_get_level(ml_data->levels_list, 0);
+    tg_data_t *tg = level->tg_data;
+    const int nc = tg->Ac->Height() + tg->interp->Width() + tg->restr->Height();       // fields read directly by callers
+    tg->coarse_solver = my_coarse_solver;                                              // test/algebraic/algebraic.cpp:282-283
+    tg->tag = 1;
+    Solver *Bprec = new VCycleSolver(tg, false);
+    Bprec->SetOperator(*Ag);
+    Bprec->Mult(*bg, *pxg);
+    VCycleSolver it(tg, true);                                                         // iterative_mode
+    it.SetOperator(*Ag);
+    it.Mult(*bg, *pxg);
+    const int iters = kalchev_pcg(*Ag, *Bprec, *bg, *pxg, 0, 1000, 1e-12, 1e-24, false);
+    tg->pre_smoother(*Ag, *bg, *pxg, tg->poly_data);                                   // smpr_ft plug
+    Array<int> dims;
+    ml_get_dims(*ml_data, dims);
+    agg_fetch_tables(*agg_part_rels, *ml_data);
+    delete Bprec;
+    ml_free_data(ml_data);
+    agg_free_partitioning(agg_part_rels);
+    delete[] nparts_arr;
+    return iters + nc + dims.Size();
+}
