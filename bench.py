@@ -66,13 +66,26 @@ KERNELS = {
 }
 
 
+# BASELINE.json configs as bench workloads (config 1 is the reference's CPU-only ctest case: tests/test_oracle_kat.py).
+# aniso128: theta = 1e-4 keeps exactly the four z-constant modes of an interior 8x8x4-element agglomerate
+# (generalised eigenvalues 0, 0.371e-4 (twice), 0.723e-4, then 1.444e-4: "4 eigenvectors/aggregate"); three
+# levels, so that the coarsest operator stays small enough for the direct coarsest solve; the second coarsening
+# uses 4x4x2-AE blocks and theta = 1e-5 (2-4 vectors per level-1 agglomerate: with 8x8x4 blocks the ~8 400-row
+# level-1 agglomerates carry more than the six pairs the few-eigenpairs path takes and fall back to the dense path).
+WORKLOADS = {
+    "poisson256": {"n": 256, "levels": 3, "theta": 0.003, "aniso": 1.0, "theta2": None},
+    "poisson128": {"n": 128, "levels": 2, "theta": 0.003, "aniso": 1.0, "theta2": None},
+    "aniso128": {"n": 128, "levels": 3, "theta": 1e-4, "aniso": 1000.0, "theta2": 1e-5, "coarse_blk": "4,4,2"},
+}
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_problem(n, levels, dev, aniso=1.0, blk=(8, 8, 4)):
+def build_problem(n, levels, dev, aniso=1.0, blk=(8, 8, 4), coarse_blk=(8, 8, 4)):
     from saamge_amd import problems
-    cb = [(8, 8, 4)] * (levels - 2)
+    cb = [tuple(coarse_blk)] * (levels - 2)
     return problems.poisson3d_device(n, blk=blk, coarse_blk=cb, K=(1.0, 1.0, aniso), device=dev)
 
 
@@ -134,7 +147,7 @@ def gpu_check_on_sample(capi, n_sample, levels, dev, theta, cpu):
 
 def pmc_traffic(symbol, n, levels):
     """Per-launch HBM bytes of `symbol` from the committed PMC passes of this command."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
         d = json.load(open(path))
     except Exception:
@@ -177,17 +190,29 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", "--n", dest="n", type=int, default=256)
-    ap.add_argument("--levels", type=int, default=3)
-    ap.add_argument("--theta", type=float, default=0.003)
-    ap.add_argument("--aniso", type=float, default=1.0, help="K = diag(1, 1, aniso) (BASELINE config 4: 1000)")
+    ap.add_argument("--workload", default="poisson256", choices=sorted(WORKLOADS),
+                    help="BASELINE.json configs: poisson256 = config 3 (the metric's configuration, default), poisson128 = "
+                         "config 2, aniso128 = config 4; --n / --levels / --theta / --aniso override the preset")
+    ap.add_argument("--size", "--n", dest="n", type=int, default=None)
+    ap.add_argument("--levels", type=int, default=None)
+    ap.add_argument("--theta", type=float, default=None)
+    ap.add_argument("--theta2", type=float, default=None, help="spectral tolerance of the coarsenings after the first (default: --theta)")
+    ap.add_argument("--aniso", type=float, default=None, help="K = diag(1, 1, aniso) (BASELINE config 4: 1000)")
     ap.add_argument("--blk", type=str, default="8,8,4", help="elements per AE along x,y,z (experiments)")
+    ap.add_argument("--coarse-blk", type=str, default=None, help="AEs per coarse AE along x,y,z (default 8,8,4)")
     ap.add_argument("--correct-nullspace", action="store_true",
                     help="extra scaling_P level under the coarsest spectral operator (reference drivers' default)")
     ap.add_argument("--nu-pro", type=int, default=0, help="prolongator smoothing degree (0 = tentative, the reference default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    for k, v in WORKLOADS[args.workload].items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    if args.theta2 is None:
+        args.theta2 = args.theta
+    if args.coarse_blk is None:
+        args.coarse_blk = "8,8,4"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus, sys.argv[1:])
 
@@ -204,10 +229,14 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with `python bench.py --gpus N` or "
                          "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
 
-    prob = build_problem(args.n, args.levels, dev, args.aniso, tuple(int(v) for v in args.blk.split(",")))
+    prob = build_problem(args.n, args.levels, dev, args.aniso, tuple(int(v) for v in args.blk.split(",")),
+                         tuple(int(v) for v in args.coarse_blk.split(",")))
     torch.cuda.synchronize()
     params = capi.default_params(num_coarsenings=args.levels - 1, theta=args.theta, nu_relax=3, nu_pro=args.nu_pro,
                                  correct_nullspace=args.correct_nullspace)
+    if args.theta2 is not None:      # first_theta / theta of the reference's MultilevelParameters (inc/ml.hpp:66-70)
+        for l in range(1, capi.MAX_LEVELS):
+            params.theta[l] = args.theta2
 
     its = conv = None
     for _ in range(args.warmup):
@@ -244,9 +273,12 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "3D Poisson %d^3 Q1 hexes%s, %d-level SAAMGE, theta=%g, nu_relax=3, "
-                               "8x8x4-element AEs%s" % (args.n, "" if args.aniso == 1.0 else
-                                                       " K=diag(1,1,%g)" % args.aniso, args.levels, args.theta,
+        "config": {"workload_id": args.workload,
+                   "workload": "3D Poisson %d^3 Q1 hexes%s, %d-level SAAMGE, theta=%s, nu_relax=3, "
+                               "8x8x4-element AEs, %s-AE coarse blocks%s" % (args.n, "" if args.aniso == 1.0 else
+                                                       " K=diag(1,1,%g)" % args.aniso, args.levels,
+                                                       ("%g" % args.theta) if args.theta2 == args.theta else "%g / %g (first / later coarsenings)" % (args.theta, args.theta2),
+                                                       args.coarse_blk.replace(",", "x"),
                                                        ("" if args.nu_pro == 0 else ", nu_pro=%d" % args.nu_pro) +
                                                        (", corrected null-space level" if args.correct_nullspace else "")),
                    "eigenvectors_per_AE": [round(i["nvec"] / max(i["nparts"], 1), 2) for i in infos],
@@ -276,7 +308,7 @@ def main():
         d = stats[0]
         symbol, bound = KERNELS.get(d["name"], (d["name"], "hbm"))
         avg_ms = d["ms"] / d["launches"]
-        traffic = pmc_traffic(symbol, args.n, args.levels)
+        traffic = pmc_traffic(symbol, args.n, args.levels) if args.workload == "poisson256" else None
         if bound == "hbm":
             ach = d["bytes"] / d["ms"] / 1e6
             res["roofline"] = {"kernel": symbol, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
@@ -292,7 +324,9 @@ def main():
         res["kernels"] = [{"name": s["name"], "ms": round(s["ms"], 3), "launches": s["launches"],
                            "GBps": round(s["bytes"] / max(s["ms"], 1e-9) / 1e6, 1)}
                           for s in stats[:10]]
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and args.workload != "poisson256":
+        log("bench.py: cpu_baseline is timed on the default workload only (poisson256)")
+    if rank == 0 and not args.no_cpu_baseline and args.workload == "poisson256":
         sample = (96, 96, 64)       # ~15 s on the GPU box's 16 cores
         cpu_raw, res["cpu_baseline"] = cpu_baseline(sample, args.levels)
         if args.aniso == 1.0 and args.nu_pro == 0 and not args.correct_nullspace and args.blk == "8,8,4":
