@@ -160,7 +160,7 @@ def pmc_traffic(symbol, n, levels):
     return (2.0 * k["fetch_bytes_raw"] + k["write_bytes"]) / k["launches"]
 
 
-def spawn_ranks(n, argv):
+def spawn_ranks(n, argv, script=None):
     """`python bench.py --gpus N` without a launcher: N child processes, one per GPU, started before
     this process imports torch or touches the GPU (a process that initialised the GPU must never be
     re-executed).  Rank 0's JSON line is relayed; any failing rank fails the run."""
@@ -174,7 +174,7 @@ def spawn_ranks(n, argv):
     for r in range(n):
         env = dict(os.environ, WORLD_SIZE=str(n), RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     rcs = [p.wait() for p in procs]
@@ -223,7 +223,10 @@ def main():
     local_dev = local_rank % max(torch.cuda.device_count(), 1)   # (rehearsals put 2 ranks on one GPU)
     torch.cuda.set_device(local_dev)
     dev = "cuda:%d" % local_dev
-    grp = Group(backend=os.environ.get("SAAMGE_AMD_DIST_BACKEND", "nccl"), device=dev)
+    backend = os.environ.get("SAAMGE_AMD_DIST_BACKEND", "nccl")
+    # collectives: the library's own RCCL communicator (SAAMGE_AMD_DIST_COMM=torch: callbacks into torch.distributed)
+    native = backend == "nccl" and os.environ.get("SAAMGE_AMD_DIST_COMM", "native") != "torch"
+    grp = Group(backend=backend, device=dev, native=native)
     world, rank = grp.world, grp.rank
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with `python bench.py --gpus N` or "
@@ -285,6 +288,8 @@ def main():
                    "dofs": prob.n, "pcg_iterations": its, "converged": bool(conv),
                    "true_relative_residual": relres,
                    "level_dims": [i["n"] for i in infos] + [infos[-1]["ncoarse"]],
+                   "collectives": ("RCCL inside the library (csrc/comm.hip)" if native else "torch.distributed callbacks (%s)" % backend)
+                   if world > 1 else None,
                    "parallelism": ("%d ranks: per-AE spectral problems, RAP and coarse element matrices sharded + "
                                    "all-gathered; levels %s solved row-partitioned (halo exchange per SpMV, "
                                    "all-reduced dots); topology/MIS SVD/P and smaller levels replicated"

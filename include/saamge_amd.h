@@ -104,6 +104,20 @@ typedef struct saamge_amd_params {
 } saamge_amd_params;
 
 void saamge_amd_params_default(saamge_amd_params *p);
+
+/* ---- native collectives: RCCL over xGMI, one process per GPU (csrc/comm.hip) --------------------------------
+ * Rank 0 draws a unique id and ships it to the other ranks by any means (MPI_Bcast, a file, torch.distributed's
+ * store); every rank then creates its communicator on the stream its hierarchy will run on and installs it in
+ * the parameters: rank, world and the three collectives are filled in, comm_stream_ordered = 1.  The
+ * allgather / allreduce_sum / alltoallv callbacks remain the plug for MPI host codes. */
+typedef struct saamge_amd_comm saamge_amd_comm;
+int saamge_amd_comm_unique_id(char id[128]);
+int saamge_amd_comm_create(int rank, int world, const char id[128], void *stream, saamge_amd_comm **out);
+void saamge_amd_comm_destroy(saamge_amd_comm *c);
+int saamge_amd_params_set_comm(saamge_amd_params *p, saamge_amd_comm *c);
+/* one all-reduce, all-gather and all-to-all of known data, checked: 0 = the communicator works */
+int saamge_amd_comm_selftest(saamge_amd_comm *c);
+const char *saamge_amd_comm_last_error(void);
 /* hipMemcpy(hipMemcpyDefault) helper for all-gather callbacks written outside C (host or device
  * pointers on either side) */
 int saamge_amd_memcpy(void *dst, const void *src, long long bytes);

@@ -23,7 +23,8 @@ SYMBOLS = [
     "saamge_amd_lower_eigens_batched", "saamge_amd_profile_enable", "saamge_amd_profile_reset",
     "saamge_amd_profile_count", "saamge_amd_profile_get", "saamge_amd_memcpy",
     "saamge_amd_update_operators", "saamge_amd_inertia_batched", "saamge_amd_vcycle",
-    "saamge_amd_set_coarse_solver",
+    "saamge_amd_set_coarse_solver", "saamge_amd_comm_unique_id", "saamge_amd_comm_create", "saamge_amd_comm_destroy",
+    "saamge_amd_params_set_comm", "saamge_amd_comm_selftest", "saamge_amd_comm_last_error",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong))
@@ -166,7 +167,14 @@ class Hierarchy(object):
         caller_params = params
         params = Params.from_buffer_copy(params)      # the caller's struct is never modified
         self._keep_params = caller_params             # (keeps extra_modes alive)
-        if group is not None and group.world > 1:
+        if group is not None and group.world > 1 and getattr(group, "native", False):
+            # the library's own RCCL collectives (csrc/comm.hip), enqueued on the hierarchy's stream
+            rc = lib.saamge_amd_params_set_comm(C.byref(params), group.native_comm(stream))
+            assert rc == 0
+            if not dist_solve:
+                params.allreduce_sum = ALLREDUCE_FN(0)
+                params.alltoallv = ALLTOALLV_FN(0)
+        elif group is not None and group.world > 1:
             # distributed setup: this rank solves the eigenproblems of its AE range only;
             # distributed solve: large levels are applied by row blocks with halo exchange
             self._cb = group.allgather_callback()

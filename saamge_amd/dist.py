@@ -26,7 +26,14 @@ def _fail_fast(what, e):
 
 
 class Group(object):
-    def __init__(self, backend=None, device=None, host_buffers=False):
+    def __init__(self, backend=None, device=None, host_buffers=False, native=False):
+        """native: the collectives of setup and solve run inside the library on its own RCCL communicator
+        (csrc/comm.hip: no Python in the solve loop); torch.distributed is then only the launcher's rendezvous
+        (unique-id broadcast, barrier, max-over-ranks timing).  Otherwise the library calls back into
+        torch.distributed (gloo rehearsals, MPI-style host codes)."""
+        self.native = bool(native)
+        self._comm = None
+        self._comm_stream = None
         self.host_buffers = bool(host_buffers)
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
@@ -44,6 +51,29 @@ class Group(object):
                 kw["device_id"] = torch.device(device)
             dist.init_process_group(backend or "gloo", **kw)
             self.dist = dist
+
+    def native_comm(self, stream=0):
+        """saamge_amd_comm of this rank on `stream` (created once; rank 0's unique id travels through
+        torch.distributed)."""
+        import ctypes as C
+        from . import capi
+        if self._comm is not None:
+            assert self._comm_stream == int(stream or 0), "one communicator per stream"
+            return self._comm
+        lib = capi.load()
+        lib.saamge_amd_comm_last_error.restype = C.c_char_p
+        buf = C.create_string_buffer(128)
+        if self.rank == 0 and lib.saamge_amd_comm_unique_id(buf):
+            raise RuntimeError("saamge_amd: " + lib.saamge_amd_comm_last_error().decode())
+        obj = [buf.raw]
+        if self.dist is not None:
+            self.dist.broadcast_object_list(obj, src=0)
+        comm = C.c_void_p()
+        if lib.saamge_amd_comm_create(C.c_int(self.rank), C.c_int(self.world), obj[0], C.c_void_p(int(stream or 0)),
+                                      C.byref(comm)):
+            raise RuntimeError("saamge_amd: " + lib.saamge_amd_comm_last_error().decode())
+        self._comm, self._comm_stream = comm, int(stream or 0)
+        return comm
 
     def barrier(self):
         if self.dist is not None:
@@ -253,6 +283,10 @@ class Group(object):
         return self.world * units_per_rank * steps / self.max_time(dt)
 
     def close(self):
+        if self._comm is not None:
+            from . import capi
+            capi.load().saamge_amd_comm_destroy(self._comm)
+            self._comm = None
         if self.dist is not None:
             self.dist.destroy_process_group()
             self.dist = None
