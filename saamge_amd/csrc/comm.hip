@@ -15,6 +15,7 @@
 // under the same SONAME) shares it, and the library loads on machines without RCCL as long as no
 // communicator is asked for.
 #include <dlfcn.h>
+#include <link.h>
 #include <rccl/rccl.h>
 
 #include <mutex>
@@ -42,8 +43,15 @@ RcclApi &rccl() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, []() {
+        // ONE RCCL per process: if any librccl is already mapped (PyTorch-ROCm ships its own copy under its own
+        // path and SONAME), that one is used; a second copy in the same process breaks both at teardown
+        std::string loaded;
+        dl_iterate_phdr([](struct dl_phdr_info *info, size_t, void *data) -> int {
+            if (info->dlpi_name && std::strstr(info->dlpi_name, "librccl")) { *(std::string *)data = info->dlpi_name; return 1; }
+            return 0;
+        }, &loaded);
+        void *h = loaded.empty() ? nullptr : dlopen(loaded.c_str(), RTLD_NOW | RTLD_NOLOAD);
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        void *h = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD);        // the copy this process already uses, if any
         for (int i = 0; !h && i < 3; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
         if (!h) return;
         api.lib = h;

@@ -193,8 +193,17 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     std::thread mis_thread([&]() {
         try {
             adopt_device(dev);   // the worker allocates and copies: same GPU as the caller
-            build_relations_mis(L.rel, aggregates ? &aggA : nullptr);
-            upload_relations_mis(L.drel, L.rel, mis_stream);
+            // MIS tables on the device (SAAMGE_AMD_HOST_MIS=1: host build); aggregates with arbitration are
+            // sequential by definition and stay on the host
+            static const bool host_mis = std::getenv("SAAMGE_AMD_HOST_MIS") != nullptr;
+            PhaseTimer tmis(mis_stream);
+            bool on_dev = false;
+            if (!aggregates && !host_mis) on_dev = build_relations_mis_device(L.rel, L.drel, mis_stream);
+            if (on_dev) tmis.lap("    device MIS tables", lev);
+            if (!on_dev) {
+                build_relations_mis(L.rel, aggregates ? &aggA : nullptr);
+                upload_relations_mis(L.drel, L.rel, mis_stream);
+            }
             SA_HIP_CHECK(hipStreamSynchronize(mis_stream));
         } catch (...) { mis_err = std::current_exception(); }
     });

@@ -73,5 +73,8 @@ bool build_relations_ae_device(Relations &r, DevRelations &d, const int *e2d_dev
                                const int *part_dev, int nparts, int ND, const signed char *bdr_dev,
                                hipStream_t s);
 void upload_relations_mis(DevRelations &d, const Relations &r, hipStream_t s);
+// build_relations_mis + upload_relations_mis on the device (topology_mis.hip): same tables bit for bit; needs the AE
+// half of `d`.  Returns false when the level has to take the host path (hash collision, invalid partition).
+bool build_relations_mis_device(Relations &r, DevRelations &d, hipStream_t s);
 
 }  // namespace saamge_amd
