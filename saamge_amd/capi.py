@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsaamge_amd.so")
+LIB_PATH = os.environ.get("SAAMGE_AMD_LIB") or os.path.join(_HERE, "libsaamge_amd.so")
 
 MAX_LEVELS = 8
 
@@ -82,7 +82,8 @@ def _share_hip_runtime_with_torch():
         spec = importlib.util.find_spec("torch")
         if spec is None or not spec.submodule_search_locations:
             return
-        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        cand = os.path.join(libdir, "libamdhip64.so")
         if os.path.exists(cand):
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
     except Exception:

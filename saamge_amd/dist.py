@@ -56,6 +56,7 @@ class Group(object):
         """saamge_amd_comm of this rank on `stream` (created once; rank 0's unique id travels through
         torch.distributed)."""
         import ctypes as C
+        import torch  # noqa: F401  (first: csrc/comm.hip binds to the RCCL the process already maps, and that must be torch's)
         from . import capi
         if self._comm is not None:
             assert self._comm_stream == int(stream or 0), "one communicator per stream"

@@ -148,22 +148,48 @@ def test_rccl_callbacks_on_raw_device_pointers(tmp_path):
     assert p.returncode == 0 and b"ok" in p.stdout, p.stdout.decode()[-3000:]
 
 
-def test_native_rccl_communicator_single_rank():
-    """csrc/comm.hip on one rank: RCCL is found at run time, a communicator comes up on the GPU and the three
-    primitives (all-reduce, all-gather, all-to-all) return what the arithmetic says.  More ranks need more
-    GPUs than the test box has (two RCCL ranks cannot share a device): the multi-rank data path is covered by
-    the gloo tests above, which drive the same library code through the callback plug."""
-    import ctypes as C
-    from saamge_amd import capi
+NATIVE_WORKER = textwrap.dedent("""
+    import sys, os
+    sys.path.insert(0, %r)
+    import torch, ctypes as C
+    import torch.distributed as dist
+    from saamge_amd import capi, problems
+    from saamge_amd.dist import Group
+    torch.cuda.set_device(0)
+    os.environ.update(WORLD_SIZE="1", RANK="0")
+    # the sequence of a bench.py rank: torch.distributed (RCCL) for the rendezvous, then the library's own communicator
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    g = Group(backend="nccl", device="cuda:0", native=True)
+    g.dist = dist
+    comm = g.native_comm(0)
     lib = capi.load()
     lib.saamge_amd_comm_last_error.restype = C.c_char_p
-    buf = C.create_string_buffer(128)
-    assert lib.saamge_amd_comm_unique_id(buf) == 0, lib.saamge_amd_comm_last_error()
-    comm = C.c_void_p()
-    assert lib.saamge_amd_comm_create(C.c_int(0), C.c_int(1), buf.raw, C.c_void_p(0), C.byref(comm)) == 0, \
-        lib.saamge_amd_comm_last_error()
     assert lib.saamge_amd_comm_selftest(comm) == 0, lib.saamge_amd_comm_last_error()
     p = capi.default_params(num_coarsenings=1)
     assert lib.saamge_amd_params_set_comm(C.byref(p), comm) == 0
     assert p.world == 1 and p.rank == 0 and p.comm_stream_ordered == 1 and bool(p.allreduce_sum) and bool(p.alltoallv)
-    lib.saamge_amd_comm_destroy(comm)
+    # a hierarchy next to the communicator, like the bench's roofline leg
+    prob = problems.poisson3d_device((16, 16, 8), blk=(8, 8, 4), device="cuda:0")
+    h = capi.Hierarchy(prob.rowptr, prob.col, prob.val, prob.n, prob.elem_to_dof, prob.elmat, prob.bdr, prob.partitions,
+                       prob.nparts, capi.default_params(num_coarsenings=1), prob.NE_, 8)
+    x = torch.zeros_like(prob.b)
+    _, it, conv, hist = h.pcg(prob.b, x, rel_tol=1e-8)
+    assert conv
+    h.close()
+    g.close()
+    print("ok")
+""" % ROOT)
+
+
+def test_native_rccl_communicator_single_rank(tmp_path):
+    """csrc/comm.hip on one rank, in the process layout of a bench.py rank (torch.distributed's RCCL for the
+    rendezvous + the library's own communicator): RCCL is found at run time (the copy the process already maps),
+    the three primitives (all-reduce, all-gather, all-to-all) return what the arithmetic says, and the process
+    exits cleanly.  More ranks need more GPUs than the test box has (two RCCL ranks cannot share a device): the
+    multi-rank data path is covered by the gloo tests above, which drive the same library code through the
+    callback plug."""
+    script = tmp_path / "native_worker.py"
+    script.write_text(NATIVE_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0 and b"ok" in p.stdout, p.stdout.decode()[-3000:]
