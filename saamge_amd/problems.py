@@ -101,7 +101,8 @@ def _eliminate(A, b, ess):
 # --------------------------------------------------------------------------
 MLTEST_PARTITION = np.array([0, 0, 1, 1, 0, 0, 2, 2, 3, 3, 3, 2], dtype=np.int32)
 MLTEST_COARSE_PARTITION = np.array([0, 0, 1, 1], dtype=np.int32)
-# 2-rank fixture: element -> rank and per-rank AE maps (mltest.cpp:230-241,279-286)
+MLTEST_VERTEX_Y = (0.0, 0.333333333, 0.666666667, 1.0)        # amg/test/mltest.mesh, vertex rows
+# 2-rank fixture `pmltest`: element -> rank and per-rank AE maps (mltest.cpp:230-241,279-286)
 MLTEST_RANK_OF_ELEM = np.array([0] * 6 + [1] * 6, dtype=np.int32)
 MLTEST_PARTITION_2RANKS = [np.array([0, 0, 1, 1, 0, 0], dtype=np.int32),
                            np.array([0, 0, 1, 1, 1, 0], dtype=np.int32)]
@@ -121,7 +122,7 @@ def checkerboard_coef(x, y, z=None):
 
 
 def quad_mesh_problem(nx, ny, lx=1.0, ly=1.0, order=1, coef="checkerboard",
-                      ess_sides=("left",), partition=None):
+                      ess_sides=("left",), partition=None, vertex_y=None):
     """2-D tensor grid of rectangles with Q1/Q2 Lagrange elements.
 
     Vertex numbering is row-major (x fastest), which is exactly mltest.mesh's
@@ -135,6 +136,11 @@ def quad_mesh_problem(nx, ny, lx=1.0, ly=1.0, order=1, coef="checkerboard",
     ex, ey = np.meshgrid(np.arange(nx), np.arange(ny), indexing="xy")
     ex = ex.ravel()
     ey = ey.ravel()
+    # `vertex_y`: the y coordinates of the vertex rows as a mesh FILE stores them (mltest.mesh keeps
+    # 0.333333333 / 0.666666667): the element heights are then what MFEM computes from the file
+    yv = np.arange(ny + 1) * hy if vertex_y is None else np.asarray(vertex_y, dtype=float)
+    assert yv.size == ny + 1
+    hy_e = (yv[1:] - yv[:-1])[ey]                # height of every element
     nvx, nvy = nx + 1, ny + 1
     vid = lambda i, j: j * nvx + i
     M1, K1, L1 = _lagrange_1d(order)
@@ -145,7 +151,7 @@ def quad_mesh_problem(nx, ny, lx=1.0, ly=1.0, order=1, coef="checkerboard",
         # tensor index (ix, iy) of each local dof in MFEM order
         loc = [(0, 0), (1, 0), (1, 1), (0, 1)]
         xs = np.tile(np.arange(nvx) * hx, nvy)
-        ys = np.repeat(np.arange(nvy) * hy, nvx)
+        ys = np.repeat(yv, nvx)
     elif order == 2:
         nV = nvx * nvy
         nEx = nx * nvy          # horizontal edges
@@ -162,28 +168,27 @@ def quad_mesh_problem(nx, ny, lx=1.0, ly=1.0, order=1, coef="checkerboard",
         ys = np.zeros(ND)
         for k, (ix, iy) in enumerate(loc):
             xs[elem_to_dof[:, k]] = (ex + 0.5 * ix) * hx
-            ys[elem_to_dof[:, k]] = (ey + 0.5 * iy) * hy
+            ys[elem_to_dof[:, k]] = yv[ey] + 0.5 * iy * hy_e
     else:
         raise ValueError("order must be 1 or 2")
     nde = len(loc)
     n1 = order + 1
     # reference element matrix in tensor ordering (ix fastest): K = Kx(x)My + Mx(x)Ky
-    Kt = (hy / hx) * np.kron(M1, K1) + (hx / hy) * np.kron(K1, M1)
-    Lt = hx * hy * np.kron(L1, L1)
     perm = np.array([iy * n1 + ix for (ix, iy) in loc])
-    Kref = Kt[np.ix_(perm, perm)]
-    Lref = Lt[perm]
+    KxMy, MxKy = np.kron(M1, K1)[np.ix_(perm, perm)], np.kron(K1, M1)[np.ix_(perm, perm)]
+    Kel = (hy_e / hx)[:, None, None] * KxMy[None] + (hx / hy_e)[:, None, None] * MxKy[None]
+    Lel = (hx * hy_e)[:, None] * np.kron(L1, L1)[perm][None]
     cx = (ex + 0.5) * hx
-    cy = (ey + 0.5) * hy
+    cy = yv[ey] + 0.5 * hy_e
     if coef == "checkerboard":
         c = checkerboard_coef(cx, cy)
     else:
         c = np.full(NE, float(coef))
-    elmat = c[:, None, None] * Kref[None, :, :]
+    elmat = c[:, None, None] * Kel
     elem_to_dof = elem_to_dof.astype(np.int32)
     A0 = _assemble(ND, elem_to_dof, elmat)
     b0 = np.zeros(ND)
-    np.add.at(b0, elem_to_dof.ravel(), np.tile(Lref, NE))
+    np.add.at(b0, elem_to_dof.ravel(), Lel.ravel())
     eps = 1e-12
     ess = np.zeros(ND, dtype=bool)
     for s in ess_sides:
@@ -205,15 +210,15 @@ def quad_mesh_problem(nx, ny, lx=1.0, ly=1.0, order=1, coef="checkerboard",
 
 def mltest_problem(order=1, levels=2):
     """The reference's ctest fixture `mltest` / `mltest2` / `threelevel`
-    (amg/CMakeLists.txt:191-217): mltest.mesh (4x3 rectangles on the unit square;
-    the file's 0.333333333 vertex coordinates are taken as exact thirds),
+    (amg/CMakeLists.txt:191-217): mltest.mesh (4x3 rectangles on the unit square with the vertex
+    rows at y = 0, 0.333333333, 0.666666667, 1 exactly as the file stores them),
     checkerboard 1e6/1 coefficient sampled at element centres, essential boundary
     = attribute 4 (x = 0), f = 1, hard-coded AE maps."""
     parts = [MLTEST_PARTITION.copy()]
     if levels >= 3:
         parts.append(MLTEST_COARSE_PARTITION.copy())
     return quad_mesh_problem(4, 3, order=order, coef="checkerboard",
-                             ess_sides=("left",), partition=parts)
+                             ess_sides=("left",), partition=parts, vertex_y=MLTEST_VERTEX_Y)
 
 
 def quad_elasticity_matrix(hx, hy, lam=1.0, mu=1.0):
@@ -254,8 +259,9 @@ def mltest_elasticity_problem(levels=2):
     vid = lambda i, j: j * nvx + i
     e2v = np.stack([vid(ex, ey), vid(ex + 1, ey), vid(ex + 1, ey + 1), vid(ex, ey + 1)], axis=1)
     elem_to_dof = (2 * e2v[:, :, None] + np.arange(2)[None, None, :]).reshape(NE, 8).astype(np.int32)
+    yv = np.asarray(MLTEST_VERTEX_Y)             # the file's vertex rows: element heights as MFEM sees them
     Kref = quad_elasticity_matrix(hx, hy)
-    elmat = np.ascontiguousarray(np.broadcast_to(Kref, (NE, 8, 8)))
+    elmat = np.ascontiguousarray(np.stack([quad_elasticity_matrix(hx, yv[j + 1] - yv[j]) for j in ey]))
     A0 = _assemble(ND, elem_to_dof, elmat)
     ess = np.repeat((np.arange(NV) % nvx) == 0, 2)
     A, b = _eliminate(A0, np.zeros(ND), ess)

@@ -49,6 +49,37 @@ def test_kat_elasticity_3_iterations():
         assert np.abs(x[~prob.ess]).max() <= 1e-3     # the solution of A x = 0 with x_ess kept
 
 
+def test_kat_pmltest_two_rank_numbering_3_iterations():
+    """amg/CMakeLists.txt:198-203: `mpirun -np 2 mltest` (pmltest) -> 3 iterations.  The two ranks own elements
+    0-5 and 6-11 (mltest.cpp:279-286) and number their agglomerates locally (mltest.cpp:230-241): globally
+    that is the serial fixture's four AEs under another numbering -- rank 1's AEs come after rank 0's.  The
+    hierarchy must not depend on how the agglomerates are numbered: same dimensions, and with the level-1
+    V-cycle as coarse solver (threelevel) the reference's 3 iterations."""
+    glob = np.empty(12, dtype=np.int32)
+    base = 0
+    for r in (0, 1):
+        own = np.nonzero(pr.MLTEST_RANK_OF_ELEM == r)[0]
+        glob[own] = base + pr.MLTEST_PARTITION_2RANKS[r]
+        base += int(pr.MLTEST_PARTITION_2RANKS[r].max()) + 1
+    assert base == 4
+    # the same four element sets as the serial map
+    sets = lambda p: sorted(tuple(np.nonzero(p == a)[0]) for a in range(4))
+    assert sets(glob) == sets(pr.MLTEST_PARTITION)
+    prob = pr.mltest_problem(order=1, levels=3)
+    ref = o.ml_produce_data(prob.A, prob.elem_to_dof, prob.elmat, prob.bdr, prob.partitions, theta=0.003, nu_relax=3)
+    # coarse map in the new numbering: serial AE a -> new id perm[a]; serial coarse map {0,0,1,1}
+    perm = np.array([glob[np.nonzero(pr.MLTEST_PARTITION == a)[0][0]] for a in range(4)])
+    coarse = np.empty(4, dtype=np.int32)
+    coarse[perm] = pr.MLTEST_COARSE_PARTITION
+    H = o.ml_produce_data(prob.A, prob.elem_to_dof, prob.elmat, prob.bdr, [glob, coarse], theta=0.003, nu_relax=3)
+    assert [lv.A.shape[0] for lv in H.levels] == [lv.A.shape[0] for lv in ref.levels]
+    assert H.levels[-1].Ac.shape[0] == ref.levels[-1].Ac.shape[0]
+    x, it, conv, hist = o.solve(H, prob.b, rel_tol=1e-6)
+    xr, itr, convr, histr = o.solve(ref, prob.b, rel_tol=1e-6)
+    assert conv and it == itr == 3
+    assert np.allclose(hist, histr, rtol=1e-9)
+
+
 def test_kat_mltest_bracketed_by_coarse_solver():
     """amg/CMakeLists.txt:191-196: `mltest` -> 3 iterations with ONE BoomerAMG V-cycle as the
     coarsest solver (third-party, unpinned).  With an exact coarsest solve the count is 2;
