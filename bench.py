@@ -76,6 +76,11 @@ WORKLOADS = {
     "poisson256": {"n": 256, "levels": 3, "theta": 0.003, "aniso": 1.0, "theta2": None},
     "poisson128": {"n": 128, "levels": 2, "theta": 0.003, "aniso": 1.0, "theta2": None},
     "aniso128": {"n": 128, "levels": 3, "theta": 1e-4, "aniso": 1000.0, "theta2": 1e-5, "coarse_blk": "4,4,2"},
+    # BASELINE config 5: 3-D linear elasticity, Q2 hexes (81 dofs per element), 4x4x4-element agglomerates of
+    # 9^3 nodes x 3 = 2187 dofs carrying the six rigid-body modes, clamped on x = 0.  64^3 (6.44 M dofs, 1.24e9
+    # stored entries, ~140 GB of HBM in use) is the preset; the operator's 32-bit row offsets end at 72^3 (1.76e9
+    # entries): BASELINE's 96^3 (4.17e9) needs 64-bit offsets, which the reference's own int cannot hold either
+    "elasticity_q2": {"n": 64, "levels": 4, "theta": 0.003, "aniso": 1.0, "theta2": None, "blk": "4,4,4", "coarse_blk": "2,2,2"},
 }
 
 
@@ -83,16 +88,18 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_problem(n, levels, dev, aniso=1.0, blk=(8, 8, 4), coarse_blk=(8, 8, 4)):
+def build_problem(n, levels, dev, aniso=1.0, blk=(8, 8, 4), coarse_blk=(8, 8, 4), workload="poisson"):
     from saamge_amd import problems
     cb = [tuple(coarse_blk)] * (levels - 2)
+    if workload == "elasticity_q2":
+        return problems.elasticity3d_q2_device(n, blk=blk, coarse_blk=cb, device=dev)
     return problems.poisson3d_device(n, blk=blk, coarse_blk=cb, K=(1.0, 1.0, aniso), device=dev)
 
 
 def one_step(capi, prob, params, rel_tol=1e-8, group=None):
     import torch
     h = capi.Hierarchy(prob.rowptr, prob.col, prob.val, prob.n, prob.elem_to_dof, prob.elmat,
-                       prob.bdr, prob.partitions, prob.nparts, params, prob.NE_, 8, group=group)
+                       prob.bdr, prob.partitions, prob.nparts, params, prob.NE_, getattr(prob, "nde_", 8), group=group)
     x = torch.zeros_like(prob.b)
     _, it, conv, hist = h.pcg(prob.b, x, rel_tol=rel_tol, max_iter=200)
     return h, x, it, conv, hist
@@ -198,7 +205,7 @@ def main():
     ap.add_argument("--theta", type=float, default=None)
     ap.add_argument("--theta2", type=float, default=None, help="spectral tolerance of the coarsenings after the first (default: --theta)")
     ap.add_argument("--aniso", type=float, default=None, help="K = diag(1, 1, aniso) (BASELINE config 4: 1000)")
-    ap.add_argument("--blk", type=str, default="8,8,4", help="elements per AE along x,y,z (experiments)")
+    ap.add_argument("--blk", type=str, default=None, help="elements per AE along x,y,z (default 8,8,4; elasticity_q2: 4,4,4)")
     ap.add_argument("--coarse-blk", type=str, default=None, help="AEs per coarse AE along x,y,z (default 8,8,4)")
     ap.add_argument("--correct-nullspace", action="store_true",
                     help="extra scaling_P level under the coarsest spectral operator (reference drivers' default)")
@@ -213,6 +220,8 @@ def main():
         args.theta2 = args.theta
     if args.coarse_blk is None:
         args.coarse_blk = "8,8,4"
+    if args.blk is None:
+        args.blk = "8,8,4"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus, sys.argv[1:])
 
@@ -233,8 +242,10 @@ def main():
                          "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
 
     prob = build_problem(args.n, args.levels, dev, args.aniso, tuple(int(v) for v in args.blk.split(",")),
-                         tuple(int(v) for v in args.coarse_blk.split(",")))
+                         tuple(int(v) for v in args.coarse_blk.split(",")),
+                         "elasticity_q2" if args.workload == "elasticity_q2" else "poisson")
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()        # the generator's temporaries go back to the device before the library allocates
     params = capi.default_params(num_coarsenings=args.levels - 1, theta=args.theta, nu_relax=3, nu_pro=args.nu_pro,
                                  correct_nullspace=args.correct_nullspace)
     if args.theta2 is not None:      # first_theta / theta of the reference's MultilevelParameters (inc/ml.hpp:66-70)
@@ -264,7 +275,7 @@ def main():
     h.close()
 
     res = {
-        "metric": "AMG setup+solve DoF/s (3D Poisson, PCG to 1e-8)",
+        "metric": "AMG setup+solve DoF/s (%s, PCG to 1e-8)" % ("3D elasticity Q2" if args.workload == "elasticity_q2" else "3D Poisson"),
         "value": prob.n * args.steps / dt,
         "unit": "DoF/s",
         "n_gpus": world,
@@ -277,7 +288,10 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload_id": args.workload,
-                   "workload": "3D Poisson %d^3 Q1 hexes%s, %d-level SAAMGE, theta=%s, nu_relax=3, "
+                   "workload": ("3D linear elasticity %d^3 Q2 hexes (81 dofs per element, lambda = mu = 1, clamped on x = 0), "
+                                "%d-level SAAMGE, theta=%g, nu_relax=3, %s-element AEs, %s-AE coarse blocks"
+                                % (args.n, args.levels, args.theta, args.blk.replace(",", "x"), args.coarse_blk.replace(",", "x")))
+                   if args.workload == "elasticity_q2" else "3D Poisson %d^3 Q1 hexes%s, %d-level SAAMGE, theta=%s, nu_relax=3, "
                                "8x8x4-element AEs, %s-AE coarse blocks%s" % (args.n, "" if args.aniso == 1.0 else
                                                        " K=diag(1,1,%g)" % args.aniso, args.levels,
                                                        ("%g" % args.theta) if args.theta2 == args.theta else "%g / %g (first / later coarsenings)" % (args.theta, args.theta2),
@@ -331,7 +345,7 @@ def main():
                           for s in stats[:10]]
     if rank == 0 and not args.no_cpu_baseline and args.workload != "poisson256":
         log("bench.py: cpu_baseline is timed on the default workload only (poisson256)")
-    if rank == 0 and not args.no_cpu_baseline and args.workload == "poisson256":
+    if rank == 0 and not args.no_cpu_baseline and args.workload == "poisson256" and args.blk == "8,8,4":
         sample = (96, 96, 64)       # ~15 s on the GPU box's 16 cores
         cpu_raw, res["cpu_baseline"] = cpu_baseline(sample, args.levels)
         if args.aniso == 1.0 and args.nu_pro == 0 and not args.correct_nullspace and args.blk == "8,8,4":

@@ -601,3 +601,123 @@ def poisson3d_device(n, blk=(8, 8, 4), coarse_blk=None, K=(1.0, 1.0, 1.0), devic
         nparts.append(nb[0] * nb[1] * nb[2])
     return Problem(rowptr=rowptr, col=A_col, val=A_val, n=ND, b=b, elem_to_dof=e2d, elmat=elmat,
                    bdr=bdr, partitions=parts, nparts=nparts, dims=n, NE_=NE, ess=ess)
+
+
+def elasticity3d_q2_device(n, blk=(4, 4, 4), coarse_blk=None, lam=1.0, mu=1.0, device="cuda", slab_nodes=1 << 20,
+                           index_dtype=None):
+    """Same problem as elasticity3d_q2_problem (BASELINE config 5: Q2 hexes, 3 displacement components per node
+    byVDIM, clamped on x = 0, body force (0, 0, -1)), generated directly in HBM with torch.
+
+    A uniform mesh with a constant coefficient has only 4^3 = 64 kinds of rows -- per direction a node sits on
+    the low end, inside, on the high end (element vertices: two, one or two elements) or at an element midpoint
+    -- so the row stencils (offsets, 3 x 3 blocks summed over the elements that contain both nodes, in
+    ascending element order like the assembly) are tabulated on the host and every stored entry is a table
+    lookup; rows are produced slab by slab to bound the working set.  rowptr is int64 when nnz >= 2^31.
+    Returns a Problem whose arrays are torch tensors on `device`."""
+    import torch
+    if np.isscalar(n):
+        n = (int(n),) * 3
+    nx, ny, nz = n
+    h = (1.0 / nx, 1.0 / ny, 1.0 / nz)
+    gx, gy, gz = 2 * nx + 1, 2 * ny + 1, 2 * nz + 1
+    NV, NE = gx * gy * gz, nx * ny * nz
+    ND = 3 * NV
+    dev = torch.device(device)
+    Ke = hex_elasticity_matrix_tensor(h, 2, lam, mu)
+    _, _, L1 = _lagrange_1d(2)
+    load = -h[0] * h[1] * h[2] * np.kron(L1, np.kron(L1, L1))          # node = (iz * 3 + iy) * 3 + ix
+    # per-direction kinds: 0 low end, 1 inside vertex, 2 high end, 3 midpoint -> [(element shift, local index)]
+    # in ascending element order
+    opts = {0: [(0, 0)], 1: [(-1, 2), (0, 0)], 2: [(-1, 2)], 3: [(0, 1)]}
+    noff = np.zeros(64, dtype=np.int64)
+    offl = np.zeros((64, 125), dtype=np.int64)                          # linear node offset of every stencil slot
+    vtab = np.zeros((64, 3, 125, 3))
+    ltab = np.zeros(64)
+    for cz in range(4):
+        for cy in range(4):
+            for cx in range(4):
+                cls = (cz * 4 + cy) * 4 + cx
+                blocks = {}
+                for (sz, lz) in opts[cz]:                               # ascending element id: z slowest
+                    for (sy, ly) in opts[cy]:
+                        for (sx, lx) in opts[cx]:
+                            la = (lz * 3 + ly) * 3 + lx
+                            ltab[cls] += load[la]
+                            for dz in range(-lz, 3 - lz):
+                                for dy in range(-ly, 3 - ly):
+                                    for dx in range(-lx, 3 - lx):
+                                        lb = ((lz + dz) * 3 + (ly + dy)) * 3 + (lx + dx)
+                                        blk3 = Ke[3 * la:3 * la + 3, 3 * lb:3 * lb + 3]
+                                        key = (dz, dy, dx)
+                                        blocks[key] = blocks[key] + blk3 if key in blocks else blk3.copy()
+                keys = sorted(blocks)
+                noff[cls] = len(keys)
+                for s, (dz, dy, dx) in enumerate(keys):
+                    offl[cls, s] = (dz * gy + dy) * gx + dx
+                    vtab[cls, :, s, :] = blocks[(dz, dy, dx)]
+    t_noff = torch.tensor(noff, device=dev)
+    t_offl = torch.tensor(offl, device=dev)
+    t_vtab = torch.tensor(vtab, device=dev)
+    t_ltab = torch.tensor(ltab, device=dev)
+
+    def kind(c, g):
+        return torch.where(c % 2 == 1, torch.full_like(c, 3), torch.where(c == 0, torch.zeros_like(c),
+                           torch.where(c == g - 1, torch.full_like(c, 2), torch.ones_like(c))))
+
+    node_all = torch.arange(NV, device=dev)
+    ci, cj, ck = node_all % gx, (node_all // gx) % gy, node_all // (gx * gy)
+    cls_all = (kind(ck, gz) * 4 + kind(cj, gy)) * 4 + kind(ci, gx)
+    ess_node = ci == 0
+    row_len = (3 * t_noff[cls_all]).repeat_interleave(3)                  # per dof row
+    nnz = int(row_len.sum())
+    big = nnz >= 2 ** 31
+    it = torch.int64 if (big or index_dtype == "int64") else torch.int32
+    rowptr = torch.zeros(ND + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(row_len, 0)
+    A_col = torch.empty(nnz, dtype=torch.int32, device=dev)
+    A_val = torch.empty(nnz, dtype=torch.float64, device=dev)
+    for n0 in range(0, NV, slab_nodes):
+        n1 = min(NV, n0 + slab_nodes)
+        rows = torch.arange(3 * n0, 3 * n1, device=dev)
+        lens = row_len[3 * n0:3 * n1]
+        e0, e1 = int(rowptr[3 * n0]), int(rowptr[3 * n1])
+        erow = rows.repeat_interleave(lens)                             # row of every entry of the slab
+        slot = torch.arange(e0, e1, device=dev) - rowptr[erow]
+        enode, ecomp = erow // 3, erow % 3
+        o, c2 = slot // 3, slot % 3
+        ecls = cls_all[enode]
+        cnode = enode + t_offl[ecls, o]
+        col = 3 * cnode + c2
+        val = t_vtab[ecls, ecomp, o, c2]
+        kill = (ess_node[enode] | ess_node[cnode]) & (col != erow)
+        A_col[e0:e1] = col.to(torch.int32)
+        A_val[e0:e1] = torch.where(kill, torch.zeros_like(val), val)
+        del erow, slot, enode, ecomp, o, c2, ecls, cnode, col, val, kill
+    # elements
+    ez = torch.arange(nz, device=dev).view(-1, 1, 1)
+    ey = torch.arange(ny, device=dev).view(1, -1, 1)
+    ex = torch.arange(nx, device=dev).view(1, 1, -1)
+    loc = [(a, b_, c) for c in range(3) for b_ in range(3) for a in range(3)]
+    e2n = torch.stack([(((2 * ez + c) * gy + (2 * ey + b_)) * gx + (2 * ex + a)).reshape(-1) for (a, b_, c) in loc], dim=1)
+    e2d = (3 * e2n.unsqueeze(2) + torch.arange(3, device=dev).view(1, 1, 3)).reshape(NE, 81).to(torch.int32).contiguous()
+    elmat = torch.tensor(Ke, device=dev).reshape(1, 81 * 81).expand(NE, 81 * 81).contiguous()
+    b = torch.zeros(ND, dtype=torch.float64, device=dev)
+    b[2::3] = torch.where(ess_node, torch.zeros(NV, dtype=torch.float64, device=dev), t_ltab[cls_all])
+    ess = ess_node.repeat_interleave(3)
+    bdr = torch.where(ess, AGG_ON_ESS_DOMAIN_BORDER_FLAG | AGG_OWNED_FLAG, AGG_OWNED_FLAG).to(torch.int8)
+
+    def blockpart(dims, bl):
+        mx, my, mz = dims
+        nbx, nby, nbz = -(-mx // bl[0]), -(-my // bl[1]), -(-mz // bl[2])
+        kz = torch.arange(mz, device=dev).view(-1, 1, 1) // bl[2]
+        ky = torch.arange(my, device=dev).view(1, -1, 1) // bl[1]
+        kx = torch.arange(mx, device=dev).view(1, 1, -1) // bl[0]
+        return ((kz * nby + ky) * nbx + kx).reshape(-1).to(torch.int32).contiguous(), (nbx, nby, nbz)
+    part0, nb = blockpart(n, blk)
+    parts, nparts = [part0], [nb[0] * nb[1] * nb[2]]
+    for cb in (coarse_blk or []):
+        p, nb = blockpart(nb, cb)
+        parts.append(p)
+        nparts.append(nb[0] * nb[1] * nb[2])
+    return Problem(rowptr=rowptr.to(it), col=A_col, val=A_val, n=ND, b=b, elem_to_dof=e2d, elmat=elmat, bdr=bdr,
+                   partitions=parts, nparts=nparts, dims=n, NE_=NE, ess=ess, nde_=81, nnz_=nnz)
