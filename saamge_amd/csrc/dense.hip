@@ -36,15 +36,17 @@ __global__ __launch_bounds__(256) void dense_scatter_kernel(int n, const int *__
 // block is padded with the identity.  Pinv: DNB x DNB column-major.
 __global__ __launch_bounds__(256) void gj_pivot_kernel(int n, int k0, int nb, const double *__restrict__ M,
                                                        double *__restrict__ Pinv, int *__restrict__ info) {
-    __shared__ double D[DNB][DNB + 1];
+    __shared__ double Dbuf[2][DNB][DNB + 1];      // ping-pong: one barrier per elimination step
     const int tid = threadIdx.x;
     const int r = tid & (DNB - 1), c0 = tid >> 6;          // this thread owns D[r][c0 + 4 u], u = 0..15
     for (int u = 0; u < DNB / 4; ++u) {
         const int c = c0 + 4 * u;
-        D[r][c] = (r < nb && c < nb) ? M[(size_t)(k0 + c) * n + k0 + r] : ((r == c) ? 1.0 : 0.0);
+        Dbuf[0][r][c] = (r < nb && c < nb) ? M[(size_t)(k0 + c) * n + k0 + r] : ((r == c) ? 1.0 : 0.0);
     }
     __syncthreads();
-    for (int j = 0; j < nb; ++j) {
+    int cur = 0;
+    for (int j = 0; j < nb; ++j, cur ^= 1) {
+        double (*D)[DNB + 1] = Dbuf[cur], (*E)[DNB + 1] = Dbuf[cur ^ 1];
         const double d = D[j][j];
         if (!(d > 0.0)) {               // not positive definite (also catches NaN): uniform exit
             if (tid == 0) atomicMax(info, k0 + j + 1);
@@ -52,23 +54,21 @@ __global__ __launch_bounds__(256) void gj_pivot_kernel(int n, int k0, int nb, co
         }
         const double inv = 1.0 / d;
         const double rj = D[r][j];
-        double v[DNB / 4];
 #pragma unroll
         for (int u = 0; u < DNB / 4; ++u) {
             const int c = c0 + 4 * u;
             const double pjc = (c == j) ? 1.0 : D[j][c];
-            if (r == j) v[u] = pjc * inv;
-            else if (c == j) v[u] = -rj * inv;
-            else v[u] = fma(-rj * inv, pjc, D[r][c]);
+            double v;
+            if (r == j) v = pjc * inv;
+            else if (c == j) v = -rj * inv;
+            else v = fma(-rj * inv, pjc, D[r][c]);
+            E[r][c] = v;
         }
-        __syncthreads();                // every read of the old block precedes every write
-#pragma unroll
-        for (int u = 0; u < DNB / 4; ++u) D[r][c0 + 4 * u] = v[u];
         __syncthreads();
     }
     for (int u = 0; u < DNB / 4; ++u) {
         const int c = c0 + 4 * u;
-        Pinv[(size_t)c * DNB + r] = D[r][c];
+        Pinv[(size_t)c * DNB + r] = Dbuf[cur][r][c];
     }
 }
 

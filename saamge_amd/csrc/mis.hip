@@ -375,7 +375,7 @@ __global__ __launch_bounds__(RAP_NT) void rap_symbolic_kernel(
     int pass, const int *__restrict__ mis2d_I, const int *__restrict__ mis2d_J,
     const int *__restrict__ Arow, const int *__restrict__ Acol, const int *__restrict__ mises,
     const int *__restrict__ k, int *__restrict__ cnt, const int *__restrict__ nbr_ptr,
-    int *__restrict__ nbr, int *__restrict__ err) {
+    int *__restrict__ nbr, int *__restrict__ err, int *__restrict__ stage = nullptr, int stage_cap = 0) {
     __shared__ int table[RAP_HASH];
     __shared__ int nfound;
     const int m1 = blockIdx.x;
@@ -406,9 +406,11 @@ __global__ __launch_bounds__(RAP_NT) void rap_symbolic_kernel(
     __syncthreads();
     if (pass == 0) {
         if (threadIdx.x == 0) cnt[m1] = nfound;
-        return;
+        // the list itself goes to a fixed-capacity staging row when it fits (it nearly always does: 27 neighbours
+        // on a hexahedral mesh), so that the second pass is a copy instead of a second walk over the rows of A
+        if (!stage || nfound > stage_cap) return;
     }
-    // pass 1: compact the table into a short list, then rank inside the list and write in order
+    // compact the table into a short list, then rank inside the list and write in order
     __shared__ int list[RAP_HASH];
     __shared__ int nlist;
     if (threadIdx.x == 0) nlist = 0;
@@ -419,13 +421,20 @@ __global__ __launch_bounds__(RAP_NT) void rap_symbolic_kernel(
     }
     __syncthreads();
     const int nl = nlist;
-    int *out = nbr + nbr_ptr[m1];
+    int *out = (pass == 0) ? stage + (size_t)m1 * stage_cap : nbr + nbr_ptr[m1];
     for (int i = threadIdx.x; i < nl; i += RAP_NT) {
         const int v = list[i];
         int rank = 0;
         for (int j = 0; j < nl; ++j) rank += (list[j] < v);
         out[rank] = v;
     }
+}
+
+__global__ __launch_bounds__(256) void rap_unstage_kernel(int nm, int cap, const int *__restrict__ stage,
+                                                          const int *__restrict__ nbr_ptr, int *__restrict__ nbr) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int m = (int)(i / cap), t = (int)(i % cap);
+    if (m < nm && t < nbr_ptr[m + 1] - nbr_ptr[m]) nbr[nbr_ptr[m] + t] = stage[i];
 }
 
 __global__ __launch_bounds__(RAP_NT) void rap_numeric_kernel(
@@ -543,17 +552,24 @@ void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, cons
     DBuf<int> cnt((size_t)nm), err(1);
     err.zero(s);
     profiler().begin(s);
+    constexpr int STAGE_CAP = 64;
+    DBuf<int> stage((size_t)nm * STAGE_CAP);
     hipLaunchKernelGGL(rap_symbolic_kernel, dim3(nm), dim3(RAP_NT), 0, s, 0, rel.mis2d_I.p,
-                       rel.mis2d_J.p, A.rowptr.p, A.col.p, rel.mises.p, d_k, cnt.p, nullptr, nullptr, err.p);
+                       rel.mis2d_J.p, A.rowptr.p, A.col.p, rel.mises.p, d_k, cnt.p, nullptr, nullptr, err.p, stage.p, STAGE_CAP);
     SA_HIP_CHECK(hipGetLastError());
     auto h_cnt = cnt.to_host(s);
     SA_REQUIRE(err.to_host(s)[0] == 0, "RAP: MIS neighbour table overflow");
     std::vector<int> h_nbr_ptr((size_t)nm + 1, 0);
-    for (int m = 0; m < nm; ++m) h_nbr_ptr[m + 1] = h_nbr_ptr[m] + h_cnt[m];
+    int cnt_max = 0;
+    for (int m = 0; m < nm; ++m) { h_nbr_ptr[m + 1] = h_nbr_ptr[m] + h_cnt[m]; cnt_max = std::max(cnt_max, (int)h_cnt[m]); }
     DBuf<int> nbr_ptr, nbr((size_t)h_nbr_ptr[nm] + 1);
     nbr_ptr.from_host(h_nbr_ptr, s);
-    hipLaunchKernelGGL(rap_symbolic_kernel, dim3(nm), dim3(RAP_NT), 0, s, 1, rel.mis2d_I.p,
-                       rel.mis2d_J.p, A.rowptr.p, A.col.p, rel.mises.p, d_k, cnt.p, nbr_ptr.p, nbr.p, err.p);
+    if (cnt_max <= STAGE_CAP)      // every list was staged by the counting pass
+        hipLaunchKernelGGL(rap_unstage_kernel, dim3(div_up((long)nm * STAGE_CAP, 256)), dim3(256), 0, s, nm, STAGE_CAP, stage.p,
+                           nbr_ptr.p, nbr.p);
+    else
+        hipLaunchKernelGGL(rap_symbolic_kernel, dim3(nm), dim3(RAP_NT), 0, s, 1, rel.mis2d_I.p,
+                           rel.mis2d_J.p, A.rowptr.p, A.col.p, rel.mises.p, d_k, cnt.p, nbr_ptr.p, nbr.p, err.p, (int *)nullptr, 0);
     SA_HIP_CHECK(hipGetLastError());
     auto h_nbr = nbr.to_host(s);
     // row pointers of Ac and LDS sizing

@@ -397,16 +397,21 @@ void smooth_first(hipStream_t s, int n, const double *dinv_neg, const double *b,
 }
 
 // ---- weighted-l1 smoother diagonal ----------------------------------------------------
+// (8 lanes per row: a lane walking its own row alone touches one cache line per lane and load)
 __global__ __launch_bounds__(256) void sqrt_abs_diag_kernel(int nrows, const int *__restrict__ rowptr,
                                                             const int *__restrict__ col,
                                                             const double *__restrict__ val,
                                                             double *__restrict__ sd) {
-    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 7;
+    const long row = gtid >> 3;
     if (row >= nrows) return;
     double d = 0.0;
-    for (int k = rowptr[row]; k < rowptr[row + 1]; ++k)
+    for (int k = rowptr[row] + lane; k < rowptr[row + 1]; k += 8)
         if (col[k] == row) d += val[k];
-    sd[row] = sqrt(fabs(d));
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) d += __shfl_down(d, o, 8);
+    if (lane == 0) sd[row] = sqrt(fabs(d));
 }
 
 template <int L>
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(256) void dinv_neg_kernel(int nrows, const int *__r
 
 void build_dinv_neg(hipStream_t s, const DCsr &A, double *sd, double *out) {
     if (!A.nrows) return;
-    hipLaunchKernelGGL(sqrt_abs_diag_kernel, dim3(div_up(A.nrows, 256)), dim3(256), 0, s, A.nrows,
+    hipLaunchKernelGGL(sqrt_abs_diag_kernel, dim3(div_up((long)A.nrows * 8, 256)), dim3(256), 0, s, A.nrows,
                        A.rowptr.p, A.col.p, A.val.p, sd);
     const int grid = div_up((long)A.nrows * 8, 256);
     hipLaunchKernelGGL((dinv_neg_kernel<8>), dim3(grid), dim3(256), 0, s, A.nrows, A.rowptr.p,
