@@ -216,6 +216,15 @@ int saamge_amd_lower_eigens_batched(int count, const int *n, const double *A, co
 int saamge_amd_inertia_batched(int count, const int *n, const double *A, const double *D, double vu,
                                int *neg);
 
+/* ---- device memory kept by the library between calls ----
+ * Freed device blocks are cached and reused by later calls (hipMalloc / hipFree stall the host and, for
+ * hipFree, the whole device); the eigensolver workspace is persistent.  saamge_amd_release_cached_memory()
+ * returns all of it to the driver (call it with no hierarchy call in flight);
+ * saamge_amd_cached_memory_bytes() reports the idle cached bytes (workspace not included).
+ * Environment: SAAMGE_AMD_POOL_MAX_GB (default 64; 0 disables the cache). */
+void saamge_amd_release_cached_memory(void);
+long long saamge_amd_cached_memory_bytes(void);
+
 /* ---- per-kernel timing for bench.py's roofline leg (HIP events around every launch) ---- */
 void saamge_amd_profile_enable(int on);
 void saamge_amd_profile_reset(void);

@@ -25,6 +25,7 @@ SYMBOLS = [
     "saamge_amd_update_operators", "saamge_amd_inertia_batched", "saamge_amd_vcycle",
     "saamge_amd_set_coarse_solver", "saamge_amd_comm_unique_id", "saamge_amd_comm_create", "saamge_amd_comm_destroy",
     "saamge_amd_params_set_comm", "saamge_amd_comm_selftest", "saamge_amd_comm_last_error",
+    "saamge_amd_release_cached_memory", "saamge_amd_cached_memory_bytes",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong))
@@ -423,6 +424,17 @@ def inertia_batched(mats, diags, vu):
     neg = np.zeros(count, dtype=np.int32)
     _check(load().saamge_amd_inertia_batched(C.c_int(count), _ptr(n), _ptr(A), _ptr(D), C.c_double(vu), _ptr(neg)))
     return neg
+
+
+def release_cached_memory():
+    """Return the library's cached device blocks and the eigensolver workspace to the driver."""
+    load().saamge_amd_release_cached_memory()
+
+
+def cached_memory_bytes():
+    lib = load()
+    lib.saamge_amd_cached_memory_bytes.restype = C.c_longlong
+    return int(lib.saamge_amd_cached_memory_bytes())
 
 
 def profile(enable=True):

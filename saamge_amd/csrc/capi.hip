@@ -31,6 +31,7 @@ static std::string g_last_error;
 // hierarchy was built on (HIP's current device is per host thread)
 static void require_device(const Hierarchy &H) {
     SA_REQUIRE(current_device() == H.device, "the calling thread's current HIP device is not the hierarchy's device");
+    set_thread_stream(H.stream);     // device blocks freed by this call are ordered after the hierarchy's stream
 }
 
 extern "C" {
@@ -123,6 +124,7 @@ int saamge_amd_ml_produce_data(int n, const int *rowptr, const int *col, const d
     p.eigensolver = params->eigensolver;
     SA_REQUIRE(p.eigensolver == 0 || p.eigensolver == 1, "bad eigensolver selector");
     SA_REQUIRE(p.world == 1 || (p.rank >= 0 && p.rank < p.world), "bad rank");
+    set_thread_stream((hipStream_t)stream);
     Hierarchy *H = hierarchy_create(n, rowptr, col, val, NE, nde, elem_to_dof, elmat, bdr_dofs,
                                     partitions, nparts, p, (hipStream_t)stream);
     *out = new saamge_amd_hierarchy{H};
@@ -139,6 +141,7 @@ int saamge_amd_update_operators(saamge_amd_hierarchy *h, const double *new_val) 
 
 void saamge_amd_ml_free_data(saamge_amd_hierarchy *h) {
     if (!h) return;
+    if (h->H) set_thread_stream(h->H->stream);
     delete h->H;
     delete h;
 }
@@ -391,6 +394,7 @@ int saamge_amd_spmv(int nrows, int ncols, const int *rowptr, const int *col, con
     SA_API_BEGIN
     SA_REQUIRE(rowptr && col && val && x && y && nrows >= 0, "bad argument");
     hipStream_t s = 0;
+    set_thread_stream(s);
     DCsr A;
     A.nrows = nrows;
     A.ncols = ncols;
@@ -427,6 +431,7 @@ int saamge_amd_lower_eigens_batched(int count, const int *n, const double *A, co
     SA_API_BEGIN
     SA_REQUIRE(count >= 0 && n && A && D && m && evals && evecs, "bad argument");
     hipStream_t s = 0;
+    set_thread_stream(s);
     std::vector<int> sizes(n, n + count);
     EigBatch b;
     eig_batch_alloc(b, sizes, s);
@@ -471,6 +476,7 @@ int saamge_amd_inertia_batched(int count, const int *n, const double *A, const d
     SA_API_BEGIN
     SA_REQUIRE(count >= 0 && n && A && D && neg, "bad argument");
     hipStream_t s = 0;
+    set_thread_stream(s);
     std::vector<int> sizes(n, n + count);
     EigBatch b;
     eig_batch_alloc(b, sizes, s);
@@ -485,6 +491,13 @@ int saamge_amd_inertia_batched(int count, const int *n, const double *A, const d
     std::copy(b.h_inertia.begin(), b.h_inertia.end(), neg);
     SA_API_END
 }
+
+void saamge_amd_release_cached_memory(void) {
+    (void)hipDeviceSynchronize();
+    eig_arena_release();
+    dev_pool_release();
+}
+long long saamge_amd_cached_memory_bytes(void) { return (long long)dev_pool_idle_bytes(); }
 
 void saamge_amd_profile_enable(int on) { profiler().enabled = on != 0; }
 void saamge_amd_profile_reset(void) { profiler().stats.clear(); }

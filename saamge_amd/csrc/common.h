@@ -83,6 +83,25 @@ inline bool is_device_ptr(const void *p) {
     return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
+// ---- device memory: caching allocator behind every DBuf -----------------------------------
+// hipMalloc costs 10 us - 1 ms and hipFree additionally waits for the whole device, which stalls the
+// host between setup kernels and serialises streams that are meant to overlap.  Freed blocks are kept
+// and handed out again: at once to the stream that freed them (stream order makes that safe), to any
+// other stream once the event recorded at the free has completed.  The freeing stream is the calling
+// thread's `thread_stream()` (set by every API entry and every worker thread); a thread without one
+// frees through hipFree as before.  Idle blocks beyond SAAMGE_AMD_POOL_MAX_GB (default 64) are returned
+// to the driver, all of them by dev_pool_release() or when a hipMalloc fails.
+void set_thread_stream(hipStream_t s);
+hipStream_t thread_stream();
+bool thread_stream_is_set();
+void *dev_alloc(size_t bytes);
+void dev_free(void *p) noexcept;
+void dev_pool_release();
+size_t dev_pool_idle_bytes();
+struct ThreadStreamScope {       // a worker thread's stream for its lifetime
+    explicit ThreadStreamScope(hipStream_t s) { set_thread_stream(s); }
+};
+
 // RAII device buffer.
 template <class T>
 struct DBuf {
@@ -104,13 +123,13 @@ struct DBuf {
     }
     ~DBuf() { release(); }
     void release() {
-        if (p && owned) (void)hipFree(p);
+        if (p && owned) dev_free(p);
         p = nullptr; n = 0; owned = true;
     }
     void alloc(size_t n_) {
         release();
         n = n_;
-        if (n) SA_HIP_CHECK(hipMalloc((void **)&p, n * sizeof(T)));
+        if (n) p = (T *)dev_alloc(n * sizeof(T));
     }
     void zero(hipStream_t s = 0) {
         if (n) SA_HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), s));

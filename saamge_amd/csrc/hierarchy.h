@@ -2,7 +2,9 @@
 // tg_data_t / interp_data_t (reference: amg/inc/ml.hpp:118-120, amg/inc/levels.hpp:47-64,
 // amg/inc/tg_data.hpp:47-83, amg/inc/interp.hpp:54-100).
 #pragma once
+#include <exception>
 #include <memory>
+#include <thread>
 
 #include "assemble.h"
 #include "common.h"
@@ -120,6 +122,14 @@ struct Hierarchy {              // ml_data_t
     int (*user_coarse_solve)(void *ctx, int n, const double *rc_host, double *xc_host) = nullptr;
     void *user_coarse_ctx = nullptr;
     DBuf<int> own_e2d;          // element-free mode: the generated identity elem_to_dof
+    // setup only: the Galerkin product of level `galerkin_lev` runs on its own thread and stream beside the
+    // next level's element matrices and eigenproblems (which need the level's size, not its operator)
+    std::thread galerkin_thread;
+    std::exception_ptr galerkin_err;
+    int galerkin_lev = -1;
+    ~Hierarchy() {
+        if (galerkin_thread.joinable()) galerkin_thread.join();
+    }
 };
 
 // ml_produce_data (amg/src/ml.cpp:379-472).  All array arguments may be host or device

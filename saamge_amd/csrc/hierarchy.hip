@@ -87,11 +87,10 @@ __global__ void fill_kernel(long n, double *p, double v) {
 // P (smoothed when nu_pro > 0), R and Ac = R A P of level `lev` from its tentative prolongator
 // (tg_smooth_interp + tg_coarse_matr, amg/inc/tg.hpp:679-709).  `first`: P / R still hold the
 // tentative pair just built; otherwise (operator update) the stored tentative one is re-smoothed.
-static void level_galerkin(Hierarchy &H, int lev, bool first) {
+static void level_galerkin(Hierarchy &H, int lev, bool first, hipStream_t s) {
     Level &L = *H.levels[lev];
     const Params &P = H.params;
     const Relations &rel = L.rel;
-    hipStream_t s = H.stream;
     const int world = P.world > 1 ? P.world : 1;
     if (P.nu_pro[lev] == 0) {
         std::vector<long long> nnz_off;
@@ -128,6 +127,23 @@ static void level_galerkin(Hierarchy &H, int lev, bool first) {
         spgemm(s, L.A, L.P, nullptr, nullptr, 1.0, 0.0, AP);
         spgemm(s, L.R, AP, nullptr, nullptr, 1.0, 0.0, L.Ac);
     }
+}
+
+static void level_galerkin(Hierarchy &H, int lev, bool first) { level_galerkin(H, lev, first, H.stream); }
+
+// The deferred Galerkin product (see Hierarchy::galerkin_thread): wait for it and hand its result to the
+// next level.
+static void join_galerkin(Hierarchy &H) {
+    if (H.galerkin_lev < 0) return;
+    if (H.galerkin_thread.joinable()) H.galerkin_thread.join();
+    const int lev = H.galerkin_lev;
+    H.galerkin_lev = -1;
+    if (H.galerkin_err) {
+        std::exception_ptr e = H.galerkin_err;
+        H.galerkin_err = nullptr;
+        std::rethrow_exception(e);
+    }
+    H.levels[lev + 1]->A = std::move(H.levels[lev]->Ac);     // A_{l+1} = Ac_l  (amg/src/ml.cpp:134)
 }
 
 struct DeviceInputs {   // level-0 inputs that already live on the device (see hierarchy_create)
@@ -177,6 +193,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     HostCsr aggA;
     const bool aggregates = P.do_aggregates && lev == P.num_coarsenings - 1;
     if (aggregates) {
+        join_galerkin(H);     // the arbitration reads this level's operator
         aggA.nrows = L.A.nrows;
         aggA.rowptr.resize((size_t)L.A.nrows + 1);
         aggA.col.resize((size_t)L.A.nnz);
@@ -193,6 +210,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     std::thread mis_thread([&]() {
         try {
             adopt_device(dev);   // the worker allocates and copies: same GPU as the caller
+            set_thread_stream(mis_stream);
             // MIS tables on the device (SAAMGE_AMD_HOST_MIS=1: host build); aggregates with arbitration are
             // sequential by definition and stay on the host
             static const bool host_mis = std::getenv("SAAMGE_AMD_HOST_MIS") != nullptr;
@@ -209,14 +227,19 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     });
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{mis_thread};
     const Relations &rel = L.rel;
-    build_sell(s, L.A);   // SELL-64 copy of the level operator for the SpMV family
-    // smoother data (smpr_init_poly_data, amg/src/smpr.cpp:359-423)
-    L.dinv_neg.alloc((size_t)L.A.nrows);
-    {
+    // SELL-64 copy of the level operator for the SpMV family + smoother data (smpr_init_poly_data,
+    // amg/src/smpr.cpp:359-423); on a coarse level the operator may still be in the making (deferred
+    // Galerkin product of the finer level): then after the eigenproblems, which do not read it
+    auto operator_data = [&]() {
+        join_galerkin(H);
+        build_sell(s, L.A);
+        L.dinv_neg.alloc((size_t)L.A.nrows);
         DBuf<double> tmp((size_t)L.A.nrows);
         build_dinv_neg(s, L.A, tmp.p, L.dinv_neg.p);
         SA_HIP_CHECK(hipStreamSynchronize(s));
-    }
+    };
+    const bool operator_pending = H.galerkin_lev >= 0;
+    if (!operator_pending) operator_data();
     L.roots = sas_poly_roots(L.nu_relax);
 
     // ---- local spectral problems, chunked over AEs (interp_compute_vectors) ----
@@ -323,6 +346,10 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     }
     if (prev >= 0) post(prev);
     tm.lap("local eigenproblems", lev);
+    if (operator_pending) {
+        operator_data();
+        tm.lap("operator (deferred Galerkin product) + SELL + D", lev);
+    }
     if (world > 1) {   // exchange the number of eigenvectors per AE
         DBuf<int> d_m;
         d_m.from_host(L.ae_m, s);
@@ -456,14 +483,35 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         prep_thread = std::thread([&L, &prep_err, prp, pvl, pnr, pnz, sd, dev]() {
             try {
                 adopt_device(dev);
+                set_thread_stream(sd);
                 prepare_next_host(L, prp, pvl, pnr, pnz, sd, L.next_prep);
+                SA_HIP_CHECK(hipStreamSynchronize(sd));      // nothing of this thread is in flight after the join
             } catch (...) { prep_err = std::current_exception(); }
         });
     }
-    level_galerkin(H, lev, true);
+    // With another spectral level to come the product runs beside that level's element matrices and
+    // eigenproblems (they need its size only); SAAMGE_AMD_NO_OVERLAP=1 and the profiled step keep it in line.
+    static const bool no_overlap = std::getenv("SAAMGE_AMD_NO_OVERLAP") != nullptr;
+    const bool defer = lev + 1 < P.num_coarsenings && P.nu_pro[lev] == 0 && world == 1 && !no_overlap &&
+                       !profiler().enabled;
+    if (defer) {
+        SA_HIP_CHECK(hipStreamSynchronize(s));       // the operands are complete
+        hipStream_t gs = side_stream(2);
+        H.galerkin_lev = lev;
+        H.galerkin_thread = std::thread([&H, lev, gs, dev]() {
+            try {
+                adopt_device(dev);
+                set_thread_stream(gs);
+                level_galerkin(H, lev, true, gs);
+                SA_HIP_CHECK(hipStreamSynchronize(gs));
+            } catch (...) { H.galerkin_err = std::current_exception(); }
+        });
+    } else {
+        level_galerkin(H, lev, true);
+    }
     if (prep_thread.joinable()) prep_thread.join();
     if (prep_err) std::rethrow_exception(prep_err);
-    tm.lap("P, R, RAP", lev);
+    tm.lap(defer ? "P, R (RAP deferred)" : "P, R, RAP", lev);
     if (!P.keep_debug) {
         L.evals.release();
         L.evecs.release();
@@ -1043,11 +1091,17 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
             e2d = prepare_next_level(H, lev);
             tm.lap("next-level elements", lev);
             Level &N = *H.levels[lev + 1];
-            N.A = std::move(L.Ac);  // A_{l+1} = Ac_l  (amg/src/ml.cpp:134)
+            if (H.galerkin_lev == lev) {       // product still running: the size is known, the arrays follow at the join
+                N.A = DCsr();
+                N.A.nrows = N.A.ncols = L.mis_coloff.back();
+            } else {
+                N.A = std::move(L.Ac);  // A_{l+1} = Ac_l  (amg/src/ml.cpp:134)
+            }
             n_elem = L.rel.nparts;
         }
     }
     profiler().level_tag = 0;
+    join_galerkin(H);
     tm0 = PhaseTimer(s);
     if (p.correct_nullspace) {
         add_nullspace_level(H);

@@ -69,6 +69,141 @@ void pinned_pool_release() {
 }
 
 // ---------------------------------------------------------------------------------------
+// device memory pool (see common.h)
+// ---------------------------------------------------------------------------------------
+namespace {
+struct IdleBlock {
+    void *p;
+    hipStream_t stream;     // the stream the block was freed on
+    hipEvent_t ev;          // recorded on that stream at the free
+    int dev;
+};
+struct DevPool {
+    std::mutex mu;
+    std::multimap<size_t, IdleBlock> idle;              // by size
+    std::unordered_map<void *, size_t> live;            // blocks handed out -> size
+    std::vector<hipEvent_t> events;                     // spare events
+    size_t idle_bytes = 0, max_idle = 0;
+    bool enabled = true;
+    DevPool() {
+        const char *e = std::getenv("SAAMGE_AMD_POOL_MAX_GB");
+        const double gb = e ? std::atof(e) : 64.0;
+        max_idle = (size_t)(gb * (double)(1ull << 30));
+        enabled = gb > 0.0;
+    }
+};
+DevPool &dev_pool() {
+    static DevPool *p = new DevPool;      // never destroyed: static DBufs are released after main() returns
+    return *p;
+}
+thread_local hipStream_t tl_stream = nullptr;
+thread_local bool tl_stream_set = false;
+inline size_t pool_round(size_t bytes) { return bytes <= (1u << 20) ? (bytes + 511) / 512 * 512 : (bytes + 65535) / 65536 * 65536; }
+// hipFree the idle blocks for which keep() is false; pool lock held
+template <class F>
+void pool_drop(DevPool &P, F keep) {
+    for (auto it = P.idle.begin(); it != P.idle.end();) {
+        if (keep(it)) { ++it; continue; }
+        (void)hipFree(it->second.p);
+        P.events.push_back(it->second.ev);
+        P.idle_bytes -= it->first;
+        it = P.idle.erase(it);
+    }
+}
+}  // namespace
+
+void set_thread_stream(hipStream_t s) { tl_stream = s; tl_stream_set = true; }
+hipStream_t thread_stream() { return tl_stream; }
+bool thread_stream_is_set() { return tl_stream_set; }
+
+void *dev_alloc(size_t bytes) {
+    if (bytes == 0) return nullptr;
+    DevPool &P = dev_pool();
+    const size_t want = pool_round(bytes);
+    const int dev = current_device();
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        // smallest idle block that fits without wasting more than an eighth; same stream, or idle for certain
+        const size_t limit = want + want / 8 + 4096;
+        for (auto it = P.idle.lower_bound(want); it != P.idle.end() && it->first <= limit; ++it) {
+            IdleBlock &b = it->second;
+            if (b.dev != dev) continue;
+            const bool same = tl_stream_set && b.stream == tl_stream;
+            if (!same && hipEventQuery(b.ev) != hipSuccess) { (void)hipGetLastError(); continue; }
+            void *p = b.p;
+            P.events.push_back(b.ev);
+            P.live[p] = it->first;
+            P.idle_bytes -= it->first;
+            P.idle.erase(it);
+            return p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {          // out of memory: give the cached blocks back and try once more
+        (void)hipGetLastError();
+        dev_pool_release();
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) throw Error((int)e, std::string("hipMalloc of ") + std::to_string(want) + " bytes failed: " + hipGetErrorString(e));
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.live[p] = want;
+    return p;
+}
+
+void dev_free(void *p) noexcept {
+    if (!p) return;
+    DevPool &P = dev_pool();
+    size_t size = 0;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto it = P.live.find(p);
+        if (it != P.live.end()) { size = it->second; P.live.erase(it); }
+    }
+    int dev = 0;
+    if (!size || !P.enabled || !tl_stream_set || size > P.max_idle || hipGetDevice(&dev) != hipSuccess) {
+        (void)hipFree(p);
+        return;
+    }
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        if (!P.events.empty()) { ev = P.events.back(); P.events.pop_back(); }
+    }
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+    if (!ev || hipEventRecord(ev, tl_stream) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ev) { std::lock_guard<std::mutex> lk(P.mu); P.events.push_back(ev); }
+        (void)hipFree(p);
+        return;
+    }
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.idle.insert(std::make_pair(size, IdleBlock{p, tl_stream, ev, dev}));
+    P.idle_bytes += size;
+    if (P.idle_bytes > P.max_idle) {        // over the cap: the largest blocks go back to the driver
+        while (P.idle_bytes > P.max_idle && !P.idle.empty()) {
+            auto last = std::prev(P.idle.end());
+            (void)hipFree(last->second.p);
+            P.events.push_back(last->second.ev);
+            P.idle_bytes -= last->first;
+            P.idle.erase(last);
+        }
+    }
+}
+
+void dev_pool_release() {
+    DevPool &P = dev_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    pool_drop(P, [](std::multimap<size_t, IdleBlock>::iterator) { return false; });
+}
+
+size_t dev_pool_idle_bytes() {
+    DevPool &P = dev_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    return P.idle_bytes;
+}
+
+// ---------------------------------------------------------------------------------------
 // tiny fork-join helper
 // ---------------------------------------------------------------------------------------
 static int num_threads() {

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--kernel", default=None)
     ap.add_argument("--from-frac", type=float, default=0.0, help="ignore dispatches that start before this fraction of the trace")
     ap.add_argument("--top", type=int, default=45)
+    ap.add_argument("--timeline", action="store_true", help="print the dispatches in time order, runs of one kernel merged")
+    ap.add_argument("--min-ms", type=float, default=0.3, help="timeline: fold runs shorter than this into the next line")
     a = ap.parse_args()
     db = sqlite3.connect(a.db)
     rows = db.execute("select name, start, end from kernels order by start").fetchall()
@@ -46,6 +48,24 @@ def main():
     print("span %.3f ms, busy %.3f ms, gaps %.3f ms, %d dispatches" % (span / 1e6, busy / 1e6, gaps / 1e6, len(rows)))
     for k, (ns, n) in sorted(tot.items(), key=lambda kv: -kv[1][0])[:a.top]:
         print("%-72s %10.3f ms %6d launches %9.1f us avg" % (k, ns / 1e6, n, ns / 1e3 / n))
+    if a.timeline:
+        base = rows[0][1]
+        run = None      # [name, start, end, busy, count]
+        pend = [0.0, 0]
+        for name, s_, e_ in rows + [("", rows[-1][2], rows[-1][2])]:
+            k = short(name)
+            if run and k == run[0]:
+                run[2] = e_; run[3] += e_ - s_; run[4] += 1
+                continue
+            if run:
+                if (run[2] - run[1]) / 1e6 < a.min_ms:
+                    pend[0] += (run[2] - run[1]) / 1e6; pend[1] += run[4]
+                else:
+                    if pend[1]:
+                        print("   ... %d short dispatches, %.3f ms" % (pend[1], pend[0]))
+                        pend = [0.0, 0]
+                    print("%9.3f ms  %-60s x%-4d span %8.3f ms busy %8.3f ms" % ((run[1] - base) / 1e6, run[0], run[4], (run[2] - run[1]) / 1e6, run[3] / 1e6))
+            run = [k, s_, e_, e_ - s_, 1]
     if a.kernel:
         print("launches of", a.kernel)
         for name, s, e in rows:
