@@ -58,7 +58,9 @@ struct Params {                 // MultilevelParameters (amg/inc/ml.hpp:59-114)
 struct NextPrep {               // host half of the next level's inputs (prepare_next_host)
     bool ready = false;
     Table e2d;                  // coarse elem_to_dof
-    std::vector<int> colpos_ptr, colpos;
+    std::vector<int> colpos_ptr, colpos;        // host build ...
+    DBuf<int> d_colpos_ptr, d_colpos;           // ... or the device build (coarse_e2d_device), already in place
+    bool on_device = false;
 };
 
 struct Level {                  // tg_data_t + interp_data_t + agg_partitioning_relations_t

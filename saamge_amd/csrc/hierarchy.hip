@@ -472,7 +472,16 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     std::exception_ptr prep_err;
     std::thread prep_thread;
     struct PrepJoiner { std::thread &t; ~PrepJoiner() { if (t.joinable()) t.join(); } } prep_joiner{prep_thread};
-    if (lev + 1 < P.num_coarsenings && P.nu_pro[lev] == 0) {
+    // (device build first: ~1 ms on the main stream; the host build is the fallback for AEs with more
+    // coarse dofs than the kernel's LDS holds)
+    static const bool host_e2d = std::getenv("SAAMGE_AMD_HOST_COARSE_E2D") != nullptr;
+    if (lev + 1 < P.num_coarsenings && P.nu_pro[lev] == 0 && !host_e2d) {
+        NextPrep &np = L.next_prep;
+        np.on_device = coarse_e2d_device(s, L.drel, rel, L.d_mis_k.p, L.d_mis_coloff.p, L.mis_coloff.back(),
+                                         L.P.rowptr.p, L.P.val.p, np.d_colpos_ptr, np.d_colpos, np.e2d);
+        np.ready = np.on_device;
+    }
+    if (lev + 1 < P.num_coarsenings && P.nu_pro[lev] == 0 && !L.next_prep.ready) {
         hipStream_t side = side_stream(1);
         SA_HIP_CHECK(hipStreamSynchronize(s));       // P is complete
         const int *prp = L.P.rowptr.p;
@@ -615,13 +624,24 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
     if (!L.next_prep.ready) {
         // (always the TENTATIVE prolongator: the coarse elements are built from mis_tent_interps)
         const DCsr &PT = L.Ptent.nrows ? L.Ptent : L.P;
-        prepare_next_host(L, PT.rowptr.p, PT.val.p, PT.nrows, PT.nnz, s, L.next_prep);
+        NextPrep &np = L.next_prep;
+        static const bool host_e2d = std::getenv("SAAMGE_AMD_HOST_COARSE_E2D") != nullptr;
+        if (!host_e2d)
+            np.on_device = coarse_e2d_device(s, L.drel, rel, L.d_mis_k.p, L.d_mis_coloff.p, L.mis_coloff.back(),
+                                             PT.rowptr.p, PT.val.p, np.d_colpos_ptr, np.d_colpos, np.e2d);
+        if (!np.on_device) prepare_next_host(L, PT.rowptr.p, PT.val.p, PT.nrows, PT.nnz, s, L.next_prep);
     }
     Table e2d = std::move(L.next_prep.e2d);
-    const std::vector<int> colpos_ptr = std::move(L.next_prep.colpos_ptr);
-    const std::vector<int> colpos = std::move(L.next_prep.colpos);
+    DBuf<int> d_colpos_ptr, d_colpos;
+    if (L.next_prep.on_device) {
+        d_colpos_ptr = std::move(L.next_prep.d_colpos_ptr);
+        d_colpos = std::move(L.next_prep.d_colpos);
+    } else {
+        for (int v : L.next_prep.colpos) SA_REQUIRE(v >= 0, "coarse dof with an all-zero prolongator column in an AE");
+        d_colpos_ptr.from_host(L.next_prep.colpos_ptr, s);
+        d_colpos.from_host(L.next_prep.colpos, s);
+    }
     L.next_prep = NextPrep();
-    for (int v : colpos) SA_REQUIRE(v >= 0, "coarse dof with an all-zero prolongator column in an AE");
     // coarse element matrices
     Level &N = *H.levels[lev + 1];
     std::vector<int64_t> out_off((size_t)nparts + 1, 0);
@@ -631,9 +651,6 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
     }
     N.elmat.off.from_host(out_off, s);
     N.elmat.val.alloc((size_t)out_off[nparts] + 1);
-    DBuf<int> d_colpos_ptr, d_colpos;
-    d_colpos_ptr.from_host(colpos_ptr, s);
-    d_colpos.from_host(colpos, s);
     std::vector<int> sizes((size_t)nparts);
     for (int p = 0; p < nparts; ++p) sizes[p] = rel.AE_to_dof.row_size(p);
     // several ranks: each computes the coarse element matrices of its AE range (the ranges of

@@ -37,6 +37,17 @@ void build_P_R(hipStream_t s, const DevRelations &rel, const Relations &hrel,
                const std::vector<int> &h_k, const std::vector<int64_t> &h_u_off, const int *d_k,
                const int *d_coloff, const int64_t *d_u_off, const double *U, DCsr &P, DCsr &R);
 
+// Coarse elements of the next level on the device: coarse elem_to_dof = AE_to_dof x pattern(P_tent) in
+// first-encounter order (agg_create_rels_except_elem_coarse, amg/src/aggregates.cpp:1510-1514; the pattern
+// is the numerically non-zero entries, contrib_tent_insert_simple, amg/src/contrib.cpp:186-187), and for
+// every (AE, MIS) incidence t (aligned with AE_to_mis.J) the positions colpos[colpos_ptr[t] + v] of the
+// MIS's coarse dofs in the coarse element's dof list.  e2d is fetched to the host (the next level's
+// topology is built from it).  Returns false when an AE has too many coarse dofs for the LDS kernel
+// (the caller then takes the host path).
+bool coarse_e2d_device(hipStream_t s, const DevRelations &rel, const Relations &hrel, const int *d_mis_k,
+                       const int *d_mis_coloff, int ncoarse, const int *p_rowptr, const double *p_val,
+                       DBuf<int> &colpos_ptr, DBuf<int> &colpos, Table &e2d);
+
 // Ac = P^T A P exploiting the MIS block structure of P (tg_coarse_matr, amg/inc/tg.hpp:696-709).
 void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, const DCsr &A,
              const std::vector<int> &h_k, const std::vector<int> &h_coloff, const int *d_k,

@@ -364,6 +364,115 @@ void build_P_R(hipStream_t s, const DevRelations &rel, const Relations &hrel,
 }
 
 // ---------------------------------------------------------------------------------------
+// coarse elem_to_dof + colpos (next level's elements)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ae_mis_k_kernel(long n, const int *__restrict__ ae2mis_J,
+                                                       const int *__restrict__ k, int *__restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = k[ae2mis_J[i]];
+}
+
+__global__ __launch_bounds__(256) void ae_ke_max_kernel(int nparts, const int *__restrict__ ae2mis_I,
+                                                        const int *__restrict__ colpos_ptr, int *__restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    int ke = 0;
+    if (e < nparts) ke = colpos_ptr[ae2mis_I[e + 1]] - colpos_ptr[ae2mis_I[e]];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ke = max(ke, __shfl_xor(ke, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, ke);
+}
+
+// One workgroup per AE.  The host loop appends coarse dof (m, v) when it meets the first dof of MIS m (in
+// AE_to_dof order) whose prolongator entry v is non-zero: the list order is the order of the keys
+// (first position, candidate index) -- a position belongs to one MIS, so ties are between entries of the
+// same MIS and the candidate index orders them by v.
+__global__ __launch_bounds__(256) void coarse_e2d_kernel(
+    const int *__restrict__ ae2d_I, const int *__restrict__ ae2d_J, const int *__restrict__ ae2mis_I,
+    const int *__restrict__ ae2mis_J, const int *__restrict__ mises, const int *__restrict__ mis_k,
+    const int *__restrict__ mis_coloff, const int *__restrict__ colpos_ptr, const int *__restrict__ prow,
+    const double *__restrict__ pval, int cap, int *__restrict__ colpos, int *__restrict__ e2d_J,
+    int *__restrict__ err) {
+    extern __shared__ unsigned long long ce_keys[];      // [cap] keys, then [cap] coarse dof ids
+    int *cd = (int *)(ce_keys + cap);
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const int tb = ae2mis_I[e], te = ae2mis_I[e + 1];
+    const int c0 = colpos_ptr[tb], KE = colpos_ptr[te] - c0;
+    for (int t = tb + tid; t < te; t += 256) {
+        const int m = ae2mis_J[t], km = mis_k[m], base = colpos_ptr[t] - c0, co = mis_coloff[m];
+        for (int v = 0; v < km; ++v) {
+            ce_keys[base + v] = ~0ull;
+            cd[base + v] = co + v;
+        }
+    }
+    __syncthreads();
+    const int d0 = ae2d_I[e], d1 = ae2d_I[e + 1];
+    for (int k = d0 + tid; k < d1; k += 256) {
+        const int dof = ae2d_J[k], m = mises[dof], km = mis_k[m];
+        if (km == 0) continue;
+        int lo = tb, hi = te;                               // AE_to_mis rows are ascending
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (ae2mis_J[mid] < m) lo = mid + 1; else hi = mid;
+        }
+        const int base = colpos_ptr[lo] - c0, pr = prow[dof];
+        for (int v = 0; v < km; ++v)
+            if (pval[pr + v] != 0.0)
+                atomicMin(&ce_keys[base + v], ((unsigned long long)(unsigned)(k - d0) << 32) | (unsigned)(base + v));
+    }
+    __syncthreads();
+    for (int idx = tid; idx < KE; idx += 256) {
+        const unsigned long long key = ce_keys[idx];
+        if (key == ~0ull) {                                 // a coarse dof with an all-zero column inside this AE
+            colpos[c0 + idx] = -1;
+            atomicExch(err, 1);
+            continue;
+        }
+        int rank = 0;
+        for (int j = 0; j < KE; ++j) rank += (ce_keys[j] < key) ? 1 : 0;
+        colpos[c0 + idx] = rank;
+        e2d_J[c0 + rank] = cd[idx];
+    }
+}
+
+bool coarse_e2d_device(hipStream_t s, const DevRelations &rel, const Relations &hrel, const int *d_mis_k,
+                       const int *d_mis_coloff, int ncoarse, const int *p_rowptr, const double *p_val,
+                       DBuf<int> &colpos_ptr, DBuf<int> &colpos, Table &e2d) {
+    const int nparts = hrel.nparts;
+    const long npairs = (long)hrel.AE_to_mis.J.size();
+    if (nparts == 0 || npairs == 0) return false;
+    DBuf<int> kk((size_t)npairs), info(2);
+    info.zero(s);
+    hipLaunchKernelGGL(ae_mis_k_kernel, dim3(div_up(npairs, 256)), dim3(256), 0, s, npairs, rel.ae2mis_J.p, d_mis_k, kk.p);
+    colpos_ptr.alloc((size_t)npairs + 1);
+    exclusive_scan_int(s, (int)npairs, kk.p, colpos_ptr.p);
+    hipLaunchKernelGGL(ae_ke_max_kernel, dim3(div_up(nparts, 256)), dim3(256), 0, s, nparts, rel.ae2mis_I.p, colpos_ptr.p, info.p);
+    SA_HIP_CHECK(hipGetLastError());
+    const int cap = info.to_host(s)[0];
+    const size_t lds = (size_t)cap * 12 + 16;
+    if (lds > 60 * 1024) return false;
+    auto h_ptr = colpos_ptr.to_host(s);
+    const int total = h_ptr[(size_t)npairs];
+    colpos.alloc((size_t)total + 1);
+    DBuf<int> d_J((size_t)total + 1);
+    if (total) {
+        hipLaunchKernelGGL(coarse_e2d_kernel, dim3(nparts), dim3(256), lds, s, rel.ae2d_I.p, rel.ae2d_J.p, rel.ae2mis_I.p,
+                           rel.ae2mis_J.p, rel.mises.p, d_mis_k, d_mis_coloff, colpos_ptr.p, p_rowptr, p_val, cap, colpos.p,
+                           d_J.p, info.p + 1);
+        SA_HIP_CHECK(hipGetLastError());
+    }
+    SA_REQUIRE(info.to_host(s)[1] == 0, "coarse dof with an all-zero prolongator column in an AE");
+    e2d.ncols = ncoarse;
+    e2d.I.resize((size_t)nparts + 1);
+    for (int e = 0; e <= nparts; ++e) e2d.I[e] = h_ptr[(size_t)hrel.AE_to_mis.I[e]];
+    e2d.J.resize((size_t)total);
+    if (total) {
+        SA_HIP_CHECK(hipMemcpyAsync(e2d.J.data(), d_J.p, sizeof(int) * (size_t)total, hipMemcpyDeviceToHost, s));
+        SA_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------
 // Galerkin product through the MIS blocks
 // ---------------------------------------------------------------------------------------
 constexpr int RAP_NT = 256;
