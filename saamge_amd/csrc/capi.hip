@@ -307,6 +307,10 @@ int saamge_amd_get_table(const saamge_amd_hierarchy *h, int level, int which, in
                          long long *nconn, int *I, int *J) {
     SA_API_BEGIN
     SA_REQUIRE(h, "null argument");
+    {   // tables kept on the device by the device topology build: host copies on demand
+        Level &Lw = *h->H->levels.at(level);
+        fetch_relations_ae_host(Lw.rel, Lw.drel, h->H->stream);
+    }
     const Relations &r = h->H->levels.at(level)->rel;
     const Table *T = nullptr;
     switch (which) {
@@ -339,6 +343,10 @@ int saamge_amd_get_mis(const saamge_amd_hierarchy *h, int level, int *mises, int
                        int *mis_ncols, signed char *agg_flags) {
     SA_API_BEGIN
     SA_REQUIRE(h, "null argument");
+    {
+        Level &Lw = *h->H->levels.at(level);
+        fetch_relations_ae_host(Lw.rel, Lw.drel, h->H->stream);
+    }
     const Level &L = *h->H->levels.at(level);
     if (mises) std::copy(L.rel.mises.begin(), L.rel.mises.end(), mises);
     if (mis_k) std::copy(L.mis_k.begin(), L.mis_k.end(), mis_k);

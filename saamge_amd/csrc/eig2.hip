@@ -1688,8 +1688,10 @@ constexpr double SS_SIGMA = -1e-3;
 constexpr double SS_TOL = 1e-12;
 
 __global__ __launch_bounds__(256) void ss_shift_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
-                                                       double *__restrict__ W, double sigma) {
+                                                       double *__restrict__ W, double sigma_all,
+                                                       const double *__restrict__ sigmas = nullptr) {
     const int b = blockIdx.x, n = ns[b];
+    const double sigma = sigmas ? sigmas[b] : sigma_all;
     double *A = W + moff[b];
     for (int i = threadIdx.x; i < n; i += 256) A[(size_t)i * n + i] -= sigma;
 }
@@ -2379,13 +2381,14 @@ __global__ __launch_bounds__(NT) void ss_solve_lds_pf_kernel(const int *__restri
 __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, const int64_t *__restrict__ voff,
                                                     double *__restrict__ X, const double *__restrict__ Z,
                                                     double *__restrict__ mu, int *__restrict__ state, int iter,
-                                                    double sigma, double vu, const int *__restrict__ inertia,
+                                                    const double *__restrict__ sigmas, double vu, const int *__restrict__ inertia,
                                                     double *__restrict__ dbg = nullptr,
         const int *__restrict__ active = nullptr) {
     __shared__ double part[4][2 * SS_B + 1][SS_B];  // [wavefront][M rows | G rows | residual][column j]
     __shared__ double Ms[SS_B][SS_B], Gs[SS_B][SS_B], Cs[SS_B][SS_B], res2[SS_B], mus[SS_B], mu_old[SS_B];
     const int b = active ? active[blockIdx.x] : (int)blockIdx.x, n = ns[b];     // (active: the matrices still iterating)
     if (state[b] & 3) return;                       // accepted earlier: X, mu stay as they are
+    const double sigma = sigmas[b];
     double *Xb = X + voff[b] * SB;
     const double *Zb = Z + voff[b] * SB;
     const int tid = threadIdx.x;
@@ -2624,8 +2627,9 @@ __global__ __launch_bounds__(256) void ss_output_kernel(const int *__restrict__ 
                                                         const int *__restrict__ ms,
                                                         const int64_t *__restrict__ eoff, const int64_t *__restrict__ xoff,
                                                         double *__restrict__ evals, double *__restrict__ evecs,
-                                                        double sigma) {
+                                                        const double *__restrict__ sigmas) {
     const int b = blockIdx.x, n = ns[b], m = ms[b];
+    const double sigma = sigmas[b];
     const double *Xb = X + voff[b] * SB;
     const short *pm = perm ? perm + voff[b] : nullptr;
     for (int q = threadIdx.x; q < m; q += 256) evals[eoff[b] + q] = sigma + mu[(size_t)b * SS_B + q];
@@ -2799,7 +2803,20 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
 
     if (!b.h_inertia.empty()) b.inertia.from_host(b.h_inertia, s);
     // ---- C - sigma I = L L^T ----
-    hipLaunchKernelGGL(ss_shift_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, SS_SIGMA);
+    // The iteration converges like (lambda_i - sigma) / (lambda_9 - sigma), so the shift belongs just below the
+    // wanted eigenvalues.  C is positive semi-definite (interior agglomerates: exactly singular), which leaves
+    // sigma < 0 in general; but a certified count of 0 says that every eigenvalue lies above vu, and the one
+    // pair the "at least one" rule then asks for is the smallest: those matrices are shifted to just below vu
+    // (agglomerates on an essential boundary, most agglomerates of a coarse level: 17 -> 9 iterations).
+    {
+        const double vu = b.window_vu;
+        const double neg = -std::min(1e-3, std::max(1e-7, std::fabs(vu) / 30.0));
+        std::vector<double> sg((size_t)b.count, b.h_inertia.empty() ? SS_SIGMA : neg);
+        for (int i = 0; i < b.count && !b.h_inertia.empty(); ++i)
+            if (b.h_inertia[i] == 0 && vu > 0.0) sg[i] = vu - std::max(1e-6, 1e-3 * vu);
+        b.ss_sigma.from_host(sg, s);
+    }
+    hipLaunchKernelGGL(ss_shift_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, 0.0, b.ss_sigma.p);
     if (lds_path) {
         profiler().begin(s);
         auto go = [&](auto kern, int win) {
@@ -2885,7 +2902,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         DBuf<double> dbgbuf;
         if (dbg_on) dbgbuf.alloc((size_t)b.count * 2 * SS_B);
         hipLaunchKernelGGL(ss_rr_kernel, dim3(nact), dim3(256), 0, s, b.n.p, b.voff.p, X, Z, mu, state.p, iter,
-                           SS_SIGMA, vu, b.h_inertia.empty() ? (const int *)nullptr : b.inertia.p, dbgbuf.p, active.p);
+                           b.ss_sigma.p, vu, b.h_inertia.empty() ? (const int *)nullptr : b.inertia.p, dbgbuf.p, active.p);
         if (dbg_on && iter > 0) {
             auto hd = dbgbuf.to_host(s);
             const int show = std::min(b.count, 3);
@@ -2953,7 +2970,7 @@ void eig_subspace_vectors(hipStream_t s, EigBatch &b, const int64_t *eoff, const
                           double *evecs) {
     profiler().begin(s);
     hipLaunchKernelGGL(ss_output_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, b.Xbuf.p, b.ss_mu.p, b.dis.p,
-                       b.has_perm ? b.perm.p : nullptr, b.m.p, eoff, xoff, evals, evecs, SS_SIGMA);
+                       b.has_perm ? b.perm.p : nullptr, b.m.p, eoff, xoff, evals, evecs, b.ss_sigma.p);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "eig_ss_output", 0.0, 0.0);
 }

@@ -219,6 +219,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
             if (!aggregates && !host_mis) on_dev = build_relations_mis_device(L.rel, L.drel, mis_stream);
             if (on_dev) tmis.lap("    device MIS tables", lev);
             if (!on_dev) {
+                fetch_relations_ae_host(L.rel, L.drel, mis_stream);
                 build_relations_mis(L.rel, aggregates ? &aggA : nullptr);
                 upload_relations_mis(L.drel, L.rel, mis_stream);
             }
@@ -252,7 +253,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     L.ae_m.assign((size_t)nparts, 0);
     struct Chunk { int ae0, count; DBuf<double> evals, evecs; std::vector<int64_t> eoff, xoff; DBuf<int64_t> d_eoff, d_xoff; };
     std::vector<Chunk> chunks;
-    if (P.keep_debug) L.ae_D.alloc((size_t)rel.AE_to_dof.J.size());
+    if (P.keep_debug) L.ae_D.alloc((size_t)rel.AE_to_dof.I[nparts]);
     // AE ownership: contiguous ranges balanced by the n^3 cost of the eigenproblems
     const int world = P.world > 1 ? P.world : 1;
     std::vector<int> ae_begin((size_t)world + 1, nparts);
@@ -540,6 +541,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
 // and stream beside the Galerkin product when the prolongator is not smoothed.
 static void prepare_next_host(const Level &L, const int *p_rowptr_dev, const double *p_val_dev, int p_nrows,
                               int64_t p_nnz, hipStream_t s, NextPrep &out) {
+    fetch_relations_ae_host(const_cast<Relations &>(L.rel), L.drel, s);
     const Relations &rel = L.rel;
     const int nparts = rel.nparts;
     // coarse elem_to_dof = AE_to_dof x pattern(P_tent), first-encounter order

@@ -35,6 +35,10 @@ struct Relations {
     hvec<int64_t> pair_loc_off;  // [npairs+1] offsets into pair_loc
     hvec<int> pair_loc;          // AE-local index of each MIS dof
     hvec<int> ae_pair;           // aligned with AE_to_mis.J: pair id of (AE, mis)
+    // device build (build_relations_ae_device): AE_to_dof.J, dof_to_AE, dof_id_inAE and agg_flags (0.4 GB at
+    // 256^3) stay on the device until a host phase asks for them (fetch_relations_ae_host): the host MIS
+    // build, the host build of the next level's elements, the inspection getters
+    bool ae_host_pending = false;
 };
 
 // agg_create_partitioning_tables + agg_produce_mises + agg_construct_agg_flags
@@ -72,6 +76,7 @@ void upload_relations_ae(DevRelations &d, const Relations &r, hipStream_t s);
 bool build_relations_ae_device(Relations &r, DevRelations &d, const int *e2d_dev, int NE, int nde,
                                const int *part_dev, int nparts, int ND, const signed char *bdr_dev,
                                hipStream_t s);
+void fetch_relations_ae_host(Relations &r, const DevRelations &d, hipStream_t s);
 void upload_relations_mis(DevRelations &d, const Relations &r, hipStream_t s);
 // build_relations_mis + upload_relations_mis on the device (topology_mis.hip): same tables bit for bit; needs the AE
 // half of `d`.  Returns false when the level has to take the host path (hash collision, invalid partition).

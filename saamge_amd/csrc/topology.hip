@@ -1001,12 +1001,8 @@ bool build_relations_ae_device(Relations &r, DevRelations &d, const int *e2d_dev
     hipLaunchKernelGGL(d2ae_sort_flags_kernel, dim3(div_up(ND, 256)), dim3(256), 0, s, ND, d.d2ae_I.p, d.d2ae_J.p,
                        d.dof_id_inAE.p, bdr_dev, d.flags.p);
     SA_HIP_CHECK(hipGetLastError());
-    // host copies for the MIS tables and the later (host) phases
-    download(r.AE_to_dof.J, d.ae2d_J, (size_t)nae2d, s);
-    download(r.dof_to_AE.I, d.d2ae_I, (size_t)ND + 1, s);
-    download(r.dof_to_AE.J, d.d2ae_J, (size_t)nae2d, s);
-    download(r.dof_id_inAE, d.dof_id_inAE, (size_t)nae2d, s);
-    download(r.agg_flags, d.flags, (size_t)ND, s);
+    // (host copies of these tables: on demand, fetch_relations_ae_host)
+    r.ae_host_pending = true;
     r.AE_to_dof.ncols = ND;
     r.dof_to_AE.ncols = nparts;
     // dof_to_elem / elem_ldof for the assembly kernels (as in upload_relations_ae)
@@ -1026,6 +1022,18 @@ bool build_relations_ae_device(Relations &r, DevRelations &d, const int *e2d_dev
     SA_HIP_CHECK(hipStreamSynchronize(s));
     SA_REQUIRE(!(err.to_host(s)[0] & 8), "dof without any element");
     return true;
+}
+
+void fetch_relations_ae_host(Relations &r, const DevRelations &d, hipStream_t s) {
+    if (!r.ae_host_pending) return;
+    const size_t nae2d = (size_t)r.AE_to_dof.I[(size_t)r.nparts];
+    download(r.AE_to_dof.J, d.ae2d_J, nae2d, s);
+    download(r.dof_to_AE.I, d.d2ae_I, (size_t)r.ND + 1, s);
+    download(r.dof_to_AE.J, d.d2ae_J, nae2d, s);
+    download(r.dof_id_inAE, d.dof_id_inAE, nae2d, s);
+    download(r.agg_flags, d.flags, (size_t)r.ND, s);
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    r.ae_host_pending = false;
 }
 
 void upload_relations_mis(DevRelations &d, const Relations &r, hipStream_t s) {
