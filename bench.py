@@ -212,6 +212,8 @@ def main():
     ap.add_argument("--correct-nullspace", action="store_true",
                     help="extra scaling_P level under the coarsest spectral operator (reference drivers' default)")
     ap.add_argument("--nu-pro", type=int, default=0, help="prolongator smoothing degree (0 = tentative, the reference default)")
+    ap.add_argument("--eigensolver", default="subspace", choices=["subspace", "dense"],
+                    help="local eigensolver: few-eigenpairs path with certified count (default) or the dense two-stage path only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -249,6 +251,7 @@ def main():
     torch.cuda.synchronize()
     torch.cuda.empty_cache()        # the generator's temporaries go back to the device before the library allocates
     params = capi.default_params(num_coarsenings=args.levels - 1, theta=args.theta, nu_relax=3, nu_pro=args.nu_pro,
+                                 eigensolver=args.eigensolver,
                                  correct_nullspace=args.correct_nullspace)
     if args.theta2 is not None:      # first_theta / theta of the reference's MultilevelParameters (inc/ml.hpp:66-70)
         for l in range(1, capi.MAX_LEVELS):

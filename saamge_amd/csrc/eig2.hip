@@ -2914,7 +2914,12 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
             }
         }
         if (prof) profiler().end(s, "eig_ss_rr", 0.0, 0.0);
-        if (iter >= 1) {      // (one small read-back per iteration: a launch costs ~1 ms here)
+        // The state is read back (and the active list rebuilt) after every iteration of the large matrices, whose
+        // iterations cost milliseconds; the small ones (LDS solves, ~0.1 ms for the few hundred survivors of a
+        // chunk) are checked after iterations 1, 3, 6, 9, ...: the read-back's host round trip (~0.25 ms) was
+        // most of an iteration, an accepted matrix leaves the kernels at once, up to two spare iterations are cheap.
+        const bool check = iter >= 1 && (b.max_n > 1280 || iter == 1 || iter % 3 == 0);
+        if (check) {
             auto t = state.to_host(s);
             hstate.assign(t.begin(), t.end());
             done = true;
