@@ -140,6 +140,15 @@ int saamge_amd_ml_produce_data(int n, const int *rowptr, const int *col, const d
                                const signed char *bdr_dofs, const int *const *partitions,
                                const int *nparts, const saamge_amd_params *params, void *stream,
                                saamge_amd_hierarchy **out);
+/* The same with 64-bit row offsets, for an operator with more than 2^31 stored entries on one GPU (the
+ * reference's HYPRE_Int is 32-bit and reaches such sizes only split over MPI ranks): Q2 elasticity on 96^3
+ * elements has 4.2e9.  Column indices and dimensions stay 32-bit.  Inside the library every operator carries
+ * 64-bit row offsets; the 32-bit entry widens its input on the device. */
+int saamge_amd_ml_produce_data64(int n, const long long *rowptr, const int *col, const double *val,
+                                 int NE, int nde, const int *elem_to_dof, const double *elmat,
+                                 const signed char *bdr_dofs, const int *const *partitions,
+                                 const int *nparts, const saamge_amd_params *params, void *stream,
+                                 saamge_amd_hierarchy **out);
 /* adapt_update_operators(A, ml_data, mlp, resmooth_interp = true), src/adapt.cpp:188-219: the
  * matrix values changed (same sparsity and topology): every interpolation is kept -- no local
  * eigenproblem is solved again --, smoother diagonals, smoothed prolongators (nu_pro > 0), all
@@ -180,7 +189,9 @@ int saamge_amd_num_levels(const saamge_amd_hierarchy *h); /* number of operators
 int saamge_amd_level_info(const saamge_amd_hierarchy *h, int level, long long info[16]);
 /* which: 0 A_l, 1 interp, 2 restr, 3 Ac (host output buffers sized from level_info) */
 int saamge_amd_get_csr(const saamge_amd_hierarchy *h, int level, int which, int *rowptr, int *col,
-                       double *val);
+                       double *val);       /* fails on an operator with more than 2^31 - 1 entries */
+int saamge_amd_get_csr64(const saamge_amd_hierarchy *h, int level, int which, long long *rowptr, int *col,
+                         double *val);
 /* which: 0 AE_to_dof, 1 dof_to_AE, 2 mis_to_dof, 3 mis_to_AE, 4 AE_to_mis, 5 elem_to_dof.
  * Pass I = J = NULL to query sizes: *nrows, *nconn. */
 int saamge_amd_get_table(const saamge_amd_hierarchy *h, int level, int which, int *nrows,
@@ -201,6 +212,8 @@ int saamge_amd_get_mis_svd(const saamge_amd_hierarchy *h, int level, long long *
 /* y = A x, hypre ParCSRMatrixMatvec as used by src/tg.cpp:115 */
 int saamge_amd_spmv(int nrows, int ncols, const int *rowptr, const int *col, const double *val,
                     const double *x, double *y);
+int saamge_amd_spmv64(int nrows, int ncols, const long long *rowptr, const int *col, const double *val,
+                      const double *x, double *y);
 /* xpacks_calc_lower_eigens_dense batched (src/xpacks.cpp:222-314) for A x = lambda D x with
  * diagonal D: matrices packed column-major one after the other, D packed likewise.
  * Outputs (host): m[i]; evals at offset sum_{j<i} n_j; evecs at offset sum_{j<i} n_j^2

@@ -26,6 +26,7 @@ SYMBOLS = [
     "saamge_amd_set_coarse_solver", "saamge_amd_comm_unique_id", "saamge_amd_comm_create", "saamge_amd_comm_destroy",
     "saamge_amd_params_set_comm", "saamge_amd_comm_selftest", "saamge_amd_comm_last_error",
     "saamge_amd_release_cached_memory", "saamge_amd_cached_memory_bytes",
+    "saamge_amd_ml_produce_data64", "saamge_amd_get_csr64", "saamge_amd_spmv64",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong))
@@ -190,7 +191,10 @@ class Hierarchy(object):
         parts = (C.c_void_p * len(partitions))(*[_ptr(p).value for p in partitions])
         npa = (C.c_int * len(nparts))(*[int(x) for x in nparts])
         h = C.c_void_p()
-        _check(lib.saamge_amd_ml_produce_data(
+        # 64-bit row offsets (torch.int64 / np.int64): operators beyond 2^31 stored entries
+        wide = str(getattr(A_rowptr, "dtype", "")).endswith("int64")
+        produce = lib.saamge_amd_ml_produce_data64 if wide else lib.saamge_amd_ml_produce_data
+        _check(produce(
             C.c_int(n), _ptr(A_rowptr), _ptr(A_col), _ptr(A_val), C.c_int(NE), C.c_int(nde),
             _ptr(elem_to_dof), _ptr(elmat), _ptr(bdr), parts, npa, C.byref(params),
             C.c_void_p(stream), C.byref(h)))
@@ -379,6 +383,14 @@ class Hierarchy(object):
         U = np.zeros(max(info["U_size"], 1))
         _check(load().saamge_amd_get_mis_svd(self.h, C.c_int(level), _ptr(off), _ptr(sig), _ptr(U)))
         return off, sig, U
+
+
+def spmv_raw(nrows, ncols, rowptr, col, val, x, y):
+    """y = A x on raw arrays (numpy or torch; host or device); 64-bit row offsets when rowptr is int64."""
+    wide = str(getattr(rowptr, "dtype", "")).endswith("int64")
+    fn = load().saamge_amd_spmv64 if wide else load().saamge_amd_spmv
+    _check(fn(C.c_int(nrows), C.c_int(ncols), _ptr(rowptr), _ptr(col), _ptr(val), _ptr(x), _ptr(y)))
+    return y
 
 
 def spmv(A, x):

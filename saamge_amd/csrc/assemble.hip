@@ -18,7 +18,7 @@ __global__ __launch_bounds__(ASM_NT) void ae_assemble_kernel(
     const int *__restrict__ d2e_J, const int *__restrict__ part, const int *__restrict__ e2d_I,
     const int *__restrict__ e2d_J, const int *__restrict__ elem_ldof,
     const int64_t *__restrict__ eloff, const double *__restrict__ elval, int has_A,
-    const int *__restrict__ Arow, const int *__restrict__ Acol, const double *__restrict__ Aval,
+    const roff_t *__restrict__ Arow, const int *__restrict__ Acol, const double *__restrict__ Aval,
     const int64_t *__restrict__ voff, const short *__restrict__ perm) {
     const int b = blockIdx.x, p = ae0 + b, n = ns[b];
     double *Wm = W + moff[b];
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(ASM_NT) void ae_assemble_kernel(
         const int fg = has_A ? flags[g] : 0;
         if (has_A) {
             // entries copied from the global matrix (aggregates.cpp:930-934)
-            for (int k = Arow[g]; k < Arow[g + 1]; ++k) {
+            for (roff_t k = Arow[g]; k < Arow[g + 1]; ++k) {
                 const int c = Acol[k];
                 int idx = -1;
                 for (int q = d2ae_I[c]; q < d2ae_I[c + 1]; ++q)
@@ -237,9 +237,9 @@ void ae_scale(hipStream_t s, EigBatch &batch, double *Dout) {
 // ---------------------------------------------------------------------------------------
 constexpr int AB_NT = 512;
 
-__global__ __launch_bounds__(256) void max_row_kernel(int n, const int *__restrict__ rowptr, int *__restrict__ out) {
+__global__ __launch_bounds__(256) void max_row_kernel(int n, const roff_t *__restrict__ rowptr, int *__restrict__ out) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    int len = (i < n) ? rowptr[i + 1] - rowptr[i] : 0;
+    int len = (i < n) ? (int)(rowptr[i + 1] - rowptr[i]) : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_xor(len, o, 64));
     // (one contended address: only the few wavefronts that raise the maximum touch it)
@@ -257,14 +257,14 @@ __global__ __launch_bounds__(256) void ae_rows8_kernel(
     const int *__restrict__ d2ae_J, const int *__restrict__ dof_id_inAE,
     const signed char *__restrict__ flags, const int *__restrict__ d2e_I, const int *__restrict__ d2e_J,
     const int *__restrict__ part, const int *__restrict__ e2d_J, const double *__restrict__ elval,
-    const int *__restrict__ Arow, const int *__restrict__ Acol, const double *__restrict__ Aval,
+    const roff_t *__restrict__ Arow, const int *__restrict__ Acol, const double *__restrict__ Aval,
     double *__restrict__ rvals, short *__restrict__ rcols) {
     const int b = blockIdx.y, p = ae0 + b, n = ns[b];
     const int it = blockIdx.x * 256 + threadIdx.x;
     if (it >= n * RW) return;
     const int lr = it / RW, k = it - lr * RW;
     const int g = ae2d_J[ae2d_I[p] + lr];
-    const int a0 = Arow[g];
+    const roff_t a0 = Arow[g];
     int lc = -1;
     double v = 0.0;
     if (k < Arow[g + 1] - a0) {
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(AB_NT) void ae_build_kernel(
     const int *__restrict__ dof_id_inAE, const signed char *__restrict__ flags,
     const int *__restrict__ d2e_I, const int *__restrict__ d2e_J, const int *__restrict__ part,
     const int *__restrict__ e2d_I, const int *__restrict__ e2d_J, const int64_t *__restrict__ eloff,
-    const double *__restrict__ elval, const int *__restrict__ Arow, const int *__restrict__ Acol,
+    const double *__restrict__ elval, const roff_t *__restrict__ Arow, const int *__restrict__ Acol,
     const double *__restrict__ Aval, const double *__restrict__ rvals, const short *__restrict__ rcols,
     const short *__restrict__ perm, int *__restrict__ bw_out, int band_only) {
     extern __shared__ __align__(16) double lds[];
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(AB_NT) void ae_build_kernel(
     for (int it = tid; it < n * RW; it += AB_NT) {
         const int lr = it / RW, k = it - lr * RW;
         const int g = gdof[lr];
-        const int a0 = Arow[g];
+        const roff_t a0 = Arow[g];
         int lc = -1;
         double v = 0.0;
         if (k < Arow[g + 1] - a0) {
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(AB_NT) void ae_build_kernel(
 __global__ __launch_bounds__(ASM_NT) void ae_extract_kernel(
     int ae0, const int *__restrict__ ns, const int64_t *__restrict__ moff, double *__restrict__ W,
     const int *__restrict__ ae2d_I, const int *__restrict__ ae2d_J, const int *__restrict__ d2ae_I,
-    const int *__restrict__ d2ae_J, const int *__restrict__ dof_id_inAE, const int *__restrict__ Arow,
+    const int *__restrict__ d2ae_J, const int *__restrict__ dof_id_inAE, const roff_t *__restrict__ Arow,
     const int *__restrict__ Acol, const double *__restrict__ Aval) {
     const int b = blockIdx.x, p = ae0 + b, n = ns[b];
     double *Wm = W + moff[b];
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(ASM_NT) void ae_extract_kernel(
         const int g = aedofs[lr];
         double rowsum = 0.0, diag = 0.0;
         int stored = 0;
-        for (int k = Arow[g]; k < Arow[g + 1]; ++k) {
+        for (roff_t k = Arow[g]; k < Arow[g + 1]; ++k) {
             const int c = Acol[k];
             const double v = Aval[k];
             if (v == 0.0) continue;
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(ASM_NT) void ae_extract_kernel(
 __global__ __launch_bounds__(ASM_NT) void ae_window_kernel(
     int ae0, const int *__restrict__ ns, const int64_t *__restrict__ moff, double *__restrict__ W,
     const int *__restrict__ ae2d_I, const int *__restrict__ ae2d_J, const int *__restrict__ d2ae_I,
-    const int *__restrict__ d2ae_J, const int *__restrict__ dof_id_inAE, const int *__restrict__ Arow,
+    const int *__restrict__ d2ae_J, const int *__restrict__ dof_id_inAE, const roff_t *__restrict__ Arow,
     const int *__restrict__ Acol, const double *__restrict__ Aval) {
     const int b = blockIdx.x, p = ae0 + b, n = ns[b];
     double *Wm = W + moff[b];
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(ASM_NT) void ae_window_kernel(
     const int *aedofs = ae2d_J + ae2d_I[p];
     for (int lr = tid; lr < n; lr += ASM_NT) {
         const int g = aedofs[lr];
-        for (int k = Arow[g]; k < Arow[g + 1]; ++k) {
+        for (roff_t k = Arow[g]; k < Arow[g + 1]; ++k) {
             const int c = Acol[k];
             const double v = Aval[k];
             const int lc = local_id(c);
@@ -598,9 +598,9 @@ __global__ __launch_bounds__(ASM_NT) void ae_window_kernel(
                 continue;
             }
             double denom = 0.0;
-            for (int kk = Arow[c]; kk < Arow[c + 1]; ++kk)
+            for (roff_t kk = Arow[c]; kk < Arow[c + 1]; ++kk)
                 if (local_id(Acol[kk]) >= 0) denom += Aval[kk];
-            for (int kk = Arow[c]; kk < Arow[c + 1]; ++kk) {
+            for (roff_t kk = Arow[c]; kk < Arow[c + 1]; ++kk) {
                 const int ll = local_id(Acol[kk]);
                 if (ll >= 0) Wm[(size_t)ll * n + lr] += v * (Aval[kk] / denom);
             }

@@ -84,11 +84,11 @@ int saamge_amd_memcpy(void *dst, const void *src, long long bytes) {
     return 0;
 }
 
-int saamge_amd_ml_produce_data(int n, const int *rowptr, const int *col, const double *val,
-                               int NE, int nde, const int *elem_to_dof, const double *elmat,
-                               const signed char *bdr_dofs, const int *const *partitions,
-                               const int *nparts, const saamge_amd_params *params, void *stream,
-                               saamge_amd_hierarchy **out) {
+static int produce_data(int n, const void *rowptr, int rowptr_bits, const int *col, const double *val,
+                        int NE, int nde, const int *elem_to_dof, const double *elmat,
+                        const signed char *bdr_dofs, const int *const *partitions,
+                        const int *nparts, const saamge_amd_params *params, void *stream,
+                        saamge_amd_hierarchy **out) {
     SA_API_BEGIN
     SA_REQUIRE(out && params && rowptr && col && val && (params->algebraic || (elem_to_dof && elmat)) && partitions && nparts,
                "null argument");
@@ -125,10 +125,26 @@ int saamge_amd_ml_produce_data(int n, const int *rowptr, const int *col, const d
     SA_REQUIRE(p.eigensolver == 0 || p.eigensolver == 1, "bad eigensolver selector");
     SA_REQUIRE(p.world == 1 || (p.rank >= 0 && p.rank < p.world), "bad rank");
     set_thread_stream((hipStream_t)stream);
-    Hierarchy *H = hierarchy_create(n, rowptr, col, val, NE, nde, elem_to_dof, elmat, bdr_dofs,
+    Hierarchy *H = hierarchy_create(n, rowptr, rowptr_bits, col, val, NE, nde, elem_to_dof, elmat, bdr_dofs,
                                     partitions, nparts, p, (hipStream_t)stream);
     *out = new saamge_amd_hierarchy{H};
     SA_API_END
+}
+
+int saamge_amd_ml_produce_data(int n, const int *rowptr, const int *col, const double *val,
+                               int NE, int nde, const int *elem_to_dof, const double *elmat,
+                               const signed char *bdr_dofs, const int *const *partitions,
+                               const int *nparts, const saamge_amd_params *params, void *stream,
+                               saamge_amd_hierarchy **out) {
+    return produce_data(n, rowptr, 32, col, val, NE, nde, elem_to_dof, elmat, bdr_dofs, partitions, nparts, params, stream, out);
+}
+
+int saamge_amd_ml_produce_data64(int n, const long long *rowptr, const int *col, const double *val,
+                                 int NE, int nde, const int *elem_to_dof, const double *elmat,
+                                 const signed char *bdr_dofs, const int *const *partitions,
+                                 const int *nparts, const saamge_amd_params *params, void *stream,
+                                 saamge_amd_hierarchy **out) {
+    return produce_data(n, rowptr, 64, col, val, NE, nde, elem_to_dof, elmat, bdr_dofs, partitions, nparts, params, stream, out);
 }
 
 int saamge_amd_update_operators(saamge_amd_hierarchy *h, const double *new_val) {
@@ -289,18 +305,26 @@ int saamge_amd_level_info(const saamge_amd_hierarchy *h, int level, long long in
     SA_API_END
 }
 
-int saamge_amd_get_csr(const saamge_amd_hierarchy *h, int level, int which, int *rowptr, int *col,
-                       double *val) {
+static int get_csr(const saamge_amd_hierarchy *h, int level, int which, void *rowptr, int rowptr_bits, int *col, double *val) {
     SA_API_BEGIN
     SA_REQUIRE(h, "null argument");
     const Hierarchy &H = *h->H;
     const DCsr &M = level_op(H, level, which);
     hipStream_t s = H.stream;
-    if (rowptr) SA_HIP_CHECK(hipMemcpyAsync(rowptr, M.rowptr.p, 4 * ((size_t)M.nrows + 1), hipMemcpyDeviceToHost, s));
+    if (rowptr && rowptr_bits == 64)
+        SA_HIP_CHECK(hipMemcpyAsync(rowptr, M.rowptr.p, sizeof(roff_t) * ((size_t)M.nrows + 1), hipMemcpyDeviceToHost, s));
+    else if (rowptr)
+        export_rowptr32((int *)rowptr, M.rowptr, (size_t)M.nrows + 1, s);
     if (col && M.nnz) SA_HIP_CHECK(hipMemcpyAsync(col, M.col.p, 4 * (size_t)M.nnz, hipMemcpyDeviceToHost, s));
     if (val && M.nnz) SA_HIP_CHECK(hipMemcpyAsync(val, M.val.p, 8 * (size_t)M.nnz, hipMemcpyDeviceToHost, s));
     SA_HIP_CHECK(hipStreamSynchronize(s));
     SA_API_END
+}
+int saamge_amd_get_csr(const saamge_amd_hierarchy *h, int level, int which, int *rowptr, int *col, double *val) {
+    return get_csr(h, level, which, rowptr, 32, col, val);
+}
+int saamge_amd_get_csr64(const saamge_amd_hierarchy *h, int level, int which, long long *rowptr, int *col, double *val) {
+    return get_csr(h, level, which, rowptr, 64, col, val);
 }
 
 int saamge_amd_get_table(const saamge_amd_hierarchy *h, int level, int which, int *nrows,
@@ -397,8 +421,8 @@ int saamge_amd_get_mis_svd(const saamge_amd_hierarchy *h, int level, long long *
     SA_API_END
 }
 
-int saamge_amd_spmv(int nrows, int ncols, const int *rowptr, const int *col, const double *val,
-                    const double *x, double *y) {
+static int spmv_entry(int nrows, int ncols, const void *rowptr, int rowptr_bits, const int *col, const double *val,
+                      const double *x, double *y) {
     SA_API_BEGIN
     SA_REQUIRE(rowptr && col && val && x && y && nrows >= 0, "bad argument");
     hipStream_t s = 0;
@@ -406,8 +430,11 @@ int saamge_amd_spmv(int nrows, int ncols, const int *rowptr, const int *col, con
     DCsr A;
     A.nrows = nrows;
     A.ncols = ncols;
-    A.nnz = fetch_host(rowptr + nrows, 1, s)[0];
-    import_array(A.rowptr, rowptr, (size_t)nrows + 1, s);
+    import_rowptr(A.rowptr, rowptr, rowptr_bits, (size_t)nrows + 1, s);
+    roff_t nnz = 0;
+    SA_HIP_CHECK(hipMemcpyAsync(&nnz, A.rowptr.p + nrows, sizeof(roff_t), hipMemcpyDeviceToHost, s));
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    A.nnz = nnz;
     import_array(A.col, col, (size_t)A.nnz, s);
     import_array(A.val, val, (size_t)A.nnz, s);
     A.lanes_per_row = pick_lanes_per_row(A.nnz, nrows > 0 ? nrows : 1);
@@ -418,6 +445,14 @@ int saamge_amd_spmv(int nrows, int ncols, const int *rowptr, const int *col, con
     spmv(s, A, vx.p, vy.p);
     vy.finish();
     SA_API_END
+}
+int saamge_amd_spmv(int nrows, int ncols, const int *rowptr, const int *col, const double *val,
+                    const double *x, double *y) {
+    return spmv_entry(nrows, ncols, rowptr, 32, col, val, x, y);
+}
+int saamge_amd_spmv64(int nrows, int ncols, const long long *rowptr, const int *col, const double *val,
+                      const double *x, double *y) {
+    return spmv_entry(nrows, ncols, rowptr, 64, col, val, x, y);
 }
 
 __global__ void apply_dscale_kernel(int count, const int *ns, const int64_t *moff, const int64_t *voff,

@@ -184,11 +184,17 @@ inline hvec<T> fetch_host(const T *src, size_t n, hipStream_t s) {
     return v;
 }
 
-// Device CSR matrix (int32 indices like the reference's hypre/MFEM types).
+// Row offsets of every CSR / SELL operator are 64-bit: column indices and dimensions are int32 like the
+// reference's hypre/MFEM types, but the stored entries of one operator may exceed 2^31 (Q2 elasticity at
+// 96^3: 4.2e9) -- the reference splits such an operator over MPI ranks, here one GPU holds it.
+typedef int64_t roff_t;
+
+// Device CSR matrix.
 struct DCsr {
     int nrows = 0, ncols = 0;
     int64_t nnz = 0;
-    DBuf<int> rowptr, col;
+    DBuf<roff_t> rowptr;
+    DBuf<int> col;
     DBuf<double> val;
     int lanes_per_row = 8;  // SpMV launch shape, chosen from the average row length
     mutable int max_row = -1;  // longest row (computed on first use by the fused AE assembly)
@@ -197,7 +203,8 @@ struct DCsr {
     bool has_sell = false;
     int nslices = 0;
     int64_t sell_size = 0;
-    DBuf<int> sell_ptr, sell_col;
+    DBuf<roff_t> sell_ptr;
+    DBuf<int> sell_col;
     DBuf<double> sell_val;
     // coded slices: <= 64 distinct offsets col - row -> sell_tab[64 s + code], one byte per entry
     // in sell_code (four consecutive entries of a row per word); sell_ntab[s] = -1: plain slice
@@ -206,6 +213,16 @@ struct DCsr {
     DBuf<unsigned> sell_code;
     DBuf<double> sell_vtab;
 };
+
+// exclusive scans (mis.hip); out has n + 1 entries
+void exclusive_scan_int(hipStream_t s, int n, const int *in, int *out);
+void exclusive_scan_off(hipStream_t s, int n, const int *in, roff_t *out);
+
+// Row offsets crossing the C ABI (sparse.hip).  In: int32 (the reference's HYPRE_Int; widened on the device)
+// or int64 (device pointers viewed in place); host or device pointer either way.  Out: narrowed to int32 for
+// the callers of the 32-bit getters (an operator beyond 2^31 entries is an error there).
+void import_rowptr(DBuf<roff_t> &dst, const void *src, int bits, size_t n, hipStream_t s);
+void export_rowptr32(int *dst_host, const DBuf<roff_t> &src, size_t n, hipStream_t s);
 
 inline int pick_lanes_per_row(int64_t nnz, int nrows) {
     double avg = nrows ? double(nnz) / nrows : 1.0;

@@ -23,13 +23,13 @@ __global__ __launch_bounds__(256) void dense_zero_kernel(size_t nn, double *__re
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < nn) L[i] = 0.0;
 }
-__global__ __launch_bounds__(256) void dense_scatter_kernel(int n, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(256) void dense_scatter_kernel(int n, const roff_t *__restrict__ rowptr,
                                                             const int *__restrict__ col,
                                                             const double *__restrict__ val, double *__restrict__ M) {
     const long gt = (long)blockIdx.x * 256 + threadIdx.x;
     const int row = (int)(gt >> 3), lane = (int)(gt & 7);
     if (row >= n) return;
-    for (int k = rowptr[row] + lane; k < rowptr[row + 1]; k += 8) M[(size_t)col[k] * n + row] = val[k];
+    for (roff_t k = rowptr[row] + lane; k < rowptr[row + 1]; k += 8) M[(size_t)col[k] * n + row] = val[k];
 }
 
 // inverse of the nb x nb pivot block at k0 (SPD) by Gauss-Jordan elimination in LDS; a short last

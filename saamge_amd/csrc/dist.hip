@@ -15,16 +15,15 @@
 
 namespace saamge_amd {
 
-void exclusive_scan_int(hipStream_t s, int n, const int *in, int *out);  // mis.hip
 
-__global__ __launch_bounds__(256) void halo_mark_kernel(int row0, int nloc, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(256) void halo_mark_kernel(int row0, int nloc, const roff_t *__restrict__ rowptr,
                                                         const int *__restrict__ col, int *__restrict__ flag) {
     const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 7;
     const long r = gtid >> 3;
     if (r >= nloc) return;
     const int row = row0 + (int)r;
-    for (int k = rowptr[row] + lane; k < rowptr[row + 1]; k += 8) {
+    for (roff_t k = rowptr[row] + lane; k < rowptr[row + 1]; k += 8) {
         const int c = col[k];
         if (c < row0 || c >= row0 + nloc) flag[c] = 1;
     }

@@ -136,7 +136,7 @@ struct Hierarchy {              // ml_data_t
 
 // ml_produce_data (amg/src/ml.cpp:379-472).  All array arguments may be host or device
 // pointers.  partitions[k] maps level-k elements to level-k AEs.
-Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const double *Aval, int NE,
+Hierarchy *hierarchy_create(int n, const void *Arow, int rowptr_bits, const int *Acol, const double *Aval, int NE,
                             int nde, const int *elem_to_dof, const double *elmat,
                             const signed char *bdr, const int *const *partitions,
                             const int *nparts, const Params &p, hipStream_t stream);

@@ -152,7 +152,7 @@ struct DeviceInputs {   // level-0 inputs that already live on the device (see h
     int NE = 0, nde = 0;
 };
 
-static void prepare_next_host(const Level &L, const int *p_rowptr_dev, const double *p_val_dev, int p_nrows,
+static void prepare_next_host(const Level &L, const roff_t *p_rowptr_dev, const double *p_val_dev, int p_nrows,
                               int64_t p_nnz, hipStream_t s, NextPrep &out);
 
 static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &part, int nparts,
@@ -198,7 +198,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         aggA.rowptr.resize((size_t)L.A.nrows + 1);
         aggA.col.resize((size_t)L.A.nnz);
         aggA.val.resize((size_t)L.A.nnz);
-        SA_HIP_CHECK(hipMemcpyAsync(aggA.rowptr.data(), L.A.rowptr.p, sizeof(int) * ((size_t)L.A.nrows + 1), hipMemcpyDeviceToHost, s));
+        SA_HIP_CHECK(hipMemcpyAsync(aggA.rowptr.data(), L.A.rowptr.p, sizeof(roff_t) * ((size_t)L.A.nrows + 1), hipMemcpyDeviceToHost, s));
         SA_HIP_CHECK(hipMemcpyAsync(aggA.col.data(), L.A.col.p, sizeof(int) * (size_t)L.A.nnz, hipMemcpyDeviceToHost, s));
         SA_HIP_CHECK(hipMemcpyAsync(aggA.val.data(), L.A.val.p, sizeof(double) * (size_t)L.A.nnz, hipMemcpyDeviceToHost, s));
         SA_HIP_CHECK(hipStreamSynchronize(s));
@@ -485,7 +485,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     if (lev + 1 < P.num_coarsenings && P.nu_pro[lev] == 0 && !L.next_prep.ready) {
         hipStream_t side = side_stream(1);
         SA_HIP_CHECK(hipStreamSynchronize(s));       // P is complete
-        const int *prp = L.P.rowptr.p;
+        const roff_t *prp = L.P.rowptr.p;
         const double *pvl = L.P.val.p;
         const int pnr = L.P.nrows;
         const int64_t pnz = L.P.nnz;
@@ -539,7 +539,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
 // Host half of the next level's inputs (everything that needs only the topology, the MIS sizes
 // and the numerically non-zero pattern of the tentative prolongator).  Runs on its own thread
 // and stream beside the Galerkin product when the prolongator is not smoothed.
-static void prepare_next_host(const Level &L, const int *p_rowptr_dev, const double *p_val_dev, int p_nrows,
+static void prepare_next_host(const Level &L, const roff_t *p_rowptr_dev, const double *p_val_dev, int p_nrows,
                               int64_t p_nnz, hipStream_t s, NextPrep &out) {
     fetch_relations_ae_host(const_cast<Relations &>(L.rel), L.drel, s);
     const Relations &rel = L.rel;
@@ -551,9 +551,9 @@ static void prepare_next_host(const Level &L, const int *p_rowptr_dev, const dou
     Table &e2d = out.e2d;
     e2d.ncols = L.mis_coloff.back();
     e2d.I.assign((size_t)nparts + 1, 0);
-    hvec<int> p_rowptr((size_t)p_nrows + 1);
+    hvec<roff_t> p_rowptr((size_t)p_nrows + 1);
     hvec<double> p_val((size_t)p_nnz + 1);
-    SA_HIP_CHECK(hipMemcpyAsync(p_rowptr.data(), p_rowptr_dev, sizeof(int) * ((size_t)p_nrows + 1), hipMemcpyDeviceToHost, s));
+    SA_HIP_CHECK(hipMemcpyAsync(p_rowptr.data(), p_rowptr_dev, sizeof(roff_t) * ((size_t)p_nrows + 1), hipMemcpyDeviceToHost, s));
     if (p_nnz) SA_HIP_CHECK(hipMemcpyAsync(p_val.data(), p_val_dev, sizeof(double) * (size_t)p_nnz, hipMemcpyDeviceToHost, s));
     SA_HIP_CHECK(hipStreamSynchronize(s));
     // colpos: for every (AE, MIS) incidence (aligned with AE_to_mis.J) the position of each of
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(64) void scaling_p_kernel(const int *__restrict__ m
                                                        const int *__restrict__ coloff,
                                                        const int64_t *__restrict__ u_off,
                                                        const double *__restrict__ U,
-                                                       const int *__restrict__ active, int *__restrict__ prow,
+                                                       const int *__restrict__ active, roff_t *__restrict__ prow,
                                                        int *__restrict__ pcol, double *__restrict__ pval) {
     extern __shared__ double xs[];
     const int m = blockIdx.x, lane = threadIdx.x;
@@ -1008,7 +1008,8 @@ static void add_nullspace_level(Hierarchy &H) {
                        L.d_mis_k.p, L.d_mis_coloff.p, L.d_mis_u_off.p, L.mis_U.p, d_active.p, N.P.rowptr.p,
                        N.P.col.p, N.P.val.p);
     SA_HIP_CHECK(hipGetLastError());
-    SA_HIP_CHECK(hipMemcpyAsync(N.P.rowptr.p + nc, &nc, sizeof(int), hipMemcpyHostToDevice, s));
+    const roff_t nc_off = nc;
+    SA_HIP_CHECK(hipMemcpyAsync(N.P.rowptr.p + nc, &nc_off, sizeof(roff_t), hipMemcpyHostToDevice, s));
     SA_HIP_CHECK(hipStreamSynchronize(s));
     N.P.lanes_per_row = 1;
     csr_transpose(s, N.P, N.R);
@@ -1023,7 +1024,7 @@ static void add_nullspace_level(Hierarchy &H) {
 // ---------------------------------------------------------------------------------------
 // ml_produce_data
 // ---------------------------------------------------------------------------------------
-Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const double *Aval, int NE,
+Hierarchy *hierarchy_create(int n, const void *Arow, int rowptr_bits, const int *Acol, const double *Aval, int NE,
                             int nde, const int *elem_to_dof, const double *elmat,
                             const signed char *bdr, const int *const *partitions,
                             const int *nparts, const Params &p, hipStream_t stream) {
@@ -1056,11 +1057,12 @@ Hierarchy *hierarchy_create(int n, const int *Arow, const int *Acol, const doubl
     // level 0 inputs
     Level &L0 = *H.levels[0];
     {
-        auto last = fetch_host(Arow + n, 1, s);
-        const int64_t nnz = last[0];
+        import_rowptr(L0.A.rowptr, Arow, rowptr_bits, (size_t)n + 1, s);
+        roff_t nnz = 0;
+        SA_HIP_CHECK(hipMemcpyAsync(&nnz, L0.A.rowptr.p + n, sizeof(roff_t), hipMemcpyDeviceToHost, s));
+        SA_HIP_CHECK(hipStreamSynchronize(s));
         L0.A.nrows = L0.A.ncols = n;
         L0.A.nnz = nnz;
-        import_array(L0.A.rowptr, Arow, (size_t)n + 1, s);
         import_array(L0.A.col, Acol, (size_t)nnz, s);
         import_array(L0.A.val, Aval, (size_t)nnz, s);
         finish_csr(L0.A);

@@ -45,7 +45,7 @@ void build_P_R(hipStream_t s, const DevRelations &rel, const Relations &hrel,
 // topology is built from it).  Returns false when an AE has too many coarse dofs for the LDS kernel
 // (the caller then takes the host path).
 bool coarse_e2d_device(hipStream_t s, const DevRelations &rel, const Relations &hrel, const int *d_mis_k,
-                       const int *d_mis_coloff, int ncoarse, const int *p_rowptr, const double *p_val,
+                       const int *d_mis_coloff, int ncoarse, const roff_t *p_rowptr, const double *p_val,
                        DBuf<int> &colpos_ptr, DBuf<int> &colpos, Table &e2d);
 
 // Ac = P^T A P exploiting the MIS block structure of P (tg_coarse_matr, amg/inc/tg.hpp:696-709).

@@ -210,12 +210,15 @@ __global__ __launch_bounds__(256) void p_count_kernel(int ND, const int *__restr
     if (i < ND) cnt[i] = k[mises[i]];
 }
 
-// exclusive scan of ints, three small kernels (tile = 1024)
+// exclusive scan of ints, three small kernels (tile = 1024); OUT = int, or roff_t for the row offsets of an
+// operator (counts are int, their running sum may pass 2^31)
+template <class OUT>
 __global__ __launch_bounds__(256) void scan_tile_kernel(int n, const int *__restrict__ in,
-                                                        int *__restrict__ out, int *__restrict__ tsum) {
-    __shared__ int sh[256];
+                                                        OUT *__restrict__ out, OUT *__restrict__ tsum) {
+    __shared__ OUT sh[256];
     const long base = (long)blockIdx.x * 1024;
-    int v[4], run = 0;
+    int v[4];
+    OUT run = 0;
     for (int q = 0; q < 4; ++q) {
         const long i = base + threadIdx.x * 4 + q;
         v[q] = (i < n) ? in[i] : 0;
@@ -224,12 +227,12 @@ __global__ __launch_bounds__(256) void scan_tile_kernel(int n, const int *__rest
     sh[threadIdx.x] = run;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {
-        const int t = (threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
+        const OUT t = (threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
         __syncthreads();
         sh[threadIdx.x] += t;
         __syncthreads();
     }
-    int excl = sh[threadIdx.x] - run;
+    OUT excl = sh[threadIdx.x] - run;
     for (int q = 0; q < 4; ++q) {
         const long i = base + threadIdx.x * 4 + q;
         if (i < n) out[i] = excl;
@@ -237,18 +240,19 @@ __global__ __launch_bounds__(256) void scan_tile_kernel(int n, const int *__rest
     }
     if (threadIdx.x == 255) tsum[blockIdx.x] = sh[255];
 }
-__global__ __launch_bounds__(256) void scan_sums_kernel(int nt, int *__restrict__ tsum, int *__restrict__ total) {
-    __shared__ int sh[256];
-    __shared__ int carry;
+template <class OUT>
+__global__ __launch_bounds__(256) void scan_sums_kernel(int nt, OUT *__restrict__ tsum, OUT *__restrict__ total) {
+    __shared__ OUT sh[256];
+    __shared__ OUT carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     for (int base = 0; base < nt; base += 256) {
         const int i = base + threadIdx.x;
-        const int x = (i < nt) ? tsum[i] : 0;
+        const OUT x = (i < nt) ? tsum[i] : 0;
         sh[threadIdx.x] = x;
         __syncthreads();
         for (int o = 1; o < 256; o <<= 1) {
-            const int t = (threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
+            const OUT t = (threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
             __syncthreads();
             sh[threadIdx.x] += t;
             __syncthreads();
@@ -260,24 +264,28 @@ __global__ __launch_bounds__(256) void scan_sums_kernel(int nt, int *__restrict_
     }
     if (threadIdx.x == 0) *total = carry;
 }
-__global__ __launch_bounds__(256) void scan_add_kernel(int n, int *__restrict__ out,
-                                                       const int *__restrict__ tsum,
-                                                       const int *__restrict__ total) {
+template <class OUT>
+__global__ __launch_bounds__(256) void scan_add_kernel(int n, OUT *__restrict__ out,
+                                                       const OUT *__restrict__ tsum,
+                                                       const OUT *__restrict__ total) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] += tsum[i >> 10];
     if (i == 0) out[n] = *total;
 }
 
 // out has n+1 entries
-void exclusive_scan_int(hipStream_t s, int n, const int *in, int *out) {
+template <class OUT>
+static void exclusive_scan_t(hipStream_t s, int n, const int *in, OUT *out) {
     const int nt = div_up(n, 1024);
-    DBuf<int> tsum((size_t)nt + 1);
-    hipLaunchKernelGGL(scan_tile_kernel, dim3(nt), dim3(256), 0, s, n, in, out, tsum.p);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, s, nt, tsum.p, tsum.p + nt);
-    hipLaunchKernelGGL(scan_add_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, out, tsum.p, tsum.p + nt);
+    DBuf<OUT> tsum((size_t)nt + 1);
+    hipLaunchKernelGGL(scan_tile_kernel<OUT>, dim3(nt), dim3(256), 0, s, n, in, out, tsum.p);
+    hipLaunchKernelGGL(scan_sums_kernel<OUT>, dim3(1), dim3(256), 0, s, nt, tsum.p, tsum.p + nt);
+    hipLaunchKernelGGL(scan_add_kernel<OUT>, dim3(div_up(n, 256)), dim3(256), 0, s, n, out, (const OUT *)tsum.p, (const OUT *)(tsum.p + nt));
     SA_HIP_CHECK(hipGetLastError());
     SA_HIP_CHECK(hipStreamSynchronize(s));  // tsum is freed on return
 }
+void exclusive_scan_int(hipStream_t s, int n, const int *in, int *out) { exclusive_scan_t<int>(s, n, in, out); }
+void exclusive_scan_off(hipStream_t s, int n, const int *in, roff_t *out) { exclusive_scan_t<roff_t>(s, n, in, out); }
 
 __global__ __launch_bounds__(256) void p_fill_kernel(int ND, const int *__restrict__ mises,
                                                      const int *__restrict__ row_in_mis,
@@ -286,14 +294,15 @@ __global__ __launch_bounds__(256) void p_fill_kernel(int ND, const int *__restri
                                                      const int *__restrict__ coloff,
                                                      const int64_t *__restrict__ u_off,
                                                      const double *__restrict__ U,
-                                                     const int *__restrict__ rowptr,
+                                                     const roff_t *__restrict__ rowptr,
                                                      int *__restrict__ col, double *__restrict__ val) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= ND) return;
     const int m = mises[i], km = k[m];
     const int r = mis2d_I[m + 1] - mis2d_I[m];
     const double *Um = U + u_off[m] + row_in_mis[i];
-    const int base = rowptr[i], c0 = coloff[m];
+    const roff_t base = rowptr[i];
+    const int c0 = coloff[m];
     for (int v = 0; v < km; ++v) {
         col[base + v] = c0 + v;
         val[base + v] = Um[(size_t)v * r];
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(256) void r_fill_kernel(int num_mises, const int *_
                                                      const int *__restrict__ coloff,
                                                      const int64_t *__restrict__ u_off,
                                                      const double *__restrict__ U,
-                                                     const int *__restrict__ rowptr,
+                                                     const roff_t *__restrict__ rowptr,
                                                      int *__restrict__ col, double *__restrict__ val) {
     const int m = blockIdx.x;
     const int km = k[m];
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(256) void r_fill_kernel(int num_mises, const int *_
     const double *Um = U + u_off[m];
     for (int idx = threadIdx.x; idx < km * r; idx += 256) {
         const int v = idx / r, i = idx % r;
-        const int base = rowptr[coloff[m] + v];
+        const roff_t base = rowptr[coloff[m] + v];
         col[base + i] = dofs[i];
         val[base + i] = Um[(size_t)v * r + i];
     }
@@ -329,7 +338,7 @@ void build_P_R(hipStream_t s, const DevRelations &rel, const Relations &hrel,
     const int ND = hrel.ND;
     int nc = 0;
     int64_t nnz = 0;
-    std::vector<int> r_rowptr;
+    std::vector<roff_t> r_rowptr;
     r_rowptr.push_back(0);
     for (int m = 0; m < hrel.num_mises; ++m) {
         const int r = hrel.mis_to_dof.row_size(m);
@@ -337,7 +346,6 @@ void build_P_R(hipStream_t s, const DevRelations &rel, const Relations &hrel,
         nnz += (int64_t)h_k[m] * r;
         for (int v = 0; v < h_k[m]; ++v) r_rowptr.push_back(r_rowptr.back() + r);
     }
-    SA_REQUIRE(nnz < (int64_t)1 << 31, "prolongator too large for 32-bit indices");
     P.nrows = ND; P.ncols = nc; P.nnz = nnz;
     P.rowptr.alloc((size_t)ND + 1);
     P.col.alloc((size_t)nnz);
@@ -345,7 +353,7 @@ void build_P_R(hipStream_t s, const DevRelations &rel, const Relations &hrel,
     {
         DBuf<int> cnt((size_t)ND);
         hipLaunchKernelGGL(p_count_kernel, dim3(div_up(ND, 256)), dim3(256), 0, s, ND, rel.mises.p, d_k, cnt.p);
-        exclusive_scan_int(s, ND, cnt.p, P.rowptr.p);
+        exclusive_scan_off(s, ND, cnt.p, P.rowptr.p);
     }
     hipLaunchKernelGGL(p_fill_kernel, dim3(div_up(ND, 256)), dim3(256), 0, s, ND, rel.mises.p,
                        rel.dof_row_in_mis.p, rel.mis2d_I.p, d_k, d_coloff, d_u_off, U, P.rowptr.p,
@@ -389,7 +397,7 @@ __global__ __launch_bounds__(256) void ae_ke_max_kernel(int nparts, const int *_
 __global__ __launch_bounds__(256) void coarse_e2d_kernel(
     const int *__restrict__ ae2d_I, const int *__restrict__ ae2d_J, const int *__restrict__ ae2mis_I,
     const int *__restrict__ ae2mis_J, const int *__restrict__ mises, const int *__restrict__ mis_k,
-    const int *__restrict__ mis_coloff, const int *__restrict__ colpos_ptr, const int *__restrict__ prow,
+    const int *__restrict__ mis_coloff, const int *__restrict__ colpos_ptr, const roff_t *__restrict__ prow,
     const double *__restrict__ pval, int cap, int *__restrict__ colpos, int *__restrict__ e2d_J,
     int *__restrict__ err) {
     extern __shared__ unsigned long long ce_keys[];      // [cap] keys, then [cap] coarse dof ids
@@ -414,7 +422,8 @@ __global__ __launch_bounds__(256) void coarse_e2d_kernel(
             const int mid = (lo + hi) >> 1;
             if (ae2mis_J[mid] < m) lo = mid + 1; else hi = mid;
         }
-        const int base = colpos_ptr[lo] - c0, pr = prow[dof];
+        const int base = colpos_ptr[lo] - c0;
+        const roff_t pr = prow[dof];
         for (int v = 0; v < km; ++v)
             if (pval[pr + v] != 0.0)
                 atomicMin(&ce_keys[base + v], ((unsigned long long)(unsigned)(k - d0) << 32) | (unsigned)(base + v));
@@ -435,7 +444,7 @@ __global__ __launch_bounds__(256) void coarse_e2d_kernel(
 }
 
 bool coarse_e2d_device(hipStream_t s, const DevRelations &rel, const Relations &hrel, const int *d_mis_k,
-                       const int *d_mis_coloff, int ncoarse, const int *p_rowptr, const double *p_val,
+                       const int *d_mis_coloff, int ncoarse, const roff_t *p_rowptr, const double *p_val,
                        DBuf<int> &colpos_ptr, DBuf<int> &colpos, Table &e2d) {
     const int nparts = hrel.nparts;
     const long npairs = (long)hrel.AE_to_mis.J.size();
@@ -482,7 +491,7 @@ constexpr int RAP_HASH = 2048;
 // ascending list.
 __global__ __launch_bounds__(RAP_NT) void rap_symbolic_kernel(
     int pass, const int *__restrict__ mis2d_I, const int *__restrict__ mis2d_J,
-    const int *__restrict__ Arow, const int *__restrict__ Acol, const int *__restrict__ mises,
+    const roff_t *__restrict__ Arow, const int *__restrict__ Acol, const int *__restrict__ mises,
     const int *__restrict__ k, int *__restrict__ cnt, const int *__restrict__ nbr_ptr,
     int *__restrict__ nbr, int *__restrict__ err, int *__restrict__ stage = nullptr, int stage_cap = 0) {
     __shared__ int table[RAP_HASH];
@@ -499,7 +508,7 @@ __global__ __launch_bounds__(RAP_NT) void rap_symbolic_kernel(
     const int *dofs = mis2d_J + mis2d_I[m1];
     for (int il = threadIdx.x; il < r1; il += RAP_NT) {
         const int g = dofs[il];
-        for (int q = Arow[g]; q < Arow[g + 1]; ++q) {
+        for (roff_t q = Arow[g]; q < Arow[g + 1]; ++q) {
             const int m2 = mises[Acol[q]];
             if (k[m2] == 0) continue;
             unsigned h = ((unsigned)m2 * 2654435761u) & (RAP_HASH - 1);
@@ -547,11 +556,11 @@ __global__ __launch_bounds__(256) void rap_unstage_kernel(int nm, int cap, const
 }
 
 __global__ __launch_bounds__(RAP_NT) void rap_numeric_kernel(
-    int m_first, const int *__restrict__ mis2d_I, const int *__restrict__ mis2d_J, const int *__restrict__ Arow,
+    int m_first, const int *__restrict__ mis2d_I, const int *__restrict__ mis2d_J, const roff_t *__restrict__ Arow,
     const int *__restrict__ Acol, const double *__restrict__ Aval, const int *__restrict__ mises,
     const int *__restrict__ row_in_mis, const int *__restrict__ k, const int *__restrict__ coloff,
     const int64_t *__restrict__ u_off, const double *__restrict__ U,
-    const int *__restrict__ nbr_ptr, const int *__restrict__ nbr, const int *__restrict__ crowptr,
+    const int *__restrict__ nbr_ptr, const int *__restrict__ nbr, const roff_t *__restrict__ crowptr,
     int *__restrict__ ccol, double *__restrict__ cval, int lds_doubles) {
     extern __shared__ __align__(16) double lds[];
     const int m1 = m_first + blockIdx.x;
@@ -614,7 +623,7 @@ __global__ __launch_bounds__(RAP_NT) void rap_numeric_kernel(
             for (int il = tid; il < rc; il += RAP_NT) {
                 const int g = dofs[c0 + il];
                 double *Trow = T + (size_t)il * ncol;
-                for (int q = Arow[g]; q < Arow[g + 1]; ++q) {
+                for (roff_t q = Arow[g]; q < Arow[g + 1]; ++q) {
                     const int j = Acol[q];
                     const int m2 = mises[j];
                     int lo = 0, hi = nn;      // (the neighbour list holds exactly the MISes with k > 0)
@@ -655,7 +664,7 @@ void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, cons
     Ac.nrows = Ac.ncols = nc;
     Ac.nnz = 0;
     if (nm == 0 || nc == 0) {
-        Ac.rowptr.from_host(std::vector<int>(1, 0), s);
+        Ac.rowptr.from_host(std::vector<roff_t>(1, 0), s);
         return;
     }
     DBuf<int> cnt((size_t)nm), err(1);
@@ -682,7 +691,7 @@ void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, cons
     SA_HIP_CHECK(hipGetLastError());
     auto h_nbr = nbr.to_host(s);
     // row pointers of Ac and LDS sizing
-    std::vector<int> crow((size_t)nc + 1, 0);
+    std::vector<roff_t> crow((size_t)nc + 1, 0);
     int64_t nnz = 0;
     size_t need_max = 0, small_max = 0;
     for (int m = 0; m < nm; ++m) {
@@ -700,7 +709,6 @@ void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, cons
         if (need > need_max) need_max = need;
         small_max = std::max(small_max, (size_t)(3 * h_cnt[m] + 2) + (size_t)(h_k[m] + 8) * ncol);
     }
-    SA_REQUIRE(nnz < (int64_t)1 << 31, "coarse operator too large for 32-bit indices");
     for (int i = 0; i < nc; ++i) crow[i + 1] += crow[i];
     // Blocks that fit 64 KiB in one pass get by with the k output rows + >= 8 rows of T per chunk of
     // MIS rows (16 KiB floor): the kernel is bound by the latency of its dependent gathers, and

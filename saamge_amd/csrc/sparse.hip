@@ -9,7 +9,7 @@ namespace saamge_amd {
 enum { MODE_PLAIN = 0, MODE_RESIDUAL = 1, MODE_ADD = 2, MODE_SMOOTH = 3 };
 
 template <int L, int MODE>
-__global__ __launch_bounds__(256) void spmv_kernel(int nrows, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(256) void spmv_kernel(int nrows, const roff_t *__restrict__ rowptr,
                                                    const int *__restrict__ col,
                                                    const double *__restrict__ val,
                                                    const double *__restrict__ x,
@@ -21,9 +21,9 @@ __global__ __launch_bounds__(256) void spmv_kernel(int nrows, const int *__restr
     const int lane = threadIdx.x & (L - 1);
     const long row = gtid / L;
     if (row >= nrows) return;  // whole L-group leaves together (256 % L == 0)
-    const int beg = rowptr[row], end = rowptr[row + 1];
+    const roff_t beg = rowptr[row], end = rowptr[row + 1];
     double sum = 0.0;
-    for (int k = beg + lane; k < end; k += L) {
+    for (roff_t k = beg + lane; k < end; k += L) {
         const double v = __builtin_nontemporal_load(val + k);
         const int c = __builtin_nontemporal_load(col + k);
         sum = fma(v, x[c], sum);
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void spmv_kernel(int nrows, const int *__restr
 // offset table, which sits one entry per lane in a register and is read with a cross-lane
 // permute.  9 instead of 12 bytes per stored entry on the level that dominates the solve.
 template <int MODE>
-__global__ __launch_bounds__(256) void sell_spmv_kernel(int nrows, int row0, const int *__restrict__ sptr,
+__global__ __launch_bounds__(256) void sell_spmv_kernel(int nrows, int row0, const roff_t *__restrict__ sptr,
                                                         const int *__restrict__ col,
                                                         const double *__restrict__ val,
                                                         const int *__restrict__ ntab,
@@ -65,10 +65,10 @@ __global__ __launch_bounds__(256) void sell_spmv_kernel(int nrows, int row0, con
     const long row = (long)blockIdx.x * 256 + threadIdx.x;
     const int slice = (int)(row >> 6), lane = threadIdx.x & 63;
     if ((long)slice * 64 >= nrows) return;
-    const int beg = sptr[slice], end = sptr[slice + 1];
+    const roff_t beg = sptr[slice], end = sptr[slice + 1];
     const int *cp = col + beg + lane;
     const double *vp = val + beg + lane;
-    const int w = (end - beg) >> 6;
+    const int w = (int)((end - beg) >> 6);
     double s0 = 0.0, s1 = 0.0;
     int k = 0;
     const int gslice = (row0 >> 6) + slice;
@@ -164,10 +164,10 @@ __global__ __launch_bounds__(256) void sell_spmv_kernel(int nrows, int row0, con
     }
 }
 
-__global__ __launch_bounds__(256) void sell_width_kernel(int nrows, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(256) void sell_width_kernel(int nrows, const roff_t *__restrict__ rowptr,
                                                          int *__restrict__ width64) {
     const long row = (long)blockIdx.x * 256 + threadIdx.x;
-    int len = (row < nrows) ? rowptr[row + 1] - rowptr[row] : 0;
+    int len = (row < nrows) ? (int)(rowptr[row + 1] - rowptr[row]) : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_xor(len, o, 64));
     const long slice = row >> 6;
@@ -180,22 +180,23 @@ __global__ __launch_bounds__(256) void sell_width_kernel(int nrows, const int *_
 // cache lines per load instruction (measured: 110 GB fetched to convert 5.5 GB).  Slices with more than
 // SF_CAP entries (dense coarse-level rows) take that slow walk.
 constexpr int SF_CAP = 2048;
-__global__ __launch_bounds__(64) void sell_fill_kernel(int nrows, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(64) void sell_fill_kernel(int nrows, const roff_t *__restrict__ rowptr,
                                                        const int *__restrict__ col,
                                                        const double *__restrict__ val,
-                                                       const int *__restrict__ sptr,
+                                                       const roff_t *__restrict__ sptr,
                                                        int *__restrict__ scol, double *__restrict__ sval) {
     __shared__ double lv[SF_CAP];
     __shared__ int lc[SF_CAP];
     const int slice = blockIdx.x, lane = threadIdx.x;
     const long row = (long)slice * 64 + lane;
-    const int beg = sptr[slice], w = (sptr[slice + 1] - beg) >> 6;
-    int rb = 0, re = 0;
+    const roff_t beg = sptr[slice];
+    const int w = (int)((sptr[slice + 1] - beg) >> 6);
+    roff_t rb = 0, re = 0;
     if (row < nrows) { rb = rowptr[row]; re = rowptr[row + 1]; }
     const int pad = (row < nrows) ? (int)row : nrows - 1;
-    const int r0 = rowptr[(long)slice * 64], r1 = rowptr[min((long)slice * 64 + 64, (long)nrows)];
+    const roff_t r0 = rowptr[(long)slice * 64], r1 = rowptr[min((long)slice * 64 + 64, (long)nrows)];
     if (r1 - r0 <= SF_CAP) {
-        for (int t = lane; t < r1 - r0; t += 64) {
+        for (int t = lane; t < (int)(r1 - r0); t += 64) {
             lc[t] = col[r0 + t];
             lv[t] = val[r0 + t];
         }
@@ -220,14 +221,15 @@ __global__ __launch_bounds__(64) void sell_fill_kernel(int nrows, const int *__r
 // 64 pairs falls back to the distinct offsets col - row alone (ntab = count, values streamed), and one with
 // more than 64 offsets keeps its 4-byte columns (ntab = -1).  The codes of four consecutive entries of a
 // row share one 32-bit word at codes[sptr/4 + 64 slice + 64 (k / 4) + lane].
-__global__ __launch_bounds__(256) void sell_code_kernel(int nslices, const int *__restrict__ sptr,
+__global__ __launch_bounds__(256) void sell_code_kernel(int nslices, const roff_t *__restrict__ sptr,
                                                         const int *__restrict__ scol, const double *__restrict__ sval,
                                                         int *__restrict__ ntab, int *__restrict__ tab,
                                                         double *__restrict__ vtab, unsigned *__restrict__ codes,
                                                         int with_values) {
     const int slice = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (slice >= nslices) return;
-    const int beg = sptr[slice], w = (sptr[slice + 1] - beg) >> 6;
+    const roff_t beg = sptr[slice];
+    const int w = (int)((sptr[slice + 1] - beg) >> 6);
     const int row = slice * 64 + lane;
     unsigned *wp = codes + ((size_t)(beg >> 2) + (size_t)slice * 64 + lane);
     for (int pass = with_values ? 0 : 1; pass < 2; ++pass) {
@@ -273,7 +275,41 @@ __global__ __launch_bounds__(256) void sell_code_kernel(int nslices, const int *
     }
 }
 
-void exclusive_scan_int(hipStream_t s, int n, const int *in, int *out);  // mis.hip
+__global__ __launch_bounds__(256) void widen_offsets_kernel(long n, const int *__restrict__ in, roff_t *__restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+__global__ __launch_bounds__(256) void narrow_offsets_kernel(long n, const roff_t *__restrict__ in, int *__restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (int)in[i];
+}
+
+void import_rowptr(DBuf<roff_t> &dst, const void *src, int bits, size_t n, hipStream_t s) {
+    SA_REQUIRE(bits == 32 || bits == 64, "row offsets must be 32 or 64 bits wide");
+    if (bits == 64) {
+        import_array(dst, (const roff_t *)src, n, s);
+        return;
+    }
+    DBuf<int> narrow;
+    import_array(narrow, (const int *)src, n, s);
+    dst.alloc(n);
+    if (n) hipLaunchKernelGGL(widen_offsets_kernel, dim3(div_up((long)n, 256)), dim3(256), 0, s, (long)n, narrow.p, dst.p);
+    SA_HIP_CHECK(hipGetLastError());
+    SA_HIP_CHECK(hipStreamSynchronize(s));      // `narrow` may be an upload that is freed on return
+}
+
+void export_rowptr32(int *dst_host, const DBuf<roff_t> &src, size_t n, hipStream_t s) {
+    if (!n) return;
+    roff_t last = 0;
+    SA_HIP_CHECK(hipMemcpyAsync(&last, src.p + (n - 1), sizeof(roff_t), hipMemcpyDeviceToHost, s));
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    SA_REQUIRE(last < ((roff_t)1 << 31), "operator has more than 2^31 entries: use the 64-bit getter");
+    DBuf<int> narrow(n);
+    hipLaunchKernelGGL(narrow_offsets_kernel, dim3(div_up((long)n, 256)), dim3(256), 0, s, (long)n, src.p, narrow.p);
+    SA_HIP_CHECK(hipGetLastError());
+    SA_HIP_CHECK(hipMemcpyAsync(dst_host, narrow.p, sizeof(int) * n, hipMemcpyDeviceToHost, s));
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+}
 
 void build_sell(hipStream_t s, DCsr &A) {
     A.has_sell = false;
@@ -283,11 +319,10 @@ void build_sell(hipStream_t s, DCsr &A) {
     const int grid = div_up((long)A.nslices * 64, 256);
     hipLaunchKernelGGL(sell_width_kernel, dim3(grid), dim3(256), 0, s, A.nrows, A.rowptr.p, w64.p);
     A.sell_ptr.alloc((size_t)A.nslices + 1);
-    exclusive_scan_int(s, A.nslices, w64.p, A.sell_ptr.p);
-    int total = 0;
-    SA_HIP_CHECK(hipMemcpyAsync(&total, A.sell_ptr.p + A.nslices, sizeof(int), hipMemcpyDeviceToHost, s));
+    exclusive_scan_off(s, A.nslices, w64.p, A.sell_ptr.p);
+    roff_t total = 0;
+    SA_HIP_CHECK(hipMemcpyAsync(&total, A.sell_ptr.p + A.nslices, sizeof(roff_t), hipMemcpyDeviceToHost, s));
     SA_HIP_CHECK(hipStreamSynchronize(s));
-    SA_REQUIRE(total >= 0, "SELL storage exceeds 32-bit indexing");
     A.sell_size = total;
     A.sell_col.alloc((size_t)total + 64);
     A.sell_val.alloc((size_t)total + 64);
@@ -398,7 +433,7 @@ void smooth_first(hipStream_t s, int n, const double *dinv_neg, const double *b,
 
 // ---- weighted-l1 smoother diagonal ----------------------------------------------------
 // (8 lanes per row: a lane walking its own row alone touches one cache line per lane and load)
-__global__ __launch_bounds__(256) void sqrt_abs_diag_kernel(int nrows, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(256) void sqrt_abs_diag_kernel(int nrows, const roff_t *__restrict__ rowptr,
                                                             const int *__restrict__ col,
                                                             const double *__restrict__ val,
                                                             double *__restrict__ sd) {
@@ -407,7 +442,7 @@ __global__ __launch_bounds__(256) void sqrt_abs_diag_kernel(int nrows, const int
     const long row = gtid >> 3;
     if (row >= nrows) return;
     double d = 0.0;
-    for (int k = rowptr[row] + lane; k < rowptr[row + 1]; k += 8)
+    for (roff_t k = rowptr[row] + lane; k < rowptr[row + 1]; k += 8)
         if (col[k] == row) d += val[k];
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1) d += __shfl_down(d, o, 8);
@@ -415,7 +450,7 @@ __global__ __launch_bounds__(256) void sqrt_abs_diag_kernel(int nrows, const int
 }
 
 template <int L>
-__global__ __launch_bounds__(256) void dinv_neg_kernel(int nrows, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(256) void dinv_neg_kernel(int nrows, const roff_t *__restrict__ rowptr,
                                                        const int *__restrict__ col,
                                                        const double *__restrict__ val,
                                                        const double *__restrict__ sd,
@@ -425,7 +460,7 @@ __global__ __launch_bounds__(256) void dinv_neg_kernel(int nrows, const int *__r
     const long row = gtid / L;
     if (row >= nrows) return;
     double sum = 0.0;
-    for (int k = rowptr[row] + lane; k < rowptr[row + 1]; k += L) sum += fabs(val[k]) / sd[col[k]];
+    for (roff_t k = rowptr[row] + lane; k < rowptr[row + 1]; k += L) sum += fabs(val[k]) / sd[col[k]];
 #pragma unroll
     for (int o = L / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, L);
     if (lane == 0) out[row] = -1.0 / (sd[row] * sum);

@@ -12,7 +12,6 @@
 
 namespace saamge_amd {
 
-void exclusive_scan_int(hipStream_t s, int n, const int *in, int *out);  // mis.hip
 
 constexpr int SPG_EMPTY = 0x7fffffff;
 
@@ -54,11 +53,11 @@ __device__ inline void wave_sort(int *keys, double *vals, int lane) {
 // mode 1: write row i (sorted) at Crow[i]
 template <int T, int WPB>
 __global__ __launch_bounds__(64 * WPB) void spgemm_kernel(
-    int mode, int nrows, const int *__restrict__ Arow, const int *__restrict__ Acol,
-    const double *__restrict__ Aval, const int *__restrict__ Brow, const int *__restrict__ Bcol,
-    const double *__restrict__ Bval, const int *__restrict__ Erow, const int *__restrict__ Ecol,
+    int mode, int nrows, const roff_t *__restrict__ Arow, const int *__restrict__ Acol,
+    const double *__restrict__ Aval, const roff_t *__restrict__ Brow, const int *__restrict__ Bcol,
+    const double *__restrict__ Bval, const roff_t *__restrict__ Erow, const int *__restrict__ Ecol,
     const double *__restrict__ Eval, const double *__restrict__ d, double alpha, double beta,
-    int *__restrict__ rowcnt, const int *__restrict__ Crow, int *__restrict__ Ccol,
+    int *__restrict__ rowcnt, const roff_t *__restrict__ Crow, int *__restrict__ Ccol,
     double *__restrict__ Cval) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -70,7 +69,7 @@ __global__ __launch_bounds__(64 * WPB) void spgemm_kernel(
     wave_lds_sync();
     int full = 0;
     if (Erow) {
-        for (int q = Erow[row] + lane; q < Erow[row + 1]; q += 64) {
+        for (roff_t q = Erow[row] + lane; q < Erow[row + 1]; q += 64) {
             const int sl = hash_slot<T>(keys, Ecol[q]);
             if (sl < 0) full = 1;
             else vals[sl] += beta * Eval[q];
@@ -78,10 +77,10 @@ __global__ __launch_bounds__(64 * WPB) void spgemm_kernel(
         wave_lds_sync();
     }
     const double sc = alpha * (d ? d[row] : 1.0);
-    for (int p = Arow[row]; p < Arow[row + 1]; ++p) {
+    for (roff_t p = Arow[row]; p < Arow[row + 1]; ++p) {
         const int k = Acol[p];
         const double a = sc * Aval[p];
-        for (int q = Brow[k] + lane; q < Brow[k + 1]; q += 64) {
+        for (roff_t q = Brow[k] + lane; q < Brow[k + 1]; q += 64) {
             const int sl = hash_slot<T>(keys, Bcol[q]);
             if (sl < 0) full = 1;
             else vals[sl] = fma(a, Bval[q], vals[sl]);
@@ -101,7 +100,8 @@ __global__ __launch_bounds__(64 * WPB) void spgemm_kernel(
         return;
     }
     wave_sort<T>(keys, vals, lane);
-    const int base = Crow[row], len = Crow[row + 1] - base;
+    const roff_t base = Crow[row];
+    const int len = (int)(Crow[row + 1] - base);
     for (int i = lane; i < len; i += 64) {
         Ccol[base + i] = keys[i];
         Cval[base + i] = vals[i];
@@ -140,24 +140,24 @@ __global__ __launch_bounds__(256) void clamp_nonneg_kernel(int n, int *__restric
 // of B's rows, fixed summation order, output already sorted by column.
 constexpr int SPD_MAXC = 2048;   // columns handled (8 per thread)
 
-__global__ __launch_bounds__(256) void densify_kernel(int nrows, int ncols, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(256) void densify_kernel(int nrows, int ncols, const roff_t *__restrict__ rowptr,
                                                       const int *__restrict__ col, const double *__restrict__ val,
                                                       double *__restrict__ Bd, unsigned char *__restrict__ Bm) {
     const long gt = (long)blockIdx.x * 256 + threadIdx.x;
     const int row = (int)(gt >> 3), lane = (int)(gt & 7);
     if (row >= nrows) return;
-    for (int k = rowptr[row] + lane; k < rowptr[row + 1]; k += 8) {
+    for (roff_t k = rowptr[row] + lane; k < rowptr[row + 1]; k += 8) {
         Bd[(size_t)row * ncols + col[k]] = val[k];
         Bm[(size_t)row * ncols + col[k]] = 1;
     }
 }
 
-__global__ __launch_bounds__(256) void spgemm_dense_b_kernel(int mode, int ncols, const int *__restrict__ Arow,
+__global__ __launch_bounds__(256) void spgemm_dense_b_kernel(int mode, int ncols, const roff_t *__restrict__ Arow,
                                                              const int *__restrict__ Acol,
                                                              const double *__restrict__ Aval,
                                                              const double *__restrict__ Bd,
                                                              const unsigned char *__restrict__ Bm,
-                                                             int *__restrict__ rowcnt, const int *__restrict__ Crow,
+                                                             int *__restrict__ rowcnt, const roff_t *__restrict__ Crow,
                                                              int *__restrict__ Ccol, double *__restrict__ Cval) {
     __shared__ int wsum[4];
     const int row = blockIdx.x, tid = threadIdx.x;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void spgemm_dense_b_kernel(int mode, int ncols
     int hit[SPD_MAXC / 256];
 #pragma unroll
     for (int u = 0; u < SPD_MAXC / 256; ++u) { acc[u] = 0.0; hit[u] = 0; }
-    for (int p = Arow[row]; p < Arow[row + 1]; ++p) {
+    for (roff_t p = Arow[row]; p < Arow[row + 1]; ++p) {
         const size_t base = (size_t)Acol[p] * ncols;
         const double a = Aval[p];
 #pragma unroll
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void spgemm_dense_b_kernel(int mode, int ncols
         int off = 0, tot = 0;
         for (int w = 0; w < 4; ++w) { if (w < (tid >> 6)) off += wsum[w]; tot += wsum[w]; }
         if (mode == 1 && hit[u]) {
-            const int pos = Crow[row] + before + off + incl - 1;
+            const roff_t pos = Crow[row] + before + off + incl - 1;
             Ccol[pos] = tid + 256 * u;
             Cval[pos] = acc[u];
         }
@@ -217,9 +217,9 @@ static bool spgemm_dense_b(hipStream_t s, const DCsr &A, const DCsr &B, DCsr &C)
     DBuf<int> rowcnt((size_t)n);
     hipLaunchKernelGGL(spgemm_dense_b_kernel, dim3(n), dim3(256), 0, s, 0, B.ncols, A.rowptr.p, A.col.p, A.val.p,
                        Bd.p, Bm.p, rowcnt.p, nullptr, nullptr, nullptr);
-    exclusive_scan_int(s, n, rowcnt.p, C.rowptr.p);
-    int nnz = 0;
-    SA_HIP_CHECK(hipMemcpyAsync(&nnz, C.rowptr.p + n, sizeof(int), hipMemcpyDeviceToHost, s));
+    exclusive_scan_off(s, n, rowcnt.p, C.rowptr.p);
+    roff_t nnz = 0;
+    SA_HIP_CHECK(hipMemcpyAsync(&nnz, C.rowptr.p + n, sizeof(roff_t), hipMemcpyDeviceToHost, s));
     SA_HIP_CHECK(hipStreamSynchronize(s));
     C.nnz = nnz;
     C.col.alloc((size_t)nnz + 1);
@@ -262,11 +262,10 @@ void spgemm(hipStream_t s, const DCsr &A, const DCsr &B, const DCsr *E, const do
         if (flag.to_host(s)[0] == 0) break;
     }
     SA_REQUIRE(tier < 3, "spgemm: a product row has more than ~8000 entries");
-    exclusive_scan_int(s, n, rowcnt.p, C.rowptr.p);
-    int nnz = 0;
-    SA_HIP_CHECK(hipMemcpyAsync(&nnz, C.rowptr.p + n, sizeof(int), hipMemcpyDeviceToHost, s));
+    exclusive_scan_off(s, n, rowcnt.p, C.rowptr.p);
+    roff_t nnz = 0;
+    SA_HIP_CHECK(hipMemcpyAsync(&nnz, C.rowptr.p + n, sizeof(roff_t), hipMemcpyDeviceToHost, s));
     SA_HIP_CHECK(hipStreamSynchronize(s));
-    SA_REQUIRE(nnz >= 0, "spgemm: product too large for 32-bit indices");
     C.nnz = nnz;
     C.col.alloc((size_t)nnz + 1);
     C.val.alloc((size_t)nnz + 1);
@@ -283,16 +282,16 @@ __global__ __launch_bounds__(256) void tr_count_kernel(long nnz, const int *__re
     const long k = (long)blockIdx.x * 256 + threadIdx.x;
     if (k < nnz) atomicAdd(&cnt[col[k]], 1);
 }
-__global__ __launch_bounds__(256) void tr_fill_kernel(int nrows, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(256) void tr_fill_kernel(int nrows, const roff_t *__restrict__ rowptr,
                                                       const int *__restrict__ col, const double *__restrict__ val,
-                                                      const int *__restrict__ Trow, int *__restrict__ cursor,
+                                                      const roff_t *__restrict__ Trow, int *__restrict__ cursor,
                                                       int *__restrict__ Tcol, double *__restrict__ Tval) {
     const long gt = (long)blockIdx.x * 256 + threadIdx.x;
     const int row = (int)(gt >> 2), lane = (int)(gt & 3);
     if (row >= nrows) return;
-    for (int k = rowptr[row] + lane; k < rowptr[row + 1]; k += 4) {
+    for (roff_t k = rowptr[row] + lane; k < rowptr[row + 1]; k += 4) {
         const int c = col[k];
-        const int pos = Trow[c] + atomicAdd(&cursor[c], 1);
+        const roff_t pos = Trow[c] + atomicAdd(&cursor[c], 1);
         Tcol[pos] = row;
         Tval[pos] = val[k];
     }
@@ -302,14 +301,15 @@ __global__ __launch_bounds__(256) void tr_fill_kernel(int nrows, const int *__re
 // (bitonic), longer ones (a coarse dof supported on a large part of a small level) by rank
 // counting: the position of an entry is the number of smaller keys in its row.
 template <int T>
-__global__ __launch_bounds__(64) void row_order_kernel(int nrows, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(64) void row_order_kernel(int nrows, const roff_t *__restrict__ rowptr,
                                                        const int *__restrict__ col_in,
                                                        const double *__restrict__ val_in, int *__restrict__ col,
                                                        double *__restrict__ val) {
     __shared__ int keys[T];
     __shared__ double vals[T];
     const int row = blockIdx.x, lane = threadIdx.x;
-    const int b = rowptr[row], len = rowptr[row + 1] - b;
+    const roff_t b = rowptr[row];
+    const int len = (int)(rowptr[row + 1] - b);
     if (len == 0) return;
     if (len > T) {
         for (int i = lane; i < len; i += 64) {
@@ -347,7 +347,7 @@ void csr_transpose(hipStream_t s, const DCsr &P, DCsr &R) {
     DBuf<double> tval((size_t)P.nnz + 1);
     cnt.zero(s);
     hipLaunchKernelGGL(tr_count_kernel, dim3(div_up(P.nnz, 256)), dim3(256), 0, s, (long)P.nnz, P.col.p, cnt.p);
-    exclusive_scan_int(s, R.nrows, cnt.p, R.rowptr.p);
+    exclusive_scan_off(s, R.nrows, cnt.p, R.rowptr.p);
     cnt.zero(s);
     hipLaunchKernelGGL(tr_fill_kernel, dim3(div_up((long)P.nrows * 4, 256)), dim3(256), 0, s, P.nrows, P.rowptr.p,
                        P.col.p, P.val.p, R.rowptr.p, cnt.p, tcol.p, tval.p);
@@ -363,21 +363,21 @@ void csr_transpose(hipStream_t s, const DCsr &P, DCsr &R) {
 // ---------------------------------------------------------------------------------------
 // One wavefront per row; the kept entries stay in their order (ballot + prefix popcount).
 template <bool FILL>
-__global__ __launch_bounds__(256) void threshold_kernel(int nrows, double tol, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(256) void threshold_kernel(int nrows, double tol, const roff_t *__restrict__ rowptr,
                                                         const int *__restrict__ col, const double *__restrict__ val,
-                                                        int *__restrict__ cnt, const int *__restrict__ orow,
+                                                        int *__restrict__ cnt, const roff_t *__restrict__ orow,
                                                         int *__restrict__ ocol, double *__restrict__ oval) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= nrows) return;
-    const int b = rowptr[row], e = rowptr[row + 1];
+    const roff_t b = rowptr[row], e = rowptr[row + 1];
     int kept = 0;
-    for (int p0 = b; p0 < e; p0 += 64) {
-        const int p = p0 + lane;
+    for (roff_t p0 = b; p0 < e; p0 += 64) {
+        const roff_t p = p0 + lane;
         const double v = (p < e) ? val[p] : 0.0;
         const bool keep = (p < e) && (fabs(v) > tol);
         const unsigned long long m = __ballot(keep);
         if (FILL && keep) {
-            const int dst = orow[row] + kept + __popcll(m & ((1ull << lane) - 1ull));
+            const roff_t dst = orow[row] + kept + __popcll(m & ((1ull << lane) - 1ull));
             ocol[dst] = col[p];
             oval[dst] = v;
         }
@@ -397,9 +397,9 @@ void csr_threshold(hipStream_t s, const DCsr &A, double tol, DCsr &C) {
     if (A.nrows > 0)
         hipLaunchKernelGGL((threshold_kernel<false>), grid, dim3(256), 0, s, A.nrows, tol, A.rowptr.p, A.col.p,
                            A.val.p, cnt.p, nullptr, nullptr, nullptr);
-    exclusive_scan_int(s, A.nrows, cnt.p, C.rowptr.p);
-    int nnz = 0;
-    SA_HIP_CHECK(hipMemcpyAsync(&nnz, C.rowptr.p + A.nrows, sizeof(int), hipMemcpyDeviceToHost, s));
+    exclusive_scan_off(s, A.nrows, cnt.p, C.rowptr.p);
+    roff_t nnz = 0;
+    SA_HIP_CHECK(hipMemcpyAsync(&nnz, C.rowptr.p + A.nrows, sizeof(roff_t), hipMemcpyDeviceToHost, s));
     SA_HIP_CHECK(hipStreamSynchronize(s));
     C.nnz = nnz;
     C.col.alloc((size_t)nnz + 1);

@@ -52,7 +52,8 @@ void build_relations_ae(Relations &r, Table &&elem_to_dof, const hvec<int> &part
 // amg/src/aggregates.cpp:324-487; Arbitrator::suggest, amg/src/arbitrator.cpp:93-204).
 struct HostCsr {
     int nrows = 0;
-    std::vector<int> rowptr, col;
+    std::vector<roff_t> rowptr;
+    std::vector<int> col;
     std::vector<double> val;
 };
 void build_relations_mis(Relations &r, const HostCsr *aggregates_A = nullptr);

@@ -695,7 +695,6 @@ void build_relations_mis(Relations &r, const HostCsr *aggregates_A) {
 // ---------------------------------------------------------------------------------------
 // device-side pieces: dof_to_elem (transpose with ascending rows) and elem_ldof
 // ---------------------------------------------------------------------------------------
-void exclusive_scan_int(hipStream_t s, int n, const int *in, int *out);  // mis.hip
 
 __global__ __launch_bounds__(256) void d2e_count_kernel(long nconn, const int *__restrict__ e2d_J,
                                                         int *__restrict__ cnt) {

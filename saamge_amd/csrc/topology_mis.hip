@@ -21,7 +21,6 @@
 
 namespace saamge_amd {
 
-void exclusive_scan_int(hipStream_t s, int n, const int *in, int *out);  // mis.hip
 
 namespace {
 
