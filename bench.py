@@ -79,10 +79,11 @@ WORKLOADS = {
     "poisson128": {"n": 128, "levels": 2, "theta": 0.003, "aniso": 1.0, "theta2": None},
     "aniso128": {"n": 128, "levels": 3, "theta": 1e-4, "aniso": 1000.0, "theta2": 1e-5, "coarse_blk": "4,4,2"},
     # BASELINE config 5: 3-D linear elasticity, Q2 hexes (81 dofs per element), 4x4x4-element agglomerates of
-    # 9^3 nodes x 3 = 2187 dofs carrying the six rigid-body modes, clamped on x = 0.  64^3 (6.44 M dofs, 1.24e9
-    # stored entries, ~140 GB of HBM in use) is the preset; the operator's 32-bit row offsets end at 72^3 (1.76e9
-    # entries): BASELINE's 96^3 (4.17e9) needs 64-bit offsets, which the reference's own int cannot hold either
-    "elasticity_q2": {"n": 64, "levels": 4, "theta": 0.003, "aniso": 1.0, "theta2": None, "blk": "4,4,4", "coarse_blk": "2,2,2"},
+    # 9^3 nodes x 3 = 2187 dofs carrying the six rigid-body modes, clamped on x = 0.  96^3 elements: 21.6 M dofs,
+    # 4.17e9 stored entries (64-bit row offsets: csrc/common.h roff_t), ~280 GB of HBM in use.  elasticity_q2_64:
+    # the 64^3 case (6.44 M dofs, 1.24e9 entries) for a quicker run.
+    "elasticity_q2": {"n": 96, "levels": 4, "theta": 0.003, "aniso": 1.0, "theta2": None, "blk": "4,4,4", "coarse_blk": "2,2,2"},
+    "elasticity_q2_64": {"n": 64, "levels": 4, "theta": 0.003, "aniso": 1.0, "theta2": None, "blk": "4,4,4", "coarse_blk": "2,2,2"},
 }
 
 
@@ -228,6 +229,11 @@ def main():
         args.blk = "8,8,4"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus, sys.argv[1:])
+    elasticity = args.workload.startswith("elasticity_q2")
+    if elasticity and args.n >= 80:
+        # 96^3 fills the card (operator 50 GB, its SELL copy 50 GB, element matrices 46 GB, eigensolver workspace):
+        # the library's cache of freed blocks is kept small so that torch's own allocations find room
+        os.environ.setdefault("SAAMGE_AMD_POOL_MAX_GB", "16")
 
     import torch
     from saamge_amd import capi
@@ -241,13 +247,15 @@ def main():
     native = backend == "nccl" and os.environ.get("SAAMGE_AMD_DIST_COMM", "native") != "torch"
     grp = Group(backend=backend, device=dev, native=native)
     world, rank = grp.world, grp.rank
+    if native and world > 1:
+        native = grp.try_native(0)       # (falls back to the torch.distributed callbacks, on all ranks together)
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with `python bench.py --gpus N` or "
                          "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
 
     prob = build_problem(args.n, args.levels, dev, args.aniso, tuple(int(v) for v in args.blk.split(",")),
                          tuple(int(v) for v in args.coarse_blk.split(",")),
-                         "elasticity_q2" if args.workload == "elasticity_q2" else "poisson")
+                         "elasticity_q2" if elasticity else "poisson")
     torch.cuda.synchronize()
     torch.cuda.empty_cache()        # the generator's temporaries go back to the device before the library allocates
     params = capi.default_params(num_coarsenings=args.levels - 1, theta=args.theta, nu_relax=3, nu_pro=args.nu_pro,
@@ -273,14 +281,25 @@ def main():
     dt = grp.max_time(time.perf_counter() - t0)
     infos = [h.level_info(l) for l in range(args.levels - 1 + int(args.correct_nullspace))]
     # size-independent check on the full-size problem: true residual of the computed solution
-    A_rowptr, A_col, A_val = prob.rowptr, prob.col, prob.val
-    Acsr = torch.sparse_csr_tensor(A_rowptr.long(), A_col.long(), A_val, size=(prob.n, prob.n))
-    relres = float(torch.linalg.norm(Acsr @ x - prob.b) / torch.linalg.norm(prob.b))
-    del Acsr
+    # (torch's CSR product, by row blocks of at most 2^28 entries: its int64 copy of the column indices
+    # of a 4e9-entry operator would not fit beside the hierarchy)
+    A_rowptr, A_col, A_val = prob.rowptr.long(), prob.col, prob.val
+    res2 = 0.0
+    r0 = 0
+    while r0 < prob.n:
+        e0 = int(A_rowptr[r0])
+        r1 = int(torch.searchsorted(A_rowptr, torch.tensor(e0 + (1 << 28), device=A_rowptr.device)))
+        r1 = min(prob.n, max(r1 - 1, r0 + 1))
+        e1 = int(A_rowptr[r1])
+        Ablk = torch.sparse_csr_tensor(A_rowptr[r0:r1 + 1] - e0, A_col[e0:e1].long(), A_val[e0:e1], size=(r1 - r0, prob.n))
+        res2 += float(torch.sum((Ablk @ x - prob.b[r0:r1]) ** 2))
+        del Ablk
+        r0 = r1
+    relres = float(res2 ** 0.5 / torch.linalg.norm(prob.b))
     h.close()
 
     res = {
-        "metric": "AMG setup+solve DoF/s (%s, PCG to 1e-8)" % ("3D elasticity Q2" if args.workload == "elasticity_q2" else "3D Poisson"),
+        "metric": "AMG setup+solve DoF/s (%s, PCG to 1e-8)" % ("3D elasticity Q2" if elasticity else "3D Poisson"),
         "value": prob.n * args.steps / dt,
         "unit": "DoF/s",
         "n_gpus": world,
@@ -296,7 +315,7 @@ def main():
                    "workload": ("3D linear elasticity %d^3 Q2 hexes (81 dofs per element, lambda = mu = 1, clamped on x = 0), "
                                 "%d-level SAAMGE, theta=%g, nu_relax=3, %s-element AEs, %s-AE coarse blocks"
                                 % (args.n, args.levels, args.theta, args.blk.replace(",", "x"), args.coarse_blk.replace(",", "x")))
-                   if args.workload == "elasticity_q2" else "3D Poisson %d^3 Q1 hexes%s, %d-level SAAMGE, theta=%s, nu_relax=3, "
+                   if elasticity else "3D Poisson %d^3 Q1 hexes%s, %d-level SAAMGE, theta=%s, nu_relax=3, "
                                "8x8x4-element AEs, %s-AE coarse blocks%s" % (args.n, "" if args.aniso == 1.0 else
                                                        " K=diag(1,1,%g)" % args.aniso, args.levels,
                                                        ("%g" % args.theta) if args.theta2 == args.theta else "%g / %g (first / later coarsenings)" % (args.theta, args.theta2),

@@ -76,6 +76,51 @@ class Group(object):
         self._comm, self._comm_stream = comm, int(stream or 0)
         return comm
 
+    def try_native(self, stream=0):
+        """Bring up the library's own RCCL communicator and run its self-test (all-reduce, all-gather, all-to-all of
+        known data); every step is agreed on by all ranks through torch.distributed, so that a rank that cannot load
+        RCCL or fails the self-test sends the whole job to the torch.distributed callbacks instead of leaving the
+        others inside a collective.  Returns True when the native communicator is in use."""
+        import ctypes as C
+        import sys
+        import torch
+        from . import capi
+        if not self.native or self.world <= 1 or self.dist is None:
+            return bool(self.native)
+
+        def all_ok(flag):
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.device or "cpu")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+
+        lib = capi.load()
+        lib.saamge_amd_comm_last_error.restype = C.c_char_p
+        why = ""
+        probe = C.create_string_buffer(128)
+        ok = lib.saamge_amd_comm_unique_id(probe) == 0          # local: are the RCCL entry points there?
+        if not ok:
+            why = lib.saamge_amd_comm_last_error().decode()
+        if all_ok(ok):
+            try:
+                comm = self.native_comm(stream)
+                ok = True
+            except Exception as e:      # noqa: BLE001  (reported below; the job continues on the callbacks)
+                ok, why = False, str(e)
+            if all_ok(ok):
+                ok = lib.saamge_amd_comm_selftest(comm) == 0
+                if not ok:
+                    why = "self-test failed: " + lib.saamge_amd_comm_last_error().decode()
+                if all_ok(ok):
+                    return True
+        if self.rank == 0 or why:
+            print("saamge_amd: native RCCL communicator not used (%s); collectives through torch.distributed"
+                  % (why or "another rank failed"), file=sys.stderr)
+        if self._comm is not None:
+            lib.saamge_amd_comm_destroy(self._comm)
+            self._comm = None
+        self.native = False
+        return False
+
     def barrier(self):
         if self.dist is not None:
             self.dist.barrier()
