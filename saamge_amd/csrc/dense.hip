@@ -5,13 +5,8 @@
 // solve must be ONE bandwidth-bound pass (a GEMV over 8 n^2 bytes: ~20 us at n = 3 300) and not a
 // chain of triangular block steps (2.4 ms) or an inner Krylov loop (~170 tiny SpMV launches).
 // The inverse is built in place by block Gauss-Jordan elimination without pivoting (Ac is SPD, so
-// is every Schur complement), DNB = 64 columns per step, four launches per step:
-//     gj_pivot_kernel     Pinv = (pivot block)^-1 in LDS, one workgroup
-//     gj_rowpanel_kernel  Rp = Pinv M[k, :]                        (64 x n, separate buffer)
-//     gj_update_kernel    M[i, j] -= M[i, k] Rp[:, j], i, j outside the pivot block
-//                         (64 x 64 output tiles, operands through LDS, 4 x 4 register tiles)
-//     gj_finish_kernel    M[k, j] = Rp,  M[i, k] = -M[i, k] Pinv,  M[k, k] = Pinv
-// 2 n^3 flops, the matrix read + written once per step (n / 64 steps).  A non-positive pivot
+// is every Schur complement), DNB = 64 columns per step, two launches per step (gj_panel_kernel, gj_apply_kernel
+// below): 2 n^3 flops on the matrix cores, the matrix read + written once per step (n / 64 steps).  A non-positive pivot
 // (semi-definite operator) is reported so that the caller falls back to the inner PCG.
 #include "dense.h"
 
@@ -32,23 +27,41 @@ __global__ __launch_bounds__(256) void dense_scatter_kernel(int n, const roff_t 
     for (roff_t k = rowptr[row] + lane; k < rowptr[row + 1]; k += 8) M[(size_t)col[k] * n + row] = val[k];
 }
 
-// inverse of the nb x nb pivot block at k0 (SPD) by Gauss-Jordan elimination in LDS; a short last
-// block is padded with the identity.  Pinv: DNB x DNB column-major.
-__global__ __launch_bounds__(256) void gj_pivot_kernel(int n, int k0, int nb, const double *__restrict__ M,
-                                                       double *__restrict__ Pinv, int *__restrict__ info) {
+// ---- step k of the block Gauss-Jordan elimination, two launches --------------------------------------
+// gj_panel_kernel, one workgroup per 64-wide block b of the matrix:
+//     Pinv = (pivot block)^-1 by Gauss-Jordan elimination in LDS (a short last block is padded with the identity);
+//            EVERY workgroup repeats this 64-step chain -- it is latency, not work, and nothing has to wait for a
+//            single workgroup's result;
+//     Rp[b] = Pinv M[k, b]                (64 x 64, stored [t][c]: row t of the panel, column c of block b)
+//     Col[b] = M[b, k]                    (64 x 64 copy of the OLD column panel, stored [t][r])
+// gj_apply_kernel, one workgroup per 64 x 64 tile (bi, bj), reads only the copies, so the tiles are independent:
+//     pivot block <- Pinv,   pivot row M[k, bj] <- Rp[bj],   pivot column M[bi, k] <- -Col[bi] Pinv,
+//     elsewhere   M[bi, bj] -= Col[bi] Rp[bj]
+// The 64 x 64 x 64 products run on the matrix cores (v_mfma_f64_16x16x4_f64: A operand row = lane & 15,
+// k = lane >> 4; B operand col = lane & 15, k = lane >> 4; C/D register r: col = lane & 15, row = (lane >> 4) + 4 r).
+// A wavefront owns a 32 x 32 quadrant and holds it TRANSPOSED, D(j, i) = sum_t X(t, j) C(i, t): the D columns are
+// then consecutive rows i of the column-major matrix, so a load / store of register r is four 128-B segments.
+typedef double gj_v4d __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void gj_panel_kernel(int n, int k0, int nb, const double *__restrict__ M,
+                                                       double *__restrict__ Pinv, double *__restrict__ Rp,
+                                                       double *__restrict__ Col, int *__restrict__ info) {
     __shared__ double Dbuf[2][DNB][DNB + 1];      // ping-pong: one barrier per elimination step
-    const int tid = threadIdx.x;
+    __shared__ double Mk[DNB][DNB + 1];           // Mk[s][c] = M[k0 + s, j0 + c]
+    const int b = blockIdx.x, tid = threadIdx.x, kb = k0 / DNB, j0 = b * DNB;
     const int r = tid & (DNB - 1), c0 = tid >> 6;          // this thread owns D[r][c0 + 4 u], u = 0..15
     for (int u = 0; u < DNB / 4; ++u) {
         const int c = c0 + 4 * u;
         Dbuf[0][r][c] = (r < nb && c < nb) ? M[(size_t)(k0 + c) * n + k0 + r] : ((r == c) ? 1.0 : 0.0);
+        Mk[r][c] = (r < nb && j0 + c < n) ? M[(size_t)(j0 + c) * n + k0 + r] : 0.0;
+        Col[((size_t)b * DNB + c) * DNB + r] = (c < nb && j0 + r < n) ? M[(size_t)(k0 + c) * n + j0 + r] : 0.0;
     }
     __syncthreads();
     int cur = 0;
     for (int j = 0; j < nb; ++j, cur ^= 1) {
         double (*D)[DNB + 1] = Dbuf[cur], (*E)[DNB + 1] = Dbuf[cur ^ 1];
         const double d = D[j][j];
-        if (!(d > 0.0)) {               // not positive definite (also catches NaN): uniform exit
+        if (!(d > 0.0)) {               // not positive definite (also catches NaN): uniform exit, in every workgroup
             if (tid == 0) atomicMax(info, k0 + j + 1);
             return;
         }
@@ -66,100 +79,104 @@ __global__ __launch_bounds__(256) void gj_pivot_kernel(int n, int k0, int nb, co
         }
         __syncthreads();
     }
-    for (int u = 0; u < DNB / 4; ++u) {
-        const int c = c0 + 4 * u;
-        Pinv[(size_t)c * DNB + r] = Dbuf[cur][r][c];
-    }
-}
-
-// Rp[t, j] = sum_s Pinv[t, s] M[k0 + s, j] for every column j (the pivot block's own columns are
-// skipped by the consumers); one thread per column j, the column segment in registers
-__global__ __launch_bounds__(256) void gj_rowpanel_kernel(int n, int k0, int nb, const double *__restrict__ M,
-                                                          const double *__restrict__ Pinv, double *__restrict__ Rp) {
-    __shared__ double P[DNB][DNB + 1];
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < DNB * DNB; idx += 256) P[idx & (DNB - 1)][idx >> 6] = Pinv[idx];
-    __syncthreads();
-    const int j = blockIdx.x * 256 + tid;
-    if (j >= n) return;
-    double x[DNB];
-#pragma unroll
-    for (int s = 0; s < DNB; ++s) x[s] = (s < nb) ? M[(size_t)j * n + k0 + min(s, nb - 1)] : 0.0;
-#pragma unroll 4
-    for (int t = 0; t < DNB; ++t) {
-        double acc = 0.0;
-#pragma unroll
-        for (int s = 0; s < DNB; ++s) acc = fma(P[t][s], x[s], acc);
-        Rp[(size_t)j * DNB + t] = acc;
-    }
-}
-
-// M[i, j] -= sum_t M[i, k0 + t] Rp[t, j] on the 64 x 64 tile (blockIdx.x, blockIdx.y); tiles of the
-// pivot block's rows / columns are left alone (k0 is a multiple of 64)
-__global__ __launch_bounds__(256) void gj_update_kernel(int n, int k0, int nb, double *__restrict__ M,
-                                                        const double *__restrict__ Rp) {
-    const int ti = blockIdx.x, tj = blockIdx.y, kt = k0 / DNB;
-    if (ti == kt || tj == kt) return;
-    __shared__ double As[DNB][DNB + 1], Bs[DNB][DNB + 1];     // As[t][r] = M[i0 + r, k0 + t], Bs[t][c] = Rp[t, j0 + c]
-    const int i0 = ti * DNB, j0 = tj * DNB, tid = threadIdx.x;
-    for (int idx = tid; idx < DNB * DNB; idx += 256) {
-        const int r = idx & (DNB - 1), t = idx >> 6;
-        As[t][r] = (i0 + r < n && t < nb) ? M[(size_t)(k0 + t) * n + i0 + r] : 0.0;
-        Bs[r][t] = (j0 + t < n) ? Rp[(size_t)(j0 + t) * DNB + r] : 0.0;     // (r plays t here: contiguous reads of Rp)
-    }
-    __syncthreads();
-    const int tx = tid & 15, ty = tid >> 4;
-    double acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-#pragma unroll 8
-    for (int t = 0; t < DNB; ++t) {
-        double av[4], bv[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) av[a] = As[t][tx + 16 * a];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) bv[b] = Bs[t][ty + 16 * b];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
-    }
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int gi = i0 + tx + 16 * a, gj = j0 + ty + 16 * b;
-            if (gi < n && gj < n) M[(size_t)gj * n + gi] -= acc[a][b];
+    double (*P)[DNB + 1] = Dbuf[cur];
+    if (b == kb)
+        for (int u = 0; u < DNB / 4; ++u) {
+            const int c = c0 + 4 * u;
+            Pinv[(size_t)c * DNB + r] = P[r][c];
         }
+    // Rp[b][t][c] = sum_s Pinv[t][s] Mk[s][c]: column c = lane, rows t = 16 wave .. 16 wave + 15 (P reads are broadcasts)
+    {
+        const int c = tid & 63, t0 = (tid >> 6) * 16;
+        double acc[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+#pragma unroll 4
+        for (int s = 0; s < DNB; ++s) {
+            const double m = Mk[s][c];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc[u] = fma(P[t0 + u][s], m, acc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) Rp[((size_t)b * DNB + t0 + u) * DNB + c] = acc[u];
+    }
 }
 
-// row panel <- Rp, column panel <- -M[:, k] Pinv, pivot block <- Pinv; one thread per index q:
-// it owns column q of the row panel and row q of the column panel
-__global__ __launch_bounds__(256) void gj_finish_kernel(int n, int k0, int nb, double *__restrict__ M,
-                                                        const double *__restrict__ Pinv, const double *__restrict__ Rp) {
-    __shared__ double P[DNB][DNB + 1];
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < DNB * DNB; idx += 256) P[idx & (DNB - 1)][idx >> 6] = Pinv[idx];
+// One workgroup per 128 x 128 tile, one wavefront per 64 x 64 quadrant = block pair (bi, bj): the panel copies are
+// fetched once for four block pairs (a 64 x 64 tile per workgroup re-read 128 KB of panels for 64 KB of matrix and
+// was bound by the L2).  As[t][r] = Col[.][t][r] (two blocks side by side), Xs[t][c] = Rp[.][t][c], or Pinv[t][c] for
+// the pivot block column.
+constexpr int GJP2 = 2 * DNB + 4;
+constexpr size_t GJ_APPLY_LDS = 2 * sizeof(double) * DNB * GJP2;
+__global__ __launch_bounds__(256) void gj_apply_kernel(int n, int k0, int nb, int nt, double *__restrict__ M,
+                                                       const double *__restrict__ Pinv, const double *__restrict__ Rp,
+                                                       const double *__restrict__ Col) {
+    extern __shared__ double gj_lds[];
+    double (*As)[GJP2] = (double (*)[GJP2])gj_lds;
+    double (*Xs)[GJP2] = (double (*)[GJP2])(gj_lds + (size_t)DNB * GJP2);
+    const int kb = k0 / DNB, tid = threadIdx.x;
+    for (int h = 0; h < 2; ++h) {
+        const int bi = 2 * blockIdx.x + h, bj = 2 * blockIdx.y + h;
+        for (int idx = tid; idx < DNB * DNB; idx += 256) {
+            const int lo = idx & (DNB - 1), hi = idx >> 6;
+            As[hi][64 * h + lo] = (bi < nt) ? Col[(size_t)bi * DNB * DNB + idx] : 0.0;
+            if (bj == kb) Xs[lo][64 * h + hi] = Pinv[idx];                       // Pinv is column-major: idx = c * 64 + t
+            else Xs[hi][64 * h + lo] = (bj < nt) ? Rp[(size_t)bj * DNB * DNB + idx] : 0.0;
+        }
+    }
     __syncthreads();
-    const int q = blockIdx.x * 256 + tid;
-    if (q >= n) return;
-    if (q >= k0 && q < k0 + nb) {            // inside the pivot block: column q - k0 of Pinv
-        for (int t = 0; t < nb; ++t) M[(size_t)q * n + k0 + t] = P[t][q - k0];
+    const int lane = tid & 63, w = tid >> 6, qi = w & 1, qj = w >> 1;
+    const int bi = 2 * blockIdx.x + qi, bj = 2 * blockIdx.y + qj;
+    if (bi >= nt || bj >= nt) return;
+    const int i0 = bi * DNB, j0 = bj * DNB;
+    if (bi == kb) {                         // pivot row <- Rp, pivot block <- Pinv: both sit in Xs
+        if (lane < nb)
+            for (int c = 0; c < DNB && j0 + c < n; ++c) {
+                if (bj == kb && c >= nb) break;
+                M[(size_t)(j0 + c) * n + k0 + lane] = Xs[lane][64 * qj + c];
+            }
         return;
     }
-    double x[DNB];
+    const bool pcol = bj == kb;             // pivot column <- -Col Pinv
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // the accumulators start as the old tile and the X operand enters negated: D = M - Col X in one chain, every
+    // load of the tile issued before the products and every store after them (a read-modify-write per element
+    // after the loop is 64 dependent round trips per wavefront: the stores may alias the next load)
+    gj_v4d acc[4][4];
 #pragma unroll
-    for (int s = 0; s < DNB; ++s) x[s] = (s < nb) ? M[(size_t)(k0 + min(s, nb - 1)) * n + q] : 0.0;     // row q of the column panel
-    for (int t = 0; t < nb; ++t) M[(size_t)q * n + k0 + t] = Rp[(size_t)q * DNB + t];                  // column q of the row panel
-#pragma unroll 4
-    for (int c = 0; c < DNB; ++c) {
-        double acc = 0.0;
+    for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
-        for (int s = 0; s < DNB; ++s) acc = fma(x[s], P[s][c], acc);
-        if (c < nb) M[(size_t)(k0 + c) * n + q] = -acc;
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int gi = i0 + 16 * ib + l15, gj = j0 + 16 * jb + l4 + 4 * reg;
+                acc[jb][ib][reg] = (!pcol && gi < n && gj < n) ? M[(size_t)gj * n + gi] : 0.0;
+            }
+#pragma unroll 2
+    for (int ks = 0; ks < DNB / 4; ++ks) {
+        const int t = 4 * ks + l4;
+        double a[4], bb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a[q] = -Xs[t][64 * qj + 16 * q + l15];
+            bb[q] = As[t][64 * qi + 16 * q + l15];
+        }
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+                acc[jb][ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jb], bb[ib], acc[jb][ib], 0, 0, 0);
     }
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int jl = 16 * jb + l4 + 4 * reg, gi = i0 + 16 * ib + l15, gj = j0 + jl;
+                if (gi >= n || gj >= n || (pcol && jl >= nb)) continue;
+                M[(size_t)gj * n + gi] = acc[jb][ib][reg];
+            }
 }
 
 // X <- (X + X^T) / 2 (the elimination is symmetric only up to round-off; the coarse solve of a
@@ -195,20 +212,20 @@ bool dense_inverse_spd(hipStream_t s, const DCsr &A, DBuf<double> &X) {
     const int n = A.nrows;
     const size_t nn = (size_t)n * n;
     X.alloc(nn);
-    DBuf<double> Pinv((size_t)DNB * DNB), Rp((size_t)DNB * n);
+    const int nt = div_up(n, DNB);
+    DBuf<double> Pinv((size_t)DNB * DNB), Rp((size_t)DNB * DNB * nt), Col((size_t)DNB * DNB * nt);
     DBuf<int> info(1);
     info.zero(s);
     profiler().begin(s);
     hipLaunchKernelGGL(dense_zero_kernel, dim3(div_up((long)nn, 256)), dim3(256), 0, s, nn, X.p);
     hipLaunchKernelGGL(dense_scatter_kernel, dim3(div_up((long)n * 8, 256)), dim3(256), 0, s, n, A.rowptr.p,
                        A.col.p, A.val.p, X.p);
-    const int nt = div_up(n, DNB);
+    const int nt2 = div_up(nt, 2);
+    SA_HIP_CHECK(hipFuncSetAttribute((const void *)gj_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GJ_APPLY_LDS));
     for (int k0 = 0; k0 < n; k0 += DNB) {
         const int nb = std::min(DNB, n - k0);
-        hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(256), 0, s, n, k0, nb, X.p, Pinv.p, info.p);
-        hipLaunchKernelGGL(gj_rowpanel_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, k0, nb, X.p, Pinv.p, Rp.p);
-        if (nt > 1) hipLaunchKernelGGL(gj_update_kernel, dim3(nt, nt), dim3(256), 0, s, n, k0, nb, X.p, Rp.p);
-        hipLaunchKernelGGL(gj_finish_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, k0, nb, X.p, Pinv.p, Rp.p);
+        hipLaunchKernelGGL(gj_panel_kernel, dim3(nt), dim3(256), 0, s, n, k0, nb, X.p, Pinv.p, Rp.p, Col.p, info.p);
+        hipLaunchKernelGGL(gj_apply_kernel, dim3(nt2, nt2), dim3(256), GJ_APPLY_LDS, s, n, k0, nb, nt, X.p, Pinv.p, Rp.p, Col.p);
     }
     hipLaunchKernelGGL(dense_symmetrize_kernel, dim3(div_up(n, 16), div_up(n, 16)), dim3(256), 0, s, n, X.p);
     SA_HIP_CHECK(hipGetLastError());

@@ -1686,6 +1686,7 @@ void eig_backtransform_two_stage(hipStream_t s, EigBatch &b, const int64_t *xoff
 constexpr int SS_B = 8;
 constexpr double SS_SIGMA = -1e-3;
 constexpr double SS_TOL = 1e-12;
+constexpr int SS_MAX_ITER = 80;
 
 __global__ __launch_bounds__(256) void ss_shift_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
                                                        double *__restrict__ W, double sigma_all,
@@ -2383,7 +2384,7 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
                                                     double *__restrict__ mu, int *__restrict__ state, int iter,
                                                     const double *__restrict__ sigmas, double vu, const int *__restrict__ inertia,
                                                     double *__restrict__ dbg = nullptr,
-        const int *__restrict__ active = nullptr) {
+        const int *__restrict__ active = nullptr, double *__restrict__ hist = nullptr, int max_iter = 80) {
     __shared__ double part[4][2 * SS_B + 1][SS_B];  // [wavefront][M rows | G rows | residual][column j]
     __shared__ double Ms[SS_B][SS_B], Gs[SS_B][SS_B], Cs[SS_B][SS_B], res2[SS_B], mus[SS_B], mu_old[SS_B];
     const int b = active ? active[blockIdx.x] : (int)blockIdx.x, n = ns[b];     // (active: the matrices still iterating)
@@ -2459,6 +2460,19 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
             if (dbg)        // (SAAMGE_AMD_SS_DEBUG: residual bounds and Ritz values of the previous pairs)
                 for (int q = 0; q < SS_B; ++q) { dbg[(size_t)b * 2 * SS_B + q] = 2.5 * mu_old[q] * sqrt(res2[q]); dbg[(size_t)b * 2 * SS_B + SS_B + q] = sigma + mu_old[q]; }
             const int cert = inertia ? inertia[b] : -2;      // certified #{lambda < vu}; -1: not certifiable, -2: none
+            // hopeless convergence (the wanted pair far above the shift inside a cluster: rate ~ 1): the bound of
+            // the slowest wanted pair four iterations ago predicts the iterations still needed; a matrix that
+            // cannot make it within the budget gives up now instead of after max_iter iterations
+            if (hist && iter >= 1) {
+                double worst = 0.0;
+                for (int q = 0; q < max(k, 1); ++q) worst = fmax(worst, 2.5 * mu_old[q] * sqrt(res2[q]));
+                const double old = hist[(size_t)b * 4 + (iter & 3)];
+                hist[(size_t)b * 4 + (iter & 3)] = worst;
+                if (iter >= 12 && worst > SS_TOL && old > 0.0) {
+                    const double r4 = worst / old;                        // decay over four iterations
+                    if (!(r4 < 1.0) || 4.0 * log(SS_TOL / worst) / log(r4) > (double)(max_iter - iter)) st |= 2;
+                }
+            }
             if (k > SS_B - 2 || cert > SS_B - 2 || cert == -1) st |= 2;
             else if (cert >= 0) {
                 // Ritz values approach the eigenvalues from above, so the number inside the window grows to the
@@ -2801,6 +2815,13 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
         }
     }
 
+    // a matrix with more wanted pairs than the block holds, or without a certificate, sends the batch to the dense
+    // path: known here, before the second factorisation and the iterations are spent on it
+    for (int v : b.h_inertia)
+        if (v > SS_B - 2 || v < 0) {
+            SA_REQUIRE(!std::getenv("SAAMGE_AMD_SS_STRICT"), "few-eigenpairs path: a matrix has more wanted pairs than the block holds, or no certificate (strict mode)");
+            return false;
+        }
     if (!b.h_inertia.empty()) b.inertia.from_host(b.h_inertia, s);
     // ---- C - sigma I = L L^T ----
     // The iteration converges like (lambda_i - sigma) / (lambda_9 - sigma), so the shift belongs just below the
@@ -2847,6 +2868,8 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     double *X = b.Xbuf.p, *Z = b.Vpk2.p, *mu = b.d.p;     // d: rows >= SS_B per matrix is checked by the caller
     DBuf<double> mubuf((size_t)b.count * SS_B);
     mu = mubuf.p;
+    DBuf<double> slow_hist((size_t)b.count * 4);       // bound of the slowest wanted pair, last four iterations
+    slow_hist.zero(s);
     const bool prof = profiler().enabled;
     const int *bws = b.h_bw.empty() ? nullptr : b.bw.p;
     if (!prof) profiler().begin(s);
@@ -2863,7 +2886,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     DBuf<int> active;
     active.from_host(h_active, s);
     int nact = b.count;
-    for (int iter = 0; iter < 80 && !done; ++iter) {
+    for (int iter = 0; iter < SS_MAX_ITER && !done; ++iter) {
         if (prof) profiler().begin(s);
         const size_t xl_bytes = sizeof(double) * (size_t)b.max_n * XLP + 64;
         if (b.max_n <= 1280) {
@@ -2902,7 +2925,8 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         DBuf<double> dbgbuf;
         if (dbg_on) dbgbuf.alloc((size_t)b.count * 2 * SS_B);
         hipLaunchKernelGGL(ss_rr_kernel, dim3(nact), dim3(256), 0, s, b.n.p, b.voff.p, X, Z, mu, state.p, iter,
-                           b.ss_sigma.p, vu, b.h_inertia.empty() ? (const int *)nullptr : b.inertia.p, dbgbuf.p, active.p);
+                           b.ss_sigma.p, vu, b.h_inertia.empty() ? (const int *)nullptr : b.inertia.p, dbgbuf.p, active.p,
+                           slow_hist.p, SS_MAX_ITER);
         if (dbg_on && iter > 0) {
             auto hd = dbgbuf.to_host(s);
             const int show = std::min(b.count, 3);
