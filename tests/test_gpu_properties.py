@@ -284,3 +284,28 @@ def test_update_operators_keeps_interpolation(variant):
     Bu, Bv = h.vcycle(u), h.vcycle(v)
     assert abs(v @ Bu - u @ Bv) <= 1e-9 * abs(v @ Bu)
     h.close()
+
+
+def test_hierarchy_on_a_nonzero_device():
+    """The library's worker threads, helper streams and cached device blocks follow the CALLER's current device
+    (round-1 advisor finding: HIP's current device is per host thread).  Needs a second visible GPU; on the one-GPU
+    test box this is skipped, on a multi-GPU node it builds and solves on device 1 and compares with device 0."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible GPU")
+    from saamge_amd import capi, problems
+    out = []
+    for dev in (0, 1):
+        torch.cuda.set_device(dev)
+        prob = problems.poisson3d_device((32, 32, 16), blk=(8, 8, 4), coarse_blk=[(2, 2, 2)], device="cuda:%d" % dev)
+        params = capi.default_params(num_coarsenings=2, theta=0.003, nu_relax=3)
+        h = capi.Hierarchy(prob.rowptr, prob.col, prob.val, prob.n, prob.elem_to_dof, prob.elmat, prob.bdr,
+                           prob.partitions, prob.nparts, params, prob.NE_, 8)
+        x = torch.zeros_like(prob.b)
+        _, it, conv, hist = h.pcg(prob.b, x, rel_tol=1e-8, max_iter=100)
+        assert conv
+        out.append((it, [h.level_info(l)["ncoarse"] for l in range(2)], x.cpu().numpy()))
+        h.close()
+    torch.cuda.set_device(0)
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    assert np.allclose(out[0][2], out[1][2], rtol=0, atol=1e-12 * np.abs(out[0][2]).max())

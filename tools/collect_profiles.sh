@@ -16,7 +16,7 @@ echo "write done"
 cd $R
 python3 tools/pmc_traffic.py $(ls $O/pmc_fetch/*counter_collection.csv | head -1) $(ls $O/pmc_write/*counter_collection.csv | head -1) $O/pmc_traffic.json > $O/pmc_traffic.txt
 SAAMGE_AMD_TIMING=1 python3 bench.py --no-cpu-baseline --no-roofline --warmup 1 --steps 1 2> $O/phase_timing.err > /dev/null
-grep TIMING $O/phase_timing.err | tail -34 > $O/phase_timing_256.txt
+grep TIMING $O/phase_timing.err | tail -31 > $O/phase_timing_256.txt
 echo "timing done"
 python3 bench.py > $O/bench_poisson256.json 2> $O/bench_poisson256.err
 echo "default bench done"
