@@ -741,337 +741,6 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
     }
 }
 
-// ---- symmetric variant (SAAMGE_AMD_EIG_FUSED=3) ----------------------------------------------
-// Only the tiles on and below the diagonal of A22' are read, updated and written: the strip of
-// 64 rows I walks its tiles J <= I.  A tile below the diagonal is used twice, for the rows of I
-// (as above) and -- transposed through LDS, so that the lane again owns the output row and the
-// operand V'(r, :) is wave-uniform -- for the rows of J: X(J) += A'(I, J)^T V'(I).  Those
-// contributions go to a per-tile partial buffer and are summed (with the partial V'^T X) by
-// sbr_xsum_kernel.  The diagonal tile is completed from its lower triangle through LDS; the
-// upper triangle of the matrix is never read again.  32 + 16 + 16 FMAs per element of the lower
-// half instead of 2 x 48 for the pair, half the matrix traffic plus 12 % for the partials.
-// Parity-green; measured at 256^3: level 1 (n = 2 600) 487 ms against 534 ms for the one-row
-// kernel and 464 ms for the two-row one, level 0 (n = 405, 7 strips: triangular imbalance and two
-// barriers per tile) 665 ms against 551 / 514 ms -- a third fewer FMAs and scalar operands buy 9 %
-// where they buy anything, so it stays opt-in (requesting the next tile before the transposed
-// product made it slower: 570 ms on level 1).
-constexpr int TP = 65;   // LDS tile pitch (conflict-free both ways)
-__global__ __launch_bounds__(S2_NT) void sbr_fused_sym_kernel(int k0, const int *__restrict__ ns,
-                                                              const int64_t *__restrict__ moff,
-                                                              const int64_t *__restrict__ voff,
-                                                              double *__restrict__ Wm,
-                                                              const double *__restrict__ Vcur,
-                                                              const double *__restrict__ Zbuf,
-                                                              const double *__restrict__ Vnext,
-                                                              double *__restrict__ Xbuf,
-                                                              const int64_t *__restrict__ xpoff,
-                                                              double *__restrict__ Xpart,
-                                                              double *__restrict__ trashbuf, int count,
-                                                              int tiles, int shift) {
-    __shared__ double tileT[64 * TP];          // tile (c, r) at c * TP + r; the epilogue reuses it
-    int b, blk;
-    xcd_decode(tiles, b, blk);
-    if (b >= count) return;
-    const int n = ns[b];
-    if (n - k0 - SB < 2) return;
-    const int np = n - k0 - SB - shift;
-    if (np < 1) return;
-    const bool prod = np >= 2;                 // np == 1: the last diagonal entry is only updated
-    const int I = tiles - 1 - blk;             // long strips first
-    const int i0 = I * 64;
-    if (i0 >= np) return;
-    double *A22 = Wm + moff[b] + (size_t)(k0 + SB + shift) * n + (k0 + SB + shift);
-    const double *__restrict__ Z = Zbuf + voff[b] * SB + shift * SB;
-    const double *__restrict__ Vc = Vcur + voff[b] * SB + shift * SB;
-    const double *__restrict__ Vn = Vnext + voff[b] * SB;
-    double *X = Xbuf + voff[b] * SB;
-    double *Xp = Xpart + (size_t)(xpoff[b] + (int64_t)I * (I - 1) / 2) * (64 * SB);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ia = i0 + lane;
-    const bool oka = ia < np;
-    double *pa = oka ? A22 + ia : trashbuf + lane;
-    const size_t sa = oka ? (size_t)n : 0;
-    const int iac = min(ia, np - 1);
-    const int rmax = min(64, np - i0);         // rows of this strip inside the matrix
-    double za[SB], va[SB], xa[SB];
-#pragma unroll
-    for (int c = 0; c < SB; ++c) {
-        za[c] = -Z[(size_t)iac * SB + c];
-        va[c] = -Vc[(size_t)iac * SB + c];
-        xa[c] = 0.0;
-    }
-    const int c0 = 16 * w;                               // this wavefront's columns of a tile
-    const int ncd = max(0, min(16, rmax - c0));          // ... of the diagonal tile
-    for (int J = 0; J <= I; ++J) {
-        const int j0 = J * 64;
-        const bool diag = J == I;
-        const int nc = diag ? ncd : 16;
-        double ta[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) ta[k] = (k < nc) ? pa[(size_t)(j0 + c0 + k) * sa] : 0.0;
-        if (diag) {
-            // entries above the diagonal of the tile come from the lower triangle
-#pragma unroll
-            for (int k = 0; k < 16; ++k) tileT[(c0 + k) * TP + lane] = ta[k];
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (c0 + k > lane && k < nc) ta[k] = tileT[lane * TP + c0 + k];
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            if (k < nc) {    // wave-uniform
-                const double *zl = Z + (size_t)(j0 + c0 + k) * SB;
-                const double *vl = Vc + (size_t)(j0 + c0 + k) * SB;
-                const double *vn = Vn + (size_t)(j0 + c0 + k) * SB;
-#pragma unroll
-                for (int c = 0; c < SB; ++c) ta[k] = fma(za[c], vl[c], fma(va[c], zl[c], ta[k]));
-                if (prod) {
-#pragma unroll
-                    for (int j = 0; j < SB; ++j) xa[j] = fma(ta[k], vn[j], xa[j]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-            if (k < nc) pa[(size_t)(j0 + c0 + k) * sa] = ta[k];
-        if (!diag) {
-            // rows of J: X(J) += A'(I, J)^T V'(I), lane = column of the tile, wavefront w does 4 of the SB outputs
-#pragma unroll
-            for (int k = 0; k < 16; ++k) tileT[(c0 + k) * TP + lane] = ta[k];
-            __syncthreads();
-            double xt[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int r = 0; r < rmax; ++r) {
-                const double a = tileT[lane * TP + r];
-                const double *vn = Vn + (size_t)(i0 + r) * SB + 4 * w;   // wave-uniform
-#pragma unroll
-                for (int q = 0; q < 4; ++q) xt[q] = fma(a, vn[q], xt[q]);
-            }
-            double *dst = Xp + (size_t)J * (64 * SB);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dst[(4 * w + q) * 64 + lane] = xt[q];
-            __syncthreads();       // the tile buffer is rewritten by the next tile
-        }
-    }
-    if (!prod) return;     // block-uniform
-    // ---- direct part of X(I): sum of the four column splits ----
-    __syncthreads();
-    double *red = tileT;           // 4 * SB * 64 doubles
-#pragma unroll
-    for (int j = 0; j < SB; ++j) red[(w * SB + j) * 64 + lane] = xa[j];
-    __syncthreads();
-    for (int idx = tid; idx < 64 * SB; idx += S2_NT) {
-        const int rr = idx & 63, j = idx >> 6;
-        if (i0 + rr < np)
-            X[(size_t)j * n + i0 + rr] = (red[(0 * SB + j) * 64 + rr] + red[(1 * SB + j) * 64 + rr]) +
-                                         (red[(2 * SB + j) * 64 + rr] + red[(3 * SB + j) * 64 + rr]);
-    }
-}
-
-// X(J) += the partial products of the tiles below J's diagonal tile; partial G = V'^T X of the block
-__global__ __launch_bounds__(256) void sbr_xsum_kernel(int k0, const int *__restrict__ ns,
-                                                       const int64_t *__restrict__ voff,
-                                                       const double *__restrict__ Vnext,
-                                                       double *__restrict__ Xbuf,
-                                                       const int64_t *__restrict__ xpoff,
-                                                       const double *__restrict__ Xpart,
-                                                       const int64_t *__restrict__ goff,
-                                                       double *__restrict__ Gbuf, int count, int tiles,
-                                                       int shift) {
-    constexpr int SBP = SB + 1;
-    __shared__ double xs[64 * SBP], vs2[64 * SBP];
-    int b, J;
-    xcd_decode(tiles, b, J);
-    if (b >= count) return;
-    const int n = ns[b];
-    if (n - k0 - SB < 2) return;
-    const int np = n - k0 - SB - shift;
-    if (np < 2) return;
-    const int j0 = J * 64;
-    if (j0 >= np) return;
-    const int T = (np + 63) / 64;
-    const double *__restrict__ Vn = Vnext + voff[b] * SB;
-    double *X = Xbuf + voff[b] * SB;
-    const double *Xp = Xpart + (size_t)xpoff[b] * (64 * SB);
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < 64 * SB; idx += 256) {
-        const int rr = idx & 63, j = idx >> 6;
-        double s = 0.0;
-        if (j0 + rr < np) {
-            s = X[(size_t)j * n + j0 + rr];
-            for (int I = J + 1; I < T; ++I)
-                s += Xp[(size_t)((int64_t)I * (I - 1) / 2 + J) * (64 * SB) + j * 64 + rr];
-            X[(size_t)j * n + j0 + rr] = s;
-        }
-        xs[rr * SBP + j] = s;
-        vs2[rr * SBP + j] = (j0 + rr < np) ? Vn[(size_t)(j0 + rr) * SB + j] : 0.0;
-    }
-    __syncthreads();
-    {
-        const int a = tid >> 4, c = tid & 15;
-        double s = 0.0;
-        for (int rr = 0; rr < 64; ++rr) s = fma(vs2[rr * SBP + a], xs[rr * SBP + c], s);
-        Gbuf[goff[b] + (size_t)J * (SB * SB) + tid] = s;
-    }
-}
-
-// ---- the same fused update + product on the matrix cores ------------------------------------
-// v_mfma_f64_16x16x4_f64 (D = A(16x4) B(4x16) + C; A: row = lane & 15, k = lane >> 4; B: col =
-// lane & 15, k = lane >> 4; C/D register r: col = lane & 15, row = (lane >> 4) + 4 r).
-// A wavefront owns 16 rows I of a 64-row block and walks the 16-column tiles L of A22'.  It holds
-// the TRANSPOSED tile, D(l, i) = A22'(i, l): the D columns are then consecutive rows i, so every
-// load/store of register r is four 128-B row segments (columns l0 + 4 r + 0..3).
-//   update   D -= [V_L Z_L] [Z_I V_I]^T         8 MFMAs, K = 2 SB; the row operands stay in VGPRs
-//   product  X^T(:, I) += Vn_L^T D              4 MFMAs: register r of D IS the B operand of
-//                                               K-group r (k = l - l0 - 4 r), no shuffles
-// The vector-FMA version above needs its column operands as SGPRs and is bound by the scalar-load
-// latency (tools/fma64_bench.hip); here operands are plain coalesced vector loads of the packed
-// row-major V / Z and 12 instructions do the 12288 FMAs of a tile.  Kept as an alternative
-// (SAAMGE_AMD_EIG_FUSED=2): on MI355X the fp64 MFMA sustains ~110 cycles per instruction per
-// SIMD, which makes this variant as fast as the vector one, not faster.
-typedef double v4d __attribute__((ext_vector_type(4)));
-
-// RG 64-row sub-blocks per workgroup (wavefront w owns rows 64 g + 16 w .. + 15 of sub-block g):
-// taller strips mean longer contiguous column segments (64 RG x 8 B) per DRAM visit and the
-// column operands are shared by the RG row groups.
-template <int RG>
-__global__ __launch_bounds__(256) void sbr_fused_mfma_kernel(int k0, const int *__restrict__ ns,
-                                                             const int64_t *__restrict__ moff,
-                                                             const int64_t *__restrict__ voff,
-                                                             double *__restrict__ Wm,
-                                                             const double *__restrict__ Vcur,
-                                                             const double *__restrict__ Zbuf,
-                                                             const double *__restrict__ Vnext,
-                                                             double *__restrict__ Xbuf,
-                                                             const int64_t *__restrict__ goff,
-                                                             double *__restrict__ Gbuf, int count,
-                                                             int tiles) {
-    constexpr int SBP = SB + 1;
-    __shared__ double xs[64 * SBP], vs2[64 * SBP];
-    int b, blk;
-    xcd_decode(tiles, b, blk);
-    if (b >= count) return;
-    const int n = ns[b];
-    if (n - k0 - SB < 2) return;               // this matrix has no panel k0
-    const int np = n - k0 - 2 * SB;            // order of A22' (may be < 2: update only)
-    if (np < 1) return;
-    const int i0 = blk * (64 * RG);
-    if (i0 >= np) return;
-    const bool prod = np >= 2;                 // the next panel has reflectors
-    double *A22 = Wm + moff[b] + (size_t)(k0 + 2 * SB) * n + (k0 + 2 * SB);
-    const double *__restrict__ Z = Zbuf + voff[b] * SB + SB * SB;     // rows shifted by SB
-    const double *__restrict__ Vc = Vcur + voff[b] * SB + SB * SB;
-    const double *__restrict__ Vn = Vnext + voff[b] * SB;
-    double *X = Xbuf + voff[b] * SB;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    int ig[RG];
-    bool iok[RG];
-    double bz[RG][4], bv[RG][4];               // negated row operands: -Z(i, 4 kg + lk), -V(i, 4 kg + lk)
-    v4d xacc[RG];
-    double *colp[RG];
-#pragma unroll
-    for (int g = 0; g < RG; ++g) {
-        ig[g] = i0 + 64 * g + 16 * w + li;
-        iok[g] = ig[g] < np;
-        const int ic = min(ig[g], np - 1);
-        colp[g] = A22 + ic;
-#pragma unroll
-        for (int kg = 0; kg < 4; ++kg) {
-            const double z = Z[(size_t)ic * SB + 4 * kg + lk], v = Vc[(size_t)ic * SB + 4 * kg + lk];
-            bz[g][kg] = iok[g] ? -z : 0.0;
-            bv[g][kg] = iok[g] ? -v : 0.0;
-        }
-        xacc[g] = v4d{0.0, 0.0, 0.0, 0.0};
-    }
-    if (i0 + 16 * w < np) {                    // wave-uniform: the wavefront has rows
-        for (int l0 = 0; l0 < np; l0 += 16) {
-            const int l = l0 + li;
-            const bool lok = l < np;
-            const int lc = min(l, np - 1);
-            double av[4], az[4];               // column operands V(l, 4 kg + lk), Z(l, 4 kg + lk)
-#pragma unroll
-            for (int kg = 0; kg < 4; ++kg) {
-                const double v = Vc[(size_t)lc * SB + 4 * kg + lk], z = Z[(size_t)lc * SB + 4 * kg + lk];
-                av[kg] = lok ? v : 0.0;
-                az[kg] = lok ? z : 0.0;
-            }
-            double an[4];
-            if (prod) {
-#pragma unroll
-                for (int kg = 0; kg < 4; ++kg) {
-                    const int lrow = l0 + 4 * kg + lk;
-                    const double a = Vn[(size_t)min(lrow, np - 1) * SB + li];
-                    an[kg] = lrow < np ? a : 0.0;
-                }
-            }
-            size_t coff[4];
-            bool cin[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int col = l0 + 4 * r + lk;
-                cin[r] = col < np;
-                coff[r] = (size_t)min(col, np - 1) * n;
-            }
-            v4d acc[RG];
-#pragma unroll
-            for (int g = 0; g < RG; ++g)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double t = colp[g][coff[r]];
-                    acc[g][r] = (iok[g] && cin[r]) ? t : 0.0;
-                }
-#pragma unroll
-            for (int g = 0; g < RG; ++g) {
-#pragma unroll
-                for (int kg = 0; kg < 4; ++kg)
-                    acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kg], bz[g][kg], acc[g], 0, 0, 0);
-#pragma unroll
-                for (int kg = 0; kg < 4; ++kg)
-                    acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(az[kg], bv[g][kg], acc[g], 0, 0, 0);
-            }
-#pragma unroll
-            for (int g = 0; g < RG; ++g)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (iok[g] && cin[r]) A22[coff[r] + ig[g]] = acc[g][r];
-            if (prod) {
-#pragma unroll
-                for (int g = 0; g < RG; ++g)
-#pragma unroll
-                    for (int kg = 0; kg < 4; ++kg)
-                        xacc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[kg], acc[g][kg], xacc[g], 0, 0, 0);
-            }
-        }
-    }
-    if (!prod) return;   // block-uniform
-    // ---- X(i, j), j = lk + 4 r; partial G = V^T X per 64-row sub-block ----
-#pragma unroll
-    for (int g = 0; g < RG; ++g) {
-        if (i0 + 64 * g >= np) break;          // block-uniform
-        if (g) __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = lk + 4 * r;
-            if (iok[g]) X[(size_t)j * n + ig[g]] = xacc[g][r];
-            xs[(16 * w + li) * SBP + j] = iok[g] ? xacc[g][r] : 0.0;
-        }
-        for (int idx = tid; idx < 64 * SB; idx += 256) {
-            const int rr = idx >> 4, j = idx & 15;
-            const int row = i0 + 64 * g + rr;
-            vs2[rr * SBP + j] = (row < np) ? Vn[(size_t)row * SB + j] : 0.0;
-        }
-        __syncthreads();
-        const int a = tid >> 4, c = tid & 15;
-        double s = 0.0;
-        for (int rr = 0; rr < 64; ++rr) s = fma(vs2[rr * SBP + a], xs[rr * SBP + c], s);
-        Gbuf[goff[b] + (size_t)(blk * RG + g) * (SB * SB) + tid] = s;
-    }
-}
-
 // ---------------------------------------------------------------------------------------
 // stage 2: bulge chasing
 // ---------------------------------------------------------------------------------------
@@ -1418,20 +1087,9 @@ struct ChaseConfig {
     int ncq, nt;
     int slots() const { return nt / (16 * ncq); }
 };
-static ChaseConfig chase_config(int nmax) {
-    static const ChaseConfig forced = []() {
-        ChaseConfig c{0, 0};
-        const char *e = std::getenv("SAAMGE_AMD_CHASE");
-        if (e && std::sscanf(e, "%d,%d", &c.ncq, &c.nt) == 2) {
-            const bool ok = (c.ncq == 4 && c.nt == 1024) || (c.ncq == 2 && (c.nt == 512 || c.nt == 1024));
-            if (!ok) c = ChaseConfig{0, 0};
-        }
-        return c;
-    }();
-    if (forced.ncq) return forced;
-    // a sweep of n rows keeps ~n / 32 sweeps in flight at the minimum spacing of two steps
-    return ChaseConfig{4, 1024};
-}
+// a whole wavefront per chase step (NCQ = 4), 16 slots per workgroup: a sweep of n rows keeps ~n / 32 sweeps in
+// flight at the minimum spacing of two steps (half-wavefront slots, NCQ = 2, measured slower in round 1)
+static ChaseConfig chase_config(int) { return ChaseConfig{4, 1024}; }
 
 void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
     if (!b.count) return;
@@ -1441,8 +1099,6 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
     SA_HIP_CHECK(hipFuncSetAttribute((const void *)band_chase_kernel<L, Q, T>,                 \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
         SA_CHASE_ATTR(true, 4, 1024); SA_CHASE_ATTR(false, 4, 1024);
-        SA_CHASE_ATTR(true, 2, 512); SA_CHASE_ATTR(false, 2, 512);
-        SA_CHASE_ATTR(true, 2, 1024); SA_CHASE_ATTR(false, 2, 1024);
 #undef SA_CHASE_ATTR
         SA_HIP_CHECK(hipFuncSetAttribute((const void *)backtransform2_kernel<256>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1460,18 +1116,7 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
     const int nmax0 = b.max_n;
     const size_t fixed0 = sizeof(double) * (chase_config(nmax0).slots() * HAND) + sizeof(int) * (2 * (size_t)nmax0 + 4);
     const bool in_lds0 = fixed0 + sizeof(double) * (size_t)nmax0 * LDB + 64 <= 160 * 1024;
-    static const int fused_mode = []() {
-        const char *e = std::getenv("SAAMGE_AMD_EIG_FUSED");
-        return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;
-    }();
     b.h_xpoff.clear();
-    if (fused_mode == 3) {      // symmetric update: room for the partial products of the tiles below the diagonal
-        b.h_xpoff.assign((size_t)b.count + 1, 0);
-        for (int i = 0; i < b.count; ++i) {
-            const int64_t T0 = std::max(0, (b.h_n[i] - 2 * SB + 63) / 64);
-            b.h_xpoff[i + 1] = b.h_xpoff[i] + T0 * (T0 - 1) / 2;
-        }
-    }
     b.h_goff.assign((size_t)b.count + 1, 0);
     for (int i = 0; i < b.count; ++i)
         b.h_goff[i + 1] = b.h_goff[i] + (int64_t)((b.h_n[i] + 63) / 64) * SB * SB;
@@ -1484,24 +1129,11 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
     // ---- stage 1 ----
     const int nmax = b.max_n;
     const bool prof = profiler().enabled;
-    // algorithmic bytes of the product / update / fused kernels (trailing matrix read once by
-    // the product; read + written once by the update, also when the next product rides on it)
-    double sbytes = 0.0, ubytes = 0.0;
-    if (prof) {
-        for (int n : b.h_n)
-            for (int k0 = 0; n - k0 - SB >= 2; k0 += SB) {
-                const double np = n - k0 - SB, npn = std::max(0.0, np - SB);
-                sbytes += 8.0 * np * np;
-                ubytes += 16.0 * np * np;
-                (void)npn;
-            }
-    }
-    // SAAMGE_AMD_EIG_FUSED: 0 = separate product / update kernels, 1 (default) = fused, vector
-    // FMAs with scalar-cache operands, 2 = fused on the matrix cores.  Measured on MI355X
-    // (256^3, profiles/r01_*): 1 is the fastest; fp64 MFMA (tools/fma64_bench.hip: 46 TFLOP/s
-    // sustained vs 69 for v_fma_f64) buys nothing here because none of the variants is bound by
-    // FMA issue or by HBM bytes -- they are bound by operand delivery (scalar-load latency).
-    const bool fused = fused_mode != 0;
+    // The product of panel p + 1 rides on the update of panel p (one fused kernel, vector FMAs with scalar-cache
+    // operands).  Measured alternatives (round 1, profiles/r01_*): separate product / update kernels, the same
+    // update on the matrix cores (fp64 MFMA sustains 46 TFLOP/s against 69 for v_fma_f64: tools/fma64_bench.hip)
+    // and a lower-triangle-only variant were all slower or equal -- none is bound by FMA issue or HBM bytes, they
+    // are bound by operand delivery (scalar-load latency).
     // rows per lane of the fused kernel (SAAMGE_AMD_EIG_RPL = 1 | 2)
     static const int rpl = []() {
         const char *e = std::getenv("SAAMGE_AMD_EIG_RPL");
@@ -1535,24 +1167,7 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
                            b.n.p, b.voff.p, Vp, b.Tfac.p, b.Xbuf.p, b.goff.p, b.Gbuf.p,
                            b.Zbuf.p, b.count, div_up(npmax, SM_NT));
     };
-    bool first = true;
-    if (!fused) {
-        for (int k0 = 0; nmax - k0 - SB >= 2; k0 += SB) {
-            const int npmax = nmax - k0 - SB;
-            if (prof) profiler().begin(s);
-            launch_qr(k0, b.Vpk.p);
-            if (prof) { profiler().end(s, "eig_sbr_qr", 0.0, 0.0); profiler().begin(s); }
-            launch_symm(k0, b.Vpk.p);
-            if (prof) { profiler().end(s, "eig_sbr_symm", first ? sbytes : 0.0, 0.0); profiler().begin(s); }
-            launch_z(k0, b.Vpk.p);
-            if (prof) { profiler().end(s, "eig_sbr_z", 0.0, 0.0); profiler().begin(s); }
-            hipLaunchKernelGGL((sbr_fused_kernel<false, 1>), dim3(cnt8 * div_up(npmax, SF_ROWS)), dim3(S2_NT), 0, s,
-                               k0, b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.Vpk.p, b.Xbuf.p,
-                               b.goff.p, b.Gbuf.p, b.trash.p, b.count, div_up(npmax, SF_ROWS), 0);
-            if (prof) profiler().end(s, "eig_sbr_syr2k", first ? ubytes : 0.0, 0.0);
-            first = false;
-        }
-    } else if (nmax - SB >= 2) {
+    if (nmax - SB >= 2) {
         // look-ahead pipeline: the product of panel p+1 rides on the update of panel p
         double *Vcur = b.Vpk.p, *Vnext = b.Vpk2.p;
         if (prof) profiler().begin(s);
@@ -1573,31 +1188,10 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
             if (prof) { profiler().end(s, "eig_sbr_panel", 0.0, 0.0); profiler().begin(s); }
             if (has_next) launch_qr(k0 + SB, Vnext);
             if (prof) { profiler().end(s, "eig_sbr_qr", 0.0, 0.0); profiler().begin(s); }
-            static const int rg = []() {
-                const char *e = std::getenv("SAAMGE_AMD_EIG_RG");
-                return (e && (e[0] == '1' || e[0] == '2' || e[0] == '4')) ? e[0] - '0' : 2;
-            }();
-            if (npn >= 1 && fused_mode == 2) {
-#define SA_FUSED(RGV)                                                                                      \
-    hipLaunchKernelGGL((sbr_fused_mfma_kernel<RGV>), dim3(cnt8 * div_up(npn, 64 * RGV)), dim3(256), 0, s,  \
-                       k0, b.n.p, b.moff.p, b.voff.p, b.W.p, Vcur, b.Zbuf.p, Vnext, b.Xbuf.p, b.goff.p,    \
-                       b.Gbuf.p, b.count, div_up(npn, 64 * RGV))
-                if (rg == 1) SA_FUSED(1); else if (rg == 2) SA_FUSED(2); else SA_FUSED(4);
-#undef SA_FUSED
-            }
             // two rows per lane are ~10 % faster per row slot but pad the strip count to 128 rows
-            const bool two_rows = rpl == 2 && fused_mode != 2 &&
+            const bool two_rows = rpl == 2 &&
                 (double)div_up(npn, 2 * SF_ROWS) * (2 * SF_ROWS) < 1.10 * (double)div_up(npn, SF_ROWS) * SF_ROWS;
-            if (fused_mode == 2) {
-                // (launched above)
-            } else if (fused_mode == 3 && npn >= 1) {
-                hipLaunchKernelGGL(sbr_fused_sym_kernel, dim3(cnt8 * div_up(npn, SF_ROWS)), dim3(S2_NT), 0, s, k0,
-                                   b.n.p, b.moff.p, b.voff.p, b.W.p, Vcur, b.Zbuf.p, Vnext, b.Xbuf.p, b.xpoff.p,
-                                   b.Xpart.p, b.trash.p, b.count, div_up(npn, SF_ROWS), SB);
-                hipLaunchKernelGGL(sbr_xsum_kernel, dim3(cnt8 * div_up(npn, SF_ROWS)), dim3(256), 0, s, k0, b.n.p,
-                                   b.voff.p, Vnext, b.Xbuf.p, b.xpoff.p, b.Xpart.p, b.goff.p, b.Gbuf.p, b.count,
-                                   div_up(npn, SF_ROWS), SB);
-            } else if (npn >= 1 && two_rows)
+            if (npn >= 1 && two_rows)
                 hipLaunchKernelGGL((sbr_fused_kernel<true, 2>), dim3(cnt8 * div_up(npn, 2 * SF_ROWS)), dim3(S2_NT), 0, s,
                                    k0, b.n.p, b.moff.p, b.voff.p, b.W.p, Vcur, b.Zbuf.p, Vnext, b.Xbuf.p,
                                    b.goff.p, b.Gbuf.p, b.trash.p, b.count, div_up(npn, 2 * SF_ROWS), SB);
@@ -1618,7 +1212,6 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
             if (has_next) launch_z(k0 + SB, Vnext);
             if (prof) profiler().end(s, "eig_sbr_z", 0.0, 0.0);
             std::swap(Vcur, Vnext);
-            first = false;
         }
     }
     SA_HIP_CHECK(hipGetLastError());
@@ -1644,7 +1237,7 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
                                b.moff.p, b.voff.p, b.roff.p, b.W.p, b.bandg.p, in_lds, b.d.p, b.e.p, b.rv.p,    \
                                b.rtau.p);                                                                       \
     }
-    SA_CHASE(4, 1024) SA_CHASE(2, 512) SA_CHASE(2, 1024)
+    SA_CHASE(4, 1024)
 #undef SA_CHASE
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "eig_band_chase", 0.0, cflops);
@@ -2092,7 +1685,7 @@ __global__ __launch_bounds__(NT) void ss_trsolve_kernel(const int *__restrict__ 
 // conflict-free for lanes = rows): the factor is then the only global traffic, read once per
 // triangle.  For agglomerates up to ~2 000 rows.
 constexpr int XLP = SS_B + 1;
-template <int NT, int MODE>
+template <int NT>
 __global__ __launch_bounds__(NT) void ss_solve_lds_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
                                                            const int64_t *__restrict__ voff,
                                                            const double *__restrict__ W, const double *__restrict__ X,
@@ -2144,29 +1737,8 @@ __global__ __launch_bounds__(NT) void ss_solve_lds_kernel(const int *__restrict_
                 double acc[SS_B];
 #pragma unroll
                 for (int j = 0; j < SS_B; ++j) acc[j] = xl[r * XLP + j];
-                if (MODE == 0) {
-                    const double *ap = A + (size_t)k0 * n + r;
-#pragma unroll 1
-                    for (int c = 0; c < SB; c += 8) {     // eight factor entries in flight (ys is zero past the block)
-                        double t[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) t[u] = ap[(size_t)min(c + u, nb - 1) * n];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)
-#pragma unroll
-                            for (int j = 0; j < SS_B; ++j) acc[j] = fma(-t[u], ys[c + u][j], acc[j]);
-                    }
-                } else if (MODE == 1) {                   // the whole block row in flight
-                    const double *ap = A + (size_t)k0 * n + r;
-                    double t[SB];
-#pragma unroll
-                    for (int u = 0; u < SB; ++u) t[u] = ap[(size_t)min(u, nb - 1) * n];
-#pragma unroll
-                    for (int u = 0; u < SB; ++u)
-#pragma unroll
-                        for (int j = 0; j < SS_B; ++j) acc[j] = fma(-t[u], ys[u][j], acc[j]);
-                } else {
-                    // the same entries from the other triangle (it holds the transpose): SB consecutive
+                {
+                    // the factor entries of this row from the other triangle (it holds the transpose): SB consecutive
                     // doubles per row.  Past a partial last block (backward pass only) the reads run into the
                     // next column of the matrix -- finite values that meet the zeros of ys.
                     const double *ap = A + (size_t)r * n + k0;
@@ -2814,18 +2386,15 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         if (prof) profiler().begin(s);
         const size_t xl_bytes = sizeof(double) * (size_t)b.max_n * XLP + 64;
         if (b.max_n <= 1280) {
-            // SAAMGE_AMD_SS_SOLVE: 3 (default) deep-prefetch kernel for narrow bands, 0 / 1 / 2 variants of the plain one
-            static const int mode = [] { const char *e = std::getenv("SAAMGE_AMD_SS_SOLVE"); return e ? std::atoi(e) : 3; }();
-            static const int snt = [] { const char *e = std::getenv("SAAMGE_AMD_SS_SOLVE_NT"); return e ? std::atoi(e) : 0; }();
+            // narrow bands: the deep-prefetch kernel; wider ones: the plain kernel, 256 or 512 threads by the band
             const int rows = std::min(b.max_n, b.ss_bwmax + SB);     // rows a block step updates
-            int nt = (snt == 256 || snt == 512) ? snt : (rows <= 256 ? 256 : 512);   // (>= SB * SB threads: the block loads)
-            auto go = [&](auto kern) {
+            auto go = [&](auto kern, int nt) {
                 SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
                 hipLaunchKernelGGL(kern, dim3(nact), dim3(nt), xl_bytes, s, b.n.p, b.moff.p, b.voff.p, b.W.p, X, Z, state.p, bws, active.p);
             };
-            if (mode == 3 && rows <= 128) { nt = 128; go(ss_solve_lds_pf_kernel<128>); }
-            else if (nt == 256) { if (mode == 0) go(ss_solve_lds_kernel<256, 0>); else if (mode == 1) go(ss_solve_lds_kernel<256, 1>); else go(ss_solve_lds_kernel<256, 2>); }
-            else { if (mode == 0) go(ss_solve_lds_kernel<512, 0>); else if (mode == 1) go(ss_solve_lds_kernel<512, 1>); else go(ss_solve_lds_kernel<512, 2>); }
+            if (rows <= 128) go(ss_solve_lds_pf_kernel<128>, 128);
+            else if (rows <= 256) go(ss_solve_lds_kernel<256>, 256);      // (>= SB * SB threads: the block loads)
+            else go(ss_solve_lds_kernel<512>, 512);
         } else {
         SA_HIP_CHECK(hipMemcpyAsync(Z, X, sizeof(double) * (size_t)b.h_voff[b.count] * SB, hipMemcpyDeviceToDevice, s));
         if (b.max_n > 768) {

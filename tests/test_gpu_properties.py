@@ -159,17 +159,16 @@ def test_one_stage_and_two_stage_eigensolvers_agree():
         "print(json.dumps({'nc': h.level_info(0)['ncoarse'], 'it': it, 'hist': list(hist)}))\n" % ROOT)
     import json
     outs = []
-    # one-stage kernel, and the variants of the band reduction kept behind SAAMGE_AMD_EIG_FUSED
-    # (0 separate product / update, 1 fused (default), 2 fused on fp64 MFMA, 3 symmetric: lower tiles only)
-    variants = [{"SAAMGE_AMD_EIG": "onestage"}] + [{"SAAMGE_AMD_EIG": "twostage", "SAAMGE_AMD_EIG_FUSED": m}
-                                                   for m in ("1", "0", "2", "3")]
+    # the dense path: one-stage kernel, two-stage band reduction (one or two rows per lane in the fused update)
+    variants = [{"SAAMGE_AMD_EIG": "onestage"}, {"SAAMGE_AMD_EIG": "twostage"},
+                {"SAAMGE_AMD_EIG": "twostage", "SAAMGE_AMD_EIG_RPL": "1"}]
     # the few-eigenpairs path (Cholesky + shift-invert subspace iteration) on every agglomerate size
     # (STRICT: giving up on a batch is an error instead of the silent dense fallback), with its variants:
     # band kept in LDS (default), banded factorisation through HBM, full Cholesky, first-encounter row order,
-    # global-dof order without the box renumbering, the plain LDS solve
+    # global-dof order without the box renumbering
     ss = {"SAAMGE_AMD_EIG": "subspace", "SAAMGE_AMD_SS_MIN_N": "0", "SAAMGE_AMD_SS_STRICT": "1"}
     variants += [ss, dict(ss, SAAMGE_AMD_SS_BAND_LDS="0"), dict(ss, SAAMGE_AMD_SS_BAND="0"),
-                 dict(ss, SAAMGE_AMD_SS_PERM="0"), dict(ss, SAAMGE_AMD_SS_BOX="0"), dict(ss, SAAMGE_AMD_SS_SOLVE="0")]
+                 dict(ss, SAAMGE_AMD_SS_PERM="0"), dict(ss, SAAMGE_AMD_SS_BOX="0")]
     for extra in variants:
         env = dict(os.environ, **extra)
         o = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
