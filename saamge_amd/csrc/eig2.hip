@@ -1657,12 +1657,14 @@ __global__ __launch_bounds__(NT) void ss_trsolve_kernel(const int *__restrict__ 
             for (int j = 0; j < SS_B; ++j) acc[j] = Xb[(size_t)r * SS_B + j];
             const double *ap = A + (size_t)k0 * n + r;        // T(r, k0 + c): column k0 + c, row r
 #pragma unroll 1
-            for (int c = 0; c < SB; c += 4) {     // four factor entries in flight (ys is zero past the block)
-                const double t0 = ap[(size_t)min(c, nb - 1) * n], t1 = ap[(size_t)min(c + 1, nb - 1) * n];
-                const double t2 = ap[(size_t)min(c + 2, nb - 1) * n], t3 = ap[(size_t)min(c + 3, nb - 1) * n];
+            for (int c = 0; c < SB; c += 8) {     // eight factor entries in flight (ys is zero past the block)
+                double t[8];
 #pragma unroll
-                for (int j = 0; j < SS_B; ++j)
-                    acc[j] = fma(-t3, ys[c + 3][j], fma(-t2, ys[c + 2][j], fma(-t1, ys[c + 1][j], fma(-t0, ys[c][j], acc[j]))));
+                for (int u = 0; u < 8; ++u) t[u] = ap[(size_t)min(c + u, nb - 1) * n];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int j = 0; j < SS_B; ++j) acc[j] = fma(-t[u], ys[c + u][j], acc[j]);
             }
             const bool in_next = (r >= kn && r < kn + SB);
 #pragma unroll
