@@ -385,13 +385,17 @@ def test_elasticity3d_matches_oracle(levels):
     h.close()
 
 
-def test_q2_elasticity3d_matches_oracle():
+@pytest.mark.parametrize("n,blk", [((4, 2, 3), (2, 2, 3)), ((8, 4, 5), (4, 4, 5))])
+def test_q2_elasticity3d_matches_oracle(n, blk):
     """BASELINE config 5's element type in small: 27-node hexes with 3 displacement components
-    (81 x 81 element matrices, 525-dof agglomerates), six rigid-body modes per free agglomerate.
-    (2 x 3 elements across, so that the bending modes of the clamped agglomerate are not a
+    (81 x 81 element matrices), six rigid-body modes per free agglomerate.  First case: 525-dof
+    agglomerates (band in LDS); second: config 5's agglomerate size class (4 x 4 x 5 elements, 2 673 dofs, half
+    bandwidth in the hundreds: the factorisations, the inertia pass and the solves through HBM panels) against
+    LAPACK's dsygvx on the same matrices.
+    (2 x 3 / 4 x 5 elements across, so that the bending modes of the clamped agglomerate are not a
     degenerate pair of which "at least one" would pick an arbitrary member.)"""
     o = _oracle()
-    prob = pr.elasticity3d_q2_problem((4, 2, 3), blk=(2, 2, 3))
+    prob = pr.elasticity3d_q2_problem(n, blk=blk)
     h, H = _build_pair(prob, 1)
     _compare_level(h, H, 0, 0.003, strict=False, degenerate=True)
     m, ev, X, Ds = h.get_ae_eigens(0)
