@@ -12,6 +12,7 @@
 #include "dist.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace saamge_amd {
 
@@ -27,6 +28,22 @@ __global__ __launch_bounds__(256) void halo_mark_kernel(int row0, int nloc, cons
         const int c = col[k];
         if (c < row0 || c >= row0 + nloc) flag[c] = 1;
     }
+}
+
+// slice s of the own rows reads a column outside the own range
+__global__ __launch_bounds__(256) void halo_slice_kernel(int row0, int nloc, const roff_t *__restrict__ rowptr,
+                                                         const int *__restrict__ col, int *__restrict__ sflag) {
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 7;
+    const long r = gtid >> 3;
+    if (r >= nloc) return;
+    const int row = row0 + (int)r;
+    bool out = false;
+    for (roff_t k = rowptr[row] + lane; k < rowptr[row + 1]; k += 8) {
+        const int c = col[k];
+        out |= (c < row0 || c >= row0 + nloc);
+    }
+    if (out) sflag[r >> 6] = 1;
 }
 
 __global__ __launch_bounds__(256) void halo_compact_kernel(int n, const int *__restrict__ flag,
@@ -83,6 +100,43 @@ void halo_exchange(Hierarchy &H, Level::Dist &D, double *x) {
         SA_HIP_CHECK(hipGetLastError());
         profiler().end(s, "halo_unpack", 20.0 * D.nrecv, 0.0);
     }
+}
+
+void halo_then(Hierarchy &H, Level::Dist *D, double *x, const std::function<void(hipStream_t, RowRange)> &op) {
+    hipStream_t s = H.stream;
+    if (!D) {
+        op(s, RowRange());
+        return;
+    }
+    RowRange own;
+    own.row0 = D->row0;
+    own.nrows = D->nloc;
+    if (D->int_nrows <= 0) {
+        halo_exchange(H, *D, x);
+        op(s, own);
+        return;
+    }
+    if (!H.ev_fork) {
+        SA_HIP_CHECK(hipEventCreateWithFlags(&H.ev_fork, hipEventDisableTiming));
+        SA_HIP_CHECK(hipEventCreateWithFlags(&H.ev_join, hipEventDisableTiming));
+    }
+    hipStream_t side = side_stream(3);
+    SA_HIP_CHECK(hipEventRecord(H.ev_fork, s));              // x is complete on the own rows
+    SA_HIP_CHECK(hipStreamWaitEvent(side, H.ev_fork, 0));
+    RowRange in;
+    in.row0 = D->int_row0;
+    in.nrows = D->int_nrows;
+    op(side, in);                                             // rows without halo entries: beside the exchange
+    SA_HIP_CHECK(hipEventRecord(H.ev_join, side));
+    halo_exchange(H, *D, x);
+    RowRange lo, hi;
+    lo.row0 = D->row0;
+    lo.nrows = D->int_row0 - D->row0;
+    hi.row0 = D->int_row0 + D->int_nrows;
+    hi.nrows = D->row0 + D->nloc - hi.row0;
+    if (lo.nrows > 0) op(s, lo);
+    if (hi.nrows > 0) op(s, hi);
+    SA_HIP_CHECK(hipStreamWaitEvent(s, H.ev_join, 0));
 }
 
 bool dist_setup_level(Hierarchy &H, int lev) {
@@ -167,6 +221,31 @@ bool dist_setup_level(Hierarchy &H, int lev) {
     }
     D.send_buf.alloc((size_t)D.nsend + 1);
     D.recv_buf.alloc((size_t)D.nrecv + 1);
+    // interior rows: the longest run of own slices without a halo column (a slab of a banded operator: everything
+    // but the two ends); overlapped with the exchange when it is at least a quarter of the own rows
+    // (SAAMGE_AMD_HALO_OVERLAP=0: never)
+    D.int_row0 = D.row0;
+    D.int_nrows = 0;
+    static const bool no_overlap = [] { const char *e = std::getenv("SAAMGE_AMD_HALO_OVERLAP"); return e && e[0] == '0'; }();
+    if (D.nloc > 0 && !no_overlap) {
+        const int nsl = div_up(D.nloc, 64);
+        DBuf<int> sflag((size_t)nsl);
+        sflag.zero(s);
+        hipLaunchKernelGGL(halo_slice_kernel, dim3(div_up((long)D.nloc * 8, 256)), dim3(256), 0, s, D.row0, D.nloc,
+                           L.A.rowptr.p, L.A.col.p, sflag.p);
+        SA_HIP_CHECK(hipGetLastError());
+        auto hf = sflag.to_host(s);
+        int best0 = 0, best = 0, run0 = 0;
+        for (int i = 0; i <= nsl; ++i)
+            if (i == nsl || hf[i]) {
+                if (i - run0 > best) { best = i - run0; best0 = run0; }
+                run0 = i + 1;
+            }
+        if (best >= 1 && 4 * best >= nsl) {
+            D.int_row0 = D.row0 + 64 * best0;
+            D.int_nrows = std::min(64 * best, D.row0 + D.nloc - D.int_row0);
+        }
+    }
     L.r.zero(s);  // the restriction R r sums over ranks: r must vanish outside the own rows
     SA_HIP_CHECK(hipStreamSynchronize(s));
     D.on = true;

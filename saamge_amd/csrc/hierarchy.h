@@ -102,6 +102,9 @@ struct Level {                  // tg_data_t + interp_data_t + agg_partitioning_
         DBuf<int> send_idx, recv_idx;
         DBuf<double> send_buf, recv_buf;
         int nsend = 0, nrecv = 0;
+        // longest run of own SELL slices whose rows read no halo entry: applied on a side stream while the
+        // exchange is in flight (dist.hip: halo_then); int_nrows = 0: no overlap on this level
+        int int_row0 = 0, int_nrows = 0;
     } dist;
 };
 
@@ -129,8 +132,12 @@ struct Hierarchy {              // ml_data_t
     std::thread galerkin_thread;
     std::exception_ptr galerkin_err;
     int galerkin_lev = -1;
+    // row-partitioned solve: fork / join events of the interior-rows stream (halo_then)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ~Hierarchy() {
         if (galerkin_thread.joinable()) galerkin_thread.join();
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
     }
 };
 

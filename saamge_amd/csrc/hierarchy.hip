@@ -744,7 +744,8 @@ static inline RowRange rows_of(const Level::Dist *D) {
 }
 
 // x = poly(b) starting from x = 0; result lands in x, `tmp` is the ping-pong partner.
-// Row-partitioned (D != null): own rows only; the halo of the result is refreshed on return.
+// Row-partitioned (D != null): own rows only; the halo of the result is NOT refreshed (the next
+// operator application does that, halo_then).
 static void smooth_from_zero(Hierarchy &H, const DCsr &A, const double *dinv,
                              const std::vector<double> &roots, const double *b, double *x, double *tmp,
                              Level::Dist *D = nullptr) {
@@ -754,16 +755,15 @@ static void smooth_from_zero(Hierarchy &H, const DCsr &A, const double *dinv,
     double *cur = ((deg - 1) % 2 == 0) ? x : tmp;
     double *oth = (cur == x) ? tmp : x;
     smooth_first(s, nl, dinv + off, b + off, cur + off, 1.0 / roots[0]);
-    if (D) halo_exchange(H, *D, cur);
     for (int i = 1; i < deg; ++i) {
-        smooth_step(s, A, dinv, b, cur, oth, 1.0 / roots[i], rows_of(D));
+        const double scale = 1.0 / roots[i];
+        halo_then(H, D, cur, [&](hipStream_t q, RowRange rr) { smooth_step(q, A, dinv, b, cur, oth, scale, rr); });
         std::swap(cur, oth);
-        if (D) halo_exchange(H, *D, cur);
     }
 }
 
-// x += M^-1 (b - A x).  Row-partitioned: the halo of x must be valid on entry; on return only
-// the own rows are.
+// x += M^-1 (b - A x).  Row-partitioned: x is valid on the own rows on entry and on return (every step
+// refreshes the halo it reads).
 static void smooth_inplace(Hierarchy &H, const DCsr &A, const double *dinv,
                            const std::vector<double> &roots, const double *b, double *x, double *tmp,
                            Level::Dist *D = nullptr) {
@@ -772,9 +772,9 @@ static void smooth_inplace(Hierarchy &H, const DCsr &A, const double *dinv,
     const int off = D ? D->row0 : 0, nl = D ? D->nloc : A.nrows;
     double *cur = x, *oth = tmp;
     for (int i = 0; i < deg; ++i) {
-        smooth_step(s, A, dinv, b, cur, oth, 1.0 / roots[i], rows_of(D));
+        const double scale = 1.0 / roots[i];
+        halo_then(H, D, cur, [&](hipStream_t q, RowRange rr) { smooth_step(q, A, dinv, b, cur, oth, scale, rr); });
         std::swap(cur, oth);
-        if (D && i + 1 < deg) halo_exchange(H, *D, cur);
     }
     if (cur != x) vec_copy(s, nl, cur + off, x + off);
 }
@@ -796,7 +796,6 @@ static int pcg_loop(Hierarchy &H, const DCsr &A, const std::function<void(const 
                     int *converged, double *hist, double *sc, Level::Dist *D = nullptr) {
     hipStream_t s = H.stream;
     const int off = D ? D->row0 : 0, n = D ? D->nloc : A.nrows;
-    const RowRange rr = rows_of(D);
     auto pdot = [&](const double *u, const double *v, double *out) {
         dot(s, n, u + off, v + off, H.partials.p, out);
         if (D) dist_allreduce(H, out, 1);
@@ -805,8 +804,7 @@ static int pcg_loop(Hierarchy &H, const DCsr &A, const std::function<void(const 
         vec_zero(s, n, x + off);
         vec_copy(s, n, b + off, r + off);
     } else {
-        if (D) halo_exchange(H, *D, x);
-        spmv_residual(s, A, x, b, r, rr);
+        halo_then(H, D, x, [&](hipStream_t q, RowRange rq) { spmv_residual(q, A, x, b, r, rq); });
     }
     prec(r, z);
     vec_copy(s, n, z + off, d + off);
@@ -820,8 +818,7 @@ static int pcg_loop(Hierarchy &H, const DCsr &A, const std::function<void(const 
         if (converged) *converged = 1;
         return 0;
     }
-    if (D) halo_exchange(H, *D, d);
-    spmv(s, A, d, q, rr);
+    halo_then(H, D, d, [&](hipStream_t st, RowRange rq) { spmv(st, A, d, q, rq); });
     pdot(q, d, sc + 1);
     if (read_scalar(s, sc + 1) == 0.0) return 0;
     int i = 1;
@@ -839,8 +836,7 @@ static int pcg_loop(Hierarchy &H, const DCsr &A, const std::function<void(const 
         }
         if (++i > max_iter) break;
         pcg_update_d(s, n, sc, d + off, z + off);
-        if (D) halo_exchange(H, *D, d);
-        spmv(s, A, d, q, rr);
+        halo_then(H, D, d, [&](hipStream_t st, RowRange rq) { spmv(st, A, d, q, rq); });
         pdot(d, q, sc + 1);
         SA_HIP_CHECK(hipMemcpyAsync(sc + 0, sc + 2, sizeof(double), hipMemcpyDeviceToDevice, s));
     }
@@ -891,7 +887,7 @@ static void vcycle_rec(Hierarchy &H, int level, const double *b, double *x) {
     Level::Dist *D = dist_of(L);
     const bool last = (level + 1 == (int)H.levels.size());
     smooth_from_zero(H, L.A, L.dinv_neg.p, L.roots, b, x, L.t0.p, D);   // pre_smoother, x0 = 0
-    spmv_residual(s, L.A, x, b, L.r.p, rows_of(D));                     // res = b - A x
+    halo_then(H, D, x, [&](hipStream_t q, RowRange rr) { spmv_residual(q, L.A, x, b, L.r.p, rr); });   // res = b - A x
     double *rc = last ? H.c_b.p : H.levels[level + 1]->b.p;
     double *xc = last ? H.c_x.p : H.levels[level + 1]->x.p;
     spmv(s, L.R, L.r.p, rc);                                            // resc = R res
@@ -904,7 +900,6 @@ static void vcycle_rec(Hierarchy &H, int level, const double *b, double *x) {
         if (N.dist.on) dist_allgather_rows(H, N.dist, xc);
     }
     spmv_add(s, L.P, xc, x, rows_of(D));                                // x += P xc
-    if (D) halo_exchange(H, *D, x);
     smooth_inplace(H, L.A, L.dinv_neg.p, L.roots, b, x, L.t0.p, D);     // post_smoother
 }
 
