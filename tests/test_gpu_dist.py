@@ -62,15 +62,15 @@ def _free_port():
     return p
 
 
-def _run(tmp_path, world, min_rows=262144):
+def _run(tmp_path, world, min_rows=262144, extra_env=None, tag=""):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = _free_port()
     procs, outs = [], []
     for rank in range(world):
         env = dict(os.environ, WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0",
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        out = str(tmp_path / ("w%d_r%d.npz" % (world, rank)))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **(extra_env or {}))
+        out = str(tmp_path / ("w%d_r%d%s.npz" % (world, rank, tag)))
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, str(script), out, str(min_rows)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
@@ -106,6 +106,16 @@ def test_row_partitioned_solve_matches_single_rank(tmp_path, world):
     assert sum(int(r["own"][0]) for r in ranks) == n[0]
     for k in ("x", "vc", "sm"):                         # every rank returns the full vectors
         assert np.array_equal(ranks[0][k], ranks[-1][k]), k
+
+
+def test_halo_overlap_does_not_change_the_arithmetic(tmp_path):
+    """Interior rows beside the halo exchange (csrc/dist.hip: halo_then) against exchange-then-apply: the same
+    kernels on the same rows, so every vector must be bit-identical."""
+    on = _run(tmp_path, 2, min_rows=1)
+    off = _run(tmp_path, 2, min_rows=1, extra_env={"SAAMGE_AMD_HALO_OVERLAP": "0"}, tag="_off")
+    for a, b in zip(on, off):
+        for k in ("x", "vc", "sm", "hist", "it"):
+            assert np.array_equal(a[k], b[k]), k
 
 
 RCCL_WORKER = textwrap.dedent("""
