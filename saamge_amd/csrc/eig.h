@@ -61,6 +61,12 @@ struct EigBatch {
     double window_vu = 0.0;
     std::vector<int> h_inertia;
     DBuf<int> inertia;      // device copy (the iteration accepts a matrix when its Ritz count reaches it)
+    // matrices whose only wanted pair is known before any factorisation (certified count 1 and the start vector
+    // D^1/2 1 already an eigenvector to the acceptance tolerance: every agglomerate without essential rows of a
+    // diffusion-type operator): pre[i] = 1, pre_val[2 i] = Rayleigh quotient, pre_val[2 i + 1] = 1 / |x0|
+    std::vector<int> h_pre;
+    DBuf<int> pre;
+    DBuf<double> pre_val;
     void set_window(double vu_) { has_window = true; window_vu = vu_; }
     bool subspace = false, dense_only = false, ss_failed = false;
     std::vector<int> h_n, h_m;

@@ -1446,7 +1446,8 @@ constexpr size_t bc_lds_bytes(int win) {      // window rows x (band + 1) column
 template <int BC_WIN, bool INERTIA = false>
 __global__ __launch_bounds__(BC_NT) void chol_band_lds_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
                                                               double *__restrict__ W, const int *__restrict__ bws,
-                                                              int *__restrict__ info, double shift = 0.0) {
+                                                              int *__restrict__ info, double shift = 0.0,
+                                                              const int *__restrict__ active = nullptr) {
     // the window is kept band-packed: row i holds columns i - BC_MAXBW .. i (only the lower band is ever
     // touched), 53 instead of 69 doubles per row at BC_WIN = 68 -- four workgroups per CU instead of three
     constexpr int BC_MAXBW = BC_WIN - SB, BC_P = BC_MAXBW + 1;
@@ -1458,7 +1459,7 @@ __global__ __launch_bounds__(BC_NT) void chol_band_lds_kernel(const int *__restr
     double (*Li)[SB + 1] = Ld + SB;
     int *bad = (int *)(Li + SB);
     double *sg = (double *)(bad + 2);                    // INERTIA: signs of the current block's pivots
-    const int b = blockIdx.x, n = ns[b], bw = bws[b];
+    const int b = active ? active[blockIdx.x] : (int)blockIdx.x, n = ns[b], bw = bws[b];     // (active: dense list of the matrices to factor)
     if (bw > BC_MAXBW) return;                           // (the host only launches this when every matrix fits)
     double *A = W + moff[b];
     const int tid = threadIdx.x;
@@ -1576,6 +1577,90 @@ __global__ __launch_bounds__(BC_NT) void chol_band_lds_kernel(const int *__restr
     }
     if (INERTIA) { if (tid == 0) info[b] = *bad ? -1 : bad[1]; }
     else if (tid == 0 && *bad) info[b] = 1;
+}
+
+// Is the start vector x0 = D^1/2 1 / |.| already the one wanted eigenvector?  C x0 over the band of the
+// (unshifted, unfactored) matrix, one workgroup per matrix, thread = row: pre[b] = 1 when the certified count
+// is 1, the Rayleigh quotient lies in the window and |C x0 - rq x0| <= tol (the acceptance tolerance of the
+// iteration).  True for every agglomerate without essential rows of a diffusion-type operator (the element
+// matrices have zero row sums): those matrices then need neither the second factorisation nor the solves.
+constexpr int NC_NT = 512;
+__global__ __launch_bounds__(NC_NT) void ss_nullcheck_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
+                                                           const int64_t *__restrict__ voff, const double *__restrict__ W,
+                                                           const double *__restrict__ dis, const short *__restrict__ perm,
+                                                           const int *__restrict__ bws, const int *__restrict__ inertia,
+                                                           double vu, double tol, int *__restrict__ pre,
+                                                           double *__restrict__ pre_val) {
+    extern __shared__ double nc_x[];            // [n] x0 in matrix order
+    __shared__ double red[3][NC_NT / 64];
+    const int b = blockIdx.x, n = ns[b], tid = threadIdx.x;
+    if (inertia[b] != 1) { if (tid == 0) pre[b] = 0; return; }
+    const double *A = W + moff[b];
+    const double *db = dis + voff[b];
+    const short *pm = perm ? perm + voff[b] : nullptr;
+    const int bw = bws ? bws[b] : n - 1;
+    for (int r = tid; r < n; r += NC_NT) nc_x[pm ? pm[r] : r] = 1.0 / db[r];
+    __syncthreads();
+    double xx = 0.0, xy = 0.0, yy = 0.0;
+    for (int i = tid; i < n + 63; i += NC_NT) {     // (whole wavefronts: the column loop below is wavefront-uniform)
+        // the wavefront owns 64 consecutive rows and walks the columns that touch any of them: every load is
+        // one column, 64 consecutive rows (walking each row's own band would put the lanes on a diagonal --
+        // 64 cache lines per load); entries outside the row's band are not part of the matrix (never written)
+        const int ib = i & ~63, jlo = max(0, ib - bw), jhi = min(n - 1, min(n - 1, ib + 63) + bw);
+        const bool live = i < n;
+        const double *ap = A + min(i, n - 1);
+        double y0 = 0.0, y1 = 0.0;
+        int j = jlo;
+        for (; j + 8 <= jhi + 1; j += 8) {          // eight columns in flight per lane
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = (live && abs(i - (j + u)) <= bw) ? __builtin_nontemporal_load(ap + (size_t)(j + u) * n) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                y0 = fma(t[u], nc_x[j + u], y0);
+                y1 = fma(t[u + 1], nc_x[j + u + 1], y1);
+            }
+        }
+        for (; j <= jhi; ++j) y0 = fma((live && abs(i - j) <= bw) ? ap[(size_t)j * n] : 0.0, nc_x[j], y0);
+        if (!live) continue;
+        const double y = y0 + y1;
+        const double x = nc_x[i];
+        xx = fma(x, x, xx);
+        xy = fma(x, y, xy);
+        yy = fma(y, y, yy);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { xx += __shfl_xor(xx, o, 64); xy += __shfl_xor(xy, o, 64); yy += __shfl_xor(yy, o, 64); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = xx; red[1][tid >> 6] = xy; red[2][tid >> 6] = yy; }
+    __syncthreads();
+    if (tid == 0) {
+        xx = xy = yy = 0.0;
+        for (int q = 0; q < NC_NT / 64; ++q) { xx += red[0][q]; xy += red[1][q]; yy += red[2][q]; }
+        const double rq = xy / xx;                                  // Rayleigh quotient of x0
+        const double res2 = fmax(0.0, yy / xx - rq * rq);           // |C x - rq x|^2 for the unit vector x = x0 / |x0|
+        const bool ok = rq <= vu && sqrt(res2) <= tol;
+        pre[b] = ok ? 1 : 0;
+        pre_val[2 * b] = rq;
+        pre_val[2 * b + 1] = 1.0 / sqrt(xx);
+    }
+}
+
+// accepted-before-the-iteration matrices: column 0 of X becomes the unit eigenvector, mu the Ritz value, the
+// state "converged, one pair inside the window, one pair returned"
+__global__ __launch_bounds__(256) void ss_preaccept_kernel(const int *__restrict__ ns, const int64_t *__restrict__ voff,
+                                                           const int *__restrict__ pre, const double *__restrict__ pre_val,
+                                                           const double *__restrict__ sigmas, double *__restrict__ X,
+                                                           double *__restrict__ mu, int *__restrict__ state) {
+    const int b = blockIdx.x;
+    if (!pre[b]) return;
+    const int n = ns[b];
+    double *Xb = X + voff[b] * SB;
+    const double sc = pre_val[2 * b + 1];
+    for (int r = threadIdx.x; r < n; r += 256) Xb[(size_t)r * SS_B] *= sc;
+    if (threadIdx.x == 0) {
+        mu[(size_t)b * SS_B] = pre_val[2 * b] - sigmas[b];
+        state[b] = 1 | (1 << 4) | (1 << 8);
+    }
 }
 
 // Start block: column 0 = D^1/2 1 (the exact null vector of C for an agglomerate without essential
@@ -2278,7 +2363,7 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
             auto go = [&](auto kern, int win) {
                 SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bc_lds_bytes(win)));
                 hipLaunchKernelGGL(kern, dim3(b.count), dim3(BC_NT), bc_lds_bytes(win), s, b.n.p, b.moff.p, b.W.p, bws, neg.p,
-                                   b.window_vu);
+                                   b.window_vu, (const int *)nullptr);
             };
             if (bwmax <= 68 - SB) go(chol_band_lds_kernel<68, true>, 68);
             else if (bwmax <= 80 - SB) go(chol_band_lds_kernel<80, true>, 80);
@@ -2335,12 +2420,40 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
             if (b.h_inertia[i] == 0 && vu > 0.0) sg[i] = vu - std::max(1e-6, 1e-3 * vu);
         b.ss_sigma.from_host(sg, s);
     }
+    // ---- matrices that are finished before they are factored ----
+    // certified count 1 and x0 = D^1/2 1 already an eigenvector to the acceptance tolerance (ss_nullcheck_kernel:
+    // one pass over the band): they skip the second factorisation, the solves and the Rayleigh-Ritz steps, which
+    // then run on a dense list of the others (85 % of the level-0 agglomerates of the 256^3 problem are of this
+    // kind; the iteration accepted them after its first step anyway, at the price of a factorisation and two
+    // solves each).  SAAMGE_AMD_SS_NULLCHECK=0 switches the shortcut off.
+    b.h_pre.clear();
+    DBuf<int> chol_active;
+    int nchol = b.count;
+    static const bool nullcheck = [] { const char *e = std::getenv("SAAMGE_AMD_SS_NULLCHECK"); return !(e && e[0] == '0'); }();
+    if (lds_path && nullcheck && !b.h_inertia.empty()) {
+        profiler().begin(s);
+        b.pre.alloc((size_t)b.count);
+        b.pre_val.alloc(2 * (size_t)b.count);
+        hipLaunchKernelGGL(ss_nullcheck_kernel, dim3(b.count), dim3(NC_NT), sizeof(double) * (size_t)nmax, s, b.n.p, b.moff.p,
+                           b.voff.p, b.W.p, b.dis.p, b.has_perm ? b.perm.p : nullptr, bws, b.inertia.p, b.window_vu, SS_TOL,
+                           b.pre.p, b.pre_val.p);
+        SA_HIP_CHECK(hipGetLastError());
+        profiler().end(s, "eig_ss_nullcheck", cb, 0.0);
+        auto hp = b.pre.to_host(s);
+        b.h_pre.assign(hp.begin(), hp.end());
+        std::vector<int> act;
+        for (int i = 0; i < b.count; ++i) if (!b.h_pre[i]) act.push_back(i);
+        nchol = (int)act.size();
+        if (nchol) chol_active.from_host(act, s);
+    }
     hipLaunchKernelGGL(ss_shift_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, 0.0, b.ss_sigma.p);
     if (lds_path) {
         profiler().begin(s);
         auto go = [&](auto kern, int win) {
+            if (!nchol) return;
             SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bc_lds_bytes(win)));
-            hipLaunchKernelGGL(kern, dim3(b.count), dim3(BC_NT), bc_lds_bytes(win), s, b.n.p, b.moff.p, b.W.p, bws, info.p, 0.0);
+            hipLaunchKernelGGL(kern, dim3(nchol), dim3(BC_NT), bc_lds_bytes(win), s, b.n.p, b.moff.p, b.W.p, bws, info.p, 0.0,
+                               b.h_pre.empty() ? (const int *)nullptr : chol_active.p);
         };
         if (bwmax <= 68 - SB) go(chol_band_lds_kernel<68, false>, 68);
         else if (bwmax <= 80 - SB) go(chol_band_lds_kernel<80, false>, 80);
@@ -2379,12 +2492,24 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     // would exit at once, but the survivors (agglomerates on the domain boundary: every 64th id, runs of 64)
     // would then sit on a few CUs -- block ids map to XCDs and CUs round-robin -- and a launch with 6 % of
     // the matrices active took as long as a full one.
-    std::vector<int> h_active((size_t)b.count);
-    for (int i = 0; i < b.count; ++i) h_active[i] = i;
-    DBuf<int> active;
-    active.from_host(h_active, s);
-    int nact = b.count;
+    std::vector<int> h_active;
+    h_active.reserve((size_t)b.count);
+    for (int i = 0; i < b.count; ++i)
+        if (b.h_pre.empty() || !b.h_pre[i]) h_active.push_back(i);
+    if (!b.h_pre.empty())       // finished before the factorisation (eig_subspace_factor): unit vector, Ritz value, state
+        hipLaunchKernelGGL(ss_preaccept_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, b.pre.p, b.pre_val.p,
+                           b.ss_sigma.p, X, mu, state.p);
+    DBuf<int> active((size_t)b.count);
+    int nact = (int)h_active.size();
+    if (nact) SA_HIP_CHECK(hipMemcpyAsync(active.p, h_active.data(), sizeof(int) * (size_t)nact, hipMemcpyHostToDevice, s));
+    SA_HIP_CHECK(hipStreamSynchronize(s));
     for (int iter = 0; iter < SS_MAX_ITER && !done; ++iter) {
+        if (nact == 0) {                 // every matrix was finished before the factorisation
+            auto t = state.to_host(s);
+            hstate.assign(t.begin(), t.end());
+            done = true;
+            break;
+        }
         if (prof) profiler().begin(s);
         const size_t xl_bytes = sizeof(double) * (size_t)b.max_n * XLP + 64;
         if (b.max_n <= 1280) {
