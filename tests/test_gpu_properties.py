@@ -165,10 +165,11 @@ def test_one_stage_and_two_stage_eigensolvers_agree():
     # the few-eigenpairs path (Cholesky + shift-invert subspace iteration) on every agglomerate size
     # (STRICT: giving up on a batch is an error instead of the silent dense fallback), with its variants:
     # band kept in LDS (default), banded factorisation through HBM, full Cholesky, first-encounter row order,
-    # global-dof order without the box renumbering
+    # global-dof order without the box renumbering, without the known-null-vector shortcut
     ss = {"SAAMGE_AMD_EIG": "subspace", "SAAMGE_AMD_SS_MIN_N": "0", "SAAMGE_AMD_SS_STRICT": "1"}
     variants += [ss, dict(ss, SAAMGE_AMD_SS_BAND_LDS="0"), dict(ss, SAAMGE_AMD_SS_BAND="0"),
-                 dict(ss, SAAMGE_AMD_SS_PERM="0"), dict(ss, SAAMGE_AMD_SS_BOX="0")]
+                 dict(ss, SAAMGE_AMD_SS_PERM="0"), dict(ss, SAAMGE_AMD_SS_BOX="0"),
+                 dict(ss, SAAMGE_AMD_SS_NULLCHECK="0")]
     for extra in variants:
         env = dict(os.environ, **extra)
         o = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
