@@ -486,7 +486,7 @@ int saamge_amd_lower_eigens_batched(int count, const int *n, const double *A, co
                        b.voff.p, b.W.p, dD.p, b.dis.p);
     eig_tridiagonalize(s, b);
     eig_count(s, b, vl, vu);
-    if (b.ss_failed) {     // few-eigenpairs path gave up: the dense path on a fresh copy
+    if (b.ss_failed || b.nbad) {     // few-eigenpairs path gave up (on the batch or on some matrices): the dense path on a fresh copy
         b.dense_only = true;
         b.subspace = b.ss_failed = false;
         SA_HIP_CHECK(hipMemcpyAsync(b.W.p, A, 8 * (size_t)b.h_moff[count], hipMemcpyDefault, s));

@@ -69,6 +69,12 @@ struct EigBatch {
     DBuf<double> pre_val;
     void set_window(double vu_) { has_window = true; window_vu = vu_; }
     bool subspace = false, dense_only = false, ss_failed = false;
+    // few-eigenpairs path, per matrix: h_bad[i] = 1 -- this matrix has to be redone by the dense path (more wanted
+    // pairs than the block holds, no certificate, a non-positive pivot, no or hopeless convergence, a count that
+    // contradicts the inertia).  The others are finished; h_m[i] = 0 for the bad ones.  With more than a tenth of
+    // the batch bad the whole batch fails instead (ss_failed).
+    std::vector<char> h_bad;
+    int nbad = 0;
     std::vector<int> h_n, h_m;
     std::vector<int64_t> h_moff, h_voff;
 };

@@ -2398,13 +2398,24 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
         }
     }
 
-    // a matrix with more wanted pairs than the block holds, or without a certificate, sends the batch to the dense
-    // path: known here, before the second factorisation and the iterations are spent on it
-    for (int v : b.h_inertia)
-        if (v > SS_B - 2 || v < 0) {
+    // a matrix with more wanted pairs than the block holds, or without a certificate, goes to the dense path:
+    // known here, before the second factorisation and the iterations are spent on it.  It goes ALONE (h_bad) as
+    // long as such matrices are few: one uncertifiable agglomerate must not send the other 14 000 of its chunk
+    // through the dense path.
+    b.h_bad.assign((size_t)b.count, 0);
+    b.nbad = 0;
+    auto mark_bad = [&](int i) { if (!b.h_bad[(size_t)i]) { b.h_bad[(size_t)i] = 1; ++b.nbad; } };
+    auto too_many_bad = [&]() { return (long)b.nbad * 10 > (long)b.count; };
+    for (size_t i = 0; i < b.h_inertia.size(); ++i)
+        if (b.h_inertia[i] > SS_B - 2 || b.h_inertia[i] < 0) {
             SA_REQUIRE(!std::getenv("SAAMGE_AMD_SS_STRICT"), "few-eigenpairs path: a matrix has more wanted pairs than the block holds, or no certificate (strict mode)");
-            return false;
+            mark_bad((int)i);
         }
+    if (const char *fb = std::getenv("SAAMGE_AMD_SS_FORCE_BAD")) {      // tests: every fb-th matrix takes the per-matrix fallback
+        const int every = std::atoi(fb);
+        for (int i = 3; every > 0 && i < b.count; i += every) mark_bad(i);
+    }
+    if (too_many_bad()) return false;
     if (!b.h_inertia.empty()) b.inertia.from_host(b.h_inertia, s);
     // ---- C - sigma I = L L^T ----
     // The iteration converges like (lambda_i - sigma) / (lambda_9 - sigma), so the shift belongs just below the
@@ -2429,6 +2440,7 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
     b.h_pre.clear();
     DBuf<int> chol_active;
     int nchol = b.count;
+    bool use_chol_list = false;
     static const bool nullcheck = [] { const char *e = std::getenv("SAAMGE_AMD_SS_NULLCHECK"); return !(e && e[0] == '0'); }();
     if (lds_path && nullcheck && !b.h_inertia.empty()) {
         profiler().begin(s);
@@ -2441,10 +2453,14 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
         profiler().end(s, "eig_ss_nullcheck", cb, 0.0);
         auto hp = b.pre.to_host(s);
         b.h_pre.assign(hp.begin(), hp.end());
+    }
+    if (lds_path && (!b.h_pre.empty() || b.nbad)) {       // the matrices the second factorisation still has to do
         std::vector<int> act;
-        for (int i = 0; i < b.count; ++i) if (!b.h_pre[i]) act.push_back(i);
+        for (int i = 0; i < b.count; ++i)
+            if (!(b.h_pre.empty() ? 0 : b.h_pre[i]) && !b.h_bad[i]) act.push_back(i);
         nchol = (int)act.size();
         if (nchol) chol_active.from_host(act, s);
+        use_chol_list = true;
     }
     hipLaunchKernelGGL(ss_shift_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, 0.0, b.ss_sigma.p);
     if (lds_path) {
@@ -2453,29 +2469,38 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
             if (!nchol) return;
             SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bc_lds_bytes(win)));
             hipLaunchKernelGGL(kern, dim3(nchol), dim3(BC_NT), bc_lds_bytes(win), s, b.n.p, b.moff.p, b.W.p, bws, info.p, 0.0,
-                               b.h_pre.empty() ? (const int *)nullptr : chol_active.p);
+                               use_chol_list ? chol_active.p : (const int *)nullptr);
         };
         if (bwmax <= 68 - SB) go(chol_band_lds_kernel<68, false>, 68);
         else if (bwmax <= 80 - SB) go(chol_band_lds_kernel<80, false>, 80);
         else go(chol_band_lds_kernel<128, false>, 128);
         SA_HIP_CHECK(hipGetLastError());
         profiler().end(s, "eig_ss_chol_lds", 3.0 * cb, 0.0);
-        auto h = info.to_host(s);
-        for (int v : h) if (v) return false;
-        return true;
+    } else {
+        if (!prof) profiler().begin(s);
+        factor_generic(false, nullptr);
+        if (!prof) profiler().end(s, "eig_ss_cholesky", 0.0, 0.0);
     }
-    if (!prof) profiler().begin(s);
-    factor_generic(false, nullptr);
-    if (!prof) profiler().end(s, "eig_ss_cholesky", 0.0, 0.0);
     auto h = info.to_host(s);
-    for (int v : h) if (v) return false;
-    return true;
+    for (int i = 0; i < b.count; ++i)
+        if (h[i] && !b.h_bad[i]) {         // a non-positive pivot: that matrix alone
+            SA_REQUIRE(!std::getenv("SAAMGE_AMD_SS_STRICT"), "few-eigenpairs path: non-positive pivot (strict mode)");
+            mark_bad(i);
+        }
+    return !too_many_bad();
 }
 
 // Subspace iteration; fills b.h_m / b.m.  Returns false when some matrix needs the dense path.
 bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     DBuf<int> state((size_t)b.count);
-    state.zero(s);
+    if (b.h_bad.size() != (size_t)b.count) { b.h_bad.assign((size_t)b.count, 0); b.nbad = 0; }
+    {       // matrices already given to the dense path start as "failed": no kernel touches them
+        std::vector<int> st0((size_t)b.count, 0);
+        for (int i = 0; i < b.count; ++i) if (b.h_bad[i]) st0[i] = 2;
+        state.from_host(st0, s);
+    }
+    auto mark_bad = [&](int i) { if (!b.h_bad[(size_t)i]) { b.h_bad[(size_t)i] = 1; ++b.nbad; } };
+    auto too_many_bad = [&]() { return (long)b.nbad * 10 > (long)b.count; };
     double *X = b.Xbuf.p, *Z = b.Vpk2.p, *mu = b.d.p;     // d: rows >= SS_B per matrix is checked by the caller
     DBuf<double> mubuf((size_t)b.count * SS_B);
     mu = mubuf.p;
@@ -2495,7 +2520,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     std::vector<int> h_active;
     h_active.reserve((size_t)b.count);
     for (int i = 0; i < b.count; ++i)
-        if (b.h_pre.empty() || !b.h_pre[i]) h_active.push_back(i);
+        if ((b.h_pre.empty() || !b.h_pre[i]) && !b.h_bad[i]) h_active.push_back(i);
     if (!b.h_pre.empty())       // finished before the factorisation (eig_subspace_factor): unit vector, Ritz value, state
         hipLaunchKernelGGL(ss_preaccept_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, b.pre.p, b.pre_val.p,
                            b.ss_sigma.p, X, mu, state.p);
@@ -2568,11 +2593,16 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
             hstate.assign(t.begin(), t.end());
             done = true;
             int nconv = 0;
-            for (int v : hstate) {
-                if (v & 2) failed = true;
+            for (int i = 0; i < b.count; ++i) {
+                const int v = hstate[i];
+                if ((v & 2) && !b.h_bad[i]) {     // gave up during the iteration (too many pairs, breakdown, hopeless rate)
+                    SA_REQUIRE(!std::getenv("SAAMGE_AMD_SS_STRICT"), "few-eigenpairs path gave up on a matrix (strict mode)");
+                    mark_bad(i);
+                }
                 if (!(v & 3)) done = false;
                 else ++nconv;
             }
+            if (too_many_bad()) failed = true;
             static const bool dbg = std::getenv("SAAMGE_AMD_SS_DEBUG") != nullptr;
             if (dbg) std::fprintf(stderr, "subspace: iteration %d, %d of %d matrices accepted (n max %d)\n", iter, nconv, b.count, b.max_n);
             if (failed) break;
@@ -2585,7 +2615,13 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     }
     SA_HIP_CHECK(hipGetLastError());
     if (!prof) profiler().end(s, "eig_ss_iterate", 0.0, 0.0);
-    if (failed || !done) {
+    if (!failed && !done) {      // out of iterations: the unfinished matrices go to the dense path
+        SA_REQUIRE(!std::getenv("SAAMGE_AMD_SS_STRICT"), "few-eigenpairs path: no convergence (strict mode)");
+        { auto t = state.to_host(s); hstate.assign(t.begin(), t.end()); }
+        for (int i = 0; i < b.count; ++i) if (!(hstate[i] & 3)) mark_bad(i);
+        if (too_many_bad()) failed = true;
+    }
+    if (failed) {
         // (SAAMGE_AMD_SS_STRICT: the tests of this path must not pass on the dense fallback)
         SA_REQUIRE(!std::getenv("SAAMGE_AMD_SS_STRICT"), "few-eigenpairs path gave up on a batch (strict mode)");
         return false;
@@ -2595,9 +2631,10 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     if (!b.h_inertia.empty()) {
         int bad = 0, unsure = 0;
         for (int i = 0; i < b.count; ++i) {
+            if (b.h_bad[i]) continue;
             const int k = (hstate[i] >> 4) & 15;
-            if (b.h_inertia[i] < 0) ++unsure;
-            else if (b.h_inertia[i] != k) ++bad;
+            if (b.h_inertia[i] < 0) { ++unsure; mark_bad(i); }
+            else if (b.h_inertia[i] != k) { ++bad; mark_bad(i); }
         }
         static const bool dbg = std::getenv("SAAMGE_AMD_SS_DEBUG") != nullptr;
         if (dbg || bad || unsure)
@@ -2605,11 +2642,11 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
                          b.count, bad, unsure);
         if (bad || unsure) {
             SA_REQUIRE(!std::getenv("SAAMGE_AMD_SS_STRICT"), "few-eigenpairs path: count not certified (strict mode)");
-            return false;
+            if (too_many_bad()) return false;
         }
     }
     b.h_m.assign((size_t)b.count, 1);
-    for (int i = 0; i < b.count; ++i) b.h_m[i] = hstate[i] >> 8;
+    for (int i = 0; i < b.count; ++i) b.h_m[i] = b.h_bad[i] ? 0 : hstate[i] >> 8;
     b.m.from_host(b.h_m, s);
     b.ss_mu = std::move(mubuf);
     return true;

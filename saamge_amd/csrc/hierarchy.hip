@@ -316,6 +316,83 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         c.d_xoff.from_host(c.xoff, qb);
         eig_vectors(qb, batch, c.d_eoff.p, c.d_xoff.p, c.evals.p, c.evecs.p);
         SA_HIP_CHECK(hipStreamSynchronize(qb));
+        if (!(batch.subspace && batch.nbad > 0)) return;
+        // ---- the few-eigenpairs path finished all but a few matrices of the chunk (h_bad): those are redone by
+        // the dense path, as contiguous runs of agglomerates (runs closer than three apart are joined), in the
+        // workspace the chunk has just left; then the chunk's packed results are put together ----
+        std::vector<char> bad(batch.h_bad.begin(), batch.h_bad.end());
+        for (int i = 0; i < cnt; ++i)
+            if (bad[i])
+                for (int j = i + 1; j < std::min(cnt, i + 4); ++j)
+                    if (bad[j]) { for (int q = i + 1; q < j; ++q) bad[q] = 1; break; }
+        std::vector<int> m_all(batch.h_m.begin(), batch.h_m.end());
+        struct Redo { int a, b; DBuf<double> evals, evecs; std::vector<int64_t> eoff, xoff; };
+        std::vector<Redo> redo;
+        for (int a = 0; a < cnt;) {
+            if (!bad[a]) { ++a; continue; }
+            int e = a;
+            while (e < cnt && bad[e]) ++e;
+            redo.emplace_back();
+            Redo &r = redo.back();
+            r.a = a;
+            r.b = e;
+            EigBatch sub;
+            eig_batch_alloc(sub, std::vector<int>(sizes.begin() + ae0 + a, sizes.begin() + ae0 + e), qb, slot);
+            sub.dense_only = true;
+            sub.set_window(L.theta);
+            int64_t rows_before = 0;
+            for (int i = 0; i < a; ++i) rows_before += sizes[ae0 + i];
+            const RowsSpan span{(int64_t)L.rel.AE_to_dof.I[ae0 + a], (int64_t)L.rel.AE_to_dof.I[nparts]};
+            ae_build(qb, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0 + a, sub, true,
+                     P.keep_debug ? L.ae_D.p + pend_row0[slot] + rows_before : nullptr, keep_rows ? &span : nullptr);
+            eig_tridiagonalize(qb, sub, 3);
+            eig_count(qb, sub, -1.0, L.theta);
+            r.eoff.assign((size_t)(e - a) + 1, 0);
+            r.xoff.assign((size_t)(e - a) + 1, 0);
+            for (int i = a; i < e; ++i) {
+                m_all[i] = sub.h_m[i - a];
+                r.eoff[i - a + 1] = r.eoff[i - a] + sub.h_m[i - a];
+                r.xoff[i - a + 1] = r.xoff[i - a] + (int64_t)sub.h_m[i - a] * sizes[ae0 + i];
+            }
+            r.evals.alloc((size_t)r.eoff.back() + 1);
+            r.evecs.alloc((size_t)r.xoff.back() + 1);
+            DBuf<int64_t> de, dx;
+            de.from_host(r.eoff, qb);
+            dx.from_host(r.xoff, qb);
+            eig_vectors(qb, sub, de.p, dx.p, r.evals.p, r.evecs.p);
+            SA_HIP_CHECK(hipStreamSynchronize(qb));
+            a = e;
+        }
+        // packed results of the whole chunk: stretches of finished matrices from the first pass, the runs from `redo`
+        std::vector<int64_t> eoff((size_t)cnt + 1, 0), xoff((size_t)cnt + 1, 0);
+        for (int i = 0; i < cnt; ++i) {
+            L.ae_m[ae0 + i] = m_all[i];
+            eoff[i + 1] = eoff[i] + m_all[i];
+            xoff[i + 1] = xoff[i] + (int64_t)m_all[i] * sizes[ae0 + i];
+        }
+        DBuf<double> evals((size_t)eoff[cnt]), evecs((size_t)xoff[cnt]);
+        auto copy = [&](double *dst, const double *src, int64_t n_) {
+            if (n_ > 0) SA_HIP_CHECK(hipMemcpyAsync(dst, src, 8 * (size_t)n_, hipMemcpyDeviceToDevice, qb));
+        };
+        size_t ri = 0;
+        for (int i = 0; i < cnt;) {
+            if (ri < redo.size() && redo[ri].a == i) {
+                const Redo &r = redo[ri++];
+                copy(evals.p + eoff[i], r.evals.p, r.eoff.back());
+                copy(evecs.p + xoff[i], r.evecs.p, r.xoff.back());
+                i = r.b;
+            } else {
+                const int e = ri < redo.size() ? redo[ri].a : cnt;       // finished matrices i .. e - 1: contiguous in both
+                copy(evals.p + eoff[i], c.evals.p + c.eoff[i], c.eoff[e] - c.eoff[i]);
+                copy(evecs.p + xoff[i], c.evecs.p + c.xoff[i], c.xoff[e] - c.xoff[i]);
+                i = e;
+            }
+        }
+        SA_HIP_CHECK(hipStreamSynchronize(qb));
+        c.evals = std::move(evals);
+        c.evecs = std::move(evecs);
+        c.eoff = eoff;
+        c.xoff = xoff;
     };
     int prev = -1, idx = 0;
     for (int ae0 = ae_lo; ae0 < ae_hi; ++idx) {

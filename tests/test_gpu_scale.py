@@ -81,6 +81,23 @@ def test_scale_golden(name, eigensolver):
     _check(g, out, "%s/%s" % (name, eigensolver))
 
 
+def test_scale_golden_with_single_matrices_on_the_dense_path():
+    """A few matrices of a chunk leave the few-eigenpairs path (no certificate, a non-positive pivot, no
+    convergence ...): they alone are redone by the dense path and the chunk's results are put together again
+    (csrc/hierarchy.hip, post()).  SAAMGE_AMD_SS_FORCE_BAD marks every 50th agglomerate: 10 of the 512 level-0
+    agglomerates go alone (in runs of one; with 1 GiB chunks also across chunk boundaries), the one marked
+    agglomerate of the 8 on level 1 exceeds the 10 % limit and takes the whole level with it."""
+    import os
+    os.environ["SAAMGE_AMD_SS_FORCE_BAD"] = "50"
+    try:
+        g, out = _run("scale_64x64x32_skew", "subspace")
+        _check(g, out, "scale_64x64x32_skew/subspace/forced-bad")
+        g, out = _run("scale_96x96x64", "subspace", workspace_bytes=1 << 30)
+        _check(g, out, "scale_96x96x64/subspace/forced-bad/1GiB-chunks")
+    finally:
+        del os.environ["SAAMGE_AMD_SS_FORCE_BAD"]
+
+
 def test_scale_golden_chunked():
     """The same answers when the level-0 agglomerates go through several workspace chunks."""
     g, out = _run("scale_96x96x64", "subspace", workspace_bytes=1 << 30)
