@@ -75,6 +75,12 @@ struct EigBatch {
     // the batch bad the whole batch fails instead (ss_failed).
     std::vector<char> h_bad;
     int nbad = 0;
+    // wide-band matrices: the band of every matrix as saved before the in-place inertia factorisation (arena
+    // buffer + offsets): a matrix whose convergence rate is hopeless at its first shift is restored from it and
+    // factored again at a shift just below its smallest Ritz value (eig_subspace_iterate)
+    double *ss_save = nullptr;
+    DBuf<int64_t> ss_soff;
+    std::vector<double> h_sigma;
     std::vector<int> h_n, h_m;
     std::vector<int64_t> h_moff, h_voff;
 };

@@ -1967,7 +1967,8 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
                                                     double *__restrict__ mu, int *__restrict__ state, int iter,
                                                     const double *__restrict__ sigmas, double vu, const int *__restrict__ inertia,
                                                     double *__restrict__ dbg = nullptr,
-        const int *__restrict__ active = nullptr, double *__restrict__ hist = nullptr, int max_iter = 80) {
+        const int *__restrict__ active = nullptr, double *__restrict__ hist = nullptr, int max_iter = 80,
+        const int *__restrict__ reshift_ok = nullptr) {
     __shared__ double part[4][2 * SS_B + 1][SS_B];  // [wavefront][M rows | G rows | residual][column j]
     __shared__ double Ms[SS_B][SS_B], Gs[SS_B][SS_B], Cs[SS_B][SS_B], res2[SS_B], mus[SS_B], mu_old[SS_B];
     const int b = active ? active[blockIdx.x] : (int)blockIdx.x, n = ns[b];     // (active: the matrices still iterating)
@@ -2051,9 +2052,13 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
                 for (int q = 0; q < max(k, 1); ++q) worst = fmax(worst, 2.5 * mu_old[q] * sqrt(res2[q]));
                 const double old = hist[(size_t)b * 4 + (iter & 3)];
                 hist[(size_t)b * 4 + (iter & 3)] = worst;
-                if (iter >= 12 && worst > SS_TOL && old > 0.0) {
+                if (iter >= 6 && worst > SS_TOL && old > 0.0) {
                     const double r4 = worst / old;                        // decay over four iterations
-                    if (!(r4 < 1.0) || 4.0 * log(SS_TOL / worst) / log(r4) > (double)(max_iter - iter)) st |= 2;
+                    const double need = (r4 < 1.0) ? 4.0 * log(SS_TOL / worst) / log(r4) : 1e30;
+                    // state bit 2: the host may move the shift to just below the smallest Ritz value and factor again
+                    // (certified count 0: the wanted pair is the smallest one; once per matrix)
+                    if (reshift_ok && reshift_ok[b] && cert == 0 && need > 10.0) st |= 4;
+                    else if (iter >= 12 && need > (double)(max_iter - iter)) st |= 2;
                 }
             }
             if (k > SS_B - 2 || cert > SS_B - 2 || cert == -1) st |= 2;
@@ -2236,6 +2241,16 @@ __global__ __launch_bounds__(256) void ss_output_kernel(const int *__restrict__ 
     }
 }
 
+// after a matrix has been factored again at a new shift: its Ritz values are kept as lambda - sigma
+__global__ void ss_reshift_mu_kernel(int nreq, const int *__restrict__ req, const double *__restrict__ delta,
+                                     double *__restrict__ mu, double *__restrict__ hist) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nreq * SS_B) return;
+    const int b = req[t / SS_B], q = t % SS_B;
+    mu[(size_t)b * SS_B + q] += delta[t / SS_B];
+    if (q < 4) hist[(size_t)b * 4 + q] = 0.0;
+}
+
 bool eig_ss_band_enabled() {
     static const bool v = [] { const char *e = std::getenv("SAAMGE_AMD_SS_BAND"); return !(e && e[0] == '0'); }();
     return v;
@@ -2243,6 +2258,71 @@ bool eig_ss_band_enabled() {
 
 // C - sigma I = L L^T for every matrix of the batch (in place, L below / L^T above the diagonal).
 // Returns false when a pivot was not positive.
+// Blocked right-looking factorisation of every matrix in place, two panels per pass over the trailing
+// matrix: panel k, its update of the next SB columns only, panel k + 1, then A22(2 SB:, 2 SB:) -=
+// L_k L_k^T + L_{k+1} L_{k+1}^T in one read + write of the lower tiles.  sgn: C - theta I = L S L^T
+// (inertia count; the factor is not kept), neg receives the negative pivots.
+static void ss_factor_generic(hipStream_t s, EigBatch &b, bool sgn, int *neg, int *info_p, const int *bws, int bwmax) {
+    const int nmax = b.max_n;
+    const int cnt8 = 8 * div_up(b.count, 8);
+    const bool prof = profiler().enabled;
+    struct { int *p; } info{info_p};
+    (void)cnt8;
+    const int *gbw = bws ? bws : (sgn ? b.bw.p : nullptr);
+    auto panel = [&](int k0, double *Vout, double *Zout, int rext, double *Sout) {
+        if (prof) profiler().begin(s);
+        const bool big = std::min(nmax, bwmax + 2 * SB) > 768;
+        if (sgn) {
+            if (big) hipLaunchKernelGGL((chol_panel_kernel<1024, true>), dim3(b.count), dim3(1024), 0, s, k0, b.n.p, b.moff.p,
+                                        b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, Sout, neg);
+            else hipLaunchKernelGGL((chol_panel_kernel<256, true>), dim3(b.count), dim3(256), 0, s, k0, b.n.p, b.moff.p,
+                                    b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, Sout, neg);
+        } else {
+            if (big) hipLaunchKernelGGL((chol_panel_kernel<1024, false>), dim3(b.count), dim3(1024), 0, s, k0, b.n.p, b.moff.p,
+                                        b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, (double *)nullptr, (int *)nullptr);
+            else hipLaunchKernelGGL((chol_panel_kernel<256, false>), dim3(b.count), dim3(256), 0, s, k0, b.n.p, b.moff.p,
+                                    b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, (double *)nullptr, (int *)nullptr);
+        }
+        if (prof) profiler().end(s, sgn ? "eig_ss_inertia_panel" : "eig_ss_panel", 0.0, 0.0);
+    };
+    const double *vrow = sgn ? b.Xbuf.p : nullptr, *zrow = sgn ? b.Tfac.p : nullptr;
+    for (int k0 = 0; k0 < nmax; k0 += 2 * SB) {
+        panel(k0, b.Vpk.p, b.Zbuf.p, SB, b.Xbuf.p);
+        const int np1f = nmax - k0 - SB;         // order of the trailing matrix after panel k
+        if (np1f < 1) break;
+        const int np1 = std::min(np1f, bwmax);   // ... of its part inside the band
+        if (np1 >= 1) {
+            if (prof) profiler().begin(s);
+            hipLaunchKernelGGL(sbr_panel_update_kernel, dim3(cnt8 * div_up(np1, 256)), dim3(256), 0, s, k0, b.n.p, b.moff.p,
+                               b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.count, div_up(np1, 256), 1, gbw);
+            if (prof) profiler().end(s, sgn ? "eig_ss_inertia_panel" : "eig_ss_panel", 0.0, 0.0);
+        }
+        panel(k0 + SB, b.Vpk2.p, nullptr, 0, b.Tfac.p);
+        const int np = std::min(np1f - SB, bwmax);    // ... after panel k + 1
+        if (np >= 1) {
+            double ub = 0.0;
+            if (prof) {      // lower tiles of the trailing matrices (inside the band), read and written once
+                for (size_t i = 0; i < b.h_n.size(); ++i) {
+                    double q = (double)b.h_n[i] - k0 - 2 * SB;
+                    if (!b.h_bw.empty()) q = std::min(q, (double)b.h_bw[i]);
+                    if (q >= 1.0) ub += 8.0 * q * q;
+                }
+                profiler().begin(s);
+            }
+            if (np > 192)
+                hipLaunchKernelGGL((sbr_fused_kernel<false, 2, 3>), dim3(cnt8 * div_up(np, 2 * SF_ROWS)), dim3(S2_NT), 0, s, k0,
+                                   b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Vpk2.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
+                                   b.Gbuf.p, b.trash.p, b.count, div_up(np, 2 * SF_ROWS), SB, gbw, vrow, zrow);
+            else
+                hipLaunchKernelGGL((sbr_fused_kernel<false, 1, 3>), dim3(cnt8 * div_up(np, SF_ROWS)), dim3(S2_NT), 0, s, k0,
+                                   b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Vpk2.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
+                                   b.Gbuf.p, b.trash.p, b.count, div_up(np, SF_ROWS), SB, gbw, vrow, zrow);
+            if (prof) profiler().end(s, sgn ? "eig_ss_inertia_update" : (np > 192 ? "eig_ss_update" : "eig_ss_update1"), ub, 0.0);
+        }
+    }
+    SA_HIP_CHECK(hipGetLastError());
+}
+
 bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
     const int nmax = b.max_n;
     b.h_xpoff.clear();
@@ -2288,73 +2368,14 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
     double cb = 0.0;      // the band read once, the factor written to both triangles
     if (lds_path)
         for (size_t i = 0; i < b.h_n.size(); ++i) cb += 8.0 * (double)b.h_n[i] * (std::min(b.h_bw[i], b.h_n[i] - 1) + 1);
-    const int cnt8 = 8 * div_up(b.count, 8);
     const bool prof = profiler().enabled;
-    // Blocked right-looking factorisation of every matrix in place, two panels per pass over the trailing
-    // matrix: panel k, its update of the next SB columns only, panel k + 1, then A22(2 SB:, 2 SB:) -=
-    // L_k L_k^T + L_{k+1} L_{k+1}^T in one read + write of the lower tiles.  sgn: C - theta I = L S L^T
-    // (inertia count; the factor is not kept), neg receives the negative pivots.
-    auto factor_generic = [&](bool sgn, int *neg) {
-        const int *gbw = bws ? bws : (sgn ? b.bw.p : nullptr);
-        auto panel = [&](int k0, double *Vout, double *Zout, int rext, double *Sout) {
-            if (prof) profiler().begin(s);
-            const bool big = std::min(nmax, bwmax + 2 * SB) > 768;
-            if (sgn) {
-                if (big) hipLaunchKernelGGL((chol_panel_kernel<1024, true>), dim3(b.count), dim3(1024), 0, s, k0, b.n.p, b.moff.p,
-                                            b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, Sout, neg);
-                else hipLaunchKernelGGL((chol_panel_kernel<256, true>), dim3(b.count), dim3(256), 0, s, k0, b.n.p, b.moff.p,
-                                        b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, Sout, neg);
-            } else {
-                if (big) hipLaunchKernelGGL((chol_panel_kernel<1024, false>), dim3(b.count), dim3(1024), 0, s, k0, b.n.p, b.moff.p,
-                                            b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, (double *)nullptr, (int *)nullptr);
-                else hipLaunchKernelGGL((chol_panel_kernel<256, false>), dim3(b.count), dim3(256), 0, s, k0, b.n.p, b.moff.p,
-                                        b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, (double *)nullptr, (int *)nullptr);
-            }
-            if (prof) profiler().end(s, sgn ? "eig_ss_inertia_panel" : "eig_ss_panel", 0.0, 0.0);
-        };
-        const double *vrow = sgn ? b.Xbuf.p : nullptr, *zrow = sgn ? b.Tfac.p : nullptr;
-        for (int k0 = 0; k0 < nmax; k0 += 2 * SB) {
-            panel(k0, b.Vpk.p, b.Zbuf.p, SB, b.Xbuf.p);
-            const int np1f = nmax - k0 - SB;         // order of the trailing matrix after panel k
-            if (np1f < 1) break;
-            const int np1 = std::min(np1f, bwmax);   // ... of its part inside the band
-            if (np1 >= 1) {
-                if (prof) profiler().begin(s);
-                hipLaunchKernelGGL(sbr_panel_update_kernel, dim3(cnt8 * div_up(np1, 256)), dim3(256), 0, s, k0, b.n.p, b.moff.p,
-                                   b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.count, div_up(np1, 256), 1, gbw);
-                if (prof) profiler().end(s, sgn ? "eig_ss_inertia_panel" : "eig_ss_panel", 0.0, 0.0);
-            }
-            panel(k0 + SB, b.Vpk2.p, nullptr, 0, b.Tfac.p);
-            const int np = std::min(np1f - SB, bwmax);    // ... after panel k + 1
-            if (np >= 1) {
-                double ub = 0.0;
-                if (prof) {      // lower tiles of the trailing matrices (inside the band), read and written once
-                    for (size_t i = 0; i < b.h_n.size(); ++i) {
-                        double q = (double)b.h_n[i] - k0 - 2 * SB;
-                        if (!b.h_bw.empty()) q = std::min(q, (double)b.h_bw[i]);
-                        if (q >= 1.0) ub += 8.0 * q * q;
-                    }
-                    profiler().begin(s);
-                }
-                if (np > 192)
-                    hipLaunchKernelGGL((sbr_fused_kernel<false, 2, 3>), dim3(cnt8 * div_up(np, 2 * SF_ROWS)), dim3(S2_NT), 0, s, k0,
-                                       b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Vpk2.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
-                                       b.Gbuf.p, b.trash.p, b.count, div_up(np, 2 * SF_ROWS), SB, gbw, vrow, zrow);
-                else
-                    hipLaunchKernelGGL((sbr_fused_kernel<false, 1, 3>), dim3(cnt8 * div_up(np, SF_ROWS)), dim3(S2_NT), 0, s, k0,
-                                       b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Vpk2.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
-                                       b.Gbuf.p, b.trash.p, b.count, div_up(np, SF_ROWS), SB, gbw, vrow, zrow);
-                if (prof) profiler().end(s, sgn ? "eig_ss_inertia_update" : (np > 192 ? "eig_ss_update" : "eig_ss_update1"), ub, 0.0);
-            }
-        }
-        SA_HIP_CHECK(hipGetLastError());
-    };
-
+    auto factor_generic = [&](bool sgn, int *neg) { ss_factor_generic(s, b, sgn, neg, info.p, bws, bwmax); };
     // ---- certified count: inertia of C - vu I, before the matrices are shifted and overwritten ----
     // (dsygvx counts by bisection, amg/src/xpacks.cpp:226-268; a subspace iteration alone cannot prove
     // that no eigenvalue below vu is missing from its block)
     static const bool certify = [] { const char *e = std::getenv("SAAMGE_AMD_SS_CERTIFY"); return !(e && e[0] == '0'); }();
     b.h_inertia.clear();
+    b.ss_save = nullptr;
     if (certify) {
         DBuf<int> neg((size_t)b.count);
         neg.zero(s);
@@ -2383,12 +2404,14 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
             DBuf<int64_t> d_soff;
             d_soff.from_host(soff, s);
             double *save = eig_arena_bandsave(b, (size_t)soff[b.count] + 1);
+            b.ss_save = save;
             const int ny = std::max(1, std::min(64, 8192 / std::max(1, b.count)));
             hipLaunchKernelGGL(band_copy_kernel<false>, dim3(b.count, ny), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, b.bw.p, d_soff.p, save);
             hipLaunchKernelGGL(ss_shift_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, b.window_vu);
             factor_generic(true, neg.p);
             hipLaunchKernelGGL(band_copy_kernel<true>, dim3(b.count, ny), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, b.bw.p, d_soff.p, save);
             SA_HIP_CHECK(hipGetLastError());
+            b.ss_soff = std::move(d_soff);
             if (!prof) profiler().end(s, "eig_ss_inertia", 0.0, 0.0);
             auto h = neg.to_host(s);
             auto hi = info.to_host(s);
@@ -2430,6 +2453,7 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
         for (int i = 0; i < b.count && !b.h_inertia.empty(); ++i)
             if (b.h_inertia[i] == 0 && vu > 0.0) sg[i] = vu - std::max(1e-6, 1e-3 * vu);
         b.ss_sigma.from_host(sg, s);
+        b.h_sigma = sg;
     }
     // ---- matrices that are finished before they are factored ----
     // certified count 1 and x0 = D^1/2 1 already an eigenvector to the acceptance tolerance (ss_nullcheck_kernel:
@@ -2506,6 +2530,14 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     mu = mubuf.p;
     DBuf<double> slow_hist((size_t)b.count * 4);       // bound of the slowest wanted pair, last four iterations
     slow_hist.zero(s);
+    // wide-band matrices with a saved band: a matrix (certified count 0) that converges too slowly may ask once
+    // for a new shift (state bit 2, ss_rr_kernel); the host then restores the bands, shifts that matrix to just
+    // below its smallest Ritz value and factors the batch again (SAAMGE_AMD_SS_RESHIFT=0: never)
+    static const bool reshift_env = [] { const char *e = std::getenv("SAAMGE_AMD_SS_RESHIFT"); return !(e && e[0] == '0'); }();
+    const bool reshift_on = reshift_env && b.max_n > 1280 && b.ss_save && !b.h_inertia.empty() && b.h_sigma.size() == (size_t)b.count;
+    DBuf<int> reshift_ok;
+    std::vector<int> h_reshift_ok((size_t)b.count, 1);
+    if (reshift_on) reshift_ok.from_host(h_reshift_ok, s);
     const bool prof = profiler().enabled;
     const int *bws = b.h_bw.empty() ? nullptr : b.bw.p;
     if (!prof) profiler().begin(s);
@@ -2571,7 +2603,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         if (dbg_on) dbgbuf.alloc((size_t)b.count * 2 * SS_B);
         hipLaunchKernelGGL(ss_rr_kernel, dim3(nact), dim3(256), 0, s, b.n.p, b.voff.p, X, Z, mu, state.p, iter,
                            b.ss_sigma.p, vu, b.h_inertia.empty() ? (const int *)nullptr : b.inertia.p, dbgbuf.p, active.p,
-                           slow_hist.p, SS_MAX_ITER);
+                           slow_hist.p, SS_MAX_ITER, reshift_on ? reshift_ok.p : (const int *)nullptr);
         if (dbg_on && iter > 0) {
             auto hd = dbgbuf.to_host(s);
             const int show = std::min(b.count, 3);
@@ -2603,6 +2635,55 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
                 else ++nconv;
             }
             if (too_many_bad()) failed = true;
+            if (reshift_on && !failed) {
+                std::vector<int> req;
+                for (int i = 0; i < b.count; ++i)
+                    if ((hstate[i] & 4) && !(hstate[i] & 3) && h_reshift_ok[i]) req.push_back(i);
+                if (!req.empty()) {
+                    auto hmu = mubuf.to_host(s);
+                    std::vector<double> delta(req.size());
+                    for (size_t t = 0; t < req.size(); ++t) {
+                        const int i = req[t];
+                        const double gap = hmu[(size_t)i * SS_B];              // smallest Ritz value - sigma (> 0)
+                        const double snew = b.h_sigma[i] + 0.98 * gap;         // 2 % of the old distance below it
+                        delta[t] = b.h_sigma[i] - snew;
+                        b.h_sigma[i] = snew;
+                        h_reshift_ok[i] = 0;
+                    }
+                    b.ss_sigma.from_host(b.h_sigma, s);
+                    reshift_ok.from_host(h_reshift_ok, s);
+                    const int ny = std::max(1, std::min(64, 8192 / std::max(1, b.count)));
+                    hipLaunchKernelGGL(band_copy_kernel<true>, dim3(b.count, ny), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, b.bw.p,
+                                       b.ss_soff.p, b.ss_save);
+                    hipLaunchKernelGGL(ss_shift_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, 0.0, b.ss_sigma.p);
+                    DBuf<int> info2((size_t)b.count);
+                    info2.zero(s);
+                    ss_factor_generic(s, b, false, nullptr, info2.p, bws, b.ss_bwmax);
+                    auto hi2 = info2.to_host(s);
+                    std::vector<int> st_fix;
+                    for (int i = 0; i < b.count; ++i)
+                        if (hi2[i] && !(hstate[i] & 1) && !b.h_bad[i]) {     // the new shift was not below the spectrum after all
+                            mark_bad(i);
+                            hstate[i] |= 2;
+                            st_fix.push_back(i);
+                        }
+                    for (int i : st_fix) {
+                        const int two = 2;
+                        SA_HIP_CHECK(hipMemcpyAsync(state.p + i, &two, sizeof(int), hipMemcpyHostToDevice, s));
+                    }
+                    DBuf<int> d_req;
+                    DBuf<double> d_delta;
+                    d_req.from_host(req, s);
+                    d_delta.from_host(delta, s);
+                    hipLaunchKernelGGL(ss_reshift_mu_kernel, dim3(div_up((long)req.size() * SS_B, 256)), dim3(256), 0, s, (int)req.size(),
+                                       d_req.p, d_delta.p, mu, slow_hist.p);
+                    SA_HIP_CHECK(hipGetLastError());
+                    SA_HIP_CHECK(hipStreamSynchronize(s));
+                    if (std::getenv("SAAMGE_AMD_SS_DEBUG"))
+                        std::fprintf(stderr, "subspace: iteration %d, %zu matrices factored again at a shift below their smallest Ritz value\n", iter, req.size());
+                    if (too_many_bad()) failed = true;
+                }
+            }
             static const bool dbg = std::getenv("SAAMGE_AMD_SS_DEBUG") != nullptr;
             if (dbg) std::fprintf(stderr, "subspace: iteration %d, %d of %d matrices accepted (n max %d)\n", iter, nconv, b.count, b.max_n);
             if (failed) break;
