@@ -114,3 +114,38 @@ def test_planted_eigenvalue_orthogonal_to_start_block():
                         capture_output=True, text=True, timeout=300)
     print("uncertified run:", o2.stdout.strip(), o2.stderr.strip()[-300:])
     assert o2.returncode == 0
+
+
+_RESHIFT = r"""
+import sys, numpy as np, scipy.linalg as sla
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+from saamge_amd import capi
+from test_gpu_inertia import _banded_spsd, _snd_D
+rng = np.random.default_rng(11)
+mats, diags = [], []
+for n in (1400, 1500):
+    A = _banded_spsd(n, 150, rng) + 100.0 * np.eye(n)    # every eigenvalue far above the window, the lowest ones close together
+    mats.append(A); diags.append(_snd_D(A))
+res = capi.lower_eigens_batched(mats, diags, -1.0, 1e-4)
+for A, D, (w, X) in zip(mats, diags, res):
+    wr = sla.eigh(A, np.diag(D), eigvals_only=True, subset_by_index=[0, 1])
+    assert len(w) == 1, len(w)
+    assert abs(w[0] - wr[0]) <= 1e-11, (w[0], wr[0])
+    R = A @ X - (D[:, None] * X) * w[None, :]
+    assert np.abs(R).max() <= 1e-10, np.abs(R).max()
+    assert abs(float(X[:, 0] @ (D * X[:, 0])) - 1.0) <= 1e-10
+print("OK")
+"""
+
+
+def test_slow_wide_band_matrix_is_factored_again_at_a_better_shift():
+    """Wide-band matrices (in-place factorisation through HBM) without an eigenvalue in the window and with their
+    lowest eigenvalues close together: at the first shift (just below the window) the smallest pair converges like
+    0.8^k; the iteration asks for a shift just below the smallest Ritz value, the batch is factored again and
+    finishes on the few-eigenpairs path (STRICT: the dense fallback is an error) with LAPACK's smallest pair."""
+    code = _RESHIFT % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, SAAMGE_AMD_SS_STRICT="1", SAAMGE_AMD_SS_DEBUG="1")
+    o = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert o.returncode == 0 and "OK" in o.stdout, o.stdout[-2000:] + o.stderr[-3000:]
+    assert "factored again" in o.stderr, o.stderr[-3000:]
