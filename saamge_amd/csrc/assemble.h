@@ -19,8 +19,10 @@ struct DevElmats {
 // Dense AE matrices for the AEs [ae0, ae0+count) into batch.W (column-major, ld = n_i).
 //   fine level  (A != null): agg_build_AE_stiffm_with_global, amg/src/aggregates.cpp:855-945
 //   coarse level (A == null): agg_build_AE_stiffm (plain sum), amg/src/aggregates.cpp:959-1086
+// `banded` (few large agglomerates in permuted order, coarse levels): the half bandwidths come from the topology
+// (batch.bw, has_bw) and only the band the eigensolver reads is cleared
 void ae_assemble(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevElmats &el,
-                 int ae0, EigBatch &batch);
+                 int ae0, EigBatch &batch, bool banded = false);
 
 // D_ii = sum_j |a_ij| sqrt(a_ii/a_jj)  (amg/src/mbox.cpp:913-949);  batch.dis = D^-1/2 and
 // W <- D^-1/2 W D^-1/2 in place.  Dout (optional, packed like batch.d) receives D.

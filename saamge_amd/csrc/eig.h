@@ -67,6 +67,11 @@ struct EigBatch {
     std::vector<int> h_pre;
     DBuf<int> pre;
     DBuf<double> pre_val;
+    // coarse levels: the level's representation of the constant vector (R ... R 1) on the rows of the batch, in
+    // agglomerate order -- D^1/2 of it is the first start vector of the few-eigenpairs iteration (instead of
+    // D^1/2 1) and the candidate of the known-null-vector shortcut
+    DBuf<double> x0c;
+    bool has_x0c = false;
     void set_window(double vu_) { has_window = true; window_vu = vu_; }
     bool subspace = false, dense_only = false, ss_failed = false;
     // few-eigenpairs path, per matrix: h_bad[i] = 1 -- this matrix has to be redone by the dense path (more wanted

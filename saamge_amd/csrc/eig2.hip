@@ -529,10 +529,12 @@ __global__ __launch_bounds__(256) void sbr_panel_update_kernel(int k0, const int
                                                                const double *__restrict__ Vpk,
                                                                const double *__restrict__ Zbuf, int count,
                                                                int tiles, int min_np = 2,
-                                                               const int *__restrict__ bws = nullptr) {
+                                                               const int *__restrict__ bws = nullptr,
+                                                               const int *__restrict__ skip = nullptr) {
     int b, blk;
     xcd_decode(tiles, b, blk);
     if (b >= count) return;
+    if (skip && skip[b]) return;
     const int n = ns[b];
     const int np = n - k0 - SB;
     if (np < min_np) return;       // (band reduction: a trailing matrix of order 1 has no reflector; Cholesky: 1)
@@ -583,7 +585,8 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
                                                           int tiles, int shift,
                                                           const int *__restrict__ bws = nullptr,
                                                           const double *__restrict__ VrowCur = nullptr,
-                                                          const double *__restrict__ ZrowBuf = nullptr) {
+                                                          const double *__restrict__ ZrowBuf = nullptr,
+                                                          const int *__restrict__ skip = nullptr) {
     // (VrowCur / ZrowBuf, TERMS = 3 only: the ROW operands come from these panels instead of Vcur / Zbuf --
     // the signed factorisation C - theta I = L S L^T updates with (L S) L^T)
     constexpr int SBP = SB + 1;
@@ -593,6 +596,7 @@ __global__ __launch_bounds__(S2_NT) void sbr_fused_kernel(int k0, const int *__r
     int b, blk;
     xcd_decode(tiles, b, blk);
     if (b >= count) return;
+    if (skip && skip[b]) return;
     const int n = ns[b];
     if (n - k0 - SB < 2) return;               // this matrix has no panel k0
     // shift = SB: look-ahead pipeline, the first SB columns / rows were handled by
@@ -1333,10 +1337,16 @@ __global__ __launch_bounds__(NT) void chol_panel_kernel(int k0, const int *__res
                                                          double *__restrict__ Vpk, double *__restrict__ Zbuf,
                                                          int *__restrict__ info, const int *__restrict__ bws,
                                                          int rext, double *__restrict__ Sout = nullptr,
-                                                         int *__restrict__ neg = nullptr) {
+                                                         int *__restrict__ neg = nullptr, int keep = 0,
+                                                         const int *__restrict__ skip = nullptr) {
+    // keep (SIGNED): the factor IS written back (L below, L^T above the diagonal, inverted diagonal blocks), as
+    // the unsigned walk does -- where every pivot turns out positive, L S L^T is the Cholesky factorisation
+    // of C - theta I and the few-eigenpairs path iterates with it instead of factoring again.
+    // skip: matrices this launch leaves alone (second factorisation of a batch whose other members kept theirs)
     __shared__ double Ld[SB][SB + 1];
     const int b = blockIdx.x, n = ns[b];
     if (k0 >= n) return;
+    if (skip && skip[b]) return;
     // rows below the band are zero and stay zero; `rext` more rows are still written (as zeros) to the
     // packed panel for the two-panel update that reads them
     const int rend = bws ? min(n, k0 + SB + bws[b] + rext) : n;
@@ -1363,6 +1373,8 @@ __global__ __launch_bounds__(NT) void chol_panel_kernel(int k0, const int *__res
         if (tid == 0) { if (bad < 0) info[b] = 1; else neg[b] += bad; }
     } else {
         if (tid == 0 && bad) info[b] = 1;
+    }
+    if (!SIGNED || keep) {
         if (tid < SB * SB) {
             const int i = tid >> 4, j = tid & 15;
             if (i < nb && j <= i) {
@@ -1392,6 +1404,10 @@ __global__ __launch_bounds__(NT) void chol_panel_kernel(int k0, const int *__res
                 Vp[pr + c] = t;
                 if (Zp) Zp[pr + c] = 0.5 * ts;
                 if (Sp) Sp[pr + c] = ts;
+                if (keep) {
+                    A[(size_t)(k0 + c) * n + r] = t;
+                    A[(size_t)r * n + (k0 + c)] = t;
+                }
             } else {
                 A[(size_t)(k0 + c) * n + r] = t;
                 A[(size_t)r * n + (k0 + c)] = t;
@@ -1408,8 +1424,11 @@ __global__ __launch_bounds__(NT) void chol_panel_kernel(int k0, const int *__res
 template <bool RESTORE>
 __global__ __launch_bounds__(256) void band_copy_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
                                                         double *__restrict__ W, const int *__restrict__ bws,
-                                                        const int64_t *__restrict__ soff, double *__restrict__ save) {
-    const int b = blockIdx.x, n = ns[b], bw = bws[b], w2 = 2 * bw + 1;
+                                                        const int64_t *__restrict__ soff, double *__restrict__ save,
+                                                        const int *__restrict__ skip = nullptr) {
+    if (skip && skip[blockIdx.x]) return;
+    // (at least the diagonal blocks: a kept factor carries the dense inverses of its SB x SB diagonal blocks)
+    const int b = blockIdx.x, n = ns[b], bw = min(max(bws[b], SB - 1), n - 1), w2 = 2 * bw + 1;
     double *A = W + moff[b];
     double *S = save + soff[b];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1590,7 +1609,8 @@ __global__ __launch_bounds__(NC_NT) void ss_nullcheck_kernel(const int *__restri
                                                            const double *__restrict__ dis, const short *__restrict__ perm,
                                                            const int *__restrict__ bws, const int *__restrict__ inertia,
                                                            double vu, double tol, int *__restrict__ pre,
-                                                           double *__restrict__ pre_val) {
+                                                           double *__restrict__ pre_val,
+                                                           const double *__restrict__ x0c = nullptr) {
     extern __shared__ double nc_x[];            // [n] x0 in matrix order
     __shared__ double red[3][NC_NT / 64];
     const int b = blockIdx.x, n = ns[b], tid = threadIdx.x;
@@ -1599,7 +1619,7 @@ __global__ __launch_bounds__(NC_NT) void ss_nullcheck_kernel(const int *__restri
     const double *db = dis + voff[b];
     const short *pm = perm ? perm + voff[b] : nullptr;
     const int bw = bws ? bws[b] : n - 1;
-    for (int r = tid; r < n; r += NC_NT) nc_x[pm ? pm[r] : r] = 1.0 / db[r];
+    for (int r = tid; r < n; r += NC_NT) nc_x[pm ? pm[r] : r] = (x0c ? x0c[voff[b] + r] : 1.0) / db[r];
     __syncthreads();
     double xx = 0.0, xy = 0.0, yy = 0.0;
     for (int i = tid; i < n + 63; i += NC_NT) {     // (whole wavefronts: the column loop below is wavefront-uniform)
@@ -1668,14 +1688,16 @@ __global__ __launch_bounds__(256) void ss_preaccept_kernel(const int *__restrict
 // dependence on the batch: the same vectors on any rank / chunking.
 __global__ __launch_bounds__(256) void ss_init_kernel(const int *__restrict__ ns, const int64_t *__restrict__ voff,
                                                       const double *__restrict__ dis, const short *__restrict__ perm,
-                                                      double *__restrict__ X) {
+                                                      double *__restrict__ X, const double *__restrict__ x0c = nullptr) {
+    // x0c (coarse levels): the level's representation of the constant vector, R ... R 1, in agglomerate order --
+    // column 0 is then D^1/2 of it: the null vector of an agglomerate whose fine agglomerates all carry theirs
     const int b = blockIdx.x, n = ns[b];
     double *Xb = X + voff[b] * SB;
     const double *db = dis + voff[b];
     const short *pm = perm ? perm + voff[b] : nullptr;
     for (int idx = threadIdx.x; idx < n * SS_B; idx += 256) {
         const int r = idx >> 3, pr = pm ? pm[r] : r;       // (dis is in agglomerate order, the matrix in perm order)
-        Xb[pr * SS_B + (idx & 7)] = ((idx & 7) == 0) ? 1.0 / db[r] : unit_rand_ss((unsigned)(pr * SS_B + (idx & 7)), (unsigned)n);
+        Xb[pr * SS_B + (idx & 7)] = ((idx & 7) == 0) ? (x0c ? x0c[voff[b] + r] : 1.0) / db[r] : unit_rand_ss((unsigned)(pr * SS_B + (idx & 7)), (unsigned)n);
     }
 }
 
@@ -2262,7 +2284,8 @@ bool eig_ss_band_enabled() {
 // matrix: panel k, its update of the next SB columns only, panel k + 1, then A22(2 SB:, 2 SB:) -=
 // L_k L_k^T + L_{k+1} L_{k+1}^T in one read + write of the lower tiles.  sgn: C - theta I = L S L^T
 // (inertia count; the factor is not kept), neg receives the negative pivots.
-static void ss_factor_generic(hipStream_t s, EigBatch &b, bool sgn, int *neg, int *info_p, const int *bws, int bwmax) {
+static void ss_factor_generic(hipStream_t s, EigBatch &b, bool sgn, int *neg, int *info_p, const int *bws, int bwmax,
+                              int keep = 0, const int *skip = nullptr) {
     const int nmax = b.max_n;
     const int cnt8 = 8 * div_up(b.count, 8);
     const bool prof = profiler().enabled;
@@ -2271,17 +2294,18 @@ static void ss_factor_generic(hipStream_t s, EigBatch &b, bool sgn, int *neg, in
     const int *gbw = bws ? bws : (sgn ? b.bw.p : nullptr);
     auto panel = [&](int k0, double *Vout, double *Zout, int rext, double *Sout) {
         if (prof) profiler().begin(s);
-        const bool big = std::min(nmax, bwmax + 2 * SB) > 768;
+        static const int big_thr = [] { const char *e = std::getenv("SAAMGE_AMD_SS_PANEL_BIG"); return e ? std::atoi(e) : 768; }();
+        const bool big = std::min(nmax, bwmax + 2 * SB) > big_thr;
         if (sgn) {
             if (big) hipLaunchKernelGGL((chol_panel_kernel<1024, true>), dim3(b.count), dim3(1024), 0, s, k0, b.n.p, b.moff.p,
-                                        b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, Sout, neg);
+                                        b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, Sout, neg, keep, skip);
             else hipLaunchKernelGGL((chol_panel_kernel<256, true>), dim3(b.count), dim3(256), 0, s, k0, b.n.p, b.moff.p,
-                                    b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, Sout, neg);
+                                    b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, Sout, neg, keep, skip);
         } else {
             if (big) hipLaunchKernelGGL((chol_panel_kernel<1024, false>), dim3(b.count), dim3(1024), 0, s, k0, b.n.p, b.moff.p,
-                                        b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, (double *)nullptr, (int *)nullptr);
+                                        b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, (double *)nullptr, (int *)nullptr, 0, skip);
             else hipLaunchKernelGGL((chol_panel_kernel<256, false>), dim3(b.count), dim3(256), 0, s, k0, b.n.p, b.moff.p,
-                                    b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, (double *)nullptr, (int *)nullptr);
+                                    b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, (double *)nullptr, (int *)nullptr, 0, skip);
         }
         if (prof) profiler().end(s, sgn ? "eig_ss_inertia_panel" : "eig_ss_panel", 0.0, 0.0);
     };
@@ -2294,7 +2318,7 @@ static void ss_factor_generic(hipStream_t s, EigBatch &b, bool sgn, int *neg, in
         if (np1 >= 1) {
             if (prof) profiler().begin(s);
             hipLaunchKernelGGL(sbr_panel_update_kernel, dim3(cnt8 * div_up(np1, 256)), dim3(256), 0, s, k0, b.n.p, b.moff.p,
-                               b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.count, div_up(np1, 256), 1, gbw);
+                               b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.count, div_up(np1, 256), 1, gbw, skip);
             if (prof) profiler().end(s, sgn ? "eig_ss_inertia_panel" : "eig_ss_panel", 0.0, 0.0);
         }
         panel(k0 + SB, b.Vpk2.p, nullptr, 0, b.Tfac.p);
@@ -2312,11 +2336,11 @@ static void ss_factor_generic(hipStream_t s, EigBatch &b, bool sgn, int *neg, in
             if (np > 192)
                 hipLaunchKernelGGL((sbr_fused_kernel<false, 2, 3>), dim3(cnt8 * div_up(np, 2 * SF_ROWS)), dim3(S2_NT), 0, s, k0,
                                    b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Vpk2.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
-                                   b.Gbuf.p, b.trash.p, b.count, div_up(np, 2 * SF_ROWS), SB, gbw, vrow, zrow);
+                                   b.Gbuf.p, b.trash.p, b.count, div_up(np, 2 * SF_ROWS), SB, gbw, vrow, zrow, skip);
             else
                 hipLaunchKernelGGL((sbr_fused_kernel<false, 1, 3>), dim3(cnt8 * div_up(np, SF_ROWS)), dim3(S2_NT), 0, s, k0,
                                    b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Vpk2.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
-                                   b.Gbuf.p, b.trash.p, b.count, div_up(np, SF_ROWS), SB, gbw, vrow, zrow);
+                                   b.Gbuf.p, b.trash.p, b.count, div_up(np, SF_ROWS), SB, gbw, vrow, zrow, skip);
             if (prof) profiler().end(s, sgn ? "eig_ss_inertia_update" : (np > 192 ? "eig_ss_update" : "eig_ss_update1"), ub, 0.0);
         }
     }
@@ -2376,6 +2400,12 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
     static const bool certify = [] { const char *e = std::getenv("SAAMGE_AMD_SS_CERTIFY"); return !(e && e[0] == '0'); }();
     b.h_inertia.clear();
     b.ss_save = nullptr;
+    // Wide-band matrices (coarse levels): a certified count of 0 means that the inertia pass met positive pivots
+    // only, i.e. it WAS the Cholesky factorisation of C - vu I -- and vu is the best shift such a matrix can get
+    // (its one wanted pair is the smallest).  Those matrices keep that factor: no restore, no second factorisation
+    // (SAAMGE_AMD_SS_REUSE=0: factor twice as before).
+    static const bool reuse = [] { const char *e = std::getenv("SAAMGE_AMD_SS_REUSE"); return !(e && e[0] == '0'); }();
+    bool generic_inertia = false;
     if (certify) {
         DBuf<int> neg((size_t)b.count);
         neg.zero(s);
@@ -2398,7 +2428,7 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
             if (!prof) profiler().begin(s);
             std::vector<int64_t> soff((size_t)b.count + 1, 0);
             for (int i = 0; i < b.count; ++i) {
-                const int64_t w = std::min(b.h_bw.empty() ? b.h_n[i] - 1 : b.h_bw[i], b.h_n[i] - 1);
+                const int64_t w = std::min(std::max(b.h_bw.empty() ? b.h_n[i] - 1 : b.h_bw[i], SB - 1), b.h_n[i] - 1);
                 soff[(size_t)i + 1] = soff[i] + (int64_t)b.h_n[i] * (2 * w + 1);
             }
             DBuf<int64_t> d_soff;
@@ -2408,8 +2438,12 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
             const int ny = std::max(1, std::min(64, 8192 / std::max(1, b.count)));
             hipLaunchKernelGGL(band_copy_kernel<false>, dim3(b.count, ny), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, b.bw.p, d_soff.p, save);
             hipLaunchKernelGGL(ss_shift_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, b.window_vu);
-            factor_generic(true, neg.p);
-            hipLaunchKernelGGL(band_copy_kernel<true>, dim3(b.count, ny), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, b.bw.p, d_soff.p, save);
+            // (reuse: the factor is written back; the bands are restored further down, once the counts say which
+            // matrices keep it)
+            ss_factor_generic(s, b, true, neg.p, info.p, bws, bwmax, reuse ? 1 : 0);
+            if (!reuse)
+                hipLaunchKernelGGL(band_copy_kernel<true>, dim3(b.count, ny), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, b.bw.p, d_soff.p, save);
+            generic_inertia = true;
             SA_HIP_CHECK(hipGetLastError());
             b.ss_soff = std::move(d_soff);
             if (!prof) profiler().end(s, "eig_ss_inertia", 0.0, 0.0);
@@ -2446,14 +2480,28 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
     // sigma < 0 in general; but a certified count of 0 says that every eigenvalue lies above vu, and the one
     // pair the "at least one" rule then asks for is the smallest: those matrices are shifted to just below vu
     // (agglomerates on an essential boundary, most agglomerates of a coarse level: 17 -> 9 iterations).
+    std::vector<int> h_keep((size_t)b.count, 0);
+    int nkeep = 0;
     {
         const double vu = b.window_vu;
         const double neg = -std::min(1e-3, std::max(1e-7, std::fabs(vu) / 30.0));
         std::vector<double> sg((size_t)b.count, b.h_inertia.empty() ? SS_SIGMA : neg);
         for (int i = 0; i < b.count && !b.h_inertia.empty(); ++i)
-            if (b.h_inertia[i] == 0 && vu > 0.0) sg[i] = vu - std::max(1e-6, 1e-3 * vu);
+            if (b.h_inertia[i] == 0 && vu > 0.0) {
+                sg[i] = vu - std::max(1e-6, 1e-3 * vu);
+                if (generic_inertia && reuse && !b.h_bad[i]) { sg[i] = vu; h_keep[(size_t)i] = 1; ++nkeep; }
+            }
         b.ss_sigma.from_host(sg, s);
         b.h_sigma = sg;
+    }
+    DBuf<int> d_skip;
+    if (generic_inertia && reuse) {       // the bands of the matrices that do not keep the inertia pass's factor
+        d_skip.from_host(h_keep, s);
+        const int ny = std::max(1, std::min(64, 8192 / std::max(1, b.count)));
+        if (nkeep < b.count)
+            hipLaunchKernelGGL(band_copy_kernel<true>, dim3(b.count, ny), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, b.bw.p,
+                               b.ss_soff.p, b.ss_save, d_skip.p);
+        SA_HIP_CHECK(hipGetLastError());
     }
     // ---- matrices that are finished before they are factored ----
     // certified count 1 and x0 = D^1/2 1 already an eigenvector to the acceptance tolerance (ss_nullcheck_kernel:
@@ -2466,13 +2514,14 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
     int nchol = b.count;
     bool use_chol_list = false;
     static const bool nullcheck = [] { const char *e = std::getenv("SAAMGE_AMD_SS_NULLCHECK"); return !(e && e[0] == '0'); }();
-    if (lds_path && nullcheck && !b.h_inertia.empty()) {
+    const bool generic_reuse = generic_inertia && reuse;
+    if ((lds_path || generic_reuse) && nullcheck && !b.h_inertia.empty()) {
         profiler().begin(s);
         b.pre.alloc((size_t)b.count);
         b.pre_val.alloc(2 * (size_t)b.count);
         hipLaunchKernelGGL(ss_nullcheck_kernel, dim3(b.count), dim3(NC_NT), sizeof(double) * (size_t)nmax, s, b.n.p, b.moff.p,
                            b.voff.p, b.W.p, b.dis.p, b.has_perm ? b.perm.p : nullptr, bws, b.inertia.p, b.window_vu, SS_TOL,
-                           b.pre.p, b.pre_val.p);
+                           b.pre.p, b.pre_val.p, b.has_x0c ? b.x0c.p : (const double *)nullptr);
         SA_HIP_CHECK(hipGetLastError());
         profiler().end(s, "eig_ss_nullcheck", cb, 0.0);
         auto hp = b.pre.to_host(s);
@@ -2486,6 +2535,26 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
         if (nchol) chol_active.from_host(act, s);
         use_chol_list = true;
     }
+    int nfactor = b.count;      // generic path: matrices the second factorisation still has to do
+    if (generic_reuse) {
+        std::vector<double> shifts(b.h_sigma);
+        nfactor = 0;
+        for (int i = 0; i < b.count; ++i) {
+            if (!b.h_pre.empty() && b.h_pre[i]) h_keep[(size_t)i] = 1;
+            if (b.h_bad[i]) h_keep[(size_t)i] = 1;
+            if (h_keep[(size_t)i]) shifts[(size_t)i] = 0.0; else ++nfactor;
+        }
+        d_skip.from_host(h_keep, s);
+        if (nfactor) {
+            DBuf<double> d_shifts;
+            d_shifts.from_host(shifts, s);
+            hipLaunchKernelGGL(ss_shift_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, 0.0, d_shifts.p);
+            SA_HIP_CHECK(hipStreamSynchronize(s));     // (d_shifts leaves scope)
+        }
+        if (std::getenv("SAAMGE_AMD_SS_DEBUG"))
+            std::fprintf(stderr, "subspace: %d of %d wide-band matrices keep the factor of the inertia pass, %d are factored again\n",
+                         nkeep, b.count, nfactor);
+    } else
     hipLaunchKernelGGL(ss_shift_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, 0.0, b.ss_sigma.p);
     if (lds_path) {
         profiler().begin(s);
@@ -2502,12 +2571,16 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
         profiler().end(s, "eig_ss_chol_lds", 3.0 * cb, 0.0);
     } else {
         if (!prof) profiler().begin(s);
-        factor_generic(false, nullptr);
+        if (!generic_reuse) factor_generic(false, nullptr);
+        else if (nfactor) ss_factor_generic(s, b, false, nullptr, info.p, bws, bwmax, 0, d_skip.p);
         if (!prof) profiler().end(s, "eig_ss_cholesky", 0.0, 0.0);
     }
     auto h = info.to_host(s);
     for (int i = 0; i < b.count; ++i)
         if (h[i] && !b.h_bad[i]) {         // a non-positive pivot: that matrix alone
+            if (std::getenv("SAAMGE_AMD_SS_DEBUG"))
+                std::fprintf(stderr, "subspace: non-positive pivot in matrix %d (n %d, band %d, inertia %d, sigma %g)\n", i, b.h_n[i],
+                             b.h_bw.empty() ? -1 : b.h_bw[i], b.h_inertia.empty() ? -2 : b.h_inertia[i], b.h_sigma[i]);
             SA_REQUIRE(!std::getenv("SAAMGE_AMD_SS_STRICT"), "few-eigenpairs path: non-positive pivot (strict mode)");
             mark_bad(i);
         }
@@ -2542,7 +2615,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     const int *bws = b.h_bw.empty() ? nullptr : b.bw.p;
     if (!prof) profiler().begin(s);
     hipLaunchKernelGGL(ss_init_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, b.dis.p,
-                       b.has_perm ? b.perm.p : nullptr, X);
+                       b.has_perm ? b.perm.p : nullptr, X, b.has_x0c ? b.x0c.p : (const double *)nullptr);
     bool done = false, failed = false;
     std::vector<int> hstate;
     // Only the matrices that are still iterating are launched, through a dense index list: accepted ones

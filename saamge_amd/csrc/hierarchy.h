@@ -91,6 +91,9 @@ struct Level {                  // tg_data_t + interp_data_t + agg_partitioning_
     // solve-phase work vectors
     DBuf<double> x, b, r, t0, t1;
     DBuf<double> extra;                 // level 0: device copy / view of Params::extra_modes
+    // R (R ... 1): the NEXT level's representation of the constant vector -- first start vector of that level's
+    // few-eigenpairs iteration and the candidate of its known-null-vector shortcut (eig.h: EigBatch::x0c)
+    DBuf<double> cvec_next;
     // row-partitioned solve: own rows [row_off[rank], row_off[rank+1]) (multiples of 64), halo
     // exchange lists of A's input vector (global indices, grouped by peer rank)
     struct Dist {

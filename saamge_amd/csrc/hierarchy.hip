@@ -76,6 +76,10 @@ __global__ void iota64_kernel(long n, int64_t scale, int64_t *p) {
     if (i < n) p[i] = i * scale;
 }
 
+__global__ void gather_kernel(long n, const int *__restrict__ idx, const double *__restrict__ src, double *__restrict__ dst) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
 __global__ void fill_kernel(long n, double *p, double v) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
@@ -410,6 +414,13 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         eig_batch_alloc(batch, std::vector<int>(sizes.begin() + ae0, sizes.begin() + ae0 + cnt), qa, slot);
         batch.dense_only = P.eigensolver == 1;
         batch.set_window(L.theta);
+        if (lev > 0 && H.levels[lev - 1]->cvec_next.n == (size_t)L.A.nrows) {
+            const size_t rows = (size_t)batch.h_voff[cnt];
+            batch.x0c.alloc(rows);
+            hipLaunchKernelGGL(gather_kernel, dim3(div_up((long)rows, 256)), dim3(256), 0, qa, (long)rows,
+                               L.drel.ae2d_J.p + L.rel.AE_to_dof.I[ae0], H.levels[lev - 1]->cvec_next.p, batch.x0c.p);
+            batch.has_x0c = true;
+        }
         const RowsSpan span{(int64_t)L.rel.AE_to_dof.I[ae0], (int64_t)L.rel.AE_to_dof.I[nparts]};
         ae_build(qa, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch, true,
                  P.keep_debug ? L.ae_D.p + row0 : nullptr, keep_rows ? &span : nullptr);
@@ -545,6 +556,19 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     L.d_mis_coloff.from_host(L.mis_coloff, s);
     build_P_R(s, L.drel, rel, L.mis_k, L.mis_u_off, L.d_mis_k.p, L.d_mis_coloff.p, L.d_mis_u_off.p,
               L.mis_U.p, L.P, L.R);
+    if (lev + 1 < P.num_coarsenings) {     // the next level's representation of the constant vector (P^T P = I)
+        L.cvec_next.alloc((size_t)L.R.nrows);
+        const double *cv = nullptr;
+        DBuf<double> ones;
+        if (lev > 0 && H.levels[lev - 1]->cvec_next.n == (size_t)L.A.nrows) cv = H.levels[lev - 1]->cvec_next.p;
+        else {
+            ones.alloc((size_t)L.A.nrows);
+            hipLaunchKernelGGL(fill_kernel, dim3(div_up((long)L.A.nrows, 256)), dim3(256), 0, s, (long)L.A.nrows, ones.p, 1.0);
+            cv = ones.p;
+        }
+        spmv(s, L.R, cv, L.cvec_next.p);
+        SA_HIP_CHECK(hipStreamSynchronize(s));
+    }
     // the host half of the next level's inputs runs beside the Galerkin product (own thread, own
     // stream); with a smoothed prolongator level_galerkin moves P, so it is done afterwards
     std::exception_ptr prep_err;

@@ -72,17 +72,30 @@ void pinned_pool_release() {
 // device memory pool (see common.h)
 // ---------------------------------------------------------------------------------------
 namespace {
+// Blocks freed on one stream share an EVENT PER BATCH instead of one each: the frees of a hierarchy teardown
+// (hundreds of blocks) used to put hundreds of markers into the stream, and on some processes the first kernel
+// after them started 10 - 30 ms late (GPU idle in the kernel trace).  A batch ("epoch") stays open while its
+// stream keeps freeing; its event is recorded -- on the freeing stream, after everything submitted to it so far,
+// hence after the work that preceded every free of the batch -- when the batch is full or when another stream
+// first asks for one of its blocks.  The freeing stream itself reuses its blocks at once, without any event.
+struct Epoch {
+    hipEvent_t ev = nullptr;
+    hipStream_t stream = nullptr;
+    int dev = 0;
+    int refs = 0;           // idle blocks that belong to the batch
+    bool recorded = false;
+};
 struct IdleBlock {
     void *p;
-    hipStream_t stream;     // the stream the block was freed on
-    hipEvent_t ev;          // recorded on that stream at the free
-    int dev;
+    Epoch *ep;
 };
+constexpr int POOL_EPOCH_BLOCKS = 64;
 struct DevPool {
     std::mutex mu;
     std::multimap<size_t, IdleBlock> idle;              // by size
     std::unordered_map<void *, size_t> live;            // blocks handed out -> size
     std::vector<hipEvent_t> events;                     // spare events
+    std::map<std::pair<int, hipStream_t>, Epoch *> open;   // the batch each (device, stream) is filling
     size_t idle_bytes = 0, max_idle = 0;
     bool enabled = true;
     DevPool() {
@@ -99,15 +112,41 @@ DevPool &dev_pool() {
 thread_local hipStream_t tl_stream = nullptr;
 thread_local bool tl_stream_set = false;
 inline size_t pool_round(size_t bytes) { return bytes <= (1u << 20) ? (bytes + 511) / 512 * 512 : (bytes + 65535) / 65536 * 65536; }
+// pool lock held: one block leaves its batch; a recorded batch without blocks gives its event back
+void epoch_unref(DevPool &P, Epoch *ep) {
+    if (--ep->refs > 0 || !ep->recorded) return;
+    P.events.push_back(ep->ev);
+    delete ep;
+}
+// pool lock held: close the batch (record its event now) so that other streams can wait for it
+bool epoch_record(DevPool &P, Epoch *ep) {
+    if (ep->recorded) return true;
+    if (hipEventRecord(ep->ev, ep->stream) != hipSuccess) { (void)hipGetLastError(); return false; }
+    ep->recorded = true;
+    auto it = P.open.find(std::make_pair(ep->dev, ep->stream));
+    if (it != P.open.end() && it->second == ep) P.open.erase(it);
+    return true;
+}
+// pool lock held: hipFree one idle block (hipFree waits for the device: whatever used the block is done)
+std::multimap<size_t, IdleBlock>::iterator pool_drop_block(DevPool &P, std::multimap<size_t, IdleBlock>::iterator it) {
+    (void)hipFree(it->second.p);
+    Epoch *ep = it->second.ep;
+    P.idle_bytes -= it->first;
+    it = P.idle.erase(it);
+    if (ep->refs == 1 && !ep->recorded) {      // the last block of an open batch: the batch goes with it
+        auto o = P.open.find(std::make_pair(ep->dev, ep->stream));
+        if (o != P.open.end() && o->second == ep) P.open.erase(o);
+        ep->recorded = true;
+    }
+    epoch_unref(P, ep);
+    return it;
+}
 // hipFree the idle blocks for which keep() is false; pool lock held
 template <class F>
 void pool_drop(DevPool &P, F keep) {
     for (auto it = P.idle.begin(); it != P.idle.end();) {
         if (keep(it)) { ++it; continue; }
-        (void)hipFree(it->second.p);
-        P.events.push_back(it->second.ev);
-        P.idle_bytes -= it->first;
-        it = P.idle.erase(it);
+        it = pool_drop_block(P, it);
     }
 }
 }  // namespace
@@ -126,15 +165,22 @@ void *dev_alloc(size_t bytes) {
         // smallest idle block that fits without wasting more than an eighth; same stream, or idle for certain
         const size_t limit = want + want / 8 + 4096;
         for (auto it = P.idle.lower_bound(want); it != P.idle.end() && it->first <= limit; ++it) {
-            IdleBlock &b = it->second;
-            if (b.dev != dev) continue;
-            const bool same = tl_stream_set && b.stream == tl_stream;
-            if (!same && hipEventQuery(b.ev) != hipSuccess) { (void)hipGetLastError(); continue; }
-            void *p = b.p;
-            P.events.push_back(b.ev);
+            Epoch *ep = it->second.ep;
+            if (ep->dev != dev) continue;
+            const bool same = tl_stream_set && ep->stream == tl_stream;
+            if (!same) {
+                if (!epoch_record(P, ep)) continue;
+                if (hipEventQuery(ep->ev) != hipSuccess) { (void)hipGetLastError(); continue; }
+            }
+            void *p = it->second.p;
             P.live[p] = it->first;
             P.idle_bytes -= it->first;
             P.idle.erase(it);
+            if (ep->refs == 1 && !ep->recorded) {      // an open batch that has just lost its last block stays open
+                --ep->refs;
+            } else {
+                epoch_unref(P, ep);
+            }
             return p;
         }
     }
@@ -165,30 +211,29 @@ void dev_free(void *p) noexcept {
         (void)hipFree(p);
         return;
     }
-    hipEvent_t ev = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(P.mu);
-        if (!P.events.empty()) { ev = P.events.back(); P.events.pop_back(); }
-    }
-    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
-    if (!ev || hipEventRecord(ev, tl_stream) != hipSuccess) {
-        (void)hipGetLastError();
-        if (ev) { std::lock_guard<std::mutex> lk(P.mu); P.events.push_back(ev); }
-        (void)hipFree(p);
-        return;
-    }
     std::lock_guard<std::mutex> lk(P.mu);
-    P.idle.insert(std::make_pair(size, IdleBlock{p, tl_stream, ev, dev}));
-    P.idle_bytes += size;
-    if (P.idle_bytes > P.max_idle) {        // over the cap: the largest blocks go back to the driver
-        while (P.idle_bytes > P.max_idle && !P.idle.empty()) {
-            auto last = std::prev(P.idle.end());
-            (void)hipFree(last->second.p);
-            P.events.push_back(last->second.ev);
-            P.idle_bytes -= last->first;
-            P.idle.erase(last);
+    Epoch *&cur = P.open[std::make_pair(dev, tl_stream)];
+    if (!cur) {
+        hipEvent_t ev = nullptr;
+        if (!P.events.empty()) { ev = P.events.back(); P.events.pop_back(); }
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            P.open.erase(std::make_pair(dev, tl_stream));
+            (void)hipFree(p);
+            return;
         }
+        cur = new Epoch;
+        cur->ev = ev;
+        cur->stream = tl_stream;
+        cur->dev = dev;
     }
+    Epoch *ep = cur;
+    ++ep->refs;
+    P.idle.insert(std::make_pair(size, IdleBlock{p, ep}));
+    P.idle_bytes += size;
+    if (ep->refs >= POOL_EPOCH_BLOCKS) (void)epoch_record(P, ep);     // (full: closed, the next free opens a new one)
+    while (P.idle_bytes > P.max_idle && !P.idle.empty())       // over the cap: the largest blocks go back to the driver
+        (void)pool_drop_block(P, std::prev(P.idle.end()));
 }
 
 void dev_pool_release() {
