@@ -1661,7 +1661,7 @@ __global__ __launch_bounds__(NC_NT) void ss_nullcheck_kernel(const int *__restri
         const bool ok = rq <= vu && sqrt(res2) <= tol;
         pre[b] = ok ? 1 : 0;
         pre_val[2 * b] = rq;
-        pre_val[2 * b + 1] = 1.0 / sqrt(xx);
+        pre_val[2 * b + 1] = ok ? 1.0 / sqrt(xx) : -sqrt(res2);      // (rejected: the residual, negated, for the debug print)
     }
 }
 
@@ -2294,8 +2294,7 @@ static void ss_factor_generic(hipStream_t s, EigBatch &b, bool sgn, int *neg, in
     const int *gbw = bws ? bws : (sgn ? b.bw.p : nullptr);
     auto panel = [&](int k0, double *Vout, double *Zout, int rext, double *Sout) {
         if (prof) profiler().begin(s);
-        static const int big_thr = [] { const char *e = std::getenv("SAAMGE_AMD_SS_PANEL_BIG"); return e ? std::atoi(e) : 768; }();
-        const bool big = std::min(nmax, bwmax + 2 * SB) > big_thr;
+        const bool big = std::min(nmax, bwmax + 2 * SB) > 768;
         if (sgn) {
             if (big) hipLaunchKernelGGL((chol_panel_kernel<1024, true>), dim3(b.count), dim3(1024), 0, s, k0, b.n.p, b.moff.p,
                                         b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, Sout, neg, keep, skip);
@@ -2526,6 +2525,16 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
         profiler().end(s, "eig_ss_nullcheck", cb, 0.0);
         auto hp = b.pre.to_host(s);
         b.h_pre.assign(hp.begin(), hp.end());
+        if (std::getenv("SAAMGE_AMD_SS_DEBUG") && !lds_path) {
+            auto hv = b.pre_val.to_host(s);
+            int shown = 0;
+            for (int i = 0; i < b.count && shown < 12; ++i)
+                if (b.h_inertia[i] == 1) {
+                    std::fprintf(stderr, "  nullcheck matrix %d: accepted %d, Rayleigh quotient %.3e, %s %.3e\n", i, hp[i], hv[2 * (size_t)i],
+                                 hp[i] ? "1/|x0|" : "residual", std::fabs(hv[2 * (size_t)i + 1]));
+                    ++shown;
+                }
+        }
     }
     if (lds_path && (!b.h_pre.empty() || b.nbad)) {       // the matrices the second factorisation still has to do
         std::vector<int> act;

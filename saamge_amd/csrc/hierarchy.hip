@@ -546,7 +546,39 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         io.extra = nextra ? L.extra.p : nullptr;
         io.nextra = nextra;
         io.ND = L.A.nrows;
-        mis_svd(s, L.drel, nm, max_ctot, io);
+        if (world > 1) {
+            // every rank takes a contiguous range of MISes (balanced by the r c^2 cost of the SVDs) and the bases,
+            // singular values and counts are all-gathered in place: the counterpart of the reference's
+            // owner-computes SVD + broadcast (SharedEntityCommunication, amg/src/contrib.cpp:519-548)
+            std::vector<int> mb((size_t)world + 1, nm);
+            double total = 0.0;
+            auto cost = [&](int m) {
+                const double r = rel.mis_to_dof.row_size(m), c = (double)(L.mis_s_off[m + 1] - L.mis_s_off[m]);
+                return r * std::min(r, c) * std::max(r, c) + 64.0;
+            };
+            for (int m = 0; m < nm; ++m) total += cost(m);
+            double run = 0.0;
+            int rk = 0;
+            mb[0] = 0;
+            for (int m = 0; m < nm && rk + 1 < world; ++m) {
+                run += cost(m);
+                while (rk + 1 < world && run >= total * (rk + 1) / world) mb[++rk] = m + 1;
+            }
+            mb[world] = nm;
+            L.d_mis_k.zero(s);
+            d_ncols.zero(s);
+            mis_svd(s, L.drel, mb[P.rank + 1] - mb[P.rank], max_ctot, io, mb[P.rank]);
+            std::vector<long long> off((size_t)world + 1);
+            for (int r = 0; r <= world; ++r) off[r] = 8ll * L.mis_u_off[mb[r]];
+            SA_REQUIRE(P.allgather(P.allgather_ctx, L.mis_U.p, off.data()) == 0, "all-gather (MIS bases) failed");
+            for (int r = 0; r <= world; ++r) off[r] = 8ll * L.mis_s_off[mb[r]];
+            SA_REQUIRE(P.allgather(P.allgather_ctx, L.mis_sig.p, off.data()) == 0, "all-gather (singular values) failed");
+            for (int r = 0; r <= world; ++r) off[r] = 4ll * mb[r];
+            SA_REQUIRE(P.allgather(P.allgather_ctx, L.d_mis_k.p, off.data()) == 0, "all-gather (MIS counts) failed");
+            SA_REQUIRE(P.allgather(P.allgather_ctx, d_ncols.p, off.data()) == 0, "all-gather (MIS columns) failed");
+        } else {
+            mis_svd(s, L.drel, nm, max_ctot, io);
+        }
         { auto t_ = L.d_mis_k.to_host(s); L.mis_k.assign(t_.begin(), t_.end()); }
         { auto t_ = d_ncols.to_host(s); L.mis_ncols.assign(t_.begin(), t_.end()); }
     }

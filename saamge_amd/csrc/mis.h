@@ -29,7 +29,9 @@ struct MisSvdIO {
 // ContribTent::SVDInsert on every MIS (amg/src/contrib.cpp:551-687): essential-boundary
 // filter (:102-163), column normalisation + SVD (amg/src/xpacks.cpp:494-589, one-sided
 // Jacobi instead of dgesvd), cut at sigma > 1e-10 sigma_max (:591-620).
-void mis_svd(hipStream_t s, const DevRelations &rel, int num_mises, int max_ctot, const MisSvdIO &io);
+// `m0`: first MIS of the range [m0, m0 + num_mises) this call works on (ranks of a multi-GPU setup take
+// contiguous ranges and all-gather the bases).
+void mis_svd(hipStream_t s, const DevRelations &rel, int num_mises, int max_ctot, const MisSvdIO &io, int m0 = 0);
 
 // P (ND x nc) and R = P^T from the MIS blocks (contrib_tent_insert_simple,
 // amg/src/contrib.cpp:170-194; explicit zeros are kept in the block pattern).

@@ -18,9 +18,9 @@ __global__ __launch_bounds__(64) void mis_svd_kernel(
     const int *__restrict__ mis2d_I, const int *__restrict__ mis2d_J,
     const int *__restrict__ mis2ae_I, const int *__restrict__ mis2ae_J,
     const int *__restrict__ ae2d_I, const int64_t *__restrict__ pair_loc_off,
-    const int *__restrict__ pair_loc, const signed char *__restrict__ flags, MisSvdIO io) {
+    const int *__restrict__ pair_loc, const signed char *__restrict__ flags, MisSvdIO io, int m0) {
     extern __shared__ __align__(16) double lds[];  // sig[ctot], then perm[ctot] (ints)
-    const int m = blockIdx.x;
+    const int m = m0 + blockIdx.x;
     const int lane = threadIdx.x;
     const int r = mis2d_I[m + 1] - mis2d_I[m];
     const int *dofs = mis2d_J + mis2d_I[m];
@@ -190,13 +190,13 @@ __global__ __launch_bounds__(64) void mis_svd_kernel(
     if (lane == 0) io.k[m] = k;
 }
 
-void mis_svd(hipStream_t s, const DevRelations &rel, int num_mises, int max_ctot, const MisSvdIO &io) {
+void mis_svd(hipStream_t s, const DevRelations &rel, int num_mises, int max_ctot, const MisSvdIO &io, int m0) {
     if (!num_mises) return;
     const size_t lds = (sizeof(double) + sizeof(int)) * (size_t)(max_ctot + 2);
     profiler().begin(s);
     hipLaunchKernelGGL(mis_svd_kernel, dim3(num_mises), dim3(64), lds, s, rel.mis2d_I.p,
                        rel.mis2d_J.p, rel.mis2ae_I.p, rel.mis2ae_J.p, rel.ae2d_I.p,
-                       rel.pair_loc_off.p, rel.pair_loc.p, rel.flags.p, io);
+                       rel.pair_loc_off.p, rel.pair_loc.p, rel.flags.p, io, m0);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "mis_svd", 0.0, 0.0);
 }
