@@ -289,11 +289,43 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     EigBatch batches[2];
     int pend_ae0[2] = {0, 0}, pend_cnt[2] = {0, 0};
     int64_t pend_row0[2] = {0, 0};
+    // The subspace iteration of a chunk (a few hundred to a few thousand small matrices still active: launches that
+    // fill a fraction of the chip, with a host round trip every few iterations) runs on its own thread and stream
+    // BESIDE the assembly and the factorisations of the next chunk (SAAMGE_AMD_EIG_OVERLAP=0: one after the other).
+    // Only eig_subspace_iterate runs there: it touches its own batch (the other workspace slot) and nothing else;
+    // everything that assembles or allocates workspace stays on this thread.
+    static const bool overlap_env = [] { const char *e = std::getenv("SAAMGE_AMD_EIG_OVERLAP"); return !(e && e[0] == '0'); }();
+    const bool overlap_iter = overlap_env && !profiler().enabled;
+    hipStream_t iter_stream = overlap_iter ? side_stream(3) : s;
+    std::thread iter_thread;
+    std::exception_ptr iter_err;
+    struct IterJoiner { std::thread &t; ~IterJoiner() { if (t.joinable()) t.join(); } } iter_joiner{iter_thread};
+    bool counted[2] = {false, false};
+    auto start_iterate = [&](int slot) {
+        EigBatch &batch = batches[slot];
+        counted[slot] = false;
+        if (!overlap_iter || !batch.subspace || batch.ss_failed || !batch.count) return;
+        counted[slot] = true;
+        iter_thread = std::thread([&, slot]() {
+            try {
+                adopt_device(dev);
+                set_thread_stream(iter_stream);
+                eig_count(iter_stream, batches[slot], -1.0, L.theta);
+                SA_HIP_CHECK(hipStreamSynchronize(iter_stream));
+            } catch (...) { iter_err = std::current_exception(); }
+        });
+    };
+    auto join_iterate = [&]() {
+        if (iter_thread.joinable()) iter_thread.join();
+        if (iter_err) { std::exception_ptr e = iter_err; iter_err = nullptr; std::rethrow_exception(e); }
+    };
     auto post = [&](int slot) {   // band -> tridiagonal, counts, eigenvectors of the chunk in `slot`
         EigBatch &batch = batches[slot];
         const int ae0 = pend_ae0[slot], cnt = pend_cnt[slot];
-        eig_tridiagonalize(qb, batch, 2);
-        eig_count(qb, batch, -1.0, L.theta);
+        if (!counted[slot]) {
+            eig_tridiagonalize(qb, batch, 2);
+            eig_count(qb, batch, -1.0, L.theta);
+        }
         if (batch.ss_failed) {   // few-eigenpairs path gave up on this chunk: dense path on re-assembled matrices
             batch.dense_only = true;
             batch.subspace = batch.ss_failed = false;
@@ -428,12 +460,13 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         pend_ae0[slot] = ae0;
         pend_cnt[slot] = cnt;
         pend_row0[slot] = row0;
-        if (prev >= 0) post(prev);
+        if (prev >= 0) { join_iterate(); post(prev); }
+        start_iterate(slot);
         prev = slot;
         row0 += batch.h_voff[cnt];
         ae0 += cnt;
     }
-    if (prev >= 0) post(prev);
+    if (prev >= 0) { join_iterate(); post(prev); }
     tm.lap("local eigenproblems", lev);
     if (operator_pending) {
         operator_data();
@@ -824,7 +857,10 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
             coarse_elmats(s, L.drel, ae0, batch, L.d_mis_k.p, L.d_mis_u_off.p, L.mis_U.p, d_colpos_ptr.p,
                           d_colpos.p, N.elmat.off.p, N.elmat.val.p, scratch, d_soff.p);
         }
-        SA_HIP_CHECK(hipStreamSynchronize(s));
+        // (single rank, last chunk: no wait -- everything that reads the element matrices follows on this stream,
+        // the buffers released here are stream-ordered, and the host goes on to the next level's topology while
+        // the kernel runs)
+        if (world > 1 || ae0 + cnt < ae_hi) SA_HIP_CHECK(hipStreamSynchronize(s));
         ae0 += cnt;
     }
     if (world > 1) {
