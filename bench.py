@@ -101,7 +101,7 @@ def build_problem(n, levels, dev, aniso=1.0, blk=(8, 8, 4), coarse_blk=(8, 8, 4)
 
 def one_step(capi, prob, params, rel_tol=1e-8, group=None):
     import torch
-    # the library works on torch's current stream (main(): a stream of the bench's own when SAAMGE_AMD_BENCH_STREAM=1)
+    # the library works on torch's current stream
     h = capi.Hierarchy(prob.rowptr, prob.col, prob.val, prob.n, prob.elem_to_dof, prob.elmat,
                        prob.bdr, prob.partitions, prob.nparts, params, prob.NE_, getattr(prob, "nde_", 8),
                        stream=torch.cuda.current_stream().cuda_stream, group=group)
@@ -259,8 +259,6 @@ def main():
                          tuple(int(v) for v in args.coarse_blk.split(",")),
                          "elasticity_q2" if elasticity else "poisson")
     torch.cuda.synchronize()
-    if os.environ.get("SAAMGE_AMD_BENCH_STREAM", "0") == "1":
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     torch.cuda.empty_cache()        # the generator's temporaries go back to the device before the library allocates
     params = capi.default_params(num_coarsenings=args.levels - 1, theta=args.theta, nu_relax=3, nu_pro=args.nu_pro,
                                  eigensolver=args.eigensolver,

@@ -189,6 +189,48 @@ def test_batched_eigens_banded_matrices_take_the_few_eigenpairs_path():
             os.environ["SAAMGE_AMD_SS_STRICT"] = old
 
 
+@pytest.mark.gpu
+def test_wide_band_matrices_without_a_wanted_eigenvalue_keep_the_inertia_factor():
+    """Wide-band matrices (the HBM path of the few-eigenpairs solver) whose spectrum lies entirely above theta:
+    the certified count is 0, the inertia pass's L S L^T is the Cholesky factorisation of C - theta I and is
+    kept (no second factorisation), the one pair the reference's "at least one" rule asks for is the smallest
+    (amg/src/spectral.cpp:124-237).  Mixed with matrices that do have a wanted pair, so that the second
+    factorisation runs on a part of the batch only.  Strict mode: no dense fallback."""
+    capi, o = _capi(), _oracle()
+    rng = np.random.default_rng(5)
+
+    def band_matrix(n, bw, lift):
+        W = np.zeros((n, n))
+        for d in range(1, bw + 1):
+            w = rng.uniform(0.5, 1.5, size=n - d)
+            W += np.diag(-w, d) + np.diag(-w, -d)
+        L = W + np.diag(-W.sum(axis=1))
+        return L + np.diag((lift * L.diagonal() if lift else 1e-4) * rng.uniform(0.5, 1.0, size=n))
+
+    old = os.environ.get("SAAMGE_AMD_SS_STRICT")
+    os.environ["SAAMGE_AMD_SS_STRICT"] = "1"
+    try:
+        for shapes in ([(300, 130, 0.05), (257, 256, 0.05), (80, 4, 0.05)],
+                       [(300, 120, 0.05), (280, 140, 0.0), (90, 7, 0.05), (200, 150, 0.0)]):
+            mats = [band_matrix(n, bw, lift) for n, bw, lift in shapes]
+            Ds = [o.snd_D_from_dense(L) for L in mats]
+            theta = 2e-3
+            res = capi.lower_eigens_batched(mats, Ds, -1.0, theta)
+            for (n, bw, lift), L, D, (w, X) in zip(shapes, mats, Ds, res):
+                wr, Xr = o.lower_eigens_dense(L, D, theta)
+                assert len(w) == len(wr) == 1
+                assert (w[0] > theta) == bool(lift)
+                assert np.allclose(w, wr, rtol=1e-10, atol=EIG_TOL)
+                R = L @ X - (D[:, None] * X) * w[None, :]
+                assert np.abs(R).max() <= 1e-10
+                assert np.allclose(_proj(X, D), _proj(Xr, D), atol=PROJ_TOL)
+    finally:
+        if old is None:
+            del os.environ["SAAMGE_AMD_SS_STRICT"]
+        else:
+            os.environ["SAAMGE_AMD_SS_STRICT"] = old
+
+
 def _range_projection(P, probe):
     """Orthogonal projection of `probe` onto range(P) (basis independent)."""
     G = (P.T @ P).toarray()
