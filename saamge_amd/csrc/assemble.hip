@@ -30,7 +30,9 @@ __global__ __launch_bounds__(ASM_NT) void ae_assemble_kernel(
     }
     const int *aedofs = ae2d_J + ae2d_I[p];
     const short *pm = perm ? perm + voff[b] : nullptr;    // position of an agglomerate row in the matrix
-    for (int lr0 = tid; lr0 < n; lr0 += ASM_NT) {
+    // (gridDim.y > 1 only without the clearing pass above: the rows are independent, large agglomerates are
+    // spread over several workgroups)
+    for (int lr0 = blockIdx.y * ASM_NT + tid; lr0 < n; lr0 += ASM_NT * gridDim.y) {
         const int g = aedofs[lr0];
         const int lr = pm ? pm[lr0] : lr0;
         const int fg = has_A ? flags[g] : 0;
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(ASM_NT) void ae_band_topo_kernel(
     const int *aedofs = ae2d_J + ae2d_I[p];
     const short *pm = perm + voff[b];
     int bw = 0;
-    for (int lr0 = tid; lr0 < n; lr0 += ASM_NT) {
+    for (int lr0 = blockIdx.y * ASM_NT + tid; lr0 < n; lr0 += ASM_NT * gridDim.y) {
         const int g = aedofs[lr0], me = pm[lr0];
         for (int q = d2e_I[g]; q < d2e_I[g + 1]; ++q) {
             const int e = d2e_J[q];
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(ASM_NT) void ae_band_topo_kernel(
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < ASM_NT / 64; ++w) bw = max(bw, wmax[w]);
-        bws[b] = bw;
+        atomicMax(bws + b, bw);         // (zeroed by the host; gridDim.y workgroups share an agglomerate)
     }
 }
 __global__ __launch_bounds__(256) void ae_zero_band_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
@@ -131,7 +133,9 @@ void ae_assemble(hipStream_t s, const DevRelations &rel, const DCsr *A, const De
     profiler().begin(s);
     if (banded) {
         if (batch.bw.n < (size_t)batch.count) batch.bw.alloc((size_t)batch.count);
-        hipLaunchKernelGGL(ae_band_topo_kernel, dim3(batch.count), dim3(ASM_NT), 0, s, ae0, batch.n.p, batch.voff.p,
+        SA_HIP_CHECK(hipMemsetAsync(batch.bw.p, 0, sizeof(int) * (size_t)batch.count, s));
+        const int ny_t = std::max(1, std::min(div_up(batch.max_n, ASM_NT), 4096 / std::max(1, batch.count)));
+        hipLaunchKernelGGL(ae_band_topo_kernel, dim3(batch.count, ny_t), dim3(ASM_NT), 0, s, ae0, batch.n.p, batch.voff.p,
                            batch.perm.p, rel.ae2d_I.p, rel.ae2d_J.p, rel.d2e_I.p, rel.d2e_J.p, rel.part.p, rel.e2d_I.p,
                            rel.e2d_J.p, rel.elem_ldof.p, el.off.p, el.val.p, batch.bw.p);
         const int ny = std::max(1, std::min(256, 65536 / std::max(1, batch.count)));
@@ -139,7 +143,8 @@ void ae_assemble(hipStream_t s, const DevRelations &rel, const DCsr *A, const De
                            batch.bw.p);
         batch.has_bw = true;
     }
-    hipLaunchKernelGGL(ae_assemble_kernel, dim3(batch.count), dim3(ASM_NT), 0, s, ae0, batch.n.p,
+    const int ny_rows = banded ? std::max(1, std::min(div_up(batch.max_n, ASM_NT), 4096 / std::max(1, batch.count))) : 1;
+    hipLaunchKernelGGL(ae_assemble_kernel, dim3(batch.count, ny_rows), dim3(ASM_NT), 0, s, ae0, batch.n.p,
                        batch.moff.p, batch.W.p, rel.ae2d_I.p, rel.ae2d_J.p, rel.d2ae_I.p,
                        rel.d2ae_J.p, rel.dof_id_inAE.p, rel.flags.p, rel.d2e_I.p, rel.d2e_J.p,
                        rel.part.p, rel.e2d_I.p, rel.e2d_J.p, rel.elem_ldof.p, el.off.p, el.val.p,

@@ -4,7 +4,7 @@
 set -o pipefail
 export TMPDIR=/tmp
 R=$PWD
-O=$R/gpurun_out/r02
+O=$R/gpurun_out/${1:-r02}
 mkdir -p $O
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o r02 -- python3 $R/bench.py --no-cpu-baseline --no-roofline --warmup 1 --steps 2 > $O/stats_bench.json 2> $O/stats_bench.err
@@ -24,4 +24,9 @@ python3 bench.py --workload poisson128 --no-cpu-baseline > $O/bench_poisson128.j
 python3 bench.py --workload aniso128 --no-cpu-baseline > $O/bench_aniso128.json 2> $O/bench_aniso128.err
 python3 bench.py --workload elasticity_q2 --no-cpu-baseline --warmup 0 > $O/bench_elasticity_q2.json 2> $O/bench_elasticity_q2.err
 echo "workloads done"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_aniso -o an -- python3 $R/bench.py --workload aniso128 --no-cpu-baseline --no-roofline --warmup 1 --steps 2 > /dev/null 2> $O/stats_aniso.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_el -o el -- python3 $R/bench.py --workload elasticity_q2 --no-cpu-baseline --no-roofline --warmup 0 --steps 1 > /dev/null 2> $O/stats_el.err
+cd $R
+echo "workload stats done"
 ls $O
