@@ -28,6 +28,9 @@ void ae_assemble(hipStream_t s, const DevRelations &rel, const DCsr *A, const De
 // W <- D^-1/2 W D^-1/2 in place.  Dout (optional, packed like batch.d) receives D.
 void ae_scale(hipStream_t s, EigBatch &batch, double *Dout);
 
+// longest row of a CSR operator (one small kernel + a read-back; callers cache it in A.max_row)
+int csr_max_row(hipStream_t s, const DCsr &A);
+
 // ae_assemble (+ ae_scale when `scale`): on the fine level, when the sparse rows of one AE fit in
 // LDS, as ONE fused kernel that writes the dense image once (see assemble.hip).
 // `rows` (optional): where the chunk's first row sits among the rows of all agglomerates of the level

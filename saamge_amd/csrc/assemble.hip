@@ -683,7 +683,7 @@ __global__ __launch_bounds__(ASM_NT) void ae_window_kernel(
     }
 }
 
-static int csr_max_row(hipStream_t s, const DCsr &A) {
+int csr_max_row(hipStream_t s, const DCsr &A) {
     DBuf<int> m(1);
     m.zero(s);
     if (A.nrows)

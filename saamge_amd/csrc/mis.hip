@@ -3,6 +3,7 @@
 // and orthogonalises them with a one-sided (Hestenes) Jacobi SVD -- all cross-lane
 // reductions are wavefront shuffles, no LDS traffic besides the tiny sort scratch.
 #include "mis.h"
+#include "assemble.h"
 
 #include <cfloat>
 
@@ -493,7 +494,8 @@ __global__ __launch_bounds__(RAP_NT) void rap_symbolic_kernel(
     int pass, const int *__restrict__ mis2d_I, const int *__restrict__ mis2d_J,
     const roff_t *__restrict__ Arow, const int *__restrict__ Acol, const int *__restrict__ mises,
     const int *__restrict__ k, int *__restrict__ cnt, const int *__restrict__ nbr_ptr,
-    int *__restrict__ nbr, int *__restrict__ err, int *__restrict__ stage = nullptr, int stage_cap = 0) {
+    int *__restrict__ nbr, int *__restrict__ err, int *__restrict__ stage = nullptr, int stage_cap = 0,
+    int maxrow = 0) {
     __shared__ int table[RAP_HASH];
     __shared__ int nfound;
     const int m1 = blockIdx.x;
@@ -501,23 +503,32 @@ __global__ __launch_bounds__(RAP_NT) void rap_symbolic_kernel(
         if (pass == 0 && threadIdx.x == 0) cnt[m1] = 0;
         return;
     }
-    for (int i = threadIdx.x; i < RAP_HASH; i += RAP_NT) table[i] = -1;
-    if (threadIdx.x == 0) nfound = 0;
-    __syncthreads();
     const int r1 = mis2d_I[m1 + 1] - mis2d_I[m1];
     const int *dofs = mis2d_J + mis2d_I[m1];
+    // The table is as large as this MIS can need: a MIS of r1 dofs has at most r1 * maxrow neighbours (most MISes
+    // are a vertex, an edge or a face of an agglomerate -- a few dofs: clearing and compacting 2 048 slots for
+    // each of them was most of this kernel).  maxrow = 0: the full table.
+    int HS = RAP_HASH;
+    if (maxrow > 0) {
+        const long bound = 2l * r1 * maxrow;
+        HS = 64;
+        while (HS < RAP_HASH && HS < bound) HS <<= 1;
+    }
+    for (int i = threadIdx.x; i < HS; i += RAP_NT) table[i] = -1;
+    if (threadIdx.x == 0) nfound = 0;
+    __syncthreads();
     for (int il = threadIdx.x; il < r1; il += RAP_NT) {
         const int g = dofs[il];
         for (roff_t q = Arow[g]; q < Arow[g + 1]; ++q) {
             const int m2 = mises[Acol[q]];
             if (k[m2] == 0) continue;
-            unsigned h = ((unsigned)m2 * 2654435761u) & (RAP_HASH - 1);
-            for (int probe = 0; probe < RAP_HASH; ++probe) {
+            unsigned h = ((unsigned)m2 * 2654435761u) & (HS - 1);
+            for (int probe = 0; probe < HS; ++probe) {
                 const int old = atomicCAS(&table[h], -1, m2);
                 if (old == -1) { atomicAdd(&nfound, 1); break; }
                 if (old == m2) break;
-                h = (h + 1) & (RAP_HASH - 1);
-                if (probe == RAP_HASH - 1) atomicExch(err, 1);
+                h = (h + 1) & (HS - 1);
+                if (probe == HS - 1) atomicExch(err, 1);
             }
         }
     }
@@ -533,7 +544,7 @@ __global__ __launch_bounds__(RAP_NT) void rap_symbolic_kernel(
     __shared__ int nlist;
     if (threadIdx.x == 0) nlist = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < RAP_HASH; i += RAP_NT) {
+    for (int i = threadIdx.x; i < HS; i += RAP_NT) {
         const int v = table[i];
         if (v >= 0) list[atomicAdd(&nlist, 1)] = v;
     }
@@ -669,11 +680,14 @@ void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, cons
     }
     DBuf<int> cnt((size_t)nm), err(1);
     err.zero(s);
+    if (A.max_row < 0) A.max_row = csr_max_row(s, A);
+    const int maxrow = A.max_row;
     profiler().begin(s);
     constexpr int STAGE_CAP = 64;
     DBuf<int> stage((size_t)nm * STAGE_CAP);
     hipLaunchKernelGGL(rap_symbolic_kernel, dim3(nm), dim3(RAP_NT), 0, s, 0, rel.mis2d_I.p,
-                       rel.mis2d_J.p, A.rowptr.p, A.col.p, rel.mises.p, d_k, cnt.p, nullptr, nullptr, err.p, stage.p, STAGE_CAP);
+                       rel.mis2d_J.p, A.rowptr.p, A.col.p, rel.mises.p, d_k, cnt.p, nullptr, nullptr, err.p, stage.p, STAGE_CAP,
+                       maxrow);
     SA_HIP_CHECK(hipGetLastError());
     auto h_cnt = cnt.to_host(s);
     SA_REQUIRE(err.to_host(s)[0] == 0, "RAP: MIS neighbour table overflow");
@@ -687,7 +701,8 @@ void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, cons
                            nbr_ptr.p, nbr.p);
     else
         hipLaunchKernelGGL(rap_symbolic_kernel, dim3(nm), dim3(RAP_NT), 0, s, 1, rel.mis2d_I.p,
-                           rel.mis2d_J.p, A.rowptr.p, A.col.p, rel.mises.p, d_k, cnt.p, nbr_ptr.p, nbr.p, err.p, (int *)nullptr, 0);
+                           rel.mis2d_J.p, A.rowptr.p, A.col.p, rel.mises.p, d_k, cnt.p, nbr_ptr.p, nbr.p, err.p, (int *)nullptr, 0,
+                           maxrow);
     SA_HIP_CHECK(hipGetLastError());
     auto h_nbr = nbr.to_host(s);
     // row pointers of Ac and LDS sizing
