@@ -110,3 +110,43 @@ def test_scale_golden_128(eigensolver):
     dimension of 151; round 1's default path gave 153 here."""
     g, out = _run("scale_128", eigensolver)
     _check(g, out, "scale_128/%s" % eigensolver)
+
+
+def test_coarse_level_switches_give_the_same_hierarchy():
+    """The round-2 switches of the coarse-level eigenproblems -- band-limited assembly / scaling of the few large
+    agglomerates (SAAMGE_AMD_BAND_ASSEMBLY), kept inertia factor (SAAMGE_AMD_SS_REUSE), subspace iteration beside
+    the next chunk (SAAMGE_AMD_EIG_OVERLAP, with the level-0 agglomerates split over several chunks) -- each switched
+    off in a process of its own: identical level dimensions, eigenvector counts and iteration counts, history to 1e-9
+    (the golden is the oracle's; this is the library against itself)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json; sys.path.insert(0, %r)\n"
+        "import numpy as np, torch, ctypes as C\n"
+        "from saamge_amd import capi, problems as pr\n"
+        "prob = pr.poisson3d_device((64, 64, 32), blk=(8, 8, 4), coarse_blk=[(8, 8, 4)], device='cuda:0')\n"
+        "params = capi.default_params(num_coarsenings=2, theta=0.003, nu_relax=3, workspace_bytes=1 << 28)\n"
+        "h = capi.Hierarchy(prob.rowptr, prob.col, prob.val, prob.n, prob.elem_to_dof, prob.elmat, prob.bdr,\n"
+        "                   prob.partitions, prob.nparts, params, prob.NE_, 8)\n"
+        "x = torch.zeros_like(prob.b)\n"
+        "_, it, conv, hist = h.pcg(prob.b, x, rel_tol=1e-8, max_iter=100)\n"
+        "infos = [h.level_info(l) for l in range(2)]\n"
+        "ms = []\n"
+        "for l in range(2):\n"
+        "    m = np.zeros(infos[l]['nparts'], dtype=np.int32)\n"
+        "    capi._check(capi.load().saamge_amd_get_ae_eigens(h.h, C.c_int(l), capi._ptr(m), None, None, None))\n"
+        "    ms.append(m.tolist())\n"
+        "print(json.dumps({'dims': [i['n'] for i in infos] + [infos[-1]['ncoarse']], 'it': it, 'conv': bool(conv),\n"
+        "                  'hist': list(hist), 'm': ms}))\n" % root)
+    outs = []
+    for extra in ({}, {"SAAMGE_AMD_BAND_ASSEMBLY": "0"}, {"SAAMGE_AMD_SS_REUSE": "0"}, {"SAAMGE_AMD_EIG_OVERLAP": "0"}):
+        o = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert o.returncode == 0, o.stderr[-2000:]
+        outs.append(json.loads(o.stdout.strip().splitlines()[-1]))
+    g = np.load(os.path.join(GOLD, "scale_64x64x32.npz"))
+    assert outs[0]["dims"] == [int(v) for v in g["level_dims"]] and outs[0]["it"] == int(g["pcg_iters"][0])
+    for other in outs[1:]:
+        assert other["conv"] and other["dims"] == outs[0]["dims"] and other["it"] == outs[0]["it"] and other["m"] == outs[0]["m"]
+        assert np.allclose(other["hist"], outs[0]["hist"], rtol=1e-9, atol=0.0)
