@@ -508,31 +508,42 @@ __global__ __launch_bounds__(RAP_NT) void rap_symbolic_kernel(
     // The table is as large as this MIS can need: a MIS of r1 dofs has at most r1 * maxrow neighbours (most MISes
     // are a vertex, an edge or a face of an agglomerate -- a few dofs: clearing and compacting 2 048 slots for
     // each of them was most of this kernel).  maxrow = 0: the full table.
+    // A larger MIS (a face or the interior of an agglomerate) could have many neighbours but on a mesh has a few
+    // dozen: it starts with 256 slots and walks its rows again with the full table only if those fill up.
+    __shared__ int overflow;
     int HS = RAP_HASH;
     if (maxrow > 0) {
         const long bound = 2l * r1 * maxrow;
         HS = 64;
-        while (HS < RAP_HASH && HS < bound) HS <<= 1;
+        while (HS < 256 && HS < bound) HS <<= 1;
     }
-    for (int i = threadIdx.x; i < HS; i += RAP_NT) table[i] = -1;
-    if (threadIdx.x == 0) nfound = 0;
-    __syncthreads();
-    for (int il = threadIdx.x; il < r1; il += RAP_NT) {
-        const int g = dofs[il];
-        for (roff_t q = Arow[g]; q < Arow[g + 1]; ++q) {
-            const int m2 = mises[Acol[q]];
-            if (k[m2] == 0) continue;
-            unsigned h = ((unsigned)m2 * 2654435761u) & (HS - 1);
-            for (int probe = 0; probe < HS; ++probe) {
-                const int old = atomicCAS(&table[h], -1, m2);
-                if (old == -1) { atomicAdd(&nfound, 1); break; }
-                if (old == m2) break;
-                h = (h + 1) & (HS - 1);
-                if (probe == HS - 1) atomicExch(err, 1);
+    const bool certain = maxrow > 0 && 2l * r1 * maxrow <= HS;     // the table cannot fill up
+    for (;;) {
+        for (int i = threadIdx.x; i < HS; i += RAP_NT) table[i] = -1;
+        if (threadIdx.x == 0) { nfound = 0; overflow = 0; }
+        __syncthreads();
+        for (int il = threadIdx.x; il < r1; il += RAP_NT) {
+            const int g = dofs[il];
+            for (roff_t q = Arow[g]; q < Arow[g + 1]; ++q) {
+                const int m2 = mises[Acol[q]];
+                if (k[m2] == 0) continue;
+                unsigned h = ((unsigned)m2 * 2654435761u) & (HS - 1);
+                for (int probe = 0; probe < HS; ++probe) {
+                    const int old = atomicCAS(&table[h], -1, m2);
+                    if (old == -1) { atomicAdd(&nfound, 1); break; }
+                    if (old == m2) break;
+                    h = (h + 1) & (HS - 1);
+                    if (probe == HS - 1) { if (HS == RAP_HASH) atomicExch(err, 1); else overflow = 1; }
+                }
             }
         }
+        __syncthreads();
+        // (more than half full counts as full: the probe sequences get long, and the rank pass below is quadratic)
+        const bool again = HS < RAP_HASH && !certain && (overflow || 2 * nfound > HS);
+        __syncthreads();
+        if (!again) break;
+        HS = RAP_HASH;
     }
-    __syncthreads();
     if (pass == 0) {
         if (threadIdx.x == 0) cnt[m1] = nfound;
         // the list itself goes to a fixed-capacity staging row when it fits (it nearly always does: 27 neighbours
