@@ -645,18 +645,42 @@ __global__ __launch_bounds__(RAP_NT) void rap_numeric_kernel(
             for (int il = tid; il < rc; il += RAP_NT) {
                 const int g = dofs[c0 + il];
                 double *Trow = T + (size_t)il * ncol;
-                for (roff_t q = Arow[g]; q < Arow[g + 1]; ++q) {
-                    const int j = Acol[q];
-                    const int m2 = mises[j];
-                    int lo = 0, hi = nn;      // (the neighbour list holds exactly the MISes with k > 0)
-                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (nbl[mid] <= m2) lo = mid; else hi = mid; }
-                    if (nn == 0 || nbl[lo] != m2) continue;
-                    const int k2 = kk[lo];
-                    const int r2 = rr[lo];
-                    const double *U2 = U + uo[lo] + row_in_mis[j];
-                    const double a = Aval[q];
-                    double *dst = Trow + pos[lo];
-                    for (int v = 0; v < k2; ++v) dst[v] = fma(a, U2[(size_t)v * r2], dst[v]);
+                // four entries of the row at a time: their gather chains (column -> MIS -> slot -> row in the MIS ->
+                // basis entry) are independent and are all requested before the first product; the products are
+                // then added in the order of the entries, as a plain loop would
+                const roff_t qe = Arow[g + 1];
+                for (roff_t q0 = Arow[g]; q0 < qe; q0 += 4) {
+                    int jj4[4], lo4[4];
+                    double a4[4], u4[4];
+                    bool on4[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const roff_t q = min(q0 + t, qe - 1);
+                        jj4[t] = Acol[q];
+                        a4[t] = Aval[q];
+                    }
+                    int m4[4], rim4[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { m4[t] = mises[jj4[t]]; rim4[t] = row_in_mis[jj4[t]]; }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        int lo = 0, hi = nn;      // (the neighbour list holds exactly the MISes with k > 0)
+                        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (nbl[mid] <= m4[t]) lo = mid; else hi = mid; }
+                        lo4[t] = lo;
+                        on4[t] = q0 + t < qe && nn != 0 && nbl[lo] == m4[t];
+                        u4[t] = on4[t] ? U[uo[lo] + rim4[t]] : 0.0;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (!on4[t]) continue;
+                        const int lo = lo4[t];
+                        const int k2 = kk[lo];
+                        const int r2 = rr[lo];
+                        const double *U2 = U + uo[lo] + rim4[t];
+                        double *dst = Trow + pos[lo];
+                        dst[0] = fma(a4[t], u4[t], dst[0]);
+                        for (int v = 1; v < k2; ++v) dst[v] = fma(a4[t], U2[(size_t)v * r2], dst[v]);
+                    }
                 }
             }
             __syncthreads();
