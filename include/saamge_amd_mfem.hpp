@@ -393,6 +393,64 @@ inline tg_data_t *tg_produce_data(mfem::HypreParMatrix &Ag, const agg_partitioni
     delete ml;
     return tg;
 }
+// tg_produce_data_algebraic (inc/tg.hpp:518-523, src/tg.cpp:862-886): the element-free two-level method -- only the
+// matrix and the dof -> AE map of agg_part_rels (fem_create_partitioning_from_matrix makes every dof its own
+// "element": partitioning[dof] = AE, NE = ND).  The agglomerate matrices are principal submatrices of A with
+// diagonal compensation (ExtractSubMatrices, src/tg.cpp:579-672) or, with use_window, the window matrices
+// (WindowSubMatrices, src/tg.cpp:741-858).  Alocal is the diagonal block of Ag on one rank and is not read.
+inline tg_data_t *tg_produce_data_algebraic(const mfem::SparseMatrix &Alocal, mfem::HypreParMatrix &Ag,
+                                            const agg_partitioning_relations_t &agg_part_rels, int nu_pro, int nu_relax,
+                                            double spectral_tol, bool smooth_interp, int polynomial_coarse_arg, bool use_window,
+                                            bool use_arpack, bool avoid_ess_bdr_dofs) {
+    (void)Alocal; (void)avoid_ess_bdr_dofs;
+    const agg_partitioning_relations_t &r = agg_part_rels;
+    const int n = Ag.Height();
+    if (r.NE != n || !r.partitioning) mfem::mfem_error("tg_produce_data_algebraic: agg_part_rels must map every dof to its AE (NE = ND)");
+    int nparts = r.nparts;
+    MultilevelParameters mlp(1, &nparts, smooth_interp ? nu_pro : 0, nu_pro, nu_relax, spectral_tol, spectral_tol,
+                             polynomial_coarse_arg, false, use_arpack, r.do_aggregates);
+    saamge_amd_params p = mlp.p;
+    p.algebraic = use_window ? 2 : 1;
+    detail::HostCsr A = detail::csr_of(Ag);
+    const int *part_ptr = r.partitioning;
+    saamge_amd_hierarchy *h = nullptr;
+    if (saamge_amd_ml_produce_data(n, A.I.data(), A.J.data(), A.V.data(), n, 1, nullptr, nullptr, nullptr, &part_ptr, &nparts, &p,
+                                   nullptr, &h))
+        mfem::mfem_error(saamge_amd_last_error());
+    tg_data_t *tg = new tg_data_t;
+    tg->h = h;
+    tg->level = 0;
+    tg->owns_h = true;
+    tg->theta = spectral_tol;
+    tg->smooth_interp = smooth_interp;
+    tg->polynomial_coarse_space = polynomial_coarse_arg;
+    tg->poly_data = new smpr_poly_data_t;
+    tg->poly_data->h = h;
+    tg->poly_data->level = 0;
+    tg->elem_data = nullptr;
+    detail::fetch_operators(*tg, Ag.GetComm());
+    return tg;
+}
+// tg_fillin_coarse_operator (inc/tg.hpp:641-657, 711-732): "if Ac is empty, it is computed".  The setup here always
+// builds Ac = P^T A P on the device; the call only (re)fetches the host copy a caller may have freed with
+// tg_free_coarse_operator.  The coarse solver stays whatever tg_data->coarse_solver is (test/algebraic/
+// algebraic.cpp:282-283 assigns its own right after this call).
+inline void tg_fillin_coarse_operator(mfem::HypreParMatrix &A, tg_data_t *tg_data, bool perform_solve_init) {
+    (void)perform_solve_init;
+    if (!tg_data || !tg_data->interp || !tg_data->restr) mfem::mfem_error("tg_fillin_coarse_operator: no interpolation");
+    if (tg_data->Ac) return;
+    delete tg_data->interp; delete tg_data->restr; delete tg_data->interp_diag; delete tg_data->restr_diag;
+    tg_data->interp = tg_data->restr = nullptr;
+    tg_data->interp_diag = tg_data->restr_diag = nullptr;
+    detail::fetch_operators(*tg_data, A.GetComm());
+}
+// tg_free_coarse_operator (inc/tg.hpp:659-667, 735-745): the caller's copy of Ac goes; the device hierarchy keeps its own
+inline void tg_free_coarse_operator(tg_data_t &tg_data) {
+    delete tg_data.Ac;
+    delete tg_data.Ac_diag;
+    tg_data.Ac = nullptr;
+    tg_data.Ac_diag = nullptr;
+}
 // tg_update_coarse_operator (inc/tg.hpp:610-612): the matrix values changed, interpolation kept
 inline void tg_update_coarse_operator(mfem::HypreParMatrix &A, tg_data_t *tg_data, bool perform_solve_init, bool coarse_direct) {
     (void)perform_solve_init; (void)coarse_direct;

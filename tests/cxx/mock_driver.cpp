@@ -44,3 +44,34 @@ int mock_driver(HypreParMatrix *Ag, SparseMatrix *Al, ParBilinearForm *a, Table 
     delete[] nparts_arr;
     return iters + nc + dims.Size();
 }
+
+// the element-free driver: amg/test/algebraic/algebraic.cpp:257-283 (the dof -> AE map is the caller's here: the
+// reference's fem_create_partitioning_from_matrix calls METIS)
+int mock_algebraic_driver(HypreParMatrix *Ag, SparseMatrix *Al, int *dof_partitioning, int nparts, Solver *my_coarse_solver,
+                          HypreParVector *bg, HypreParVector *pxg, bool window_amg) {
+    const int n = Ag->Height();
+    Table *dof_to_dof = new Table;                 // every dof its own "element"
+    dof_to_dof->MakeI(n);
+    for (int i = 0; i < n; ++i) dof_to_dof->AddAColumnInRow(i);
+    dof_to_dof->MakeJ();
+    for (int i = 0; i < n; ++i) dof_to_dof->AddConnection(i, i);
+    dof_to_dof->ShiftUpI();
+    agg_partitioning_relations_t *agg_part_rels =
+        agg_create_partitioning_fine(*Ag, n, dof_to_dof, NULL, dof_partitioning, NULL, &nparts, NULL, false);
+    const int first_nu_pro = 0, nu_pro = 0, nu_relax = 3, polynomial_coarse = -1;
+    const double first_theta = 0.003;
+    const bool use_arpack = true, avoid_ess_bdr_dofs = true;
+    tg_data_t *tg_data = tg_produce_data_algebraic(*Al, *Ag, *agg_part_rels, first_nu_pro, nu_relax, first_theta, (nu_pro > 0),
+                                                   polynomial_coarse, window_amg, use_arpack, avoid_ess_bdr_dofs);
+    tg_fillin_coarse_operator(*Ag, tg_data, false);
+    tg_data->coarse_solver = my_coarse_solver;
+    VCycleSolver prec(tg_data, false);
+    prec.SetOperator(*Ag);
+    const int iters = kalchev_pcg(*Ag, prec, *bg, *pxg, 0, 1000, 1e-12, 1e-24, false);
+    tg_free_coarse_operator(*tg_data);
+    tg_fillin_coarse_operator(*Ag, tg_data, false);
+    const int nc = tg_data->Ac->Height();
+    tg_free_data(tg_data);
+    agg_free_partitioning(agg_part_rels);
+    return iters + nc;
+}
