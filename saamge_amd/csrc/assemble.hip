@@ -143,13 +143,16 @@ void ae_assemble(hipStream_t s, const DevRelations &rel, const DCsr *A, const De
                            batch.bw.p);
         batch.has_bw = true;
     }
-    const int ny_rows = banded ? std::max(1, std::min(div_up(batch.max_n, ASM_NT), 4096 / std::max(1, batch.count))) : 1;
+    // (not banded: the whole images are cleared by a memset -- one workgroup per agglomerate clearing 38 MB of a
+    // 2 187-row Q2 elasticity agglomerate with 256 threads was most of this kernel: 1.1 s of config 5's 23 s)
+    if (!banded) SA_HIP_CHECK(hipMemsetAsync(batch.W.p, 0, sizeof(double) * (size_t)batch.h_moff[batch.count], s));
+    const int ny_rows = std::max(1, std::min(div_up(batch.max_n, ASM_NT), 4096 / std::max(1, batch.count)));
     hipLaunchKernelGGL(ae_assemble_kernel, dim3(batch.count, ny_rows), dim3(ASM_NT), 0, s, ae0, batch.n.p,
                        batch.moff.p, batch.W.p, rel.ae2d_I.p, rel.ae2d_J.p, rel.d2ae_I.p,
                        rel.d2ae_J.p, rel.dof_id_inAE.p, rel.flags.p, rel.d2e_I.p, rel.d2e_J.p,
                        rel.part.p, rel.e2d_I.p, rel.e2d_J.p, rel.elem_ldof.p, el.off.p, el.val.p,
                        A ? 1 : 0, A ? A->rowptr.p : nullptr, A ? A->col.p : nullptr,
-                       A ? A->val.p : nullptr, batch.voff.p, batch.has_perm ? batch.perm.p : nullptr, banded ? 0 : 1);
+                       A ? A->val.p : nullptr, batch.voff.p, batch.has_perm ? batch.perm.p : nullptr, 0);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "ae_assemble", bytes, 0.0);
 }

@@ -1404,10 +1404,7 @@ __global__ __launch_bounds__(NT) void chol_panel_kernel(int k0, const int *__res
                 Vp[pr + c] = t;
                 if (Zp) Zp[pr + c] = 0.5 * ts;
                 if (Sp) Sp[pr + c] = ts;
-                if (keep) {
-                    A[(size_t)(k0 + c) * n + r] = t;
-                    A[(size_t)r * n + (k0 + c)] = t;
-                }
+                if (keep) A[(size_t)(k0 + c) * n + r] = t;      // (L only, coalesced; L^T: ss_keep_transpose_kernel, kept matrices only)
             } else {
                 A[(size_t)(k0 + c) * n + r] = t;
                 A[(size_t)r * n + (k0 + c)] = t;
@@ -1418,6 +1415,24 @@ __global__ __launch_bounds__(NT) void chol_panel_kernel(int k0, const int *__res
     }
 }
 
+
+// Kept inertia factors (eig_subspace_factor): the signed panel kernel writes L only -- the transposed, strided
+// writes of L^T cost every matrix of the batch 180 us per panel (0.6 s of config 5's 23 s, where no matrix keeps its
+// factor), this pass costs the few that do one sweep.  Column j of L, below its diagonal block, goes to row j of
+// the upper triangle; the diagonal blocks (inverses, both triangles) are the panel kernel's.
+__global__ __launch_bounds__(256) void ss_keep_transpose_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
+                                                                double *__restrict__ W, const int *__restrict__ bws,
+                                                                const int *__restrict__ keep) {
+    const int b = blockIdx.x;
+    if (!keep[b]) return;
+    const int n = ns[b], reach = (bws ? bws[b] : n) + 2 * SB;
+    double *A = W + moff[b];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int j = blockIdx.y * 4 + wv; j < n; j += 4 * gridDim.y) {
+        const int i0 = (j / SB + 1) * SB, i1 = min(n, j + reach + 1);
+        for (int i = i0 + lane; i < i1; i += 64) A[(size_t)i * n + j] = A[(size_t)j * n + i];
+    }
+}
 
 // full band |i - j| <= bw of every column, packed (column j of matrix b at soff[b] + j (2 bw + 1)):
 // saved before / restored after the in-place inertia factorisation of the wide-band matrices
@@ -1699,6 +1714,14 @@ __global__ __launch_bounds__(256) void ss_init_kernel(const int *__restrict__ ns
         const int r = idx >> 3, pr = pm ? pm[r] : r;       // (dis is in agglomerate order, the matrix in perm order)
         Xb[pr * SS_B + (idx & 7)] = ((idx & 7) == 0) ? (x0c ? x0c[voff[b] + r] : 1.0) / db[r] : unit_rand_ss((unsigned)(pr * SS_B + (idx & 7)), (unsigned)n);
     }
+}
+
+__global__ __launch_bounds__(256) void ss_copy_active_kernel(const int *__restrict__ ns, const int64_t *__restrict__ voff,
+                                                             const int *__restrict__ active, const double *__restrict__ X,
+                                                             double *__restrict__ Z) {
+    const int b = active[blockIdx.x];
+    const size_t base = (size_t)voff[b] * SB, cnt = (size_t)ns[b] * SS_B;
+    for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < cnt; i += (size_t)256 * gridDim.y) Z[base + i] = X[base + i];
 }
 
 // X <- T^-1 X for the lower (UPPER = false: L y = x) or the upper (UPPER = true: L^T z = y) factor,
@@ -2500,6 +2523,8 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
         if (nkeep < b.count)
             hipLaunchKernelGGL(band_copy_kernel<true>, dim3(b.count, ny), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, b.bw.p,
                                b.ss_soff.p, b.ss_save, d_skip.p);
+        if (nkeep > 0)
+            hipLaunchKernelGGL(ss_keep_transpose_kernel, dim3(b.count, ny), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, bws, d_skip.p);
         SA_HIP_CHECK(hipGetLastError());
     }
     // ---- matrices that are finished before they are factored ----
@@ -2662,7 +2687,10 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
             else if (rows <= 256) go(ss_solve_lds_kernel<256>, 256);      // (>= SB * SB threads: the block loads)
             else go(ss_solve_lds_kernel<512>, 512);
         } else {
-        SA_HIP_CHECK(hipMemcpyAsync(Z, X, sizeof(double) * (size_t)b.h_voff[b.count] * SB, hipMemcpyDeviceToDevice, s));
+        // Z <- X for the matrices still iterating (the whole buffer used to be copied every iteration: 0.6 s of
+        // config 5's 23 s, where most matrices of a chunk are done long before the last one)
+        hipLaunchKernelGGL(ss_copy_active_kernel, dim3(nact, std::max(1, std::min(16, b.max_n / 256))), dim3(256), 0, s, b.n.p,
+                           b.voff.p, active.p, X, Z);
         if (b.max_n > 768) {
             hipLaunchKernelGGL((ss_trsolve_kernel<false, 1024>), dim3(nact), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
             hipLaunchKernelGGL((ss_trsolve_kernel<true, 1024>), dim3(nact), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
