@@ -875,7 +875,10 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
     if (!A || no_fused || lds > 160 * 1024 - 256 || batch.max_n > 32767) {
         if (!split_scale) batch.has_perm = false;       // (the one-kernel scaling works in agglomerate order)
         static const bool band_asm = [] { const char *e = std::getenv("SAAMGE_AMD_BAND_ASSEMBLY"); return !(e && e[0] == '0'); }();
-        const bool banded = band_asm && batch.has_perm && split_scale && scale && !A && eig_ss_band_enabled();
+        // (also with the global matrix at hand -- level 0 of Q2 elasticity, whose agglomerates do not fit the fused
+        // kernel's LDS: an entry copied from A couples two dofs of an element of this agglomerate, so the band of the
+        // element matrices holds it)
+        const bool banded = band_asm && batch.has_perm && split_scale && scale && eig_ss_band_enabled();
         ae_assemble(s, rel, A, el, ae0, batch, banded);
         if (scale) ae_scale(s, batch, Dout);
         return;
