@@ -6,7 +6,8 @@
 // chain of triangular block steps (2.4 ms) or an inner Krylov loop (~170 tiny SpMV launches).
 // The inverse is built in place by block Gauss-Jordan elimination without pivoting (Ac is SPD, so
 // is every Schur complement), DNB = 64 columns per step, two launches per step (gj_panel_kernel, gj_apply_kernel
-// below): 2 n^3 flops on the matrix cores, the matrix read + written once per step (n / 64 steps).  A non-positive pivot
+// below), on the LOWER block triangle only (the partially inverted matrix is symmetric up to the sign of its
+// swept x unswept blocks): n^3 flops on the matrix cores, half the matrix read + written per step (n / 64 steps).  A non-positive pivot
 // (semi-definite operator) is reported so that the caller falls back to the inner PCG.
 #include "dense.h"
 
@@ -50,11 +51,18 @@ __global__ __launch_bounds__(256) void gj_panel_kernel(int n, int k0, int nb, co
     __shared__ double Mk[DNB][DNB + 1];           // Mk[s][c] = M[k0 + s, j0 + c]
     const int b = blockIdx.x, tid = threadIdx.x, kb = k0 / DNB, j0 = b * DNB;
     const int r = tid & (DNB - 1), c0 = tid >> 6;          // this thread owns D[r][c0 + 4 u], u = 0..15
+    // Only the LOWER block triangle of M is kept up to date (gj_apply_kernel).  With S the swept and U the unswept
+    // blocks, the partially inverted matrix is symmetric inside S x S and U x U and M(S, U) = -M(U, S)^T, so the
+    // blocks above the diagonal come from their mirror images: the row panel right of the pivot block (U x U) as
+    // the transpose, the column panel above it (S x U) as the negated transpose -- read along the contiguous
+    // direction of the mirror image.
     for (int u = 0; u < DNB / 4; ++u) {
         const int c = c0 + 4 * u;
         Dbuf[0][r][c] = (r < nb && c < nb) ? M[(size_t)(k0 + c) * n + k0 + r] : ((r == c) ? 1.0 : 0.0);
-        Mk[r][c] = (r < nb && j0 + c < n) ? M[(size_t)(j0 + c) * n + k0 + r] : 0.0;
-        Col[((size_t)b * DNB + c) * DNB + r] = (c < nb && j0 + r < n) ? M[(size_t)(k0 + c) * n + j0 + r] : 0.0;
+        if (b <= kb) Mk[r][c] = (r < nb && j0 + c < n) ? M[(size_t)(j0 + c) * n + k0 + r] : 0.0;
+        else Mk[c][r] = (c < nb && j0 + r < n) ? M[(size_t)(k0 + c) * n + j0 + r] : 0.0;          // M[k0 + c, j0 + r] = M[j0 + r, k0 + c]
+        if (b >= kb) Col[((size_t)b * DNB + c) * DNB + r] = (c < nb && j0 + r < n) ? M[(size_t)(k0 + c) * n + j0 + r] : 0.0;
+        else Col[((size_t)b * DNB + r) * DNB + c] = (r < nb && j0 + c < n) ? -M[(size_t)(j0 + c) * n + k0 + r] : 0.0;   // M[j0 + c, k0 + r] = -M[k0 + r, j0 + c]
     }
     __syncthreads();
     int cur = 0;
@@ -115,6 +123,7 @@ __global__ __launch_bounds__(256) void gj_apply_kernel(int n, int k0, int nb, in
     double (*As)[GJP2] = (double (*)[GJP2])gj_lds;
     double (*Xs)[GJP2] = (double (*)[GJP2])(gj_lds + (size_t)DNB * GJP2);
     const int kb = k0 / DNB, tid = threadIdx.x;
+    if (blockIdx.y > blockIdx.x) return;        // (tiles above the diagonal are not kept: half the products, half the traffic)
     for (int h = 0; h < 2; ++h) {
         const int bi = 2 * blockIdx.x + h, bj = 2 * blockIdx.y + h;
         for (int idx = tid; idx < DNB * DNB; idx += 256) {
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256) void gj_apply_kernel(int n, int k0, int nb, in
     __syncthreads();
     const int lane = tid & 63, w = tid >> 6, qi = w & 1, qj = w >> 1;
     const int bi = 2 * blockIdx.x + qi, bj = 2 * blockIdx.y + qj;
-    if (bi >= nt || bj >= nt) return;
+    if (bi >= nt || bj >= nt || bi < bj) return;
     const int i0 = bi * DNB, j0 = bj * DNB;
     if (bi == kb) {                         // pivot row <- Rp, pivot block <- Pinv: both sit in Xs
         if (lane < nb)
@@ -184,7 +193,9 @@ __global__ __launch_bounds__(256) void gj_apply_kernel(int n, int k0, int nb, in
 __global__ __launch_bounds__(256) void dense_symmetrize_kernel(int n, double *__restrict__ M) {
     const int i = blockIdx.x * 16 + (threadIdx.x & 15), j = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (i >= n || j >= n || i <= j) return;
-    const double v = 0.5 * (M[(size_t)j * n + i] + M[(size_t)i * n + j]);
+    // (off the diagonal blocks only the lower triangle was kept: it is mirrored; inside a diagonal block both
+    // triangles were, and are averaged)
+    const double v = (i / DNB == j / DNB) ? 0.5 * (M[(size_t)j * n + i] + M[(size_t)i * n + j]) : M[(size_t)j * n + i];
     M[(size_t)j * n + i] = v;
     M[(size_t)i * n + j] = v;
 }
