@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -37,6 +38,9 @@ void LAPACK_NAME(dgesvd)(const char *jobu, const char *jobvt, const int *m, cons
                          double *s, double *u, const int *ldu, double *vt, const int *ldvt, double *work,
                          const int *lwork, int *info);
 void LAPACK_NAME(dpotrf)(const char *uplo, const int *n, double *a, const int *lda, int *info);
+void LAPACK_NAME(dpbtrf)(const char *uplo, const int *n, const int *kd, double *ab, const int *ldab, int *info);
+void LAPACK_NAME(dpbtrs)(const char *uplo, const int *n, const int *kd, const int *nrhs, const double *ab, const int *ldab,
+                         double *b, const int *ldb, int *info);
 void LAPACK_NAME(dpotrs)(const char *uplo, const int *n, const int *nrhs, const double *a, const int *lda, double *b,
                          const int *ldb, int *info);
 double LAPACK_NAME(dlamch)(const char *cmach);
@@ -53,6 +57,8 @@ constexpr double SVD_EPS = 1e-10; // ContribTent::svd_eps, src/contrib.cpp:61
 constexpr double DIFF_EPS = 1e-10;// GLOBAL.diff_eps, inc/config.hpp:68
 
 int g_threads = 1;
+bool g_verbose = false;
+void note(const char *what, long long v = 0) { if (g_verbose) { std::fprintf(stderr, "cpu_ref: %s %lld\n", what, v); std::fflush(stderr); } }
 
 void parallel_for(int64_t n, const std::function<void(int64_t, int)> &fn) {   // dynamic, one item at a time
     const int T = (int)std::min<int64_t>(g_threads, std::max<int64_t>(n, 1));
@@ -288,6 +294,12 @@ struct Level {        // tg_data_t + interp_data_t (inc/tg_data.hpp:47-83, inc/i
     std::vector<Dense> evects;
     std::vector<Dense> mis_tent;          // mis_tent_interps
     std::vector<int> mis_k;               // mis_numcoarsedof
+    std::vector<double> sv_kept, sv_dropped;   // per MIS: smallest kept / largest dropped sigma / sigma_0 (the cut of xpack_orth_set)
+    // lean mode (fine level of problems whose dense AE matrices do not fit the host: 256^3 = 86 GB): the AE matrix is
+    // rebuilt from the element matrices whenever it is needed instead of being kept (same arithmetic, same order)
+    bool lean = false;
+    const double *elmat = nullptr;
+    int nde = 0;
     std::vector<int> mis_coloff;          // mis_coarsedofoffsets
     std::vector<double> dinv_neg, roots;
     std::vector<double> t0, r, xc, rc;    // solve-phase work vectors
@@ -297,6 +309,7 @@ struct Hier {
     std::vector<std::unique_ptr<Level>> levels;
     std::vector<double> coarse_chol;      // Cholesky factor of the coarsest operator (exact solve)
     int nc = 0;
+    int coarse_kd = -1;                   // >= 0: coarse_chol holds the BAND Cholesky factor (dpbtrf, lower, kd sub-diagonals)
     double setup_s = 0.0;
 };
 
@@ -329,6 +342,9 @@ Dense fine_AE_matrix(const Csr &A, int p, const Relations &rel, const double *el
     return out;
 }
 
+// AEs_stiffm[p] of a level, or (lean fine level) that matrix rebuilt into `tmp`; pos: ND entries of -1
+const Dense &AE_matrix(const Level &L, int p, std::vector<int> &pos, Dense &tmp);
+
 // a5: mbox_snd_D_sparse_from_sparse (src/mbox.cpp:913-949)
 std::vector<double> snd_D(const Dense &A) {
     const int n = A.r;
@@ -341,6 +357,12 @@ std::vector<double> snd_D(const Dense &A) {
         }
     }
     return D;
+}
+
+const Dense &AE_matrix(const Level &L, int p, std::vector<int> &pos, Dense &tmp) {
+    if (!L.lean) return L.AEs_stiffm[(size_t)p];
+    tmp = fine_AE_matrix(L.A, p, L.rel, L.elmat, L.nde, pos);
+    return tmp;
 }
 
 // a6: xpacks_calc_lower_eigens_dense (src/xpacks.cpp:222-314): dsygvx itype 1, range 'V' on (-1, theta], abstol =
@@ -377,7 +399,9 @@ void lower_eigens(const Dense &A, const std::vector<double> &D, double theta, st
 
 // a7/a8: ContribTent::contrib_mises (src/contrib.cpp:492-687), xpack_svd_dense_arr (src/xpacks.cpp:494-589),
 // xpack_orth_set (:591-620)
-void mis_block(const Level &L, int mis, std::vector<int> &pos, Dense &U, int &k) {
+void mis_block(const Level &L, int mis, std::vector<int> &pos, Dense &U, int &k, double &sv_kept, double &sv_dropped) {
+    sv_kept = INFINITY;
+    sv_dropped = 0.0;
     const Relations &rel = L.rel;
     const int dim = rel.mis_to_dof.size(mis);
     const int *mdofs = rel.mis_to_dof.row(mis);
@@ -435,6 +459,8 @@ void mis_block(const Level &L, int mis, std::vector<int> &pos, Dense &U, int &k)
     if (info != 0) throw std::runtime_error("dgesvd failed");
     const double eps = SVD_EPS * s[0];
     while (k < mn && s[k] > eps) ++k;
+    if (k > 0) sv_kept = s[k - 1] / s[0];
+    if (k < mn) sv_dropped = s[k] / s[0];
     U = Dense(dim, k);
     std::copy(u.begin(), u.begin() + (size_t)dim * k, U.v.begin());
 }
@@ -469,17 +495,25 @@ void build_level(Level &L, double theta, int nu_relax) {
     L.roots = sas_roots(nu_relax);
     L.evals.resize((size_t)np);
     L.evects.resize((size_t)np);
-    parallel_for(np, [&](int64_t p, int) {
-        const Dense &Ae = L.AEs_stiffm[(size_t)p];
-        lower_eigens(Ae, snd_D(Ae), theta, L.evals[(size_t)p], L.evects[(size_t)p]);
-    });
+    {
+        std::vector<std::vector<int>> apos((size_t)g_threads);
+        std::vector<Dense> atmp((size_t)g_threads);
+        parallel_for(np, [&](int64_t p, int t) {
+            if (L.lean && apos[t].empty()) apos[t].assign((size_t)rel.ND, -1);
+            const Dense &Ae = AE_matrix(L, (int)p, apos[t], atmp[t]);
+            lower_eigens(Ae, snd_D(Ae), theta, L.evals[(size_t)p], L.evects[(size_t)p]);
+        });
+    }
+    note("eigenproblems done");
     const int nm = rel.num_mises;
     L.mis_tent.resize((size_t)nm);
     L.mis_k.assign((size_t)nm, 0);
+    L.sv_kept.assign((size_t)nm, INFINITY);
+    L.sv_dropped.assign((size_t)nm, 0.0);
     std::vector<std::vector<int>> pos((size_t)g_threads);
     parallel_for(nm, [&](int64_t m, int t) {
         if (pos[t].empty()) pos[t].assign((size_t)rel.ND, -1);
-        mis_block(L, (int)m, pos[t], L.mis_tent[(size_t)m], L.mis_k[(size_t)m]);
+        mis_block(L, (int)m, pos[t], L.mis_tent[(size_t)m], L.mis_k[(size_t)m], L.sv_kept[(size_t)m], L.sv_dropped[(size_t)m]);
     });
     L.mis_coloff.assign((size_t)nm + 1, 0);
     for (int m = 0; m < nm; ++m) L.mis_coloff[m + 1] = L.mis_coloff[m] + L.mis_k[m];
@@ -507,6 +541,7 @@ void build_level(Level &L, double theta, int nu_relax) {
             if (std::fabs(v) > 0.0) { P.J[p] = L.mis_coloff[m] + c; P.V[p++] = v; }
         }
     }
+    note("MIS SVDs done, P assembled");
     L.R = csr_transpose(P);
     L.Ac = spgemm(L.R, spgemm(L.A, P));      // tg_coarse_matr == RAP (inc/tg.hpp:696-709)
     const size_t n = (size_t)L.A.nrows;
@@ -519,7 +554,8 @@ void build_level(Level &L, double theta, int nu_relax) {
 // ElementMatrixParallelCoarse::GetMatrix (src/elmat.cpp:105-195): P_loc^T AEs_stiffm[e] P_loc
 Dense coarse_element_matrix(int e, const Level &F, const Relations &rc, std::vector<int> &pos, std::vector<int> &cpos) {
     const Relations &rf = F.rel;
-    const Dense &Ae = F.AEs_stiffm[(size_t)e];
+    Dense aetmp;
+    const Dense &Ae = AE_matrix(F, e, pos, aetmp);
     const int nf = Ae.r;
     const int *fd = rf.AE_to_dof.row(e);
     for (int i = 0; i < nf; ++i) pos[fd[i]] = i;
@@ -581,7 +617,11 @@ void vcycle(Hier &H, int lev, const double *b, double *x) {
         L.xc = L.rc;
         const int one = 1;
         int info = 0;
-        if (H.nc) LAPACK_NAME(dpotrs)("L", &H.nc, &one, H.coarse_chol.data(), &H.nc, L.xc.data(), &H.nc, &info);
+        if (H.nc && H.coarse_kd >= 0) {
+            const int ldab = H.coarse_kd + 1;
+            LAPACK_NAME(dpbtrs)("L", &H.nc, &H.coarse_kd, &one, H.coarse_chol.data(), &ldab, L.xc.data(), &H.nc, &info);
+        } else if (H.nc)
+            LAPACK_NAME(dpotrs)("L", &H.nc, &one, H.coarse_chol.data(), &H.nc, L.xc.data(), &H.nc, &info);
     }
     spmv(L.P, L.xc.data(), L.t0.data());
     for (int i = 0; i < n; ++i) x[i] += L.t0[i];
@@ -601,12 +641,16 @@ extern "C" {
 struct cpu_ref_hier { Hier H; std::string err; };
 
 // ml_produce_data (src/ml.cpp:379-472) on raw arrays; same inputs as saamge_amd_ml_produce_data
-cpu_ref_hier *cpu_ref_setup(int n, const int *rowptr, const int *col, const double *val, int NE, int nde,
-                            const int *elem_to_dof, const double *elmat, const signed char *bdr, int ncoarsen,
-                            const int *const *partitions, const int *nparts, double theta, int nu_relax, int threads) {
+// thetas: one spectral tolerance per coarsening (first_theta / theta of MultilevelParameters, inc/ml.hpp:66-70);
+// lean != 0: the fine level's dense AE matrices are rebuilt on demand instead of kept
+cpu_ref_hier *cpu_ref_setup2(int n, const int *rowptr, const int *col, const double *val, int NE, int nde,
+                             const int *elem_to_dof, const double *elmat, const signed char *bdr, int ncoarsen,
+                             const int *const *partitions, const int *nparts, const double *thetas, int nu_relax,
+                             int threads, int lean) {
     cpu_ref_hier *h = new cpu_ref_hier;
     try {
         g_threads = std::max(1, threads);
+        g_verbose = std::getenv("CPU_REF_VERBOSE") != nullptr;
 #ifdef BLAS_SET_THREADS
         BLAS_SET_THREADS(1);
 #endif
@@ -624,15 +668,20 @@ cpu_ref_hier *cpu_ref_setup(int n, const int *rowptr, const int *col, const doub
         for (int e = 0; e <= NE; ++e) e2d.I[e] = e * nde;
         e2d.J.assign(elem_to_dof, elem_to_dof + (size_t)NE * nde);
         build_relations(L0.rel, std::move(e2d), partitions[0], nparts[0], n, bdr);
-        L0.AEs_stiffm.resize((size_t)nparts[0]);
-        {
+        L0.lean = lean != 0;
+        L0.elmat = elmat;
+        L0.nde = nde;
+        if (!L0.lean) L0.AEs_stiffm.resize((size_t)nparts[0]);
+        if (!L0.lean) {
             std::vector<std::vector<int>> pos((size_t)g_threads);
             parallel_for(nparts[0], [&](int64_t p, int t) {
                 if (pos[t].empty()) pos[t].assign((size_t)n, -1);
                 L0.AEs_stiffm[(size_t)p] = fine_AE_matrix(L0.A, (int)p, L0.rel, elmat, nde, pos[t]);
             });
         }
-        build_level(L0, theta, nu_relax);
+        note("level 0: relations built, AEs", nparts[0]);
+        build_level(L0, thetas[0], nu_relax);
+        note("level 0 done, coarse dim", L0.P.ncols);
         for (int k = 1; k < ncoarsen; ++k) {
             Level &F = *H.levels.back();
             H.levels.emplace_back(new Level);
@@ -677,22 +726,47 @@ cpu_ref_hier *cpu_ref_setup(int n, const int *rowptr, const int *col, const doub
                     L.AEs_stiffm[(size_t)p] = std::move(out);
                 });
             }
-            build_level(L, theta, nu_relax);
+            note("coarse level: AE matrices assembled, AEs", nparts[k]);
+            build_level(L, thetas[k], nu_relax);
+            note("coarse level done, coarse dim", L.P.ncols);
         }
         // exact coarsest solve (the reference's --coarse-direct, src/tg.cpp:989-997)
         const Csr &Ac = H.levels.back()->Ac;
         H.nc = Ac.nrows;
-        H.coarse_chol.assign((size_t)H.nc * H.nc, 0.0);
-        for (int i = 0; i < H.nc; ++i)
-            for (int64_t k = Ac.I[i]; k < Ac.I[i + 1]; ++k) H.coarse_chol[(size_t)Ac.J[k] * H.nc + i] = Ac.V[k];
         int info = 0;
-        if (H.nc) LAPACK_NAME(dpotrf)("L", &H.nc, H.coarse_chol.data(), &H.nc, &info);
+        const char *bm = std::getenv("CPU_REF_BAND_MIN");      // (tests lower it to reach the band path on small problems)
+        if (H.nc > (bm ? std::atoi(bm) : 8192)) {      // (2-level hierarchies of the large problems: 67 975 rows at 128^3) band Cholesky, still exact
+            int kd = 0;
+            for (int i = 0; i < H.nc; ++i)
+                for (int64_t k = Ac.I[i]; k < Ac.I[i + 1]; ++k) kd = std::max(kd, std::abs(i - Ac.J[k]));
+            H.coarse_kd = kd;
+            note("coarsest: band Cholesky, half bandwidth", kd);
+            const int ldab = kd + 1;
+            H.coarse_chol.assign((size_t)H.nc * ldab, 0.0);
+            for (int i = 0; i < H.nc; ++i)
+                for (int64_t k = Ac.I[i]; k < Ac.I[i + 1]; ++k)
+                    if (Ac.J[k] <= i) H.coarse_chol[(size_t)Ac.J[k] * ldab + (i - Ac.J[k])] = Ac.V[k];
+            LAPACK_NAME(dpbtrf)("L", &H.nc, &kd, H.coarse_chol.data(), &ldab, &info);     // (single-threaded BLAS: n kd^2 = 2.4e11 flop at 128^3)
+        } else {
+            H.coarse_chol.assign((size_t)H.nc * H.nc, 0.0);
+            for (int i = 0; i < H.nc; ++i)
+                for (int64_t k = Ac.I[i]; k < Ac.I[i + 1]; ++k) H.coarse_chol[(size_t)Ac.J[k] * H.nc + i] = Ac.V[k];
+            if (H.nc) LAPACK_NAME(dpotrf)("L", &H.nc, H.coarse_chol.data(), &H.nc, &info);
+        }
         if (info != 0) throw std::runtime_error("coarsest operator is not positive definite");
         H.setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     } catch (const std::exception &e) {
         h->err = e.what();
     }
     return h;
+}
+
+cpu_ref_hier *cpu_ref_setup(int n, const int *rowptr, const int *col, const double *val, int NE, int nde,
+                            const int *elem_to_dof, const double *elmat, const signed char *bdr, int ncoarsen,
+                            const int *const *partitions, const int *nparts, double theta, int nu_relax, int threads) {
+    std::vector<double> th((size_t)std::max(ncoarsen, 1), theta);
+    return cpu_ref_setup2(n, rowptr, col, val, NE, nde, elem_to_dof, elmat, bdr, ncoarsen, partitions, nparts, th.data(),
+                          nu_relax, threads, 0);
 }
 
 const char *cpu_ref_error(const cpu_ref_hier *h) { return h->err.empty() ? nullptr : h->err.c_str(); }
@@ -716,6 +790,21 @@ void cpu_ref_get_ints(const cpu_ref_hier *h, int l, int which, int *out) {
 void cpu_ref_get_evals_max(const cpu_ref_hier *h, int l, double *out) {
     const Level &L = *h->H.levels[(size_t)l];
     for (int p = 0; p < L.rel.nparts; ++p) out[p] = L.evals[(size_t)p].back();
+}
+// per MIS (num_mises): which 0 = smallest kept sigma / sigma_0 (inf: nothing kept or no SVD), 1 = largest dropped (0: none)
+void cpu_ref_get_sv_ratios(const cpu_ref_hier *h, int l, int which, double *out) {
+    const Level &L = *h->H.levels[(size_t)l];
+    const std::vector<double> &v = which == 0 ? L.sv_kept : L.sv_dropped;
+    std::copy(v.begin(), v.end(), out);
+}
+// trace of the level's Galerkin operator
+double cpu_ref_Ac_trace(const cpu_ref_hier *h, int l) {
+    const Csr &Ac = h->H.levels[(size_t)l]->Ac;
+    double s = 0.0;
+    for (int i = 0; i < Ac.nrows; ++i)
+        for (int64_t k = Ac.I[i]; k < Ac.I[i + 1]; ++k)
+            if (Ac.J[k] == i) s += Ac.V[k];
+    return s;
 }
 void cpu_ref_vcycle(cpu_ref_hier *h, const double *b, double *x) { vcycle(h->H, 0, b, x); }
 

@@ -24,6 +24,9 @@ def load():
             build()
         lib = C.CDLL(LIB_PATH)
         lib.cpu_ref_setup.restype = C.c_void_p
+        lib.cpu_ref_setup2.restype = C.c_void_p
+        lib.cpu_ref_Ac_trace.restype = C.c_double
+        lib.cpu_ref_Ac_trace.argtypes = [C.c_void_p, C.c_int]
         lib.cpu_ref_error.restype = C.c_char_p
         lib.cpu_ref_error.argtypes = [C.c_void_p]
         lib.cpu_ref_free.argtypes = [C.c_void_p]
@@ -41,23 +44,31 @@ def _p(a):
 class Hierarchy(object):
     """ml_produce_data on the host cores; same inputs as saamge_amd.capi.Hierarchy.from_problem."""
 
-    def __init__(self, prob, num_coarsenings=1, theta=0.003, nu_relax=3, threads=1):
+    def __init__(self, prob, num_coarsenings=1, theta=0.003, nu_relax=3, threads=1, lean=False):
+        """`theta`: one value or one per coarsening.  `prob`: a host Problem (scipy `A`) or the output of
+        problems.poisson3d_device(device="cpu") (`rowptr` / `col` / `val` tensors).  `lean`: rebuild the fine level's
+        dense AE matrices on demand (256^3: 86 GB otherwise)."""
         lib = load()
-        A = prob.A.tocsr()
-        self.n = A.shape[0]
-        rowptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
-        col = np.ascontiguousarray(A.indices, dtype=np.int32)
-        val = np.ascontiguousarray(A.data, dtype=np.float64)
-        e2d = np.ascontiguousarray(prob.elem_to_dof, dtype=np.int32)
-        elmat = np.ascontiguousarray(prob.elmat, dtype=np.float64)
-        bdr = np.ascontiguousarray(prob.bdr, dtype=np.int8)
-        parts = [np.ascontiguousarray(p, dtype=np.int32) for p in prob.partitions[:num_coarsenings]]
+        def host(a, dt):
+            return np.ascontiguousarray(a.numpy() if hasattr(a, "numpy") else a, dtype=dt)
+        if hasattr(prob, "A"):
+            A = prob.A.tocsr()
+            self.n = A.shape[0]
+            rowptr, col, val = host(A.indptr, np.int32), host(A.indices, np.int32), host(A.data, np.float64)
+        else:
+            self.n = int(prob.n)
+            rowptr, col, val = host(prob.rowptr, np.int32), host(prob.col, np.int32), host(prob.val, np.float64)
+        e2d = host(prob.elem_to_dof, np.int32)
+        self._elmat = elmat = host(prob.elmat, np.float64).reshape(e2d.shape[0], -1)    # (lean mode reads it during the setup only)
+        bdr = host(prob.bdr, np.int8)
+        parts = [host(p, np.int32) for p in prob.partitions[:num_coarsenings]]
         nparts = (C.c_int * len(parts))(*[int(p.max()) + 1 for p in parts])
         pp = (C.c_void_p * len(parts))(*[p.ctypes.data for p in parts])
-        self.h = C.c_void_p(lib.cpu_ref_setup(
+        thetas = np.ascontiguousarray(np.broadcast_to(np.asarray(theta, dtype=np.float64), (len(parts),)))
+        self.h = C.c_void_p(lib.cpu_ref_setup2(
             C.c_int(self.n), _p(rowptr), _p(col), _p(val), C.c_int(e2d.shape[0]), C.c_int(e2d.shape[1]), _p(e2d),
-            _p(elmat), _p(bdr), C.c_int(len(parts)), pp, nparts, C.c_double(theta), C.c_int(nu_relax),
-            C.c_int(threads)))
+            _p(elmat), _p(bdr), C.c_int(len(parts)), pp, nparts, _p(thetas), C.c_int(nu_relax),
+            C.c_int(threads), C.c_int(int(lean))))
         err = lib.cpu_ref_error(self.h)
         if err:
             raise RuntimeError("cpu_ref: " + err.decode())
@@ -92,6 +103,17 @@ class Hierarchy(object):
         out = np.zeros(self.level_info(l)["nparts"])
         load().cpu_ref_get_evals_max(self.h, C.c_int(l), _p(out))
         return out
+
+    def sv_ratios(self, l):
+        """per MIS: (smallest kept, largest dropped) singular value over the largest (the 1e-10 cut, src/xpacks.cpp:591-620)"""
+        nm = self.level_info(l)["num_mises"]
+        kept, dropped = np.zeros(nm), np.zeros(nm)
+        load().cpu_ref_get_sv_ratios(self.h, C.c_int(l), C.c_int(0), _p(kept))
+        load().cpu_ref_get_sv_ratios(self.h, C.c_int(l), C.c_int(1), _p(dropped))
+        return kept, dropped
+
+    def Ac_trace(self, l):
+        return float(load().cpu_ref_Ac_trace(self.h, C.c_int(l)))
 
     def vcycle(self, b):
         b = np.ascontiguousarray(b, dtype=np.float64)

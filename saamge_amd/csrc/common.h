@@ -212,6 +212,12 @@ struct DCsr {
     DBuf<int> sell_ntab, sell_tab;
     DBuf<unsigned> sell_code;
     DBuf<double> sell_vtab;
+    // census of the copy (build_sell): slices and stored entries per format [pair-coded, offset-coded, plain], the
+    // bytes of matrix data one application streams in the formats in use, and whether the short-chain path of the
+    // pair-coded slices may be used (32-bit byte offsets into x)
+    int64_t sell_class_slices[3] = {0, 0, 0}, sell_class_entries[3] = {0, 0, 0};
+    double sell_stream_bytes = 0.0;
+    bool sell_fast_ok = false;
 };
 
 // exclusive scans (mis.hip); out has n + 1 entries

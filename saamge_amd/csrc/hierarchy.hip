@@ -211,7 +211,10 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     hipStream_t mis_stream = side_stream(0);
     const int dev = current_device();
     std::exception_ptr mis_err;
-    std::thread mis_thread([&]() {
+    // SAAMGE_AMD_SERIAL=1: no worker threads anywhere in the setup (rocprofv3's counter collection aborts on launches
+    // from threads it has not seen: "stream_stack.cpp: Check failed"); the work runs in line, same streams
+    static const bool serial = std::getenv("SAAMGE_AMD_SERIAL") != nullptr;
+    auto mis_work = [&]() {
         try {
             adopt_device(dev);   // the worker allocates and copies: same GPU as the caller
             set_thread_stream(mis_stream);
@@ -229,7 +232,14 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
             }
             SA_HIP_CHECK(hipStreamSynchronize(mis_stream));
         } catch (...) { mis_err = std::current_exception(); }
-    });
+    };
+    std::thread mis_thread;
+    if (serial) {
+        mis_work();
+        set_thread_stream(s);
+    } else {
+        mis_thread = std::thread(mis_work);
+    }
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{mis_thread};
     const Relations &rel = L.rel;
     // SELL-64 copy of the level operator for the SpMV family + smoother data (smpr_init_poly_data,
@@ -294,7 +304,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     // BESIDE the assembly and the factorisations of the next chunk (SAAMGE_AMD_EIG_OVERLAP=0: one after the other).
     // Only eig_subspace_iterate runs there: it touches its own batch (the other workspace slot) and nothing else;
     // everything that assembles or allocates workspace stays on this thread.
-    static const bool overlap_env = [] { const char *e = std::getenv("SAAMGE_AMD_EIG_OVERLAP"); return !(e && e[0] == '0'); }();
+    static const bool overlap_env = [] { const char *e = std::getenv("SAAMGE_AMD_EIG_OVERLAP"); return !(e && e[0] == '0') && !std::getenv("SAAMGE_AMD_SERIAL"); }();
     const bool overlap_iter = overlap_env && !profiler().enabled;
     hipStream_t iter_stream = overlap_iter ? side_stream(3) : s;
     std::thread iter_thread;
@@ -531,7 +541,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     }
 
     // ---- MIS stage (ContribTent::contrib_mises) ----
-    mis_thread.join();
+    if (mis_thread.joinable()) mis_thread.join();
     if (mis_err) std::rethrow_exception(mis_err);
     tm.lap("MIS tables (join)", lev);
     const int nm = rel.num_mises;
@@ -667,7 +677,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     }
     // With another spectral level to come the product runs beside that level's element matrices and
     // eigenproblems (they need its size only); SAAMGE_AMD_NO_OVERLAP=1 and the profiled step keep it in line.
-    static const bool no_overlap = std::getenv("SAAMGE_AMD_NO_OVERLAP") != nullptr;
+    static const bool no_overlap = std::getenv("SAAMGE_AMD_NO_OVERLAP") != nullptr || std::getenv("SAAMGE_AMD_SERIAL") != nullptr;
     const bool defer = lev + 1 < P.num_coarsenings && P.nu_pro[lev] == 0 && world == 1 && !no_overlap &&
                        !profiler().enabled;
     if (defer) {

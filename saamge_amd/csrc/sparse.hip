@@ -49,30 +49,16 @@ __global__ __launch_bounds__(256) void spmv_kernel(int nrows, const roff_t *__re
 // stencil matrix -- carry ONE BYTE per entry instead of the 4-byte column: a code into the slice's
 // offset table, which sits one entry per lane in a register and is read with a cross-lane
 // permute.  9 instead of 12 bytes per stored entry on the level that dominates the solve.
-template <int MODE>
-__global__ __launch_bounds__(256) void sell_spmv_kernel(int nrows, int row0, const roff_t *__restrict__ sptr,
-                                                        const int *__restrict__ col,
-                                                        const double *__restrict__ val,
-                                                        const int *__restrict__ ntab,
-                                                        const int *__restrict__ tab,
-                                                        const unsigned *__restrict__ codes,
-                                                        const double *__restrict__ x,
-                                                        double *__restrict__ y,
-                                                        const double *__restrict__ b,
-                                                        const double *__restrict__ dinv, double scale,
-                                                        const double *__restrict__ xrow,
-                                                        const double *__restrict__ vtab) {
-    const long row = (long)blockIdx.x * 256 + threadIdx.x;
-    const int slice = (int)(row >> 6), lane = threadIdx.x & 63;
-    if ((long)slice * 64 >= nrows) return;
-    const roff_t beg = sptr[slice], end = sptr[slice + 1];
+// general path: any mix of slice formats, any width.  Returns the row's sum; `slice` / `gslice` are wave-uniform.
+__device__ __forceinline__ double sell_row_general(int lane, int grow, int gslice, roff_t beg, roff_t end, int nt,
+                                                   const int *__restrict__ col, const double *__restrict__ val,
+                                                   const int *__restrict__ tab, const unsigned *__restrict__ codes,
+                                                   const double *__restrict__ x, const double *__restrict__ vtab) {
     const int *cp = col + beg + lane;
     const double *vp = val + beg + lane;
     const int w = (int)((end - beg) >> 6);
     double s0 = 0.0, s1 = 0.0;
     int k = 0;
-    const int gslice = (row0 >> 6) + slice;
-    const int nt = ntab[gslice];
     if (nt >= 256) {
         // pair-coded slice: the byte indexes a table of (offset, VALUE) pairs -- at most 64 distinct ones in
         // the slice, which is every slice of a constant-coefficient stencil matrix (the whole fine level of the
@@ -80,7 +66,6 @@ __global__ __launch_bounds__(256) void sell_spmv_kernel(int nrows, int row0, con
         const int np = nt - 256;
         const int mytab = (lane < np) ? tab[(size_t)gslice * 64 + lane] : 0;
         const double myval = (lane < np) ? vtab[(size_t)gslice * 64 + lane] : 0.0;
-        const int grow = row0 + (int)row;
         const unsigned *wp = codes + ((size_t)(beg >> 2) + (size_t)gslice * 64 + lane);
         auto quad = [&](unsigned cw) {
             const int i0 = (int)(cw & 255u), i1 = (int)((cw >> 8) & 255u), i2 = (int)((cw >> 16) & 255u), i3 = (int)(cw >> 24);
@@ -121,7 +106,6 @@ __global__ __launch_bounds__(256) void sell_spmv_kernel(int nrows, int row0, con
         }
     } else if (nt >= 0) {
         const int mytab = tab[(size_t)gslice * 64 + lane];
-        const int grow = row0 + (int)row;                  // global row: columns are row + offset
         const unsigned *wp = codes + ((size_t)(beg >> 2) + (size_t)gslice * 64 + lane);
         for (; k + 4 <= w; k += 4) {
             const unsigned cw = __builtin_nontemporal_load(wp + 16 * k);
@@ -151,17 +135,133 @@ __global__ __launch_bounds__(256) void sell_spmv_kernel(int nrows, int row0, con
         s1 = fma(v3, x[c3], s1);
     }
     for (; k < w; ++k) s0 = fma(__builtin_nontemporal_load(vp + 64 * k), x[__builtin_nontemporal_load(cp + 64 * k)], s0);
-    const double sum = s0 + s1;
-    if (row >= nrows) return;
+    return s0 + s1;
+}
+
+struct alignas(16) PairEntry {
+    int off, pad;
+    double val;
+};
+
+// The SELL-64 kernel of the whole SpMV family.  One wavefront per slice, one lane per row.
+//   * Consecutive workgroups are dealt to the XCDs round-robin (block -> XCD = block % 8, position = block / 8):
+//     XCD k walks the k-th contiguous eighth of the slices, so that the x-planes a stencil row touches are fetched into
+//     ONE L2 instead of all eight (speed only; any placement gives the same result).
+//   * The slice is wave-uniform (readfirstlane): its offsets, width and format come through the scalar cache.
+//   * Pair-coded slices of at most 32 entries per row (every slice of a constant-coefficient stencil: the fine level
+//     of the headline problem) take the short-chain path: every code word of the row and the epilogue operands
+//     (b, D^-1, y) are requested up front, the gathers of up to 16 entries are in flight together (SGPR base + 32-bit
+//     lane offset) and the value permutes run while they are.  The general path looked up and gathered four entries at a
+//     time and waited for each group before the next four permutes: seven serial gather latencies per row.
+//   * Everything else (offset-coded, plain, wide rows) goes through sell_row_general.
+// Same arithmetic and the same order of additions on both paths (two accumulators, even / odd entries).
+template <int MODE>
+__global__ __launch_bounds__(256) void sell_spmv_kernel(int nrows, int row0, int nblocks, int per_xcd, int fast_ok,
+                                                        const roff_t *__restrict__ sptr,
+                                                        const int *__restrict__ col,
+                                                        const double *__restrict__ val,
+                                                        const int *__restrict__ ntab,
+                                                        const int *__restrict__ tab,
+                                                        const unsigned *__restrict__ codes,
+                                                        const double *__restrict__ x,
+                                                        double *__restrict__ y,
+                                                        const double *__restrict__ b,
+                                                        const double *__restrict__ dinv, double scale,
+                                                        const double *__restrict__ xrow,
+                                                        const double *__restrict__ vtab) {
+    __shared__ PairEntry ltab[4][64];
+    const int blk = per_xcd > 0 ? (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (blk >= nblocks) return;
+    const long row = (long)blk * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int slice = __builtin_amdgcn_readfirstlane((int)(row >> 6));
+    if ((long)slice * 64 >= nrows) return;
+    const roff_t beg = sptr[slice], end = sptr[slice + 1];
+    const int gslice = (row0 >> 6) + slice;
+    const int nt = ntab[gslice];
+    const int w = (int)((end - beg) >> 6);
+    const bool live = row < nrows;
+    const int grow = row0 + (int)row;
+    double e_b = 0.0, e_d = 0.0, e_x = 0.0, sum;
+    if (fast_ok && nt >= 256 && w <= 32) {
+        const int np = nt - 256;
+        const unsigned *wp = codes + ((size_t)(beg >> 2) + (size_t)gslice * 64 + lane);
+        unsigned cws[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cws[q] = (4 * q < w) ? __builtin_nontemporal_load(wp + 64 * q) : 0u;
+        const int mytab = (lane < np) ? tab[(size_t)gslice * 64 + lane] : 0;
+        const double myval = (lane < np) ? vtab[(size_t)gslice * 64 + lane] : 0.0;
+        if (MODE == MODE_RESIDUAL && live) e_b = b[row];
+        if (MODE == MODE_ADD && live) e_x = y[row];
+        if (MODE == MODE_SMOOTH && live) { e_b = b[row]; e_d = dinv[row]; e_x = xrow[row]; }
+        // The slice's (offset, value) table goes to LDS, one 16-byte entry per lane, in a region private to this
+        // wavefront: an entry then costs ONE ds_read_b128 (lanes of a stencil slice mostly read the same entry: a
+        // broadcast) instead of three cross-lane permutes.  Counters on the 257^3 level with the permutes: 96 LDS
+        // instructions per wavefront at 8 cycles each = 86 % of the kernel's cycles on every CU -- the LDS pipe, not
+        // HBM (2.9 TB/s), was what bounded the smoother.
+        PairEntry *lt = ltab[threadIdx.x >> 6];
+        lt[lane] = PairEntry{mytab, 0, myval};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const char *xb = (const char *)x;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (16 * h < w) {
+                double xs[16], vs[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int idx = (int)((cws[4 * h + (j >> 2)] >> (8 * (j & 3))) & 255u);
+                    const PairEntry e = lt[idx];
+                    vs[j] = e.val;
+                    if (fast_ok == 2 && (j % 3)) xs[j] = (double)e.off;      // LAB: a third of the gathers
+                    else xs[j] = *(const double *)(xb + ((unsigned)(grow + e.off) << 3));
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const double v = vs[j];
+                    if (16 * h + j < w) {      // (whole groups of four alternate between the accumulators, the tail goes to s0)
+                        if ((j & 1) && 16 * h + j < (w & ~3)) s1 = fma(v, xs[j], s1);
+                        else s0 = fma(v, xs[j], s0);
+                    }
+                }
+            }
+        }
+        sum = s0 + s1;
+    } else {
+        sum = sell_row_general(lane, grow, gslice, beg, end, nt, col, val, tab, codes, x, vtab);
+        if (MODE == MODE_RESIDUAL && live) e_b = b[row];
+        if (MODE == MODE_ADD && live) e_x = y[row];
+        if (MODE == MODE_SMOOTH && live) { e_b = b[row]; e_d = dinv[row]; e_x = xrow[row]; }
+    }
+    if (!live) return;
     if (MODE == MODE_PLAIN) {
         y[row] = sum;
     } else if (MODE == MODE_RESIDUAL) {
-        y[row] = b[row] - sum;
+        y[row] = e_b - sum;
     } else if (MODE == MODE_ADD) {
-        y[row] += sum;
+        y[row] = e_x + sum;
     } else {
-        y[row] = xrow[row] + scale * (dinv[row] * (sum - b[row]));
+        y[row] = e_x + scale * (e_d * (sum - e_b));
     }
+}
+
+// Slice census of a SELL copy: cls[0..2] = pair-coded / offset-coded / plain slices, cls[3..5] = their stored entries
+// (64 x width), cls[6] = code words of the coded slices, cls[7] = widest slice
+__global__ __launch_bounds__(256) void sell_census_kernel(int nslices, const roff_t *__restrict__ sptr,
+                                                          const int *__restrict__ ntab,
+                                                          unsigned long long *__restrict__ cls) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= nslices) return;
+    const int w = (int)((sptr[s + 1] - sptr[s]) >> 6);
+    const int nt = ntab[s];
+
+    const int c = nt >= 256 ? 0 : (nt >= 0 ? 1 : 2);
+    atomicAdd(cls + c, 1ull);
+    atomicAdd(cls + 3 + c, (unsigned long long)w * 64ull);
+    if (c < 2) atomicAdd(cls + 6, (unsigned long long)((w + 3) / 4) * 64ull);
+    atomicMax(cls + 7, (unsigned long long)w);
 }
 
 __global__ __launch_bounds__(256) void sell_width_kernel(int nrows, const roff_t *__restrict__ rowptr,
@@ -344,6 +444,26 @@ void build_sell(hipStream_t s, DCsr &A) {
                            A.sell_col.p, A.sell_val.p, A.sell_ntab.p, A.sell_tab.p, A.sell_vtab.p, A.sell_code.p,
                            no_vals ? 0 : 1);
     SA_HIP_CHECK(hipGetLastError());
+    // what the copy holds, per slice format: the bytes one application has to move (the roofline of the SpMV family
+    // prices THESE, bench.py) and whether the all-pair-coded fast path applies
+    DBuf<unsigned long long> cls(8);
+    SA_HIP_CHECK(hipMemsetAsync(cls.p, 0, 8 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(sell_census_kernel, dim3(div_up(A.nslices, 256)), dim3(256), 0, s, A.nslices, A.sell_ptr.p,
+                       A.sell_ntab.p, cls.p);
+    SA_HIP_CHECK(hipGetLastError());
+    unsigned long long h[8];
+    SA_HIP_CHECK(hipMemcpyAsync(h, cls.p, sizeof(h), hipMemcpyDeviceToHost, s));
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+    for (int c = 0; c < 3; ++c) { A.sell_class_slices[c] = (int64_t)h[c]; A.sell_class_entries[c] = (int64_t)h[3 + c]; }
+    // codes 4 B per word, tables 4 (+8) B per lane of a coded slice, values / columns of the formats that stream them,
+    // 8 B slice offset + 4 B table size per slice
+    A.sell_stream_bytes = 4.0 * (double)h[6] + 12.0 * 64.0 * (double)h[0] + 4.0 * 64.0 * (double)h[1] +
+                          8.0 * (double)h[4] + 12.0 * (double)h[5] + 12.0 * (double)A.nslices;
+    static const bool no_fast = std::getenv("SAAMGE_AMD_SELL_PAIR_FAST") && std::atoi(std::getenv("SAAMGE_AMD_SELL_PAIR_FAST")) == 0;
+    A.sell_fast_ok = !no_fast && A.ncols < (1 << 29);      // (32-bit byte offsets into x on the short-chain path)
+    if (std::getenv("SAAMGE_AMD_SELL_VERBOSE"))
+        std::fprintf(stderr, "build_sell: %d rows, slices pair/offset/plain %lld/%lld/%lld, widest %llu, stream bytes %.0f, fast path %d\n",
+                     A.nrows, (long long)h[0], (long long)h[1], (long long)h[2], h[7], A.sell_stream_bytes, (int)A.sell_fast_ok);
     A.has_sell = true;
 }
 
@@ -361,10 +481,12 @@ static void launch_spmv(hipStream_t s, const DCsr &A, RowRange rr, const double 
     if (dinv) dinv += row0;
     const double *xrow = x + row0;
     if (A.has_sell) {
-        const int grid = div_up((long)div_up(nrows, 64) * 64, 256);
-        hipLaunchKernelGGL((sell_spmv_kernel<MODE>), dim3(grid), dim3(256), 0, s, nrows, row0,
-                           A.sell_ptr.p + row0 / 64, A.sell_col.p, A.sell_val.p, A.sell_ntab.p, A.sell_tab.p,
-                           A.sell_code.p, x, y, b, dinv, scale, xrow, A.sell_vtab.p);
+        const int nblocks = div_up((long)div_up(nrows, 64) * 64, 256);
+        static const bool no_xcd = std::getenv("SAAMGE_AMD_SELL_XCD") && std::atoi(std::getenv("SAAMGE_AMD_SELL_XCD")) == 0;
+        const int per_xcd = no_xcd ? 0 : div_up(nblocks, 8);     // (0: blocks in launch order)
+        hipLaunchKernelGGL((sell_spmv_kernel<MODE>), dim3(no_xcd ? nblocks : per_xcd * 8), dim3(256), 0, s, nrows, row0, nblocks, per_xcd,
+                           (int)A.sell_fast_ok * (std::getenv("SAAMGE_AMD_LAB") ? 2 : 1), A.sell_ptr.p + row0 / 64, A.sell_col.p, A.sell_val.p, A.sell_ntab.p,
+                           A.sell_tab.p, A.sell_code.p, x, y, b, dinv, scale, xrow, A.sell_vtab.p);
         SA_HIP_CHECK(hipGetLastError());
         return;
     }

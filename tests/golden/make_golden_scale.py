@@ -15,6 +15,11 @@ A ratio within a decade of 1e-10 names a MIS whose k is round-off dependent.
     python tests/golden/make_golden_scale.py [case ...]      (cases: see CASES; default all)
 
 Run time on 8 cores: 64x64x32 ~1 min, 96x96x64 ~4 min, 128^3 ~15 min (about 25 GB of RAM).
+
+The BASELINE-size cases (`base_*`: BASELINE.json configs 2, 3 and 4 exactly as bench.py runs them) go through the
+threaded C++ restatement oracle/cpu_ref.cpp (held to the Python oracle by tests/test_cpu_ref.py) -- the same
+LAPACK dsygvx / dgesvd, the fine level's dense AE matrices rebuilt on demand ("lean": 256^3 would need 86 GB):
+base_poisson128_2level ~3 min, base_aniso128 ~10 min, base_poisson256 ~25 min on 6-8 cores (about 45 GB of RAM).
 """
 import os
 import sys
@@ -38,6 +43,52 @@ CASES = {
     "scale_96x96x64": ((96, 96, 64), None, 0.003),
     "scale_128": ((128, 128, 128), None, 0.003),
 }
+
+
+# BASELINE.json configs at their full sizes, in bench.py's shapes (WORKLOADS there): name -> (n, K, thetas per
+# coarsening, coarse blocks)
+BASE_CASES = {
+    "base_poisson128_2level": (128, (1.0, 1.0, 1.0), [0.003], []),                        # config 2
+    "base_poisson256": (256, (1.0, 1.0, 1.0), [0.003, 0.003], [(8, 8, 4)]),                # config 3 (the headline)
+    "base_aniso128": (128, (1.0, 1.0, 1000.0), [1e-4, 1e-5], [(4, 4, 2)]),                # config 4
+    "base_aniso128_blk884": (128, (1.0, 1.0, 1000.0), [1e-4, 1e-4], [(8, 8, 4)]),         # config 4, the other configs' coarse blocks
+}
+
+
+def run_base(name):
+    from oracle import cpu_ref
+    n, K, thetas, cblk = BASE_CASES[name]
+    threads = int(os.environ.get("GOLDEN_THREADS", max(1, min(len(os.sched_getaffinity(0)), 16))))
+    t0 = time.perf_counter()
+    prob = pr.poisson3d_device(n, blk=(8, 8, 4), coarse_blk=cblk, K=K, device="cpu")
+    print("%s: problem generated in %.1f s" % (name, time.perf_counter() - t0), flush=True)
+    h = cpu_ref.Hierarchy(prob, num_coarsenings=len(thetas), theta=thetas, nu_relax=3, threads=threads, lean=True)
+    b = prob.b.numpy()
+    x, it, conv, hist = h.pcg(b, rel_tol=1e-8, max_iter=200)
+    rowptr, col, val = prob.rowptr.numpy(), prob.col.numpy(), prob.val.numpy()
+    import scipy.sparse as sp
+    A = sp.csr_matrix((val, col, rowptr), shape=(prob.n, prob.n))
+    out = {"dims": np.array((n,) * 3, dtype=np.int32), "K": np.array(K), "thetas": np.array(thetas),
+           "coarse_blk": np.array(cblk, dtype=np.int32).reshape(-1, 3),
+           "level_dims": np.array(h.level_dims(), dtype=np.int64),
+           "pcg_iters": np.array([it], dtype=np.int32), "pcg_hist": np.array(hist), "converged": np.array([conv]),
+           "x_norm": np.array([np.linalg.norm(x)]),
+           "relres": np.array([np.linalg.norm(b - A @ x) / np.linalg.norm(b)])}
+    near = []
+    for l in range(h.num_levels):
+        out["l%d_ae_m" % l] = h.ae_m(l).astype(np.int16)
+        out["l%d_mis_k" % l] = h.mis_k(l).astype(np.int16)
+        out["l%d_evals_max_kept" % l] = h.evals_max(l)
+        kept, dropped = h.sv_ratios(l)
+        out["l%d_sv_min_kept" % l] = kept
+        out["l%d_sv_max_dropped" % l] = dropped
+        out["l%d_Ac_trace" % l] = np.array([h.Ac_trace(l)])
+        near.append(int(np.sum((kept < 1e-9) | (dropped > 1e-11))))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("%s: dims %s, %d its (converged %s), setup %.1f s, solve %.1f s on %d threads, MISes with a singular value within "
+          "a decade of the cut: %s" % (name, out["level_dims"].tolist(), it, conv, h.setup_s, h.solve_s, threads, near),
+          flush=True)
+    h.close()
 
 
 def cut_ratios(lv):
@@ -88,4 +139,4 @@ def run(name):
 
 if __name__ == "__main__":
     for c in (sys.argv[1:] or list(CASES)):
-        run(c)
+        (run_base if c in BASE_CASES else run)(c)

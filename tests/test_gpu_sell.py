@@ -35,8 +35,10 @@ for name, A in mats.items():
 """
 
 
-def _run(codes):
+def _run(codes, pair_fast=None):
     env = dict(os.environ, SAAMGE_AMD_SPMV_SELL="1")
+    if pair_fast is not None:
+        env["SAAMGE_AMD_SELL_PAIR_FAST"] = str(pair_fast)
     if codes is not None:
         env["SAAMGE_AMD_SELL_CODES"] = str(codes)
     o = subprocess.run([sys.executable, "-c", _CODE % ROOT], env=env, capture_output=True, text=True, timeout=600)
@@ -50,7 +52,9 @@ def _run(codes):
 
 
 def test_sell_formats_match_scipy_and_each_other():
-    full = _run(None)          # pair codes where possible
+    full = _run(None)          # pair codes where possible (all-pair operators: the fast kernel, sell_pair_kernel)
+    slow = _run(None, 0)       # the same through the general kernel
+    assert {k: v[1] for k, v in slow.items()} == {k: v[1] for k, v in full.items()}      # identical bits
     offs = _run(1)             # offset codes only
     plain = _run(0)            # no codes
     assert set(full) == set(offs) == set(plain) and len(full) == 5

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Times the fine-level smoother application (10 fused steps x + tau^-1 D^-1 (b - A x)) and the PCG solve on an
+existing hierarchy:  python tools/smoother_bench.py [n] [levels] [coef]
+Prints per-step microseconds of level 0 and the solve time; used to compare kernel variants (environment switches)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from saamge_amd import capi  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+levels = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+prob = bench.build_problem(n, levels, "cuda:0")
+params = capi.default_params(num_coarsenings=levels - 1)
+h, x, it, conv, hist = bench.one_step(capi, prob, params)
+b = prob.b
+for lev in range(levels - 1):
+    nl = h.level_info(lev)["n"]
+    bb = torch.randn(nl, dtype=torch.float64, device="cuda:0")
+    xx = torch.zeros_like(bb)
+    h.smoother(lev, bb, xx)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        h.smoother(lev, bb, xx)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (reps * 10)
+    print("level %d: %d rows, smoother step %.1f us" % (lev, nl, us), flush=True)
+if 'quick' in sys.argv:
+    h.close()
+    sys.exit(0)
+if 'pcg1' in sys.argv:       # one solve (for counter passes: the SpMV / residual / update kernels of the PCG loop)
+    h.pcg(b, torch.zeros_like(b), rel_tol=1e-8, max_iter=200)
+    torch.cuda.synchronize()
+    h.close()
+    sys.exit(0)
+for rep in range(3):
+    x = torch.zeros_like(b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, it, conv, hist = h.pcg(b, x, rel_tol=1e-8, max_iter=200)
+    torch.cuda.synchronize()
+    print("solve %.1f ms, %d iterations, last (Br,r) %.6e" % ((time.perf_counter() - t0) * 1e3, it, hist[-1]), flush=True)
+capi.profile(True)
+capi.profile_reset()
+x = torch.zeros_like(b)
+h.pcg(b, x, rel_tol=1e-8, max_iter=200)
+capi.profile(False)
+for s in sorted(capi.profile_stats(), key=lambda s: -s["ms"])[:8]:
+    print("  %-24s %9.3f ms %6d launches %9.1f us/launch" % (s["name"], s["ms"], s["launches"], 1e3 * s["ms"] / s["launches"]))
+h.close()
