@@ -189,6 +189,9 @@ inline hvec<T> fetch_host(const T *src, size_t n, hipStream_t s) {
 // 96^3: 4.2e9) -- the reference splits such an operator over MPI ranks, here one GPU holds it.
 typedef int64_t roff_t;
 
+constexpr int SELL_SEG_MAX = 16;      // segments per staged tile
+constexpr int SELL_STAGE_CAP = 3584;  // doubles of x one tile may stage (28 KB of LDS)
+
 // Device CSR matrix.
 struct DCsr {
     int nrows = 0, ncols = 0;
@@ -218,6 +221,16 @@ struct DCsr {
     int64_t sell_class_slices[3] = {0, 0, 0}, sell_class_entries[3] = {0, 0, 0};
     double sell_stream_bytes = 0.0;
     bool sell_fast_ok = false;
+    // x-staging of the pair-coded slices (sell_stage_kernel): a TILE = 4 consecutive slices = the 256 rows of one workgroup.
+    // Where the column offsets of a tile cluster into few runs (a stencil: 9), the x-entries those runs touch are
+    // contiguous segments: sell_tile_nseg[t] of them (0: not staged), sell_tile_seg[SELL_SEG_MAX t + s] = {first offset
+    // relative to the tile's first row, doubles to load}; the workgroup loads them into LDS with wide coalesced loads
+    // and the products read LDS instead of gathering from global memory.  sell_stage_cap = doubles of the largest tile.
+    DBuf<int> sell_tile_nseg;
+    DBuf<int2> sell_tile_seg;
+    int sell_stage_cap = 0;
+    DBuf<int> sell_unstaged;       // tiles left to the gather kernel (sell_nunstaged of them)
+    int sell_nunstaged = 0;
 };
 
 // exclusive scans (mis.hip); out has n + 1 entries

@@ -3,6 +3,7 @@
 // the XCD L2 keeps the gathered x entries, fused epilogues for the residual, the
 // prolongation-add and the polynomial-smoother step.  HBM-bound: 12 B per nonzero.
 #include "sparse.h"
+#include <climits>
 
 namespace saamge_amd {
 
@@ -143,38 +144,35 @@ struct alignas(16) PairEntry {
     double val;
 };
 
-// The SELL-64 kernel of the whole SpMV family.  One wavefront per slice, one lane per row.
-//   * Consecutive workgroups are dealt to the XCDs round-robin (block -> XCD = block % 8, position = block / 8):
-//     XCD k walks the k-th contiguous eighth of the slices, so that the x-planes a stencil row touches are fetched into
-//     ONE L2 instead of all eight (speed only; any placement gives the same result).
+// ---- the SELL-64 kernels of the whole SpMV family: one wavefront per slice, one lane per row ----------------------
+// What bounds them (MI355X, 257^3 rows x 27 entries, counters + tools/spmv_lab, tools/vmem_rate): not HBM.  A
+// vector-memory wave-instruction of 8 or 16 bytes per lane occupies the CU's address / L1 path for ~17 cycles
+// whatever it returns (4 bytes per lane: 5-9), and a row-per-lane SpMV issues one such instruction PER STORED ENTRY
+// for the gather of x: 27 + 17 others per slice = ~620 of the ~890 cycles a CU spends per slice, at 2.9 TB/s of the
+// bytes the format needs (a pure stream of the same bytes: 5.1 TB/s).  Before that the cross-lane permutes of the
+// table look-ups (96 LDS instructions x 8 cycles per slice) held the same place.  Hence:
+//   * sell_staged_kernel: where the offsets of a 256-row tile cluster into few runs, the workgroup loads the x-segments
+//     those runs touch into LDS with 16-byte coalesced loads (27 gathers per wavefront -> ~7 loads) and the products
+//     read LDS; the slice's (offset, value) table sits in LDS too, one 16-byte entry per lane, read with plain LDS
+//     loads (a broadcast for the lanes that share an entry) instead of three permutes per entry.
+//   * sell_slice: the same per slice with gathers from global memory (tiles that cannot be staged), up to 16 in
+//     flight; offset-coded, plain and wide slices go through sell_row_general.
+//   * Consecutive workgroups are dealt to the XCDs round-robin (block -> XCD = block % 8, position = block / 8): XCD k
+//     walks the k-th contiguous eighth of the tiles, so that the x-planes a stencil row touches are fetched into ONE L2
+//     instead of all eight (PMC: 2.0 -> 1.14 GB per launch, the format's own bytes being 1.12 GB; speed only, any
+//     placement gives the same result).
 //   * The slice is wave-uniform (readfirstlane): its offsets, width and format come through the scalar cache.
-//   * Pair-coded slices of at most 32 entries per row (every slice of a constant-coefficient stencil: the fine level
-//     of the headline problem) take the short-chain path: every code word of the row and the epilogue operands
-//     (b, D^-1, y) are requested up front, the gathers of up to 16 entries are in flight together (SGPR base + 32-bit
-//     lane offset) and the value permutes run while they are.  The general path looked up and gathered four entries at a
-//     time and waited for each group before the next four permutes: seven serial gather latencies per row.
-//   * Everything else (offset-coded, plain, wide rows) goes through sell_row_general.
-// Same arithmetic and the same order of additions on both paths (two accumulators, even / odd entries).
+// Same arithmetic and the same order of additions on every path (two accumulators over whole groups of four entries,
+// the tail into the first).
 template <int MODE>
-__global__ __launch_bounds__(256) void sell_spmv_kernel(int nrows, int row0, int nblocks, int per_xcd, int fast_ok,
-                                                        const roff_t *__restrict__ sptr,
-                                                        const int *__restrict__ col,
-                                                        const double *__restrict__ val,
-                                                        const int *__restrict__ ntab,
-                                                        const int *__restrict__ tab,
-                                                        const unsigned *__restrict__ codes,
-                                                        const double *__restrict__ x,
-                                                        double *__restrict__ y,
-                                                        const double *__restrict__ b,
-                                                        const double *__restrict__ dinv, double scale,
-                                                        const double *__restrict__ xrow,
-                                                        const double *__restrict__ vtab) {
-    __shared__ PairEntry ltab[4][64];
-    const int blk = per_xcd > 0 ? (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    if (blk >= nblocks) return;
-    const long row = (long)blk * 256 + threadIdx.x;
+__device__ __forceinline__ void sell_slice(PairEntry *lt, int nrows, int row0, long row, int slice, int fast_ok,
+                                           const roff_t *__restrict__ sptr, const int *__restrict__ col,
+                                           const double *__restrict__ val, const int *__restrict__ ntab,
+                                           const int *__restrict__ tab, const unsigned *__restrict__ codes,
+                                           const double *__restrict__ x, double *__restrict__ y,
+                                           const double *__restrict__ b, const double *__restrict__ dinv, double scale,
+                                           const double *__restrict__ xrow, const double *__restrict__ vtab) {
     const int lane = threadIdx.x & 63;
-    const int slice = __builtin_amdgcn_readfirstlane((int)(row >> 6));
     if ((long)slice * 64 >= nrows) return;
     const roff_t beg = sptr[slice], end = sptr[slice + 1];
     const int gslice = (row0 >> 6) + slice;
@@ -194,13 +192,7 @@ __global__ __launch_bounds__(256) void sell_spmv_kernel(int nrows, int row0, int
         if (MODE == MODE_RESIDUAL && live) e_b = b[row];
         if (MODE == MODE_ADD && live) e_x = y[row];
         if (MODE == MODE_SMOOTH && live) { e_b = b[row]; e_d = dinv[row]; e_x = xrow[row]; }
-        // The slice's (offset, value) table goes to LDS, one 16-byte entry per lane, in a region private to this
-        // wavefront: an entry then costs ONE ds_read_b128 (lanes of a stencil slice mostly read the same entry: a
-        // broadcast) instead of three cross-lane permutes.  Counters on the 257^3 level with the permutes: 96 LDS
-        // instructions per wavefront at 8 cycles each = 86 % of the kernel's cycles on every CU -- the LDS pipe, not
-        // HBM (2.9 TB/s), was what bounded the smoother.
-        PairEntry *lt = ltab[threadIdx.x >> 6];
-        lt[lane] = PairEntry{mytab, 0, myval};
+        lt[lane] = PairEntry{mytab, 0, myval};      // (a region private to this wavefront)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -215,15 +207,13 @@ __global__ __launch_bounds__(256) void sell_spmv_kernel(int nrows, int row0, int
                     const int idx = (int)((cws[4 * h + (j >> 2)] >> (8 * (j & 3))) & 255u);
                     const PairEntry e = lt[idx];
                     vs[j] = e.val;
-                    if (fast_ok == 2 && (j % 3)) xs[j] = (double)e.off;      // LAB: a third of the gathers
-                    else xs[j] = *(const double *)(xb + ((unsigned)(grow + e.off) << 3));
+                    xs[j] = *(const double *)(xb + ((unsigned)(grow + e.off) << 3));
                 }
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    const double v = vs[j];
-                    if (16 * h + j < w) {      // (whole groups of four alternate between the accumulators, the tail goes to s0)
-                        if ((j & 1) && 16 * h + j < (w & ~3)) s1 = fma(v, xs[j], s1);
-                        else s0 = fma(v, xs[j], s0);
+                    if (16 * h + j < w) {
+                        if ((j & 1) && 16 * h + j < (w & ~3)) s1 = fma(vs[j], xs[j], s1);
+                        else s0 = fma(vs[j], xs[j], s0);
                     }
                 }
             }
@@ -247,21 +237,305 @@ __global__ __launch_bounds__(256) void sell_spmv_kernel(int nrows, int row0, int
     }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(256) void sell_spmv_kernel(int nrows, int row0, int nblocks, int per_xcd, int fast_ok,
+                                                        const roff_t *__restrict__ sptr,
+                                                        const int *__restrict__ col,
+                                                        const double *__restrict__ val,
+                                                        const int *__restrict__ ntab,
+                                                        const int *__restrict__ tab,
+                                                        const unsigned *__restrict__ codes,
+                                                        const double *__restrict__ x,
+                                                        double *__restrict__ y,
+                                                        const double *__restrict__ b,
+                                                        const double *__restrict__ dinv, double scale,
+                                                        const double *__restrict__ xrow,
+                                                        const double *__restrict__ vtab) {
+    __shared__ PairEntry ltab[4][64];
+    const int blk = per_xcd > 0 ? (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (blk >= nblocks) return;
+    const long row = (long)blk * 256 + threadIdx.x;
+    const int slice = __builtin_amdgcn_readfirstlane((int)(row >> 6));
+    sell_slice<MODE>(ltab[threadIdx.x >> 6], nrows, row0, row, slice, fast_ok, sptr, col, val, ntab, tab, codes, x, y, b,
+                     dinv, scale, xrow, vtab);
+}
+
+// Staged tiles only (the others are left to sell_tiles_kernel).  row0 must be a multiple of 256 (tiles are global);
+// dynamic LDS: stage_cap doubles + 4 slice tables.
+template <int MODE>
+__global__ __launch_bounds__(256) void sell_staged_kernel(int nrows, int row0, int nblocks, int per_xcd, int stage_cap,
+                                                          int ncols, const roff_t *__restrict__ sptr,
+                                                          const int *__restrict__ ntab,
+                                                          const int *__restrict__ tab,
+                                                          const unsigned *__restrict__ codes,
+                                                          const double *__restrict__ x,
+                                                          double *__restrict__ y,
+                                                          const double *__restrict__ b,
+                                                          const double *__restrict__ dinv, double scale,
+                                                          const double *__restrict__ xrow,
+                                                          const double *__restrict__ vtab,
+                                                          const int *__restrict__ tile_nseg,
+                                                          const int2 *__restrict__ tile_seg) {
+    extern __shared__ __align__(16) double lds[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    PairEntry *lt = (PairEntry *)(lds + stage_cap) + 64 * wv;
+    const int blk = per_xcd > 0 ? (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (blk >= nblocks || (long)blk * 256 + 256 > nrows) return;
+    const long row = (long)blk * 256 + threadIdx.x;
+    const int slice = __builtin_amdgcn_readfirstlane((int)(row >> 6));
+    const int gtile = (row0 >> 8) + blk;
+    const int nseg = tile_nseg[gtile];
+    if (nseg == 0) return;
+    // this slice's streams first: they are in flight while the segments are staged
+    const roff_t beg = sptr[slice], end = sptr[slice + 1];
+    const int gslice = (row0 >> 6) + slice;
+    const int np = ntab[gslice] - 256;
+    const int w = (int)((end - beg) >> 6);
+    const unsigned *wp = codes + ((size_t)(beg >> 2) + (size_t)gslice * 64 + lane);
+    unsigned cws[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) cws[q] = (4 * q < w) ? __builtin_nontemporal_load(wp + 64 * q) : 0u;
+    const int mytab = (lane < np) ? tab[(size_t)gslice * 64 + lane] : 0;
+    const double myval = (lane < np) ? vtab[(size_t)gslice * 64 + lane] : 0.0;
+    double e_b = 0.0, e_d = 0.0, e_x = 0.0;
+    if (MODE == MODE_RESIDUAL) e_b = b[row];
+    if (MODE == MODE_ADD) e_x = y[row];
+    if (MODE == MODE_SMOOTH) { e_b = b[row]; e_d = dinv[row]; e_x = xrow[row]; }
+    // the tile's segments: x[R0 + lo .. R0 + lo + len) -> lds[pre ..), 16 bytes per lane (starts and lengths are even).
+    // Four segments at a time: the loads of their first two passes (512 doubles per pass of the workgroup), then the
+    // LDS stores -- one memory latency per batch, not one per segment; the thread assignment rotates by one wavefront
+    // per segment so that the partial last passes land on different wavefronts.
+    const int2 *sg = tile_seg + (size_t)gtile * SELL_SEG_MAX;
+    const int R0 = row0 + blk * 256;
+    auto fetch = [&](int g) {
+        // (a tile's table is the union over its rows: near the ends of the operator a segment reaches outside
+        // [0, ncols), where no row of the tile has an entry)
+        double2 v = make_double2(0.0, 0.0);
+        if (g >= 0 && g + 1 < ncols) v = *(const double2 *)(x + g);
+        else if (g >= 0 && g < ncols) v.x = x[g];
+        else if (g == -1 && ncols > 0) v.y = x[0];
+        return v;
+    };
+    int pre = 0, mybase = 0;
+    bool longer = false;
+#pragma unroll
+    for (int batch = 0; batch < SELL_SEG_MAX; batch += 4) {
+        if (batch < nseg) {
+            double2 st[8];
+            int pre_k[4], len_k[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int sidx = batch + k;
+                pre_k[k] = pre;
+                len_k[k] = 0;
+                if (sidx < nseg) {
+                    const int2 d = sg[sidx];
+                    len_k[k] = d.y;
+                    const int i = 2 * (int)((threadIdx.x + 64u * sidx) & 255u);
+                    if (i < d.y) st[2 * k] = fetch(R0 + d.x + i);
+                    if (i + 512 < d.y) st[2 * k + 1] = fetch(R0 + d.x + i + 512);
+                    longer = longer || d.y > 1024;
+                    if (mytab >= d.x) mybase = pre - d.x;      // (segments ascend: the last one at or below the offset holds it)
+                    pre += d.y;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = 2 * (int)((threadIdx.x + 64u * (batch + k)) & 255u);
+                if (i < len_k[k]) *(double2 *)(lds + pre_k[k] + i) = st[2 * k];
+                if (i + 512 < len_k[k]) *(double2 *)(lds + pre_k[k] + i + 512) = st[2 * k + 1];
+            }
+        }
+    }
+    if (longer) {      // segments beyond two passes (1024 doubles): the rest of them
+        int p2 = 0;
+        for (int sidx = 0; sidx < nseg; ++sidx) {
+            const int2 d = sg[sidx];
+            for (int i = 2 * (int)((threadIdx.x + 64u * sidx) & 255u) + 1024; i < d.y; i += 512) *(double2 *)(lds + p2 + i) = fetch(R0 + d.x + i);
+            p2 += d.y;
+        }
+    }
+    lt[lane] = PairEntry{(mybase + mytab + 64 * wv) << 3, 0, myval};      // byte offset of lane 0's x-entry in lds
+    __syncthreads();
+    const char *lb = (const char *)lds + 8 * lane;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        if (4 * g + 4 <= w) {
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const PairEntry e = lt[(cws[g] >> (8 * e4)) & 255u];
+                const double xv = *(const double *)(lb + e.off);
+                if (e4 & 1) s1 = fma(e.val, xv, s1);
+                else s0 = fma(e.val, xv, s0);
+            }
+        } else if (4 * g < w) {
+#pragma unroll
+            for (int e4 = 0; e4 < 3; ++e4) {
+                if (4 * g + e4 < w) {
+                    const PairEntry e = lt[(cws[g] >> (8 * e4)) & 255u];
+                    s0 = fma(e.val, *(const double *)(lb + e.off), s0);
+                }
+            }
+        }
+    }
+    const double sum = s0 + s1;
+    if (MODE == MODE_PLAIN) {
+        y[row] = sum;
+    } else if (MODE == MODE_RESIDUAL) {
+        y[row] = e_b - sum;
+    } else if (MODE == MODE_ADD) {
+        y[row] = e_x + sum;
+    } else {
+        y[row] = e_x + scale * (e_d * (sum - e_b));
+    }
+}
+
+// The tiles the staged kernel leaves out, from the list the staging plan made (ids of the whole operator; those
+// outside the row range are skipped), one workgroup per tile through sell_slice.
+template <int MODE>
+__global__ __launch_bounds__(256) void sell_tiles_kernel(int ntl, const int *__restrict__ tiles, int nrows, int row0,
+                                                         const roff_t *__restrict__ sptr, const int *__restrict__ col,
+                                                         const double *__restrict__ val, const int *__restrict__ ntab,
+                                                         const int *__restrict__ tab, const unsigned *__restrict__ codes,
+                                                         const double *__restrict__ x, double *__restrict__ y,
+                                                         const double *__restrict__ b, const double *__restrict__ dinv,
+                                                         double scale, const double *__restrict__ xrow,
+                                                         const double *__restrict__ vtab) {
+    __shared__ PairEntry ltab[4][64];
+    const long lrow0 = (long)tiles[blockIdx.x] * 256 - row0;      // the tile's first row, local to the range
+    if (lrow0 < 0 || lrow0 >= nrows) return;
+    const long row = lrow0 + threadIdx.x;
+    const int slice = __builtin_amdgcn_readfirstlane((int)(row >> 6));
+    sell_slice<MODE>(ltab[threadIdx.x >> 6], nrows, row0, row, slice, 1, sptr, col, val, ntab, tab, codes, x, y, b, dinv,
+                     scale, xrow, vtab);
+}
+
+// x-staging plan of the pair-coded tiles (see DCsr::sell_tile_seg): one wavefront per tile of 4 slices.  The
+// distinct column offsets of the four slice tables are sorted (bitonic, 256 keys in LDS).  An offset o needs
+// x[R0 + o .. R0 + o + 255] for the tile's 256 rows R0..: offsets no more than 256 + STAGE_GAP apart have ranges that
+// touch or overlap and become one segment [lo, hi] covering x[R0 + lo .. R0 + hi + 255] (a 27-point stencil: one
+// segment per z-plane, three of 772 doubles), its start moved down to an even index (16-byte aligned loads) and its
+// length made even.  Tiles with
+// a slice that is not pair-coded / wider than 32, with more than SELL_SEG_MAX segments or more than SELL_STAGE_CAP
+// doubles are not staged (nseg = 0) and take the gather path.
+constexpr int STAGE_GAP = 32;
+__global__ __launch_bounds__(64) void sell_stage_kernel(int ntiles, int nslices, int nrows, const roff_t *__restrict__ sptr,
+                                                        const int *__restrict__ ntab, const int *__restrict__ tab,
+                                                        int *__restrict__ tile_nseg, int2 *__restrict__ tile_seg,
+                                                        int *__restrict__ max_total, int *__restrict__ unstaged) {
+    __shared__ int v[256];
+    __shared__ int lo[SELL_SEG_MAX], hi[SELL_SEG_MAX];
+    const int t = blockIdx.x, lane = threadIdx.x;
+    bool ok = (long)(4 * t + 4) * 64 <= nrows;      // four whole slices
+    for (int q = 0; q < 4 && ok; ++q) {
+        const int sl = 4 * t + q;
+        const int nt = ntab[sl];
+        const int w = (int)((sptr[sl + 1] - sptr[sl]) >> 6);
+        ok = nt >= 256 && w <= 32;
+        if (ok) v[64 * q + lane] = lane < nt - 256 ? tab[(size_t)sl * 64 + lane] : INT_MAX;
+    }
+    auto give_up = [&]() {      // max_total[2]: number of tiles left to the gather kernel, listed in `unstaged`
+        if (lane == 0) {
+            tile_nseg[t] = 0;
+            unstaged[atomicAdd(max_total + 2, 1)] = t;
+        }
+    };
+    if (!ok) {
+        give_up();
+        return;
+    }
+    __syncthreads();
+    for (int k = 2; k <= 256; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < 256; i += 64) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const int a = v[i], b = v[p];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { v[i] = b; v[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // segment starts among the sorted keys (duplicates and the INT_MAX padding start nothing)
+    int nseg = 0, nend = 0;
+    for (int c = 0; c < 4; ++c) {
+        const int i = 64 * c + lane;
+        const int a = v[i];
+        const int prev = i ? v[i - 1] : INT_MIN;
+        const bool valid = a != INT_MAX;
+        const bool start = valid && (i == 0 || (long)a - (long)prev > 256 + STAGE_GAP);
+        const int next = i < 255 ? v[i + 1] : INT_MAX;
+        const bool end = valid && (next == INT_MAX || (long)next - (long)a > 256 + STAGE_GAP);
+        const unsigned long long sm = __ballot(start), em = __ballot(end);
+        const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+        if (start) { const int sidx = nseg + __popcll(sm & below); if (sidx < SELL_SEG_MAX) lo[sidx] = a; }
+        if (end) { const int eidx = nend + __popcll(em & below); if (eidx < SELL_SEG_MAX) hi[eidx] = a; }
+        nseg += __popcll(sm);
+        nend += __popcll(em);
+    }
+    __syncthreads();
+    if (nseg > SELL_SEG_MAX) {
+        give_up();
+        return;
+    }
+    const long R0 = (long)t * 256;
+    int mylo = 0, mylen = 0;
+    if (lane < nseg) {
+        mylo = lo[lane];
+        if ((R0 + mylo) & 1) mylo -= 1;
+        mylen = 256 + (hi[lane] - mylo);
+        mylen += mylen & 1;
+    }
+    int total = mylen;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+    if (total > SELL_STAGE_CAP) {
+        give_up();
+        return;
+    }
+    if (lane < SELL_SEG_MAX) tile_seg[(size_t)t * SELL_SEG_MAX + lane] = make_int2(mylo, mylen);
+    if (lane == 0) {
+        tile_nseg[t] = nseg;
+        atomicMax(max_total, total);
+        atomicAdd(max_total + 1, 1);
+    }
+}
+
 // Slice census of a SELL copy: cls[0..2] = pair-coded / offset-coded / plain slices, cls[3..5] = their stored entries
 // (64 x width), cls[6] = code words of the coded slices, cls[7] = widest slice
 __global__ __launch_bounds__(256) void sell_census_kernel(int nslices, const roff_t *__restrict__ sptr,
                                                           const int *__restrict__ ntab,
                                                           unsigned long long *__restrict__ cls) {
     const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= nslices) return;
-    const int w = (int)((sptr[s + 1] - sptr[s]) >> 6);
-    const int nt = ntab[s];
-
+    const bool in = s < nslices;
+    const int w = in ? (int)((sptr[s + 1] - sptr[s]) >> 6) : 0;
+    const int nt = in ? ntab[s] : -1;
     const int c = nt >= 256 ? 0 : (nt >= 0 ? 1 : 2);
-    atomicAdd(cls + c, 1ull);
-    atomicAdd(cls + 3 + c, (unsigned long long)w * 64ull);
-    if (c < 2) atomicAdd(cls + 6, (unsigned long long)((w + 3) / 4) * 64ull);
-    atomicMax(cls + 7, (unsigned long long)w);
+    // (one atomic per wavefront and counter: 265 000 threads adding to the same eight words took 6.5 ms)
+    unsigned long long part[8];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        part[k] = in && c == k ? 1ull : 0ull;
+        part[3 + k] = in && c == k ? (unsigned long long)w * 64ull : 0ull;
+    }
+    part[6] = in && c < 2 ? (unsigned long long)((w + 3) / 4) * 64ull : 0ull;
+    part[7] = (unsigned long long)w;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(part[k], o, 64);
+            part[k] = k == 7 ? (other > part[k] ? other : part[k]) : part[k] + other;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            if (part[k]) atomicAdd(cls + k, part[k]);
+        atomicMax(cls + 7, part[7]);
+    }
 }
 
 __global__ __launch_bounds__(256) void sell_width_kernel(int nrows, const roff_t *__restrict__ rowptr,
@@ -461,6 +735,31 @@ void build_sell(hipStream_t s, DCsr &A) {
                           8.0 * (double)h[4] + 12.0 * (double)h[5] + 12.0 * (double)A.nslices;
     static const bool no_fast = std::getenv("SAAMGE_AMD_SELL_PAIR_FAST") && std::atoi(std::getenv("SAAMGE_AMD_SELL_PAIR_FAST")) == 0;
     A.sell_fast_ok = !no_fast && A.ncols < (1 << 29);      // (32-bit byte offsets into x on the short-chain path)
+    // x-staging plan of the pair-coded tiles (SAAMGE_AMD_SELL_STAGE=0: none)
+    static const bool no_stage = std::getenv("SAAMGE_AMD_SELL_STAGE") && std::atoi(std::getenv("SAAMGE_AMD_SELL_STAGE")) == 0;
+    A.sell_stage_cap = 0;
+    int staged_tiles = 0;
+    if (A.sell_fast_ok && !no_stage && h[0] * 2 >= (unsigned long long)A.nslices) {      // (worth a plan: most slices pair-coded)
+        const int ntiles = div_up(A.nslices, 4);
+        A.sell_tile_nseg.alloc((size_t)ntiles);
+        A.sell_tile_seg.alloc((size_t)ntiles * SELL_SEG_MAX);
+        A.sell_unstaged.alloc((size_t)ntiles);
+        DBuf<int> mx(3);
+        SA_HIP_CHECK(hipMemsetAsync(mx.p, 0, 3 * sizeof(int), s));
+        hipLaunchKernelGGL(sell_stage_kernel, dim3(ntiles), dim3(64), 0, s, ntiles, A.nslices, A.nrows, A.sell_ptr.p, A.sell_ntab.p,
+                           A.sell_tab.p, A.sell_tile_nseg.p, A.sell_tile_seg.p, mx.p, A.sell_unstaged.p);
+        SA_HIP_CHECK(hipGetLastError());
+        int hm[3];
+        SA_HIP_CHECK(hipMemcpyAsync(hm, mx.p, sizeof(hm), hipMemcpyDeviceToHost, s));
+        SA_HIP_CHECK(hipStreamSynchronize(s));
+        A.sell_stage_cap = hm[0];
+        staged_tiles = hm[1];
+        A.sell_nunstaged = hm[2];
+        if (A.sell_nunstaged * 4 > ntiles) A.sell_stage_cap = 0;      // too few tiles staged to be worth two launches
+        A.sell_stream_bytes += (4.0 + 8.0 * SELL_SEG_MAX) * ntiles;
+    }
+    if (std::getenv("SAAMGE_AMD_SELL_VERBOSE"))
+        std::fprintf(stderr, "build_sell: staging plan: %d of %d tiles, largest %d doubles\n", staged_tiles, div_up(A.nslices, 4), A.sell_stage_cap);
     if (std::getenv("SAAMGE_AMD_SELL_VERBOSE"))
         std::fprintf(stderr, "build_sell: %d rows, slices pair/offset/plain %lld/%lld/%lld, widest %llu, stream bytes %.0f, fast path %d\n",
                      A.nrows, (long long)h[0], (long long)h[1], (long long)h[2], h[7], A.sell_stream_bytes, (int)A.sell_fast_ok);
@@ -480,12 +779,27 @@ static void launch_spmv(hipStream_t s, const DCsr &A, RowRange rr, const double 
     if (b) b += row0;
     if (dinv) dinv += row0;
     const double *xrow = x + row0;
+    if (A.has_sell && A.sell_stage_cap > 0 && row0 % 256 == 0) {
+        const int nblocks = div_up((long)div_up(nrows, 64) * 64, 256);
+        static const bool no_xcd = std::getenv("SAAMGE_AMD_SELL_XCD") && std::atoi(std::getenv("SAAMGE_AMD_SELL_XCD")) == 0;
+        const int per_xcd = no_xcd ? 0 : div_up(nblocks, 8);
+        const size_t lds_bytes = 8 * (size_t)A.sell_stage_cap + 4 * 64 * sizeof(PairEntry);
+        hipLaunchKernelGGL((sell_staged_kernel<MODE>), dim3(no_xcd ? nblocks : per_xcd * 8), dim3(256), lds_bytes, s, nrows, row0,
+                           nblocks, per_xcd, A.sell_stage_cap, A.ncols, A.sell_ptr.p + row0 / 64, A.sell_ntab.p, A.sell_tab.p,
+                           A.sell_code.p, x, y, b, dinv, scale, xrow, A.sell_vtab.p, A.sell_tile_nseg.p, A.sell_tile_seg.p);
+        if (A.sell_nunstaged > 0)
+            hipLaunchKernelGGL((sell_tiles_kernel<MODE>), dim3(A.sell_nunstaged), dim3(256), 0, s, A.sell_nunstaged, A.sell_unstaged.p,
+                               nrows, row0, A.sell_ptr.p + row0 / 64, A.sell_col.p, A.sell_val.p, A.sell_ntab.p, A.sell_tab.p,
+                               A.sell_code.p, x, y, b, dinv, scale, xrow, A.sell_vtab.p);
+        SA_HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (A.has_sell) {
         const int nblocks = div_up((long)div_up(nrows, 64) * 64, 256);
         static const bool no_xcd = std::getenv("SAAMGE_AMD_SELL_XCD") && std::atoi(std::getenv("SAAMGE_AMD_SELL_XCD")) == 0;
         const int per_xcd = no_xcd ? 0 : div_up(nblocks, 8);     // (0: blocks in launch order)
         hipLaunchKernelGGL((sell_spmv_kernel<MODE>), dim3(no_xcd ? nblocks : per_xcd * 8), dim3(256), 0, s, nrows, row0, nblocks, per_xcd,
-                           (int)A.sell_fast_ok * (std::getenv("SAAMGE_AMD_LAB") ? 2 : 1), A.sell_ptr.p + row0 / 64, A.sell_col.p, A.sell_val.p, A.sell_ntab.p,
+                           (int)A.sell_fast_ok, A.sell_ptr.p + row0 / 64, A.sell_col.p, A.sell_val.p, A.sell_ntab.p,
                            A.sell_tab.p, A.sell_code.p, x, y, b, dinv, scale, xrow, A.sell_vtab.p);
         SA_HIP_CHECK(hipGetLastError());
         return;

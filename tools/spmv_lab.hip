@@ -51,6 +51,73 @@ __global__ __launch_bounds__(256) void stream_mix_kernel(long n, const unsigned 
     y[i] = a[i] + b[i] * c[i] + (double)(acc & 1u);
 }
 
+// constructive experiment: start from the stream and add the pieces of the SpMV kernel one by one
+struct alignas(16) LabEntry { int off, pad; double val; };
+enum { L_SCALAR = 1, L_TABLE = 2, L_FMA = 4, L_GATHER = 8, L_XCD = 16, L_NOCODES = 32, L_LDSX = 64 };
+template <int F>
+__global__ __launch_bounds__(256) void lab_kernel(int nrows, int nblocks, int per_xcd, const roff_t *__restrict__ sptr,
+                                                  const int *__restrict__ ntab, const int *__restrict__ tab,
+                                                  const double *__restrict__ vtab, const unsigned *__restrict__ codes,
+                                                  const double *__restrict__ x, const double *__restrict__ b,
+                                                  const double *__restrict__ dinv, double *__restrict__ y) {
+    __shared__ LabEntry ltab[4][64];
+    __shared__ double lx[4][64 + 8];
+    const int blk = (F & L_XCD) ? (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (blk >= nblocks) return;
+    const long row = (long)blk * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int slice = __builtin_amdgcn_readfirstlane((int)(row >> 6));
+    if ((long)slice * 64 >= nrows) return;
+    roff_t beg;
+    int w, np;
+    if (F & L_SCALAR) {
+        beg = sptr[slice];
+        w = (int)((sptr[slice + 1] - beg) >> 6);
+        np = ntab[slice] - 256;
+        if (np < 0 || w > 27) { w = 27; np = 27; }
+    } else {
+        beg = (roff_t)slice * 26 * 64;      // (close to the real offsets and inside the allocation: boundary slices are narrower)
+        w = 27;
+        np = 27;
+    }
+    const unsigned *wp = codes + ((size_t)(beg >> 2) + (size_t)slice * 64 + lane);
+    unsigned cws[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) cws[q] = (F & L_NOCODES) ? (unsigned)(q * 0x01010101u) : __builtin_nontemporal_load(wp + 64 * q);
+    const bool live = row < nrows;
+    LabEntry *lt = ltab[threadIdx.x >> 6];
+    if (F & L_TABLE) {
+        const int mytab = (lane < np) ? tab[(size_t)slice * 64 + lane] : 0;
+        const double myval = (lane < np) ? vtab[(size_t)slice * 64 + lane] : 0.0;
+        lt[lane] = LabEntry{mytab, 0, myval};
+    }
+    const double e_b = live ? b[row] : 0.0, e_d = live ? dinv[row] : 0.0, e_x = live ? x[row] : 0.0;
+    if (F & L_LDSX) lx[threadIdx.x >> 6][lane + 4] = e_x;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double s0 = 0.0, s1 = 0.0;
+    const char *xb = (const char *)x;
+#pragma unroll
+    for (int j = 0; j < 27; ++j) {
+        const int idx = (int)((cws[j >> 2] >> (8 * (j & 3))) & 255u);
+        int off = 0;
+        double v = 1.0 + idx;
+        if (F & L_TABLE) { const LabEntry e = lt[idx & 63]; off = e.off; v = e.val; }
+        double xv = e_x;
+        if (F & L_GATHER) {
+            long c = row + off;
+            if (c < 0 || c >= nrows) c = live ? row : 0;
+            xv = *(const double *)(xb + ((unsigned)c << 3));
+        } else if (F & L_LDSX) {
+            xv = lx[threadIdx.x >> 6][lane + 4 + (off % 3)];
+        }
+        if (F & L_FMA) { if (j & 1) s1 = fma(v, xv, s1); else s0 = fma(v, xv, s0); }
+        else s0 += (j == 13 ? v * xv : 0.0) + (double)off;
+    }
+    if (live) y[row] = e_x + 0.7 * (e_d * (s0 + s1 - e_b));
+}
+
 template <class F>
 static double time_us(hipStream_t s, int reps, F f) {
     hipEvent_t e0, e1;
@@ -127,5 +194,23 @@ int main(int argc, char **argv) {
     report("stream_mix with one vector in", us, (4.0 * wpr + 16.0) * N);
     us = time_us(s, reps, [&](int) { hipLaunchKernelGGL(stream_mix_kernel, dim3(grid), dim3(256), 0, s, N, A.sell_code.p, x0.p, b.p, dinv.p, x1.p, 0); });
     report("stream_mix without codes (3 vectors in, 1 out)", us, 32.0 * N);
+    {
+        const int nblocks = (int)((N + 255) / 256), per_xcd = (nblocks + 7) / 8;
+#define LAB(FLAGS, NAME)                                                                                                      \
+        us = time_us(s, reps, [&](int) {                                                                                      \
+            hipLaunchKernelGGL((lab_kernel<FLAGS>), dim3(((FLAGS) & L_XCD) ? per_xcd * 8 : nblocks), dim3(256), 0, s, (int)N, nblocks, \
+                               per_xcd, A.sell_ptr.p, A.sell_ntab.p, A.sell_tab.p, A.sell_vtab.p, A.sell_code.p, x0.p, b.p, dinv.p, x1.p); \
+        });                                                                                                                   \
+        report(NAME, us, fmt + 32.0 * N);
+        LAB(0, "lab: codes + b, dinv, x in, y out (no table, no fma)")
+        LAB(L_NOCODES, "lab: the same without the code loads")
+        LAB(L_SCALAR, "lab: + scalar slice descriptors")
+        LAB(L_SCALAR | L_TABLE, "lab: + slice table -> LDS, 27 table reads")
+        LAB(L_SCALAR | L_TABLE | L_FMA, "lab: + 27 fma")
+        LAB(L_SCALAR | L_TABLE | L_FMA | L_LDSX, "lab: + x from LDS (27 ds_read_b64)")
+        LAB(L_SCALAR | L_TABLE | L_FMA | L_GATHER, "lab: + 27 global gathers instead")
+        LAB(L_SCALAR | L_TABLE | L_FMA | L_GATHER | L_XCD, "lab: + XCD-contiguous blocks")
+        LAB(L_FMA | L_GATHER | L_XCD | L_TABLE, "lab: gathers, table, no scalar descriptors")
+    }
     return 0;
 }
