@@ -171,6 +171,16 @@ int saamge_amd_vcycle(saamge_amd_hierarchy *h, const double *b, double *x, int i
  * success.  NULL restores the built-in solver. */
 typedef int (*saamge_amd_coarse_solve_fn)(void *ctx, int n, const double *rc_host, double *xc_host);
 int saamge_amd_set_coarse_solver(saamge_amd_hierarchy *h, saamge_amd_coarse_solve_fn fn, void *ctx);
+/* The smoother plug of the cycle: typedef void (*smpr_ft)(HypreParMatrix& A, const Vector& b, Vector& x, void *data)
+ * (inc/smpr.hpp:59-60), selected per tg_data_t through the TG options pre_smoother / post_smoother (inc/tg.hpp:99-119,
+ * copied at src/tg.cpp:411-414) and called by tg_cycle_atb as pre_smoother(A, b, x, data) ... post_smoother(A, b, x, data)
+ * (src/tg.cpp:113,131) with the semantics x += M^-1 (b - A x).  Here: host callbacks on `n` = rows of the level's
+ * operator; the library copies b and x to the host, calls, and copies x back (pre-smoothing of a cycle from a zero
+ * start vector hands over x = 0).  NULL for either restores the built-in polynomial smoother (smpr_sym_poly) in that
+ * place.  A level that is row-partitioned over several ranks refuses a plug (error at the cycle).  Return 0 on success. */
+typedef int (*saamge_amd_smoother_fn)(void *ctx, int level, int n, const double *b_host, double *x_host);
+int saamge_amd_set_smoother(saamge_amd_hierarchy *h, int level, saamge_amd_smoother_fn pre, saamge_amd_smoother_fn post,
+                            void *ctx);
 /* smpr_sym_poly on one level (inc/smpr.hpp:59-60, src/smpr.cpp:213-234): x += M^-1 (b - A x) */
 int saamge_amd_smoother(saamge_amd_hierarchy *h, int level, const double *b, double *x);
 /* Outer Krylov loop: MFEM CGSolver as driven by test/mltest/mltest.cpp:773-781

@@ -162,6 +162,11 @@ struct tg_data_t {
     saamge_amd_hierarchy *h = nullptr;     // shared by the tg_data of every level of one ml_data_t
     int level = 0;
     bool owns_h = false;
+    tg_data_t *coarser_tg = nullptr;       // the next level's tg_data (NULL on the last spectral level)
+    // what tg_init_data recorded for tg_build_hierarchy (inc/tg.hpp:428-432,478-481)
+    int init_nu_pro = 0, init_nu_relax = 3;
+    double init_smooth_drop_tol = 0.0;
+    bool init_use_arpack = false;
     mfem::SparseMatrix *Ac_diag = nullptr, *interp_diag = nullptr, *restr_diag = nullptr;
     HYPRE_Int row_starts[2][2];
 };
@@ -197,6 +202,16 @@ inline ml_partitioner_t &ml_coarse_partitioner() {
     return p;
 }
 inline void ml_set_coarse_partitioner(const ml_partitioner_t &p) { ml_coarse_partitioner() = p; }
+// Fine partition for the entry points that derive it themselves in the reference (SpectralAMGSolver ->
+// fem_create_partitioning -> METIS, src/solve.cpp:185-187, src/part.cpp:170-183): partition(level 0, NE, nparts,
+// elem_to_elem, out[NE]).  Default: contiguous element ranges.
+inline ml_partitioner_t &ml_fine_partitioner() {
+    static ml_partitioner_t p = [](int, int n_elem, int nparts, const mfem::Table &, int *out) {
+        for (int e = 0; e < n_elem; ++e) out[e] = (int)((long long)e * nparts / n_elem);
+    };
+    return p;
+}
+inline void ml_set_fine_partitioner(const ml_partitioner_t &p) { ml_fine_partitioner() = p; }
 
 namespace detail {
 
@@ -206,6 +221,12 @@ struct HostCsr {
 };
 // the rank's matrix as sorted CSR (hypre keeps the diagonal entry first in each row: src/mbox.cpp:1664-1667)
 inline HostCsr csr_of(mfem::HypreParMatrix &A) {
+    // one MPI rank per hierarchy: a matrix distributed over several ranks has an off-diagonal block that GetDiag()
+    // does not return -- refused loudly instead of solving a truncated operator (multi-GPU runs go through the C ABI's
+    // rank / world parameters)
+    if (A.GetGlobalNumRows() != A.Height() || A.GetGlobalNumCols() != A.Width())
+        mfem::mfem_error("saamge_amd: the HypreParMatrix is distributed over several MPI ranks (global size != local size); "
+                         "this adaptor takes the rank's whole matrix");
     mfem::SparseMatrix diag;
     A.GetDiag(diag);
     const int n = diag.Height();
@@ -264,6 +285,29 @@ inline int coarse_solver_trampoline(void *ctx, int n, const double *rc, double *
     X = 0.0;                        // "XC pre-zeroed", src/tg.cpp:110-126
     s->Mult(R, X);
     return 0;
+}
+
+// the smpr_ft plug: the C ABI calls back with host arrays, the caller's smoother gets the level's operator and its
+// polynomial data exactly as tg_cycle_atb passes them (src/tg.cpp:113,131)
+struct SmootherPlug {
+    tg_data_t *tg;
+    mfem::HypreParMatrix *A;
+};
+inline int smoother_trampoline(SmootherPlug *p, smpr_ft fn, int n, const double *b, double *x) {
+    if (!p->A) mfem::mfem_error("VCycleSolver: a caller's smoother needs the level's operator (SetOperator / tg_data->Ac)");
+    mfem::Vector B(const_cast<double *>(b), n), X(x, n);
+    fn(*p->A, B, X, p->tg->poly_data);
+    return 0;
+}
+inline int pre_smoother_trampoline(void *ctx, int level, int n, const double *b, double *x) {
+    (void)level;
+    SmootherPlug *p = (SmootherPlug *)ctx;
+    return smoother_trampoline(p, p->tg->pre_smoother, n, b, x);
+}
+inline int post_smoother_trampoline(void *ctx, int level, int n, const double *b, double *x) {
+    (void)level;
+    SmootherPlug *p = (SmootherPlug *)ctx;
+    return smoother_trampoline(p, p->tg->post_smoother, n, b, x);
 }
 
 }  // namespace detail
@@ -350,7 +394,7 @@ inline ml_data_t *ml_produce_data(mfem::HypreParMatrix &Ag, agg_partitioning_rel
         lv->tg_data = tg;
         lv->agg_part_rels = (k == 0) ? agg_part_rels : nullptr;
         lv->finer = prev;
-        if (prev) prev->coarser = lv; else ml->levels_list.finest = lv;
+        if (prev) { prev->coarser = lv; prev->tg_data->coarser_tg = tg; } else ml->levels_list.finest = lv;
         prev = lv;
     }
     ml->levels_list.coarsest = prev;
@@ -393,6 +437,49 @@ inline tg_data_t *tg_produce_data(mfem::HypreParMatrix &Ag, const agg_partitioni
     delete ml;
     return tg;
 }
+// tg_init_data + tg_build_hierarchy (inc/tg.hpp:428-432, 478-481; src/tg.cpp:402-430, 502-540): the split form of
+// tg_produce_data.  tg_init_data records the parameters (and the smoother plugs: pre_smoother / post_smoother default to
+// smpr_sym_poly like the TG options, a caller may assign others before or after building); tg_build_hierarchy runs the
+// setup into the SAME struct.  use_arpack is accepted and ignored: the local eigenproblems are always solved directly.
+inline tg_data_t *tg_init_data(mfem::HypreParMatrix &A, const agg_partitioning_relations_t &agg_part_rels, int nu_pro,
+                               int nu_relax, double theta, bool smooth_interp, double smooth_drop_tol, bool use_arpack) {
+    (void)A; (void)agg_part_rels;
+    tg_data_t *tg = new tg_data_t;
+    tg->theta = theta;
+    tg->smooth_interp = smooth_interp;
+    tg->init_nu_pro = nu_pro;
+    tg->init_nu_relax = nu_relax;
+    tg->init_smooth_drop_tol = smooth_drop_tol;
+    tg->init_use_arpack = use_arpack;
+    return tg;
+}
+inline void tg_build_hierarchy(mfem::HypreParMatrix &Ag, tg_data_t &tg_data, const agg_partitioning_relations_t &agg_part_rels,
+                               ElementMatrixProvider *elem_data, bool avoid_ess_bdr_dofs) {
+    (void)avoid_ess_bdr_dofs;
+    if (tg_data.h) mfem::mfem_error("tg_build_hierarchy: this tg_data already holds a hierarchy");
+    if (!elem_data) mfem::mfem_error("tg_build_hierarchy: coarse-level construction (elem_data == NULL) happens inside ml_produce_data here");
+    int nparts = agg_part_rels.nparts;
+    MultilevelParameters mlp(1, &nparts, tg_data.smooth_interp ? tg_data.init_nu_pro : 0, tg_data.init_nu_pro, tg_data.init_nu_relax,
+                             tg_data.theta, tg_data.theta, tg_data.polynomial_coarse_space, false, tg_data.init_use_arpack,
+                             agg_part_rels.do_aggregates);
+    mlp.set_smooth_drop_tol(tg_data.init_smooth_drop_tol);
+    ml_data_t *ml = ml_produce_data(Ag, const_cast<agg_partitioning_relations_t *>(&agg_part_rels), elem_data, mlp);
+    tg_data_t *built = ml->levels_list.finest->tg_data;
+    // move what the setup made into the caller's struct; its own choices (plugs, tag, coarse_solver) stay
+    const smpr_ft pre = tg_data.pre_smoother, post = tg_data.post_smoother;
+    mfem::Solver *cs = tg_data.coarse_solver;
+    const int tag = tg_data.tag;
+    const int inp = tg_data.init_nu_pro, inr = tg_data.init_nu_relax;
+    const double idt = tg_data.init_smooth_drop_tol;
+    const bool iua = tg_data.init_use_arpack;
+    tg_data = *built;
+    tg_data.pre_smoother = pre; tg_data.post_smoother = post; tg_data.coarse_solver = cs; tg_data.tag = tag;
+    tg_data.init_nu_pro = inp; tg_data.init_nu_relax = inr; tg_data.init_smooth_drop_tol = idt; tg_data.init_use_arpack = iua;
+    delete built;                      // (shallow: every owned pointer moved to tg_data)
+    delete ml->levels_list.finest;
+    delete ml;
+}
+
 // tg_produce_data_algebraic (inc/tg.hpp:518-523, src/tg.cpp:862-886): the element-free two-level method -- only the
 // matrix and the dof -> AE map of agg_part_rels (fem_create_partitioning_from_matrix makes every dof its own
 // "element": partitioning[dof] = AE, NE = ND).  The agglomerate matrices are principal submatrices of A with
@@ -451,7 +538,9 @@ inline void tg_free_coarse_operator(tg_data_t &tg_data) {
     tg_data.Ac = nullptr;
     tg_data.Ac_diag = nullptr;
 }
-// tg_update_coarse_operator (inc/tg.hpp:610-612): the matrix values changed, interpolation kept
+// tg_update_coarse_operator (inc/tg.hpp:610-612): the matrix values changed, interpolation kept.  coarse_direct is
+// accepted and ignored: the coarsest solver stays the one the hierarchy was built with (MultilevelParameters::
+// set_coarse_direct / saamge_amd_params.coarse_solver) or the caller's coarse_solver plug.
 inline void tg_update_coarse_operator(mfem::HypreParMatrix &A, tg_data_t *tg_data, bool perform_solve_init, bool coarse_direct) {
     (void)perform_solve_init; (void)coarse_direct;
     detail::HostCsr c = detail::csr_of(A);
@@ -490,6 +579,11 @@ public:
     VCycleSolver(tg_data_t *tg_data_in, bool iterative_mode_)
         : mfem::Solver(tg_data_in->restr->Width(), iterative_mode_), tg_data(tg_data_in), A(NULL), plugged(NULL) {
         if (tg_data->level != 0) mfem::mfem_error("VCycleSolver: only the finest level's tg_data can be cycled from outside");
+        for (tg_data_t *t = tg_data; t; t = t->coarser_tg) {
+            detail::SmootherPlug pl = {t, NULL};
+            plugs.push_back(pl);
+            installed.push_back(std::make_pair((smpr_ft)smpr_sym_poly, (smpr_ft)smpr_sym_poly));
+        }
     }
     virtual ~VCycleSolver() {}
     virtual void SetOperator(const mfem::Operator &op) {
@@ -502,6 +596,20 @@ public:
             plugged = tg_data->coarse_solver;
             if (saamge_amd_set_coarse_solver(tg_data->h, plugged ? detail::coarse_solver_trampoline : nullptr,
                                              (void *)&tg_data->coarse_solver))
+                mfem::mfem_error(saamge_amd_last_error());
+        }
+        // pre_smoother / post_smoother assigned by the caller (the reference copies the TG options into every tg_data_t,
+        // src/tg.cpp:411-414, and tg_cycle_atb calls them, :113,131): anything but smpr_sym_poly is routed through the
+        // C ABI's smoother plug, with the level's operator (the finer level's Ac below the finest)
+        size_t k = 0;
+        for (tg_data_t *t = tg_data; t; t = t->coarser_tg, ++k) {
+            plugs[k].A = (k == 0) ? A : plugs[k - 1].tg->Ac;
+            if (t->pre_smoother == installed[k].first && t->post_smoother == installed[k].second) continue;
+            installed[k] = std::make_pair(t->pre_smoother, t->post_smoother);
+            if (saamge_amd_set_smoother(tg_data->h, t->level,
+                                        t->pre_smoother != smpr_sym_poly ? detail::pre_smoother_trampoline : nullptr,
+                                        t->post_smoother != smpr_sym_poly ? detail::post_smoother_trampoline : nullptr,
+                                        (void *)&plugs[k]))
                 mfem::mfem_error(saamge_amd_last_error());
         }
         if (saamge_amd_vcycle(tg_data->h, b.GetData(), x.GetData(), iterative_mode ? 1 : 0)) mfem::mfem_error(saamge_amd_last_error());
@@ -520,6 +628,8 @@ private:
     tg_data_t *tg_data;
     mfem::HypreParMatrix *A;
     mutable mfem::Solver *plugged;
+    mutable std::vector<detail::SmootherPlug> plugs;                   // one per level (their addresses are the plug's ctx)
+    mutable std::vector<std::pair<smpr_ft, smpr_ft> > installed;       // what the C ABI currently holds per level
 };
 
 // == SpectralAMGSolver (inc/solve.hpp:149-177, src/solve.cpp:167-230).  The reference derives the partition
@@ -527,11 +637,51 @@ private:
 // partition is an argument.  polynomial_coarse = -1: corrected null-space level, like the reference.
 class SpectralAMGSolver : public mfem::Solver {
 public:
+    // The reference's constructor (inc/solve.hpp:160-166, src/solve.cpp:167-212; test/encapsulate/encapsulate.cpp:282-284):
+    // essential dofs from fes.GetEssentialVDofs(ess_bdr, .) (fem_find_bdr_dofs), nparts[0] = NE / elems_per_agg, the
+    // element partition from the fine-partitioner hook (METIS in the reference), then the 15-argument form below.
+    SpectralAMGSolver(mfem::HypreParMatrix &Ag, mfem::ParBilinearForm &aform, mfem::SparseMatrix &Alocal,
+                      mfem::Array<int> &ess_bdr, int elems_per_agg, int num_levels, int nu_pro, int nu_relax,
+                      double theta, int polynomial_coarse, bool coarse_direct)
+        : mfem::Solver(Ag.Height(), false), Ag_(Ag) {
+        mfem::ParFiniteElementSpace *fes = aform.ParFESpace();
+        const int NE = fes->GetParMesh()->GetNE();
+        mfem::Array<int> ess_dofs;
+        fes->GetEssentialVDofs(ess_bdr, ess_dofs);
+        std::vector<agg_dof_status_t> bdr((size_t)Ag.Height());
+        for (int i = 0; i < Ag.Height(); ++i)
+            bdr[(size_t)i] = (agg_dof_status_t)(AGG_OWNED_FLAG | (ess_dofs[i] ? AGG_ON_ESS_DOMAIN_BORDER_FLAG : 0));
+        mfem::Table *e2d = new mfem::Table(fes->GetElementToDofTable());                    // (owned by agg_part_rels_)
+        mfem::Table *e2e = new mfem::Table(fes->GetParMesh()->ElementToElementTable());
+        int nparts0 = NE / elems_per_agg;
+        if (nparts0 < 1) nparts0 = 1;
+        int *partitioning = new int[NE];
+        ml_fine_partitioner()(0, NE, nparts0, *e2e, partitioning);
+        build(aform, Alocal, bdr.data(), e2d, e2e, partitioning, nparts0, elems_per_agg, num_levels, nu_pro, nu_relax, theta,
+              polynomial_coarse, coarse_direct);
+    }
+    // the same with the topology as arguments (no mesh needed)
     SpectralAMGSolver(mfem::HypreParMatrix &Ag, mfem::ParBilinearForm &aform, mfem::SparseMatrix &Alocal,
                       const agg_dof_status_t *bdr_dofs, mfem::Table *elem_to_dof, mfem::Table *elem_to_elem,
                       int *partitioning, int nparts0, int elems_per_agg, int num_levels, int nu_pro, int nu_relax,
                       double theta, int polynomial_coarse, bool coarse_direct)
         : mfem::Solver(Ag.Height(), false), Ag_(Ag) {
+        build(aform, Alocal, bdr_dofs, elem_to_dof, elem_to_elem, partitioning, nparts0, elems_per_agg, num_levels, nu_pro,
+              nu_relax, theta, polynomial_coarse, coarse_direct);
+    }
+    ~SpectralAMGSolver() {
+        delete[] nparts_arr_;
+        delete v_cycle_;
+        ml_free_data(ml_data_);
+        agg_free_partitioning(agg_part_rels_);
+    }
+    void SetOperator(const mfem::Operator &op) { (void)op; }       // "implemented in constructor", src/solve.cpp:219-223
+    void Mult(const mfem::Vector &x, mfem::Vector &y) const { v_cycle_->Mult(x, y); }
+private:
+    void build(mfem::ParBilinearForm &aform, mfem::SparseMatrix &Alocal, const agg_dof_status_t *bdr_dofs,
+               mfem::Table *elem_to_dof, mfem::Table *elem_to_elem, int *partitioning, int nparts0, int elems_per_agg,
+               int num_levels, int nu_pro, int nu_relax, double theta, int polynomial_coarse, bool coarse_direct) {
+        mfem::HypreParMatrix &Ag = Ag_;
         nparts_arr_ = new int[num_levels - 1];
         nparts_arr_[0] = nparts0;
         for (int i = 1; i < num_levels - 1; ++i) {
@@ -549,15 +699,6 @@ public:
         v_cycle_ = new VCycleSolver(levels_list_get_level(ml_data_->levels_list, 0)->tg_data, false);
         v_cycle_->SetOperator(Ag_);
     }
-    ~SpectralAMGSolver() {
-        delete[] nparts_arr_;
-        delete v_cycle_;
-        ml_free_data(ml_data_);
-        agg_free_partitioning(agg_part_rels_);
-    }
-    void SetOperator(const mfem::Operator &op) { (void)op; }       // "implemented in constructor", src/solve.cpp:219-223
-    void Mult(const mfem::Vector &x, mfem::Vector &y) const { v_cycle_->Mult(x, y); }
-private:
     mfem::HypreParMatrix &Ag_;
     int *nparts_arr_;
     agg_partitioning_relations_t *agg_part_rels_;

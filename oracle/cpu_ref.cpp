@@ -791,6 +791,18 @@ void cpu_ref_get_evals_max(const cpu_ref_hier *h, int l, double *out) {
     const Level &L = *h->H.levels[(size_t)l];
     for (int p = 0; p < L.rel.nparts; ++p) out[p] = L.evals[(size_t)p].back();
 }
+// all kept eigenvalues, AE after AE (sum of cpu_ref_get_ints(.., 0, ..) values)
+void cpu_ref_get_evals(const cpu_ref_hier *h, int l, double *out) {
+    const Level &L = *h->H.levels[(size_t)l];
+    for (int p = 0; p < L.rel.nparts; ++p)
+        for (double w : L.evals[(size_t)p]) *out++ = w;
+}
+// mis_to_AE as CSR: I (num_mises + 1), J (I[num_mises]); pass J = NULL to get I alone
+void cpu_ref_get_mis_to_AE(const cpu_ref_hier *h, int l, int *I, int *J) {
+    const Table &T = h->H.levels[(size_t)l]->rel.mis_to_AE;
+    std::copy(T.I.begin(), T.I.end(), I);
+    if (J) std::copy(T.J.begin(), T.J.end(), J);
+}
 // per MIS (num_mises): which 0 = smallest kept sigma / sigma_0 (inf: nothing kept or no SVD), 1 = largest dropped (0: none)
 void cpu_ref_get_sv_ratios(const cpu_ref_hier *h, int l, int which, double *out) {
     const Level &L = *h->H.levels[(size_t)l];

@@ -104,6 +104,20 @@ class Hierarchy(object):
         load().cpu_ref_get_evals_max(self.h, C.c_int(l), _p(out))
         return out
 
+    def evals(self, l):
+        """all kept eigenvalues of level l, agglomerate after agglomerate (split with np.cumsum(ae_m))"""
+        out = np.zeros(int(self.ae_m(l).sum()))
+        load().cpu_ref_get_evals(self.h, C.c_int(l), _p(out))
+        return out
+
+    def mis_to_AE(self, l):
+        nm = self.level_info(l)["num_mises"]
+        I = np.zeros(nm + 1, dtype=np.int32)
+        load().cpu_ref_get_mis_to_AE(self.h, C.c_int(l), _p(I), None)
+        J = np.zeros(int(I[-1]), dtype=np.int32)
+        load().cpu_ref_get_mis_to_AE(self.h, C.c_int(l), _p(I), _p(J))
+        return I, J
+
     def sv_ratios(self, l):
         """per MIS: (smallest kept, largest dropped) singular value over the largest (the 1e-10 cut, src/xpacks.cpp:591-620)"""
         nm = self.level_info(l)["num_mises"]

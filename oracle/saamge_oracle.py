@@ -395,6 +395,12 @@ def _eig_task(args):
     return w, z, D_i
 
 
+# Test hook (tests/test_oracle_mis_rotation.py): callable (AE, w, Z) -> Z' applied to the eigenvectors dsygvx returned for
+# an agglomerate.  Inside a group of EQUAL eigenvalues (the six rigid-body modes of an elasticity agglomerate, all at
+# zero) dsygvx returns one D-orthonormal basis of the eigenspace among all of them.
+EVECTS_HOOK = None
+
+
 def compute_vectors(rel, AEs_stiffm, theta, testmesh=False):
     """interp_compute_vectors + Eigensolver::SolveDirect
     (src/interp.cpp:387-556, src/spectral.cpp:124-237)."""
@@ -403,6 +409,8 @@ def compute_vectors(rel, AEs_stiffm, theta, testmesh=False):
     results = list(mapper(_eig_task, [(AEs_stiffm[i], theta) for i in range(rel.nparts)]))
     for i in range(rel.nparts):
         w, z, D_i = results[i]
+        if EVECTS_HOOK is not None:
+            z = EVECTS_HOOK(i, w, z)
         if testmesh and i == 0:
             # extra all-ones vector on AE 0 of rank 0 (src/interp.cpp:510-524)
             z = np.concatenate([z, np.ones((z.shape[0], 1))], axis=1)
@@ -430,6 +438,12 @@ def svd_dense_normalized(M):
     u, s, vt, info = lapack.dgesvd(a, compute_uv=1, full_matrices=0)
     assert info == 0
     return u, s
+
+
+# Test hook (tests/test_oracle_mis_rotation.py): callable (mis, U, s) -> U' applied to the kept left singular vectors of a
+# MIS before they are inserted.  dgesvd's basis inside a group of EQUAL singular values is one orthonormal basis of
+# that group's space among all of them; the hook lets a test pick another one and watch what depends on the choice.
+MIS_BASIS_HOOK = None
 
 
 def contrib_mises(rel, evects, avoid_ess=True, extra=None):
@@ -485,6 +499,8 @@ def contrib_mises(rel, evects, avoid_ess=True, extra=None):
                 k += 1
             assert k > 0
             U = u[:, :k]
+            if MIS_BASIS_HOOK is not None:
+                U = MIS_BASIS_HOOK(mis, U, s)
             mis_svals[mis] = s
         mis_tent[mis] = np.array(U, copy=True)
         k = U.shape[1]
@@ -700,20 +716,30 @@ def coarse_solve(H, rc):
     return sla.lu_solve(H.coarse_lu, rc)
 
 
-def vcycle(H, b, level=0):
+def vcycle(H, b, level=0, smoothers=None):
     """VCycleSolver::Mult (x = 0 start, src/solve.cpp:309-323) -> tg_cycle_atb
-    (src/tg.cpp:91-132), recursing through ml_impose_cycle (src/ml.cpp:361-377)."""
+    (src/tg.cpp:91-132), recursing through ml_impose_cycle (src/ml.cpp:361-377).
+    `smoothers`: {level: (pre, post)} replacing the polynomial smoother in either place (None keeps it) -- the
+    reference's smpr_ft plug, tg_data_t::pre_smoother / post_smoother (src/tg.cpp:113,131,411-414); each is called
+    as fn(A, b, x) and updates x in place, x += M^-1 (b - A x)."""
     lv = H.levels[level]
+    pre, post = (smoothers or {}).get(level, (None, None))
     x = np.zeros_like(b)
-    compute_poly(lv.A, b, x, lv.roots, lv.Dinv_neg)          # pre_smoother
+    if pre is not None:
+        pre(lv.A, b, x)
+    else:
+        compute_poly(lv.A, b, x, lv.roots, lv.Dinv_neg)      # pre_smoother
     res = b - lv.A @ x
     rc = lv.R @ res
     if level + 1 < len(H.levels):
-        xc = vcycle(H, rc, level + 1)
+        xc = vcycle(H, rc, level + 1, smoothers)
     else:
         xc = coarse_solve(H, rc)
     x += lv.P @ xc
-    compute_poly(lv.A, b, x, lv.roots, lv.Dinv_neg)          # post_smoother
+    if post is not None:
+        post(lv.A, b, x)
+    else:
+        compute_poly(lv.A, b, x, lv.roots, lv.Dinv_neg)      # post_smoother
     return x
 
 

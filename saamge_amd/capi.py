@@ -26,12 +26,13 @@ SYMBOLS = [
     "saamge_amd_set_coarse_solver", "saamge_amd_comm_unique_id", "saamge_amd_comm_create", "saamge_amd_comm_destroy",
     "saamge_amd_params_set_comm", "saamge_amd_comm_selftest", "saamge_amd_comm_last_error",
     "saamge_amd_release_cached_memory", "saamge_amd_cached_memory_bytes",
-    "saamge_amd_ml_produce_data64", "saamge_amd_get_csr64", "saamge_amd_spmv64",
+    "saamge_amd_ml_produce_data64", "saamge_amd_get_csr64", "saamge_amd_spmv64", "saamge_amd_set_smoother",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong))
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_longlong)
 COARSE_SOLVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double))
+SMOOTHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double))
 ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p,
                            C.POINTER(C.c_longlong))
 
@@ -279,6 +280,29 @@ class Hierarchy(object):
                 return 1
         self._coarse_cb = COARSE_SOLVE_FN(tramp)
         _check(load().saamge_amd_set_coarse_solver(self.h, self._coarse_cb, None))
+
+    def set_smoother(self, level, pre, post):
+        """The smpr_ft plug (inc/smpr.hpp:59-60): pre / post = fn(level, b: ndarray, x: ndarray) -> new x with the semantics
+        x += M^-1 (b - A x) on the host, or None for the built-in polynomial smoother in that place."""
+        def wrap(fn):
+            if fn is None:
+                return SMOOTHER_FN()
+            def tramp(ctx, lev, n, bp, xp):
+                try:
+                    bb = np.ctypeslib.as_array(bp, shape=(n,))
+                    xx = np.ctypeslib.as_array(xp, shape=(n,))
+                    xx[:] = fn(lev, bb.copy(), xx.copy())
+                    return 0
+                except Exception as e:
+                    import sys
+                    print("smoother callback failed: %r" % (e,), file=sys.stderr)
+                    return 1
+            return SMOOTHER_FN(tramp)
+        if not hasattr(self, "_smoother_cbs"):
+            self._smoother_cbs = {}
+        self._smoother_cbs[level] = (wrap(pre), wrap(post))
+        _check(load().saamge_amd_set_smoother(self.h, C.c_int(level), self._smoother_cbs[level][0],
+                                              self._smoother_cbs[level][1], None))
 
     def smoother(self, level, b, x):
         _check(load().saamge_amd_smoother(self.h, C.c_int(level), _ptr(b), _ptr(x)))

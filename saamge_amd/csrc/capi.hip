@@ -230,6 +230,19 @@ int saamge_amd_set_coarse_solver(saamge_amd_hierarchy *h, saamge_amd_coarse_solv
     SA_API_END
 }
 
+int saamge_amd_set_smoother(saamge_amd_hierarchy *h, int level, saamge_amd_smoother_fn pre, saamge_amd_smoother_fn post,
+                            void *ctx) {
+    SA_API_BEGIN
+    SA_REQUIRE(h, "null argument");
+    Hierarchy &H = *h->H;
+    SA_REQUIRE(level >= 0 && level < (int)H.levels.size(), "bad level");
+    if (H.user_smoothers.size() < H.levels.size()) H.user_smoothers.resize(H.levels.size());
+    H.user_smoothers[(size_t)level].pre = pre;
+    H.user_smoothers[(size_t)level].post = post;
+    H.user_smoothers[(size_t)level].ctx = ctx;
+    SA_API_END
+}
+
 int saamge_amd_smoother(saamge_amd_hierarchy *h, int level, const double *b, double *x) {
     SA_API_BEGIN
     SA_REQUIRE(h && b && x, "null argument");

@@ -129,6 +129,13 @@ struct Hierarchy {              // ml_data_t
     // tg_data_t::coarse_solver plug: host callback replacing the built-in coarsest solve
     int (*user_coarse_solve)(void *ctx, int n, const double *rc_host, double *xc_host) = nullptr;
     void *user_coarse_ctx = nullptr;
+    // smoother plug per level (saamge_amd_set_smoother): host callbacks, x += M^-1 (b - A x)
+    struct UserSmoother {
+        int (*pre)(void *ctx, int level, int n, const double *b_host, double *x_host) = nullptr;
+        int (*post)(void *ctx, int level, int n, const double *b_host, double *x_host) = nullptr;
+        void *ctx = nullptr;
+    };
+    std::vector<UserSmoother> user_smoothers;
     DBuf<int> own_e2d;          // element-free mode: the generated identity elem_to_dof
     // setup only: the Galerkin product of level `galerkin_lev` runs on its own thread and stream beside the
     // next level's element matrices and eigenproblems (which need the level's size, not its operator)

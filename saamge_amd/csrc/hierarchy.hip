@@ -1058,6 +1058,22 @@ static void coarse_solve(Hierarchy &H, const double *rc, double *xc) {
 
 static Level::Dist *dist_of(Level &L) { return L.dist.on ? &L.dist : nullptr; }
 
+// a caller's smoother (saamge_amd_set_smoother; the reference's smpr_ft plug, src/tg.cpp:113,131): x += M^-1 (b - A x)
+// on host copies.  zero_start: the cycle's x is not initialised yet, the callback receives x = 0.
+static void user_smooth(Hierarchy &H, int level, int (*fn)(void *, int, int, const double *, double *), void *ctx,
+                        const double *b, double *x, bool zero_start) {
+    Level &L = *H.levels[level];
+    SA_REQUIRE(!L.dist.on, "a caller's smoother cannot run on a level that is row-partitioned over several ranks");
+    const size_t n = (size_t)L.A.nrows;
+    hvec<double> hb(n), hx(n, 0.0);
+    SA_HIP_CHECK(hipMemcpyAsync(hb.data(), b, 8 * n, hipMemcpyDeviceToHost, H.stream));
+    if (!zero_start) SA_HIP_CHECK(hipMemcpyAsync(hx.data(), x, 8 * n, hipMemcpyDeviceToHost, H.stream));
+    SA_HIP_CHECK(hipStreamSynchronize(H.stream));
+    SA_REQUIRE(fn(ctx, level, (int)n, hb.data(), hx.data()) == 0, "the caller's smoother failed");
+    SA_HIP_CHECK(hipMemcpyAsync(x, hx.data(), 8 * n, hipMemcpyHostToDevice, H.stream));
+    SA_HIP_CHECK(hipStreamSynchronize(H.stream));
+}
+
 // One V(1,1)-cycle from x = 0 (tg_cycle_atb, amg/src/tg.cpp:91-132).  On a row-partitioned
 // level b is read and x is written on the own rows only.
 static void vcycle_rec(Hierarchy &H, int level, const double *b, double *x) {
@@ -1065,7 +1081,9 @@ static void vcycle_rec(Hierarchy &H, int level, const double *b, double *x) {
     hipStream_t s = H.stream;
     Level::Dist *D = dist_of(L);
     const bool last = (level + 1 == (int)H.levels.size());
-    smooth_from_zero(H, L.A, L.dinv_neg.p, L.roots, b, x, L.t0.p, D);   // pre_smoother, x0 = 0
+    const Hierarchy::UserSmoother us = level < (int)H.user_smoothers.size() ? H.user_smoothers[level] : Hierarchy::UserSmoother();
+    if (us.pre) user_smooth(H, level, us.pre, us.ctx, b, x, true);
+    else smooth_from_zero(H, L.A, L.dinv_neg.p, L.roots, b, x, L.t0.p, D);   // pre_smoother, x0 = 0
     halo_then(H, D, x, [&](hipStream_t q, RowRange rr) { spmv_residual(q, L.A, x, b, L.r.p, rr); });   // res = b - A x
     double *rc = last ? H.c_b.p : H.levels[level + 1]->b.p;
     double *xc = last ? H.c_x.p : H.levels[level + 1]->x.p;
@@ -1079,7 +1097,8 @@ static void vcycle_rec(Hierarchy &H, int level, const double *b, double *x) {
         if (N.dist.on) dist_allgather_rows(H, N.dist, xc);
     }
     spmv_add(s, L.P, xc, x, rows_of(D));                                // x += P xc
-    smooth_inplace(H, L.A, L.dinv_neg.p, L.roots, b, x, L.t0.p, D);     // post_smoother
+    if (us.post) user_smooth(H, level, us.post, us.ctx, b, x, false);
+    else smooth_inplace(H, L.A, L.dinv_neg.p, L.roots, b, x, L.t0.p, D);     // post_smoother
 }
 
 void smoother_apply(Hierarchy &H, int level, const double *b, double *x) {

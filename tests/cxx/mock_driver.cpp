@@ -5,6 +5,11 @@
 using namespace mfem;
 using namespace saamge;
 
+// a driver's own smoother with the smpr_ft signature (inc/smpr.hpp:59-60)
+static void my_jacobi(HypreParMatrix &A, const Vector &b, Vector &x, void *data) {
+    (void)A; (void)b; (void)x; (void)data;
+}
+
 int mock_driver(HypreParMatrix *Ag, SparseMatrix *Al, ParBilinearForm *a, Table *elem_to_dof, Table *elem_to_elem,
                 int *partitioning, const agg_dof_status_t *bdr_dofs, HypreParVector *bg, HypreParVector *pxg,
                 Solver *my_coarse_solver, int num_levels, int elems_per_agg) {
@@ -35,6 +40,9 @@ int mock_driver(HypreParMatrix *Ag, SparseMatrix *Al, ParBilinearForm *a, Table 
     it.Mult(*bg, *pxg);
     const int iters = kalchev_pcg(*Ag, *Bprec, *bg, *pxg, 0, 1000, 1e-12, 1e-24, false);
     tg->pre_smoother(*Ag, *bg, *pxg, tg->poly_data);                                   // smpr_ft plug
+    tg->pre_smoother = my_jacobi;                                                      // a caller's smoother (inc/tg.hpp:99-119): honoured by the next Mult
+    tg->post_smoother = my_jacobi;
+    Bprec->Mult(*bg, *pxg);
     Array<int> dims;
     ml_get_dims(*ml_data, dims);
     agg_fetch_tables(*agg_part_rels, *ml_data);
@@ -74,4 +82,33 @@ int mock_algebraic_driver(HypreParMatrix *Ag, SparseMatrix *Al, int *dof_partiti
     tg_free_data(tg_data);
     agg_free_partitioning(agg_part_rels);
     return iters + nc;
+}
+
+// test/encapsulate/encapsulate.cpp:282-284: the solver object built from the bilinear form alone, the reference's 11 arguments
+int mock_encapsulate_driver(HypreParMatrix *Ag, ParBilinearForm *aform, Array<int> &ess_bdr, HypreParVector *bg, HypreParVector *pxg,
+                            int elems_per_agg, int num_levels, int nu_pro, int nu_relax, double theta) {
+    int polynomial_coarse = -1;
+    const bool coarse_direct = false;
+    SpectralAMGSolver spectral_pc(*Ag, *aform, aform->SpMat(), ess_bdr, elems_per_agg, num_levels, nu_pro, nu_relax, theta,
+                                  polynomial_coarse, coarse_direct);
+    spectral_pc.Mult(*bg, *pxg);
+    return spectral_pc.Height();
+}
+
+// the split two-level setup, inc/tg.hpp:428-432 + 478-481 (tg_produce_data's two halves, src/tg.cpp:542-578)
+int mock_tg_split_driver(HypreParMatrix *Ag, SparseMatrix *Al, ParBilinearForm *a, Table *elem_to_dof, Table *elem_to_elem,
+                         int *partitioning, const agg_dof_status_t *bdr_dofs, int nparts, HypreParVector *bg, HypreParVector *pxg) {
+    agg_partitioning_relations_t *agg_part_rels =
+        agg_create_partitioning_fine(*Ag, elem_to_dof->Size(), elem_to_dof, elem_to_elem, partitioning, bdr_dofs, &nparts, NULL, false);
+    ElementMatrixProvider *emp = new ElementMatrixStandardGeometric(*agg_part_rels, Al, a);
+    tg_data_t *tg_data = tg_init_data(*Ag, *agg_part_rels, 0, 3, 0.003, false, 0.0, false);
+    tg_data->tag = 7;
+    tg_build_hierarchy(*Ag, *tg_data, *agg_part_rels, emp, true);
+    VCycleSolver prec(tg_data, false);
+    prec.SetOperator(*Ag);
+    prec.Mult(*bg, *pxg);
+    const int nc = tg_data->Ac->Height() + tg_data->tag;
+    tg_free_data(tg_data);
+    agg_free_partitioning(agg_part_rels);
+    return nc;
 }

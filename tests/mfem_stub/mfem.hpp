@@ -82,6 +82,7 @@ public:
 class Table {
 public:
     Table();
+    Table(const Table &);
     ~Table();
     void SetDims(int rows, int nnz);
     int Size() const;
@@ -105,6 +106,8 @@ public:
                    HYPRE_Int *col_starts, SparseMatrix *diag);
     ~HypreParMatrix();
     MPI_Comm GetComm() const;
+    HYPRE_Int GetGlobalNumRows() const;
+    HYPRE_Int GetGlobalNumCols() const;
     void GetDiag(SparseMatrix &diag) const;
     virtual void Mult(const Vector &x, Vector &y) const;
 };
@@ -114,9 +117,24 @@ public:
     HypreParVector();
 };
 
+class ParMesh {
+public:
+    int GetNE() const;
+    const Table &ElementToElementTable();
+};
+
+class ParFiniteElementSpace {
+public:
+    ParMesh *GetParMesh() const;
+    const Table &GetElementToDofTable() const;
+    void GetEssentialVDofs(const Array<int> &bdr_attr_is_ess, Array<int> &ess_dofs) const;
+};
+
 class ParBilinearForm {
 public:
     void ComputeElementMatrix(int i, DenseMatrix &elmat);
+    ParFiniteElementSpace *ParFESpace() const;
+    SparseMatrix &SpMat();
 };
 
 }  // namespace mfem

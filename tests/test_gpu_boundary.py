@@ -57,3 +57,48 @@ def test_assigned_coarse_solver_is_used():
     h.set_coarse_solver(None)
     assert np.linalg.norm(h.vcycle(prob.b) - x_builtin) <= 1e-14 * np.linalg.norm(x_builtin)
     h.close()
+
+
+@pytest.mark.parametrize("levels", [2, 3])
+def test_assigned_smoothers_change_the_cycle_as_in_the_reference(levels):
+    """tg_data_t::pre_smoother / post_smoother (inc/smpr.hpp:59-60, src/tg.cpp:113,131,411-414) through
+    saamge_amd_set_smoother: a caller's damped Jacobi in the place of the polynomial smoother -- before the coarse
+    correction only, after it only, on both sides of level 0, and (three levels) on level 1 -- gives the cycle the
+    oracle gives with the same smoother in the same place."""
+    capi, o, prob, h, H = _setup(levels)
+    calls = []
+
+    def jacobi_for(level):
+        A = h.get_csr(level, "A").tocsr()
+        d = A.diagonal()
+        def gpu_side(lev, b, x):
+            calls.append((lev, "zero start" if not np.any(x) else "from x"))
+            return x + 0.6 * (b - A @ x) / d
+        return gpu_side
+
+    def jacobi_oracle(A, b, x):
+        x += 0.6 * (b - A @ x) / A.diagonal()
+
+    x_builtin = h.vcycle(prob.b)
+    cases = [({0: ("pre",)}, "pre only"), ({0: ("post",)}, "post only"), ({0: ("pre", "post")}, "both")]
+    if levels == 3:
+        cases.append(({1: ("pre", "post")}, "level 1"))
+        cases.append(({0: ("pre", "post"), 1: ("pre", "post")}, "levels 0 and 1"))
+    for where, tag in cases:
+        del calls[:]
+        plugs = {}
+        for lev in range(levels - 1):
+            pre = jacobi_for(lev) if "pre" in where.get(lev, ()) else None
+            post = jacobi_for(lev) if "post" in where.get(lev, ()) else None
+            h.set_smoother(lev, pre, post)
+            plugs[lev] = (jacobi_oracle if pre else None, jacobi_oracle if post else None)
+        x = h.vcycle(prob.b)
+        ref = o.vcycle(H, prob.b, 0, plugs)
+        assert len(calls) == sum(len(v) for v in where.values()), (tag, calls)
+        assert all(c[1] == "zero start" for c in calls[:1] if "pre" in where.get(0, ())), (tag, calls)
+        assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref), tag
+        assert np.linalg.norm(x - x_builtin) > 1e-7 * np.linalg.norm(x_builtin), tag      # (the plug is not ignored)
+    for lev in range(levels - 1):
+        h.set_smoother(lev, None, None)
+    assert np.linalg.norm(h.vcycle(prob.b) - x_builtin) <= 1e-14 * np.linalg.norm(x_builtin)
+    h.close()
