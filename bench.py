@@ -12,9 +12,17 @@ Default workload = the configuration BASELINE.json quotes the metric on: 3-D Poi
 Prints ONE JSON line (rank 0).  Extra legs, outside the timed region:
   * roofline: one more step with the library's HIP-event pair around every kernel launch
     (events recorded on the launch stream); reported for the kernel with the largest total
-    time.  `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes of this
-    same command (profiles/r01_pmc_traffic.json, produced by tools/pmc_traffic.py; FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for gfx950, calibrated on pcg_update_xr).
+    time (the SpMV family is listed per operator, i.e. per level).  `achieved` / `frac` price the
+    bytes the kernel has to move IN THE FORMAT IT RUNS (coded SELL slices + slice tables + tile
+    descriptors + vectors: the library's census of the operator, csrc/sparse.hip build_sell) --
+    a fraction of the 8 TB/s HBM peak that cannot exceed 1.  The SURVEY 8(d) figure (the CSR
+    stream of the reference, 12 B per stored entry) is kept beside it as `csr_model_*`.
+    `traffic` = HBM bytes per launch from committed rocprofv3 --pmc passes over the same
+    kernel at the same size (profiles/r03_pmc_traffic.json, tools/pmc_lab.sh; FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950; `traffic_source` says so).
+  * general_coefficient: the same workload with a coefficient without any symmetry
+    (problems.poisson3d_device(coef="skew")): no slice of the operator can be pair-coded, the
+    smoother streams 9 - 12 B per entry -- what a general MFEM operator gets.
   * cpu_baseline: the CPU restatement (oracle/cpu_ref.cpp: threaded C++, LAPACK dsygvx/dgesvd, one
     agglomerate per core) on a bounded sample of the same workload, timed on this box's host cores;
     the GPU path is then run on the same sample and must give the same level dimensions, iteration
@@ -43,9 +51,9 @@ FP64_PEAK_TFLOPS = 78.6    # MI355X datasheet fp64 vector == matrix
 
 # profiler label -> (kernel symbol in rocprofv3 output, roofline bound)
 KERNELS = {
-    "smooth_step": ("sell_spmv_kernel<3>", "hbm"),
-    "spmv": ("sell_spmv_kernel<0>", "hbm"),
-    "spmv_residual": ("sell_spmv_kernel<1>", "hbm"),
+    "smooth_step": ("sell_staged_kernel<3> / sell_spmv_kernel<3>", "hbm"),
+    "spmv": ("sell_staged_kernel<0> / sell_spmv_kernel<0>", "hbm"),
+    "spmv_residual": ("sell_staged_kernel<1> / sell_spmv_kernel<1>", "hbm"),
     "eig_sbr_symm": ("sbr_symm_kernel", "hbm"),
     "eig_sbr_syr2k": ("sbr_fused_kernel<false, 1>", "hbm"),
     "eig_sbr_fused": ("sbr_fused_kernel<true, 2>", "hbm"),
@@ -91,12 +99,12 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_problem(n, levels, dev, aniso=1.0, blk=(8, 8, 4), coarse_blk=(8, 8, 4), workload="poisson"):
+def build_problem(n, levels, dev, aniso=1.0, blk=(8, 8, 4), coarse_blk=(8, 8, 4), workload="poisson", coef=None):
     from saamge_amd import problems
     cb = [tuple(coarse_blk)] * (levels - 2)
     if workload == "elasticity_q2":
         return problems.elasticity3d_q2_device(n, blk=blk, coarse_blk=cb, device=dev)
-    return problems.poisson3d_device(n, blk=blk, coarse_blk=cb, K=(1.0, 1.0, aniso), device=dev)
+    return problems.poisson3d_device(n, blk=blk, coarse_blk=cb, K=(1.0, 1.0, aniso), device=dev, coef=coef)
 
 
 def one_step(capi, prob, params, rel_tol=1e-8, group=None):
@@ -157,16 +165,15 @@ def gpu_check_on_sample(capi, n_sample, levels, dev, theta, cpu):
     return res
 
 
-def pmc_traffic(symbol, n, levels):
-    """Per-launch HBM bytes of `symbol` from the committed PMC passes of this command."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+def pmc_traffic(label, rows):
+    """Per-launch HBM bytes of the kernel behind profiler label `label` on an operator of `rows` rows, from the committed
+    PMC passes (profiles/r03_pmc_traffic.json: {"<label>@<rows>": {"fetch_bytes_raw": .., "write_bytes": .., "launches": ..}})."""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     try:
         d = json.load(open(path))
     except Exception:
         return None
-    if d.get("_config") != {"n": n, "levels": levels}:
-        return None
-    k = d.get(symbol)
+    k = d.get("%s@%d" % (label, rows))
     if not k or not k.get("launches"):
         return None
     return (2.0 * k["fetch_bytes_raw"] + k["write_bytes"]) / k["launches"]
@@ -188,9 +195,33 @@ def spawn_ranks(n, argv, script=None):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out.decode())
+    # poll every child: the first one that dies takes the others with it (a rank that fails during start-up would
+    # otherwise leave rank 0 in the rendezvous until the process-group timeout, the survivors holding their GPUs)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = r
+                break
+        time.sleep(0.2)
+    if failed is None:
+        failed = next((r for r, p in enumerate(procs) if p.returncode != 0), None)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except Exception:
+                p.kill()
+    reader.join(timeout=5)
+    rcs = [p.returncode for p in procs]
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
     sys.stdout.flush()
     if any(rcs):
         log("bench.py: rank exit codes %s" % rcs)
@@ -219,6 +250,7 @@ def main():
                     help="local eigensolver: few-eigenpairs path with certified count (default) or the dense two-stage path only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-general", action="store_true", help="skip the general-coefficient leg of the default workload")
     args = ap.parse_args()
     for k, v in WORKLOADS[args.workload].items():
         if getattr(args, k) is None:
@@ -298,6 +330,7 @@ def main():
         del Ablk
         r0 = r1
     relres = float(res2 ** 0.5 / torch.linalg.norm(prob.b))
+    op_formats = [h.level_format(l)["slices"] for l in range(args.levels - 1)]
     h.close()
 
     res = {
@@ -328,6 +361,7 @@ def main():
                    "dofs": prob.n, "pcg_iterations": its, "converged": bool(conv),
                    "true_relative_residual": relres,
                    "level_dims": [i["n"] for i in infos] + [infos[-1]["ncoarse"]],
+                   "operator_formats": op_formats,
                    "collectives": ("RCCL inside the library (csrc/comm.hip)" if native else "torch.distributed callbacks (%s)" % backend)
                    if world > 1 else None,
                    "parallelism": ("%d ranks: per-AE spectral problems, RAP and coarse element matrices sharded + "
@@ -341,40 +375,75 @@ def main():
         capi.profile(True)
         capi.profile_reset()
         h, x, its2, conv2, hist2 = one_step(capi, prob, params)      # (single rank: no group)
+        h_formats = [h.level_format(l) for l in range(args.levels - 1)]
         h.close()
         capi.profile(False)
         stats = sorted(capi.profile_stats(), key=lambda s: -s["ms"])
         tot = sum(s["ms"] for s in stats)
         for s in stats:
-            log("  %-18s %9.3f ms %6d launches  %8.1f GB/s  %8.2f TFLOP/s"
-                % (s["name"], s["ms"], s["launches"], s["bytes"] / max(s["ms"], 1e-9) / 1e6,
-                   s["flops"] / max(s["ms"], 1e-9) / 1e9))
+            log("  %-28s %9.3f ms %6d launches  %8.1f GB/s (format)  %8.1f GB/s (CSR model)  %8.2f TFLOP/s"
+                % (s["name"], s["ms"], s["launches"], s["fmt_bytes"] / max(s["ms"], 1e-9) / 1e6,
+                   s["bytes"] / max(s["ms"], 1e-9) / 1e6, s["flops"] / max(s["ms"], 1e-9) / 1e9))
         log("  kernel total %.3f ms (profiled step)" % tot)
         d = stats[0]
-        symbol, bound = KERNELS.get(d["name"], (d["name"], "hbm"))
+        label, _, rows = d["name"].partition("@")
+        symbol, bound = KERNELS.get(label, (label, "hbm"))
         avg_ms = d["ms"] / d["launches"]
-        traffic = pmc_traffic(symbol, args.n, args.levels) if args.workload == "poisson256" else None
+        traffic = pmc_traffic(label, int(rows)) if rows else None
         if bound == "hbm":
-            ach = d["bytes"] / d["ms"] / 1e6
-            res["roofline"] = {"kernel": symbol, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+            ach = d["fmt_bytes"] / d["ms"] / 1e6
+            res["roofline"] = {"kernel": symbol, "profiler_label": d["name"], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                               "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+                               "traffic_source": ("profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                                                  "this kernel at this size, committed; not collected in this run)") if traffic else None,
+                               "format_bytes_per_launch": d["fmt_bytes"] / d["launches"],
+                               "csr_model_bytes_per_launch": d["bytes"] / d["launches"],
+                               "csr_model_GBps": d["bytes"] / d["ms"] / 1e6,
                                "avg_launch_ms": avg_ms, "launches": d["launches"]}
-            if traffic:
-                # `achieved` counts ALGORITHMIC bytes (12 B per stored entry + vectors); the coded SELL slices
-                # move far fewer (one byte per entry where a slice has <= 64 distinct (offset, value) pairs), so frac can
-                # exceed 1: the bytes that really crossed the HBM interface are `traffic` (PMC), i.e. this rate
-                res["roofline"]["hbm_real_GBps"] = traffic / (avg_ms * 1e-3) / 1e9
-                res["roofline"]["hbm_real_frac"] = res["roofline"]["hbm_real_GBps"] / HBM_PEAK_GBS
+            if label in ("smooth_step", "spmv", "spmv_residual") and rows:
+                lev = [l for l, i in enumerate(infos) if i["n"] == int(rows)]
+                if lev:
+                    res["roofline"]["operator_format"] = h_formats[lev[0]]
         else:
             ach = d["flops"] / d["ms"] / 1e9
-            res["roofline"] = {"kernel": symbol, "bound": "mfma", "achieved": ach,
+            res["roofline"] = {"kernel": symbol, "profiler_label": d["name"], "bound": "mfma", "achieved": ach,
                                "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic,
                                "avg_launch_ms": avg_ms, "launches": d["launches"]}
         res["kernels"] = [{"name": s["name"], "ms": round(s["ms"], 3), "launches": s["launches"],
-                           "GBps": round(s["bytes"] / max(s["ms"], 1e-9) / 1e6, 1)}
+                           "format_GBps": round(s["fmt_bytes"] / max(s["ms"], 1e-9) / 1e6, 1),
+                           "csr_model_GBps": round(s["bytes"] / max(s["ms"], 1e-9) / 1e6, 1)}
                           for s in stats[:10]]
+    if rank == 0 and not args.no_general and args.workload == "poisson256" and args.aniso == 1.0:
+        # the same workload on a GENERAL operator (outside the timed region): a coefficient without any symmetry, so that
+        # no 64-row slice repeats its (offset, value) pairs -- the pair-coded format of the constant-coefficient headline
+        # does not apply and the smoother streams the values
+        del prob
+        torch.cuda.empty_cache()
+        gprob = build_problem(args.n, args.levels, dev, args.aniso, tuple(int(v) for v in args.blk.split(",")),
+                              tuple(int(v) for v in args.coarse_blk.split(",")), "poisson", coef="skew")
+        torch.cuda.synchronize()
+        hg, xg, itg, convg, _ = one_step(capi, gprob, params)
+        hg.close()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gsteps = 2
+        for i in range(gsteps):
+            hg, xg, itg, convg, _ = one_step(capi, gprob, params)
+            if i < gsteps - 1:
+                hg.close()
+        torch.cuda.synchronize()
+        gdt = (time.perf_counter() - t0) / gsteps
+        ginfos = [hg.level_info(l) for l in range(args.levels - 1)]
+        res["config"]["general_coefficient"] = {
+            "coefficient": "exp(0.7x + 0.4y - 0.3z) (1 + 0.3 sin(5x + 3y + 7z)) per element (problems.poisson3d_device(coef='skew'))",
+            "ms_per_step": 1e3 * gdt, "value": gprob.n / gdt, "unit": "DoF/s", "steps": gsteps,
+            "pcg_iterations": itg, "converged": bool(convg),
+            "level_dims": [i["n"] for i in ginfos] + [ginfos[-1]["ncoarse"]],
+            "slice_formats": [hg.level_format(l)["slices"] for l in range(args.levels - 1)]}
+        hg.close()
+        del gprob, xg
+        torch.cuda.empty_cache()
     if rank == 0 and not args.no_cpu_baseline and args.workload != "poisson256":
         log("bench.py: cpu_baseline is timed on the default workload only (poisson256)")
     if rank == 0 and not args.no_cpu_baseline and args.workload == "poisson256" and args.blk == "8,8,4":

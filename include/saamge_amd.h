@@ -197,6 +197,10 @@ int saamge_amd_num_levels(const saamge_amd_hierarchy *h); /* number of operators
  * [7]=total eigenvectors [8]=inner PCG iterations of the last coarsest solve
  * [12]=1 if the level is row-partitioned [13]=first own row [14]=own rows [15]=halo entries received */
 int saamge_amd_level_info(const saamge_amd_hierarchy *h, int level, long long info[16]);
+/* Storage formats of the level operator's SELL-64 copy (no reference counterpart: hypre keeps CSR): info[0..2] = slices
+ * that are pair-coded / offset-coded / plain, [3..5] = their stored entries, [6] = 256-row tiles whose x-segments are
+ * staged through LDS, [7] = bytes of matrix data one application streams in these formats. */
+int saamge_amd_level_format(const saamge_amd_hierarchy *h, int level, long long info[8]);
 /* which: 0 A_l, 1 interp, 2 restr, 3 Ac (host output buffers sized from level_info) */
 int saamge_amd_get_csr(const saamge_amd_hierarchy *h, int level, int which, int *rowptr, int *col,
                        double *val);       /* fails on an operator with more than 2^31 - 1 entries */
@@ -254,6 +258,11 @@ void saamge_amd_profile_reset(void);
 int saamge_amd_profile_count(void);
 int saamge_amd_profile_get(int i, char *name, int name_len, double *ms, long long *launches,
                            double *bytes, double *flops);
+/* The same, plus the bytes the launches had to move IN THE FORMAT THEY RAN (coded SELL slices + tables + vectors for the
+ * SpMV family; equal to `bytes` elsewhere): the figure a roofline fraction is computed from.  The SpMV family is listed
+ * per operator as "<name>@<rows>". */
+int saamge_amd_profile_get2(int i, char *name, int name_len, double *ms, long long *launches, double *bytes, double *flops,
+                            double *fmt_bytes);
 
 #ifdef __cplusplus
 }

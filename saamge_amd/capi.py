@@ -26,7 +26,7 @@ SYMBOLS = [
     "saamge_amd_set_coarse_solver", "saamge_amd_comm_unique_id", "saamge_amd_comm_create", "saamge_amd_comm_destroy",
     "saamge_amd_params_set_comm", "saamge_amd_comm_selftest", "saamge_amd_comm_last_error",
     "saamge_amd_release_cached_memory", "saamge_amd_cached_memory_bytes",
-    "saamge_amd_ml_produce_data64", "saamge_amd_get_csr64", "saamge_amd_spmv64", "saamge_amd_set_smoother",
+    "saamge_amd_ml_produce_data64", "saamge_amd_get_csr64", "saamge_amd_spmv64", "saamge_amd_set_smoother", "saamge_amd_profile_get2", "saamge_amd_level_format",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong))
@@ -333,6 +333,14 @@ class Hierarchy(object):
                 "own_rows", "halo_recv"]
         return dict(zip(keys, [int(v) for v in info[:len(keys)]]))
 
+    def level_format(self, level):
+        info = (C.c_longlong * 8)()
+        _check(load().saamge_amd_level_format(self.h, C.c_int(level), info))
+        v = [int(x) for x in info]
+        return {"slices": {"pair_coded": v[0], "offset_coded": v[1], "plain": v[2]},
+                "entries": {"pair_coded": v[3], "offset_coded": v[4], "plain": v[5]},
+                "staged_tiles": v[6], "stream_bytes": v[7]}
+
     def get_csr(self, level, which):
         import scipy.sparse as sp
         info = self.level_info(level)
@@ -490,8 +498,9 @@ def profile_stats():
         launches = C.c_longlong()
         by = C.c_double()
         fl = C.c_double()
-        lib.saamge_amd_profile_get(C.c_int(i), name, C.c_int(64), C.byref(ms), C.byref(launches),
-                                   C.byref(by), C.byref(fl))
+        fb = C.c_double()
+        lib.saamge_amd_profile_get2(C.c_int(i), name, C.c_int(64), C.byref(ms), C.byref(launches),
+                                    C.byref(by), C.byref(fl), C.byref(fb))
         out.append(dict(name=name.value.decode(), ms=ms.value, launches=launches.value,
-                        bytes=by.value, flops=fl.value))
+                        bytes=by.value, flops=fl.value, fmt_bytes=fb.value))
     return out

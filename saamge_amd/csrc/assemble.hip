@@ -981,8 +981,9 @@ __global__ __launch_bounds__(ASM_NT) void coarse_elmat_sparse_kernel(
     const int64_t *__restrict__ mis_u_off, const double *__restrict__ mis_u,
     const int *__restrict__ colpos_ptr, const int *__restrict__ colpos,
     const int64_t *__restrict__ out_off, double *__restrict__ out,
-    double *__restrict__ scratch, const int64_t *__restrict__ scratch_off) {
+    double *__restrict__ scratch, const int64_t *__restrict__ scratch_off, const int *__restrict__ only_flagged) {
     extern __shared__ __align__(16) short dof_tq[];   // [2 n]: MIS slot of the AE and row in that MIS, per local dof
+    if (only_flagged && !only_flagged[blockIdx.x]) return;      // (the fallback pass behind coarse_elmat_rows_kernel)
     constexpr int MAXT = 64;                          // MISes of one AE kept in LDS (27 for a box of hexes)
     __shared__ int tk[MAXT], tr[MAXT], tcp[MAXT];
     __shared__ long long tu[MAXT];
@@ -1054,16 +1055,235 @@ __global__ __launch_bounds__(ASM_NT) void coarse_elmat_sparse_kernel(
     }
 }
 
+
+// The same around the sparsity of T = A_e P_loc (round 3; the kernel above kept T as a dense n x k_e image in global
+// memory, zero-filled and read-modify-written one 8-byte entry at a time: 135 GB fetched + 15 GB written per setup of
+// the 256^3 problem for 7 GB of input, 22 ms).  A row of a fine-level agglomerate matrix reaches at most NS = 8
+// MISes (the 2 x 2 x 2 cells around a vertex of the MIS decomposition), so its row of T has few non-zero entries
+// (the coarse dofs of those MISes: 1 - 2 for most rows).  They live in LDS in a packed pool, row after row: per row a
+// key word (byte s = the MIS of slot s), a word of starting columns per slot and the row's offset into the pool.
+//   count   one thread per row over the cached column indices: distinct MISes -> slots, columns per row; block scan
+//   fill    the same walk with the values: products into the pool (the thread owns its row: no conflicts)
+//   reduce  one thread per entry of E: the rows of its row-MIS in their fixed order (a deterministic sum), the
+//           column-MIS's slot found in the row's key word
+// The MISes' row lists and bases are copied to LDS first, in one round of loads.  An agglomerate with a row that
+// reaches more than NS MISes, or whose pool / bases exceed the LDS set aside (pool_cap / u_cap doubles), is flagged and
+// redone by the kernel above (only_flagged).
+constexpr int CE_NS = 8;
+__global__ __launch_bounds__(ASM_NT) void coarse_elmat_rows_kernel(
+    int ae0, int RW, int pool_cap, int u_cap, const int *__restrict__ ns, const int64_t *__restrict__ voff,
+    const double *__restrict__ rvals, const short *__restrict__ rcols, const int *__restrict__ ae2mis_I,
+    const int *__restrict__ ae2mis_J, const int *__restrict__ ae_pair,
+    const int64_t *__restrict__ pair_loc_off, const int *__restrict__ pair_loc,
+    const int *__restrict__ mis2d_I, const int *__restrict__ mis_k,
+    const int64_t *__restrict__ mis_u_off, const double *__restrict__ mis_u,
+    const int *__restrict__ colpos_ptr, const int *__restrict__ colpos,
+    const int64_t *__restrict__ out_off, double *__restrict__ out, int *__restrict__ flagged) {
+    extern __shared__ __align__(16) unsigned char ce_lds[];
+    constexpr int MAXT = 64, MAXKE = 256;
+    __shared__ int tk[MAXT], tr[MAXT];
+    __shared__ long long tu[MAXT];
+    __shared__ unsigned char col_t[MAXKE], col_w[MAXKE];
+    __shared__ int bad, wsum[ASM_NT / 64], total_s;
+    const int b = blockIdx.x, e = ae0 + b, n = ns[b];
+    double *E = out + out_off[e];
+    const int ke = (int)(sqrt((double)(out_off[e + 1] - out_off[e])) + 0.5);
+    const int tid = threadIdx.x;
+    const int mb = ae2mis_I[e], me = ae2mis_I[e + 1], nt = me - mb;
+    // LDS: pool [pool_cap] doubles, the MIS bases U [u_cap] doubles, keys [n] + column starts [n] 64-bit, row offsets [n]
+    // and MIS row lists [n] ints, dof_t / dof_q [n] shorts
+    double *pool = (double *)ce_lds;
+    double *lU = pool + pool_cap;
+    unsigned long long *lkeys = (unsigned long long *)(lU + u_cap);
+    unsigned long long *lcols = lkeys + n;
+    int *rowoff = (int *)(lcols + n);
+    int *lloc = rowoff + n;
+    short *dof_t = (short *)(lloc + n), *dof_q = dof_t + n;
+    __shared__ int troff[MAXT + 1], tuoff[MAXT + 1];      // prefix sums of the MIS sizes r_t and of r_t k_t
+    __shared__ long long tloc[MAXT];                      // where the MIS's row list starts in pair_loc
+    if (tid == 0) bad = (nt > MAXT || ke > MAXKE) ? 1 : 0;
+    for (int t = tid; t < nt && t < MAXT; t += ASM_NT) {
+        const int mis = ae2mis_J[mb + t];
+        tk[t] = mis_k[mis];
+        tr[t] = mis2d_I[mis + 1] - mis2d_I[mis];
+        tu[t] = mis_u_off[mis];
+        tloc[t] = pair_loc_off[ae_pair[mb + t]];
+        const int *cp = colpos + colpos_ptr[mb + t];
+        for (int w = 0; w < tk[t]; ++w)
+            if (cp[w] < MAXKE) { col_t[cp[w]] = (unsigned char)t; col_w[cp[w]] = (unsigned char)w; }
+    }
+    __syncthreads();
+    if (bad) {
+        if (tid == 0) flagged[b] = 1;
+        return;
+    }
+    if (tid == 0) {      // (at most 64 MISes: a serial scan in LDS)
+        int ar = 0, au = 0;
+        for (int t = 0; t < nt; ++t) {
+            troff[t] = ar;
+            tuoff[t] = au;
+            ar += tr[t];
+            au += tr[t] * tk[t];
+        }
+        troff[nt] = ar;
+        tuoff[nt] = au;
+        if (au > u_cap || ar != n) bad = 1;
+    }
+    __syncthreads();
+    if (bad) {
+        if (tid == 0) flagged[b] = 1;
+        return;
+    }
+    // the row lists and the bases of all MISes in ONE round of loads (flat index -> MIS by bisection over the prefix sums;
+    // the loops below then run out of LDS: with the lists and bases in global memory every step of the reduction was a
+    // dependent L2 access, 147 of them in a row for the interior MIS)
+    for (int idx = tid; idx < n; idx += ASM_NT) {
+        int lo = 0, hi = nt;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (troff[mid] <= idx) lo = mid; else hi = mid; }
+        const int q = idx - troff[lo];
+        const int d = pair_loc[tloc[lo] + q];
+        lloc[idx] = d;
+        dof_t[d] = (short)lo;
+        dof_q[d] = (short)q;
+    }
+    for (int idx = tid; idx < tuoff[nt]; idx += ASM_NT) {
+        int lo = 0, hi = nt;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tuoff[mid] <= idx) lo = mid; else hi = mid; }
+        lU[idx] = mis_u[tu[lo] + (idx - tuoff[lo])];      // (U of a MIS: r x k column-major, copied as it is)
+    }
+    __syncthreads();
+    // count: a contiguous run of rows per thread (the scan below is over threads)
+    const size_t rbase = (size_t)voff[b] * RW;
+    const int per = (n + ASM_NT - 1) / ASM_NT;
+    const int i0 = min(tid * per, n), i1 = min(i0 + per, n);
+    bool over = false;
+    int mine = 0;
+    for (int i = i0; i < i1; ++i) {
+        const short *rc_i = rcols + rbase + (size_t)i * RW;
+        unsigned long long keys = ~0ull, cols = 0ull;      // byte s: MIS (AE-local) of slot s (0xff free) / first column of slot s
+        int cnt = 0, ncol = 0;
+        for (int k = 0; k < RW; ++k) {
+            const int c = rc_i[k];
+            if (c < 0) continue;
+            const int tl = dof_t[c];
+            const int km = tk[tl];
+            if (km == 0) continue;
+            bool found = false;
+#pragma unroll
+            for (int sl = 0; sl < CE_NS; ++sl) found = found || (int)((keys >> (8 * sl)) & 0xffull) == tl;
+            if (found) continue;
+            if (cnt == CE_NS || ncol + km > 255) { over = true; continue; }
+            keys = (keys & ~(0xffull << (8 * cnt))) | ((unsigned long long)tl << (8 * cnt));
+            cols |= (unsigned long long)ncol << (8 * cnt);
+            ncol += km;
+            ++cnt;
+        }
+        lkeys[i] = keys;
+        lcols[i] = cols;
+        rowoff[i] = ncol;      // (the count; turned into the offset below)
+        mine += ncol;
+    }
+    // exclusive scan of `mine` over the threads
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if ((tid & 63) >= o) incl += up;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    if (over) bad = 1;
+    __syncthreads();
+    int base = incl - mine;
+    for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+    if (tid == ASM_NT - 1) total_s = base + mine;
+    for (int i = i0; i < i1; ++i) {
+        const int c = rowoff[i];
+        rowoff[i] = base;
+        base += c;
+    }
+    __syncthreads();
+    const int total = total_s;
+    if (bad || total > pool_cap) {
+        if (tid == 0) flagged[b] = 1;
+        return;
+    }
+    for (int idx = tid; idx < total; idx += ASM_NT) pool[idx] = 0.0;
+    __syncthreads();
+    // fill: row i of T, slot by slot
+    for (int i = i0; i < i1; ++i) {
+        const short *rc_i = rcols + rbase + (size_t)i * RW;
+        const double *rv_i = rvals + rbase + (size_t)i * RW;
+        const unsigned long long keys = lkeys[i], cols = lcols[i];
+        double *row = pool + rowoff[i];
+        for (int k = 0; k < RW; ++k) {
+            const int c = rc_i[k];
+            if (c < 0) continue;
+            const int tl = dof_t[c];
+            const int km = tk[tl];
+            if (km == 0) continue;
+            int col0 = 0;
+#pragma unroll
+            for (int sl = 0; sl < CE_NS; ++sl)
+                if ((int)((keys >> (8 * sl)) & 0xffull) == tl) col0 = (int)((cols >> (8 * sl)) & 0xffull);
+            const double v = rv_i[k];
+            const double *U = lU + tuoff[tl] + dof_q[c];
+            const int r = tr[tl];
+            for (int w = 0; w < km; ++w) row[col0 + w] = fma(v, U[w * r], row[col0 + w]);
+        }
+    }
+    __syncthreads();
+    // reduce: E[a][c] = sum over the rows i of a's MIS (in the MIS's own order) of U[q_i][w_a] T_i[column of c]
+    for (int idx = tid; idx < ke * ke; idx += ASM_NT) {
+        const int a = idx / ke, c = idx - a * ke;
+        const int t = col_t[a], w = col_w[a], t2 = col_t[c], w2 = col_w[c];
+        const int r = tr[t];
+        const int *loc = lloc + troff[t];
+        const double *U = lU + tuoff[t] + w * r;
+        double sum = 0.0;
+        for (int q = 0; q < r; ++q) {
+            const int i = loc[q];
+            const unsigned long long keys = lkeys[i];
+            int pos = -1;
+#pragma unroll
+            for (int sl = 0; sl < CE_NS; ++sl)
+                if ((int)((keys >> (8 * sl)) & 0xffull) == t2) pos = sl;
+            if (pos >= 0) sum = fma(U[q], pool[rowoff[i] + (int)((lcols[i] >> (8 * pos)) & 0xffull) + w2], sum);
+        }
+        E[(size_t)a * ke + c] = sum;
+    }
+}
+
 void coarse_elmats_sparse(hipStream_t s, const DevRelations &rel, int ae0, const EigBatch &batch, int RW,
                           const double *rv, const short *rc, const int *mis_k, const int64_t *mis_u_off,
                           const double *mis_u, const int *colpos_ptr, const int *colpos, const int64_t *out_off,
-                          double *out, double *scratch, const int64_t *scratch_off) {
+                          double *out, double *scratch, const int64_t *scratch_off, int kmax) {
     if (!batch.count) return;
     profiler().begin(s);
+    // the packed rows of T of one agglomerate in LDS: a pool of 6 doubles per row on average (+ keys, column starts, offsets
+    // and dof maps: 24 bytes per row); an agglomerate that needs more is redone by the dense-T kernel
+    static const bool old_only = std::getenv("SAAMGE_AMD_COARSE_ELMAT_ROWS") && std::atoi(std::getenv("SAAMGE_AMD_COARSE_ELMAT_ROWS")) == 0;
+    const int pool_cap = 6 * batch.max_n, u_cap = 3 * batch.max_n;
+    const size_t lds = 8 * (size_t)(pool_cap + u_cap) + 28 * (size_t)batch.max_n + 16;
+    if (std::getenv("SAAMGE_AMD_COARSE_ELMAT_VERBOSE"))
+        std::fprintf(stderr, "coarse_elmats_sparse: %d agglomerates, max n %d, kmax %d, RW %d, LDS %zu\n", batch.count, batch.max_n, kmax, RW, lds);
+    const int *only = nullptr;
+    DBuf<int> flagged;
+    if (!old_only && kmax >= 1 && kmax < 256 && lds <= 64 * 1024) {
+        flagged.alloc((size_t)batch.count);
+        flagged.zero(s);
+        hipLaunchKernelGGL(coarse_elmat_rows_kernel, dim3(batch.count), dim3(ASM_NT), lds, s, ae0, RW, pool_cap, u_cap, batch.n.p,
+                           batch.voff.p, rv, rc, rel.ae2mis_I.p, rel.ae2mis_J.p, rel.ae_pair.p, rel.pair_loc_off.p,
+                           rel.pair_loc.p, rel.mis2d_I.p, mis_k, mis_u_off, mis_u, colpos_ptr, colpos, out_off, out,
+                           flagged.p);
+        SA_HIP_CHECK(hipGetLastError());
+        only = flagged.p;
+        profiler().end(s, "coarse_elmats_rows", 0.0, 0.0);
+        profiler().begin(s);
+    }
     hipLaunchKernelGGL(coarse_elmat_sparse_kernel, dim3(batch.count), dim3(ASM_NT), 4 * (size_t)batch.max_n + 16, s,
                        ae0, RW, batch.n.p, batch.voff.p, rv, rc, rel.ae2mis_I.p, rel.ae2mis_J.p, rel.ae_pair.p,
                        rel.pair_loc_off.p, rel.pair_loc.p, rel.mis2d_I.p, mis_k, mis_u_off, mis_u, colpos_ptr,
-                       colpos, out_off, out, scratch, scratch_off);
+                       colpos, out_off, out, scratch, scratch_off, only);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "coarse_elmats", 0.0, 0.0);
 }

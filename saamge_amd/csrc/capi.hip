@@ -318,6 +318,18 @@ int saamge_amd_level_info(const saamge_amd_hierarchy *h, int level, long long in
     SA_API_END
 }
 
+int saamge_amd_level_format(const saamge_amd_hierarchy *h, int level, long long info[8]) {
+    SA_API_BEGIN
+    SA_REQUIRE(h && info, "null argument");
+    const Hierarchy &H = *h->H;
+    const DCsr &A = H.levels.at(level)->A;
+    for (int i = 0; i < 8; ++i) info[i] = 0;
+    for (int c = 0; c < 3; ++c) { info[c] = A.sell_class_slices[c]; info[3 + c] = A.sell_class_entries[c]; }
+    info[6] = A.sell_stage_cap > 0 ? (long long)div_up(A.nslices, 4) - A.sell_nunstaged : 0;
+    info[7] = (long long)A.sell_stream_bytes;
+    SA_API_END
+}
+
 static int get_csr(const saamge_amd_hierarchy *h, int level, int which, void *rowptr, int rowptr_bits, int *col, double *val) {
     SA_API_BEGIN
     SA_REQUIRE(h, "null argument");
@@ -569,6 +581,14 @@ int saamge_amd_profile_get(int i, char *name, int name_len, double *ms, long lon
     if (launches) *launches = k.launches;
     if (bytes) *bytes = k.bytes;
     if (flops) *flops = k.flops;
+    return 0;
+}
+
+// the same with the bytes of the format in use (KernelStat::fmt_bytes) and, for the SpMV family, the operator's slice census
+int saamge_amd_profile_get2(int i, char *name, int name_len, double *ms, long long *launches, double *bytes, double *flops,
+                            double *fmt_bytes) {
+    if (saamge_amd_profile_get(i, name, name_len, ms, launches, bytes, flops)) return 1;
+    if (fmt_bytes) *fmt_bytes = profiler().stats[i].fmt_bytes;
     return 0;
 }
 

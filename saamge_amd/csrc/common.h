@@ -257,8 +257,9 @@ struct KernelStat {
     std::string name;
     double ms = 0.0;
     int64_t launches = 0;
-    double bytes = 0.0;  // ALGORITHMIC bytes summed over launches
+    double bytes = 0.0;  // ALGORITHMIC bytes summed over launches (the CSR stream of the reference)
     double flops = 0.0;  // ALGORITHMIC flops summed over launches
+    double fmt_bytes = 0.0;  // bytes the kernel has to move IN THE FORMAT IT RUNS (coded SELL slices, tables, vectors); 0: same as bytes
 };
 
 struct Profiler {
@@ -281,7 +282,7 @@ struct Profiler {
         }
         SA_HIP_CHECK(hipEventRecord(e0, s));
     }
-    void end(hipStream_t s, const char *name, double bytes, double flops) {
+    void end(hipStream_t s, const char *name, double bytes, double flops, double fmt_bytes = 0.0) {
         if (!enabled) return;
         SA_HIP_CHECK(hipEventRecord(e1, s));
         SA_HIP_CHECK(hipEventSynchronize(e1));
@@ -292,6 +293,7 @@ struct Profiler {
         k.launches += 1;
         k.bytes += bytes;
         k.flops += flops;
+        k.fmt_bytes += fmt_bytes > 0.0 ? fmt_bytes : bytes;
     }
 };
 

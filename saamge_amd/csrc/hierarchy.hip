@@ -860,8 +860,10 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
         const RowsSpan span{(int64_t)rel.AE_to_dof.I[ae0], (int64_t)rel.AE_to_dof.I[nparts]};
         if (lev == 0 && !dense_only && ae_sparse_rows(s, L.drel, L.A, L.elmat, ae0, batch, RW, rv, rc, &span)) {
             // fine level: straight from the sparse rows of the AE matrices
+            int kmax = 0;
+            for (int km : L.mis_k) kmax = std::max(kmax, km);
             coarse_elmats_sparse(s, L.drel, ae0, batch, RW, rv, rc, L.d_mis_k.p, L.d_mis_u_off.p, L.mis_U.p,
-                                 d_colpos_ptr.p, d_colpos.p, N.elmat.off.p, N.elmat.val.p, scratch, d_soff.p);
+                                 d_colpos_ptr.p, d_colpos.p, N.elmat.off.p, N.elmat.val.p, scratch, d_soff.p, kmax);
         } else {
             ae_build(s, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch, false, nullptr);
             coarse_elmats(s, L.drel, ae0, batch, L.d_mis_k.p, L.d_mis_u_off.p, L.mis_U.p, d_colpos_ptr.p,

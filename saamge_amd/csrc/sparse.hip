@@ -825,6 +825,14 @@ static inline double spmv_bytes(const DCsr &A, RowRange rr) {
     return (12.0 * A.nnz + 20.0 * A.nrows) * frac;
 }
 static inline double spmv_rows(const DCsr &A, RowRange rr) { return rr.nrows < 0 ? A.nrows : rr.nrows; }
+// bytes of matrix data in the format the kernels run (build_sell's census) + x read and y written once
+static inline double spmv_fmt_bytes(const DCsr &A, RowRange rr) {
+    if (!A.has_sell) return 0.0;
+    const double frac = (rr.nrows < 0 || A.nrows == 0) ? 1.0 : (double)rr.nrows / A.nrows;
+    return (A.sell_stream_bytes + 16.0 * A.nrows) * frac;
+}
+// the SpMV family is listed per operator size: "<name>@<rows>" (the levels of a hierarchy have very different formats)
+static inline std::string spmv_label(const char *name, const DCsr &A) { return std::string(name) + "@" + std::to_string(A.nrows); }
 static inline double spmv_flops(const DCsr &A, RowRange rr) {
     return 2.0 * A.nnz * ((rr.nrows < 0 || A.nrows == 0) ? 1.0 : (double)rr.nrows / A.nrows);
 }
@@ -832,23 +840,26 @@ static inline double spmv_flops(const DCsr &A, RowRange rr) {
 void spmv(hipStream_t s, const DCsr &A, const double *x, double *y, RowRange rr) {
     profiler().begin(s);
     launch_spmv<MODE_PLAIN>(s, A, rr, x, y, nullptr, nullptr, 0.0);
-    profiler().end(s, "spmv", spmv_bytes(A, rr), spmv_flops(A, rr));
+    profiler().end(s, spmv_label("spmv", A).c_str(), spmv_bytes(A, rr), spmv_flops(A, rr), spmv_fmt_bytes(A, rr));
 }
 void spmv_residual(hipStream_t s, const DCsr &A, const double *x, const double *b, double *r, RowRange rr) {
     profiler().begin(s);
     launch_spmv<MODE_RESIDUAL>(s, A, rr, x, r, b, nullptr, 0.0);
-    profiler().end(s, "spmv_residual", spmv_bytes(A, rr) + 8.0 * spmv_rows(A, rr), spmv_flops(A, rr));
+    profiler().end(s, spmv_label("spmv_residual", A).c_str(), spmv_bytes(A, rr) + 8.0 * spmv_rows(A, rr), spmv_flops(A, rr),
+                   spmv_fmt_bytes(A, rr) + (A.has_sell ? 8.0 * spmv_rows(A, rr) : 0.0));
 }
 void spmv_add(hipStream_t s, const DCsr &P, const double *xc, double *x, RowRange rr) {
     profiler().begin(s);
     launch_spmv<MODE_ADD>(s, P, rr, xc, x, nullptr, nullptr, 0.0);
-    profiler().end(s, "spmv_add", spmv_bytes(P, rr) + 8.0 * spmv_rows(P, rr), spmv_flops(P, rr));
+    profiler().end(s, spmv_label("spmv_add", P).c_str(), spmv_bytes(P, rr) + 8.0 * spmv_rows(P, rr), spmv_flops(P, rr),
+                   spmv_fmt_bytes(P, rr) + (P.has_sell ? 8.0 * spmv_rows(P, rr) : 0.0));
 }
 void smooth_step(hipStream_t s, const DCsr &A, const double *dinv_neg, const double *b,
                  const double *xin, double *xout, double scale, RowRange rr) {
     profiler().begin(s);
     launch_spmv<MODE_SMOOTH>(s, A, rr, xin, xout, b, dinv_neg, scale);
-    profiler().end(s, "smooth_step", spmv_bytes(A, rr) + 24.0 * spmv_rows(A, rr), spmv_flops(A, rr));
+    profiler().end(s, spmv_label("smooth_step", A).c_str(), spmv_bytes(A, rr) + 24.0 * spmv_rows(A, rr), spmv_flops(A, rr),
+                   spmv_fmt_bytes(A, rr) + (A.has_sell ? 16.0 * spmv_rows(A, rr) : 0.0));
 }
 
 __global__ __launch_bounds__(256) void smooth_first_kernel(int n, const double *__restrict__ dinv,

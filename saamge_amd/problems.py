@@ -511,10 +511,11 @@ def elasticity3d_problem(n, blk=(4, 4, 4), lam=1.0, mu=1.0, coarse_blk=None):
                    partitions=parts, dims=n, order=1, Kref=Kref, coefs=np.ones(NE))
 
 
-def poisson3d_device(n, blk=(8, 8, 4), coarse_blk=None, K=(1.0, 1.0, 1.0), device="cuda"):
-    """Same problem as poisson3d_problem (constant coefficient), generated directly in
-    HBM with torch so that 128^3 / 256^3 inputs never touch the host.  Returns a Problem
-    whose arrays are torch tensors on `device` (A as rowptr/col/val tensors)."""
+def poisson3d_device(n, blk=(8, 8, 4), coarse_blk=None, K=(1.0, 1.0, 1.0), device="cuda", coef=None):
+    """Same problem as poisson3d_problem, generated directly in HBM with torch so that 128^3 / 256^3 inputs never
+    touch the host.  Returns a Problem whose arrays are torch tensors on `device` (A as rowptr/col/val tensors).
+    coef: None (constant) or "skew" (poisson3d_problem's smooth coefficient without any symmetry: no two
+    agglomerates congruent, every stored entry a different value -- a GENERAL operator for the SpMV formats)."""
     import torch
     if np.isscalar(n):
         n = (int(n),) * 3
@@ -534,6 +535,16 @@ def poisson3d_device(n, blk=(8, 8, 4), coarse_blk=None, K=(1.0, 1.0, 1.0), devic
     ix = torch.arange(nvx, device=dev).view(1, 1, -1)
     ess = ((ix == 0) | (ix == nx) | (iy == 0) | (iy == ny) | (iz == 0) | (iz == nz)).reshape(-1)
     node = ((iz * nvy + iy) * nvx + ix).reshape(-1)
+    cel = None
+    if coef == "skew":
+        cz = ((torch.arange(nz, device=dev, dtype=torch.float64) + 0.5) * h[2]).view(-1, 1, 1)
+        cy = ((torch.arange(ny, device=dev, dtype=torch.float64) + 0.5) * h[1]).view(1, -1, 1)
+        cx = ((torch.arange(nx, device=dev, dtype=torch.float64) + 0.5) * h[0]).view(1, 1, -1)
+        cel = torch.exp(0.7 * cx + 0.4 * cy - 0.3 * cz) * (1.0 + 0.3 * torch.sin(5.0 * cx + 3.0 * cy + 7.0 * cz))
+        cpad = torch.zeros((nz + 2, ny + 2, nx + 2), dtype=torch.float64, device=dev)      # zero outside the mesh
+        cpad[1:-1, 1:-1, 1:-1] = cel
+    elif coef is not None:
+        raise ValueError("poisson3d_device: coef must be None or 'skew'")
     vals = torch.zeros((ND, 27), dtype=torch.float64, device=dev)
     cols = torch.zeros((ND, 27), dtype=torch.int32, device=dev)
     valid = torch.zeros((ND, 27), dtype=torch.bool, device=dev)
@@ -555,7 +566,11 @@ def poisson3d_device(n, blk=(8, 8, 4), coarse_blk=None, K=(1.0, 1.0, 1.0), devic
                                 continue
                             inside = ((ex >= 0) & (ex < nx) & (ey >= 0) & (ey < ny) &
                                       (ez >= 0) & (ez < nz))
-                            acc = acc + torch.where(inside & ok, Kref[lidx[a], lidx[b]], 0.0)
+                            if cel is None:
+                                acc = acc + torch.where(inside & ok, Kref[lidx[a], lidx[b]], 0.0)
+                            else:      # coefficient of element (ex, ey, ez): the padded array, shifted views
+                                ce = cpad[1 + sz:1 + sz + nvz, 1 + sy:1 + sy + nvy, 1 + sx:1 + sx + nvx]
+                                acc = acc + torch.where(inside & ok, ce * Kref[lidx[a], lidx[b]], 0.0)
                 vals[:, o] = acc.reshape(-1)
                 cols[:, o] = ((jz * nvy + jy) * nvx + jx).reshape(-1).to(torch.int32)
                 valid[:, o] = ok.expand(nvz, nvy, nvx).reshape(-1)
@@ -577,7 +592,10 @@ def poisson3d_device(n, blk=(8, 8, 4), coarse_blk=None, K=(1.0, 1.0, 1.0), devic
     ex = torch.arange(nx, device=dev).view(1, 1, -1)
     e2d = torch.stack([(((ez + c) * nvy + (ey + b_)) * nvx + (ex + a)).reshape(-1)
                        for (a, b_, c) in _HEX_LOC], dim=1).to(torch.int32).contiguous()
-    elmat = Kref.reshape(1, 64).expand(NE, 64).contiguous()
+    if cel is None:
+        elmat = Kref.reshape(1, 64).expand(NE, 64).contiguous()
+    else:
+        elmat = (cel.reshape(-1, 1) * Kref.reshape(1, 64)).contiguous()
     # right-hand side f = 1
     wx = torch.full((nvx,), 1.0, dtype=torch.float64, device=dev); wx[0] = wx[-1] = 0.5
     wy = torch.full((nvy,), 1.0, dtype=torch.float64, device=dev); wy[0] = wy[-1] = 0.5
