@@ -157,9 +157,16 @@ int saamge_amd_update_operators(saamge_amd_hierarchy *h, const double *new_val) 
 
 void saamge_amd_ml_free_data(saamge_amd_hierarchy *h) {
     if (!h) return;
-    if (h->H) set_thread_stream(h->H->stream);
+    hipStream_t hs = nullptr;
+    const bool had = h->H != nullptr;
+    if (had) {
+        hs = h->H->stream;
+        set_thread_stream(hs);
+    }
     delete h->H;
     delete h;
+    // the caller may destroy its stream right after this call: no batch of frees stays open on it
+    if (had) dev_pool_close_stream(hs);
 }
 
 // stage a host vector on the device when needed
@@ -334,6 +341,7 @@ static int get_csr(const saamge_amd_hierarchy *h, int level, int which, void *ro
     SA_API_BEGIN
     SA_REQUIRE(h, "null argument");
     const Hierarchy &H = *h->H;
+    require_device(H);
     const DCsr &M = level_op(H, level, which);
     hipStream_t s = H.stream;
     if (rowptr && rowptr_bits == 64)
@@ -356,6 +364,7 @@ int saamge_amd_get_table(const saamge_amd_hierarchy *h, int level, int which, in
                          long long *nconn, int *I, int *J) {
     SA_API_BEGIN
     SA_REQUIRE(h, "null argument");
+    require_device(*h->H);
     {   // tables kept on the device by the device topology build: host copies on demand
         Level &Lw = *h->H->levels.at(level);
         fetch_relations_ae_host(Lw.rel, Lw.drel, h->H->stream);
@@ -392,6 +401,7 @@ int saamge_amd_get_mis(const saamge_amd_hierarchy *h, int level, int *mises, int
                        int *mis_ncols, signed char *agg_flags) {
     SA_API_BEGIN
     SA_REQUIRE(h, "null argument");
+    require_device(*h->H);
     {
         Level &Lw = *h->H->levels.at(level);
         fetch_relations_ae_host(Lw.rel, Lw.drel, h->H->stream);

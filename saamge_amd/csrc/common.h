@@ -98,9 +98,16 @@ void *dev_alloc(size_t bytes);
 void dev_free(void *p) noexcept;
 void dev_pool_release();
 size_t dev_pool_idle_bytes();
-struct ThreadStreamScope {       // a worker thread's stream for its lifetime
-    explicit ThreadStreamScope(hipStream_t s) { set_thread_stream(s); }
+struct ThreadStreamScope {       // the calling thread's stream for a scope (restored at its end)
+    hipStream_t prev;
+    bool had;
+    explicit ThreadStreamScope(hipStream_t s) : prev(thread_stream()), had(thread_stream_is_set()) { set_thread_stream(s); }
+    ~ThreadStreamScope() { if (had) set_thread_stream(prev); }
 };
+// Close the batch of frees `s` is filling NOW (its event is recorded while the stream is certainly alive) -- called
+// when a hierarchy is destroyed: its caller may destroy the stream next, and an open batch would later record its
+// event on a dead handle.
+void dev_pool_close_stream(hipStream_t s);
 
 // RAII device buffer.
 template <class T>

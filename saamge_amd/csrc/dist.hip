@@ -126,7 +126,10 @@ void halo_then(Hierarchy &H, Level::Dist *D, double *x, const std::function<void
     RowRange in;
     in.row0 = D->int_row0;
     in.nrows = D->int_nrows;
-    op(side, in);                                             // rows without halo entries: beside the exchange
+    {
+        ThreadStreamScope on_side(side);                      // (temporaries of op() are freed in the side stream's order)
+        op(side, in);                                         // rows without halo entries: beside the exchange
+    }
     SA_HIP_CHECK(hipEventRecord(H.ev_join, side));
     halo_exchange(H, *D, x);
     RowRange lo, hi;

@@ -236,6 +236,26 @@ void dev_free(void *p) noexcept {
         (void)pool_drop_block(P, std::prev(P.idle.end()));
 }
 
+void dev_pool_close_stream(hipStream_t s) {
+    DevPool &P = dev_pool();
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lk(P.mu);
+    auto it = P.open.find(std::make_pair(dev, s));
+    if (it == P.open.end()) return;
+    Epoch *ep = it->second;
+    if (ep->refs == 0) {                  // an open batch without blocks: it just goes
+        P.events.push_back(ep->ev);
+        P.open.erase(it);
+        delete ep;
+        return;
+    }
+    if (!epoch_record(P, ep)) {           // (cannot record: wait for the stream instead, then the blocks are idle for certain)
+        (void)hipStreamSynchronize(s);
+        ep->recorded = true;
+        P.open.erase(it);
+    }
+}
+
 void dev_pool_release() {
     DevPool &P = dev_pool();
     std::lock_guard<std::mutex> lk(P.mu);

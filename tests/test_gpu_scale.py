@@ -75,7 +75,7 @@ def _check(g, out, tag):
 
 
 @pytest.mark.parametrize("eigensolver", ["subspace", "dense"])
-@pytest.mark.parametrize("name", ["scale_64x64x32", "scale_64x64x32_skew", "scale_96x96x64"])
+@pytest.mark.parametrize("name", ["scale_64x64x32", "scale_64x64x32_skew", "scale_96x96x64", "scale_96x96x64_skew"])
 def test_scale_golden(name, eigensolver):
     g, out = _run(name, eigensolver)
     _check(g, out, "%s/%s" % (name, eigensolver))
