@@ -50,6 +50,11 @@ __global__ __launch_bounds__(256) void spmv_kernel(int nrows, const roff_t *__re
 // stencil matrix -- carry ONE BYTE per entry instead of the 4-byte column: a code into the slice's
 // offset table, which sits one entry per lane in a register and is read with a cross-lane
 // permute.  9 instead of 12 bytes per stored entry on the level that dominates the solve.
+// pair-coded slices: ntab = 256 + pairs (own table at tab[64 slice ..]) or 512 + pairs (the table of the slice's tile of
+// four, at the tile's first slice: sell_code_kernel's merge)
+__device__ __forceinline__ int pair_count(int nt) { return nt >= 512 ? nt - 512 : nt - 256; }
+__device__ __forceinline__ size_t pair_table_at(int gslice, int nt) { return (size_t)(nt >= 512 ? (gslice & ~3) : gslice) * 64; }
+
 // general path: any mix of slice formats, any width.  Returns the row's sum; `slice` / `gslice` are wave-uniform.
 __device__ __forceinline__ double sell_row_general(int lane, int grow, int gslice, roff_t beg, roff_t end, int nt,
                                                    const int *__restrict__ col, const double *__restrict__ val,
@@ -64,9 +69,9 @@ __device__ __forceinline__ double sell_row_general(int lane, int grow, int gslic
         // pair-coded slice: the byte indexes a table of (offset, VALUE) pairs -- at most 64 distinct ones in
         // the slice, which is every slice of a constant-coefficient stencil matrix (the whole fine level of the
         // headline problem).  Neither columns nor values are streamed: 1 byte per stored entry instead of 12.
-        const int np = nt - 256;
-        const int mytab = (lane < np) ? tab[(size_t)gslice * 64 + lane] : 0;
-        const double myval = (lane < np) ? vtab[(size_t)gslice * 64 + lane] : 0.0;
+        const int np = pair_count(nt);
+        const int mytab = (lane < np) ? tab[pair_table_at(gslice, nt) + lane] : 0;
+        const double myval = (lane < np) ? vtab[pair_table_at(gslice, nt) + lane] : 0.0;
         const unsigned *wp = codes + ((size_t)(beg >> 2) + (size_t)gslice * 64 + lane);
         auto quad = [&](unsigned cw) {
             const int i0 = (int)(cw & 255u), i1 = (int)((cw >> 8) & 255u), i2 = (int)((cw >> 16) & 255u), i3 = (int)(cw >> 24);
@@ -182,13 +187,13 @@ __device__ __forceinline__ void sell_slice(PairEntry *lt, int nrows, int row0, l
     const int grow = row0 + (int)row;
     double e_b = 0.0, e_d = 0.0, e_x = 0.0, sum;
     if (fast_ok && nt >= 256 && w <= 32) {
-        const int np = nt - 256;
+        const int np = pair_count(nt);
         const unsigned *wp = codes + ((size_t)(beg >> 2) + (size_t)gslice * 64 + lane);
         unsigned cws[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) cws[q] = (4 * q < w) ? __builtin_nontemporal_load(wp + 64 * q) : 0u;
-        const int mytab = (lane < np) ? tab[(size_t)gslice * 64 + lane] : 0;
-        const double myval = (lane < np) ? vtab[(size_t)gslice * 64 + lane] : 0.0;
+        const int mytab = (lane < np) ? tab[pair_table_at(gslice, nt) + lane] : 0;
+        const double myval = (lane < np) ? vtab[pair_table_at(gslice, nt) + lane] : 0.0;
         if (MODE == MODE_RESIDUAL && live) e_b = b[row];
         if (MODE == MODE_ADD && live) e_x = y[row];
         if (MODE == MODE_SMOOTH && live) { e_b = b[row]; e_d = dinv[row]; e_x = xrow[row]; }
@@ -289,14 +294,15 @@ __global__ __launch_bounds__(256) void sell_staged_kernel(int nrows, int row0, i
     // this slice's streams first: they are in flight while the segments are staged
     const roff_t beg = sptr[slice], end = sptr[slice + 1];
     const int gslice = (row0 >> 6) + slice;
-    const int np = ntab[gslice] - 256;
+    const int nt = ntab[gslice];
+    const int np = pair_count(nt);
     const int w = (int)((end - beg) >> 6);
     const unsigned *wp = codes + ((size_t)(beg >> 2) + (size_t)gslice * 64 + lane);
     unsigned cws[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) cws[q] = (4 * q < w) ? __builtin_nontemporal_load(wp + 64 * q) : 0u;
-    const int mytab = (lane < np) ? tab[(size_t)gslice * 64 + lane] : 0;
-    const double myval = (lane < np) ? vtab[(size_t)gslice * 64 + lane] : 0.0;
+    const int mytab = (lane < np) ? tab[pair_table_at(gslice, nt) + lane] : 0;
+    const double myval = (lane < np) ? vtab[pair_table_at(gslice, nt) + lane] : 0.0;
     double e_b = 0.0, e_d = 0.0, e_x = 0.0;
     if (MODE == MODE_RESIDUAL) e_b = b[row];
     if (MODE == MODE_ADD) e_x = y[row];
@@ -433,7 +439,8 @@ __global__ __launch_bounds__(64) void sell_stage_kernel(int ntiles, int nslices,
         const int nt = ntab[sl];
         const int w = (int)((sptr[sl + 1] - sptr[sl]) >> 6);
         ok = nt >= 256 && w <= 32;
-        if (ok) v[64 * q + lane] = lane < nt - 256 ? tab[(size_t)sl * 64 + lane] : INT_MAX;
+        // (a tile that shares one table: listed once, by its first slice)
+        if (ok) v[64 * q + lane] = (lane < pair_count(nt) && (nt < 512 || q == 0)) ? tab[pair_table_at(sl, nt) + lane] : INT_MAX;
     }
     auto give_up = [&]() {      // max_total[2]: number of tiles left to the gather kernel, listed in `unstaged`
         if (lane == 0) {
@@ -514,7 +521,7 @@ __global__ __launch_bounds__(256) void sell_census_kernel(int nslices, const rof
     const int nt = in ? ntab[s] : -1;
     const int c = nt >= 256 ? 0 : (nt >= 0 ? 1 : 2);
     // (one atomic per wavefront and counter: 265 000 threads adding to the same eight words took 6.5 ms)
-    unsigned long long part[8];
+    unsigned long long part[9];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         part[k] = in && c == k ? 1ull : 0ull;
@@ -522,8 +529,10 @@ __global__ __launch_bounds__(256) void sell_census_kernel(int nslices, const rof
     }
     part[6] = in && c < 2 ? (unsigned long long)((w + 3) / 4) * 64ull : 0ull;
     part[7] = (unsigned long long)w;
+    // (a slice that reads its tile's table has none of its own: counted as a negative share of the table bytes below)
+    part[8] = in && nt >= 512 && (s & 3) != 0 ? 1ull : 0ull;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 9; ++k) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const unsigned long long other = __shfl_xor(part[k], o, 64);
@@ -535,6 +544,7 @@ __global__ __launch_bounds__(256) void sell_census_kernel(int nslices, const rof
         for (int k = 0; k < 7; ++k)
             if (part[k]) atomicAdd(cls + k, part[k]);
         atomicMax(cls + 7, part[7]);
+        if (part[8]) atomicAdd(cls + 8, part[8]);
     }
 }
 
@@ -599,14 +609,22 @@ __global__ __launch_bounds__(256) void sell_code_kernel(int nslices, const roff_
                                                         const int *__restrict__ scol, const double *__restrict__ sval,
                                                         int *__restrict__ ntab, int *__restrict__ tab,
                                                         double *__restrict__ vtab, unsigned *__restrict__ codes,
-                                                        int with_values) {
-    const int slice = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (slice >= nslices) return;
-    const roff_t beg = sptr[slice];
-    const int w = (int)((sptr[slice + 1] - beg) >> 6);
+                                                        int with_values, int share_tables) {
+    // (tile = the four slices of this block; merge phase below)
+    __shared__ int m_off[4][64];
+    __shared__ long long m_val[4][64];
+    __shared__ int m_np[4];                 // pairs of the slice's own table, -1: the slice is not (short) pair-coded
+    __shared__ unsigned char m_map[4][64];  // own code -> code in the tile's table
+    __shared__ int m_ok, m_nt;
+    const int wv = threadIdx.x >> 6;
+    const int slice = blockIdx.x * 4 + wv, lane = threadIdx.x & 63;
+    const bool have = slice < nslices;
+    const roff_t beg = have ? sptr[slice] : 0;
+    const int w = have ? (int)((sptr[slice + 1] - beg) >> 6) : 0;
     const int row = slice * 64 + lane;
     unsigned *wp = codes + ((size_t)(beg >> 2) + (size_t)slice * 64 + lane);
-    for (int pass = with_values ? 0 : 1; pass < 2; ++pass) {
+    int my_np = -1;
+    for (int pass = with_values ? 0 : 1; pass < 2 && have; ++pass) {
         const bool pairs = pass == 0;
         int mytab = 0, nt = 0;
         long long myval = 0;
@@ -644,9 +662,66 @@ __global__ __launch_bounds__(256) void sell_code_kernel(int nslices, const roff_
             tab[(size_t)slice * 64 + lane] = mytab;
             if (pairs) vtab[(size_t)slice * 64 + lane] = __longlong_as_double(myval);
             if (lane == 0) ntab[slice] = ok ? (pairs ? 256 + nt : nt) : -1;
-            return;
+            if (ok && pairs && w <= 32) {
+                my_np = nt;
+                m_off[wv][lane] = mytab;
+                m_val[wv][lane] = myval;
+            }
+            break;
         }
     }
+    // ---- one table for the tile (share_tables): the four slice tables of a stencil operator hold the same pairs in
+    // different orders (12 bytes per row of table traffic, a third of the matrix stream); merged into one of at most
+    // 64 pairs the tile's four wavefronts read the same 768 bytes.  ntab = 512 + pairs marks "table at the tile's
+    // first slice".  Lossless: every code still names the same (offset, value) pair.
+    if (!share_tables) return;
+    if (lane == 0) m_np[wv] = my_np;
+    if (threadIdx.x == 0) m_ok = 1;
+    __syncthreads();
+    if (m_np[0] < 0 || m_np[1] < 0 || m_np[2] < 0 || m_np[3] < 0) return;      // (uniform: a partial or mixed tile keeps its own tables)
+    if (wv == 0) {
+        int t_off = m_off[0][lane];
+        long long t_val = m_val[0][lane];
+        int nT = m_np[0];
+        m_map[0][lane] = (unsigned char)lane;
+        bool ok = true;
+        for (int q = 1; q < 4 && ok; ++q)
+            for (int e = 0; e < m_np[q]; ++e) {
+                const int d = m_off[q][e];
+                const long long dv = m_val[q][e];
+                const unsigned long long hit = __ballot(lane < nT && t_off == d && t_val == dv);
+                int code;
+                if (hit) code = __ffsll((long long)hit) - 1;
+                else {
+                    if (nT == 64) { ok = false; break; }
+                    if (lane == nT) { t_off = d; t_val = dv; }
+                    code = nT++;
+                }
+                if (lane == 0) m_map[q][e] = (unsigned char)code;
+            }
+        if (lane == 0) { m_ok = ok ? 1 : 0; m_nt = nT; }
+        if (ok) {
+            m_off[0][lane] = t_off;
+            m_val[0][lane] = t_val;
+        }
+    }
+    __syncthreads();
+    if (!m_ok) return;
+    // every wavefront rewrites ITS OWN code words (written above by the same lanes) through the map
+    for (int q4 = 0; 4 * q4 < w; ++q4) {
+        const unsigned cw = wp[64 * q4];
+        unsigned out = 0;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4)
+            if (4 * q4 + e4 < w) out |= (unsigned)m_map[wv][(cw >> (8 * e4)) & 63u] << (8 * e4);
+        wp[64 * q4] = out;
+    }
+    const int first = blockIdx.x * 4;
+    if (wv == 0) {
+        tab[(size_t)first * 64 + lane] = lane < m_nt ? m_off[0][lane] : 0;
+        vtab[(size_t)first * 64 + lane] = lane < m_nt ? __longlong_as_double(m_val[0][lane]) : 0.0;
+    }
+    if (lane == 0) ntab[slice] = 512 + m_nt;
 }
 
 __global__ __launch_bounds__(256) void widen_offsets_kernel(long n, const int *__restrict__ in, roff_t *__restrict__ out) {
@@ -711,27 +786,28 @@ void build_sell(hipStream_t s, DCsr &A) {
     A.sell_vtab.alloc((size_t)A.nslices * 64);
     // (SAAMGE_AMD_SELL_CODES=1: offset codes only, values always streamed)
     static const bool no_vals = std::getenv("SAAMGE_AMD_SELL_CODES") && std::atoi(std::getenv("SAAMGE_AMD_SELL_CODES")) == 1;
+    static const bool no_share = std::getenv("SAAMGE_AMD_SELL_SHARE") && std::atoi(std::getenv("SAAMGE_AMD_SELL_SHARE")) == 0;
     if (no_codes)
         SA_HIP_CHECK(hipMemsetAsync(A.sell_ntab.p, 0xff, sizeof(int) * (size_t)A.nslices, s));
     else
         hipLaunchKernelGGL(sell_code_kernel, dim3(div_up(A.nslices, 4)), dim3(256), 0, s, A.nslices, A.sell_ptr.p,
                            A.sell_col.p, A.sell_val.p, A.sell_ntab.p, A.sell_tab.p, A.sell_vtab.p, A.sell_code.p,
-                           no_vals ? 0 : 1);
+                           no_vals ? 0 : 1, no_share ? 0 : 1);
     SA_HIP_CHECK(hipGetLastError());
     // what the copy holds, per slice format: the bytes one application has to move (the roofline of the SpMV family
     // prices THESE, bench.py) and whether the all-pair-coded fast path applies
-    DBuf<unsigned long long> cls(8);
-    SA_HIP_CHECK(hipMemsetAsync(cls.p, 0, 8 * sizeof(unsigned long long), s));
+    DBuf<unsigned long long> cls(9);
+    SA_HIP_CHECK(hipMemsetAsync(cls.p, 0, 9 * sizeof(unsigned long long), s));
     hipLaunchKernelGGL(sell_census_kernel, dim3(div_up(A.nslices, 256)), dim3(256), 0, s, A.nslices, A.sell_ptr.p,
                        A.sell_ntab.p, cls.p);
     SA_HIP_CHECK(hipGetLastError());
-    unsigned long long h[8];
+    unsigned long long h[9];
     SA_HIP_CHECK(hipMemcpyAsync(h, cls.p, sizeof(h), hipMemcpyDeviceToHost, s));
     SA_HIP_CHECK(hipStreamSynchronize(s));
     for (int c = 0; c < 3; ++c) { A.sell_class_slices[c] = (int64_t)h[c]; A.sell_class_entries[c] = (int64_t)h[3 + c]; }
     // codes 4 B per word, tables 4 (+8) B per lane of a coded slice, values / columns of the formats that stream them,
     // 8 B slice offset + 4 B table size per slice
-    A.sell_stream_bytes = 4.0 * (double)h[6] + 12.0 * 64.0 * (double)h[0] + 4.0 * 64.0 * (double)h[1] +
+    A.sell_stream_bytes = 4.0 * (double)h[6] + 12.0 * 64.0 * (double)(h[0] - h[8]) + 4.0 * 64.0 * (double)h[1] +
                           8.0 * (double)h[4] + 12.0 * (double)h[5] + 12.0 * (double)A.nslices;
     static const bool no_fast = std::getenv("SAAMGE_AMD_SELL_PAIR_FAST") && std::atoi(std::getenv("SAAMGE_AMD_SELL_PAIR_FAST")) == 0;
     A.sell_fast_ok = !no_fast && A.ncols < (1 << 29);      // (32-bit byte offsets into x on the short-chain path)
