@@ -7,7 +7,7 @@ cd /tmp
 i=0
 for C in "$@"; do
   i=$((i+1))
-  timeout -k 10 90 rocprofv3 --pmc $C --kernel-include-regex "sell_spmv|stream_mix" --kernel-trace --output-format csv -d $O/p$i -o p -- $R/tools/spmv_lab 257 > $O/p$i.log 2>&1
+  timeout -k 10 90 rocprofv3 --pmc $C --kernel-include-regex "sell_|stream_mix|lab_kernel" --kernel-trace --output-format csv -d $O/p$i -o p -- $R/tools/spmv_lab 257 > $O/p$i.log 2>&1
   echo "pass $i ($C) rc=$?"
 done
 cd $R
