@@ -4,7 +4,7 @@
 // the PCG inner products (amg/src/mfem_addons.cpp:106-248).
 //
 // Layout: every rank keeps GLOBAL-length vectors; rank r owns rows [row_off[r], row_off[r+1])
-// (boundaries are multiples of 64 so that SELL-64 slices are never split) and applies only those
+// (boundaries are multiples of 256 so that neither SELL-64 slices nor the 256-row tiles of the staged kernel are split) and applies only those
 // rows of A_l, reading x by global column index.  Entries of x outside the own range are valid
 // only at the halo positions (the columns the own rows reference), which are refreshed from
 // their owners before each SpMV: pack kernel -> alltoallv (RCCL send/recv groups through
@@ -154,7 +154,7 @@ bool dist_setup_level(Hierarchy &H, int lev) {
     hipStream_t s = H.stream;
     D.row_off.assign((size_t)world + 1, 0);
     for (int r = 1; r < world; ++r) {
-        long long b = ((long long)n * r / world + 63) / 64 * 64;
+        long long b = ((long long)n * r / world + 255) / 256 * 256;
         D.row_off[r] = (int)std::min<long long>(std::max<long long>(b, D.row_off[r - 1]), n);
     }
     D.row_off[world] = n;
@@ -244,9 +244,13 @@ bool dist_setup_level(Hierarchy &H, int lev) {
                 if (i - run0 > best) { best = i - run0; best0 = run0; }
                 run0 = i + 1;
             }
-        if (best >= 1 && 4 * best >= nsl) {
-            D.int_row0 = D.row0 + 64 * best0;
-            D.int_nrows = std::min(64 * best, D.row0 + D.nloc - D.int_row0);
+        // (whole 256-row tiles: the three row ranges of an application then all take the staged kernel)
+        const int end0 = best0 + best;
+        const int a0 = (best0 + 3) / 4 * 4;
+        const int a1 = (end0 == nsl) ? nsl : end0 / 4 * 4;
+        if (a1 - a0 >= 1 && 4 * (a1 - a0) >= nsl) {
+            D.int_row0 = D.row0 + 64 * a0;
+            D.int_nrows = std::min(64 * (a1 - a0), D.row0 + D.nloc - D.int_row0);
         }
     }
     L.r.zero(s);  // the restriction R r sums over ranks: r must vanish outside the own rows

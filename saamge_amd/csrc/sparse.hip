@@ -855,7 +855,8 @@ static void launch_spmv(hipStream_t s, const DCsr &A, RowRange rr, const double 
     if (b) b += row0;
     if (dinv) dinv += row0;
     const double *xrow = x + row0;
-    if (A.has_sell && A.sell_stage_cap > 0 && row0 % 256 == 0) {
+    // (tiles are global: a row range takes the staged kernel when it starts on a tile and ends on one or with the operator)
+    if (A.has_sell && A.sell_stage_cap > 0 && row0 % 256 == 0 && (nrows % 256 == 0 || row0 + nrows == A.nrows)) {
         const int nblocks = div_up((long)div_up(nrows, 64) * 64, 256);
         static const bool no_xcd = std::getenv("SAAMGE_AMD_SELL_XCD") && std::atoi(std::getenv("SAAMGE_AMD_SELL_XCD")) == 0;
         const int per_xcd = no_xcd ? 0 : div_up(nblocks, 8);
