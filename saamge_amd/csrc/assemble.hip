@@ -395,6 +395,110 @@ __global__ __launch_bounds__(256) void ae_rows8_kernel(
     rcols[o] = (short)lc;
 }
 
+// The same with one workgroup per agglomerate and the agglomerate's own tables in LDS (round 3).  The kernel above
+// starts every (row, entry) thread from scratch: the row's dof and row offsets, then, for the entry's column, the
+// dof -> AE list scanned for this agglomerate, the local index, two flags -- a dozen loads per thread, six of them
+// scattered (one cache line per lane) and dependent.  Here the agglomerate's dof list goes into an LDS hash table
+// (dof -> local index) together with the flags and row offsets of its dofs; an entry then costs its column and value
+// (coalesced: the entries of a row are contiguous) and LDS look-ups.  Interface entries (both dofs between
+// agglomerates) still gather their element matrices as above.  hsize: a power of two >= 2 n.
+__global__ __launch_bounds__(256) void ae_rows8_lds_kernel(
+    int ae0, int RW, int hsize, const int *__restrict__ ns, const int64_t *__restrict__ voff,
+    const int *__restrict__ ae2d_I, const int *__restrict__ ae2d_J, const signed char *__restrict__ flags,
+    const int *__restrict__ d2e_I, const int *__restrict__ d2e_J, const int *__restrict__ part,
+    const int *__restrict__ e2d_J, const double *__restrict__ elval, const roff_t *__restrict__ Arow,
+    const int *__restrict__ Acol, const double *__restrict__ Aval, double *__restrict__ rvals,
+    short *__restrict__ rcols) {
+    extern __shared__ __align__(16) unsigned char ar_lds[];
+    const int b = blockIdx.x, p = ae0 + b, n = ns[b];
+    roff_t *la0 = (roff_t *)ar_lds;                 // [n] first entry of the row in A
+    int *lg = (int *)(la0 + n);                     // [n] global dof
+    int *llen = lg + n;                             // [n] entries of the row
+    int *hkey = llen + n;                           // [hsize] dof or -1
+    short *hval = (short *)(hkey + hsize);          // [hsize] local index
+    signed char *lflag = (signed char *)(hval + hsize);   // [n]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < hsize; i += 256) hkey[i] = -1;
+    __syncthreads();
+    const int *dofs = ae2d_J + ae2d_I[p];
+    for (int i = tid; i < n; i += 256) {
+        const int g = dofs[i];
+        const roff_t a0 = Arow[g];
+        lg[i] = g;
+        la0[i] = a0;
+        llen[i] = (int)(Arow[g + 1] - a0);
+        lflag[i] = flags[g];
+        unsigned hpos = ((unsigned)g * 2654435761u) & (unsigned)(hsize - 1);
+        while (atomicCAS(&hkey[hpos], -1, g) != -1) hpos = (hpos + 1) & (unsigned)(hsize - 1);
+        hval[hpos] = (short)i;
+    }
+    __syncthreads();
+    const size_t obase = (size_t)voff[b] * RW;
+    // four entries per thread and trip: their columns and values are requested together (one entry at a time, a thread
+    // walked its ~43 entries through 43 x two dependent global latencies)
+    constexpr int UN = 4;
+    for (int it0 = tid; it0 < n * RW; it0 += 256 * UN) {
+        int lrs[UN], cs[UN], lcs[UN];
+        double vs[UN];
+        roff_t as[UN];
+        bool on[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int it = it0 + 256 * u;
+            const int lr = it < n * RW ? it / RW : 0, k = it - lr * RW;
+            lrs[u] = lr;
+            on[u] = it < n * RW && k < llen[lr];
+            as[u] = la0[lr] + k;
+            cs[u] = on[u] ? Acol[as[u]] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) vs[u] = on[u] ? Aval[as[u]] : 0.0;      // (used unless the entry is assembled from elements)
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            lcs[u] = -1;
+            if (on[u]) {
+                const int c = cs[u];
+                unsigned hpos = ((unsigned)c * 2654435761u) & (unsigned)(hsize - 1);
+                for (;;) {
+                    const int key = hkey[hpos];
+                    if (key == c) { lcs[u] = hval[hpos]; break; }
+                    if (key == -1) break;
+                    hpos = (hpos + 1) & (unsigned)(hsize - 1);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int it = it0 + 256 * u;
+            if (it >= n * RW) continue;
+            const int lr = lrs[u], lc = lcs[u], c = cs[u];
+            double v = 0.0;
+            if (lc >= 0) {
+                const int g = lg[lr];
+                const int fg = lflag[lr], fc = lflag[lc];
+                const bool assembled = (fg & 1) && (fc & 1) && (!((fg | fc) & 2) || c == g);
+                if (!assembled) {
+                    v = vs[u];                      // copied from the global matrix (aggregates.cpp:930-934)
+                } else {                            // agg_assemble_value, aggregates.cpp:68-184
+                    const int qb = d2e_I[g], cnt = d2e_I[g + 1] - qb;
+                    for (int q = 0; q < cnt; ++q) {      // ascending element id: the order of the kernel above
+                        const int e = d2e_J[qb + q];
+                        if (part[e] != p) continue;
+                        const int4 lo = *(const int4 *)(e2d_J + (size_t)e * 8), hi = *(const int4 *)(e2d_J + (size_t)e * 8 + 4);
+                        const int kk = (lo.x == g) ? 0 : (lo.y == g) ? 1 : (lo.z == g) ? 2 : (lo.w == g) ? 3 :
+                                       (hi.x == g) ? 4 : (hi.y == g) ? 5 : (hi.z == g) ? 6 : 7;
+                        const int jj = (lo.x == c) ? 0 : (lo.y == c) ? 1 : (lo.z == c) ? 2 : (lo.w == c) ? 3 :
+                                       (hi.x == c) ? 4 : (hi.y == c) ? 5 : (hi.z == c) ? 6 : (hi.w == c) ? 7 : -1;
+                        if (jj >= 0) v += elval[((size_t)e * 8 + kk) * 8 + jj];
+                    }
+                }
+            }
+            rvals[obase + it] = v;
+            rcols[obase + it] = (short)lc;
+        }
+    }
+}
+
 constexpr int AB_MAXE = 8;   // elements per dof kept in the LDS row tables (hexes: <= 8)
 
 // NDE > 0: every element has exactly NDE dofs (level 0: elem_to_dof is a dense NE x NDE array),
@@ -739,6 +843,15 @@ static void launch_rows8(hipStream_t s, const DevRelations &rel, const DCsr &A, 
         dc = g_rcols.p;
     }
     profiler().begin(s);
+    static const bool old_rows = std::getenv("SAAMGE_AMD_AE_ROWS_LDS") && std::atoi(std::getenv("SAAMGE_AMD_AE_ROWS_LDS")) == 0;
+    int hsize = 64;
+    while (hsize < 2 * batch.max_n) hsize <<= 1;
+    const size_t lds = (size_t)batch.max_n * (8 + 4 + 4 + 1) + (size_t)hsize * 6 + 16;
+    if (!old_rows && lds <= 64 * 1024)
+        hipLaunchKernelGGL(ae_rows8_lds_kernel, dim3(batch.count), dim3(256), lds, s, ae0, RW, hsize, batch.n.p, batch.voff.p,
+                           rel.ae2d_I.p, rel.ae2d_J.p, rel.flags.p, rel.d2e_I.p, rel.d2e_J.p, rel.part.p, rel.e2d_J.p,
+                           el.val.p, A.rowptr.p, A.col.p, A.val.p, dv, dc);
+    else
     hipLaunchKernelGGL(ae_rows8_kernel, dim3(div_up((long)batch.max_n * RW, 256), batch.count), dim3(256), 0, s,
                        ae0, RW, batch.n.p, batch.voff.p, rel.ae2d_I.p, rel.ae2d_J.p, rel.d2ae_I.p,
                        rel.d2ae_J.p, rel.dof_id_inAE.p, rel.flags.p, rel.d2e_I.p, rel.d2e_J.p, rel.part.p,
