@@ -108,8 +108,10 @@ void saamge_amd_params_default(saamge_amd_params *p);
 /* ---- native collectives: RCCL over xGMI, one process per GPU (csrc/comm.hip) --------------------------------
  * Rank 0 draws a unique id and ships it to the other ranks by any means (MPI_Bcast, a file, torch.distributed's
  * store); every rank then creates its communicator on the stream its hierarchy will run on and installs it in
- * the parameters: rank, world and the three collectives are filled in, comm_stream_ordered = 1.  The
- * allgather / allreduce_sum / alltoallv callbacks remain the plug for MPI host codes. */
+ * the parameters: rank, world and the three collectives are filled in, comm_stream_ordered = 1.  The stream MUST be
+ * the one later given to saamge_amd_ml_produce_data (the collectives are ordered with the hierarchy's kernels only
+ * there): a mismatch is an error of saamge_amd_ml_produce_data.  The allgather / allreduce_sum / alltoallv callbacks
+ * remain the plug for MPI host codes. */
 typedef struct saamge_amd_comm saamge_amd_comm;
 int saamge_amd_comm_unique_id(char id[128]);
 int saamge_amd_comm_create(int rank, int world, const char id[128], void *stream, saamge_amd_comm **out);

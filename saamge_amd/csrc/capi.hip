@@ -34,6 +34,8 @@ static void require_device(const Hierarchy &H) {
     set_thread_stream(H.stream);     // device blocks freed by this call are ordered after the hierarchy's stream
 }
 
+extern "C" int saamge_amd_comm_native_stream(const saamge_amd_params *p, void **stream);      // comm.hip
+
 extern "C" {
 
 const char *saamge_amd_last_error(void) { return g_last_error.c_str(); }
@@ -115,6 +117,13 @@ static int produce_data(int n, const void *rowptr, int rowptr_bits, const int *c
     p.alltoallv = params->alltoallv;
     p.dist_min_local_rows = params->dist_min_local_rows;
     p.comm_stream_ordered = params->comm_stream_ordered;
+    {   // a native communicator enqueues its collectives on the stream it was created with: only on the hierarchy's own
+        // stream are they ordered with the hierarchy's kernels (round-2 advisor finding: nothing checked this on the C side)
+        void *cs = nullptr;
+        SA_REQUIRE(!saamge_amd_comm_native_stream(params, &cs) || cs == stream,
+                   "the communicator was created on another stream than the one given to saamge_amd_ml_produce_data: "
+                   "create it with saamge_amd_comm_create(..., stream, ...) on the hierarchy's stream");
+    }
     p.correct_nullspace = params->correct_nullspace;
     p.extra_modes = params->extra_modes;
     p.num_extra_modes = params->num_extra_modes;

@@ -174,6 +174,14 @@ void saamge_amd_comm_destroy(saamge_amd_comm *c) {
     delete c;
 }
 
+// For saamge_amd_ml_produce_data: is `p` wired to a native communicator, and on which stream does that one enqueue?
+// (the collectives are stream-ordered with the hierarchy only if it is the hierarchy's stream)
+extern "C" int saamge_amd_comm_native_stream(const saamge_amd_params *p, void **stream) {
+    if (!p || p->allgather != native_allgather || !p->allgather_ctx) return 0;
+    if (stream) *stream = (void *)((saamge_amd_comm *)p->allgather_ctx)->stream;
+    return 1;
+}
+
 int saamge_amd_params_set_comm(saamge_amd_params *p, saamge_amd_comm *c) {
     if (!p || !c) return 1;
     p->rank = c->rank;

@@ -236,6 +236,7 @@ struct DCsr {
     DBuf<int> sell_tile_nseg;
     DBuf<int2> sell_tile_seg;
     int sell_stage_cap = 0;
+    bool sell_one_table = false;   // every staged tile shares one pair table among its four slices
     DBuf<int> sell_unstaged;       // tiles left to the gather kernel (sell_nunstaged of them)
     int sell_nunstaged = 0;
 };

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void sell_spmv_kernel(int nrows, int row0, int
 // dynamic LDS: stage_cap doubles + 4 slice tables.
 template <int MODE>
 __global__ __launch_bounds__(256) void sell_staged_kernel(int nrows, int row0, int nblocks, int per_xcd, int stage_cap,
-                                                          int ncols, const roff_t *__restrict__ sptr,
+                                                          int ncols, int one_table, const roff_t *__restrict__ sptr,
                                                           const int *__restrict__ ntab,
                                                           const int *__restrict__ tab,
                                                           const unsigned *__restrict__ codes,
@@ -283,7 +283,9 @@ __global__ __launch_bounds__(256) void sell_staged_kernel(int nrows, int row0, i
                                                           const int2 *__restrict__ tile_seg) {
     extern __shared__ __align__(16) double lds[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    PairEntry *lt = (PairEntry *)(lds + stage_cap) + 64 * wv;
+    // one_table: every staged tile of the operator shares one pair table among its four slices -- 1 KB of LDS for it
+    // instead of 4 (one more workgroup per CU); the wavefront's row offset then goes into the x-address, not the table
+    PairEntry *lt = (PairEntry *)(lds + stage_cap) + (one_table ? 0 : 64 * wv);
     const int blk = per_xcd > 0 ? (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (blk >= nblocks || (long)blk * 256 + 256 > nrows) return;
     const long row = (long)blk * 256 + threadIdx.x;
@@ -361,9 +363,11 @@ __global__ __launch_bounds__(256) void sell_staged_kernel(int nrows, int row0, i
             p2 += d.y;
         }
     }
-    lt[lane] = PairEntry{(mybase + mytab + 64 * wv) << 3, 0, myval};      // byte offset of lane 0's x-entry in lds
+    // byte offset of the x-entry of the wavefront's (one_table: the tile's) first row in lds
+    if (!one_table) lt[lane] = PairEntry{(mybase + mytab + 64 * wv) << 3, 0, myval};
+    else if (wv == 0) lt[lane] = PairEntry{(mybase + mytab) << 3, 0, myval};
     __syncthreads();
-    const char *lb = (const char *)lds + 8 * lane;
+    const char *lb = (const char *)lds + 8 * (lane + (one_table ? 64 * wv : 0));
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
@@ -507,6 +511,9 @@ __global__ __launch_bounds__(64) void sell_stage_kernel(int ntiles, int nslices,
         tile_nseg[t] = nseg;
         atomicMax(max_total, total);
         atomicAdd(max_total + 1, 1);
+        bool shared_all = true;
+        for (int q = 0; q < 4; ++q) shared_all = shared_all && ntab[4 * t + q] >= 512;
+        if (!shared_all) atomicAdd(max_total + 3, 1);      // staged tiles whose slices keep tables of their own
     }
 }
 
@@ -820,18 +827,19 @@ void build_sell(hipStream_t s, DCsr &A) {
         A.sell_tile_nseg.alloc((size_t)ntiles);
         A.sell_tile_seg.alloc((size_t)ntiles * SELL_SEG_MAX);
         A.sell_unstaged.alloc((size_t)ntiles);
-        DBuf<int> mx(3);
-        SA_HIP_CHECK(hipMemsetAsync(mx.p, 0, 3 * sizeof(int), s));
+        DBuf<int> mx(4);
+        SA_HIP_CHECK(hipMemsetAsync(mx.p, 0, 4 * sizeof(int), s));
         hipLaunchKernelGGL(sell_stage_kernel, dim3(ntiles), dim3(64), 0, s, ntiles, A.nslices, A.nrows, A.sell_ptr.p, A.sell_ntab.p,
                            A.sell_tab.p, A.sell_tile_nseg.p, A.sell_tile_seg.p, mx.p, A.sell_unstaged.p);
         SA_HIP_CHECK(hipGetLastError());
-        int hm[3];
+        int hm[4];
         SA_HIP_CHECK(hipMemcpyAsync(hm, mx.p, sizeof(hm), hipMemcpyDeviceToHost, s));
         SA_HIP_CHECK(hipStreamSynchronize(s));
         A.sell_stage_cap = hm[0];
         staged_tiles = hm[1];
         A.sell_nunstaged = hm[2];
         if (A.sell_nunstaged * 4 > ntiles) A.sell_stage_cap = 0;      // too few tiles staged to be worth two launches
+        A.sell_one_table = hm[3] == 0;
         A.sell_stream_bytes += (4.0 + 8.0 * SELL_SEG_MAX) * ntiles;
     }
     if (std::getenv("SAAMGE_AMD_SELL_VERBOSE"))
@@ -860,9 +868,9 @@ static void launch_spmv(hipStream_t s, const DCsr &A, RowRange rr, const double 
         const int nblocks = div_up((long)div_up(nrows, 64) * 64, 256);
         static const bool no_xcd = std::getenv("SAAMGE_AMD_SELL_XCD") && std::atoi(std::getenv("SAAMGE_AMD_SELL_XCD")) == 0;
         const int per_xcd = no_xcd ? 0 : div_up(nblocks, 8);
-        const size_t lds_bytes = 8 * (size_t)A.sell_stage_cap + 4 * 64 * sizeof(PairEntry);
+        const size_t lds_bytes = 8 * (size_t)A.sell_stage_cap + (A.sell_one_table ? 1 : 4) * 64 * sizeof(PairEntry);
         hipLaunchKernelGGL((sell_staged_kernel<MODE>), dim3(no_xcd ? nblocks : per_xcd * 8), dim3(256), lds_bytes, s, nrows, row0,
-                           nblocks, per_xcd, A.sell_stage_cap, A.ncols, A.sell_ptr.p + row0 / 64, A.sell_ntab.p, A.sell_tab.p,
+                           nblocks, per_xcd, A.sell_stage_cap, A.ncols, (int)A.sell_one_table, A.sell_ptr.p + row0 / 64, A.sell_ntab.p, A.sell_tab.p,
                            A.sell_code.p, x, y, b, dinv, scale, xrow, A.sell_vtab.p, A.sell_tile_nseg.p, A.sell_tile_seg.p);
         if (A.sell_nunstaged > 0)
             hipLaunchKernelGGL((sell_tiles_kernel<MODE>), dim3(A.sell_nunstaged), dim3(256), 0, s, A.sell_nunstaged, A.sell_unstaged.p,
