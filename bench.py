@@ -251,6 +251,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-general", action="store_true", help="skip the general-coefficient leg of the default workload")
+    ap.add_argument("--coef", default=None, choices=["skew"], help="Poisson workloads: variable coefficient instead of the constant one "
+                    "(the timed workload itself becomes the general-coefficient problem; used to profile it)")
     args = ap.parse_args()
     for k, v in WORKLOADS[args.workload].items():
         if getattr(args, k) is None:
@@ -289,7 +291,7 @@ def main():
 
     prob = build_problem(args.n, args.levels, dev, args.aniso, tuple(int(v) for v in args.blk.split(",")),
                          tuple(int(v) for v in args.coarse_blk.split(",")),
-                         "elasticity_q2" if elasticity else "poisson")
+                         "elasticity_q2" if elasticity else "poisson", coef=args.coef)
     torch.cuda.synchronize()
     torch.cuda.empty_cache()        # the generator's temporaries go back to the device before the library allocates
     params = capi.default_params(num_coarsenings=args.levels - 1, theta=args.theta, nu_relax=3, nu_pro=args.nu_pro,
@@ -351,7 +353,7 @@ def main():
                                 "%d-level SAAMGE, theta=%g, nu_relax=3, %s-element AEs, %s-AE coarse blocks"
                                 % (args.n, args.levels, args.theta, args.blk.replace(",", "x"), args.coarse_blk.replace(",", "x")))
                    if elasticity else "3D Poisson %d^3 Q1 hexes%s, %d-level SAAMGE, theta=%s, nu_relax=3, "
-                               "8x8x4-element AEs, %s-AE coarse blocks%s" % (args.n, "" if args.aniso == 1.0 else
+                               "8x8x4-element AEs, %s-AE coarse blocks%s" % (args.n, (" coefficient=" + args.coef if args.coef else "") if args.aniso == 1.0 else
                                                        " K=diag(1,1,%g)" % args.aniso, args.levels,
                                                        ("%g" % args.theta) if args.theta2 == args.theta else "%g / %g (first / later coarsenings)" % (args.theta, args.theta2),
                                                        args.coarse_blk.replace(",", "x"),
@@ -414,7 +416,7 @@ def main():
                            "format_GBps": round(s["fmt_bytes"] / max(s["ms"], 1e-9) / 1e6, 1),
                            "csr_model_GBps": round(s["bytes"] / max(s["ms"], 1e-9) / 1e6, 1)}
                           for s in stats[:10]]
-    if rank == 0 and not args.no_general and args.workload == "poisson256" and args.aniso == 1.0:
+    if rank == 0 and world == 1 and not args.no_general and args.workload == "poisson256" and args.aniso == 1.0 and args.coef is None:
         # the same workload on a GENERAL operator (outside the timed region): a coefficient without any symmetry, so that
         # no 64-row slice repeats its (offset, value) pairs -- the pair-coded format of the constant-coefficient headline
         # does not apply and the smoother streams the values
@@ -446,7 +448,7 @@ def main():
         torch.cuda.empty_cache()
     if rank == 0 and not args.no_cpu_baseline and args.workload != "poisson256":
         log("bench.py: cpu_baseline is timed on the default workload only (poisson256)")
-    if rank == 0 and not args.no_cpu_baseline and args.workload == "poisson256" and args.blk == "8,8,4":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "poisson256" and args.blk == "8,8,4" and args.coef is None:
         sample = (96, 96, 64)       # ~15 s on the GPU box's 16 cores
         cpu_raw, res["cpu_baseline"] = cpu_baseline(sample, args.levels)
         if args.aniso == 1.0 and args.nu_pro == 0 and not args.correct_nullspace and args.blk == "8,8,4":
