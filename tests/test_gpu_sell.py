@@ -22,6 +22,12 @@ mats = {
   "stencil_const": pr.poisson3d_problem((20, 12, 9), blk=(4, 4, 3)).A.tocsr(),
   "stencil_skew": pr.poisson3d_problem((12, 12, 12), blk=(4, 4, 4), coef="skew").A.tocsr(),
   "random": sp.random(1000, 1000, density=0.02, random_state=rng, format="csr"),
+  # 30 diagonals spread over +-600 with one value each: pair-coded, ONE x-segment of 256 + 1200 doubles per tile (longer than
+  # two passes of the staging loop), segments reaching outside [0, n) at both ends of the operator
+  "toeplitz_wide_band": sp.diags([np.full(6000 - abs(o), 1.0 + 0.01 * j) for j, o in enumerate(range(-600, 600, 40))],
+                                 list(range(-600, 600, 40)), format="csr"),
+  # 9-point stencil on a 300 x 40 grid: three x-segments per tile, tiles that straddle grid lines
+  "stencil_2d": (sp.kron(sp.diags([1.0, 2.0, 1.0], [-1, 0, 1], shape=(40, 40)), sp.diags([1.0, -4.0, 1.0], [-1, 0, 1], shape=(300, 300)))).tocsr(),
   "tiny": sp.csr_matrix(np.array([[2.0, -1.0, 0.0], [-1.0, 2.0, -1.0], [0.0, -1.0, 2.0]])),
 }
 out = {}
@@ -57,7 +63,7 @@ def test_sell_formats_match_scipy_and_each_other():
     assert {k: v[1] for k, v in slow.items()} == {k: v[1] for k, v in full.items()}      # identical bits
     offs = _run(1)             # offset codes only
     plain = _run(0)            # no codes
-    assert set(full) == set(offs) == set(plain) and len(full) == 5
+    assert set(full) == set(offs) == set(plain) and len(full) == 7
     for name in full:
         for res in (full, offs, plain):
             assert res[name][0] <= 1e-15, (name, res[name])
