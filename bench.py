@@ -332,7 +332,7 @@ def main():
         del Ablk
         r0 = r1
     relres = float(res2 ** 0.5 / torch.linalg.norm(prob.b))
-    op_formats = [h.level_format(l)["slices"] for l in range(args.levels - 1)]
+    op_formats = [dict(h.level_format(l)["slices"], dictionary_pairs=h.level_format(l)["dictionary_pairs"]) for l in range(args.levels - 1)]
     h.close()
 
     res = {
@@ -406,6 +406,10 @@ def main():
                 lev = [l for l, i in enumerate(infos) if i["n"] == int(rows)]
                 if lev:
                     res["roofline"]["operator_format"] = h_formats[lev[0]]
+                    if h_formats[lev[0]]["dictionary_pairs"]:      # plain slices replaced by the operator-level dictionary
+                        mode = symbol[symbol.index("<"):symbol.index(">") + 1]
+                        res["roofline"]["kernel"] = ("sell_gpair3_kernel%s (+ sell_gpair3_fix_kernel)" if h_formats[lev[0]]["node_blocks"]
+                                                     else "sell_gpair_kernel%s") % mode
         else:
             ach = d["flops"] / d["ms"] / 1e9
             res["roofline"] = {"kernel": symbol, "profiler_label": d["name"], "bound": "mfma", "achieved": ach,

@@ -334,12 +334,13 @@ class Hierarchy(object):
         return dict(zip(keys, [int(v) for v in info[:len(keys)]]))
 
     def level_format(self, level):
-        info = (C.c_longlong * 8)()
+        info = (C.c_longlong * 12)()
         _check(load().saamge_amd_level_format(self.h, C.c_int(level), info))
         v = [int(x) for x in info]
         return {"slices": {"pair_coded": v[0], "offset_coded": v[1], "plain": v[2]},
                 "entries": {"pair_coded": v[3], "offset_coded": v[4], "plain": v[5]},
-                "staged_tiles": v[6], "stream_bytes": v[7]}
+                "staged_tiles": v[6], "stream_bytes": v[7],
+                "dictionary_pairs": v[8], "node_blocks": bool(v[9]), "irregular_rows": v[10]}
 
     def get_csr(self, level, which):
         import scipy.sparse as sp

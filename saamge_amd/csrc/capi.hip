@@ -334,13 +334,14 @@ int saamge_amd_level_info(const saamge_amd_hierarchy *h, int level, long long in
     SA_API_END
 }
 
-int saamge_amd_level_format(const saamge_amd_hierarchy *h, int level, long long info[8]) {
+int saamge_amd_level_format(const saamge_amd_hierarchy *h, int level, long long info[12]) {
     SA_API_BEGIN
     SA_REQUIRE(h && info, "null argument");
     const Hierarchy &H = *h->H;
     const DCsr &A = H.levels.at(level)->A;
-    for (int i = 0; i < 8; ++i) info[i] = 0;
+    for (int i = 0; i < 12; ++i) info[i] = 0;
     for (int c = 0; c < 3; ++c) { info[c] = A.sell_class_slices[c]; info[3 + c] = A.sell_class_entries[c]; }
+    if (A.sell_gpair) { info[8] = A.sell_ng; info[9] = A.sell_bs3 ? 1 : 0; info[10] = A.sell_bs3 ? A.sell_nirr : 0; }
     info[6] = A.sell_stage_cap > 0 ? (long long)div_up(A.nslices, 4) - A.sell_nunstaged : 0;
     info[7] = (long long)A.sell_stream_bytes;
     SA_API_END

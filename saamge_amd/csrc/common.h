@@ -228,6 +228,17 @@ struct DCsr {
     int64_t sell_class_slices[3] = {0, 0, 0}, sell_class_entries[3] = {0, 0, 0};
     double sell_stream_bytes = 0.0;
     bool sell_fast_ok = false;
+    // operator-level pair dictionary (sell_gdict_kernel): an operator none of whose slices could be coded per slice but
+    // whose (offset, value) pairs repeat across the WHOLE operator (a uniform high-order mesh: Q2 elasticity has 243
+    // entries per row and ~4 900 distinct pairs) stores a 16-bit code per entry into one table of 16-byte pairs:
+    // 2 B instead of 12 B per stored entry.  sell_gcode: four codes of a row per 8-byte word, laid out like sell_code.
+    bool sell_gpair = false;
+    bool sell_bs3 = false;         // 3 x 3 node blocks: the lanes of a node share their gathers of x (sell_gpair_kernel)
+    int sell_nirr = 0;             // rows outside regular node blocks ...
+    DBuf<int> sell_irr;            // ... listed: sell_gpair3_fix_kernel redoes them
+    int sell_ng = 0;
+    DBuf<unsigned long long> sell_gcode;
+    DBuf<double2> sell_gtab;       // {offset (as the low 32 bits of .x's pattern), value}: see GPair in sparse.hip
     // x-staging of the pair-coded slices (sell_stage_kernel): a TILE = 4 consecutive slices = the 256 rows of one workgroup.
     // Where the column offsets of a tile cluster into few runs (a stencil: 9), the x-entries those runs touch are
     // contiguous segments: sell_tile_nseg[t] of them (0: not staged), sell_tile_seg[SELL_SEG_MAX t + s] = {first offset

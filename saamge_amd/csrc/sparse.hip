@@ -517,6 +517,366 @@ __global__ __launch_bounds__(64) void sell_stage_kernel(int ntiles, int nslices,
     }
 }
 
+
+// ---- operator-level pair dictionary (DCsr::sell_gpair) ------------------------------------------------------------
+struct alignas(16) GPair {
+    int off, pad;      // off: (col - row) * 8, a byte offset into x (operators below 2^28 columns)
+    double val;
+};
+// x[row + offset]: scalar base + 32-bit byte offset (one add per gather)
+__device__ __forceinline__ double gp_x(const double *__restrict__ x, unsigned row8, int off8) {
+    return *(const double *)((const char *)x + (row8 + (unsigned)off8));
+}
+constexpr int GD_CAP = 1 << 18;      // hash slots
+constexpr int GP_MAX = 6144;         // pairs accepted: the table has to fit LDS (96 KB; see sell_gpair_kernel)
+// One wavefront per slice, one lane per row: every stored entry (padding included) looks its (col - row, value) pair
+// up in a hash table shared by the whole operator, inserting it on first sight (the pair's code = order of insertion:
+// run-dependent, immaterial -- a code only names its pair).  Slot protocol: state 0 empty -> 1 claimed (atomicCAS) ->
+// 2 published (key, code and table entry written, then a release store); readers use agent-scope loads.
+// counter[0] = pairs so far; beyond GP_MAX the build is abandoned (counter[1] = 1).
+__global__ __launch_bounds__(256) void sell_gdict_kernel(int nslices, const roff_t *__restrict__ sptr,
+                                                         const int *__restrict__ scol, const double *__restrict__ sval,
+                                                         int *__restrict__ state, int *__restrict__ koff,
+                                                         unsigned long long *__restrict__ kval, int *__restrict__ kid,
+                                                         int *__restrict__ counter, GPair *__restrict__ gtab,
+                                                         unsigned short *__restrict__ gcode) {
+    const int slice = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (slice >= nslices) return;
+    const roff_t beg = sptr[slice];
+    const int w = (int)((sptr[slice + 1] - beg) >> 6);
+    const int row = slice * 64 + lane;
+    unsigned short *cp = gcode + 4 * ((size_t)(beg >> 2) + (size_t)slice * 64 + lane);
+    for (int k = 0; k < w; ++k) {
+        const int off = scol[beg + 64 * k + lane] - row;
+        const unsigned long long vb = (unsigned long long)__double_as_longlong(sval[beg + 64 * k + lane]);
+        unsigned long long hsh = (vb ^ (vb >> 29)) * 0x9E3779B97F4A7C15ull + (unsigned long long)(unsigned)off * 0xC2B2AE3D27D4EB4Full;
+        unsigned slot = (unsigned)(hsh >> 40) & (GD_CAP - 1);
+        int code = -1;
+        for (int probes = 0; probes < GD_CAP && code < 0; ++probes) {
+            int st = __hip_atomic_load(&state[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if (st == 0) {
+                if (__hip_atomic_load(&counter[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { code = 0; break; }      // abandoned
+                if (atomicCAS(&state[slot], 0, 1) == 0) {
+                    const int id = atomicAdd(&counter[0], 1);
+                    if (id >= GP_MAX) {
+                        __hip_atomic_store(&counter[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        code = 0;
+                    } else {
+                        gtab[id] = GPair{off * 8, 0, __longlong_as_double((long long)vb)};      // (byte offset)
+                        code = id;
+                    }
+                    __hip_atomic_store(&koff[slot], off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&kval[slot], vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&kid[slot], code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&state[slot], 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                st = 1;      // somebody else claimed it: look again
+            }
+            if (st == 1) { --probes; continue; }      // being published: same slot again
+            if (__hip_atomic_load(&koff[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == off &&
+                __hip_atomic_load(&kval[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == vb)
+                code = __hip_atomic_load(&kid[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                slot = (slot + 1) & (GD_CAP - 1);
+        }
+        cp[256 * (k >> 2) + (k & 3)] = (unsigned short)max(code, 0);
+    }
+    for (int k = w; k & 3; ++k) cp[256 * (k >> 2) + (k & 3)] = 0;      // (the rest of the last word)
+}
+
+// 3 x 3 node blocks?  One wavefront per 63 rows (21 nodes: sell_gpair3_kernel's waves), one lane per row.  A row is
+// REGULAR when its node's rows 3i, 3i+1, 3i+2 hold the same columns, in runs 3j, 3j+1, 3j+2; the others (rows eliminated
+// for essential conditions, a last partial node) are listed in irr_rows (count[0] of them, in no particular order).
+__global__ __launch_bounds__(256) void sell_bs3_kernel(int nrows, int nwaves, const roff_t *__restrict__ rowptr,
+                                                       const int *__restrict__ col, int *__restrict__ irr_rows, int cap,
+                                                       int *__restrict__ count) {
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wave >= nwaves) return;
+    const int row = wave * 63 + lane;
+    const int a = lane % 3, first = row - a;
+    bool ok = lane < 63 && first + 2 < nrows;
+    if (ok) {
+        const roff_t rb = rowptr[row], fb = rowptr[first];
+        const int len = (int)(rowptr[row + 1] - rb);
+        ok = len % 3 == 0 && len == (int)(rowptr[first + 1] - fb);
+        for (int k = 0; ok && k < len; ++k) {
+            const int c = col[rb + k];
+            ok = c % 3 == k % 3 && c == col[fb + k] && (k % 3 == 0 || c == col[rb + k - 1] + 1);
+        }
+    }
+    const unsigned long long good = __ballot(ok);      // a node is regular only if its three rows are
+    const bool node_ok = lane < 63 && ((good >> (lane - a)) & 7ull) == 7ull;
+    if (lane < 63 && row < nrows && !node_ok) {
+        const int at = atomicAdd(count, 1);
+        if (at < cap) irr_rows[at] = row;
+    }
+}
+
+// SpMV family on a dictionary-coded operator.  The table lives in LDS (at most GP_MAX pairs = 96 KB: one workgroup of
+// 16 wavefronts per CU, persistent -- it copies the table once and then walks the slices of its XCD's contiguous eighth,
+// interleaved with the other 31 workgroups of that XCD).  One wavefront per slice, one lane per row; per four entries one
+// 8-byte code word, four LDS table reads and four gathers of x, eight entries in flight.  With the table in global
+// memory the table look-ups were vector-memory gathers like those of x (scattered 16-byte entries: ~50 cycles each on
+// the CU's address path) and the kernel was SLOWER than the plain slices it replaces although it moves a sixth of their
+// bytes (3.3 against 3.2 ms per application of the 64^3 Q2 operator); from LDS they cost an LDS read.
+// Same order of additions as the plain path (whole groups of four alternate between the two accumulators, the tail
+// goes to the first): bit-identical results.
+template <int MODE>
+__global__ __launch_bounds__(1024) void sell_gpair_kernel(int nrows, int row0, int nslices, int per_xcd, int wg_per_xcd, int ng,
+                                                          const roff_t *__restrict__ sptr,
+                                                          const unsigned long long *__restrict__ gcode,
+                                                          const GPair *__restrict__ gtab,
+                                                          const double *__restrict__ x, double *__restrict__ y,
+                                                          const double *__restrict__ b,
+                                                          const double *__restrict__ dinv, double scale,
+                                                          const double *__restrict__ xrow) {
+    extern __shared__ __align__(16) GPair ltab[];
+    for (int i = threadIdx.x; i < ng; i += 1024) ltab[i] = gtab[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int xcd = (int)(blockIdx.x & 7u), p = (int)(blockIdx.x >> 3);
+    const int c0 = xcd * per_xcd, c1 = min(c0 + per_xcd, nslices);
+    const int g0 = row0 >> 6;
+    for (int slice = c0 + p * 16 + wv; slice < c1; slice += wg_per_xcd * 16) {
+        const roff_t beg = sptr[slice], end = sptr[slice + 1];
+        const int gslice = g0 + slice;
+        const int w = (int)((end - beg) >> 6);
+        const long row = (long)slice * 64 + lane;
+        const bool live = row < nrows;
+        const int grow = row0 + (int)row;
+        double e_b = 0.0, e_d = 0.0, e_x = 0.0;
+        if (MODE == MODE_RESIDUAL && live) e_b = b[row];
+        if (MODE == MODE_ADD && live) e_x = y[row];
+        if (MODE == MODE_SMOOTH && live) { e_b = b[row]; e_d = dinv[row]; e_x = xrow[row]; }
+        const unsigned long long *wp = gcode + ((size_t)(beg >> 2) + (size_t)gslice * 64 + lane);
+        const unsigned grow8 = (unsigned)grow << 3;
+        double s0 = 0.0, s1 = 0.0;
+        int k = 0;
+        for (; k + 8 <= w; k += 8) {
+            const unsigned long long ca = __builtin_nontemporal_load(wp + 16 * k), cb = __builtin_nontemporal_load(wp + 16 * (k + 4));
+            GPair e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = ltab[(unsigned)(((j < 4 ? ca : cb) >> (16 * (j & 3))) & 0xffffull)];
+            double xs[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xs[j] = gp_x(x, grow8, e[j].off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j & 1) s1 = fma(e[j].val, xs[j], s1);
+                else s0 = fma(e[j].val, xs[j], s0);
+            }
+        }
+        for (; k + 4 <= w; k += 4) {
+            const unsigned long long ca = __builtin_nontemporal_load(wp + 16 * k);
+            GPair e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = ltab[(unsigned)((ca >> (16 * j)) & 0xffffull)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double xv = gp_x(x, grow8, e[j].off);
+                if (j & 1) s1 = fma(e[j].val, xv, s1);
+                else s0 = fma(e[j].val, xv, s0);
+            }
+        }
+        if (k < w) {
+            unsigned long long ca = __builtin_nontemporal_load(wp + 16 * k);
+            for (; k < w; ++k, ca >>= 16) {
+                const GPair e = ltab[(unsigned)(ca & 0xffffull)];
+                s0 = fma(e.val, gp_x(x, grow8, e.off), s0);
+            }
+        }
+        const double sum = s0 + s1;
+        if (live) {
+            if (MODE == MODE_PLAIN) {
+                y[row] = sum;
+            } else if (MODE == MODE_RESIDUAL) {
+                y[row] = e_b - sum;
+            } else if (MODE == MODE_ADD) {
+                y[row] = e_x + sum;
+            } else {
+                y[row] = e_x + scale * (e_d * (sum - e_b));
+            }
+        }
+    }
+}
+
+// The same for operators with 3 x 3 NODE BLOCKS (vector problems numbered node by node, three components each: rows
+// 3i..3i+2 store the same columns, in runs 3j..3j+2 -- sell_bs3_kernel).  The three lanes of a node would gather the
+// same three entries of x one after the other; here each lane gathers ONE of them (entry 3s + a of its row, a = its
+// component: x[3j + a]) and takes the other two from its neighbours with wave shifts (v_mov_b32_dpp wave_shr / wave_shl):
+// a third of the gathers, which are what bounds the kernel above (~39 cycles of the CU's address path per instruction,
+// whatever the number of active lanes: extra loads for a few lanes of a wave cost as much as for all of them).
+// So that no node is cut, a wavefront takes 63 ROWS (21 nodes; lane 63 idles): rows 63 j .. 63 j + 62 of the operator,
+// which lie in one or two storage slices -- slice, width and code address are per lane.  Irregular rows (eliminated for
+// essential conditions: their lanes compute nothing useful here) are redone by sell_gpair3_fix_kernel afterwards.
+// Same products in the same order per row: entries below w & ~3 (w = the row's slice width) alternate between the two
+// accumulators, the rest goes to the first; entries past the row's slice (the wave's other slice is wider) add nothing.
+__device__ __forceinline__ double wave_from_prev(double v) {      // lane l <- lane l - 1
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, true),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ double wave_from_next(double v) {      // lane l <- lane l + 1
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, true),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, true));
+}
+// x of the three entries of one node block from the lane's own gather (its component a) and its neighbours'
+__device__ __forceinline__ void bs3_share(double own, int a, double &x0, double &x1, double &x2) {
+    const double m1 = wave_from_prev(own), m2 = wave_from_prev(m1), p1 = wave_from_next(own), p2 = wave_from_next(p1);
+    x0 = a == 0 ? own : (a == 1 ? m1 : m2);
+    x1 = a == 0 ? p1 : (a == 1 ? own : m1);
+    x2 = a == 0 ? p2 : (a == 1 ? p1 : own);
+}
+// code of entry 3 t + a of a group of 12 (code words cw[0..2], four codes each; a = the lane's component, t constant)
+__device__ __forceinline__ unsigned bs3_own_code(const unsigned long long (&cw)[3], int t, int a) {
+    unsigned c[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) c[q] = (unsigned)((cw[(3 * t + q) >> 2] >> (16 * ((3 * t + q) & 3))) & 0xffffull);
+    return a == 0 ? c[0] : (a == 1 ? c[1] : c[2]);
+}
+template <int MODE>
+__device__ __forceinline__ void spmv_epilogue(double sum, double *__restrict__ y, const double *__restrict__ b,
+                                              const double *__restrict__ dinv, double scale, const double *__restrict__ xrow, long row) {
+    if (MODE == MODE_PLAIN) {
+        y[row] = sum;
+    } else if (MODE == MODE_RESIDUAL) {
+        y[row] = b[row] - sum;
+    } else if (MODE == MODE_ADD) {
+        y[row] = y[row] + sum;
+    } else {
+        y[row] = xrow[row] + scale * (dinv[row] * (sum - b[row]));
+    }
+}
+template <int MODE>
+__global__ __launch_bounds__(1024) void sell_gpair3_kernel(int nrows_all, int row_lo, int row_hi, int wave0, int nwaves, int per_xcd, int wg_per_xcd, int ng,
+                                                           const roff_t *__restrict__ sptr,
+                                                           const unsigned long long *gcode,
+                                                           const GPair *__restrict__ gtab,
+                                                           const double *x, double *y,
+                                                           const double *__restrict__ b,
+                                                           const double *__restrict__ dinv, double scale) {
+    // (sptr, x, y, b, dinv: whole-operator arrays here; rows row_lo .. row_hi - 1 are written.  gcode, x and y are not
+    // __restrict__: loads through restrict-qualified const pointers move across the compiler barriers of the pipeline)
+    extern __shared__ __align__(16) GPair ltab[];
+    for (int i = threadIdx.x; i < ng; i += 1024) ltab[i] = gtab[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int xcd = (int)(blockIdx.x & 7u), p = (int)(blockIdx.x >> 3);
+    const int c0 = xcd * per_xcd, c1 = min(c0 + per_xcd, nwaves);
+    const int a = lane % 3;
+    for (int wi = c0 + p * 16 + wv; wi < c1; wi += wg_per_xcd * 16) {
+        const int first = (wave0 + wi) * 63;
+        const int row = min(first + min(lane, 62), nrows_all - 1);      // (idle lanes repeat a valid row and store nothing)
+        const bool live = lane < 63 && first + lane >= row_lo && first + lane < row_hi;
+        const int slice = row >> 6;
+        const roff_t beg = sptr[slice];
+        const int w = (int)((sptr[slice + 1] - beg) >> 6), w4 = w & ~3;
+        const unsigned long long *wp = gcode + ((size_t)(beg >> 2) + (size_t)slice * 64 + (row & 63));
+        const unsigned short *cp = (const unsigned short *)wp;
+        const unsigned row8 = (unsigned)row << 3;
+        // the wave's rows lie in at most two slices: the narrower one bounds the unguarded loop
+        const int wa = __builtin_amdgcn_readfirstlane(w), wb = __builtin_amdgcn_readlane(w, 62);
+        const int wmin = min(wa, wb), wmax = max(wa, wb);
+        double s0 = 0.0, s1 = 0.0;
+        int k = 0;
+        // Software pipeline over groups of 12 entries (four node blocks): the code words of group g + 2 and the table
+        // look-ups and gathers of group g + 1 are issued before the products of group g -- a wave then waits for one
+        // memory latency per group instead of two in a row (code word, then x), with 16 waves per CU the difference
+        // between 37 and ~20 cycles per entry.
+        // (two register sets in turn, and a compiler barrier between issue and use that the gathered values pass through:
+        // with one set and copies at the end of the iteration, or with the shifts free to move above the loads, the
+        // compiler waits for every load where it is issued)
+        const int ngroups = wmin / 12;
+        if (ngroups > 0) {
+            unsigned long long cwA[3], cwB[3];
+            double v0[12], own0[4], v1[12], own1[4];
+            auto codes = [&](unsigned long long (&cw)[3], int g) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) cw[q] = __builtin_nontemporal_load(wp + 16 * (12 * g + 4 * q));
+            };
+            auto lookups = [&](const unsigned long long (&cw)[3], double (&v)[12], double (&own)[4]) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) own[t] = gp_x(x, row8, ltab[bs3_own_code(cw, t, a)].off);
+#pragma unroll
+                for (int j = 0; j < 12; ++j) v[j] = ltab[(unsigned)((cw[j >> 2] >> (16 * (j & 3))) & 0xffffull)].val;
+            };
+            auto products = [&](const double (&v)[12], const double (&own)[4]) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    double xs[3];
+                    bs3_share(own[t], a, xs[0], xs[1], xs[2]);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        if ((3 * t + c) & 1) s1 = fma(v[3 * t + c], xs[c], s1);
+                        else s0 = fma(v[3 * t + c], xs[c], s0);
+                    }
+                }
+            };
+            const int last = ngroups - 1;      // (groups past the end: a valid group loaded again and dropped)
+            codes(cwA, 0);      // (issue order as at the end of the loop body: the code words of the next group, then the gathers)
+            codes(cwB, min(1, last));
+            asm volatile("" ::: "memory");
+            lookups(cwA, v0, own0);
+            for (int g = 0; g + 2 <= ngroups; g += 2) {      // (a straight-line body: pairs of groups)
+                codes(cwA, min(g + 2, last));
+                lookups(cwB, v1, own1);          // group g + 1
+                asm volatile("" : "+v"(own0[0]), "+v"(own0[1]), "+v"(own0[2]), "+v"(own0[3]) : : "memory");
+                products(v0, own0);              // group g
+                codes(cwB, min(g + 3, last));
+                lookups(cwA, v0, own0);          // group g + 2
+                asm volatile("" : "+v"(own1[0]), "+v"(own1[1]), "+v"(own1[2]), "+v"(own1[3]) : : "memory");
+                products(v1, own1);              // group g + 1
+            }
+            if (ngroups & 1) products(v0, own0);      // (the last group of an odd number: loaded by the prologue or the last pair)
+            k = 12 * ngroups;
+        }
+        for (; k < wmax; k += 3) {      // (per-lane bounds: the last entries of the narrower slice, the rest of the wider one)
+            GPair e[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int kk = k + c;
+                e[c] = kk < w ? ltab[cp[64 * (size_t)(kk - (kk & 3)) + (kk & 3)]] : GPair{0, 0, 0.0};
+            }
+            int o0 = e[0].off, o1 = e[1].off, o2 = e[2].off;
+            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2));      // (one gather, not one per component under its own mask)
+            const double own = gp_x(x, row8, a == 0 ? o0 : (a == 1 ? o1 : o2));
+            double xs[3];
+            bs3_share(own, a, xs[0], xs[1], xs[2]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (k + c < w4 && ((k + c) & 1)) s1 = fma(e[c].val, xs[c], s1);
+                else s0 = fma(e[c].val, xs[c], s0);
+            }
+        }
+        if (live) spmv_epilogue<MODE>(s0 + s1, y, b, dinv, scale, x, row);
+    }
+}
+// The irregular rows of a node-block operator, one lane per row (a few rows per thousand: strided reads do not matter).
+template <int MODE>
+__global__ __launch_bounds__(256) void sell_gpair3_fix_kernel(int nirr, const int *__restrict__ irr_rows, int row_lo, int row_hi,
+                                                              const roff_t *__restrict__ sptr,
+                                                              const unsigned long long *__restrict__ gcode,
+                                                              const GPair *__restrict__ gtab,
+                                                              const double *__restrict__ x, double *__restrict__ y,
+                                                              const double *__restrict__ b,
+                                                              const double *__restrict__ dinv, double scale) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nirr) return;
+    const int row = irr_rows[i];
+    if (row < row_lo || row >= row_hi) return;
+    const int slice = row >> 6;
+    const roff_t beg = sptr[slice];
+    const int w = (int)((sptr[slice + 1] - beg) >> 6), w4 = w & ~3;
+    const unsigned short *cp = (const unsigned short *)(gcode + ((size_t)(beg >> 2) + (size_t)slice * 64 + (row & 63)));
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < w; ++k) {
+        const GPair e = gtab[cp[64 * (size_t)(k - (k & 3)) + (k & 3)]];
+        if (k < w4 && (k & 1)) s1 = fma(e.val, gp_x(x, (unsigned)row << 3, e.off), s1);
+        else s0 = fma(e.val, gp_x(x, (unsigned)row << 3, e.off), s0);
+    }
+    spmv_epilogue<MODE>(s0 + s1, y, b, dinv, scale, x, row);
+}
+
 // Slice census of a SELL copy: cls[0..2] = pair-coded / offset-coded / plain slices, cls[3..5] = their stored entries
 // (64 x width), cls[6] = code words of the coded slices, cls[7] = widest slice
 __global__ __launch_bounds__(256) void sell_census_kernel(int nslices, const roff_t *__restrict__ sptr,
@@ -816,6 +1176,54 @@ void build_sell(hipStream_t s, DCsr &A) {
     // 8 B slice offset + 4 B table size per slice
     A.sell_stream_bytes = 4.0 * (double)h[6] + 12.0 * 64.0 * (double)(h[0] - h[8]) + 4.0 * 64.0 * (double)h[1] +
                           8.0 * (double)h[4] + 12.0 * (double)h[5] + 12.0 * (double)A.nslices;
+    // operator-level pair dictionary for operators that are all plain slices (SAAMGE_AMD_SELL_GPAIR=0: never)
+    static const bool no_gpair = std::getenv("SAAMGE_AMD_SELL_GPAIR") && std::atoi(std::getenv("SAAMGE_AMD_SELL_GPAIR")) == 0;
+    A.sell_gpair = false;
+    if (!no_gpair && !no_codes && h[0] == 0 && h[1] == 0 && A.nnz >= (1 << 22) && A.ncols < (1 << 28)) {
+        DBuf<int> st((size_t)GD_CAP), ko((size_t)GD_CAP), ki((size_t)GD_CAP), ctr(2);
+        DBuf<unsigned long long> kv((size_t)GD_CAP);
+        SA_HIP_CHECK(hipMemsetAsync(st.p, 0, sizeof(int) * (size_t)GD_CAP, s));
+        SA_HIP_CHECK(hipMemsetAsync(ctr.p, 0, 2 * sizeof(int), s));
+        A.sell_gcode.alloc((size_t)total / 4 + (size_t)A.nslices * 64 + 64);
+        A.sell_gtab.alloc(GP_MAX);
+        hipLaunchKernelGGL(sell_gdict_kernel, dim3(div_up(A.nslices, 4)), dim3(256), 0, s, A.nslices, A.sell_ptr.p, A.sell_col.p,
+                           A.sell_val.p, st.p, ko.p, kv.p, ki.p, ctr.p, (GPair *)A.sell_gtab.p, (unsigned short *)A.sell_gcode.p);
+        SA_HIP_CHECK(hipGetLastError());
+        int hc[2];
+        SA_HIP_CHECK(hipMemcpyAsync(hc, ctr.p, sizeof(hc), hipMemcpyDeviceToHost, s));
+        SA_HIP_CHECK(hipStreamSynchronize(s));
+        if (!hc[1] && hc[0] <= GP_MAX) {      // (the table has to fit LDS: see sell_gpair_kernel)
+            A.sell_gpair = true;
+            A.sell_ng = hc[0];
+            // codes 2 B per stored entry (rounded up to four per row), the table, 8 B per slice
+            const double words = (double)total / 4.0 + 64.0 * (double)A.nslices;           // upper bound of the 8-byte code words
+            A.sell_stream_bytes = 8.0 * words + 16.0 * (double)hc[0] + 8.0 * (double)A.nslices;
+            A.sell_col.release();      // the dictionary replaces the streamed columns and values (12 B per stored entry)
+            A.sell_val.release();
+            static const bool no_bs3 = std::getenv("SAAMGE_AMD_SELL_BS3") && std::atoi(std::getenv("SAAMGE_AMD_SELL_BS3")) == 0;
+            A.sell_bs3 = false;
+            if (!no_bs3 && A.ncols == A.nrows && A.nrows >= 63) {
+                const int nwaves = div_up(A.nrows, 63), cap = A.nrows / 16 + 1;      // at most a sixteenth of the rows on their own
+                A.sell_irr.alloc((size_t)cap);
+                SA_HIP_CHECK(hipMemsetAsync(ctr.p, 0, sizeof(int), s));
+                hipLaunchKernelGGL(sell_bs3_kernel, dim3(div_up(nwaves, 4)), dim3(256), 0, s, A.nrows, nwaves, A.rowptr.p, A.col.p,
+                                   A.sell_irr.p, cap, ctr.p);
+                SA_HIP_CHECK(hipGetLastError());
+                SA_HIP_CHECK(hipMemcpyAsync(&A.sell_nirr, ctr.p, sizeof(int), hipMemcpyDeviceToHost, s));
+                SA_HIP_CHECK(hipStreamSynchronize(s));
+                A.sell_bs3 = A.sell_nirr <= cap;
+                if (!A.sell_bs3) A.sell_irr.release();
+            }
+        } else {
+            A.sell_gcode.release();
+            A.sell_gtab.release();
+        }
+        if (std::getenv("SAAMGE_AMD_SELL_VERBOSE"))
+            std::fprintf(stderr, "build_sell: operator-level pair dictionary: %d pairs%s%s\n", hc[0], A.sell_gpair ? "" : " (abandoned)",
+                         A.sell_gpair && A.sell_bs3 ? ", 3 x 3 node blocks" : "");
+        if (std::getenv("SAAMGE_AMD_SELL_VERBOSE") && A.sell_gpair)
+            std::fprintf(stderr, "build_sell: %d of %d rows outside regular node blocks\n", A.sell_nirr, A.nrows);
+    }
     static const bool no_fast = std::getenv("SAAMGE_AMD_SELL_PAIR_FAST") && std::atoi(std::getenv("SAAMGE_AMD_SELL_PAIR_FAST")) == 0;
     A.sell_fast_ok = !no_fast && A.ncols < (1 << 29);      // (32-bit byte offsets into x on the short-chain path)
     // x-staging plan of the pair-coded tiles (SAAMGE_AMD_SELL_STAGE=0: none)
@@ -863,6 +1271,38 @@ static void launch_spmv(hipStream_t s, const DCsr &A, RowRange rr, const double 
     if (b) b += row0;
     if (dinv) dinv += row0;
     const double *xrow = x + row0;
+    if (A.has_sell && A.sell_gpair && A.sell_bs3) {
+        // waves of 63 rows, numbered over the whole operator; the kernels take whole-operator arrays
+        const int wave0 = row0 / 63, nw = (row0 + nrows - 1) / 63 - wave0 + 1;
+        const int per_xcd = div_up(div_up(nw, 8), 16) * 16;
+        const int wg_per_xcd = std::min(32, div_up(per_xcd, 16));
+        const size_t lds = sizeof(GPair) * (size_t)A.sell_ng;
+        auto kern = sell_gpair3_kernel<MODE>;
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(GPair) * GP_MAX)));
+        hipLaunchKernelGGL(kern, dim3(wg_per_xcd * 8), dim3(1024), lds, s, A.nrows, row0, row0 + nrows, wave0, nw, per_xcd, wg_per_xcd, A.sell_ng,
+                           A.sell_ptr.p, A.sell_gcode.p, (const GPair *)A.sell_gtab.p, x, y - row0, b ? b - row0 : nullptr,
+                           dinv ? dinv - row0 : nullptr, scale);
+        SA_HIP_CHECK(hipGetLastError());
+        if (A.sell_nirr) {
+            hipLaunchKernelGGL(sell_gpair3_fix_kernel<MODE>, dim3(div_up(A.sell_nirr, 256)), dim3(256), 0, s, A.sell_nirr, A.sell_irr.p,
+                               row0, row0 + nrows, A.sell_ptr.p, A.sell_gcode.p, (const GPair *)A.sell_gtab.p, x, y - row0,
+                               b ? b - row0 : nullptr, dinv ? dinv - row0 : nullptr, scale);
+            SA_HIP_CHECK(hipGetLastError());
+        }
+        return;
+    }
+    if (A.has_sell && A.sell_gpair) {
+        const int nsl = div_up(nrows, 64);
+        const int per_xcd = div_up(div_up(nsl, 8), 16) * 16;
+        const int wg_per_xcd = std::min(32, div_up(per_xcd, 16));
+        const size_t lds = sizeof(GPair) * (size_t)A.sell_ng;
+        auto kern = sell_gpair_kernel<MODE>;
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(GPair) * GP_MAX)));
+        hipLaunchKernelGGL(kern, dim3(wg_per_xcd * 8), dim3(1024), lds, s, nrows, row0, nsl, per_xcd, wg_per_xcd, A.sell_ng,
+                           A.sell_ptr.p + row0 / 64, A.sell_gcode.p, (const GPair *)A.sell_gtab.p, x, y, b, dinv, scale, xrow);
+        SA_HIP_CHECK(hipGetLastError());
+        return;
+    }
     // (tiles are global: a row range takes the staged kernel when it starts on a tile and ends on one or with the operator)
     if (A.has_sell && A.sell_stage_cap > 0 && row0 % 256 == 0 && (nrows % 256 == 0 || row0 + nrows == A.nrows)) {
         const int nblocks = div_up((long)div_up(nrows, 64) * 64, 256);

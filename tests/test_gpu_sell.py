@@ -68,3 +68,42 @@ def test_sell_formats_match_scipy_and_each_other():
         for res in (full, offs, plain):
             assert res[name][0] <= 1e-15, (name, res[name])
         assert full[name][1] == offs[name][1] == plain[name][1], name      # identical bits
+
+
+_CODE_GPAIR = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from saamge_amd import capi, problems as pr
+A = pr.elasticity3d_q2_problem((10, 10, 10), blk=(2, 2, 2)).A.tocsr()      # 243 entries per row, 4.8e6 stored entries, ~4 900 pairs
+A.sort_indices()
+x = np.random.default_rng(5).standard_normal(A.shape[1])
+y = capi.spmv(A, x)
+err = np.abs(y - A @ x).max() / (np.abs(A) @ np.abs(x)).max()
+ys = [y]
+for other in (x[::-1].copy(), np.abs(x)):          # (two more vectors)
+    ys.append(capi.spmv(A, other))
+import hashlib
+print("RESULT", repr(float(err)), hashlib.sha256(b"".join(v.tobytes() for v in ys)).hexdigest())
+"""
+
+
+def test_operator_level_pair_dictionary_is_lossless():
+    """An operator whose slices cannot be coded one by one (Q2 elasticity: 243 entries per row) but whose (offset, value)
+    pairs repeat across the whole operator: 16-bit codes into one table (csrc/sparse.hip, sell_gdict_kernel /
+    sell_gpair_kernel) give the same bits as the plain SELL slices they replace -- with the lanes of a 3 x 3 node block
+    sharing their gathers of x (the clamped face's eliminated rows and the nodes cut by slice boundaries are the
+    irregular lanes), without the sharing, and without the dictionary."""
+    outs = []
+    for gpair, bs3 in (("1", "1"), ("1", "0"), ("0", "0")):
+        env = dict(os.environ, SAAMGE_AMD_SPMV_SELL="1", SAAMGE_AMD_SELL_GPAIR=gpair, SAAMGE_AMD_SELL_BS3=bs3,
+                   SAAMGE_AMD_SELL_VERBOSE="1")
+        o = subprocess.run([sys.executable, "-c", _CODE_GPAIR % ROOT], env=env, capture_output=True, text=True, timeout=900)
+        assert o.returncode == 0, o.stdout + o.stderr
+        line = [l for l in o.stdout.splitlines() if l.startswith("RESULT")][0].split()
+        outs.append((float(line[1]), line[2], "pair dictionary" in o.stderr and "abandoned" not in o.stderr,
+                     ", 3 x 3 node blocks" in o.stderr))
+        print(o.stderr[-400:])
+    assert outs[0][2] and outs[1][2] and not outs[2][2]          # the dictionary was built in the first two runs only
+    assert outs[0][3] and not outs[1][3]                         # node blocks were found, and used in the first run only
+    assert all(o[0] <= 1e-15 for o in outs)
+    assert outs[0][1] == outs[1][1] == outs[2][1]                # identical bits
