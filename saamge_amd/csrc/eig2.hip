@@ -1813,6 +1813,152 @@ __global__ __launch_bounds__(NT) void ss_trsolve_kernel(const int *__restrict__ 
     }
 }
 
+// The same solve for wide agglomerates, reorganised around what bound the kernel above on them: every thread read the
+// whole 16 x 8 block y from LDS for its row -- 64 full-width LDS reads per wavefront and block step, 2.3 us of LDS time
+// per step on config 5's 2 187-row agglomerates (band 668, 137 steps per triangle) on top of four memory latencies in
+// a row.  Here the update  X[rows, :] -= T[rows, block] Y  of a step runs on the matrix cores (v_mfma_f64_16x16x4: a
+// wavefront takes 16 rows at a time; A operand = factor entries straight from global memory, 16 consecutive rows per
+// column; B operand = -Y, four LDS reads per lane and step; eight of the sixteen columns carry right-hand sides), the
+// right-hand side rows a step touches -- the block and the bw rows after (before) it -- live in an LDS ring of
+// WR >= bw + 32 rows, and everything a step needs from global memory is requested ahead: the factor entries of the
+// coming step (at the end of the step before), the 16 rows that enter the window (untouched until then), the inverse
+// of the next diagonal block.  The products of a row are accumulated in the same order as above (k ascending, one
+// fused multiply-add each).
+// Measured on config 5 at 64^3 (rocprofv3 kernel trace, per triangle): a chunk's full launch (577 agglomerates, 6.7 GB
+// of factors) takes 2.3 - 4.1 ms -- 1.6 - 3 TB/s, memory-bound beside the next chunk's factorisation; the late launches
+// (3 - 57 agglomerates still iterating) take 0.6 - 1.0 ms = 4.5 us per block step for a lone workgroup, which is what a
+// single CU needs to pull 85 KB of factor per step one step ahead (in-kernel clocks: half of it waiting for them).
+typedef double ss_v4d __attribute__((ext_vector_type(4)));
+constexpr int TW_NT = 1024, TW_TPW = 4;      // threads, tiles of 16 rows per wavefront with prefetched factor entries
+template <bool UPPER>
+__global__ __launch_bounds__(TW_NT) void ss_trsolve_win_kernel(int WR, const int *__restrict__ ns, const int64_t *__restrict__ moff,
+                                                                const int64_t *__restrict__ voff,
+                                                                const double *__restrict__ W, double *__restrict__ X,
+                                                                const int *__restrict__ state, const int *__restrict__ bws,
+                                                                const int *__restrict__ active) {
+    extern __shared__ __align__(16) double win[];      // [SS_B][WR]: WR is odd
+    __shared__ double Td[SB][SB + 1];
+    __shared__ double ys[SB][SS_B];
+    const int b = active ? active[blockIdx.x] : (int)blockIdx.x, n = ns[b];
+    if (state[b] & 3) return;
+    const int bw = min(bws ? max(bws[b], SB) : n, WR - 2 * SB);
+    const double *A = W + moff[b];
+    double *Xb = X + voff[b] * SB;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nblk = (n + SB - 1) / SB;
+    const int ti = (tid >> 4) & 15, tj = tid & 15;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int ntile = (bw + 15) >> 4;
+    // position of a row relative to the current block: p = row - k0 (lower) or k0 + SB - 1 - row (upper), 0 <= p < bw + SB;
+    // slot = (wbase + p) mod WR, wbase advances by SB per step
+    auto row_at = [&](int k0, int p) { return UPPER ? k0 + SB - 1 - p : k0 + p; };
+    // Loads that are requested ahead are UNCONDITIONAL, from clamped addresses, and masked where they are used: a load
+    // under a condition is a branch with its own wait, and twelve of them in a row were twelve latencies in a row.
+    auto load_td = [&](int k0) {             // T11^-1 of the block at k0 (stored inverted), raw
+        const int kc = min(max(k0, 0), n - 1);
+        return A[(size_t)min(kc + tj, n - 1) * n + min(kc + ti, n - 1)];
+    };
+    auto mask_td = [&](int k0, double v) {   // ... 0 outside its triangle
+        const int nb = min(SB, n - k0);
+        return (ti < nb && tj < nb && (UPPER ? tj >= ti : tj <= ti)) ? v : 0.0;
+    };
+    // A operand of tile t of the step at k0: T(row of position SB + 16 t + l15, k0 + 4 kk + l4), 0 outside
+    auto load_a = [&](double (&a)[4], int k0, int t) {      // raw
+        const int r = min(max(row_at(k0, SB + 16 * t + l15), 0), n - 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) a[kk] = A[(size_t)min(k0 + 4 * kk + l4, n - 1) * n + r];
+    };
+    auto mask_a = [&](double (&a)[4], int k0, int t) {      // ... 0 outside the band, the matrix and the block
+        const int q = 16 * t + l15, r = row_at(k0, SB + q);
+        const int nb = min(SB, n - k0);
+        const bool ok = q < bw && r >= 0 && r < n;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) a[kk] = (ok && 4 * kk + l4 < nb) ? a[kk] : 0.0;
+    };
+    const int kfirst = UPPER ? (nblk - 1) * SB : 0;
+    for (int idx = tid; idx < (bw + SB) * SS_B; idx += TW_NT) {      // the first window: positions 0 .. bw + SB - 1
+        const int p = idx >> 3, r = row_at(kfirst, p);
+        win[(idx & 7) * WR + p] = (r >= 0 && r < n) ? Xb[(size_t)r * SS_B + (idx & 7)] : 0.0;
+    }
+    double td_next = load_td(kfirst);
+    double an[TW_TPW][4];
+#pragma unroll
+    for (int u = 0; u < TW_TPW; ++u)
+        if (wv + 16 * u < ntile) load_a(an[u], kfirst, wv + 16 * u);
+    int wbase = 0;
+    for (int bb = 0; bb < nblk; ++bb) {
+        const int k0 = UPPER ? (nblk - 1 - bb) * SB : bb * SB;
+        const int nb = min(SB, n - k0);
+        const int kn = UPPER ? k0 - SB : k0 + SB;
+        const bool more = bb + 1 < nblk;
+        if (tid < SB * SB) Td[ti][tj] = mask_td(k0, td_next);
+        __syncthreads();
+        if (more) td_next = load_td(kn);
+        double enter = 0.0;
+        const int pe = bw + SB + (tid >> 3);              // position (relative to THIS block) of the rows that enter
+        const int re = row_at(k0, pe);
+        if (more && tid < SB * SS_B) enter = Xb[(size_t)min(max(re, 0), n - 1) * SS_B + (tid & 7)];      // (raw)
+        if (tid < SB * SS_B) {      // y = T11^-1 x
+            const int c = tid >> 3, jj = tid & 7;
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int pi = UPPER ? SB - 1 - i : i;      // position of block row i
+                int sl = wbase + pi;
+                if (sl >= WR) sl -= WR;
+                acc = fma(Td[c][i], win[jj * WR + sl], acc);
+            }
+            ys[c][jj] = (c < nb) ? acc : 0.0;
+            if (c < nb) Xb[(size_t)(k0 + c) * SS_B + jj] = acc;
+        }
+        __syncthreads();
+        double bq[4];      // B operand: -y(4 kk + l4, l15), zero in the eight unused columns
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) bq[kk] = l15 < SS_B ? -ys[4 * kk + l4][l15 & 7] : 0.0;
+        auto do_tile = [&](int t, double (&a)[4]) {      // 16 rows after (before) the block
+            mask_a(a, k0, t);
+            ss_v4d c;
+            int sl[4];
+            bool ok[4];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int q = 16 * t + l4 + 4 * reg, r = row_at(k0, SB + q);
+                ok[reg] = l15 < SS_B && q < bw && r >= 0 && r < n;
+                sl[reg] = wbase + SB + q;
+                if (sl[reg] >= WR) sl[reg] -= WR;
+                c[reg] = ok[reg] ? win[(l15 & 7) * WR + sl[reg]] : 0.0;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], bq[kk], c, 0, 0, 0);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                if (ok[reg]) win[(l15 & 7) * WR + sl[reg]] = c[reg];
+        };
+#pragma unroll
+        for (int u = 0; u < TW_TPW; ++u)
+            if (wv + 16 * u < ntile) do_tile(wv + 16 * u, an[u]);
+#pragma unroll 1
+        for (int t = wv + 16 * TW_TPW; t < ntile; t += 16) {      // (bands beyond 1 024 rows: entries read where they are used)
+            double a[4];
+            load_a(a, k0, t);
+            do_tile(t, a);
+        }
+        if (more) {      // the coming step's factor entries: in flight over the barriers and the block solve
+#pragma unroll
+            for (int u = 0; u < TW_TPW; ++u)
+                if (wv + 16 * u < ntile) load_a(an[u], kn, wv + 16 * u);
+        }
+        if (more && tid < SB * SS_B) {
+            int se = wbase + pe;
+            if (se >= WR) se -= WR;
+            win[(tid & 7) * WR + se] = (re >= 0 && re < n) ? enter : 0.0;
+        }
+        wbase += SB;
+        if (wbase >= WR) wbase -= WR;
+        // (the next step's first barrier orders these LDS writes before its reads)
+    }
+}
+
 // Both solves in one launch with the right-hand sides resident in LDS (row pitch 9 doubles:
 // conflict-free for lanes = rows): the factor is then the only global traffic, read once per
 // triangle.  For agglomerates up to ~2 000 rows.
@@ -2691,7 +2837,16 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         // config 5's 23 s, where most matrices of a chunk are done long before the last one)
         hipLaunchKernelGGL(ss_copy_active_kernel, dim3(nact, std::max(1, std::min(16, b.max_n / 256))), dim3(256), 0, s, b.n.p,
                            b.voff.p, active.p, X, Z);
-        if (b.max_n > 768) {
+        static const bool no_win = std::getenv("SAAMGE_AMD_SS_TRSOLVE_WIN") && std::atoi(std::getenv("SAAMGE_AMD_SS_TRSOLVE_WIN")) == 0;
+        const int wr = (std::min(b.max_n, bws ? std::max(b.ss_bwmax, SB) : b.max_n) + 2 * SB) | 1;      // rows of the LDS window (odd)
+        const size_t win_bytes = sizeof(double) * SS_B * (size_t)wr;
+        if (b.max_n > 768 && !no_win && win_bytes <= 150 * 1024) {
+            auto lo = ss_trsolve_win_kernel<false>, up = ss_trsolve_win_kernel<true>;
+            SA_HIP_CHECK(hipFuncSetAttribute((const void *)lo, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            SA_HIP_CHECK(hipFuncSetAttribute((const void *)up, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            hipLaunchKernelGGL(lo, dim3(nact), dim3(1024), win_bytes, s, wr, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
+            hipLaunchKernelGGL(up, dim3(nact), dim3(1024), win_bytes, s, wr, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
+        } else if (b.max_n > 768) {
             hipLaunchKernelGGL((ss_trsolve_kernel<false, 1024>), dim3(nact), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
             hipLaunchKernelGGL((ss_trsolve_kernel<true, 1024>), dim3(nact), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
         } else {
