@@ -531,58 +531,82 @@ constexpr int GD_CAP = 1 << 18;      // hash slots
 constexpr int GP_MAX = 6144;         // pairs accepted: the table has to fit LDS (96 KB; see sell_gpair_kernel)
 // One wavefront per slice, one lane per row: every stored entry (padding included) looks its (col - row, value) pair
 // up in a hash table shared by the whole operator, inserting it on first sight (the pair's code = order of insertion:
-// run-dependent, immaterial -- a code only names its pair).  Slot protocol: state 0 empty -> 1 claimed (atomicCAS) ->
-// 2 published (key, code and table entry written, then a release store); readers use agent-scope loads.
-// counter[0] = pairs so far; beyond GP_MAX the build is abandoned (counter[1] = 1).
-__global__ __launch_bounds__(256) void sell_gdict_kernel(int nslices, const roff_t *__restrict__ sptr,
-                                                         const int *__restrict__ scol, const double *__restrict__ sval,
-                                                         int *__restrict__ state, int *__restrict__ koff,
-                                                         unsigned long long *__restrict__ kval, int *__restrict__ kid,
-                                                         int *__restrict__ counter, GPair *__restrict__ gtab,
-                                                         unsigned short *__restrict__ gcode) {
-    const int slice = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (slice >= nslices) return;
-    const roff_t beg = sptr[slice];
-    const int w = (int)((sptr[slice + 1] - beg) >> 6);
-    const int row = slice * 64 + lane;
-    unsigned short *cp = gcode + 4 * ((size_t)(beg >> 2) + (size_t)slice * 64 + lane);
-    for (int k = 0; k < w; ++k) {
-        const int off = scol[beg + 64 * k + lane] - row;
-        const unsigned long long vb = (unsigned long long)__double_as_longlong(sval[beg + 64 * k + lane]);
-        unsigned long long hsh = (vb ^ (vb >> 29)) * 0x9E3779B97F4A7C15ull + (unsigned long long)(unsigned)off * 0xC2B2AE3D27D4EB4Full;
-        unsigned slot = (unsigned)(hsh >> 40) & (GD_CAP - 1);
-        int code = -1;
-        for (int probes = 0; probes < GD_CAP && code < 0; ++probes) {
-            int st = __hip_atomic_load(&state[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+// run-dependent, immaterial -- a code only names its pair).
+// A slot is a 16-byte record {value bits; offset, code + 1} that is written once (its second word last, with release
+// order, after the slot was claimed through state[]: 0 -> 1 by atomicCAS) and never changes.  The common case -- the
+// pair is there -- is ONE ordinary cached 16-byte load: a record whose second word is non-zero is complete (both words
+// sit in one cache line and the first was written first) and final, whichever cache it comes from.  Only a record that
+// looks empty is looked at again with device-coherent accesses: those bypass the XCD's L2 (the eight L2s are not
+// coherent with one another), and with every look-up made of them the build of the 64^3 Q2 operator's dictionary
+// (1.6e9 entries) took 205 ms; a workgroup-level LDS cache in front of them did not change that, nor did one look-up
+// per distinct pair of a wavefront's 64 entries (570 ms: look-ups one after the other instead of side by side).
+// counter[0] = pairs so far; beyond GP_MAX the build is abandoned (counter[1] = 1) and every wavefront leaves.
+__device__ __forceinline__ int gdict_lookup(int off, unsigned long long vb, int *__restrict__ state,
+                                            unsigned long long *rec, int *__restrict__ counter, GPair *__restrict__ gtab) {
+    const unsigned long long hsh = (vb ^ (vb >> 29)) * 0x9E3779B97F4A7C15ull + (unsigned long long)(unsigned)off * 0xC2B2AE3D27D4EB4Full;
+    unsigned slot = (unsigned)(hsh >> 40) & (GD_CAP - 1);
+    for (int probes = 0; probes < GD_CAP; ++probes) {
+        typedef unsigned long long gd_u2 __attribute__((ext_vector_type(2)));
+        const gd_u2 r = *(const gd_u2 *)(rec + 2 * (size_t)slot);      // (ordinary, cached)
+        unsigned long long w1 = r[1], w0 = r[0];
+        if (w1 == 0) {      // empty, or not visible here yet
+            int st = __hip_atomic_load(&state[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (st == 0) {
-                if (__hip_atomic_load(&counter[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { code = 0; break; }      // abandoned
+                if (__hip_atomic_load(&counter[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 0;      // abandoned
                 if (atomicCAS(&state[slot], 0, 1) == 0) {
                     const int id = atomicAdd(&counter[0], 1);
+                    int code = id;
                     if (id >= GP_MAX) {
                         __hip_atomic_store(&counter[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         code = 0;
                     } else {
                         gtab[id] = GPair{off * 8, 0, __longlong_as_double((long long)vb)};      // (byte offset)
-                        code = id;
                     }
-                    __hip_atomic_store(&koff[slot], off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&kval[slot], vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&kid[slot], code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&state[slot], 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+                    __hip_atomic_store(&rec[2 * (size_t)slot], vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&rec[2 * (size_t)slot + 1], ((unsigned long long)(unsigned)(code + 1) << 32) | (unsigned)off,
+                                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    return code;
                 }
-                st = 1;      // somebody else claimed it: look again
             }
-            if (st == 1) { --probes; continue; }      // being published: same slot again
-            if (__hip_atomic_load(&koff[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == off &&
-                __hip_atomic_load(&kval[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == vb)
-                code = __hip_atomic_load(&kid[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else
-                slot = (slot + 1) & (GD_CAP - 1);
+            // claimed by somebody else: the record again, with device-coherent loads; not there yet -> the same slot
+            // again through the whole loop body (the claimer may be a lane of this wavefront: it publishes inside the
+            // body, so waiting anywhere else would wait for a lane that is not running)
+            w1 = __hip_atomic_load(&rec[2 * (size_t)slot + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if (w1 == 0) {
+                if (__hip_atomic_load(&counter[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 0;      // abandoned
+                --probes;
+                continue;
+            }
+            w0 = __hip_atomic_load(&rec[2 * (size_t)slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        cp[256 * (k >> 2) + (k & 3)] = (unsigned short)max(code, 0);
+        if ((int)(unsigned)(w1 & 0xffffffffull) == off && w0 == vb) return (int)(w1 >> 32) - 1;
+        slot = (slot + 1) & (GD_CAP - 1);
     }
-    for (int k = w; k & 3; ++k) cp[256 * (k >> 2) + (k & 3)] = 0;      // (the rest of the last word)
+    return 0;
+}
+__global__ __launch_bounds__(256) void sell_gdict_kernel(int nslices, const roff_t *__restrict__ sptr,
+                                                         const int *__restrict__ scol, const double *__restrict__ sval,
+                                                         int *__restrict__ state, unsigned long long *rec,
+                                                         int *__restrict__ counter, GPair *__restrict__ gtab,
+                                                         unsigned long long *__restrict__ gcode) {
+    const int slice = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (slice >= nslices) return;
+    const roff_t beg = sptr[slice];
+    const int w = (int)((sptr[slice + 1] - beg) >> 6);
+    const int row = slice * 64 + lane;
+    unsigned long long *wp = gcode + ((size_t)(beg >> 2) + (size_t)slice * 64 + lane);
+    unsigned long long word = 0;      // four codes of the row per 8-byte word
+    for (int k = 0; k < w; ++k) {
+        const int off = scol[beg + 64 * k + lane] - row;
+        const unsigned long long vb = (unsigned long long)__double_as_longlong(sval[beg + 64 * k + lane]);
+        if ((k & 15) == 0 && __hip_atomic_load(&counter[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;      // abandoned (wave-uniform)
+        const int code = gdict_lookup(off, vb, state, rec, counter, gtab);
+        word |= (unsigned long long)(unsigned)(code & 0xffff) << (16 * (k & 3));
+        if ((k & 3) == 3 || k + 1 == w) {
+            wp[64 * (size_t)(k >> 2)] = word;      // (the rest of the last word stays 0)
+            word = 0;
+        }
+    }
 }
 
 // 3 x 3 node blocks?  One wavefront per 63 rows (21 nodes: sell_gpair3_kernel's waves), one lane per row.  A row is
@@ -1180,14 +1204,15 @@ void build_sell(hipStream_t s, DCsr &A) {
     static const bool no_gpair = std::getenv("SAAMGE_AMD_SELL_GPAIR") && std::atoi(std::getenv("SAAMGE_AMD_SELL_GPAIR")) == 0;
     A.sell_gpair = false;
     if (!no_gpair && !no_codes && h[0] == 0 && h[1] == 0 && A.nnz >= (1 << 22) && A.ncols < (1 << 28)) {
-        DBuf<int> st((size_t)GD_CAP), ko((size_t)GD_CAP), ki((size_t)GD_CAP), ctr(2);
-        DBuf<unsigned long long> kv((size_t)GD_CAP);
+        DBuf<int> st((size_t)GD_CAP), ctr(2);
+        DBuf<unsigned long long> rec(2 * (size_t)GD_CAP);
         SA_HIP_CHECK(hipMemsetAsync(st.p, 0, sizeof(int) * (size_t)GD_CAP, s));
+        SA_HIP_CHECK(hipMemsetAsync(rec.p, 0, 16 * (size_t)GD_CAP, s));
         SA_HIP_CHECK(hipMemsetAsync(ctr.p, 0, 2 * sizeof(int), s));
         A.sell_gcode.alloc((size_t)total / 4 + (size_t)A.nslices * 64 + 64);
         A.sell_gtab.alloc(GP_MAX);
         hipLaunchKernelGGL(sell_gdict_kernel, dim3(div_up(A.nslices, 4)), dim3(256), 0, s, A.nslices, A.sell_ptr.p, A.sell_col.p,
-                           A.sell_val.p, st.p, ko.p, kv.p, ki.p, ctr.p, (GPair *)A.sell_gtab.p, (unsigned short *)A.sell_gcode.p);
+                           A.sell_val.p, st.p, rec.p, ctr.p, (GPair *)A.sell_gtab.p, A.sell_gcode.p);
         SA_HIP_CHECK(hipGetLastError());
         int hc[2];
         SA_HIP_CHECK(hipMemcpyAsync(hc, ctr.p, sizeof(hc), hipMemcpyDeviceToHost, s));
