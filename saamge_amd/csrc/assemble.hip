@@ -1030,8 +1030,15 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
     profiler().end(s, "ae_build", bytes, 0.0);
 }
 
-// E_e = P_loc^T A_e P_loc.  T = A_e P_loc goes through a global scratch block (n x k_e).
-__global__ __launch_bounds__(ASM_NT) void coarse_elmat_kernel(
+// E_e = P_loc^T A_e P_loc from the DENSE image of A_e (coarse levels, elements that are not 8-dof hexes), in two
+// launches; T = A_e P_loc goes through a global scratch block (n x k_e).
+// coarse_elmat_T_kernel, grid (agglomerates, row chunks): a thread takes a row i and ALL the columns of a MIS at once
+// (eight accumulators at a time), so that a column of A_e is read once per MIS -- one thread per (row, column) re-read
+// A_e k times (38 MB per 2 187-row agglomerate of config 5, far beyond the L2: 2.5 TB/s of re-reads, 1.25 s per step)
+// -- and one workgroup per agglomerate left most of the card idle.  Per (row, column) the products are added in the
+// same order as before (q ascending).
+constexpr int CE_KC = 8;
+__global__ __launch_bounds__(ASM_NT) void coarse_elmat_T_kernel(
     int ae0, const int *__restrict__ ns, const int64_t *__restrict__ moff,
     const double *__restrict__ W, const int *__restrict__ ae2mis_I,
     const int *__restrict__ ae2mis_J, const int *__restrict__ ae_pair,
@@ -1039,16 +1046,14 @@ __global__ __launch_bounds__(ASM_NT) void coarse_elmat_kernel(
     const int *__restrict__ mis2d_I, const int *__restrict__ mis_k,
     const int64_t *__restrict__ mis_u_off, const double *__restrict__ mis_u,
     const int *__restrict__ colpos_ptr, const int *__restrict__ colpos,
-    const int64_t *__restrict__ out_off, double *__restrict__ out,
     double *__restrict__ scratch, const int64_t *__restrict__ scratch_off) {
     const int b = blockIdx.x, e = ae0 + b, n = ns[b];
     const double *Am = W + moff[b];
     double *T = scratch + scratch_off[b];
-    double *E = out + out_off[e];
-    const int ke = (int)(sqrt((double)(out_off[e + 1] - out_off[e])) + 0.5);
-    const int tid = threadIdx.x;
+    const int i = blockIdx.y * ASM_NT + threadIdx.x;
+    if (blockIdx.y * ASM_NT >= n) return;
+    const int ic = min(i, n - 1);      // (threads past the last row repeat it and store nothing)
     const int mb = ae2mis_I[e], me = ae2mis_I[e + 1];
-    // T[:, cb+v] = A_e[:, loc] U[:, v]
     for (int t = mb; t < me; ++t) {
         const int mis = ae2mis_J[t], k = mis_k[mis];
         if (k == 0) continue;
@@ -1056,16 +1061,53 @@ __global__ __launch_bounds__(ASM_NT) void coarse_elmat_kernel(
         const int *loc = pair_loc + pair_loc_off[ae_pair[t]];
         const double *U = mis_u + mis_u_off[mis];
         const int *cp = colpos + colpos_ptr[t];
-        for (int idx = tid; idx < n * k; idx += ASM_NT) {
-            const int i = idx % n, v = idx / n;
-            double sum = 0.0;
-            for (int q = 0; q < r; ++q) sum = fma(Am[(size_t)loc[q] * n + i], U[(size_t)v * r + q], sum);
-            T[(size_t)cp[v] * n + i] = sum;
+        for (int v0 = 0; v0 < k; v0 += CE_KC) {
+            const int kc = min(CE_KC, k - v0);
+            double acc[CE_KC];
+#pragma unroll
+            for (int v = 0; v < CE_KC; ++v) acc[v] = 0.0;
+            int q = 0;
+            for (; q + 4 <= r; q += 4) {      // four columns of A_e in flight (U and loc are uniform: scalar loads)
+                double a4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a4[u] = Am[(size_t)loc[q + u] * n + ic];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < CE_KC; ++v)
+                        if (v < kc) acc[v] = fma(a4[u], U[(size_t)(v0 + v) * r + q + u], acc[v]);
+            }
+            for (; q < r; ++q) {
+                const double a = Am[(size_t)loc[q] * n + ic];
+#pragma unroll
+                for (int v = 0; v < CE_KC; ++v)
+                    if (v < kc) acc[v] = fma(a, U[(size_t)(v0 + v) * r + q], acc[v]);
+            }
+            if (i < n) {
+#pragma unroll
+                for (int v = 0; v < CE_KC; ++v)
+                    if (v < kc) T[(size_t)cp[v0 + v] * n + i] = acc[v];
+            }
         }
     }
-    __syncthreads();
-    // E[(cb+v), :] = U[:, v]^T T[loc, :]
-    for (int t = mb; t < me; ++t) {
+}
+// E[(cb + v), :] = U[:, v]^T T[loc, :]
+__global__ __launch_bounds__(ASM_NT) void coarse_elmat_E_kernel(
+    int ae0, const int *__restrict__ ns, const int *__restrict__ ae2mis_I,
+    const int *__restrict__ ae2mis_J, const int *__restrict__ ae_pair,
+    const int64_t *__restrict__ pair_loc_off, const int *__restrict__ pair_loc,
+    const int *__restrict__ mis2d_I, const int *__restrict__ mis_k,
+    const int64_t *__restrict__ mis_u_off, const double *__restrict__ mis_u,
+    const int *__restrict__ colpos_ptr, const int *__restrict__ colpos,
+    const int64_t *__restrict__ out_off, double *__restrict__ out,
+    const double *__restrict__ scratch, const int64_t *__restrict__ scratch_off) {
+    const int b = blockIdx.x, e = ae0 + b, n = ns[b];
+    const double *T = scratch + scratch_off[b];
+    double *E = out + out_off[e];
+    const int ke = (int)(sqrt((double)(out_off[e + 1] - out_off[e])) + 0.5);
+    const int tid = threadIdx.x;
+    const int mb = ae2mis_I[e], me = ae2mis_I[e + 1];
+    for (int t = mb + blockIdx.y; t < me; t += gridDim.y) {
         const int mis = ae2mis_J[t], k = mis_k[mis];
         if (k == 0) continue;
         const int r = mis2d_I[mis + 1] - mis2d_I[mis];
@@ -1407,8 +1449,12 @@ void coarse_elmats(hipStream_t s, const DevRelations &rel, int ae0, const EigBat
                    double *scratch, const int64_t *scratch_off) {
     if (!batch.count) return;
     profiler().begin(s);
-    hipLaunchKernelGGL(coarse_elmat_kernel, dim3(batch.count), dim3(ASM_NT), 0, s, ae0, batch.n.p,
+    hipLaunchKernelGGL(coarse_elmat_T_kernel, dim3(batch.count, div_up(batch.max_n, ASM_NT)), dim3(ASM_NT), 0, s, ae0, batch.n.p,
                        batch.moff.p, batch.W.p, rel.ae2mis_I.p, rel.ae2mis_J.p, rel.ae_pair.p,
+                       rel.pair_loc_off.p, rel.pair_loc.p, rel.mis2d_I.p, mis_k, mis_u_off, mis_u,
+                       colpos_ptr, colpos, scratch, scratch_off);
+    hipLaunchKernelGGL(coarse_elmat_E_kernel, dim3(batch.count, 4), dim3(ASM_NT), 0, s, ae0, batch.n.p,
+                       rel.ae2mis_I.p, rel.ae2mis_J.p, rel.ae_pair.p,
                        rel.pair_loc_off.p, rel.pair_loc.p, rel.mis2d_I.p, mis_k, mis_u_off, mis_u,
                        colpos_ptr, colpos, out_off, out, scratch, scratch_off);
     SA_HIP_CHECK(hipGetLastError());
