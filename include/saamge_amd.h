@@ -157,6 +157,10 @@ int saamge_amd_ml_produce_data64(int n, const long long *rowptr, const int *col,
  * Galerkin operators and the coarsest solver are rebuilt.  new_val: nnz(A) values in the order
  * given at setup (host or device); NULL if the caller changed its device array in place. */
 int saamge_amd_update_operators(saamge_amd_hierarchy *h, const double *new_val);
+/* tg_update_coarse_operator(A, tg_data, perform_solve_init, coarse_direct), inc/tg.hpp:610-612: the same update with
+ * the coarsest solver chosen again -- coarse_solver with the meaning of the params field of that name: 1 = the
+ * reference's coarse_direct = true, 2 = its CG on the coarsest operator; -1 keeps the one the hierarchy was built with. */
+int saamge_amd_update_operators2(saamge_amd_hierarchy *h, const double *new_val, int coarse_solver);
 /* ml_free_data, inc/ml.hpp:196 */
 void saamge_amd_ml_free_data(saamge_amd_hierarchy *h);
 

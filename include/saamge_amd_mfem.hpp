@@ -538,13 +538,15 @@ inline void tg_free_coarse_operator(tg_data_t &tg_data) {
     tg_data.Ac = nullptr;
     tg_data.Ac_diag = nullptr;
 }
-// tg_update_coarse_operator (inc/tg.hpp:610-612): the matrix values changed, interpolation kept.  coarse_direct is
-// accepted and ignored: the coarsest solver stays the one the hierarchy was built with (MultilevelParameters::
-// set_coarse_direct / saamge_amd_params.coarse_solver) or the caller's coarse_solver plug.
+// tg_update_coarse_operator (inc/tg.hpp:610-612): the matrix values changed, interpolation kept; the coarsest solver
+// is set up again as coarse_direct asks (true: the explicit inverse, false: CG on the coarsest operator), as the
+// reference does (src/tg.cpp, tg_update_coarse_operator -> solve_init with the new Ac).  perform_solve_init = false in
+// the reference leaves the old solver object in place for the caller to replace: here the caller's coarse_solver plug
+// (saamge_amd_set_coarse_solver), if any, stays installed either way.
 inline void tg_update_coarse_operator(mfem::HypreParMatrix &A, tg_data_t *tg_data, bool perform_solve_init, bool coarse_direct) {
-    (void)perform_solve_init; (void)coarse_direct;
     detail::HostCsr c = detail::csr_of(A);
-    if (saamge_amd_update_operators(tg_data->h, c.V.data())) mfem::mfem_error(saamge_amd_last_error());
+    if (saamge_amd_update_operators2(tg_data->h, c.V.data(), perform_solve_init ? (coarse_direct ? 1 : 2) : -1))
+        mfem::mfem_error(saamge_amd_last_error());
 }
 
 // Tables built on the GPU, on request (agg_partitioning_relations_t fields of inc/aggregates.hpp:120-179)

@@ -26,7 +26,7 @@ SYMBOLS = [
     "saamge_amd_set_coarse_solver", "saamge_amd_comm_unique_id", "saamge_amd_comm_create", "saamge_amd_comm_destroy",
     "saamge_amd_params_set_comm", "saamge_amd_comm_selftest", "saamge_amd_comm_last_error",
     "saamge_amd_release_cached_memory", "saamge_amd_cached_memory_bytes",
-    "saamge_amd_ml_produce_data64", "saamge_amd_get_csr64", "saamge_amd_spmv64", "saamge_amd_set_smoother", "saamge_amd_profile_get2", "saamge_amd_level_format",
+    "saamge_amd_ml_produce_data64", "saamge_amd_get_csr64", "saamge_amd_spmv64", "saamge_amd_set_smoother", "saamge_amd_profile_get2", "saamge_amd_level_format", "saamge_amd_update_operators2",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong))
@@ -232,11 +232,15 @@ class Hierarchy(object):
         return cls(rowptr, col, val, A.shape[0], None, None, None, parts, nparts, params, A.shape[0], 1,
                    stream, group)
 
-    def update_operators(self, new_val=None):
-        """adapt_update_operators: new matrix values (same pattern), interpolations kept."""
+    def update_operators(self, new_val=None, coarse_solver=None):
+        """adapt_update_operators: new matrix values (same pattern), interpolations kept.  coarse_solver (1 dense
+        inverse, 2 inner PCG, 0 auto): tg_update_coarse_operator's coarse_direct -- the coarsest solver is chosen again."""
         if new_val is not None:
             new_val = np.ascontiguousarray(new_val, dtype=np.float64) if not hasattr(new_val, "data_ptr") else new_val
-        _check(load().saamge_amd_update_operators(self.h, _ptr(new_val)))
+        if coarse_solver is None:
+            _check(load().saamge_amd_update_operators(self.h, _ptr(new_val)))
+        else:
+            _check(load().saamge_amd_update_operators2(self.h, _ptr(new_val), C.c_int(int(coarse_solver))))
 
     def close(self):
         if self.h:

@@ -164,6 +164,16 @@ int saamge_amd_update_operators(saamge_amd_hierarchy *h, const double *new_val) 
     SA_API_END
 }
 
+int saamge_amd_update_operators2(saamge_amd_hierarchy *h, const double *new_val, int coarse_solver) {
+    SA_API_BEGIN
+    SA_REQUIRE(h, "null argument");
+    SA_REQUIRE(coarse_solver >= -1 && coarse_solver <= 2, "coarse_solver: -1 (keep), 0 (auto), 1 (dense inverse) or 2 (inner PCG)");
+    require_device(*h->H);
+    if (coarse_solver >= 0) h->H->params.coarse_solver = coarse_solver;
+    hierarchy_update_operators(*h->H, new_val);
+    SA_API_END
+}
+
 void saamge_amd_ml_free_data(saamge_amd_hierarchy *h) {
     if (!h) return;
     hipStream_t hs = nullptr;

@@ -286,6 +286,33 @@ def test_update_operators_keeps_interpolation(variant):
     h.close()
 
 
+def test_update_operators_chooses_the_coarsest_solver_again():
+    """tg_update_coarse_operator(A, tg_data, perform_solve_init, coarse_direct) (inc/tg.hpp:610-612): the update sets
+    the coarsest solver up again as coarse_direct says -- saamge_amd_update_operators2(h, val, 1 | 2).  Built with the
+    explicit inverse; updated with the same values and coarse_solver = 2 the coarsest level is solved by the inner PCG
+    (its iteration count shows in level_info), updated again with 1 it is the inverse again; the solutions agree."""
+    capi = _capi()
+    prob = pr.poisson3d_problem((12, 8, 8), blk=(4, 4, 2), coef="checkerboard")
+    params = capi.default_params(num_coarsenings=1, coarse_rtol=1e-28, coarse_solver=1)
+    h = capi.Hierarchy.from_problem(prob, params)
+    A = prob.A.tocsr()
+    A.sort_indices()
+    res = []
+    for kind in (None, 2, 1):
+        if kind is not None:
+            h.update_operators(A.data, coarse_solver=kind)
+        x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-10)
+        res.append((x, it, h.level_info(0)["coarse_iters"]))
+        assert conv
+    assert res[0][2] == 0 and res[1][2] > 0 and res[2][2] == 0          # direct, inner PCG, direct again
+    assert res[0][1] == res[1][1] == res[2][1]
+    for x, _, _ in res[1:]:
+        assert np.linalg.norm(x - res[0][0]) <= 1e-9 * np.linalg.norm(res[0][0])
+    with pytest.raises(Exception):
+        h.update_operators(A.data, coarse_solver=7)
+    h.close()
+
+
 def test_hierarchy_on_a_nonzero_device():
     """The library's worker threads, helper streams and cached device blocks follow the CALLER's current device
     (round-1 advisor finding: HIP's current device is per host thread).  Needs a second visible GPU; on the one-GPU
