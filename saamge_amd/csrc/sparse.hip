@@ -1296,7 +1296,9 @@ static void launch_spmv(hipStream_t s, const DCsr &A, RowRange rr, const double 
     if (b) b += row0;
     if (dinv) dinv += row0;
     const double *xrow = x + row0;
-    if (A.has_sell && A.sell_gpair && A.sell_bs3) {
+    // (y += A x with irregular rows: the wave kernel's result for them would be added before the fix kernel adds the right
+    // one -- the plain dictionary kernel takes that case)
+    if (A.has_sell && A.sell_gpair && A.sell_bs3 && !(MODE == MODE_ADD && A.sell_nirr > 0)) {
         // waves of 63 rows, numbered over the whole operator; the kernels take whole-operator arrays
         const int wave0 = row0 / 63, nw = (row0 + nrows - 1) / 63 - wave0 + 1;
         const int per_xcd = div_up(div_up(nw, 8), 16) * 16;

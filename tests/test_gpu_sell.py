@@ -82,6 +82,23 @@ err = np.abs(y - A @ x).max() / (np.abs(A) @ np.abs(x)).max()
 ys = [y]
 for other in (x[::-1].copy(), np.abs(x)):          # (two more vectors)
     ys.append(capi.spmv(A, other))
+# rows outside regular node blocks (every 97th dof keeps its diagonal entry only, as an eliminated row would): they are
+# redone by sell_gpair3_fix_kernel
+C = A.tocoo()
+keep = (C.row %% 97 != 5) | (C.row == C.col)
+import scipy.sparse as sp
+A2 = sp.csr_matrix((C.data[keep], (C.row[keep], C.col[keep])), shape=A.shape)
+A2.sort_indices()
+y2 = capi.spmv(A2, x)
+err = max(err, np.abs(y2 - A2 @ x).max() / (np.abs(A2) @ np.abs(x)).max())
+ys.append(y2)
+# the other members of the family (residual, fused smoother step) through a two-level hierarchy on the same operator:
+# the (B r, r) history of a few PCG iterations and the solution, bit for bit
+prob = pr.elasticity3d_q2_problem((10, 10, 10), blk=(2, 2, 2))
+h = capi.Hierarchy.from_problem(prob, capi.default_params(num_coarsenings=1, theta=0.003, nu_relax=3))
+xs, it, conv, hist = h.pcg(prob.b, rel_tol=1e-6, max_iter=6)
+ys += [np.asarray(hist, dtype=np.float64), np.asarray(xs, dtype=np.float64)]
+h.close()
 import hashlib
 print("RESULT", repr(float(err)), hashlib.sha256(b"".join(v.tobytes() for v in ys)).hexdigest())
 """
@@ -100,10 +117,13 @@ def test_operator_level_pair_dictionary_is_lossless():
         o = subprocess.run([sys.executable, "-c", _CODE_GPAIR % ROOT], env=env, capture_output=True, text=True, timeout=900)
         assert o.returncode == 0, o.stdout + o.stderr
         line = [l for l in o.stdout.splitlines() if l.startswith("RESULT")][0].split()
+        import re
+        irregular = [int(m) for m in re.findall(r"build_sell: (\d+) of \d+ rows outside regular node blocks", o.stderr)]
         outs.append((float(line[1]), line[2], "pair dictionary" in o.stderr and "abandoned" not in o.stderr,
-                     ", 3 x 3 node blocks" in o.stderr))
-        print(o.stderr[-400:])
+                     ", 3 x 3 node blocks" in o.stderr, max(irregular) if irregular else -1))
+        print([l for l in o.stderr.splitlines() if "dictionary" in l or "rows outside" in l])
     assert outs[0][2] and outs[1][2] and not outs[2][2]          # the dictionary was built in the first two runs only
     assert outs[0][3] and not outs[1][3]                         # node blocks were found, and used in the first run only
+    assert outs[0][4] > 100                                      # ... with rows outside them on the second operator (the fix kernel ran)
     assert all(o[0] <= 1e-15 for o in outs)
     assert outs[0][1] == outs[1][1] == outs[2][1]                # identical bits
