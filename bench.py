@@ -80,12 +80,15 @@ KERNELS = {
 # aniso128: theta = 1e-4 keeps exactly the four z-constant modes of an interior 8x8x4-element agglomerate
 # (generalised eigenvalues 0, 0.371e-4 (twice), 0.723e-4, then 1.444e-4: "4 eigenvectors/aggregate"); three
 # levels, so that the coarsest operator stays small enough for the direct coarsest solve; the second coarsening
-# uses 4x4x2-AE blocks and theta = 1e-5 (2-4 vectors per level-1 agglomerate: with 8x8x4 blocks the ~8 400-row
-# level-1 agglomerates carry more than the six pairs the few-eigenpairs path takes and fall back to the dense path).
+# uses 4x4x2-AE blocks and theta = 1e-5 (2-4 vectors per level-1 agglomerate); aniso128_c884 below: 8x8x4 blocks.
 WORKLOADS = {
     "poisson256": {"n": 256, "levels": 3, "theta": 0.003, "aniso": 1.0, "theta2": None},
     "poisson128": {"n": 128, "levels": 2, "theta": 0.003, "aniso": 1.0, "theta2": None},
     "aniso128": {"n": 128, "levels": 3, "theta": 1e-4, "aniso": 1000.0, "theta2": 1e-5, "coarse_blk": "4,4,2"},
+    # the same with the other configs' 8x8x4-AE coarse blocks: 32 level-1 agglomerates of ~7 900 rows, 24 of them with
+    # EIGHT wanted pairs -- more than the six a block of the few-eigenpairs path holds: the first six are locked and the
+    # iteration goes on (csrc/eig2.hip, ss_lock_kernel); before round 3's last part the level fell back to the dense path
+    "aniso128_c884": {"n": 128, "levels": 3, "theta": 1e-4, "aniso": 1000.0, "theta2": 1e-5, "coarse_blk": "8,8,4"},
     # BASELINE config 5: 3-D linear elasticity, Q2 hexes (81 dofs per element), 4x4x4-element agglomerates of
     # 9^3 nodes x 3 = 2187 dofs carrying the six rigid-body modes, clamped on x = 0.  96^3 elements: 21.6 M dofs,
     # 4.17e9 stored entries (64-bit row offsets: csrc/common.h roff_t), ~280 GB of HBM in use.  elasticity_q2_64:

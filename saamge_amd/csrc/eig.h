@@ -44,6 +44,10 @@ struct EigBatch {
     // few-eigenpairs path (SAAMGE_AMD_EIG=subspace): Ritz values of the accepted block; `dense_only`
     // forces the dense path for this batch (fallback after a failed subspace attempt)
     DBuf<double> ss_mu;
+    // locked (converged and deflated) pairs of matrices with more wanted pairs than one block holds: see ss_lock_kernel
+    DBuf<double> ss_Vlock, ss_lock_mu;
+    DBuf<int> ss_ndefl;
+    bool ss_has_lock = false;
     DBuf<double> ss_sigma;          // shift of every matrix (few-eigenpairs path), see eig_subspace_factor
     // [sum n_i] position of agglomerate-local row r in the matrix as assembled (rows ordered by global
     // dof number: a far narrower band than the first-encounter order of the tables); has_perm = false:

@@ -1284,6 +1284,10 @@ constexpr int SS_B = 8;
 constexpr double SS_SIGMA = -1e-3;
 constexpr double SS_TOL = 1e-12;
 constexpr int SS_MAX_ITER = 80;
+// Matrices with more wanted pairs than the block's six: the first six converged pairs are LOCKED (copied out, the block
+// started again and kept orthogonal to them: ss_lock_kernel, ss_deflate_kernel) and the iteration goes on for the
+// next ones, on the same factor.  One lock of six: up to twelve wanted pairs.
+constexpr int SS_LOCK = 6, SS_LOCK_PITCH = 8, SS_WANT_MAX = 2 * SS_LOCK;
 
 __global__ __launch_bounds__(256) void ss_shift_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
                                                        double *__restrict__ W, double sigma_all,
@@ -2159,7 +2163,11 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
                                                     const double *__restrict__ sigmas, double vu, const int *__restrict__ inertia,
                                                     double *__restrict__ dbg = nullptr,
         const int *__restrict__ active = nullptr, double *__restrict__ hist = nullptr, int max_iter = 80,
-        const int *__restrict__ reshift_ok = nullptr) {
+        const int *__restrict__ reshift_ok = nullptr, const int *__restrict__ ndefl = nullptr,
+        const int *__restrict__ it0 = nullptr) {
+    // ndefl[b]: pairs of this matrix locked so far (the block is kept orthogonal to them); it0[b]: the iteration at which
+    // its block was last started (0, or the lock): convergence is judged from the second iteration after that
+    if (it0) iter -= it0[active ? active[blockIdx.x] : (int)blockIdx.x];
     __shared__ double part[4][2 * SS_B + 1][SS_B];  // [wavefront][M rows | G rows | residual][column j]
     __shared__ double Ms[SS_B][SS_B], Gs[SS_B][SS_B], Cs[SS_B][SS_B], res2[SS_B], mus[SS_B], mu_old[SS_B];
     const int b = active ? active[blockIdx.x] : (int)blockIdx.x, n = ns[b];     // (active: the matrices still iterating)
@@ -2234,13 +2242,16 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
             for (int q = 0; q < SS_B; ++q) if (sigma + mu_old[q] <= vu) ++k;
             if (dbg)        // (SAAMGE_AMD_SS_DEBUG: residual bounds and Ritz values of the previous pairs)
                 for (int q = 0; q < SS_B; ++q) { dbg[(size_t)b * 2 * SS_B + q] = 2.5 * mu_old[q] * sqrt(res2[q]); dbg[(size_t)b * 2 * SS_B + SS_B + q] = sigma + mu_old[q]; }
-            const int cert = inertia ? inertia[b] : -2;      // certified #{lambda < vu}; -1: not certifiable, -2: none
+            const int nd = ndefl ? ndefl[b] : 0;
+            const int cert0 = inertia ? inertia[b] : -2;     // certified #{lambda < vu}; -1: not certifiable, -2: none
+            const int cert = cert0 > 0 ? cert0 - nd : cert0; // ... of which nd are locked already
+            const bool partial = cert > SS_B - 2;            // more wanted pairs than the block holds: lock the first six
             // hopeless convergence (the wanted pair far above the shift inside a cluster: rate ~ 1): the bound of
             // the slowest wanted pair four iterations ago predicts the iterations still needed; a matrix that
             // cannot make it within the budget gives up now instead of after max_iter iterations
             if (hist && iter >= 1) {
                 double worst = 0.0;
-                for (int q = 0; q < max(k, 1); ++q) worst = fmax(worst, 2.5 * mu_old[q] * sqrt(res2[q]));
+                for (int q = 0; q < (partial ? SS_LOCK : max(k, 1)); ++q) worst = fmax(worst, 2.5 * mu_old[q] * sqrt(res2[q]));
                 const double old = hist[(size_t)b * 4 + (iter & 3)];
                 hist[(size_t)b * 4 + (iter & 3)] = worst;
                 if (iter >= 6 && worst > SS_TOL && old > 0.0) {
@@ -2252,7 +2263,13 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
                     else if (iter >= 12 && need > (double)(max_iter - iter)) st |= 2;
                 }
             }
-            if (k > SS_B - 2 || cert > SS_B - 2 || cert == -1) st |= 2;
+            if (partial && cert0 <= SS_WANT_MAX) {
+                // the six smallest Ritz pairs of the block converged (they lie below the window's end: more than six
+                // eigenvalues do): state bit 3 asks the host to lock them
+                bool ok = k >= SS_LOCK;
+                for (int q = 0; q < SS_LOCK; ++q) ok = ok && (2.5 * mu_old[q] * sqrt(res2[q]) <= SS_TOL);
+                if (ok) st |= 8;
+            } else if (k > SS_B - 2 || cert > SS_B - 2 || cert == -1) st |= 2;
             else if (cert >= 0) {
                 // Ritz values approach the eigenvalues from above, so the number inside the window grows to the
                 // certified count: accept once it is reached and those pairs have converged (count 0: the
@@ -2414,21 +2431,98 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
     }
 }
 
+// Z <- Z - V (V^T Z) for the matrices with locked pairs V (orthonormal: converged Ritz vectors of one block): the block
+// stays in the complement the remaining wanted pairs live in.  One workgroup per matrix, fixed summation order.
+__global__ __launch_bounds__(256) void ss_deflate_kernel(const int *__restrict__ ns, const int64_t *__restrict__ voff,
+                                                         const double *__restrict__ Vl, const int *__restrict__ ndefl,
+                                                         double *__restrict__ Z, const int *__restrict__ state,
+                                                         const int *__restrict__ active) {
+    const int b = active ? active[blockIdx.x] : (int)blockIdx.x, n = ns[b], nd = ndefl[b];
+    if (nd == 0 || (state[b] & 3)) return;
+    __shared__ double part[4][SS_LOCK_PITCH][SS_B], proj[SS_LOCK_PITCH][SS_B];
+    double *Zb = Z + voff[b] * SB;
+    const double *Vb = Vl + voff[b] * SS_LOCK_PITCH;
+    const int tid = threadIdx.x, j = tid & 7, grp = tid >> 3;
+    double acc[SS_LOCK_PITCH];
+#pragma unroll
+    for (int v = 0; v < SS_LOCK_PITCH; ++v) acc[v] = 0.0;
+    for (int r = grp; r < n; r += 32) {
+        const double z = Zb[(size_t)r * SS_B + j];
+#pragma unroll
+        for (int v = 0; v < SS_LOCK_PITCH; ++v) acc[v] = fma(Vb[(size_t)r * SS_LOCK_PITCH + v], z, acc[v]);
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+        for (int v = 0; v < SS_LOCK_PITCH; ++v) acc[v] += __shfl_xor(acc[v], o, 64);
+    if ((tid & 63) < SS_B)
+#pragma unroll
+        for (int v = 0; v < SS_LOCK_PITCH; ++v) part[tid >> 6][v][j] = acc[v];
+    __syncthreads();
+    if (tid < SS_LOCK_PITCH * SS_B) {
+        const int v = tid >> 3, jj = tid & 7;
+        proj[v][jj] = v < nd ? (part[0][v][jj] + part[1][v][jj]) + (part[2][v][jj] + part[3][v][jj]) : 0.0;
+    }
+    __syncthreads();
+    for (int r = grp; r < n; r += 32) {
+        double z = Zb[(size_t)r * SS_B + j];
+#pragma unroll
+        for (int v = 0; v < SS_LOCK_PITCH; ++v) z = fma(-Vb[(size_t)r * SS_LOCK_PITCH + v], proj[v][j], z);
+        Zb[(size_t)r * SS_B + j] = z;
+    }
+}
+// Lock the six smallest Ritz pairs of the listed matrices (state bit 3): vectors to Vl, values to lock_mu.  The block's
+// last two pairs -- the next wanted ones, usually as good as converged by then -- move to its first two columns, the
+// other six start again from pseudo-random vectors (the next Rayleigh-Ritz step sees them after the deflation); the
+// convergence history is reset.
+__global__ __launch_bounds__(256) void ss_lock_kernel(const int *__restrict__ list, const int *__restrict__ ns,
+                                                      const int64_t *__restrict__ voff, double *__restrict__ X,
+                                                      double *__restrict__ mu, const double *__restrict__ sigmas,
+                                                      double *__restrict__ Vl, double *__restrict__ lock_mu,
+                                                      int *__restrict__ ndefl, int *__restrict__ it0, int iter,
+                                                      int *__restrict__ state, double *__restrict__ hist) {
+    const int b = list[blockIdx.x], n = ns[b];
+    double *Xb = X + voff[b] * SB;
+    double *Vb = Vl + voff[b] * SS_LOCK_PITCH;
+    for (int r = threadIdx.x; r < n; r += 256) {
+        double x[SS_B];
+#pragma unroll
+        for (int q = 0; q < SS_B; ++q) x[q] = Xb[(size_t)r * SS_B + q];
+#pragma unroll
+        for (int q = 0; q < SS_LOCK_PITCH; ++q) Vb[(size_t)r * SS_LOCK_PITCH + q] = q < SS_LOCK ? x[q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < SS_B; ++q)
+            Xb[(size_t)r * SS_B + q] = q < SS_B - SS_LOCK ? x[SS_LOCK + q] : unit_rand_ss((unsigned)(r * SS_B + q) + 0x9E3779B9u, (unsigned)n + 17u);
+    }
+    __shared__ double m_old[SS_B];
+    if (threadIdx.x < SS_B) m_old[threadIdx.x] = mu[(size_t)b * SS_B + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < SS_LOCK) lock_mu[(size_t)b * SS_LOCK_PITCH + threadIdx.x] = sigmas[b] + m_old[threadIdx.x];
+    if (threadIdx.x < SS_B) mu[(size_t)b * SS_B + threadIdx.x] = threadIdx.x < SS_B - SS_LOCK ? m_old[SS_LOCK + threadIdx.x] : 1.0;
+    if (threadIdx.x < 4) hist[(size_t)b * 4 + threadIdx.x] = 0.0;
+    if (threadIdx.x == 0) { ndefl[b] = SS_LOCK; it0[b] = iter + 1; state[b] = 0; }
+}
+
 __global__ __launch_bounds__(256) void ss_output_kernel(const int *__restrict__ ns, const int64_t *__restrict__ voff,
                                                         const double *__restrict__ X, const double *__restrict__ mu,
                                                         const double *__restrict__ dis, const short *__restrict__ perm,
                                                         const int *__restrict__ ms,
                                                         const int64_t *__restrict__ eoff, const int64_t *__restrict__ xoff,
                                                         double *__restrict__ evals, double *__restrict__ evecs,
-                                                        const double *__restrict__ sigmas) {
-    const int b = blockIdx.x, n = ns[b], m = ms[b];
+                                                        const double *__restrict__ sigmas,
+                                                        const int *__restrict__ ndefl = nullptr, const double *__restrict__ Vl = nullptr,
+                                                        const double *__restrict__ lock_mu = nullptr) {
+    // (locked pairs first: they are the smaller ones)
+    const int b = blockIdx.x, n = ns[b], m = ms[b], nd = ndefl ? min(ndefl[b], m) : 0;
     const double sigma = sigmas[b];
     const double *Xb = X + voff[b] * SB;
+    const double *Vb = Vl ? Vl + voff[b] * SS_LOCK_PITCH : nullptr;
     const short *pm = perm ? perm + voff[b] : nullptr;
-    for (int q = threadIdx.x; q < m; q += 256) evals[eoff[b] + q] = sigma + mu[(size_t)b * SS_B + q];
+    for (int q = threadIdx.x; q < m; q += 256)
+        evals[eoff[b] + q] = q < nd ? lock_mu[(size_t)b * SS_LOCK_PITCH + q] : sigma + mu[(size_t)b * SS_B + (q - nd)];
     for (int idx = threadIdx.x; idx < n * m; idx += 256) {
-        const int r = idx % n, q = idx / n;
-        evecs[xoff[b] + (size_t)q * n + r] = dis[voff[b] + r] * Xb[(size_t)(pm ? pm[r] : r) * SS_B + q];
+        const int r = idx % n, q = idx / n, pr = pm ? pm[r] : r;
+        evecs[xoff[b] + (size_t)q * n + r] = dis[voff[b] + r] * (q < nd ? Vb[(size_t)pr * SS_LOCK_PITCH + q] : Xb[(size_t)pr * SS_B + (q - nd)]);
     }
 }
 
@@ -2631,8 +2725,9 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
     b.nbad = 0;
     auto mark_bad = [&](int i) { if (!b.h_bad[(size_t)i]) { b.h_bad[(size_t)i] = 1; ++b.nbad; } };
     auto too_many_bad = [&]() { return (long)b.nbad * 10 > (long)b.count; };
+    static const bool lock_on = [] { const char *e = std::getenv("SAAMGE_AMD_SS_LOCK"); return !(e && e[0] == '0'); }();
     for (size_t i = 0; i < b.h_inertia.size(); ++i)
-        if (b.h_inertia[i] > SS_B - 2 || b.h_inertia[i] < 0) {
+        if (b.h_inertia[i] > (lock_on ? SS_WANT_MAX : SS_B - 2) || b.h_inertia[i] < 0) {
             SA_REQUIRE(!std::getenv("SAAMGE_AMD_SS_STRICT"), "few-eigenpairs path: a matrix has more wanted pairs than the block holds, or no certificate (strict mode)");
             mark_bad((int)i);
         }
@@ -2790,9 +2885,30 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     const bool reshift_on = reshift_env && b.max_n > 1280 && b.ss_save && !b.h_inertia.empty() && b.h_sigma.size() == (size_t)b.count;
     DBuf<int> reshift_ok;
     std::vector<int> h_reshift_ok((size_t)b.count, 1);
+    std::vector<double> reshift_prev((size_t)b.count, 0.0), reshift_margin((size_t)b.count, 0.0);
     if (reshift_on) reshift_ok.from_host(h_reshift_ok, s);
     const bool prof = profiler().enabled;
     const int *bws = b.h_bw.empty() ? nullptr : b.bw.p;
+    // matrices with seven to twelve wanted pairs: the first six are locked when they have converged (ss_lock_kernel)
+    std::vector<int> h_ndefl((size_t)b.count, 0);
+    bool any_lock = false;
+    for (int i = 0; i < b.count && !b.h_inertia.empty(); ++i) any_lock = any_lock || (!b.h_bad[i] && b.h_inertia[i] > SS_B - 2);
+    DBuf<int> it0;
+    b.ss_has_lock = false;
+    if (any_lock) {
+        b.ss_ndefl.alloc((size_t)b.count);
+        b.ss_ndefl.zero(s);
+        it0.alloc((size_t)b.count);
+        it0.zero(s);
+        b.ss_lock_mu.alloc((size_t)b.count * SS_LOCK_PITCH);
+        b.ss_Vlock.alloc((size_t)b.h_voff[b.count] * SS_LOCK_PITCH);
+        b.ss_has_lock = true;
+    }
+    if (std::getenv("SAAMGE_AMD_SS_DEBUG") && b.max_n > 1280 && !b.h_inertia.empty()) {
+        std::fprintf(stderr, "subspace: certified counts (bad):");
+        for (int i = 0; i < b.count; ++i) std::fprintf(stderr, " %d%s", b.h_inertia[i], b.h_bad[i] ? "*" : "");
+        std::fprintf(stderr, "\n");
+    }
     if (!prof) profiler().begin(s);
     hipLaunchKernelGGL(ss_init_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, b.dis.p,
                        b.has_perm ? b.perm.p : nullptr, X, b.has_x0c ? b.x0c.p : (const double *)nullptr);
@@ -2813,7 +2929,8 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     int nact = (int)h_active.size();
     if (nact) SA_HIP_CHECK(hipMemcpyAsync(active.p, h_active.data(), sizeof(int) * (size_t)nact, hipMemcpyHostToDevice, s));
     SA_HIP_CHECK(hipStreamSynchronize(s));
-    for (int iter = 0; iter < SS_MAX_ITER && !done; ++iter) {
+    const int max_iter = any_lock ? 2 * SS_MAX_ITER : SS_MAX_ITER;      // (a locked matrix starts a second run)
+    for (int iter = 0; iter < max_iter && !done; ++iter) {
         if (nact == 0) {                 // every matrix was finished before the factorisation
             auto t = state.to_host(s);
             hstate.assign(t.begin(), t.end());
@@ -2866,13 +2983,24 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         static const bool dbg_on = std::getenv("SAAMGE_AMD_SS_DEBUG") != nullptr;
         DBuf<double> dbgbuf;
         if (dbg_on) dbgbuf.alloc((size_t)b.count * 2 * SS_B);
+        if (any_lock)
+            hipLaunchKernelGGL(ss_deflate_kernel, dim3(nact), dim3(256), 0, s, b.n.p, b.voff.p, b.ss_Vlock.p, b.ss_ndefl.p, Z, state.p, active.p);
         hipLaunchKernelGGL(ss_rr_kernel, dim3(nact), dim3(256), 0, s, b.n.p, b.voff.p, X, Z, mu, state.p, iter,
                            b.ss_sigma.p, vu, b.h_inertia.empty() ? (const int *)nullptr : b.inertia.p, dbgbuf.p, active.p,
-                           slow_hist.p, SS_MAX_ITER, reshift_on ? reshift_ok.p : (const int *)nullptr);
+                           slow_hist.p, max_iter, reshift_on ? reshift_ok.p : (const int *)nullptr,
+                           any_lock ? b.ss_ndefl.p : (const int *)nullptr, any_lock ? it0.p : (const int *)nullptr);
         if (dbg_on && iter > 0) {
             auto hd = dbgbuf.to_host(s);
             const int show = std::min(b.count, 3);
-            for (int i = 0; i < show; ++i) {
+            static const int dbg_one = std::getenv("SAAMGE_AMD_SS_DEBUG_MATRIX") ? std::atoi(std::getenv("SAAMGE_AMD_SS_DEBUG_MATRIX")) : -1;
+            if (dbg_one >= 0 && dbg_one < b.count) {
+                std::fprintf(stderr, "  iter %d matrix %d: bounds", iter, dbg_one);
+                for (int q = 0; q < 8; ++q) std::fprintf(stderr, " %.2e", hd[(size_t)dbg_one * 16 + q]);
+                std::fprintf(stderr, " | lambda");
+                for (int q = 0; q < 8; ++q) std::fprintf(stderr, " %.5e", hd[(size_t)dbg_one * 16 + 8 + q]);
+                std::fprintf(stderr, " | inertia %d locked %d\n", b.h_inertia.empty() ? -2 : b.h_inertia[dbg_one], h_ndefl[dbg_one]);
+            }
+            for (int i = 0; i < show && dbg_one < 0; ++i) {
                 const int mi = (int)((int64_t)i * (b.count - 1) / std::max(1, show - 1));
                 std::fprintf(stderr, "  iter %d matrix %d (n %d): bounds %.2e %.2e %.2e | lambda %.6e %.6e %.6e | inertia %d\n", iter, mi, b.h_n[mi],
                              hd[(size_t)mi * 16], hd[(size_t)mi * 16 + 1], hd[(size_t)mi * 16 + 2], hd[(size_t)mi * 16 + 8],
@@ -2888,6 +3016,21 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         if (check) {
             auto t = state.to_host(s);
             hstate.assign(t.begin(), t.end());
+            if (any_lock) {      // lock requests (state bit 3)
+                std::vector<int> req;
+                for (int i = 0; i < b.count; ++i)
+                    if ((hstate[i] & 8) && !(hstate[i] & 3) && h_ndefl[i] == 0 && !b.h_bad[i]) { req.push_back(i); h_ndefl[i] = SS_LOCK; hstate[i] = 0; }
+                if (!req.empty()) {
+                    DBuf<int> d_req;
+                    d_req.from_host(req, s);
+                    hipLaunchKernelGGL(ss_lock_kernel, dim3((unsigned)req.size()), dim3(256), 0, s, d_req.p, b.n.p, b.voff.p, X, mu, b.ss_sigma.p,
+                                       b.ss_Vlock.p, b.ss_lock_mu.p, b.ss_ndefl.p, it0.p, iter, state.p, slow_hist.p);
+                    SA_HIP_CHECK(hipGetLastError());
+                    SA_HIP_CHECK(hipStreamSynchronize(s));
+                    if (std::getenv("SAAMGE_AMD_SS_DEBUG"))
+                        std::fprintf(stderr, "subspace: iteration %d, six pairs of %zu matrices locked (first: matrix %d)\n", iter, req.size(), req[0]);
+                }
+            }
             done = true;
             int nconv = 0;
             for (int i = 0; i < b.count; ++i) {
@@ -2900,17 +3043,34 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
                 else ++nconv;
             }
             if (too_many_bad()) failed = true;
+            if (failed && std::getenv("SAAMGE_AMD_SS_DEBUG")) {
+                std::fprintf(stderr, "subspace: iteration %d: too many matrices gave up (states:", iter);
+                for (int i = 0; i < b.count && i < 64; ++i) std::fprintf(stderr, " %x", hstate[i]);
+                std::fprintf(stderr, ")\n");
+            }
             if (reshift_on && !failed) {
-                std::vector<int> req;
+                std::vector<int> req, cand;
                 for (int i = 0; i < b.count; ++i)
-                    if ((hstate[i] & 4) && !(hstate[i] & 3) && h_reshift_ok[i]) req.push_back(i);
+                    if ((hstate[i] & 4) && !(hstate[i] & 3) && h_reshift_ok[i]) cand.push_back(i);
+                std::vector<double> hmu;
+                if (!cand.empty()) { auto t2 = mubuf.to_host(s); hmu.assign(t2.begin(), t2.end()); }
+                // The smallest Ritz value comes down towards the eigenvalue: the new shift has to stay below where it
+                // will end.  A request is granted once the value has moved by less than half a percent in an iteration,
+                // and the shift keeps five such steps (at least 2 % of the old distance) below it -- on the 7 900-row
+                // level-1 agglomerates of config 4 with 8 x 8 x 4-AE blocks the value of iteration 6 was still more
+                // than 2 % too high and the factorisation at the new shift met a negative pivot.
+                for (int i : cand) {
+                    const double gap = hmu[(size_t)i * SS_B];
+                    const double moved = reshift_prev[(size_t)i] > 0.0 ? reshift_prev[(size_t)i] - gap : 1e300;
+                    reshift_prev[(size_t)i] = gap;
+                    if (moved <= 0.005 * gap) { reshift_margin[(size_t)i] = std::max(0.02 * gap, 5.0 * std::max(moved, 0.0)); req.push_back(i); }
+                }
                 if (!req.empty()) {
-                    auto hmu = mubuf.to_host(s);
                     std::vector<double> delta(req.size());
                     for (size_t t = 0; t < req.size(); ++t) {
                         const int i = req[t];
                         const double gap = hmu[(size_t)i * SS_B];              // smallest Ritz value - sigma (> 0)
-                        const double snew = b.h_sigma[i] + 0.98 * gap;         // 2 % of the old distance below it
+                        const double snew = b.h_sigma[i] + gap - reshift_margin[(size_t)i];
                         delta[t] = b.h_sigma[i] - snew;
                         b.h_sigma[i] = snew;
                         h_reshift_ok[i] = 0;
@@ -2947,6 +3107,11 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
                     if (std::getenv("SAAMGE_AMD_SS_DEBUG"))
                         std::fprintf(stderr, "subspace: iteration %d, %zu matrices factored again at a shift below their smallest Ritz value\n", iter, req.size());
                     if (too_many_bad()) failed = true;
+                    if (failed && std::getenv("SAAMGE_AMD_SS_DEBUG")) {
+                        std::fprintf(stderr, "subspace: iteration %d: the factorisation at the new shifts failed (info:", iter);
+                        for (int i = 0; i < b.count && i < 64; ++i) std::fprintf(stderr, " %d", hi2[i]);
+                        std::fprintf(stderr, ")\n");
+                    }
                 }
             }
             static const bool dbg = std::getenv("SAAMGE_AMD_SS_DEBUG") != nullptr;
@@ -2978,7 +3143,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         int bad = 0, unsure = 0;
         for (int i = 0; i < b.count; ++i) {
             if (b.h_bad[i]) continue;
-            const int k = (hstate[i] >> 4) & 15;
+            const int k = ((hstate[i] >> 4) & 15) + h_ndefl[i];
             if (b.h_inertia[i] < 0) { ++unsure; mark_bad(i); }
             else if (b.h_inertia[i] != k) { ++bad; mark_bad(i); }
         }
@@ -2992,7 +3157,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         }
     }
     b.h_m.assign((size_t)b.count, 1);
-    for (int i = 0; i < b.count; ++i) b.h_m[i] = b.h_bad[i] ? 0 : hstate[i] >> 8;
+    for (int i = 0; i < b.count; ++i) b.h_m[i] = b.h_bad[i] ? 0 : (hstate[i] >> 8) + h_ndefl[i];
     b.m.from_host(b.h_m, s);
     b.ss_mu = std::move(mubuf);
     return true;
@@ -3002,7 +3167,9 @@ void eig_subspace_vectors(hipStream_t s, EigBatch &b, const int64_t *eoff, const
                           double *evecs) {
     profiler().begin(s);
     hipLaunchKernelGGL(ss_output_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, b.Xbuf.p, b.ss_mu.p, b.dis.p,
-                       b.has_perm ? b.perm.p : nullptr, b.m.p, eoff, xoff, evals, evecs, b.ss_sigma.p);
+                       b.has_perm ? b.perm.p : nullptr, b.m.p, eoff, xoff, evals, evecs, b.ss_sigma.p,
+                       b.ss_has_lock ? b.ss_ndefl.p : (const int *)nullptr, b.ss_has_lock ? b.ss_Vlock.p : (const double *)nullptr,
+                       b.ss_has_lock ? b.ss_lock_mu.p : (const double *)nullptr);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "eig_ss_output", 0.0, 0.0);
 }

@@ -430,6 +430,38 @@ def test_poisson3d_three_level_without_symmetry_matches_oracle_tightly(n, blk, c
     h.close()
 
 
+@pytest.mark.parametrize("theta,m_interior", [(0.06, 7), (0.08, 8)])
+def test_more_wanted_pairs_than_the_block_holds_are_locked(theta, m_interior):
+    """Agglomerates with seven to twelve wanted pairs (the reference's dsygvx has no such limit, src/xpacks.cpp:222-314):
+    the few-eigenpairs path locks the first six when they have converged and goes on for the others on the same factor
+    (csrc/eig2.hip: ss_lock_kernel, ss_deflate_kernel) instead of sending the agglomerate -- or, beyond a tenth of them,
+    the whole chunk -- to the dense path.  STRICT: any fallback is an error.  The eight interior agglomerates of a
+    32 x 32 x 16 mesh carry 7 (theta = 0.06) / 8 (0.08) pairs; counts, coarse dimension, iterations and history against
+    the oracle."""
+    o = _oracle()
+    prob = pr.poisson3d_problem((32, 32, 16), blk=(8, 8, 4))
+    old = os.environ.get("SAAMGE_AMD_SS_STRICT")
+    os.environ["SAAMGE_AMD_SS_STRICT"] = "1"
+    try:
+        h, H = _build_pair(prob, 1, theta=theta)
+    finally:
+        if old is None:
+            del os.environ["SAAMGE_AMD_SS_STRICT"]
+        else:
+            os.environ["SAAMGE_AMD_SS_STRICT"] = old
+    m, ev, X, Ds = h.get_ae_eigens(0)
+    assert sorted(m.tolist())[-8:] == [m_interior] * 8 and max(m.tolist()) == m_interior
+    # (a box of equal elements: repeated eigenvalues, so the eigenspaces are compared -- projectors -- and not the
+    # singular values of the MIS blocks, which depend on the basis inside them)
+    _compare_level(h, H, 0, theta, strict=False, degenerate=True)
+    assert h.level_info(0)["ncoarse"] == H.levels[0].P.shape[1]
+    x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-8)
+    xr, itr, convr, histr = o.solve(H, prob.b, rel_tol=1e-8)
+    assert conv and convr and it == itr
+    assert np.allclose(hist, histr, rtol=1e-9, atol=1e-12 * histr[0])
+    h.close()
+
+
 @pytest.mark.parametrize("levels", [2, 3])
 def test_elasticity3d_matches_oracle(levels):
     """Vector dofs (3 per vertex, byVDIM, 24 x 24 element matrices): the six rigid-body modes
