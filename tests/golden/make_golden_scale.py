@@ -52,6 +52,8 @@ BASE_CASES = {
     "base_poisson256": (256, (1.0, 1.0, 1.0), [0.003, 0.003], [(8, 8, 4)]),                # config 3 (the headline)
     "base_aniso128": (128, (1.0, 1.0, 1000.0), [1e-4, 1e-5], [(4, 4, 2)]),                # config 4
     "base_aniso128_blk884": (128, (1.0, 1.0, 1000.0), [1e-4, 1e-4], [(8, 8, 4)]),         # config 4, the other configs' coarse blocks
+    # ... and with theta_2 = 1e-5 (bench.py --workload aniso128_c884): level-1 agglomerates with eight wanted pairs
+    "base_aniso128_c884": (128, (1.0, 1.0, 1000.0), [1e-4, 1e-5], [(8, 8, 4)]),
     # a general operator (no symmetry, every stored entry a different value) at the size of bench.py's cpu_baseline sample;
     # read by tests/test_gpu_scale.py like the scale_* goldens of the Python oracle
     "scale_96x96x64_skew": ((96, 96, 64), (1.0, 1.0, 1.0), [0.003, 0.003], [(8, 8, 4)], "skew"),
@@ -216,9 +218,25 @@ def run(name):
           % (name, out["level_dims"].tolist(), it, t1 - t0, t2 - t1, near), flush=True)
 
 
+def copy_sensitivity(src, dst):
+    """`copysens:<src>:<dst>`: two goldens with the SAME fine level (same mesh, coefficient, agglomerates and first theta:
+    checked -- their level-0 eigenvector counts and coarse dofs per MIS must be identical) share the level-0
+    rounding-sensitivity fields; the perturbed oracle runs behind them (sens:<src>) are not repeated for <dst>."""
+    a = dict(np.load(os.path.join(HERE, src + ".npz")))
+    b = dict(np.load(os.path.join(HERE, dst + ".npz")))
+    assert np.array_equal(a["l0_ae_m"], b["l0_ae_m"]) and np.array_equal(a["l0_mis_k"], b["l0_mis_k"]), "different fine levels"
+    assert int(a["level_dims"][1]) == int(b["level_dims"][1])
+    for k in ("l0_mis_sensitive", "l0_ae_near_degenerate", "sens_level1_dims"):
+        b[k] = a[k]
+    np.savez_compressed(os.path.join(HERE, dst + ".npz"), **b)
+    print("%s: level-0 sensitivity fields copied from %s (%d flagged MISes)" % (dst, src, int(np.asarray(a["l0_mis_sensitive"]).sum())))
+
+
 if __name__ == "__main__":
     for c in (sys.argv[1:] or list(CASES)):
-        if c.startswith("sens:"):
+        if c.startswith("copysens:"):
+            copy_sensitivity(*c.split(":")[1:3])
+        elif c.startswith("sens:"):
             add_sensitivity(c[5:])
         else:
             (run_base if c in BASE_CASES else run)(c)
