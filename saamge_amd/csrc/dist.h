@@ -20,5 +20,6 @@ void halo_then(Hierarchy &H, Level::Dist *D, double *x, const std::function<void
 void dist_allreduce(Hierarchy &H, double *buf, long long count);
 // in-place all-gather of the own row ranges of the global-length vector x
 void dist_allgather_rows(Hierarchy &H, Level::Dist &D, double *x);
+void dist_reduce_scatter_rows(Hierarchy &H, Level::Dist &D, double *buf);
 
 }  // namespace saamge_amd

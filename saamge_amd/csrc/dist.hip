@@ -80,6 +80,39 @@ void dist_allgather_rows(Hierarchy &H, Level::Dist &D, double *x) {
                "allgather callback failed");
 }
 
+// Reduce-scatter of a vector of partial sums over the ownership ranges of D (the restricted residual on its way to a
+// row-partitioned coarser level, which reads it on its own rows only): every rank sends each owner its slab of partial
+// sums (one all-to-all: half the bytes of the full-vector all-reduce it replaces) and adds the world contributions of its
+// own slab in RANK ORDER -- the sum does not depend on the collective's algorithm.  The other rows of buf keep this
+// rank's partial sums (nobody reads them).
+// (the all-to-all implementations skip a rank's piece for itself: its own partial sums are read where they lie)
+__global__ __launch_bounds__(256) void slab_sum_kernel(int world, int rank, int nloc, const double *__restrict__ parts, double *out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nloc) return;
+    double s = 0.0;
+    for (int p = 0; p < world; ++p) {
+        const double v = (p == rank) ? out[i] : parts[(size_t)p * nloc + i];
+        s = (p == 0) ? v : s + v;
+    }
+    out[i] = s;
+}
+void dist_reduce_scatter_rows(Hierarchy &H, Level::Dist &D, double *buf) {
+    const int world = H.params.world;
+    if (world <= 1) return;
+    if (D.rs_buf.n < (size_t)world * (size_t)D.nloc) D.rs_buf.alloc((size_t)world * (size_t)D.nloc + 1);
+    if (D.rs_off.empty()) {
+        D.rs_off.resize((size_t)world + 1);
+        for (int p = 0; p <= world; ++p) D.rs_off[(size_t)p] = 8ll * p * D.nloc;
+    }
+    comm_fence(H);
+    SA_REQUIRE(H.params.alltoallv(H.params.allgather_ctx, buf, D.own_off.data(), D.rs_buf.p, D.rs_off.data()) == 0,
+               "alltoallv callback failed");
+    if (D.nloc) {
+        hipLaunchKernelGGL(slab_sum_kernel, dim3(div_up(D.nloc, 256)), dim3(256), 0, H.stream, world, H.params.rank, D.nloc, D.rs_buf.p, buf + D.row0);
+        SA_HIP_CHECK(hipGetLastError());
+    }
+}
+
 void halo_exchange(Hierarchy &H, Level::Dist &D, double *x) {
     hipStream_t s = H.stream;
     if (D.nsend) {

@@ -104,6 +104,8 @@ struct Level {                  // tg_data_t + interp_data_t + agg_partitioning_
         std::vector<long long> own_off;             // byte offsets of the ownership ranges (all-gather)
         DBuf<int> send_idx, recv_idx;
         DBuf<double> send_buf, recv_buf;
+        DBuf<double> rs_buf;                        // reduce-scatter of the restricted residual: world slabs of nloc
+        std::vector<long long> rs_off;
         int nsend = 0, nrecv = 0;
         // longest run of own SELL slices whose rows read no halo entry: applied on a side stream while the
         // exchange is in flight (dist.hip: halo_then); int_nrows = 0: no overlap on this level

@@ -1090,7 +1090,12 @@ static void vcycle_rec(Hierarchy &H, int level, const double *b, double *x) {
     double *rc = last ? H.c_b.p : H.levels[level + 1]->b.p;
     double *xc = last ? H.c_x.p : H.levels[level + 1]->x.p;
     spmv(s, L.R, L.r.p, rc);                                            // resc = R res
-    if (D) dist_allreduce(H, rc, L.R.nrows);    // res is zero outside the own rows: partial sums
+    if (D) {      // res is zero outside the own rows: partial sums
+        static const bool no_rs = std::getenv("SAAMGE_AMD_DIST_REDUCE_SCATTER") && std::atoi(std::getenv("SAAMGE_AMD_DIST_REDUCE_SCATTER")) == 0;
+        // a row-partitioned coarser level reads the restricted residual on its own rows only: reduce-scatter
+        if (!last && !no_rs && H.levels[level + 1]->dist.on) dist_reduce_scatter_rows(H, H.levels[level + 1]->dist, rc);
+        else dist_allreduce(H, rc, L.R.nrows);
+    }
     if (last) {
         coarse_solve(H, rc, xc);
     } else {
