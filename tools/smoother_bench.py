@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the fine-level smoother application (10 fused steps x + tau^-1 D^-1 (b - A x)) and the PCG solve on an
-existing hierarchy:  python tools/smoother_bench.py [n] [levels] [coef]
+existing hierarchy:  python tools/smoother_bench.py [n] [levels] [quick] [q2]
 Prints per-step microseconds of level 0 and the solve time; used to compare kernel variants (environment switches)."""
 import os
 import sys
@@ -15,7 +15,8 @@ from saamge_amd import capi  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 levels = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-prob = bench.build_problem(n, levels, "cuda:0")
+q2 = 'q2' in sys.argv          # Q2 elasticity (BASELINE config 5's operator: dictionary-coded, sell_gpair3_kernel)
+prob = bench.build_problem(n, levels, "cuda:0", blk=(4, 4, 4), coarse_blk=(2, 2, 2), workload="elasticity_q2") if q2 else bench.build_problem(n, levels, "cuda:0")
 params = capi.default_params(num_coarsenings=levels - 1)
 h, x, it, conv, hist = bench.one_step(capi, prob, params)
 b = prob.b
