@@ -450,6 +450,11 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
             bytes += add;
             ++cnt;
         }
+        // Large agglomerates (the wide-band path: one workgroup per matrix in the panel and solve kernels, one or two
+        // workgroups per CU): a chunk of 577 of them is two full rounds over the 256 CUs and a third at a quarter of
+        // the card -- whole multiples of 512 instead (config 5: 27 chunks of 512 instead of 24 of 577).
+        static const bool round_chunks = [] { const char *e = std::getenv("SAAMGE_AMD_CHUNK_ROUND"); return !(e && e[0] == '0'); }();
+        if (round_chunks && cnt > 512 && ae0 + cnt < ae_hi && sizes[ae0] > 1280) cnt = (cnt / 512) * 512;
         const int slot = idx & 1;
         EigBatch &batch = batches[slot];
         batch = EigBatch();
