@@ -771,18 +771,22 @@ __device__ __forceinline__ void spmv_epilogue(double sum, double *__restrict__ y
         y[row] = xrow[row] + scale * (dinv[row] * (sum - b[row]));
     }
 }
+// Lean enough for TWO workgroups per CU (32 wavefronts): the table split into values (8 B) and byte offsets (4 B) -- 12 B
+// per pair, 66 KB for 5 540 pairs -- and 63 VGPRs.  A version with one 16-byte table (one workgroup per CU) and a software
+// pipeline over two register sets (code words of group g + 2 and the look-ups + gathers of group g + 1 issued before the
+// products of group g; 95 VGPRs) ran at 1.22 ms per application of the 64^3 Q2 operator against 1.47 without the pipeline;
+// its counters showed 71 % of the wave-cycles waiting at four wavefronts per SIMD, and this one, with eight and no
+// pipeline, takes 1.05 ms (git history: sell_gpair3_kernel before "two workgroups per CU").
 template <int MODE>
-__global__ __launch_bounds__(1024) void sell_gpair3_kernel(int nrows_all, int row_lo, int row_hi, int wave0, int nwaves, int per_xcd, int wg_per_xcd, int ng,
-                                                           const roff_t *__restrict__ sptr,
-                                                           const unsigned long long *gcode,
-                                                           const GPair *__restrict__ gtab,
-                                                           const double *x, double *y,
-                                                           const double *__restrict__ b,
-                                                           const double *__restrict__ dinv, double scale) {
-    // (sptr, x, y, b, dinv: whole-operator arrays here; rows row_lo .. row_hi - 1 are written.  gcode, x and y are not
-    // __restrict__: loads through restrict-qualified const pointers move across the compiler barriers of the pipeline)
-    extern __shared__ __align__(16) GPair ltab[];
-    for (int i = threadIdx.x; i < ng; i += 1024) ltab[i] = gtab[i];
+__global__ __launch_bounds__(1024, 2) void sell_gpair3_kernel(int nrows_all, int row_lo, int row_hi, int wave0, int nwaves, int per_xcd,
+                                                               int wg_per_xcd, int ng, const roff_t *__restrict__ sptr,
+                                                               const unsigned long long *__restrict__ gcode,
+                                                               const GPair *__restrict__ gtab, const double *__restrict__ x,
+                                                               double *__restrict__ y, const double *__restrict__ b,
+                                                               const double *__restrict__ dinv, double scale) {
+    extern __shared__ __align__(16) double lval[];      // [ng] values, then [ng] byte offsets
+    int *loff = (int *)(lval + ng);
+    for (int i = threadIdx.x; i < ng; i += 1024) { const GPair e = gtab[i]; lval[i] = e.val; loff[i] = e.off; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int xcd = (int)(blockIdx.x & 7u), p = (int)(blockIdx.x >> 3);
@@ -790,7 +794,7 @@ __global__ __launch_bounds__(1024) void sell_gpair3_kernel(int nrows_all, int ro
     const int a = lane % 3;
     for (int wi = c0 + p * 16 + wv; wi < c1; wi += wg_per_xcd * 16) {
         const int first = (wave0 + wi) * 63;
-        const int row = min(first + min(lane, 62), nrows_all - 1);      // (idle lanes repeat a valid row and store nothing)
+        const int row = min(first + min(lane, 62), nrows_all - 1);
         const bool live = lane < 63 && first + lane >= row_lo && first + lane < row_hi;
         const int slice = row >> 6;
         const roff_t beg = sptr[slice];
@@ -798,78 +802,48 @@ __global__ __launch_bounds__(1024) void sell_gpair3_kernel(int nrows_all, int ro
         const unsigned long long *wp = gcode + ((size_t)(beg >> 2) + (size_t)slice * 64 + (row & 63));
         const unsigned short *cp = (const unsigned short *)wp;
         const unsigned row8 = (unsigned)row << 3;
-        // the wave's rows lie in at most two slices: the narrower one bounds the unguarded loop
         const int wa = __builtin_amdgcn_readfirstlane(w), wb = __builtin_amdgcn_readlane(w, 62);
         const int wmin = min(wa, wb), wmax = max(wa, wb);
         double s0 = 0.0, s1 = 0.0;
         int k = 0;
-        // Software pipeline over groups of 12 entries (four node blocks): the code words of group g + 2 and the table
-        // look-ups and gathers of group g + 1 are issued before the products of group g -- a wave then waits for one
-        // memory latency per group instead of two in a row (code word, then x), with 16 waves per CU the difference
-        // between 37 and ~20 cycles per entry.
-        // (two register sets in turn, and a compiler barrier between issue and use that the gathered values pass through:
-        // with one set and copies at the end of the iteration, or with the shifts free to move above the loads, the
-        // compiler waits for every load where it is issued)
-        const int ngroups = wmin / 12;
-        if (ngroups > 0) {
-            unsigned long long cwA[3], cwB[3];
-            double v0[12], own0[4], v1[12], own1[4];
-            auto codes = [&](unsigned long long (&cw)[3], int g) {
+        for (; k + 12 <= wmin; k += 12) {
+            unsigned long long cw[3];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) cw[q] = __builtin_nontemporal_load(wp + 16 * (12 * g + 4 * q));
-            };
-            auto lookups = [&](const unsigned long long (&cw)[3], double (&v)[12], double (&own)[4]) {
+            for (int q = 0; q < 3; ++q) cw[q] = __builtin_nontemporal_load(wp + 16 * (k + 4 * q));
+            double own[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) own[t] = gp_x(x, row8, ltab[bs3_own_code(cw, t, a)].off);
+            for (int t = 0; t < 4; ++t) own[t] = gp_x(x, row8, loff[bs3_own_code(cw, t, a)]);
 #pragma unroll
-                for (int j = 0; j < 12; ++j) v[j] = ltab[(unsigned)((cw[j >> 2] >> (16 * (j & 3))) & 0xffffull)].val;
-            };
-            auto products = [&](const double (&v)[12], const double (&own)[4]) {
+            for (int t = 0; t < 4; ++t) {
+                double xs[3];
+                bs3_share(own[t], a, xs[0], xs[1], xs[2]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    double xs[3];
-                    bs3_share(own[t], a, xs[0], xs[1], xs[2]);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        if ((3 * t + c) & 1) s1 = fma(v[3 * t + c], xs[c], s1);
-                        else s0 = fma(v[3 * t + c], xs[c], s0);
-                    }
+                for (int c = 0; c < 3; ++c) {
+                    const int j = 3 * t + c;
+                    const double v = lval[(unsigned)((cw[j >> 2] >> (16 * (j & 3))) & 0xffffull)];
+                    if (j & 1) s1 = fma(v, xs[c], s1);
+                    else s0 = fma(v, xs[c], s0);
                 }
-            };
-            const int last = ngroups - 1;      // (groups past the end: a valid group loaded again and dropped)
-            codes(cwA, 0);      // (issue order as at the end of the loop body: the code words of the next group, then the gathers)
-            codes(cwB, min(1, last));
-            asm volatile("" ::: "memory");
-            lookups(cwA, v0, own0);
-            for (int g = 0; g + 2 <= ngroups; g += 2) {      // (a straight-line body: pairs of groups)
-                codes(cwA, min(g + 2, last));
-                lookups(cwB, v1, own1);          // group g + 1
-                asm volatile("" : "+v"(own0[0]), "+v"(own0[1]), "+v"(own0[2]), "+v"(own0[3]) : : "memory");
-                products(v0, own0);              // group g
-                codes(cwB, min(g + 3, last));
-                lookups(cwA, v0, own0);          // group g + 2
-                asm volatile("" : "+v"(own1[0]), "+v"(own1[1]), "+v"(own1[2]), "+v"(own1[3]) : : "memory");
-                products(v1, own1);              // group g + 1
             }
-            if (ngroups & 1) products(v0, own0);      // (the last group of an odd number: loaded by the prologue or the last pair)
-            k = 12 * ngroups;
         }
-        for (; k < wmax; k += 3) {      // (per-lane bounds: the last entries of the narrower slice, the rest of the wider one)
-            GPair e[3];
+        for (; k < wmax; k += 3) {
+            int o[3];
+            double v[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const int kk = k + c;
-                e[c] = kk < w ? ltab[cp[64 * (size_t)(kk - (kk & 3)) + (kk & 3)]] : GPair{0, 0, 0.0};
+                const unsigned code = kk < w ? cp[64 * (size_t)(kk - (kk & 3)) + (kk & 3)] : 0xffffu;
+                o[c] = code != 0xffffu ? loff[code] : 0;
+                v[c] = code != 0xffffu ? lval[code] : 0.0;
             }
-            int o0 = e[0].off, o1 = e[1].off, o2 = e[2].off;
-            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2));      // (one gather, not one per component under its own mask)
-            const double own = gp_x(x, row8, a == 0 ? o0 : (a == 1 ? o1 : o2));
+            asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]));
+            const double own = gp_x(x, row8, a == 0 ? o[0] : (a == 1 ? o[1] : o[2]));
             double xs[3];
             bs3_share(own, a, xs[0], xs[1], xs[2]);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                if (k + c < w4 && ((k + c) & 1)) s1 = fma(e[c].val, xs[c], s1);
-                else s0 = fma(e[c].val, xs[c], s0);
+                if (k + c < w4 && ((k + c) & 1)) s1 = fma(v[c], xs[c], s1);
+                else s0 = fma(v[c], xs[c], s0);
             }
         }
         if (live) spmv_epilogue<MODE>(s0 + s1, y, b, dinv, scale, x, row);
@@ -1302,11 +1276,10 @@ static void launch_spmv(hipStream_t s, const DCsr &A, RowRange rr, const double 
         // waves of 63 rows, numbered over the whole operator; the kernels take whole-operator arrays
         const int wave0 = row0 / 63, nw = (row0 + nrows - 1) / 63 - wave0 + 1;
         const int per_xcd = div_up(div_up(nw, 8), 16) * 16;
-        const int wg_per_xcd = std::min(32, div_up(per_xcd, 16));
-        const size_t lds = sizeof(GPair) * (size_t)A.sell_ng;
+        const int wgl = std::min(64, div_up(per_xcd, 16));      // (two workgroups per CU)
         auto kern = sell_gpair3_kernel<MODE>;
-        SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(GPair) * GP_MAX)));
-        hipLaunchKernelGGL(kern, dim3(wg_per_xcd * 8), dim3(1024), lds, s, A.nrows, row0, row0 + nrows, wave0, nw, per_xcd, wg_per_xcd, A.sell_ng,
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 12 * GP_MAX + 16));
+        hipLaunchKernelGGL(kern, dim3(wgl * 8), dim3(1024), 12 * (size_t)A.sell_ng + 16, s, A.nrows, row0, row0 + nrows, wave0, nw, per_xcd, wgl, A.sell_ng,
                            A.sell_ptr.p, A.sell_gcode.p, (const GPair *)A.sell_gtab.p, x, y - row0, b ? b - row0 : nullptr,
                            dinv ? dinv - row0 : nullptr, scale);
         SA_HIP_CHECK(hipGetLastError());
