@@ -1833,9 +1833,11 @@ __global__ __launch_bounds__(NT) void ss_trsolve_kernel(const int *__restrict__ 
 // (3 - 57 agglomerates still iterating) take 0.6 - 1.0 ms = 4.5 us per block step for a lone workgroup, which is what a
 // single CU needs to pull 85 KB of factor per step one step ahead (in-kernel clocks: half of it waiting for them).
 typedef double ss_v4d __attribute__((ext_vector_type(4)));
-constexpr int TW_NT = 1024, TW_TPW = 4;      // threads, tiles of 16 rows per wavefront with prefetched factor entries
-template <bool UPPER>
-__global__ __launch_bounds__(TW_NT) void ss_trsolve_win_kernel(int WR, const int *__restrict__ ns, const int64_t *__restrict__ moff,
+constexpr int TW_NT = 1024;      // threads
+// TW_TPW: tiles of 16 rows per wavefront whose factor entries are requested a step ahead (4: one workgroup per CU;
+// 0: nothing ahead, few enough registers for two workgroups per CU -- chunks of more than 256 matrices)
+template <bool UPPER, int TW_TPW, int WGS>
+__global__ __launch_bounds__(TW_NT) __attribute__((amdgpu_waves_per_eu(4 * WGS, 4 * WGS))) void ss_trsolve_win_kernel(int WR, const int *__restrict__ ns, const int64_t *__restrict__ moff,
                                                                 const int64_t *__restrict__ voff,
                                                                 const double *__restrict__ W, double *__restrict__ X,
                                                                 const int *__restrict__ state, const int *__restrict__ bws,
@@ -1885,7 +1887,7 @@ __global__ __launch_bounds__(TW_NT) void ss_trsolve_win_kernel(int WR, const int
         win[(idx & 7) * WR + p] = (r >= 0 && r < n) ? Xb[(size_t)r * SS_B + (idx & 7)] : 0.0;
     }
     double td_next = load_td(kfirst);
-    double an[TW_TPW][4];
+    double an[TW_TPW ? TW_TPW : 1][4];
 #pragma unroll
     for (int u = 0; u < TW_TPW; ++u)
         if (wv + 16 * u < ntile) load_a(an[u], kfirst, wv + 16 * u);
@@ -2958,11 +2960,17 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         const int wr = (std::min(b.max_n, bws ? std::max(b.ss_bwmax, SB) : b.max_n) + 2 * SB) | 1;      // rows of the LDS window (odd)
         const size_t win_bytes = sizeof(double) * SS_B * (size_t)wr;
         if (b.max_n > 768 && !no_win && win_bytes <= 150 * 1024) {
-            auto lo = ss_trsolve_win_kernel<false>, up = ss_trsolve_win_kernel<true>;
-            SA_HIP_CHECK(hipFuncSetAttribute((const void *)lo, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            SA_HIP_CHECK(hipFuncSetAttribute((const void *)up, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            hipLaunchKernelGGL(lo, dim3(nact), dim3(1024), win_bytes, s, wr, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
-            hipLaunchKernelGGL(up, dim3(nact), dim3(1024), win_bytes, s, wr, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
+            // more matrices than CUs: the variant without requests ahead, two workgroups per CU (config 5 at 64^3: solves 448 -> 397 ms
+            // per step; SAAMGE_AMD_SS_TRSOLVE_TWO=0: one per CU always)
+            static const bool two_env = !(std::getenv("SAAMGE_AMD_SS_TRSOLVE_TWO") && std::atoi(std::getenv("SAAMGE_AMD_SS_TRSOLVE_TWO")) == 0);
+            auto go = [&](auto lo, auto up) {
+                SA_HIP_CHECK(hipFuncSetAttribute((const void *)lo, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                SA_HIP_CHECK(hipFuncSetAttribute((const void *)up, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                hipLaunchKernelGGL(lo, dim3(nact), dim3(1024), win_bytes, s, wr, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
+                hipLaunchKernelGGL(up, dim3(nact), dim3(1024), win_bytes, s, wr, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
+            };
+            if (two_env && nact > 256 && win_bytes <= 70 * 1024) go(ss_trsolve_win_kernel<false, 0, 2>, ss_trsolve_win_kernel<true, 0, 2>);
+            else go(ss_trsolve_win_kernel<false, 4, 1>, ss_trsolve_win_kernel<true, 4, 1>);
         } else if (b.max_n > 768) {
             hipLaunchKernelGGL((ss_trsolve_kernel<false, 1024>), dim3(nact), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
             hipLaunchKernelGGL((ss_trsolve_kernel<true, 1024>), dim3(nact), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
