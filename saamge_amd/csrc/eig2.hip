@@ -2597,7 +2597,10 @@ static void ss_factor_generic(hipStream_t s, EigBatch &b, bool sgn, int *neg, in
                 }
                 profiler().begin(s);
             }
-            if (np > 192)
+            // (one row per lane, 108 VGPRs, four wavefronts per SIMD: 8 % faster on the 2 187-row agglomerates of config 5 than two
+            // rows per lane at 212 VGPRs and two wavefronts per SIMD; SAAMGE_AMD_SS_RPL2=1: two rows for trailing matrices beyond 192)
+            static const bool rpl2 = std::getenv("SAAMGE_AMD_SS_RPL2") != nullptr;
+            if (np > 192 && rpl2)
                 hipLaunchKernelGGL((sbr_fused_kernel<false, 2, 3>), dim3(cnt8 * div_up(np, 2 * SF_ROWS)), dim3(S2_NT), 0, s, k0,
                                    b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Vpk2.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
                                    b.Gbuf.p, b.trash.p, b.count, div_up(np, 2 * SF_ROWS), SB, gbw, vrow, zrow, skip);
