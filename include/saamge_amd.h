@@ -36,7 +36,10 @@ typedef struct saamge_amd_params {
     int nu_pro[SAAMGE_AMD_MAX_LEVELS];        /* prolongator smoothing degree (interp_smooth, src/interp.cpp:172-229); 0 = tentative */
     int avoid_ess_bdr_dofs;                   /* src/ml.cpp:64, always true in the reference */
     int testmesh;                             /* mltest fixture: ones-vector on AE 0, src/interp.cpp:510-524 */
-    int coarse_solver;                        /* 0 auto (explicit dense inverse up to 8192 rows, else inner PCG), 1 dense inverse, 2 inner PCG */
+    int coarse_solver;                        /* 0 auto (explicit dense inverse up to 8192 rows, else inner PCG); 1 direct = the reference's
+                                               * coarse_direct (src/tg.cpp:990-996): dense inverse up to 16384 rows, beyond that block-
+                                               * tridiagonal elimination over a level structure of the operator's graph; 2 inner PCG;
+                                               * 3 block-tridiagonal elimination whatever the size */
     double coarse_rtol;                       /* inner PCG tolerance on (B r, r), un-squared */
     int coarse_max_iter;
     long long workspace_bytes;                /* dense AE matrices are processed in chunks of this size (default 32 GiB) */
@@ -101,6 +104,14 @@ typedef struct saamge_amd_params {
      * any batch that fails certification redone by the dense path; 1: dense path only (dsygvx's
      * own algorithm: reduction to tridiagonal form, Sturm counts, inverse iteration). */
     int eigensolver;
+    /* Few-eigenpairs path: a Ritz pair is accepted when the bound of its residual || C x - lambda x || (C scaled to
+     * lambda_max <= 1, like the reference's generalised problem, src/spectral.cpp:134) is at most eig_tol.  Default 1e-12:
+     * an invariant subspace is then determined to eig_tol / gap (the reference's dsygvx delivers eps / gap), i.e. to
+     * ~1e-8 for the 7e-5 gaps of BASELINE config 4 (theta = 1e-4).  Measured there (tests/test_gpu_baseline_sizes.py, the
+     * well-posed config-4 golden): 1e-12, 1e-13 and 1e-14 give the same level dimensions, the same counts and the same PCG
+     * history to 3 digits of its 6e-8 deviation from the oracle's -- that deviation comes from the singular vectors of the
+     * smallest kept singular values, not from the eigenvectors.  Allowed: 1e-15 ... 1e-8. */
+    double eig_tol;
 } saamge_amd_params;
 
 void saamge_amd_params_default(saamge_amd_params *p);

@@ -818,6 +818,14 @@ double cpu_ref_Ac_trace(const cpu_ref_hier *h, int l) {
             if (Ac.J[k] == i) s += Ac.V[k];
     return s;
 }
+// squared Frobenius norm of the level's Galerkin operator (like the trace: invariant under an orthogonal change of basis of
+// the coarse space, i.e. under the freedom a degenerate local eigenspace leaves)
+double cpu_ref_Ac_fro2(const cpu_ref_hier *h, int l) {
+    const Csr &Ac = h->H.levels[(size_t)l]->Ac;
+    double s = 0.0;
+    for (int64_t k = 0; k < Ac.I[Ac.nrows]; ++k) s += Ac.V[k] * Ac.V[k];
+    return s;
+}
 void cpu_ref_vcycle(cpu_ref_hier *h, const double *b, double *x) { vcycle(h->H, 0, b, x); }
 
 // MFEM CGSolver::Mult as driven by test/mltest/mltest.cpp:773-781 (squared_tol) == kalchev_pcg

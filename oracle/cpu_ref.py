@@ -27,6 +27,8 @@ def load():
         lib.cpu_ref_setup2.restype = C.c_void_p
         lib.cpu_ref_Ac_trace.restype = C.c_double
         lib.cpu_ref_Ac_trace.argtypes = [C.c_void_p, C.c_int]
+        lib.cpu_ref_Ac_fro2.restype = C.c_double
+        lib.cpu_ref_Ac_fro2.argtypes = [C.c_void_p, C.c_int]
         lib.cpu_ref_error.restype = C.c_char_p
         lib.cpu_ref_error.argtypes = [C.c_void_p]
         lib.cpu_ref_free.argtypes = [C.c_void_p]
@@ -128,6 +130,9 @@ class Hierarchy(object):
 
     def Ac_trace(self, l):
         return float(load().cpu_ref_Ac_trace(self.h, C.c_int(l)))
+
+    def Ac_fro(self, l):
+        return float(load().cpu_ref_Ac_fro2(self.h, C.c_int(l))) ** 0.5
 
     def vcycle(self, b):
         b = np.ascontiguousarray(b, dtype=np.float64)

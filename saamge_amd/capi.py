@@ -65,6 +65,7 @@ class Params(C.Structure):
         ("smooth_drop_tol", C.c_double),
         ("do_aggregates", C.c_int),
         ("eigensolver", C.c_int),
+        ("eig_tol", C.c_double),
     ]
 
 
@@ -129,7 +130,7 @@ def _ptr(a):
 def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, keep_debug=False,
                    coarse_rtol=1e-14, workspace_bytes=None, dist_min_local_rows=None,
                    coarse_solver=None, nu_pro=0, correct_nullspace=False, extra_modes=None, algebraic=False,
-                   smooth_drop_tol=0.0, do_aggregates=False, eigensolver=0):
+                   smooth_drop_tol=0.0, do_aggregates=False, eigensolver=0, eig_tol=None):
     p = Params()
     load().saamge_amd_params_default(C.byref(p))
     p.num_coarsenings = num_coarsenings
@@ -144,6 +145,8 @@ def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, k
     p.do_aggregates = int(do_aggregates)
     p.eigensolver = {"subspace": 0, "dense": 1}.get(eigensolver, eigensolver)
     p.keep_debug = int(keep_debug)
+    if eig_tol is not None:
+        p.eig_tol = float(eig_tol)
     p.coarse_rtol = coarse_rtol
     if workspace_bytes is not None:
         p.workspace_bytes = int(workspace_bytes)

@@ -811,15 +811,15 @@ struct RowsCache {
     DBuf<double> vals;
     DBuf<short> cols;
 };
-static RowsCache g_rows;
+static RowsCache &g_rows = *new RowsCache;       // never destroyed: no HIP calls from static destructors (see eig.hip arena())
 static int g_rows_gen = 0;
 void ae_rows_new_build() { ++g_rows_gen; }
 
 static void launch_rows8(hipStream_t s, const DevRelations &rel, const DCsr &A, const DevElmats &el, int ae0,
                          const EigBatch &batch, int RW, const double *&rv, const short *&rc,
                          const RowsSpan *rows = nullptr) {
-    static DBuf<double> g_rvals;
-    static DBuf<short> g_rcols;
+    static DBuf<double> &g_rvals = *new DBuf<double>;
+    static DBuf<short> &g_rcols = *new DBuf<short>;
     double *dv;
     short *dc;
     if (rows) {

@@ -74,6 +74,7 @@ void saamge_amd_params_default(saamge_amd_params *p) {
     p->smooth_drop_tol = 0.0;
     p->do_aggregates = 0;
     p->eigensolver = 0;
+    p->eig_tol = 1e-12;
 }
 
 int saamge_amd_memcpy(void *dst, const void *src, long long bytes) {
@@ -132,6 +133,8 @@ static int produce_data(int n, const void *rowptr, int rowptr_bits, const int *c
     p.do_aggregates = params->do_aggregates;
     p.eigensolver = params->eigensolver;
     SA_REQUIRE(p.eigensolver == 0 || p.eigensolver == 1, "bad eigensolver selector");
+    p.eig_tol = params->eig_tol;
+    SA_REQUIRE(p.eig_tol >= 1e-15 && p.eig_tol <= 1e-8, "eig_tol must lie in [1e-15, 1e-8] (saamge_amd_params_default sets 1e-12)");
     SA_REQUIRE(p.world == 1 || (p.rank >= 0 && p.rank < p.world), "bad rank");
     set_thread_stream((hipStream_t)stream);
     Hierarchy *H = hierarchy_create(n, rowptr, rowptr_bits, col, val, NE, nde, elem_to_dof, elmat, bdr_dofs,
@@ -167,7 +170,7 @@ int saamge_amd_update_operators(saamge_amd_hierarchy *h, const double *new_val) 
 int saamge_amd_update_operators2(saamge_amd_hierarchy *h, const double *new_val, int coarse_solver) {
     SA_API_BEGIN
     SA_REQUIRE(h, "null argument");
-    SA_REQUIRE(coarse_solver >= -1 && coarse_solver <= 2, "coarse_solver: -1 (keep), 0 (auto), 1 (dense inverse) or 2 (inner PCG)");
+    SA_REQUIRE(coarse_solver >= -1 && coarse_solver <= 3, "coarse_solver: -1 (keep), 0 (auto), 1 (direct), 2 (inner PCG) or 3 (block-tridiagonal direct)");
     require_device(*h->H);
     if (coarse_solver >= 0) h->H->params.coarse_solver = coarse_solver;
     hierarchy_update_operators(*h->H, new_val);
@@ -185,7 +188,10 @@ void saamge_amd_ml_free_data(saamge_amd_hierarchy *h) {
     delete h->H;
     delete h;
     // the caller may destroy its stream right after this call: no batch of frees stays open on it
-    if (had) dev_pool_close_stream(hs);
+    if (had) {
+        dev_pool_close_stream(hs);
+        unset_thread_stream();      // ... and this thread no longer frees into it
+    }
 }
 
 // stage a host vector on the device when needed

@@ -92,6 +92,7 @@ inline bool is_device_ptr(const void *p) {
 // frees through hipFree as before.  Idle blocks beyond SAAMGE_AMD_POOL_MAX_GB (default 64) are returned
 // to the driver, all of them by dev_pool_release() or when a hipMalloc fails.
 void set_thread_stream(hipStream_t s);
+void unset_thread_stream();      // the thread frees through hipFree again (its stream may be destroyed next)
 hipStream_t thread_stream();
 bool thread_stream_is_set();
 void *dev_alloc(size_t bytes);
@@ -102,7 +103,7 @@ struct ThreadStreamScope {       // the calling thread's stream for a scope (res
     hipStream_t prev;
     bool had;
     explicit ThreadStreamScope(hipStream_t s) : prev(thread_stream()), had(thread_stream_is_set()) { set_thread_stream(s); }
-    ~ThreadStreamScope() { if (had) set_thread_stream(prev); }
+    ~ThreadStreamScope() { if (had) set_thread_stream(prev); else unset_thread_stream(); }
 };
 // Close the batch of frees `s` is filling NOW (its event is recorded while the stream is certainly alive) -- called
 // when a hierarchy is destroyed: its caller may destroy the stream next, and an open batch would later record its

@@ -219,29 +219,48 @@ __global__ __launch_bounds__(256) void dense_symv_kernel(int n, const double *__
     if (lane == 0) y[row] = add ? y[row] + s : s;
 }
 
+void GjWork::reserve(int nmax, hipStream_t s) {
+    const size_t nt = (size_t)div_up(nmax, DNB);
+    if (Pinv.n < (size_t)DNB * DNB) Pinv.alloc((size_t)DNB * DNB);
+    if (Rp.n < (size_t)DNB * DNB * nt) { Rp.alloc((size_t)DNB * DNB * nt); Col.alloc((size_t)DNB * DNB * nt); }
+    if (!info.n) { info.alloc(1); info.zero(s); }
+}
+
+void dense_zero(hipStream_t s, size_t nn, double *X) {
+    hipLaunchKernelGGL(dense_zero_kernel, dim3(div_up((long)nn, 256)), dim3(256), 0, s, nn, X);
+}
+void dense_scatter(hipStream_t s, int n, const roff_t *rowptr, const int *col, const double *val, double *X) {
+    hipLaunchKernelGGL(dense_scatter_kernel, dim3(div_up((long)n * 8, 256)), dim3(256), 0, s, n, rowptr, col, val, X);
+}
+
+void dense_inverse_inplace(hipStream_t s, int n, double *X, GjWork &w) {
+    w.reserve(n, s);
+    const int nt = div_up(n, DNB), nt2 = div_up(nt, 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)gj_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GJ_APPLY_LDS));
+        attr_set = true;
+    }
+    for (int k0 = 0; k0 < n; k0 += DNB) {
+        const int nb = std::min(DNB, n - k0);
+        hipLaunchKernelGGL(gj_panel_kernel, dim3(nt), dim3(256), 0, s, n, k0, nb, X, w.Pinv.p, w.Rp.p, w.Col.p, w.info.p);
+        hipLaunchKernelGGL(gj_apply_kernel, dim3(nt2, nt2), dim3(256), GJ_APPLY_LDS, s, n, k0, nb, nt, X, w.Pinv.p, w.Rp.p, w.Col.p);
+    }
+    hipLaunchKernelGGL(dense_symmetrize_kernel, dim3(div_up(n, 16), div_up(n, 16)), dim3(256), 0, s, n, X);
+    SA_HIP_CHECK(hipGetLastError());
+}
+
 bool dense_inverse_spd(hipStream_t s, const DCsr &A, DBuf<double> &X) {
     const int n = A.nrows;
     const size_t nn = (size_t)n * n;
     X.alloc(nn);
-    const int nt = div_up(n, DNB);
-    DBuf<double> Pinv((size_t)DNB * DNB), Rp((size_t)DNB * DNB * nt), Col((size_t)DNB * DNB * nt);
-    DBuf<int> info(1);
-    info.zero(s);
+    GjWork w;
     profiler().begin(s);
-    hipLaunchKernelGGL(dense_zero_kernel, dim3(div_up((long)nn, 256)), dim3(256), 0, s, nn, X.p);
-    hipLaunchKernelGGL(dense_scatter_kernel, dim3(div_up((long)n * 8, 256)), dim3(256), 0, s, n, A.rowptr.p,
-                       A.col.p, A.val.p, X.p);
-    const int nt2 = div_up(nt, 2);
-    SA_HIP_CHECK(hipFuncSetAttribute((const void *)gj_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GJ_APPLY_LDS));
-    for (int k0 = 0; k0 < n; k0 += DNB) {
-        const int nb = std::min(DNB, n - k0);
-        hipLaunchKernelGGL(gj_panel_kernel, dim3(nt), dim3(256), 0, s, n, k0, nb, X.p, Pinv.p, Rp.p, Col.p, info.p);
-        hipLaunchKernelGGL(gj_apply_kernel, dim3(nt2, nt2), dim3(256), GJ_APPLY_LDS, s, n, k0, nb, nt, X.p, Pinv.p, Rp.p, Col.p);
-    }
-    hipLaunchKernelGGL(dense_symmetrize_kernel, dim3(div_up(n, 16), div_up(n, 16)), dim3(256), 0, s, n, X.p);
-    SA_HIP_CHECK(hipGetLastError());
-    const int bad = info.to_host(s)[0];       // (synchronises: Pinv / Rp may go)
-    profiler().end(s, "coarse_inverse", 16.0 * (double)nn * nt, 2.0 * (double)n * n * n);
+    dense_zero(s, nn, X.p);
+    dense_scatter(s, n, A.rowptr.p, A.col.p, A.val.p, X.p);
+    dense_inverse_inplace(s, n, X.p, w);
+    const int bad = w.info.to_host(s)[0];       // (synchronises: the work buffers may go)
+    profiler().end(s, "coarse_inverse", 16.0 * (double)nn * div_up(n, DNB), 2.0 * (double)n * n * n);
     return bad == 0;
 }
 

@@ -763,7 +763,9 @@ struct EigArena {
 };
 static int g_slot = 0;   // workspace of the batch being set up (single host thread)
 static EigArena &arena() {
-    static EigArena a[2];
+    // heap objects that are never destroyed: a static's destructor would call into HIP (dev_free -> hipEventRecord)
+    // after main() has returned, when the runtime -- and a profiler hooked into it -- is already torn down
+    static EigArena *a = new EigArena[2];
     return a[g_slot];
 }
 template <class T>

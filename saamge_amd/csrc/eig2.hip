@@ -1276,13 +1276,12 @@ void eig_backtransform_two_stage(hipStream_t s, EigBatch &b, const int64_t *xoff
 //   Z = (C - sigma)^-1 X,  M = Z^T X (= Z^T (C - sigma) Z),  G = Z^T Z,  M c = mu G c,
 //   X <- Z c,  lambda = sigma + mu.
 // A pair is accepted when its inverse residual || Z_j - X_j / mu_j || bounds the residual of C
-// below SS_TOL; the count is certified by the first unwanted pair having converged above vu.
+// below the tolerance (EigBatch::ss_tol); the count is certified by the first unwanted pair having converged above vu.
 // Anything that does not fit (more than SS_B - 2 wanted pairs, no convergence, a non-positive
 // pivot) makes the caller fall back to the dense path on a re-assembled matrix.
 // =========================================================================================
 constexpr int SS_B = 8;
 constexpr double SS_SIGMA = -1e-3;
-constexpr double SS_TOL = 1e-12;
 constexpr int SS_MAX_ITER = 80;
 // Matrices with more wanted pairs than the block's six: the first six converged pairs are LOCKED (copied out, the block
 // started again and kept orthogonal to them: ss_lock_kernel, ss_deflate_kernel) and the iteration goes on for the
@@ -1473,8 +1472,16 @@ __global__ __launch_bounds__(256) void band_copy_kernel(const int *__restrict__ 
 // two per CU) and 68 (up to 52, three per CU) -- the kernel is a chain of short dependent stages, so
 // the resident workgroups of other matrices are what fills the CU.
 constexpr int BC_NT = 256;
-constexpr size_t bc_lds_bytes(int win) {      // window rows x (band + 1) columns, L21^T, the two block buffers, signs
-    return sizeof(double) * ((size_t)win * (win - SB + 1) + (size_t)SB * (win - SB + 4) + 2 * SB * (SB + 1) + SB) + 64;
+// Pitch of a window row: band + 1 columns, made EVEN wherever that costs no resident workgroup.  The panel stage reads
+// entry (r, k0 + c) with thread = row r, i.e. with a stride of pitch - 1 doubles between lanes: 52 doubles (window 68, pitch
+// 53) put the 64 lanes on 8 of the 32 bank pairs (round 3's counters: 80 % of the kernel's LDS cycles were bank conflicts),
+// 64 doubles (window 80, pitch 65) on ONE; an odd stride spreads them over all.  Window 68 keeps pitch 53 (one more
+// double per row would cost the fourth workgroup of a CU by 512 bytes); bands up to 51 -- the 8 x 8 x 4-element agglomerates
+// of the Q1 problems have exactly 51 -- take the window of 67 rows, pitch 52.
+constexpr int bc_pitch(int win) { return win == 68 ? win - SB + 1 : ((win - SB + 1) + 1) / 2 * 2; }
+constexpr int bc_pitch_t(int win) { return ((win - SB + 4) + 1) / 2 * 2; }      // transposed panel: rows stay 16-byte aligned
+constexpr size_t bc_lds_bytes(int win) {      // window rows x pitch, L21^T, the two block buffers, signs
+    return sizeof(double) * ((size_t)win * bc_pitch(win) + (size_t)SB * bc_pitch_t(win) + 2 * SB * (SB + 1) + SB) + 64;
 }
 // INERTIA = true: nothing is written back.  The same window walk factors C - shift I = L S L^T
 // (S = diag(+-1), no pivoting) and info[b] receives the number of negative pivots = the number of
@@ -1488,8 +1495,8 @@ __global__ __launch_bounds__(BC_NT) void chol_band_lds_kernel(const int *__restr
                                                               const int *__restrict__ active = nullptr) {
     // the window is kept band-packed: row i holds columns i - BC_MAXBW .. i (only the lower band is ever
     // touched), 53 instead of 69 doubles per row at BC_WIN = 68 -- four workgroups per CU instead of three
-    constexpr int BC_MAXBW = BC_WIN - SB, BC_P = BC_MAXBW + 1;
-    constexpr int BC_PT = BC_MAXBW + 4;      // pitch of the transposed panel (rows padded to the 4-row tiles)
+    constexpr int BC_MAXBW = BC_WIN - SB, BC_P = bc_pitch(BC_WIN);
+    constexpr int BC_PT = bc_pitch_t(BC_WIN);      // pitch of the transposed panel (rows padded to the 4-row tiles)
     extern __shared__ __align__(16) double bc_lds[];
     double *S = bc_lds;                                  // [BC_WIN][BC_P]
     double *Lp = S + BC_WIN * BC_P;                      // [SB][BC_PT]: L21^T of the current block (16-byte aligned rows)
@@ -1500,6 +1507,9 @@ __global__ __launch_bounds__(BC_NT) void chol_band_lds_kernel(const int *__restr
     const int b = active ? active[blockIdx.x] : (int)blockIdx.x, n = ns[b], bw = bws[b];     // (active: dense list of the matrices to factor)
     if (bw > BC_MAXBW) return;                           // (the host only launches this when every matrix fits)
     double *A = W + moff[b];
+    // (The serial stages -- diagonal block: one wavefront; panel: <= 52 threads; update: <= 2 wavefronts -- run on the first
+    // wavefronts of the workgroup.  tools/simd_map.hip: the hardware already puts wavefront 0 of the four workgroups resident
+    // on a CU on four DIFFERENT SIMDs; rotating the roles by the block index lined them up instead: 25.4 -> 32 ms, round 4.)
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     auto sl = [&](int i, int j) -> double & { return S[(i % BC_WIN) * BC_P + (j - i + BC_MAXBW)]; };     // (0 <= i - j <= BC_MAXBW)
@@ -2166,7 +2176,7 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
                                                     double *__restrict__ dbg = nullptr,
         const int *__restrict__ active = nullptr, double *__restrict__ hist = nullptr, int max_iter = 80,
         const int *__restrict__ reshift_ok = nullptr, const int *__restrict__ ndefl = nullptr,
-        const int *__restrict__ it0 = nullptr) {
+        const int *__restrict__ it0 = nullptr, double SS_TOL = 1e-12) {
     // ndefl[b]: pairs of this matrix locked so far (the block is kept orthogonal to them); it0[b]: the iteration at which
     // its block was last started (0, or the lock): convergence is judged from the second iteration after that
     if (it0) iter -= it0[active ? active[blockIdx.x] : (int)blockIdx.x];
@@ -2683,7 +2693,8 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
                 hipLaunchKernelGGL(kern, dim3(b.count), dim3(BC_NT), bc_lds_bytes(win), s, b.n.p, b.moff.p, b.W.p, bws, neg.p,
                                    b.window_vu, (const int *)nullptr);
             };
-            if (bwmax <= 68 - SB) go(chol_band_lds_kernel<68, true>, 68);
+            if (bwmax <= 67 - SB) go(chol_band_lds_kernel<67, true>, 67);
+            else if (bwmax <= 68 - SB) go(chol_band_lds_kernel<68, true>, 68);
             else if (bwmax <= 80 - SB) go(chol_band_lds_kernel<80, true>, 80);
             else go(chol_band_lds_kernel<128, true>, 128);
             SA_HIP_CHECK(hipGetLastError());
@@ -2790,7 +2801,7 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
         b.pre.alloc((size_t)b.count);
         b.pre_val.alloc(2 * (size_t)b.count);
         hipLaunchKernelGGL(ss_nullcheck_kernel, dim3(b.count), dim3(NC_NT), sizeof(double) * (size_t)nmax, s, b.n.p, b.moff.p,
-                           b.voff.p, b.W.p, b.dis.p, b.has_perm ? b.perm.p : nullptr, bws, b.inertia.p, b.window_vu, SS_TOL,
+                           b.voff.p, b.W.p, b.dis.p, b.has_perm ? b.perm.p : nullptr, bws, b.inertia.p, b.window_vu, b.ss_tol,
                            b.pre.p, b.pre_val.p, b.has_x0c ? b.x0c.p : (const double *)nullptr);
         SA_HIP_CHECK(hipGetLastError());
         profiler().end(s, "eig_ss_nullcheck", cb, 0.0);
@@ -2844,7 +2855,8 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
             hipLaunchKernelGGL(kern, dim3(nchol), dim3(BC_NT), bc_lds_bytes(win), s, b.n.p, b.moff.p, b.W.p, bws, info.p, 0.0,
                                use_chol_list ? chol_active.p : (const int *)nullptr);
         };
-        if (bwmax <= 68 - SB) go(chol_band_lds_kernel<68, false>, 68);
+        if (bwmax <= 67 - SB) go(chol_band_lds_kernel<67, false>, 67);
+        else if (bwmax <= 68 - SB) go(chol_band_lds_kernel<68, false>, 68);
         else if (bwmax <= 80 - SB) go(chol_band_lds_kernel<80, false>, 80);
         else go(chol_band_lds_kernel<128, false>, 128);
         SA_HIP_CHECK(hipGetLastError());
@@ -2999,7 +3011,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         hipLaunchKernelGGL(ss_rr_kernel, dim3(nact), dim3(256), 0, s, b.n.p, b.voff.p, X, Z, mu, state.p, iter,
                            b.ss_sigma.p, vu, b.h_inertia.empty() ? (const int *)nullptr : b.inertia.p, dbgbuf.p, active.p,
                            slow_hist.p, max_iter, reshift_on ? reshift_ok.p : (const int *)nullptr,
-                           any_lock ? b.ss_ndefl.p : (const int *)nullptr, any_lock ? it0.p : (const int *)nullptr);
+                           any_lock ? b.ss_ndefl.p : (const int *)nullptr, any_lock ? it0.p : (const int *)nullptr, b.ss_tol);
         if (dbg_on && iter > 0) {
             auto hd = dbgbuf.to_host(s);
             const int show = std::min(b.count, 3);

@@ -7,6 +7,7 @@
 #include <thread>
 
 #include "assemble.h"
+#include "blocktri.h"
 #include "common.h"
 #include "eig.h"
 #include "mis.h"
@@ -24,7 +25,7 @@ struct Params {                 // MultilevelParameters (amg/inc/ml.hpp:59-114)
     int nu_pro[MAX_LEVELS];     // prolongator smoothing degree (0 = tentative)
     int avoid_ess_bdr_dofs = 1; // amg/src/ml.cpp:64
     int testmesh = 0;           // mltest fixture: extra ones-vector on AE 0 (amg/src/interp.cpp:510-524)
-    int coarse_solver = 0;      // 0 auto, 1 explicit dense inverse, 2 inner PCG
+    int coarse_solver = 0;      // 0 auto, 1 direct (dense inverse up to 16 384 rows, block-tridiagonal beyond), 2 inner PCG, 3 block-tridiagonal
     double coarse_rtol = 1e-14; // inner PCG: relative (B r, r) reduction, un-squared
     int coarse_max_iter = 2000;
     size_t workspace_bytes = (size_t)32 << 30;  // dense AE matrices are processed in chunks of this size
@@ -53,6 +54,7 @@ struct Params {                 // MultilevelParameters (amg/inc/ml.hpp:59-114)
     int do_aggregates = 0;        // aggregates with arbitration instead of MISes on the last coarsening
     int algebraic = 0;            // element-free mode (tg_produce_data_algebraic): elements = dofs
     int eigensolver = 0;          // 0 few-eigenpairs path (certified count, dense fallback), 1 dense path only
+    double eig_tol = 1e-12;       // few-eigenpairs path: acceptance bound of a Ritz pair's residual
 };
 
 struct NextPrep {               // host half of the next level's inputs (prepare_next_host)
@@ -121,7 +123,8 @@ struct Hierarchy {              // ml_data_t
     int device = 0;             // the GPU this hierarchy lives on (current device of the creating thread)
     std::vector<std::unique_ptr<Level>> levels;
     // coarsest solver
-    int coarse_kind = 2;        // 1 explicit dense inverse, 2 inner PCG
+    int coarse_kind = 2;        // 1 explicit dense inverse, 2 inner PCG, 3 block-tridiagonal direct solve (blocktri.hip)
+    BlockTri c_bt;
     DBuf<double> c_dinv, c_r, c_z, c_d, c_q, c_t0, c_t1, c_b, c_x;
     DBuf<double> c_L, c_work;   // explicit inverse of the coarsest operator (coarse_kind 1)
     std::vector<double> c_roots;

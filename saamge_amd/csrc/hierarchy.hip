@@ -55,7 +55,7 @@ struct PhaseTimer {
 
 // grow-only scratch buffers that survive across chunks / levels / hierarchies
 static DBuf<double> &scratch_pool(int slot) {
-    static DBuf<double> pools[4];
+    static DBuf<double> *pools = new DBuf<double>[4];     // never destroyed: no HIP calls from static destructors
     return pools[slot];
 }
 static double *scratch_get(int slot, size_t need) {
@@ -211,8 +211,9 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     hipStream_t mis_stream = side_stream(0);
     const int dev = current_device();
     std::exception_ptr mis_err;
-    // SAAMGE_AMD_SERIAL=1: no worker threads anywhere in the setup (rocprofv3's counter collection aborts on launches
-    // from threads it has not seen: "stream_stack.cpp: Check failed"); the work runs in line, same streams
+    // SAAMGE_AMD_SERIAL=1: no worker threads anywhere in the setup (counter passes attribute launches per thread; the
+    // work runs in line, same streams).  The "stream_stack.cpp: Check failed" aborts once seen under rocprofv3 --pmc came
+    // from static destructors calling HIP at exit (fixed in round 4: those objects are never destroyed), not from threads
     static const bool serial = std::getenv("SAAMGE_AMD_SERIAL") != nullptr;
     auto mis_work = [&]() {
         try {
@@ -460,6 +461,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         batch = EigBatch();
         eig_batch_alloc(batch, std::vector<int>(sizes.begin() + ae0, sizes.begin() + ae0 + cnt), qa, slot);
         batch.dense_only = P.eigensolver == 1;
+        batch.ss_tol = P.eig_tol;
         batch.set_window(L.theta);
         if (lev > 0 && H.levels[lev - 1]->cvec_next.n == (size_t)L.A.nrows) {
             const size_t rows = (size_t)batch.h_voff[cnt];
@@ -917,9 +919,14 @@ static void setup_coarse_solver(Hierarchy &H) {
     const int want = H.params.coarse_solver;
     static const long dense_max = std::getenv("SAAMGE_AMD_COARSE_DENSE_MAX")
                                       ? atol(std::getenv("SAAMGE_AMD_COARSE_DENSE_MAX")) : 8192;
+    H.c_bt = BlockTri();
     if (n && (want == 1 || (want == 0 && (long)n <= dense_max)) && n <= 16384) {
         if (dense_inverse_spd(s, Ac, H.c_L)) H.coarse_kind = 1;
         else H.c_L.release();
+    } else if (n && (want == 1 || want == 3)) {
+        // a DIRECT solve was asked for (the reference's coarse_direct, src/tg.cpp:990-996) on an operator beyond one dense
+        // inverse: block-tridiagonal elimination over a level structure of its graph (blocktri.hip)
+        if (blocktri_factor(s, Ac, H.c_bt)) H.coarse_kind = 3;
     }
 }
 
@@ -1050,6 +1057,11 @@ static void coarse_solve(Hierarchy &H, const double *rc, double *xc) {
         dense_symv(H.stream, n, H.c_L.p, rc, xc, false);
         spmv_residual(H.stream, Ac, xc, rc, H.c_r.p);
         dense_symv(H.stream, n, H.c_L.p, H.c_r.p, xc, true);
+        H.last_coarse_iters = 0;
+        return;
+    }
+    if (H.coarse_kind == 3) {
+        blocktri_solve(H.stream, Ac, H.c_bt, rc, xc);
         H.last_coarse_iters = 0;
         return;
     }

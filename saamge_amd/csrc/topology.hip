@@ -152,6 +152,7 @@ void pool_drop(DevPool &P, F keep) {
 }  // namespace
 
 void set_thread_stream(hipStream_t s) { tl_stream = s; tl_stream_set = true; }
+void unset_thread_stream() { tl_stream = nullptr; tl_stream_set = false; }
 hipStream_t thread_stream() { return tl_stream; }
 bool thread_stream_is_set() { return tl_stream_set; }
 

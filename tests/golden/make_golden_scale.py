@@ -54,6 +54,13 @@ BASE_CASES = {
     "base_aniso128_blk884": (128, (1.0, 1.0, 1000.0), [1e-4, 1e-4], [(8, 8, 4)]),         # config 4, the other configs' coarse blocks
     # ... and with theta_2 = 1e-5 (bench.py --workload aniso128_c884): level-1 agglomerates with eight wanted pairs
     "base_aniso128_c884": (128, (1.0, 1.0, 1000.0), [1e-4, 1e-5], [(8, 8, 4)]),
+    # config 4 in a WELL-POSED form (round 4): K = diag(1,1,1000) times the `skew` coefficient -- no x-y mirror symmetry, hence no
+    # nearly degenerate eigenvalue pairs and no singular value anywhere near the 1e-10 cut: exact agreement is demanded
+    "base_aniso128_skew": (128, (1.0, 1.0, 1000.0), [1e-4, 1e-5], [(4, 4, 2)], "skew"),
+    # config 5's SHAPE at a size the oracle finishes (round 4): Q2 elasticity 32^3 (823 875 dofs), 4x4x4-element agglomerates of
+    # 2 187 dofs, 2x2x2 coarse blocks twice, four levels -- bench.py --workload elasticity_q2 with n = 32.  It reaches the
+    # dictionary-coded smoother, the wide-band few-eigenpairs path in several chunks and the three-level recursion
+    "base_elasticity_q2_32": (32, None, [0.003, 0.003, 0.003], [(2, 2, 2), (2, 2, 2)], "elasticity_q2"),
     # a general operator (no symmetry, every stored entry a different value) at the size of bench.py's cpu_baseline sample;
     # read by tests/test_gpu_scale.py like the scale_* goldens of the Python oracle
     "scale_96x96x64_skew": ((96, 96, 64), (1.0, 1.0, 1.0), [0.003, 0.003], [(8, 8, 4)], "skew"),
@@ -66,7 +73,11 @@ def run_base(name):
     coef = BASE_CASES[name][4] if len(BASE_CASES[name]) > 4 else None
     threads = int(os.environ.get("GOLDEN_THREADS", max(1, min(len(os.sched_getaffinity(0)), 16))))
     t0 = time.perf_counter()
-    prob = pr.poisson3d_device(n, blk=(8, 8, 4), coarse_blk=cblk, K=K, device="cpu", coef=coef)
+    if coef == "elasticity_q2":
+        prob = pr.elasticity3d_q2_device(n, blk=(4, 4, 4), coarse_blk=cblk, device="cpu")
+        K = (1.0, 1.0, 1.0)
+    else:
+        prob = pr.poisson3d_device(n, blk=(8, 8, 4), coarse_blk=cblk, K=K, device="cpu", coef=coef)
     print("%s: problem generated in %.1f s" % (name, time.perf_counter() - t0), flush=True)
     h = cpu_ref.Hierarchy(prob, num_coarsenings=len(thetas), theta=thetas, nu_relax=3, threads=threads, lean=True)
     b = prob.b.numpy()
@@ -77,7 +88,7 @@ def run_base(name):
     out = {"dims": np.array(n if isinstance(n, tuple) else (n,) * 3, dtype=np.int32), "K": np.array(K), "thetas": np.array(thetas),
            "theta": np.array(thetas[:1]),
            "coarse_blk": np.array(cblk, dtype=np.int32).reshape(-1, 3),
-           "level_dims": np.array(h.level_dims(), dtype=np.int64),
+           "level_dims": np.array(h.level_dims(), dtype=np.int64), "coef": np.array(coef or ""),
            "pcg_iters": np.array([it], dtype=np.int32), "pcg_hist": np.array(hist), "converged": np.array([conv]),
            "x_norm": np.array([np.linalg.norm(x)]),
            "relres": np.array([np.linalg.norm(b - A @ x) / np.linalg.norm(b)])}
@@ -90,6 +101,7 @@ def run_base(name):
         out["l%d_sv_min_kept" % l] = kept
         out["l%d_sv_max_dropped" % l] = dropped
         out["l%d_Ac_trace" % l] = np.array([h.Ac_trace(l)])
+        out["l%d_Ac_fro" % l] = np.array([h.Ac_fro(l)])
         near.append(int(np.sum((kept < 1e-9) | (dropped > 1e-11))))
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print("%s: dims %s, %d its (converged %s), setup %.1f s, solve %.1f s on %d threads, MISes with a singular value within "

@@ -1,8 +1,10 @@
 #!/bin/bash
 # Collects the round's evidence on the GPU box into gpurun_out/<tag>/ (summaries are copied to profiles/ afterwards).
 #   bash tools/collect_profiles.sh r03 [part ...]      parts: stats pmc sq timing bench workloads (default: all but workloads)
-# Every rocprofv3 pass runs under a timeout: with counters the profiler aborts at the library's hipGraph capture or at
-# process exit ("stream_stack.cpp: Check failed") AFTER it has written its files and then hangs in its signal handler.
+# Every rocprofv3 pass runs under a timeout as a GUARD only.  Until round 3 counter passes aborted at process exit
+# ("stream_stack.cpp: Check failed", then a hang in the signal handler): the library's static buffers were destroyed
+# after main() and called hipEventRecord into a runtime that was already torn down.  Round 4: no static object of the
+# library owns device memory through a destructor any more (csrc/eig.hip arena(), assemble.hip, hierarchy.hip).
 set -o pipefail
 export TMPDIR=/tmp
 R=$PWD

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic of the dictionary-coded smoother kernel (Q2 elasticity 48^3, two levels): FETCH_SIZE and WRITE_SIZE in
-# separate passes, each under a timeout (the profiler hangs at process exit with counters: its files are written by then).
+# separate passes, each under a timeout (a guard only: the exit-time abort of rounds 1-3 was the library's own static destructors calling HIP, fixed in round 4).
 #   bash tools/pmc_q2.sh <outdir-under-gpurun_out>
 export TMPDIR=/tmp SAAMGE_AMD_SERIAL=1
 R=$PWD; O=$R/gpurun_out/$1
