@@ -168,18 +168,59 @@ def gpu_check_on_sample(capi, n_sample, levels, dev, theta, cpu):
     return res
 
 
-def pmc_traffic(label, rows):
+PMC_TRAFFIC_FILE = "profiles/r04_pmc_traffic.json"
+
+
+def pmc_traffic(label, rows, fmt):
     """Per-launch HBM bytes of the kernel behind profiler label `label` on an operator of `rows` rows, from the committed
-    PMC passes (profiles/r03_pmc_traffic.json: {"<label>@<rows>": {"fetch_bytes_raw": .., "write_bytes": .., "launches": ..}})."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    PMC passes (PMC_TRAFFIC_FILE: {"<label>@<rows>": {"fetch_bytes_raw": .., "write_bytes": .., "launches": .., "format":
+    {...}}}).  Only when the operator's FORMAT CENSUS (slices per format, staged tiles, dictionary pairs: the library's
+    level_format) equals the one the passes were taken on -- the same number of rows in another format runs another kernel
+    over other bytes (--coef skew, other theta / block settings): then None."""
     try:
-        d = json.load(open(path))
+        d = json.load(open(os.path.join(ROOT, PMC_TRAFFIC_FILE)))
     except Exception:
         return None
     k = d.get("%s@%d" % (label, rows))
-    if not k or not k.get("launches"):
+    if not k or not k.get("launches") or fmt is None:
+        return None
+    want = k.get("format")
+    have = {"slices": fmt["slices"], "staged_tiles": fmt["staged_tiles"], "dictionary_pairs": fmt["dictionary_pairs"]}
+    if want != have:
         return None
     return (2.0 * k["fetch_bytes_raw"] + k["write_bytes"]) / k["launches"]
+
+
+def side_workload(capi, name, dev, coarse_solver=None, steps=2):
+    """One more BASELINE config as a short leg OUTSIDE the timed region (one warm-up step, `steps` timed ones)."""
+    import torch
+    w = WORKLOADS[name]
+    levels = w["levels"]
+    cb = tuple(int(v) for v in w.get("coarse_blk", "8,8,4").split(","))
+    prob = build_problem(w["n"], levels, dev, w["aniso"], (8, 8, 4), cb)
+    params = capi.default_params(num_coarsenings=levels - 1, theta=w["theta"], nu_relax=3, coarse_solver=coarse_solver)
+    if w["theta2"] is not None:
+        for l in range(1, capi.MAX_LEVELS):
+            params.theta[l] = w["theta2"]
+    torch.cuda.synchronize()
+    h, x, its, conv, _ = one_step(capi, prob, params)
+    h.close()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        h, x, its, conv, _ = one_step(capi, prob, params)
+        if i < steps - 1:
+            h.close()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    infos = [h.level_info(l) for l in range(levels - 1)]
+    out = {"ms_per_step": 1e3 * dt, "value": prob.n / dt, "unit": "DoF/s", "steps": steps, "dofs": prob.n,
+           "pcg_iterations": its, "converged": bool(conv), "level_dims": [i["n"] for i in infos] + [infos[-1]["ncoarse"]],
+           "eigenvectors_per_AE": [round(i["nvec"] / max(i["nparts"], 1), 2) for i in infos]}
+    h.close()
+    del prob, x
+    torch.cuda.empty_cache()
+    return out
 
 
 def spawn_ranks(n, argv, script=None):
@@ -254,6 +295,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-general", action="store_true", help="skip the general-coefficient leg of the default workload")
+    ap.add_argument("--no-others", action="store_true", help="skip the BASELINE config 2 / config 4 legs of the default workload")
+    ap.add_argument("--coarse-solver", default="auto", choices=["auto", "direct", "pcg", "blocktri"],
+                    help="coarsest solve: auto (dense inverse up to 8192 rows, inner PCG beyond), direct (the reference's "
+                         "coarse_direct: dense inverse / block-tridiagonal elimination), pcg, blocktri")
     ap.add_argument("--coef", default=None, choices=["skew"], help="Poisson workloads: variable coefficient instead of the constant one "
                     "(the timed workload itself becomes the general-coefficient problem; used to profile it)")
     args = ap.parse_args()
@@ -299,7 +344,8 @@ def main():
     torch.cuda.empty_cache()        # the generator's temporaries go back to the device before the library allocates
     params = capi.default_params(num_coarsenings=args.levels - 1, theta=args.theta, nu_relax=3, nu_pro=args.nu_pro,
                                  eigensolver=args.eigensolver,
-                                 correct_nullspace=args.correct_nullspace)
+                                 correct_nullspace=args.correct_nullspace,
+                                 coarse_solver={"auto": None, "direct": 1, "pcg": 2, "blocktri": 3}[args.coarse_solver])
     if args.theta2 is not None:      # first_theta / theta of the reference's MultilevelParameters (inc/ml.hpp:66-70)
         for l in range(1, capi.MAX_LEVELS):
             params.theta[l] = args.theta2
@@ -394,13 +440,15 @@ def main():
         label, _, rows = d["name"].partition("@")
         symbol, bound = KERNELS.get(label, (label, "hbm"))
         avg_ms = d["ms"] / d["launches"]
-        traffic = pmc_traffic(label, int(rows)) if rows else None
+        lev_of = [l for l, i in enumerate(infos) if rows and i["n"] == int(rows)]
+        traffic = pmc_traffic(label, int(rows), h_formats[lev_of[0]] if lev_of and lev_of[0] < len(h_formats) else None) if rows else None
         if bound == "hbm":
             ach = d["fmt_bytes"] / d["ms"] / 1e6
             res["roofline"] = {"kernel": symbol, "profiler_label": d["name"], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                               "traffic_source": ("profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
-                                                  "this kernel at this size, committed; not collected in this run)") if traffic else None,
+                               "traffic_source": (PMC_TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel "
+                                                  "on an operator of this size AND format census, committed; not collected in this "
+                                                  "run)") if traffic else None,
                                "format_bytes_per_launch": d["fmt_bytes"] / d["launches"],
                                "csr_model_bytes_per_launch": d["bytes"] / d["launches"],
                                "csr_model_GBps": d["bytes"] / d["ms"] / 1e6,
@@ -453,6 +501,23 @@ def main():
         hg.close()
         del gprob, xg
         torch.cuda.empty_cache()
+    if (rank == 0 and world == 1 and not args.no_others and args.workload == "poisson256" and args.n == 256 and args.aniso == 1.0
+            and args.coef is None and args.nu_pro == 0 and not args.correct_nullspace):
+        # BASELINE configs 2 and 4 in the driver's line (outside the timed region; config 5 fills the card and takes ~10 s per
+        # step: it stays a separate run, `--workload elasticity_q2`, profiles/r04_bench_elasticity_q2.json)
+        try:
+            del prob
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        res["config"]["other_workloads"] = {
+            "poisson128": dict(side_workload(capi, "poisson128", dev), config="BASELINE config 2: 3D Poisson 128^3 Q1, theta=0.003, 2-level; "
+                               "coarsest solve: inner PCG (the default beyond 8192 rows)"),
+            "poisson128_coarse_direct": dict(side_workload(capi, "poisson128", dev, coarse_solver=1), config="the same with the reference's "
+                                             "coarse_direct: block-tridiagonal elimination of the 67 975-row coarsest operator (csrc/blocktri.hip)"),
+            "aniso128": dict(side_workload(capi, "aniso128", dev), config="BASELINE config 4: K=diag(1,1,1000) 128^3, theta=1e-4 / 1e-5, "
+                             "3-level, 4x4x2-AE coarse blocks"),
+            "elasticity_q2": "not run here (BASELINE config 5 fills the card, ~10 s per step): python bench.py --workload elasticity_q2"}
     if rank == 0 and not args.no_cpu_baseline and args.workload != "poisson256":
         log("bench.py: cpu_baseline is timed on the default workload only (poisson256)")
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "poisson256" and args.blk == "8,8,4" and args.coef is None:

@@ -28,6 +28,35 @@ extern "C" {
 
 typedef struct saamge_amd_hierarchy saamge_amd_hierarchy; /* == ml_data_t, inc/ml.hpp:118-120 */
 
+/* Options of the library's own machinery (no counterpart in the reference): what is left of the environment switches of
+ * rounds 1-3.  The variants that were measured without gain are gone; these remain because tests need them to reach a code
+ * path or because a caller may want them.  PROCESS-WIDE: saamge_amd_set_options() sets them, and every
+ * saamge_amd_ml_produce_data* call sets them from params->options before it builds (the last hierarchy built wins; do not
+ * build hierarchies with different options concurrently).  Environment variables that remain: SAAMGE_AMD_TIMING (phase
+ * times on stderr), SAAMGE_AMD_SERIAL (no worker threads in the setup: counter passes), SAAMGE_AMD_POOL_MAX_GB (device
+ * block cache, default 64), SAAMGE_AMD_THREADS (host threads of the host topology builds). */
+typedef struct saamge_amd_options {
+    int eig_strict;               /* 0.  1: a fallback of the few-eigenpairs path to the dense path is an ERROR */
+    int eig_certify;              /* 1.  0: no inertia certificate (residual bounds only): kept to show what the certificate is for */
+    int eig_min_n;                /* 64: smallest agglomerate of a batch that takes the few-eigenpairs path */
+    int eig_force_fallback;       /* 0.  k > 0: every k-th matrix of a batch takes the per-matrix dense fallback (tests) */
+    int eig_dense_only;           /* 0.  1: saamge_amd_lower_eigens_batched uses the dense path (a hierarchy: params.eigensolver) */
+    int eig_dense_one_stage;      /* 0.  1: dense path by the one-stage blocked Householder reduction instead of the two-stage one */
+    int eig_nullcheck;            /* 1: agglomerates whose one wanted pair is the known null vector skip the iteration */
+    int eig_keep_inertia_factor;  /* 1: wide-band matrices with certified count 0 keep the factor of the inertia pass */
+    int band_assembly;            /* 1: coarse-level agglomerate matrices are assembled, summed and scaled inside their band */
+    int overlap;                  /* 7: bit 0 subspace iteration of a chunk beside the next chunk's assembly, bit 1 halo exchange
+                                   * beside the interior rows, bit 2 Galerkin product beside the next level's eigenproblems */
+    int sell;                     /* 31: SELL slice formats: bit 0 coded slices at all, bit 1 pair coding (values in the table),
+                                   * bit 2 the short-chain kernel path, bit 3 operator-level dictionary, bit 4 3 x 3 node blocks */
+    int spmv_sell;                /* 0.  1: saamge_amd_spmv / spmv64 build and use the SELL copy (tests of the SELL kernels) */
+    int debug;                    /* 0: bit 0 iteration traces of the few-eigenpairs path, bit 1 operator format census on stderr,
+                                   * bit 2 level tags in the kernel profile */
+} saamge_amd_options;
+void saamge_amd_options_default(saamge_amd_options *o);
+void saamge_amd_set_options(const saamge_amd_options *o);
+void saamge_amd_get_options(saamge_amd_options *o);
+
 /* == MultilevelParameters, inc/ml.hpp:59-114 (+ the hidden defaults of src/ml.cpp:64-67) */
 typedef struct saamge_amd_params {
     int num_coarsenings;                      /* levels - 1 */
@@ -112,6 +141,7 @@ typedef struct saamge_amd_params {
      * history to 3 digits of its 6e-8 deviation from the oracle's -- that deviation comes from the singular vectors of the
      * smallest kept singular values, not from the eigenvectors.  Allowed: 1e-15 ... 1e-8. */
     double eig_tol;
+    saamge_amd_options options;               /* applied process-wide by saamge_amd_ml_produce_data* (see saamge_amd_options) */
 } saamge_amd_params;
 
 void saamge_amd_params_default(saamge_amd_params *p);
@@ -162,6 +192,38 @@ int saamge_amd_ml_produce_data64(int n, const long long *rowptr, const int *col,
                                  const signed char *bdr_dofs, const int *const *partitions,
                                  const int *nparts, const saamge_amd_params *params, void *stream,
                                  saamge_amd_hierarchy **out);
+/* ml_produce_data from PER-RANK inputs (one process per GPU; params->rank / world and the collectives set): what the
+ * reference's multi-rank drivers pass (pmltest, amg/CMakeLists.txt:198-203; test/mltest/mltest.cpp:619-745):
+ *   A            this rank's row block as a HypreParMatrix holds it -- hypre's ParCSR split (hypre_ParCSRMatrix: `diag` =
+ *                the columns of the rank's own range with LOCAL indices, `offd` = the others, compressed, col_map_offd[c] =
+ *                global column of offd column c; inc/SharedEntityCommunication.hpp:74-245 works on the same split).  Row
+ *                blocks are contiguous and ordered by rank (row_starts, world + 1 entries, may be NULL); entries of a row
+ *                may come in any order.
+ *   elem_to_dof  NE_local x nde, GLOBAL (true) dof ids -- the reference's local dofs mapped through Dof_TrueDof;
+ *   elmat        the matrices of the rank's OWN elements: they stay on this rank and are never exchanged;
+ *   bdr_dofs     flags of the rank's own rows (A->nrows of them; may be NULL);
+ *   partitions   partitions[0][e] = local agglomerate (0 .. nparts_local[0] - 1) of local element e; partitions[k], k > 0,
+ *                maps the rank's level-(k-1) agglomerates to its level-k agglomerates: no agglomerate straddles ranks
+ *                (the reference's invariant, src/aggregates.cpp:1340-1443).
+ * Global numbering = rank order (rank 0's elements / agglomerates first).  The hierarchy is identical to the one
+ * saamge_amd_ml_produce_data builds from the assembled global problem.  A rank assembles, factors and coarsens the
+ * agglomerates made of its own elements; round 4: the operator's rows and the integer topology are all-gathered inside
+ * (DESIGN.md section 6 lists what is replicated), the element matrices are not.  Host or device pointers. */
+typedef struct saamge_amd_parcsr {
+    long long global_rows;              /* 0 = the sum of the ranks' rows */
+    const long long *row_starts;        /* world + 1 entries, or NULL */
+    int nrows;                          /* rows of this rank */
+    const int *diag_i, *diag_j;         /* nrows x nrows */
+    const double *diag_a;
+    const int *offd_i, *offd_j;         /* nrows x num_cols_offd; offd_i may be NULL when num_cols_offd == 0 */
+    const double *offd_a;
+    int num_cols_offd;
+    const long long *col_map_offd;
+} saamge_amd_parcsr;
+int saamge_amd_ml_produce_data_parcsr(const saamge_amd_parcsr *A, int NE_local, int nde, const int *elem_to_dof,
+                                      const double *elmat, const signed char *bdr_dofs, const int *const *partitions,
+                                      const int *nparts_local, const saamge_amd_params *params, void *stream,
+                                      saamge_amd_hierarchy **out);
 /* adapt_update_operators(A, ml_data, mlp, resmooth_interp = true), src/adapt.cpp:188-219: the
  * matrix values changed (same sparsity and topology): every interpolation is kept -- no local
  * eigenproblem is solved again --, smoother diagonals, smoothed prolongators (nu_pro > 0), all
@@ -270,6 +332,9 @@ int saamge_amd_inertia_batched(int count, const int *n, const double *A, const d
  * Environment: SAAMGE_AMD_POOL_MAX_GB (default 64; 0 disables the cache). */
 void saamge_amd_release_cached_memory(void);
 long long saamge_amd_cached_memory_bytes(void);
+/* device bytes the library holds right now (hierarchies, workspace in use; the caller's own arrays and the idle cache
+ * are not counted) and their high-water mark since the last call with reset_peak != 0 */
+void saamge_amd_memory_stats(long long *live_bytes, long long *peak_bytes, int reset_peak);
 
 /* ---- per-kernel timing for bench.py's roofline leg (HIP events around every launch) ---- */
 void saamge_amd_profile_enable(int on);

@@ -20,9 +20,13 @@
 // agg_create_partitioning_fine (partitioning, elem_to_dof, flags) and the tables are fetched from the
 // hierarchy on request (agg_fetch_tables).  Coarse partitions (METIS in the reference,
 // src/part.cpp:170-183 -- third party) come from a hook, ml_set_coarse_partitioner(); the default cuts
-// the coarse elements into contiguous index ranges.  One MPI rank per GPU: the HypreParMatrix must be
-// the rank's whole matrix (serial hypre layout); multi-GPU runs go through the C ABI's rank / world
-// parameters.
+// the coarse elements into contiguous index ranges.  One MPI rank per GPU.  A HypreParMatrix that is DISTRIBUTED
+// over several ranks is taken as it is (round 4): ml_produce_data hands the rank's diag / offd / col_map_offd blocks, the
+// rank's own elements (local dofs mapped to true dofs through agg_part_rels' Dof_TrueDof) and its own partition to
+// saamge_amd_ml_produce_data_parcsr, with MPI-backed collectives (detail::MpiCollectives: staged through host memory,
+// the plug for MPI host codes; a driver that owns an RCCL communicator installs saamge_amd_params_set_comm through
+// MultilevelParameters::p instead).  Vectors at this boundary are the rank's true-dof blocks, like HypreParVectors; the
+// host copies of P / R / Ac (tg_data_t::interp, restr, Ac) are not made for a distributed hierarchy.
 #ifndef SAAMGE_AMD_MFEM_HPP
 #define SAAMGE_AMD_MFEM_HPP
 
@@ -55,6 +59,7 @@ struct agg_partitioning_relations_t {
     bool testmesh = false;
     bool do_aggregates = false;
     int NE = 0;
+    mfem::HypreParMatrix *Dof_TrueDof = nullptr;      // not owned (the caller's fes.Dof_TrueDof_Matrix(), src/aggregates.cpp:1347)
 };
 
 // agg_create_partitioning_fine (inc/aggregates.hpp:385-390, src/aggregates.cpp:1316-1355): takes ownership
@@ -65,9 +70,10 @@ inline agg_partitioning_relations_t *agg_create_partitioning_fine(
     const agg_dof_status_t *bdr_dofs, int *nparts, mfem::HypreParMatrix *dof_truedof, bool do_aggregates,
     bool testmesh = false) {
     if (!partitioning) mfem::mfem_error("agg_create_partitioning_fine: a partitioning array is required (METIS is not part of this library)");
-    (void)dof_truedof;
     agg_partitioning_relations_t *r = new agg_partitioning_relations_t;
-    r->ND = A.Height();
+    r->Dof_TrueDof = dof_truedof;
+    // ND = LOCAL dofs (shared copies included): the rows of Dof_TrueDof; on one rank the matrix's own rows
+    r->ND = dof_truedof ? dof_truedof->Height() : A.Height();
     r->NE = NE;
     r->nparts = *nparts;
     r->partitioning = partitioning;
@@ -138,6 +144,7 @@ inline void smpr_sym_poly(mfem::HypreParMatrix &A, const mfem::Vector &b, mfem::
     if (saamge_amd_smoother(d->h, d->level, b.GetData(), x.GetData())) mfem::mfem_error(saamge_amd_last_error());
 }
 
+namespace detail { struct DistLayout; }
 struct interp_data_t;       // (opaque here: the per-AE eigenpairs live on the GPU; saamge_amd_get_ae_eigens exports them)
 
 // == tg_data_t (inc/tg_data.hpp:47-83).  Ac / interp / restr are host copies for inspection; the GPU owns the
@@ -169,6 +176,9 @@ struct tg_data_t {
     bool init_use_arpack = false;
     mfem::SparseMatrix *Ac_diag = nullptr, *interp_diag = nullptr, *restr_diag = nullptr;
     HYPRE_Int row_starts[2][2];
+    // a hierarchy built from a DISTRIBUTED HypreParMatrix: the ranks' row blocks (vectors at this boundary are the rank's
+    // true-dof block) and the MPI collectives the library calls back into; owned by the finest level's tg_data
+    detail::DistLayout *dist = nullptr;
 };
 
 // == levels (inc/levels.hpp:47-64)
@@ -214,6 +224,84 @@ inline ml_partitioner_t &ml_fine_partitioner() {
 inline void ml_set_fine_partitioner(const ml_partitioner_t &p) { ml_fine_partitioner() = p; }
 
 namespace detail {
+
+// ---- MPI-backed collectives for the C ABI's callback plug (staged through host memory) --------------------------
+struct MpiCollectives {
+    MPI_Comm comm;
+    int rank, world;
+    std::vector<char> sbuf, rbuf;
+    explicit MpiCollectives(MPI_Comm c) : comm(c), rank(0), world(1) {
+        MPI_Comm_rank(c, &rank);
+        MPI_Comm_size(c, &world);
+    }
+    static int allgather(void *ctx, void *buf, const long long *off) {           // in place, rank r owns bytes [off[r], off[r+1])
+        MpiCollectives &m = *(MpiCollectives *)ctx;
+        const long long total = off[m.world], lo = off[m.rank], hi = off[m.rank + 1];
+        m.sbuf.resize((size_t)(hi - lo));
+        m.rbuf.resize((size_t)total);
+        if (saamge_amd_memcpy(m.sbuf.data(), (const char *)buf + lo, hi - lo)) return 1;
+        std::vector<int> cnt((size_t)m.world), dsp((size_t)m.world);
+        for (int r = 0; r < m.world; ++r) { cnt[(size_t)r] = (int)(off[r + 1] - off[r]); dsp[(size_t)r] = (int)off[r]; }
+        if (total >= (1ll << 31)) return 2;      // (one MPI call: split larger gathers on the caller's side)
+        if (MPI_Allgatherv(m.sbuf.data(), (int)(hi - lo), MPI_BYTE, m.rbuf.data(), cnt.data(), dsp.data(), MPI_BYTE, m.comm)) return 3;
+        if (lo > 0 && saamge_amd_memcpy(buf, m.rbuf.data(), lo)) return 1;
+        if (total > hi && saamge_amd_memcpy((char *)buf + hi, m.rbuf.data() + hi, total - hi)) return 1;
+        return 0;
+    }
+    static int allreduce(void *ctx, double *buf, long long count) {
+        MpiCollectives &m = *(MpiCollectives *)ctx;
+        std::vector<double> h((size_t)count), out((size_t)count);
+        if (saamge_amd_memcpy(h.data(), buf, 8 * count)) return 1;
+        if (MPI_Allreduce(h.data(), out.data(), (int)count, MPI_DOUBLE, MPI_SUM, m.comm)) return 3;
+        return saamge_amd_memcpy(buf, out.data(), 8 * count);
+    }
+    static int alltoallv(void *ctx, const void *send, const long long *soff, void *recv, const long long *roff) {
+        MpiCollectives &m = *(MpiCollectives *)ctx;
+        m.sbuf.resize((size_t)soff[m.world]);
+        m.rbuf.resize((size_t)roff[m.world]);
+        if (soff[m.world] && saamge_amd_memcpy(m.sbuf.data(), send, soff[m.world])) return 1;
+        std::vector<int> sc((size_t)m.world), sd((size_t)m.world), rc((size_t)m.world), rd((size_t)m.world);
+        for (int r = 0; r < m.world; ++r) {
+            sc[(size_t)r] = (int)(soff[r + 1] - soff[r]); sd[(size_t)r] = (int)soff[r];
+            rc[(size_t)r] = (int)(roff[r + 1] - roff[r]); rd[(size_t)r] = (int)roff[r];
+        }
+        if (MPI_Alltoallv(m.sbuf.data(), sc.data(), sd.data(), MPI_BYTE, m.rbuf.data(), rc.data(), rd.data(), MPI_BYTE, m.comm)) return 3;
+        if (roff[m.world] && saamge_amd_memcpy(recv, m.rbuf.data(), roff[m.world])) return 1;
+        return 0;
+    }
+};
+// what a distributed hierarchy needs at the vector boundary: the ranks' row blocks of the global numbering
+struct DistLayout {
+    MpiCollectives *coll = nullptr;           // owned
+    std::vector<int> row_count, row_first;    // per rank
+    int nloc = 0, nglob = 0;
+    ~DistLayout() { delete coll; }
+    // the rank's block b -> the global vector g (every rank gets all of it)
+    void gather(const double *b, std::vector<double> &g) const {
+        g.resize((size_t)nglob);
+        MPI_Allgatherv(const_cast<double *>(b), nloc, MPI_DOUBLE, g.data(), const_cast<int *>(row_count.data()),
+                       const_cast<int *>(row_first.data()), MPI_DOUBLE, coll->comm);
+    }
+};
+inline bool is_distributed(const mfem::HypreParMatrix &A) {
+    return A.GetGlobalNumRows() != A.Height() || A.GetGlobalNumCols() != A.Width();
+}
+// local dof -> global true dof through Dof_TrueDof (one entry per row: in diag for a dof this rank owns, in offd otherwise)
+inline void local_to_true(const mfem::HypreParMatrix &D, std::vector<int> &gdof, std::vector<char> &owned) {
+    mfem::SparseMatrix diag, offd;
+    HYPRE_Int *cmap = nullptr;
+    D.GetDiag(diag);
+    D.GetOffd(offd, cmap);
+    const int nl = diag.Height();
+    const HYPRE_Int first = D.ColPart()[0];
+    gdof.assign((size_t)nl, -1);
+    owned.assign((size_t)nl, 0);
+    for (int i = 0; i < nl; ++i) {
+        if (diag.GetI()[i + 1] > diag.GetI()[i]) { gdof[(size_t)i] = (int)(first + diag.GetJ()[diag.GetI()[i]]); owned[(size_t)i] = 1; }
+        else if (offd.GetI()[i + 1] > offd.GetI()[i]) gdof[(size_t)i] = (int)cmap[offd.GetJ()[offd.GetI()[i]]];
+        else mfem::mfem_error("saamge_amd: a local dof without a true dof in Dof_TrueDof");
+    }
+}
 
 struct HostCsr {
     std::vector<int> I, J;
@@ -319,7 +407,11 @@ inline ml_data_t *ml_produce_data(mfem::HypreParMatrix &Ag, agg_partitioning_rel
                                   ElementMatrixProvider *elem_data_finest, const MultilevelParameters &mlp) {
     const int nco = mlp.get_num_coarsenings();
     agg_partitioning_relations_t &r = *agg_part_rels;
-    detail::HostCsr A = detail::csr_of(Ag);
+    const bool distributed = detail::is_distributed(Ag);
+    if (distributed && !r.Dof_TrueDof)
+        mfem::mfem_error("ml_produce_data: a distributed HypreParMatrix needs agg_create_partitioning_fine's dof_truedof argument");
+    detail::HostCsr A;
+    if (!distributed) A = detail::csr_of(Ag);
     const int n = Ag.Height(), NE = r.NE;
     // element matrices, raw (row-major nde x nde per element); uniform element size required by the batched assembly
     const int nde = r.elem_to_dof->RowSize(0);
@@ -364,16 +456,68 @@ inline ml_data_t *ml_produce_data(mfem::HypreParMatrix &Ag, agg_partitioning_rel
     }
     for (size_t i = 0; i < owned.size(); ++i) delete owned[i];
     for (int k = 0; k < nco; ++k) part_ptrs[(size_t)k] = parts[(size_t)k].data();
-    std::vector<signed char> bdr((size_t)n);
-    for (int i = 0; i < n; ++i) bdr[(size_t)i] = (signed char)r.agg_flags[i];
     saamge_amd_params p = mlp.p;
     p.testmesh = r.testmesh ? 1 : 0;
     std::vector<int> nparts((size_t)nco);
     for (int k = 0; k < nco; ++k) nparts[(size_t)k] = mlp.get_nparts(k);
     saamge_amd_hierarchy *h = nullptr;
-    if (saamge_amd_ml_produce_data(n, A.I.data(), A.J.data(), A.V.data(), NE, nde, r.elem_to_dof->GetJ(), elmat.data(),
-                                   bdr.data(), part_ptrs.data(), nparts.data(), &p, nullptr, &h))
-        mfem::mfem_error(saamge_amd_last_error());
+    detail::DistLayout *layout = nullptr;
+    if (!distributed) {
+        std::vector<signed char> bdr((size_t)n);
+        for (int i = 0; i < n; ++i) bdr[(size_t)i] = (signed char)r.agg_flags[i];
+        if (saamge_amd_ml_produce_data(n, A.I.data(), A.J.data(), A.V.data(), NE, nde, r.elem_to_dof->GetJ(), elmat.data(),
+                                       bdr.data(), part_ptrs.data(), nparts.data(), &p, nullptr, &h))
+            mfem::mfem_error(saamge_amd_last_error());
+    } else {
+        // per-rank inputs (saamge_amd_ml_produce_data_parcsr): the rank's row block in hypre's own split, its elements with
+        // local dofs mapped to true dofs, the flags of the rows it owns, its own partitions (local agglomerate ids)
+        layout = new detail::DistLayout;
+        layout->coll = new detail::MpiCollectives(Ag.GetComm());
+        const int world = layout->coll->world, rank = layout->coll->rank;
+        mfem::SparseMatrix diag, offd;
+        HYPRE_Int *cmap = nullptr;
+        Ag.GetDiag(diag);
+        Ag.GetOffd(offd, cmap);
+        std::vector<long long> cmap64((size_t)std::max(offd.Width(), 1), 0);
+        for (int c = 0; c < offd.Width(); ++c) cmap64[(size_t)c] = (long long)cmap[c];
+        std::vector<int> gdof;
+        std::vector<char> owned;
+        detail::local_to_true(*r.Dof_TrueDof, gdof, owned);
+        if ((int)gdof.size() != r.ND) mfem::mfem_error("ml_produce_data: Dof_TrueDof does not match the local dofs of agg_part_rels");
+        std::vector<int> e2d_glob((size_t)NE * nde);
+        const int *J = r.elem_to_dof->GetJ();
+        for (size_t q = 0; q < e2d_glob.size(); ++q) e2d_glob[q] = gdof[(size_t)J[q]];
+        const HYPRE_Int first_row = Ag.RowPart()[0];
+        std::vector<signed char> bdr_own((size_t)n, (signed char)AGG_OWNED_FLAG);
+        for (int i = 0; i < r.ND; ++i)
+            if (owned[(size_t)i]) bdr_own[(size_t)(gdof[(size_t)i] - first_row)] = (signed char)r.agg_flags[i];
+        layout->nloc = n;
+        layout->row_count.assign((size_t)world, 0);
+        layout->row_first.assign((size_t)world, 0);
+        MPI_Allgather(const_cast<int *>(&n), 1, MPI_INT, layout->row_count.data(), 1, MPI_INT, layout->coll->comm);
+        for (int q = 1; q < world; ++q) layout->row_first[(size_t)q] = layout->row_first[(size_t)q - 1] + layout->row_count[(size_t)q - 1];
+        layout->nglob = layout->row_first[(size_t)world - 1] + layout->row_count[(size_t)world - 1];
+        if (!p.allgather) {          // (a driver that installed a communicator of its own keeps it)
+            p.rank = rank;
+            p.world = world;
+            p.allgather = detail::MpiCollectives::allgather;
+            p.allreduce_sum = detail::MpiCollectives::allreduce;
+            p.alltoallv = detail::MpiCollectives::alltoallv;
+            p.allgather_ctx = layout->coll;
+            p.comm_stream_ordered = 0;
+        }
+        saamge_amd_parcsr P;
+        P.global_rows = (long long)Ag.GetGlobalNumRows();
+        P.row_starts = nullptr;
+        P.nrows = n;
+        P.diag_i = diag.GetI(); P.diag_j = diag.GetJ(); P.diag_a = diag.GetData();
+        P.offd_i = offd.GetI(); P.offd_j = offd.GetJ(); P.offd_a = offd.GetData();
+        P.num_cols_offd = offd.Width();
+        P.col_map_offd = cmap64.data();
+        if (saamge_amd_ml_produce_data_parcsr(&P, NE, nde, e2d_glob.data(), elmat.data(), bdr_own.data(), part_ptrs.data(),
+                                              nparts.data(), &p, nullptr, &h))
+            mfem::mfem_error(saamge_amd_last_error());
+    }
     // the list of levels (ml_produce_hierarchy_from_level, src/ml.cpp:111-236)
     ml_data_t *ml = new ml_data_t;
     levels_level_t *prev = nullptr;
@@ -390,7 +534,8 @@ inline ml_data_t *ml_produce_data(mfem::HypreParMatrix &Ag, agg_partitioning_rel
         tg->poly_data->h = h;
         tg->poly_data->level = k;
         tg->elem_data = (k == 0) ? elem_data_finest : nullptr;
-        detail::fetch_operators(*tg, Ag.GetComm());
+        if (k == 0) tg->dist = layout;
+        if (!distributed) detail::fetch_operators(*tg, Ag.GetComm());     // (host copies of P / R / Ac: single-rank hierarchies only)
         lv->tg_data = tg;
         lv->agg_part_rels = (k == 0) ? agg_part_rels : nullptr;
         lv->finer = prev;
@@ -409,6 +554,7 @@ inline void tg_free_data(tg_data_t *tg) {           // inc/tg.hpp:576, src/tg.cp
     delete tg->poly_data;
     delete tg->elem_data;
     if (tg->owns_h) saamge_amd_ml_free_data(tg->h);
+    delete tg->dist;          // (after the hierarchy: its collectives are the hierarchy's callbacks)
     delete tg;
 }
 inline void ml_free_data(ml_data_t *ml) {           // inc/ml.hpp:196
@@ -579,7 +725,8 @@ inline void ml_get_dims(const ml_data_t &ml, mfem::Array<int> &dims) {      // i
 class VCycleSolver : public mfem::Solver {
 public:
     VCycleSolver(tg_data_t *tg_data_in, bool iterative_mode_)
-        : mfem::Solver(tg_data_in->restr->Width(), iterative_mode_), tg_data(tg_data_in), A(NULL), plugged(NULL) {
+        : mfem::Solver(tg_data_in->dist ? tg_data_in->dist->nloc : tg_data_in->restr->Width(), iterative_mode_), tg_data(tg_data_in),
+          A(NULL), plugged(NULL) {
         if (tg_data->level != 0) mfem::mfem_error("VCycleSolver: only the finest level's tg_data can be cycled from outside");
         for (tg_data_t *t = tg_data; t; t = t->coarser_tg) {
             detail::SmootherPlug pl = {t, NULL};
@@ -614,12 +761,32 @@ public:
                                         (void *)&plugs[k]))
                 mfem::mfem_error(saamge_amd_last_error());
         }
+        if (tg_data->dist) {
+            // distributed: b and x are the rank's true-dof blocks (HypreParVector data); the library's vectors are global
+            const detail::DistLayout &d = *tg_data->dist;
+            std::vector<double> bg, xg((size_t)d.nglob, 0.0);
+            d.gather(b.GetData(), bg);
+            if (iterative_mode) d.gather(x.GetData(), xg);
+            if (saamge_amd_vcycle(tg_data->h, bg.data(), xg.data(), iterative_mode ? 1 : 0)) mfem::mfem_error(saamge_amd_last_error());
+            std::copy(xg.begin() + d.row_first[(size_t)d.coll->rank], xg.begin() + d.row_first[(size_t)d.coll->rank] + d.nloc, x.GetData());
+            return;
+        }
         if (saamge_amd_vcycle(tg_data->h, b.GetData(), x.GetData(), iterative_mode ? 1 : 0)) mfem::mfem_error(saamge_amd_last_error());
     }
     // the PCG loop of kalchev_pcg on the GPU with this cycle as the preconditioner
     int pcg(const double *b, double *x, int print_iter, int max_num_iter, double RTOLERANCE, double ATOLERANCE,
             bool zero_rhs) const {
         try {
+            if (tg_data->dist) {
+                const detail::DistLayout &d = *tg_data->dist;
+                std::vector<double> bg, xg;
+                d.gather(b, bg);
+                d.gather(x, xg);
+                const int it = saamge_amd::api::kalchev_pcg(tg_data->h, bg.data(), xg.data(), print_iter, max_num_iter, RTOLERANCE,
+                                                            ATOLERANCE, zero_rhs);
+                std::copy(xg.begin() + d.row_first[(size_t)d.coll->rank], xg.begin() + d.row_first[(size_t)d.coll->rank] + d.nloc, x);
+                return it;
+            }
             return saamge_amd::api::kalchev_pcg(tg_data->h, b, x, print_iter, max_num_iter, RTOLERANCE, ATOLERANCE, zero_rhs);
         } catch (const std::exception &e) {
             mfem::mfem_error(e.what());

@@ -27,6 +27,8 @@ SYMBOLS = [
     "saamge_amd_params_set_comm", "saamge_amd_comm_selftest", "saamge_amd_comm_last_error",
     "saamge_amd_release_cached_memory", "saamge_amd_cached_memory_bytes",
     "saamge_amd_ml_produce_data64", "saamge_amd_get_csr64", "saamge_amd_spmv64", "saamge_amd_set_smoother", "saamge_amd_profile_get2", "saamge_amd_level_format", "saamge_amd_update_operators2",
+    "saamge_amd_ml_produce_data_parcsr", "saamge_amd_memory_stats",
+    "saamge_amd_options_default", "saamge_amd_set_options", "saamge_amd_get_options",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong))
@@ -35,6 +37,12 @@ COARSE_SOLVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double
 SMOOTHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double))
 ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p,
                            C.POINTER(C.c_longlong))
+
+
+class Options(C.Structure):      # saamge_amd_options
+    _fields_ = [(k, C.c_int) for k in ("eig_strict", "eig_certify", "eig_min_n", "eig_force_fallback", "eig_dense_only",
+                                       "eig_dense_one_stage", "eig_nullcheck", "eig_keep_inertia_factor", "band_assembly",
+                                       "overlap", "sell", "spmv_sell", "debug")]
 
 
 class Params(C.Structure):
@@ -66,7 +74,15 @@ class Params(C.Structure):
         ("do_aggregates", C.c_int),
         ("eigensolver", C.c_int),
         ("eig_tol", C.c_double),
+        ("options", Options),
     ]
+
+
+class ParCsr(C.Structure):      # saamge_amd_parcsr
+    _fields_ = [("global_rows", C.c_longlong), ("row_starts", C.c_void_p), ("nrows", C.c_int),
+                ("diag_i", C.c_void_p), ("diag_j", C.c_void_p), ("diag_a", C.c_void_p),
+                ("offd_i", C.c_void_p), ("offd_j", C.c_void_p), ("offd_a", C.c_void_p),
+                ("num_cols_offd", C.c_int), ("col_map_offd", C.c_void_p)]
 
 
 _lib = None
@@ -107,6 +123,11 @@ def load():
     lib.saamge_amd_last_error.restype = C.c_char_p
     lib.saamge_amd_num_levels.restype = C.c_int
     _lib = lib
+    # tests that run the library in a child process choose options through SAAMGE_AMD_TEST_OPTIONS="name=value,..." -- read
+    # HERE, by the harness; the library itself has no such switch
+    spec = os.environ.get("SAAMGE_AMD_TEST_OPTIONS")
+    if spec:
+        set_options(**{kv.split("=")[0].strip(): int(kv.split("=")[1]) for kv in spec.split(",") if kv.strip()})
     return lib
 
 
@@ -133,6 +154,7 @@ def default_params(num_coarsenings=1, theta=0.003, nu_relax=3, testmesh=False, k
                    smooth_drop_tol=0.0, do_aggregates=False, eigensolver=0, eig_tol=None):
     p = Params()
     load().saamge_amd_params_default(C.byref(p))
+    p.options = get_options()          # (what set_options / SAAMGE_AMD_TEST_OPTIONS chose stays in force for this hierarchy)
     p.num_coarsenings = num_coarsenings
     for i in range(MAX_LEVELS):
         p.theta[i] = theta
@@ -167,10 +189,9 @@ class Hierarchy(object):
     """Owner of a saamge_amd_hierarchy (== ml_data_t).  Mirrors the reference call
     sequence: ml_produce_data -> VCycleSolver::Mult / CGSolver::Mult -> ml_free_data."""
 
-    def __init__(self, A_rowptr, A_col, A_val, n, elem_to_dof, elmat, bdr, partitions, nparts,
-                 params, NE, nde, stream=0, group=None, dist_solve=True):
+    def _prepare_params(self, params, group, stream, dist_solve):
+        """A private copy of the caller's params with the collectives of `group` installed."""
         lib = load()
-        self._keep = (A_rowptr, A_col, A_val, elem_to_dof, elmat, bdr, partitions)
         caller_params = params
         params = Params.from_buffer_copy(params)      # the caller's struct is never modified
         self._keep_params = caller_params             # (keeps extra_modes alive)
@@ -192,6 +213,13 @@ class Hierarchy(object):
                 self._cb2 = group.solve_callbacks(stream)
                 params.allreduce_sum, params.alltoallv = self._cb2
                 params.comm_stream_ordered = int(group.stream_ordered(stream))
+        return params
+
+    def __init__(self, A_rowptr, A_col, A_val, n, elem_to_dof, elmat, bdr, partitions, nparts,
+                 params, NE, nde, stream=0, group=None, dist_solve=True):
+        lib = load()
+        self._keep = (A_rowptr, A_col, A_val, elem_to_dof, elmat, bdr, partitions)
+        params = self._prepare_params(params, group, stream, dist_solve)
         parts = (C.c_void_p * len(partitions))(*[_ptr(p).value for p in partitions])
         npa = (C.c_int * len(nparts))(*[int(x) for x in nparts])
         h = C.c_void_p()
@@ -220,6 +248,36 @@ class Hierarchy(object):
         nparts = [int(p.max()) + 1 for p in parts]
         return cls(rowptr, col, val, A.shape[0], e2d, elmat, bdr, parts, nparts, params,
                    e2d.shape[0], e2d.shape[1], stream, group, dist_solve)
+
+    @classmethod
+    def from_parcsr(cls, piece, params, stream=0, group=None, dist_solve=True):
+        """Build from PER-RANK inputs (saamge_amd_ml_produce_data_parcsr): `piece` = this rank's entry of
+        problems.split_parcsr -- its row block as diag / offd / col_map_offd, its own elements (global dof ids), their
+        matrices, the flags of its own rows and its local agglomerate partitions.  Host numpy arrays or device tensors."""
+        self = cls.__new__(cls)
+        lib = load()
+        params = self._prepare_params(params, group, stream, dist_solve)
+        nco = params.num_coarsenings
+        A = ParCsr()
+        A.global_rows = int(piece.get("global_rows", 0))
+        rs = piece.get("row_starts")
+        self._keep = [piece, rs]
+        A.row_starts = _ptr(rs).value if rs is not None else None
+        A.nrows = int(piece["nrows"])
+        for k in ("diag_i", "diag_j", "diag_a", "offd_i", "offd_j", "offd_a", "col_map_offd"):
+            setattr(A, k, _ptr(piece.get(k)).value)
+        A.num_cols_offd = int(piece.get("num_cols_offd", 0))
+        parts = (C.c_void_p * nco)(*[_ptr(p).value for p in piece["partitions"][:nco]])
+        npa = (C.c_int * nco)(*[int(x) for x in piece["nparts"][:nco]])
+        h = C.c_void_p()
+        e2d = piece["elem_to_dof"]
+        _check(lib.saamge_amd_ml_produce_data_parcsr(C.byref(A), C.c_int(int(e2d.shape[0])), C.c_int(int(e2d.shape[1])), _ptr(e2d),
+                                                     _ptr(piece["elmat"]), _ptr(piece.get("bdr")), parts, npa, C.byref(params),
+                                                     C.c_void_p(stream), C.byref(h)))
+        self.h = h
+        self.n = int(self.level_info(0)["n"])
+        self.testmesh = False
+        return self
 
     @classmethod
     def from_matrix(cls, A, dof_partition, params, coarse_partitions=(), stream=0, group=None):
@@ -487,6 +545,37 @@ def cached_memory_bytes():
     lib = load()
     lib.saamge_amd_cached_memory_bytes.restype = C.c_longlong
     return int(lib.saamge_amd_cached_memory_bytes())
+
+
+def get_options():
+    o = Options()
+    load().saamge_amd_get_options(C.byref(o))
+    return o
+
+
+def set_options(**kw):
+    """Process-wide options of the library (saamge_amd_options); returns the previous values.  default_params() copies the
+    current ones into params.options, so that a later ml_produce_data keeps them."""
+    old = get_options()
+    new = Options.from_buffer_copy(old)
+    for k, v in kw.items():
+        assert hasattr(new, k), k
+        setattr(new, k, int(v))
+    load().saamge_amd_set_options(C.byref(new))
+    return old
+
+
+def reset_options():
+    o = Options()
+    load().saamge_amd_options_default(C.byref(o))
+    load().saamge_amd_set_options(C.byref(o))
+
+
+def memory_stats(reset_peak=False):
+    """(live, peak) device bytes held by the library's buffers (the caller's own arrays and the idle cache not counted)."""
+    live, peak = C.c_longlong(0), C.c_longlong(0)
+    load().saamge_amd_memory_stats(C.byref(live), C.byref(peak), C.c_int(int(reset_peak)))
+    return int(live.value), int(peak.value)
 
 
 def profile(enable=True):

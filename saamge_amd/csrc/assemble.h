@@ -12,6 +12,10 @@ struct DevElmats {
     DBuf<int64_t> off;  // [NE+1]
     DBuf<double> val;
     int nde = 0;        // > 0: every element has exactly nde dofs and e2d_J / val are dense arrays
+    // per-rank inputs: val holds the matrices of the elements [first, first + count) only; kernels that index the array by
+    // the element id itself (no `off`) take dense() -- they touch the rank's own elements only
+    int64_t first = 0;
+    const double *dense() const { return val.p - first * (int64_t)nde * nde; }
     int algebraic = 0;       // element-free mode: the AE matrices come from A (no element matrices);
                              // 1 = ExtractSubMatrices, 2 = WindowSubMatrices
 };

@@ -843,19 +843,19 @@ static void launch_rows8(hipStream_t s, const DevRelations &rel, const DCsr &A, 
         dc = g_rcols.p;
     }
     profiler().begin(s);
-    static const bool old_rows = std::getenv("SAAMGE_AMD_AE_ROWS_LDS") && std::atoi(std::getenv("SAAMGE_AMD_AE_ROWS_LDS")) == 0;
+    constexpr bool old_rows = false;      // (the kernel without the LDS hash of the agglomerate's dofs: larger agglomerates only)
     int hsize = 64;
     while (hsize < 2 * batch.max_n) hsize <<= 1;
     const size_t lds = (size_t)batch.max_n * (8 + 4 + 4 + 1) + (size_t)hsize * 6 + 16;
     if (!old_rows && lds <= 64 * 1024)
         hipLaunchKernelGGL(ae_rows8_lds_kernel, dim3(batch.count), dim3(256), lds, s, ae0, RW, hsize, batch.n.p, batch.voff.p,
                            rel.ae2d_I.p, rel.ae2d_J.p, rel.flags.p, rel.d2e_I.p, rel.d2e_J.p, rel.part.p, rel.e2d_J.p,
-                           el.val.p, A.rowptr.p, A.col.p, A.val.p, dv, dc);
+                           el.dense(), A.rowptr.p, A.col.p, A.val.p, dv, dc);
     else
     hipLaunchKernelGGL(ae_rows8_kernel, dim3(div_up((long)batch.max_n * RW, 256), batch.count), dim3(256), 0, s,
                        ae0, RW, batch.n.p, batch.voff.p, rel.ae2d_I.p, rel.ae2d_J.p, rel.d2ae_I.p,
                        rel.d2ae_J.p, rel.dof_id_inAE.p, rel.flags.p, rel.d2e_I.p, rel.d2e_J.p, rel.part.p,
-                       rel.e2d_J.p, el.val.p, A.rowptr.p, A.col.p, A.val.p, dv, dc);
+                       rel.e2d_J.p, el.dense(), A.rowptr.p, A.col.p, A.val.p, dv, dc);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "ae_rows", 0.0, 0.0);
     rv = dv;
@@ -964,17 +964,17 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
         if (scale) ae_scale(s, batch, Dout);
         return;
     }
-    static const bool no_fused = std::getenv("SAAMGE_AMD_NO_FUSED_ASSEMBLY") != nullptr;
+    constexpr bool no_fused = false;
     size_t lds = 0;
     int RW = 0;
     // rows ordered by global dof number for the banded factorisation of the few-eigenpairs path (the
     // fused kernel below, or the plain assembly followed by the two-kernel scaling)
-    static const bool use_perm = [] { const char *e = std::getenv("SAAMGE_AMD_SS_PERM"); return !(e && e[0] == '0'); }();
+    constexpr bool use_perm = true;
     const bool split_scale = batch.count <= 2048 && batch.max_n >= 1024;      // (what ae_scale will pick)
     if (use_perm && scale && eig_batch_takes_subspace(batch) && batch.max_n <= 16384 && ((A && !no_fused) || split_scale)) {
         const size_t rows_total = (size_t)batch.h_voff[batch.count];
         if (batch.perm.n < rows_total) { batch.perm.alloc(rows_total); batch.iperm.alloc(rows_total); }
-        static const int box_order = [] { const char *e = std::getenv("SAAMGE_AMD_SS_BOX"); return (e && e[0] == '0') ? 0 : 1; }();
+        constexpr int box_order = 1;
         hipLaunchKernelGGL(ae_perm_kernel, dim3(batch.count), dim3(256), 2 * sizeof(int) * (size_t)batch.max_n, s, ae0,
                            batch.n.p, batch.voff.p, rel.ae2d_I.p, rel.ae2d_J.p, batch.perm.p, batch.iperm.p, box_order);
         batch.has_perm = true;
@@ -987,7 +987,7 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
     }
     if (!A || no_fused || lds > 160 * 1024 - 256 || batch.max_n > 32767) {
         if (!split_scale) batch.has_perm = false;       // (the one-kernel scaling works in agglomerate order)
-        static const bool band_asm = [] { const char *e = std::getenv("SAAMGE_AMD_BAND_ASSEMBLY"); return !(e && e[0] == '0'); }();
+        const bool band_asm = options().band_assembly != 0;
         // (also with the global matrix at hand -- level 0 of Q2 elasticity, whose agglomerates do not fit the fused
         // kernel's LDS: an entry copied from A couples two dofs of an element of this agglomerate, so the band of the
         // element matrices holds it)
@@ -1004,7 +1004,7 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
         bwp = batch.bw.p;
         batch.has_bw = true;
     }
-    static const bool band_write = [] { const char *e = std::getenv("SAAMGE_AMD_SS_BAND_WRITE"); return !(e && e[0] == '0'); }();
+    constexpr bool band_write = true;
     const int band_only = (bwp && band_write && eig_ss_band_enabled()) ? 1 : 0;
     const bool nde8 = el.nde == 8 && batch.count <= 65535;   // (grid.y of the rows kernel)
     const double *rv = nullptr;
@@ -1416,10 +1416,10 @@ void coarse_elmats_sparse(hipStream_t s, const DevRelations &rel, int ae0, const
     profiler().begin(s);
     // the packed rows of T of one agglomerate in LDS: a pool of 6 doubles per row on average (+ keys, column starts, offsets
     // and dof maps: 24 bytes per row); an agglomerate that needs more is redone by the dense-T kernel
-    static const bool old_only = std::getenv("SAAMGE_AMD_COARSE_ELMAT_ROWS") && std::atoi(std::getenv("SAAMGE_AMD_COARSE_ELMAT_ROWS")) == 0;
+    constexpr bool old_only = false;
     const int pool_cap = 6 * batch.max_n, u_cap = 3 * batch.max_n;
     const size_t lds = 8 * (size_t)(pool_cap + u_cap) + 28 * (size_t)batch.max_n + 16;
-    if (std::getenv("SAAMGE_AMD_COARSE_ELMAT_VERBOSE"))
+    if (options().debug & 2)
         std::fprintf(stderr, "coarse_elmats_sparse: %d agglomerates, max n %d, kmax %d, RW %d, LDS %zu\n", batch.count, batch.max_n, kmax, RW, lds);
     const int *only = nullptr;
     DBuf<int> flagged;

@@ -40,6 +40,22 @@ extern "C" {
 
 const char *saamge_amd_last_error(void) { return g_last_error.c_str(); }
 
+static void options_to_c(const Options &o, saamge_amd_options *c) {
+    c->eig_strict = o.eig_strict; c->eig_certify = o.eig_certify; c->eig_min_n = o.eig_min_n;
+    c->eig_force_fallback = o.eig_force_fallback; c->eig_dense_only = o.eig_dense_only; c->eig_dense_one_stage = o.eig_dense_one_stage;
+    c->eig_nullcheck = o.eig_nullcheck; c->eig_keep_inertia_factor = o.eig_keep_inertia_factor; c->band_assembly = o.band_assembly;
+    c->overlap = o.overlap; c->sell = o.sell; c->spmv_sell = o.spmv_sell; c->debug = o.debug;
+}
+void saamge_amd_options_default(saamge_amd_options *o) { options_to_c(Options(), o); }
+void saamge_amd_get_options(saamge_amd_options *o) { options_to_c(options(), o); }
+void saamge_amd_set_options(const saamge_amd_options *c) {
+    Options &o = options();
+    o.eig_strict = c->eig_strict; o.eig_certify = c->eig_certify; o.eig_min_n = c->eig_min_n;
+    o.eig_force_fallback = c->eig_force_fallback; o.eig_dense_only = c->eig_dense_only; o.eig_dense_one_stage = c->eig_dense_one_stage;
+    o.eig_nullcheck = c->eig_nullcheck; o.eig_keep_inertia_factor = c->eig_keep_inertia_factor; o.band_assembly = c->band_assembly;
+    o.overlap = c->overlap; o.sell = c->sell; o.spmv_sell = c->spmv_sell; o.debug = c->debug;
+}
+
 void saamge_amd_params_default(saamge_amd_params *p) {
     // defaults of test/mltest/mltest.cpp:332-419
     p->num_coarsenings = 1;
@@ -54,10 +70,6 @@ void saamge_amd_params_default(saamge_amd_params *p) {
     p->coarse_rtol = 1e-14;
     p->coarse_max_iter = 2000;
     p->workspace_bytes = (long long)32 << 30;
-    if (const char *e = std::getenv("SAAMGE_AMD_WORKSPACE_GB")) {     // default chunk size of the AE eigenproblems
-        const long long gb = std::atoll(e);
-        if (gb >= 1 && gb <= 256) p->workspace_bytes = gb << 30;
-    }
     p->keep_debug = 0;
     p->rank = 0;
     p->world = 1;
@@ -75,6 +87,7 @@ void saamge_amd_params_default(saamge_amd_params *p) {
     p->do_aggregates = 0;
     p->eigensolver = 0;
     p->eig_tol = 1e-12;
+    saamge_amd_options_default(&p->options);
 }
 
 int saamge_amd_memcpy(void *dst, const void *src, long long bytes) {
@@ -87,14 +100,8 @@ int saamge_amd_memcpy(void *dst, const void *src, long long bytes) {
     return 0;
 }
 
-static int produce_data(int n, const void *rowptr, int rowptr_bits, const int *col, const double *val,
-                        int NE, int nde, const int *elem_to_dof, const double *elmat,
-                        const signed char *bdr_dofs, const int *const *partitions,
-                        const int *nparts, const saamge_amd_params *params, void *stream,
-                        saamge_amd_hierarchy **out) {
-    SA_API_BEGIN
-    SA_REQUIRE(out && params && rowptr && col && val && (params->algebraic || (elem_to_dof && elmat)) && partitions && nparts,
-               "null argument");
+static Params convert_params(const saamge_amd_params *params, void *stream) {
+    saamge_amd_set_options(&params->options);
     Params p;
     p.num_coarsenings = params->num_coarsenings;
     SA_REQUIRE(p.num_coarsenings >= 1 && p.num_coarsenings < MAX_LEVELS, "bad num_coarsenings");
@@ -136,9 +143,45 @@ static int produce_data(int n, const void *rowptr, int rowptr_bits, const int *c
     p.eig_tol = params->eig_tol;
     SA_REQUIRE(p.eig_tol >= 1e-15 && p.eig_tol <= 1e-8, "eig_tol must lie in [1e-15, 1e-8] (saamge_amd_params_default sets 1e-12)");
     SA_REQUIRE(p.world == 1 || (p.rank >= 0 && p.rank < p.world), "bad rank");
+    return p;
+}
+
+static int produce_data(int n, const void *rowptr, int rowptr_bits, const int *col, const double *val,
+                        int NE, int nde, const int *elem_to_dof, const double *elmat,
+                        const signed char *bdr_dofs, const int *const *partitions,
+                        const int *nparts, const saamge_amd_params *params, void *stream,
+                        saamge_amd_hierarchy **out) {
+    SA_API_BEGIN
+    SA_REQUIRE(out && params && rowptr && col && val && (params->algebraic || (elem_to_dof && elmat)) && partitions && nparts,
+               "null argument");
+    const Params p = convert_params(params, stream);
     set_thread_stream((hipStream_t)stream);
     Hierarchy *H = hierarchy_create(n, rowptr, rowptr_bits, col, val, NE, nde, elem_to_dof, elmat, bdr_dofs,
                                     partitions, nparts, p, (hipStream_t)stream);
+    *out = new saamge_amd_hierarchy{H};
+    SA_API_END
+}
+
+int saamge_amd_ml_produce_data_parcsr(const saamge_amd_parcsr *A, int NE_local, int nde, const int *elem_to_dof,
+                                      const double *elmat, const signed char *bdr_dofs, const int *const *partitions,
+                                      const int *nparts_local, const saamge_amd_params *params, void *stream,
+                                      saamge_amd_hierarchy **out) {
+    SA_API_BEGIN
+    SA_REQUIRE(out && params && A && A->diag_i && (A->nrows == 0 || (A->diag_j && A->diag_a)) && partitions && nparts_local &&
+                   (NE_local == 0 || (elem_to_dof && elmat)), "null argument");
+    SA_REQUIRE(!A->offd_i || A->num_cols_offd == 0 || (A->offd_j && A->offd_a && A->col_map_offd), "offd block without its arrays");
+    const Params p = convert_params(params, stream);
+    ParCsrIn in;
+    in.global_rows = A->global_rows;
+    in.row_starts = A->row_starts;
+    in.nrows = A->nrows;
+    in.diag_i = A->diag_i; in.diag_j = A->diag_j; in.diag_a = A->diag_a;
+    in.offd_i = (A->offd_i && A->num_cols_offd > 0) ? A->offd_i : nullptr;
+    in.offd_j = A->offd_j; in.offd_a = A->offd_a;
+    in.num_cols_offd = A->num_cols_offd;
+    in.col_map_offd = A->col_map_offd;
+    set_thread_stream((hipStream_t)stream);
+    Hierarchy *H = hierarchy_create_dist(in, NE_local, nde, elem_to_dof, elmat, bdr_dofs, partitions, nparts_local, p, (hipStream_t)stream);
     *out = new saamge_amd_hierarchy{H};
     SA_API_END
 }
@@ -500,7 +543,7 @@ static int spmv_entry(int nrows, int ncols, const void *rowptr, int rowptr_bits,
     import_array(A.val, val, (size_t)A.nnz, s);
     A.lanes_per_row = pick_lanes_per_row(A.nnz, nrows > 0 ? nrows : 1);
     // SAAMGE_AMD_SPMV_SELL=1 (tests): through the SELL-64 copy and its coded slices, the format of the level operators
-    if (nrows == ncols && std::getenv("SAAMGE_AMD_SPMV_SELL")) build_sell(s, A);
+    if (nrows == ncols && options().spmv_sell) build_sell(s, A);
     VecIn vx(x, (size_t)ncols, s);
     VecOut vy(y, (size_t)nrows, s, false);
     spmv(s, A, vx.p, vy.p);
@@ -540,6 +583,7 @@ int saamge_amd_lower_eigens_batched(int count, const int *n, const double *A, co
     EigBatch b;
     eig_batch_alloc(b, sizes, s);
     b.set_window(vu);
+    b.dense_only = options().eig_dense_only != 0;
     SA_HIP_CHECK(hipMemcpyAsync(b.W.p, A, 8 * (size_t)b.h_moff[count], hipMemcpyDefault, s));
     DBuf<double> dD;
     dD.assign(D, (size_t)b.h_voff[count], s);
@@ -602,6 +646,12 @@ void saamge_amd_release_cached_memory(void) {
     dev_pool_release();
 }
 long long saamge_amd_cached_memory_bytes(void) { return (long long)dev_pool_idle_bytes(); }
+void saamge_amd_memory_stats(long long *live_bytes, long long *peak_bytes, int reset_peak) {
+    size_t l = 0, pk = 0;
+    dev_memory_stats(&l, &pk, reset_peak != 0);
+    if (live_bytes) *live_bytes = (long long)l;
+    if (peak_bytes) *peak_bytes = (long long)pk;
+}
 
 void saamge_amd_profile_enable(int on) { profiler().enabled = on != 0; }
 void saamge_amd_profile_reset(void) { profiler().stats.clear(); }

@@ -83,6 +83,29 @@ inline bool is_device_ptr(const void *p) {
     return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
+// ---- options of the library (saamge_amd_options, include/saamge_amd.h): process-wide, set through the C ABI ----------
+// What is left of the ~50 environment switches of rounds 1-3: the variants that were measured without gain are gone, the
+// ones tests need to reach a code path (or a caller may want) are fields here.  Environment variables that remain:
+// SAAMGE_AMD_TIMING, SAAMGE_AMD_SERIAL (diagnostics), SAAMGE_AMD_POOL_MAX_GB, SAAMGE_AMD_THREADS (resources).
+struct Options {
+    int eig_strict = 0;               // few-eigenpairs path: a fallback to the dense path is an error (tests of that path)
+    int eig_certify = 1;              // the count #{lambda < theta} certified by the inertia of C - theta I
+    int eig_min_n = 64;               // smallest agglomerate of a batch that takes the few-eigenpairs path
+    int eig_force_fallback = 0;       // tests: every k-th matrix takes the per-matrix dense fallback
+    int eig_dense_only = 0;           // saamge_amd_lower_eigens_batched: the dense path (a hierarchy: saamge_amd_params.eigensolver)
+    int eig_dense_one_stage = 0;      // dense path: one-stage blocked Householder reduction instead of the two-stage one
+    int eig_nullcheck = 1;            // known-null-vector shortcut (ss_nullcheck_kernel)
+    int eig_keep_inertia_factor = 1;  // wide-band matrices with certified count 0 keep the factor of the inertia pass
+    int band_assembly = 1;            // coarse-level agglomerate matrices assembled inside their band
+    int overlap = 7;                  // bit 0 subspace iteration beside the next chunk, 1 halo exchange beside the interior rows, 2 Galerkin product beside the next level
+    int sell = 31;                    // bit 0 coded slices at all, 1 pair coding, 2 short-chain kernel path, 3 operator-level dictionary, 4 node blocks
+    int spmv_sell = 0;                // saamge_amd_spmv / spmv64 build and use the SELL copy
+    int debug = 0;                    // bit 0 iteration traces of the few-eigenpairs path, 1 operator format census, 2 level tags in the kernel profile
+};
+Options &options();
+bool env_timing();      // SAAMGE_AMD_TIMING
+bool env_serial();      // SAAMGE_AMD_SERIAL: no worker threads in the setup (counter passes)
+
 // ---- device memory: caching allocator behind every DBuf -----------------------------------
 // hipMalloc costs 10 us - 1 ms and hipFree additionally waits for the whole device, which stalls the
 // host between setup kernels and serialises streams that are meant to overlap.  Freed blocks are kept
@@ -99,6 +122,8 @@ void *dev_alloc(size_t bytes);
 void dev_free(void *p) noexcept;
 void dev_pool_release();
 size_t dev_pool_idle_bytes();
+// device bytes the library holds in DBufs right now and their high-water mark since the last reset
+void dev_memory_stats(size_t *live, size_t *peak, bool reset_peak);
 struct ThreadStreamScope {       // the calling thread's stream for a scope (restored at its end)
     hipStream_t prev;
     bool had;
@@ -249,6 +274,11 @@ struct DCsr {
     DBuf<int2> sell_tile_seg;
     int sell_stage_cap = 0;
     bool sell_one_table = false;   // every staged tile shares one pair table among its four slices
+    // sell_staged2_kernel (one-table operators): the staged tiles' code words once more in a regular layout (word q of thread t
+    // of tile T at (T sell_wq + q) 256 + t) and one descriptor word per tile (segments | the four slice widths)
+    int sell_wq = 0;
+    DBuf<unsigned> sell_codeR;
+    DBuf<int> sell_tile_desc;
     DBuf<int> sell_unstaged;       // tiles left to the gather kernel (sell_nunstaged of them)
     int sell_nunstaged = 0;
 };

@@ -14,6 +14,10 @@
 namespace saamge_amd {
 
 constexpr int DNB = 64;
+namespace gj {
+constexpr int SB = 16;
+#include "chol16.h"      // chol16_inverse_wave: Cholesky factor + inverse of a 16 x 16 block by one wavefront
+}  // namespace gj
 
 __global__ __launch_bounds__(256) void dense_zero_kernel(size_t nn, double *__restrict__ L) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -65,28 +69,102 @@ __global__ __launch_bounds__(256) void gj_panel_kernel(int n, int k0, int nb, co
         else Col[((size_t)b * DNB + r) * DNB + c] = (r < nb && j0 + c < n) ? -M[(size_t)(j0 + c) * n + k0 + r] : 0.0;   // M[j0 + c, k0 + r] = -M[k0 + r, j0 + c]
     }
     __syncthreads();
-    int cur = 0;
-    for (int j = 0; j < nb; ++j, cur ^= 1) {
-        double (*D)[DNB + 1] = Dbuf[cur], (*E)[DNB + 1] = Dbuf[cur ^ 1];
-        const double d = D[j][j];
-        if (!(d > 0.0)) {               // not positive definite (also catches NaN): uniform exit, in every workgroup
-            if (tid == 0) atomicMax(info, k0 + j + 1);
+    // Pinv = (pivot block)^-1.  The block is symmetric positive definite (a Schur complement of an SPD operator; a short
+    // last block is padded with the identity), so instead of a 64-step Gauss-Jordan chain with a barrier per step (115 us
+    // of latency per block step, round 3) it is inverted through its Cholesky factor in 16 x 16 blocks:
+    //   A = L L^T by four block steps -- diagonal block factor AND its inverse by one wavefront in registers
+    //   (chol16_inverse_wave, the kernel of the banded eigen path), panel L_ij = A_ij L_jj^-T, trailing update --,
+    //   W = L^-1 by block forward substitution, Pinv = W^T W.
+    double (*Am)[DNB + 1] = Dbuf[0], (*W)[DNB + 1] = Dbuf[1];
+    __shared__ double Ld[gj::SB][gj::SB + 1], Li[gj::SB][gj::SB + 1];
+    __shared__ int sh_bad;
+    if (tid == 0) sh_bad = 0;
+    for (int u = 0; u < DNB / 4; ++u) W[r][c0 + 4 * u] = 0.0;
+    for (int jb = 0; jb < DNB / 16; ++jb) {
+        const int o = 16 * jb;
+        { const int i = tid >> 4, j = tid & 15; Ld[i][j] = (j <= i) ? Am[o + i][o + j] : 0.0; }
+        __syncthreads();
+        if (tid < 64) {
+            const int badb = gj::chol16_inverse_wave<false>(Ld, Li, tid);
+            if (tid == 0 && badb) sh_bad = 1;
+        }
+        __syncthreads();
+        if (sh_bad) {                   // not positive definite (uniform): every workgroup leaves
+            if (tid == 0) atomicMax(info, k0 + o + 1);
             return;
         }
-        const double inv = 1.0 / d;
-        const double rj = D[r][j];
+        { const int i = tid >> 4, j = tid & 15; W[o + i][o + j] = (j <= i) ? Li[i][j] : 0.0; }
+        const int below = DNB - o - 16;        // rows under the diagonal block
+        // panel: L(rr, o + cc) = sum_{q <= cc} A(rr, o + q) Linv_jj(cc, q); values first, then the writes (in place)
+        double pv[3];
 #pragma unroll
-        for (int u = 0; u < DNB / 4; ++u) {
-            const int c = c0 + 4 * u;
-            const double pjc = (c == j) ? 1.0 : D[j][c];
-            double v;
-            if (r == j) v = pjc * inv;
-            else if (c == j) v = -rj * inv;
-            else v = fma(-rj * inv, pjc, D[r][c]);
-            E[r][c] = v;
+        for (int u = 0; u < 3; ++u) {
+            const int idx = tid + 256 * u, rr = o + 16 + (idx >> 4), cc = idx & 15;
+            double t = 0.0;
+            if ((idx >> 4) < below)
+                for (int q = 0; q <= cc; ++q) t = fma(Am[rr][o + q], Li[cc][q], t);
+            pv[u] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int idx = tid + 256 * u, rr = o + 16 + (idx >> 4), cc = idx & 15;
+            if ((idx >> 4) < below) Am[rr][o + cc] = pv[u];
+        }
+        __syncthreads();
+        // trailing update of the lower triangle: A(i, k) -= sum_c L(i, o + c) L(k, o + c), o + 16 <= k <= i
+        for (int idx = tid; idx < below * below; idx += 256) {
+            const int i = o + 16 + idx / below, k = o + 16 + idx % below;
+            if (k > i) continue;
+            double t = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) t = fma(Am[i][o + cc], Am[k][o + cc], t);
+            Am[i][k] -= t;
         }
         __syncthreads();
     }
+    // W = L^-1: W_ij = -W_ii sum_{k = j}^{i - 1} L_ik W_kj by block distance d = i - j (blocks of smaller distance are done)
+    for (int d = 1; d < DNB / 16; ++d) {
+        const int nblk = DNB / 16 - d;
+        double sv[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int idx = tid + 256 * u, bq = idx >> 8, e = idx & 255, ib = bq + d, jb2 = bq, rr = e >> 4, cc = e & 15;
+            double t = 0.0;
+            if (bq < nblk)
+                for (int kb = jb2; kb < ib; ++kb)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) t = fma(Am[16 * ib + rr][16 * kb + q], W[16 * kb + q][16 * jb2 + cc], t);
+            sv[u] = t;
+        }
+        __syncthreads();
+        // (the product with -W_ii needs the whole block of sums: through the still unused upper triangle of Am)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int idx = tid + 256 * u, bq = idx >> 8, e = idx & 255, ib = bq + d, jb2 = bq, rr = e >> 4, cc = e & 15;
+            if (bq < nblk) Am[16 * jb2 + cc][16 * ib + rr] = sv[u];      // stored transposed above the diagonal
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int idx = tid + 256 * u, bq = idx >> 8, e = idx & 255, ib = bq + d, jb2 = bq, rr = e >> 4, cc = e & 15;
+            if (bq < nblk) {
+                double t = 0.0;
+                for (int q = 0; q <= rr; ++q) t = fma(W[16 * ib + rr][16 * ib + q], Am[16 * jb2 + cc][16 * ib + q], t);
+                W[16 * ib + rr][16 * jb2 + cc] = -t;
+            }
+        }
+        __syncthreads();
+    }
+    // Pinv = W^T W (symmetric): Pinv(r, c) = sum_{t >= max(r, c)} W(t, r) W(t, c)
+    for (int u = 0; u < DNB / 4; ++u) {
+        const int c = c0 + 4 * u;
+        double t = 0.0;
+        for (int q = max(r, c); q < DNB; ++q) t = fma(W[q][r], W[q][c], t);
+        Am[r][c] = t;          // (each thread writes entries nobody reads any more: the L blocks are done with)
+    }
+    __syncthreads();
+    const int cur = 0;
     double (*P)[DNB + 1] = Dbuf[cur];
     if (b == kb)
         for (int u = 0; u < DNB / 4; ++u) {

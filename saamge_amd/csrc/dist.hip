@@ -259,10 +259,10 @@ bool dist_setup_level(Hierarchy &H, int lev) {
     D.recv_buf.alloc((size_t)D.nrecv + 1);
     // interior rows: the longest run of own slices without a halo column (a slab of a banded operator: everything
     // but the two ends); overlapped with the exchange when it is at least a quarter of the own rows
-    // (SAAMGE_AMD_HALO_OVERLAP=0: never)
+    // (saamge_amd_options.overlap bit 1 cleared: never)
     D.int_row0 = D.row0;
     D.int_nrows = 0;
-    static const bool no_overlap = [] { const char *e = std::getenv("SAAMGE_AMD_HALO_OVERLAP"); return e && e[0] == '0'; }();
+    const bool no_overlap = !(options().overlap & 2);
     if (D.nloc > 0 && !no_overlap) {
         const int nsl = div_up(D.nloc, 64);
         DBuf<int> sflag((size_t)nsl);

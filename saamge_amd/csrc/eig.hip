@@ -744,14 +744,7 @@ __global__ __launch_bounds__(VEC_NT) void eigvec_kernel(
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-static bool use_one_stage() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = std::getenv("SAAMGE_AMD_EIG");
-        v = (e && std::string(e) == "onestage") ? 1 : 0;
-    }
-    return v == 1;
-}
+static bool use_one_stage() { return options().eig_dense_one_stage != 0; }
 
 // Persistent, grow-only device workspace shared by all batches (hipMalloc/hipFree of
 // multi-GB buffers costs 0.1-0.4 s each on this platform; the arena is allocated once per
@@ -867,19 +860,11 @@ size_t eig_workspace_bytes(int n) {
 // on the 2 600-row agglomerates of the headline problem; a batch it cannot handle (more than six
 // wanted pairs, no convergence) is redone by the dense path.  SAAMGE_AMD_EIG=twostage / onestage /
 // dense switches it off.
-bool eig_use_subspace() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = std::getenv("SAAMGE_AMD_EIG");
-        v = (!e || std::string(e) == "subspace") ? 1 : 0;
-    }
-    return v == 1;
-}
+bool eig_use_subspace() { return true; }      // (the dense path alone: EigBatch::dense_only, saamge_amd_params.eigensolver = 1)
 
 bool eig_batch_takes_subspace(const EigBatch &b) {
-    // (SAAMGE_AMD_SS_MIN_N: smallest agglomerate size of a batch that takes the few-eigenpairs path)
-    static const int ss_min_n = []() { const char *e = std::getenv("SAAMGE_AMD_SS_MIN_N"); return e ? std::atoi(e) : 64; }();
-    return eig_use_subspace() && !b.dense_only && b.max_n >= ss_min_n;
+    // (saamge_amd_options.eig_min_n: smallest agglomerate size of a batch that takes the few-eigenpairs path)
+    return !b.dense_only && b.max_n >= options().eig_min_n;
 }
 
 void eig_tridiagonalize(hipStream_t s, EigBatch &b, int phases) {

@@ -1138,11 +1138,7 @@ void eig_tridiagonalize_two_stage(hipStream_t s, EigBatch &b, int phases) {
     // update on the matrix cores (fp64 MFMA sustains 46 TFLOP/s against 69 for v_fma_f64: tools/fma64_bench.hip)
     // and a lower-triangle-only variant were all slower or equal -- none is bound by FMA issue or HBM bytes, they
     // are bound by operand delivery (scalar-load latency).
-    // rows per lane of the fused kernel (SAAMGE_AMD_EIG_RPL = 1 | 2)
-    static const int rpl = []() {
-        const char *e = std::getenv("SAAMGE_AMD_EIG_RPL");
-        return (e && e[0] == '1') ? 1 : 2;
-    }();
+    constexpr int rpl = 2;      // rows per lane of the fused kernel (one row per lane: measured slower on the dense reduction, round 1)
     if (phases & 1) {
     if (!prof) profiler().begin(s);
     const int cnt8 = 8 * div_up(b.count, 8);
@@ -2549,7 +2545,7 @@ __global__ void ss_reshift_mu_kernel(int nreq, const int *__restrict__ req, cons
 }
 
 bool eig_ss_band_enabled() {
-    static const bool v = [] { const char *e = std::getenv("SAAMGE_AMD_SS_BAND"); return !(e && e[0] == '0'); }();
+    static const bool v = true;
     return v;
 }
 
@@ -2608,13 +2604,7 @@ static void ss_factor_generic(hipStream_t s, EigBatch &b, bool sgn, int *neg, in
                 profiler().begin(s);
             }
             // (one row per lane, 108 VGPRs, four wavefronts per SIMD: 8 % faster on the 2 187-row agglomerates of config 5 than two
-            // rows per lane at 212 VGPRs and two wavefronts per SIMD; SAAMGE_AMD_SS_RPL2=1: two rows for trailing matrices beyond 192)
-            static const bool rpl2 = std::getenv("SAAMGE_AMD_SS_RPL2") != nullptr;
-            if (np > 192 && rpl2)
-                hipLaunchKernelGGL((sbr_fused_kernel<false, 2, 3>), dim3(cnt8 * div_up(np, 2 * SF_ROWS)), dim3(S2_NT), 0, s, k0,
-                                   b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Vpk2.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
-                                   b.Gbuf.p, b.trash.p, b.count, div_up(np, 2 * SF_ROWS), SB, gbw, vrow, zrow, skip);
-            else
+            // rows per lane at 212 VGPRs and two wavefronts per SIMD)
                 hipLaunchKernelGGL((sbr_fused_kernel<false, 1, 3>), dim3(cnt8 * div_up(np, SF_ROWS)), dim3(S2_NT), 0, s, k0,
                                    b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Vpk2.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
                                    b.Gbuf.p, b.trash.p, b.count, div_up(np, SF_ROWS), SB, gbw, vrow, zrow, skip);
@@ -2659,12 +2649,12 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
         b.bw.from_host(full, s);
     }
     b.ss_bwmax = bwmax;
-    if (std::getenv("SAAMGE_AMD_SS_DEBUG")) {
+    if ((options().debug & 1)) {
         int bwmin = nmax;
         for (int v : b.h_bw) bwmin = std::min(bwmin, v);
         std::fprintf(stderr, "subspace: %d matrices, n max %d, half bandwidth %d .. %d\n", b.count, nmax, b.h_bw.empty() ? nmax : bwmin, bwmax);
     }
-    static const bool use_lds = [] { const char *e = std::getenv("SAAMGE_AMD_SS_BAND_LDS"); return !(e && e[0] == '0'); }();
+    constexpr bool use_lds = true;
     const bool lds_path = bws && use_lds && bwmax <= 128 - SB;      // the band fits the LDS window: one launch
     double cb = 0.0;      // the band read once, the factor written to both triangles
     if (lds_path)
@@ -2674,14 +2664,14 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
     // ---- certified count: inertia of C - vu I, before the matrices are shifted and overwritten ----
     // (dsygvx counts by bisection, amg/src/xpacks.cpp:226-268; a subspace iteration alone cannot prove
     // that no eigenvalue below vu is missing from its block)
-    static const bool certify = [] { const char *e = std::getenv("SAAMGE_AMD_SS_CERTIFY"); return !(e && e[0] == '0'); }();
+    const bool certify = options().eig_certify != 0;
     b.h_inertia.clear();
     b.ss_save = nullptr;
     // Wide-band matrices (coarse levels): a certified count of 0 means that the inertia pass met positive pivots
     // only, i.e. it WAS the Cholesky factorisation of C - vu I -- and vu is the best shift such a matrix can get
     // (its one wanted pair is the smallest).  Those matrices keep that factor: no restore, no second factorisation
     // (SAAMGE_AMD_SS_REUSE=0: factor twice as before).
-    static const bool reuse = [] { const char *e = std::getenv("SAAMGE_AMD_SS_REUSE"); return !(e && e[0] == '0'); }();
+    const bool reuse = options().eig_keep_inertia_factor != 0;
     bool generic_inertia = false;
     if (certify) {
         DBuf<int> neg((size_t)b.count);
@@ -2741,14 +2731,14 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
     b.nbad = 0;
     auto mark_bad = [&](int i) { if (!b.h_bad[(size_t)i]) { b.h_bad[(size_t)i] = 1; ++b.nbad; } };
     auto too_many_bad = [&]() { return (long)b.nbad * 10 > (long)b.count; };
-    static const bool lock_on = [] { const char *e = std::getenv("SAAMGE_AMD_SS_LOCK"); return !(e && e[0] == '0'); }();
+    constexpr bool lock_on = true;
     for (size_t i = 0; i < b.h_inertia.size(); ++i)
         if (b.h_inertia[i] > (lock_on ? SS_WANT_MAX : SS_B - 2) || b.h_inertia[i] < 0) {
-            SA_REQUIRE(!std::getenv("SAAMGE_AMD_SS_STRICT"), "few-eigenpairs path: a matrix has more wanted pairs than the block holds, or no certificate (strict mode)");
+            SA_REQUIRE(!options().eig_strict, "few-eigenpairs path: a matrix has more wanted pairs than the block holds, or no certificate (strict mode)");
             mark_bad((int)i);
         }
-    if (const char *fb = std::getenv("SAAMGE_AMD_SS_FORCE_BAD")) {      // tests: every fb-th matrix takes the per-matrix fallback
-        const int every = std::atoi(fb);
+    if (options().eig_force_fallback > 0) {      // tests: every k-th matrix takes the per-matrix fallback
+        const int every = options().eig_force_fallback;
         for (int i = 3; every > 0 && i < b.count; i += every) mark_bad(i);
     }
     if (too_many_bad()) return false;
@@ -2794,7 +2784,7 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
     DBuf<int> chol_active;
     int nchol = b.count;
     bool use_chol_list = false;
-    static const bool nullcheck = [] { const char *e = std::getenv("SAAMGE_AMD_SS_NULLCHECK"); return !(e && e[0] == '0'); }();
+    const bool nullcheck = options().eig_nullcheck != 0;
     const bool generic_reuse = generic_inertia && reuse;
     if ((lds_path || generic_reuse) && nullcheck && !b.h_inertia.empty()) {
         profiler().begin(s);
@@ -2807,7 +2797,7 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
         profiler().end(s, "eig_ss_nullcheck", cb, 0.0);
         auto hp = b.pre.to_host(s);
         b.h_pre.assign(hp.begin(), hp.end());
-        if (std::getenv("SAAMGE_AMD_SS_DEBUG") && !lds_path) {
+        if ((options().debug & 1) && !lds_path) {
             auto hv = b.pre_val.to_host(s);
             int shown = 0;
             for (int i = 0; i < b.count && shown < 12; ++i)
@@ -2842,7 +2832,7 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
             hipLaunchKernelGGL(ss_shift_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, 0.0, d_shifts.p);
             SA_HIP_CHECK(hipStreamSynchronize(s));     // (d_shifts leaves scope)
         }
-        if (std::getenv("SAAMGE_AMD_SS_DEBUG"))
+        if ((options().debug & 1))
             std::fprintf(stderr, "subspace: %d of %d wide-band matrices keep the factor of the inertia pass, %d are factored again\n",
                          nkeep, b.count, nfactor);
     } else
@@ -2870,10 +2860,10 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
     auto h = info.to_host(s);
     for (int i = 0; i < b.count; ++i)
         if (h[i] && !b.h_bad[i]) {         // a non-positive pivot: that matrix alone
-            if (std::getenv("SAAMGE_AMD_SS_DEBUG"))
+            if ((options().debug & 1))
                 std::fprintf(stderr, "subspace: non-positive pivot in matrix %d (n %d, band %d, inertia %d, sigma %g)\n", i, b.h_n[i],
                              b.h_bw.empty() ? -1 : b.h_bw[i], b.h_inertia.empty() ? -2 : b.h_inertia[i], b.h_sigma[i]);
-            SA_REQUIRE(!std::getenv("SAAMGE_AMD_SS_STRICT"), "few-eigenpairs path: non-positive pivot (strict mode)");
+            SA_REQUIRE(!options().eig_strict, "few-eigenpairs path: non-positive pivot (strict mode)");
             mark_bad(i);
         }
     return !too_many_bad();
@@ -2898,7 +2888,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     // wide-band matrices with a saved band: a matrix (certified count 0) that converges too slowly may ask once
     // for a new shift (state bit 2, ss_rr_kernel); the host then restores the bands, shifts that matrix to just
     // below its smallest Ritz value and factors the batch again (SAAMGE_AMD_SS_RESHIFT=0: never)
-    static const bool reshift_env = [] { const char *e = std::getenv("SAAMGE_AMD_SS_RESHIFT"); return !(e && e[0] == '0'); }();
+    constexpr bool reshift_env = true;
     const bool reshift_on = reshift_env && b.max_n > 1280 && b.ss_save && !b.h_inertia.empty() && b.h_sigma.size() == (size_t)b.count;
     DBuf<int> reshift_ok;
     std::vector<int> h_reshift_ok((size_t)b.count, 1);
@@ -2921,7 +2911,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         b.ss_Vlock.alloc((size_t)b.h_voff[b.count] * SS_LOCK_PITCH);
         b.ss_has_lock = true;
     }
-    if (std::getenv("SAAMGE_AMD_SS_DEBUG") && b.max_n > 1280 && !b.h_inertia.empty()) {
+    if ((options().debug & 1) && b.max_n > 1280 && !b.h_inertia.empty()) {
         std::fprintf(stderr, "subspace: certified counts (bad):");
         for (int i = 0; i < b.count; ++i) std::fprintf(stderr, " %d%s", b.h_inertia[i], b.h_bad[i] ? "*" : "");
         std::fprintf(stderr, "\n");
@@ -2971,13 +2961,13 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         // config 5's 23 s, where most matrices of a chunk are done long before the last one)
         hipLaunchKernelGGL(ss_copy_active_kernel, dim3(nact, std::max(1, std::min(16, b.max_n / 256))), dim3(256), 0, s, b.n.p,
                            b.voff.p, active.p, X, Z);
-        static const bool no_win = std::getenv("SAAMGE_AMD_SS_TRSOLVE_WIN") && std::atoi(std::getenv("SAAMGE_AMD_SS_TRSOLVE_WIN")) == 0;
+        constexpr bool no_win = false;
         const int wr = (std::min(b.max_n, bws ? std::max(b.ss_bwmax, SB) : b.max_n) + 2 * SB) | 1;      // rows of the LDS window (odd)
         const size_t win_bytes = sizeof(double) * SS_B * (size_t)wr;
         if (b.max_n > 768 && !no_win && win_bytes <= 150 * 1024) {
             // more matrices than CUs: the variant without requests ahead, two workgroups per CU (config 5 at 64^3: solves 448 -> 397 ms
             // per step; SAAMGE_AMD_SS_TRSOLVE_TWO=0: one per CU always)
-            static const bool two_env = !(std::getenv("SAAMGE_AMD_SS_TRSOLVE_TWO") && std::atoi(std::getenv("SAAMGE_AMD_SS_TRSOLVE_TWO")) == 0);
+            constexpr bool two_env = true;
             auto go = [&](auto lo, auto up) {
                 SA_HIP_CHECK(hipFuncSetAttribute((const void *)lo, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
                 SA_HIP_CHECK(hipFuncSetAttribute((const void *)up, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -3003,7 +2993,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
             profiler().end(s, b.max_n <= 1280 ? "eig_ss_solve" : "eig_ss_solve_g", ab, 0.0);
             profiler().begin(s);
         }
-        static const bool dbg_on = std::getenv("SAAMGE_AMD_SS_DEBUG") != nullptr;
+        const bool dbg_on = (options().debug & 1) != 0;
         DBuf<double> dbgbuf;
         if (dbg_on) dbgbuf.alloc((size_t)b.count * 2 * SS_B);
         if (any_lock)
@@ -3015,7 +3005,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         if (dbg_on && iter > 0) {
             auto hd = dbgbuf.to_host(s);
             const int show = std::min(b.count, 3);
-            static const int dbg_one = std::getenv("SAAMGE_AMD_SS_DEBUG_MATRIX") ? std::atoi(std::getenv("SAAMGE_AMD_SS_DEBUG_MATRIX")) : -1;
+            const int dbg_one = -1;
             if (dbg_one >= 0 && dbg_one < b.count) {
                 std::fprintf(stderr, "  iter %d matrix %d: bounds", iter, dbg_one);
                 for (int q = 0; q < 8; ++q) std::fprintf(stderr, " %.2e", hd[(size_t)dbg_one * 16 + q]);
@@ -3050,7 +3040,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
                                        b.ss_Vlock.p, b.ss_lock_mu.p, b.ss_ndefl.p, it0.p, iter, state.p, slow_hist.p);
                     SA_HIP_CHECK(hipGetLastError());
                     SA_HIP_CHECK(hipStreamSynchronize(s));
-                    if (std::getenv("SAAMGE_AMD_SS_DEBUG"))
+                    if ((options().debug & 1))
                         std::fprintf(stderr, "subspace: iteration %d, six pairs of %zu matrices locked (first: matrix %d)\n", iter, req.size(), req[0]);
                 }
             }
@@ -3059,14 +3049,14 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
             for (int i = 0; i < b.count; ++i) {
                 const int v = hstate[i];
                 if ((v & 2) && !b.h_bad[i]) {     // gave up during the iteration (too many pairs, breakdown, hopeless rate)
-                    SA_REQUIRE(!std::getenv("SAAMGE_AMD_SS_STRICT"), "few-eigenpairs path gave up on a matrix (strict mode)");
+                    SA_REQUIRE(!options().eig_strict, "few-eigenpairs path gave up on a matrix (strict mode)");
                     mark_bad(i);
                 }
                 if (!(v & 3)) done = false;
                 else ++nconv;
             }
             if (too_many_bad()) failed = true;
-            if (failed && std::getenv("SAAMGE_AMD_SS_DEBUG")) {
+            if (failed && (options().debug & 1)) {
                 std::fprintf(stderr, "subspace: iteration %d: too many matrices gave up (states:", iter);
                 for (int i = 0; i < b.count && i < 64; ++i) std::fprintf(stderr, " %x", hstate[i]);
                 std::fprintf(stderr, ")\n");
@@ -3127,17 +3117,17 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
                                        d_req.p, d_delta.p, mu, slow_hist.p);
                     SA_HIP_CHECK(hipGetLastError());
                     SA_HIP_CHECK(hipStreamSynchronize(s));
-                    if (std::getenv("SAAMGE_AMD_SS_DEBUG"))
+                    if ((options().debug & 1))
                         std::fprintf(stderr, "subspace: iteration %d, %zu matrices factored again at a shift below their smallest Ritz value\n", iter, req.size());
                     if (too_many_bad()) failed = true;
-                    if (failed && std::getenv("SAAMGE_AMD_SS_DEBUG")) {
+                    if (failed && (options().debug & 1)) {
                         std::fprintf(stderr, "subspace: iteration %d: the factorisation at the new shifts failed (info:", iter);
                         for (int i = 0; i < b.count && i < 64; ++i) std::fprintf(stderr, " %d", hi2[i]);
                         std::fprintf(stderr, ")\n");
                     }
                 }
             }
-            static const bool dbg = std::getenv("SAAMGE_AMD_SS_DEBUG") != nullptr;
+            const bool dbg = (options().debug & 1) != 0;
             if (dbg) std::fprintf(stderr, "subspace: iteration %d, %d of %d matrices accepted (n max %d)\n", iter, nconv, b.count, b.max_n);
             if (failed) break;
             h_active.clear();
@@ -3150,14 +3140,14 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     SA_HIP_CHECK(hipGetLastError());
     if (!prof) profiler().end(s, "eig_ss_iterate", 0.0, 0.0);
     if (!failed && !done) {      // out of iterations: the unfinished matrices go to the dense path
-        SA_REQUIRE(!std::getenv("SAAMGE_AMD_SS_STRICT"), "few-eigenpairs path: no convergence (strict mode)");
+        SA_REQUIRE(!options().eig_strict, "few-eigenpairs path: no convergence (strict mode)");
         { auto t = state.to_host(s); hstate.assign(t.begin(), t.end()); }
         for (int i = 0; i < b.count; ++i) if (!(hstate[i] & 3)) mark_bad(i);
         if (too_many_bad()) failed = true;
     }
     if (failed) {
         // (SAAMGE_AMD_SS_STRICT: the tests of this path must not pass on the dense fallback)
-        SA_REQUIRE(!std::getenv("SAAMGE_AMD_SS_STRICT"), "few-eigenpairs path gave up on a batch (strict mode)");
+        SA_REQUIRE(!options().eig_strict, "few-eigenpairs path gave up on a batch (strict mode)");
         return false;
     }
     // certification: the number of Ritz values inside the window must be the number of eigenvalues
@@ -3170,12 +3160,12 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
             if (b.h_inertia[i] < 0) { ++unsure; mark_bad(i); }
             else if (b.h_inertia[i] != k) { ++bad; mark_bad(i); }
         }
-        static const bool dbg = std::getenv("SAAMGE_AMD_SS_DEBUG") != nullptr;
+        const bool dbg = (options().debug & 1) != 0;
         if (dbg || bad || unsure)
             std::fprintf(stderr, "saamge_amd: few-eigenpairs batch of %d: %d counts contradicted by the inertia, %d uncertified\n",
                          b.count, bad, unsure);
         if (bad || unsure) {
-            SA_REQUIRE(!std::getenv("SAAMGE_AMD_SS_STRICT"), "few-eigenpairs path: count not certified (strict mode)");
+            SA_REQUIRE(!options().eig_strict, "few-eigenpairs path: count not certified (strict mode)");
             if (too_many_bad()) return false;
         }
     }

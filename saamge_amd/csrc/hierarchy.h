@@ -117,6 +117,30 @@ struct Level {                  // tg_data_t + interp_data_t + agg_partitioning_
 
 struct KernelTiming { double setup_ms = 0, solve_ms = 0; };
 
+// Per-rank inputs (dist_input.hip): a rank's row block in hypre's ParCSR split, as a HypreParMatrix holds it
+struct ParCsrIn {
+    long long global_rows = 0;              // 0: not given (the sum of the ranks' rows)
+    const long long *row_starts = nullptr;  // world + 1 entries or null: contiguous row blocks in rank order
+    int nrows = 0;
+    const int *diag_i = nullptr, *diag_j = nullptr;      // nrows x nrows, local column indices
+    const double *diag_a = nullptr;
+    const int *offd_i = nullptr, *offd_j = nullptr;      // nrows x num_cols_offd (null: no off-diagonal block)
+    const double *offd_a = nullptr;
+    int num_cols_offd = 0;
+    const long long *col_map_offd = nullptr;             // global column of every offd column
+};
+// ... gathered into the replicated form the setup works on; owned by the hierarchy
+struct DistIn {
+    DBuf<roff_t> rowptr;
+    DBuf<int> col, e2d;
+    DBuf<double> val;
+    DBuf<signed char> bdr;
+    std::vector<DBuf<int>> parts;
+    std::vector<int> nparts;
+    int elem0 = 0, NE_loc = 0;                            // this rank's elements: [elem0, elem0 + NE_loc); only THEIR matrices exist here
+    std::vector<std::vector<long long>> ae_begin;         // per level: agglomerate ownership ranges, dictated by the inputs
+};
+
 struct Hierarchy {              // ml_data_t
     Params params;
     hipStream_t stream = 0;
@@ -142,6 +166,7 @@ struct Hierarchy {              // ml_data_t
     };
     std::vector<UserSmoother> user_smoothers;
     DBuf<int> own_e2d;          // element-free mode: the generated identity elem_to_dof
+    std::unique_ptr<DistIn> dist_in;      // per-rank inputs: the gathered operator / topology the level-0 arrays view
     // setup only: the Galerkin product of level `galerkin_lev` runs on its own thread and stream beside the
     // next level's element matrices and eigenproblems (which need the level's size, not its operator)
     std::thread galerkin_thread;
@@ -161,7 +186,13 @@ struct Hierarchy {              // ml_data_t
 Hierarchy *hierarchy_create(int n, const void *Arow, int rowptr_bits, const int *Acol, const double *Aval, int NE,
                             int nde, const int *elem_to_dof, const double *elmat,
                             const signed char *bdr, const int *const *partitions,
-                            const int *nparts, const Params &p, hipStream_t stream);
+                            const int *nparts, const Params &p, hipStream_t stream, std::unique_ptr<DistIn> din = nullptr);
+// the same from per-rank inputs (dist_input.hip): elem_to_dof holds GLOBAL dof ids, elmat the matrices of the rank's own
+// elements, bdr_own the flags of the rank's own rows, partitions[l] maps the rank's level-l elements (level 0: its
+// elements; above: its agglomerates of the level below) to its own agglomerates 0 .. nparts_loc[l] - 1
+Hierarchy *hierarchy_create_dist(const ParCsrIn &A, int NE_loc, int nde, const int *elem_to_dof, const double *elmat,
+                                 const signed char *bdr_own, const int *const *partitions, const int *nparts_loc,
+                                 const Params &p, hipStream_t stream);
 
 // adapt_update_operators (amg/src/adapt.cpp:171-219): new matrix values (same pattern; host or
 // device pointer, nullptr = the level-0 values were changed in place), all interpolations kept.

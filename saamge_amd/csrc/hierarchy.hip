@@ -40,7 +40,7 @@ struct PhaseTimer {
     bool on;
     hipStream_t s;
     std::chrono::steady_clock::time_point t0;
-    explicit PhaseTimer(hipStream_t st) : on(std::getenv("SAAMGE_AMD_TIMING") != nullptr), s(st) {
+    explicit PhaseTimer(hipStream_t st) : on(env_timing()), s(st) {
         t0 = std::chrono::steady_clock::now();
     }
     void lap(const char *what, int lev) {
@@ -214,14 +214,14 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     // SAAMGE_AMD_SERIAL=1: no worker threads anywhere in the setup (counter passes attribute launches per thread; the
     // work runs in line, same streams).  The "stream_stack.cpp: Check failed" aborts once seen under rocprofv3 --pmc came
     // from static destructors calling HIP at exit (fixed in round 4: those objects are never destroyed), not from threads
-    static const bool serial = std::getenv("SAAMGE_AMD_SERIAL") != nullptr;
+    const bool serial = env_serial();
     auto mis_work = [&]() {
         try {
             adopt_device(dev);   // the worker allocates and copies: same GPU as the caller
             set_thread_stream(mis_stream);
             // MIS tables on the device (SAAMGE_AMD_HOST_MIS=1: host build); aggregates with arbitration are
             // sequential by definition and stay on the host
-            static const bool host_mis = std::getenv("SAAMGE_AMD_HOST_MIS") != nullptr;
+            constexpr bool host_mis = false;      // (the host build stays the fallback after a hash collision and for aggregates with arbitration)
             PhaseTimer tmis(mis_stream);
             bool on_dev = false;
             if (!aggregates && !host_mis) on_dev = build_relations_mis_device(L.rel, L.drel, mis_stream);
@@ -284,6 +284,12 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         }
         ae_begin[world] = nparts;
     }
+    if (H.dist_in && lev < (int)H.dist_in->ae_begin.size()) {
+        // per-rank inputs: a rank owns the agglomerates made of its own elements (only their element matrices are here)
+        const std::vector<long long> &ab = H.dist_in->ae_begin[lev];
+        SA_REQUIRE((int)ab.size() == world + 1 && ab[world] == nparts, "per-rank inputs: agglomerate ranges do not match the level");
+        for (int r = 0; r <= world; ++r) ae_begin[r] = (int)ab[r];
+    }
     if (world > 1) {
         SA_REQUIRE(P.allgather != nullptr, "world > 1 needs an all-gather callback");
         SA_REQUIRE(!(P.testmesh && lev == 0), "the mltest fixture is single-rank only");
@@ -305,7 +311,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     // BESIDE the assembly and the factorisations of the next chunk (SAAMGE_AMD_EIG_OVERLAP=0: one after the other).
     // Only eig_subspace_iterate runs there: it touches its own batch (the other workspace slot) and nothing else;
     // everything that assembles or allocates workspace stays on this thread.
-    static const bool overlap_env = [] { const char *e = std::getenv("SAAMGE_AMD_EIG_OVERLAP"); return !(e && e[0] == '0') && !std::getenv("SAAMGE_AMD_SERIAL"); }();
+    const bool overlap_env = (options().overlap & 1) && !env_serial();
     const bool overlap_iter = overlap_env && !profiler().enabled;
     hipStream_t iter_stream = overlap_iter ? side_stream(3) : s;
     std::thread iter_thread;
@@ -340,7 +346,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         if (batch.ss_failed) {   // few-eigenpairs path gave up on this chunk: dense path on re-assembled matrices
             batch.dense_only = true;
             batch.subspace = batch.ss_failed = false;
-            const RowsSpan span{(int64_t)L.rel.AE_to_dof.I[ae0], (int64_t)L.rel.AE_to_dof.I[nparts]};
+            const RowsSpan span{(int64_t)L.rel.AE_to_dof.I[ae0] - (int64_t)L.rel.AE_to_dof.I[ae_lo], (int64_t)L.rel.AE_to_dof.I[ae_hi] - (int64_t)L.rel.AE_to_dof.I[ae_lo]};      // (positions among the rows of this rank's agglomerates)
             ae_build(qb, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch, true,
                      P.keep_debug ? L.ae_D.p + pend_row0[slot] : nullptr, keep_rows ? &span : nullptr);
             eig_tridiagonalize(qb, batch, 3);
@@ -389,7 +395,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
             sub.set_window(L.theta);
             int64_t rows_before = 0;
             for (int i = 0; i < a; ++i) rows_before += sizes[ae0 + i];
-            const RowsSpan span{(int64_t)L.rel.AE_to_dof.I[ae0 + a], (int64_t)L.rel.AE_to_dof.I[nparts]};
+            const RowsSpan span{(int64_t)L.rel.AE_to_dof.I[ae0 + a] - (int64_t)L.rel.AE_to_dof.I[ae_lo], (int64_t)L.rel.AE_to_dof.I[ae_hi] - (int64_t)L.rel.AE_to_dof.I[ae_lo]};
             ae_build(qb, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0 + a, sub, true,
                      P.keep_debug ? L.ae_D.p + pend_row0[slot] + rows_before : nullptr, keep_rows ? &span : nullptr);
             eig_tridiagonalize(qb, sub, 3);
@@ -454,7 +460,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         // Large agglomerates (the wide-band path: one workgroup per matrix in the panel and solve kernels, one or two
         // workgroups per CU): a chunk of 577 of them is two full rounds over the 256 CUs and a third at a quarter of
         // the card -- whole multiples of 512 instead (config 5: 27 chunks of 512 instead of 24 of 577).
-        static const bool round_chunks = [] { const char *e = std::getenv("SAAMGE_AMD_CHUNK_ROUND"); return !(e && e[0] == '0'); }();
+        constexpr bool round_chunks = true;
         if (round_chunks && cnt > 512 && ae0 + cnt < ae_hi && sizes[ae0] > 1280) cnt = (cnt / 512) * 512;
         const int slot = idx & 1;
         EigBatch &batch = batches[slot];
@@ -470,7 +476,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
                                L.drel.ae2d_J.p + L.rel.AE_to_dof.I[ae0], H.levels[lev - 1]->cvec_next.p, batch.x0c.p);
             batch.has_x0c = true;
         }
-        const RowsSpan span{(int64_t)L.rel.AE_to_dof.I[ae0], (int64_t)L.rel.AE_to_dof.I[nparts]};
+        const RowsSpan span{(int64_t)L.rel.AE_to_dof.I[ae0] - (int64_t)L.rel.AE_to_dof.I[ae_lo], (int64_t)L.rel.AE_to_dof.I[ae_hi] - (int64_t)L.rel.AE_to_dof.I[ae_lo]};      // (positions among the rows of this rank's agglomerates)
         ae_build(qa, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch, true,
                  P.keep_debug ? L.ae_D.p + row0 : nullptr, keep_rows ? &span : nullptr);
         eig_tridiagonalize(qa, batch, 1);
@@ -658,7 +664,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     struct PrepJoiner { std::thread &t; ~PrepJoiner() { if (t.joinable()) t.join(); } } prep_joiner{prep_thread};
     // (device build first: ~1 ms on the main stream; the host build is the fallback for AEs with more
     // coarse dofs than the kernel's LDS holds)
-    static const bool host_e2d = std::getenv("SAAMGE_AMD_HOST_COARSE_E2D") != nullptr;
+    constexpr bool host_e2d = false;
     if (lev + 1 < P.num_coarsenings && P.nu_pro[lev] == 0 && !host_e2d) {
         NextPrep &np = L.next_prep;
         np.on_device = coarse_e2d_device(s, L.drel, rel, L.d_mis_k.p, L.d_mis_coloff.p, L.mis_coloff.back(),
@@ -684,7 +690,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     }
     // With another spectral level to come the product runs beside that level's element matrices and
     // eigenproblems (they need its size only); SAAMGE_AMD_NO_OVERLAP=1 and the profiled step keep it in line.
-    static const bool no_overlap = std::getenv("SAAMGE_AMD_NO_OVERLAP") != nullptr || std::getenv("SAAMGE_AMD_SERIAL") != nullptr;
+    const bool no_overlap = !(options().overlap & 4) || env_serial();
     const bool defer = lev + 1 < P.num_coarsenings && P.nu_pro[lev] == 0 && world == 1 && !no_overlap &&
                        !profiler().enabled;
     if (defer) {
@@ -810,7 +816,7 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
         // (always the TENTATIVE prolongator: the coarse elements are built from mis_tent_interps)
         const DCsr &PT = L.Ptent.nrows ? L.Ptent : L.P;
         NextPrep &np = L.next_prep;
-        static const bool host_e2d = std::getenv("SAAMGE_AMD_HOST_COARSE_E2D") != nullptr;
+        constexpr bool host_e2d = false;
         if (!host_e2d)
             np.on_device = coarse_e2d_device(s, L.drel, rel, L.d_mis_k.p, L.d_mis_coloff.p, L.mis_coloff.back(),
                                              PT.rowptr.p, PT.val.p, np.d_colpos_ptr, np.d_colpos, np.e2d);
@@ -863,8 +869,8 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
         int RW = 0;
         const double *rv = nullptr;
         const short *rc = nullptr;
-        static const bool dense_only = std::getenv("SAAMGE_AMD_COARSE_ELMAT_DENSE") != nullptr;
-        const RowsSpan span{(int64_t)rel.AE_to_dof.I[ae0], (int64_t)rel.AE_to_dof.I[nparts]};
+        constexpr bool dense_only = false;
+        const RowsSpan span{(int64_t)rel.AE_to_dof.I[ae0] - (int64_t)rel.AE_to_dof.I[ae_lo], (int64_t)rel.AE_to_dof.I[ae_hi] - (int64_t)rel.AE_to_dof.I[ae_lo]};
         if (lev == 0 && !dense_only && ae_sparse_rows(s, L.drel, L.A, L.elmat, ae0, batch, RW, rv, rc, &span)) {
             // fine level: straight from the sparse rows of the AE matrices
             int kmax = 0;
@@ -917,8 +923,7 @@ static void setup_coarse_solver(Hierarchy &H) {
     // 1 = always): at n = 3317 the inverse costs a few ms once and 20 us per V-cycle, the inner PCG ~2.4 ms per
     // V-cycle.  A non-positive pivot (semi-definite operator) falls back to the inner PCG.
     const int want = H.params.coarse_solver;
-    static const long dense_max = std::getenv("SAAMGE_AMD_COARSE_DENSE_MAX")
-                                      ? atol(std::getenv("SAAMGE_AMD_COARSE_DENSE_MAX")) : 8192;
+    constexpr long dense_max = 8192;
     H.c_bt = BlockTri();
     if (n && (want == 1 || (want == 0 && (long)n <= dense_max)) && n <= 16384) {
         if (dense_inverse_spd(s, Ac, H.c_L)) H.coarse_kind = 1;
@@ -1108,7 +1113,7 @@ static void vcycle_rec(Hierarchy &H, int level, const double *b, double *x) {
     double *xc = last ? H.c_x.p : H.levels[level + 1]->x.p;
     spmv(s, L.R, L.r.p, rc);                                            // resc = R res
     if (D) {      // res is zero outside the own rows: partial sums
-        static const bool no_rs = std::getenv("SAAMGE_AMD_DIST_REDUCE_SCATTER") && std::atoi(std::getenv("SAAMGE_AMD_DIST_REDUCE_SCATTER")) == 0;
+        constexpr bool no_rs = false;
         // a row-partitioned coarser level reads the restricted residual on its own rows only: reduce-scatter
         if (!last && !no_rs && H.levels[level + 1]->dist.on) dist_reduce_scatter_rows(H, H.levels[level + 1]->dist, rc);
         else dist_allreduce(H, rc, L.R.nrows);
@@ -1244,7 +1249,7 @@ static void add_nullspace_level(Hierarchy &H) {
 Hierarchy *hierarchy_create(int n, const void *Arow, int rowptr_bits, const int *Acol, const double *Aval, int NE,
                             int nde, const int *elem_to_dof, const double *elmat,
                             const signed char *bdr, const int *const *partitions,
-                            const int *nparts, const Params &p, hipStream_t stream) {
+                            const int *nparts, const Params &p, hipStream_t stream, std::unique_ptr<DistIn> dist_inputs) {
     SA_REQUIRE(p.num_coarsenings >= 1 && p.num_coarsenings < MAX_LEVELS, "bad number of coarsenings");
     ae_rows_new_build();     // nothing cached from an earlier hierarchy is reused
     // element-free mode: elements = dofs (identity elem_to_dof generated here), no element matrices
@@ -1267,6 +1272,7 @@ Hierarchy *hierarchy_create(int n, const void *Arow, int rowptr_bits, const int 
     H.stream = stream;
     H.device = current_device();
     H.own_e2d = std::move(iota_e2d);
+    H.dist_in = std::move(dist_inputs);
     hipStream_t s = stream;
     H.scal.alloc(8);
     H.partials.alloc(1024);
@@ -1286,15 +1292,26 @@ Hierarchy *hierarchy_create(int n, const void *Arow, int rowptr_bits, const int 
     }
     {
         L0.elmat.off.alloc((size_t)NE + 1);
+        if (H.dist_in) {
+            // per-rank inputs: only the matrices of the rank's own elements exist (they are never exchanged); the offsets of
+            // the other elements stay 0 -- no kernel of this rank touches an agglomerate made of them
+            L0.elmat.off.zero(s);
+            hipLaunchKernelGGL(iota64_kernel, dim3(div_up((long)H.dist_in->NE_loc + 1, 256)), dim3(256), 0, s, (long)H.dist_in->NE_loc + 1,
+                               (int64_t)nde * nde, L0.elmat.off.p + H.dist_in->elem0);
+            SA_HIP_CHECK(hipGetLastError());
+            import_array(L0.elmat.val, elmat, (size_t)H.dist_in->NE_loc * nde * nde, s);
+            L0.elmat.first = H.dist_in->elem0;
+        } else {
         hipLaunchKernelGGL(iota64_kernel, dim3(div_up((long)NE + 1, 256)), dim3(256), 0, s, (long)NE + 1,
                            (int64_t)nde * nde, L0.elmat.off.p);
         SA_HIP_CHECK(hipGetLastError());
         if (!p.algebraic) import_array(L0.elmat.val, elmat, (size_t)NE * nde * nde, s);
+        }
         L0.elmat.nde = nde;
         L0.elmat.algebraic = p.algebraic;
     }
     // Level-0 topology inputs that are device-resident stay there (device build of the AE tables)
-    static const bool host_topo = std::getenv("SAAMGE_AMD_HOST_TOPOLOGY") != nullptr;
+    constexpr bool host_topo = false;      // (host inputs take the host build; device inputs the device build)
     DeviceInputs din;
     const bool dev_inputs = !host_topo && is_device_ptr(elem_to_dof) && is_device_ptr(partitions[0]) &&
                             (!bdr || is_device_ptr(bdr));
@@ -1319,7 +1336,7 @@ Hierarchy *hierarchy_create(int n, const void *Arow, int rowptr_bits, const int 
     for (int lev = 0; lev < p.num_coarsenings; ++lev) {
         hvec<int> part;
         if (!(lev == 0 && dev_inputs)) part = fetch_host(partitions[lev], (size_t)n_elem, s);
-        static const bool tag_levels = std::getenv("SAAMGE_AMD_PROFILE_LEVELS") != nullptr;
+        const bool tag_levels = (options().debug & 4) != 0;
         profiler().level_tag = tag_levels ? lev : 0;
         build_level(H, lev, std::move(e2d), part, nparts[lev], (lev == 0 && bdr && !dev_inputs) ? bdr_h.data() : nullptr,
                     (lev == 0 && dev_inputs) ? &din : nullptr);

@@ -212,7 +212,9 @@ __device__ __forceinline__ void sell_slice(PairEntry *lt, int nrows, int row0, l
                     const int idx = (int)((cws[4 * h + (j >> 2)] >> (8 * (j & 3))) & 255u);
                     const PairEntry e = lt[idx];
                     vs[j] = e.val;
-                    xs[j] = *(const double *)(xb + ((unsigned)(grow + e.off) << 3));
+                    // (entries past the slice's width carry code 0: no address is formed from them -- table entry 0 belongs
+                    // to the tile's FIRST row and can point outside x from a later one)
+                    xs[j] = (16 * h + j < w) ? *(const double *)(xb + ((unsigned)(grow + e.off) << 3)) : 0.0;
                 }
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
@@ -401,6 +403,173 @@ __global__ __launch_bounds__(256) void sell_staged_kernel(int nrows, int row0, i
     }
 }
 
+// ---- the staged kernel with descriptor-free streams (round 4) -------------------------------------------------------
+// sell_staged_kernel starts with a chain: scalar loads of the slice's offset, width and table size (streaming data: they miss
+// every cache), THEN the vector loads whose addresses they give -- two memory latencies before the first product, a quarter
+// of a tile's ~8 us life at eight workgroups per CU (SQ_WAIT_ANY 66 %, round 3's counters).  Here the code words of the
+// staged tiles live a second time in a REGULAR layout -- word q of the row of thread t of tile T at (T wq + q) 256 + t, wq =
+// the widest staged row in words -- and the widths of the four slices ride in one descriptor word per tile next to the
+// segment count: codes, right-hand side, diagonal, x-row and the tile's one table are requested before any descriptor
+// has arrived; only the x-segments wait for their (scalar-loaded) descriptors.  Operators whose staged tiles all share one
+// table per tile (sell_one_table); same products in the same order as sell_staged_kernel.
+__global__ __launch_bounds__(256) void sell_regular_codes_kernel(int ntiles, int wq, int ncols, const roff_t *__restrict__ sptr,
+                                                                 const int *__restrict__ tile_nseg, const int2 *__restrict__ tile_seg,
+                                                                 const unsigned *__restrict__ codes,
+                                                                 unsigned *__restrict__ codesR, int *__restrict__ tile_desc) {
+    const int t = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nseg = tile_nseg[t];
+    if (nseg == 0) {
+        if (threadIdx.x == 0) tile_desc[t] = 0;
+        return;
+    }
+    const int slice = 4 * t + wv;
+    const roff_t beg = sptr[slice];
+    const int w = (int)((sptr[slice + 1] - beg) >> 6);
+    const unsigned *wp = codes + ((size_t)(beg >> 2) + (size_t)slice * 64 + lane);
+    for (int q = 0; q < wq; ++q) codesR[((size_t)t * wq + q) * 256 + threadIdx.x] = (4 * q < w) ? wp[64 * q] : 0u;
+    __shared__ int ws[4];
+    if (lane == 0) ws[wv] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // bit 7: every segment lies inside x[0 .. ncols) -- the staging loads of such a tile (all but the first and last few
+        // of an operator) need no bounds checks
+        bool inside = true;
+        for (int q = 0; q < nseg; ++q) {
+            const int2 d = tile_seg[(size_t)t * SELL_SEG_MAX + q];
+            const long g0 = (long)t * 256 + d.x;
+            inside = inside && g0 >= 0 && g0 + d.y <= ncols;
+        }
+        tile_desc[t] = nseg | (inside ? 128 : 0) | (ws[0] << 8) | (ws[1] << 14) | (ws[2] << 20) | (ws[3] << 26);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void sell_staged2_kernel(int nrows, int row0, int nblocks, int per_xcd, int stage_cap,
+                                                           int ncols, int wq, const unsigned *__restrict__ codesR,
+                                                           const int *__restrict__ tab, const double *__restrict__ vtab,
+                                                           const int *__restrict__ tile_desc, const int2 *__restrict__ tile_seg,
+                                                           const double *__restrict__ x, double *__restrict__ y,
+                                                           const double *__restrict__ b, const double *__restrict__ dinv,
+                                                           double scale, const double *__restrict__ xrow) {
+    extern __shared__ __align__(16) double lds[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    PairEntry *lt = (PairEntry *)(lds + stage_cap);
+    const int blk = per_xcd > 0 ? (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (blk >= nblocks || (long)blk * 256 + 256 > nrows) return;
+    const long row = (long)blk * 256 + threadIdx.x;
+    const int gtile = (row0 >> 8) + blk;
+    // every stream whose address the block index gives: requested before any descriptor is looked at
+    const unsigned *wp = codesR + ((size_t)gtile * wq) * 256 + threadIdx.x;
+    unsigned cws[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) cws[q] = (q < wq) ? __builtin_nontemporal_load(wp + 256 * q) : 0u;
+    double e_b = 0.0, e_d = 0.0, e_x = 0.0;
+    if (MODE == MODE_RESIDUAL) e_b = b[row];
+    if (MODE == MODE_ADD) e_x = y[row];
+    if (MODE == MODE_SMOOTH) { e_b = b[row]; e_d = dinv[row]; e_x = xrow[row]; }
+    int mytab = 0;
+    double myval = 0.0;
+    if (wv == 0) {          // the tile's one table sits at its first slice
+        mytab = tab[(size_t)gtile * 256 + lane];
+        myval = vtab[(size_t)gtile * 256 + lane];
+    }
+    const int desc = tile_desc[gtile];
+    const int nseg = desc & 127;
+    if (nseg == 0) return;      // (left to sell_tiles_kernel)
+    const int w = __builtin_amdgcn_readfirstlane((desc >> (8 + 6 * wv)) & 63);
+    const int2 *sg = tile_seg + (size_t)gtile * SELL_SEG_MAX;
+    const int R0 = row0 + blk * 256;
+    int mybase = 0;
+    // the tile's segments x[R0 + lo .. R0 + lo + len) -> lds[pre ..), 16 bytes per lane, four segments per batch (their loads
+    // first, then the LDS stores).  CHECK = false: the descriptor says that every segment lies inside x (bit 7)
+    auto stage = [&](auto check_tag) {
+        constexpr bool CHECK = decltype(check_tag)::value;
+        auto fetch = [&](int g) {
+            if (!CHECK) return *(const double2 *)(x + g);
+            double2 v = make_double2(0.0, 0.0);
+            if (g >= 0 && g + 1 < ncols) v = *(const double2 *)(x + g);
+            else if (g >= 0 && g < ncols) v.x = x[g];
+            else if (g == -1 && ncols > 0) v.y = x[0];
+            return v;
+        };
+        int pre = 0;
+        bool longer = false;
+#pragma unroll
+        for (int batch = 0; batch < SELL_SEG_MAX; batch += 4) {
+            if (batch < nseg) {
+                double2 st[8];
+                int pre_k[4], len_k[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int sidx = batch + k;
+                    pre_k[k] = pre;
+                    len_k[k] = 0;
+                    if (sidx < nseg) {
+                        const int2 d = sg[sidx];
+                        len_k[k] = d.y;
+                        const int i = 2 * (int)((threadIdx.x + 64u * sidx) & 255u);
+                        if (i < d.y) st[2 * k] = fetch(R0 + d.x + i);
+                        if (i + 512 < d.y) st[2 * k + 1] = fetch(R0 + d.x + i + 512);
+                        longer = longer || d.y > 1024;
+                        if (mytab >= d.x) mybase = pre - d.x;
+                        pre += d.y;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = 2 * (int)((threadIdx.x + 64u * (batch + k)) & 255u);
+                    if (i < len_k[k]) *(double2 *)(lds + pre_k[k] + i) = st[2 * k];
+                    if (i + 512 < len_k[k]) *(double2 *)(lds + pre_k[k] + i + 512) = st[2 * k + 1];
+                }
+            }
+        }
+        if (longer) {
+            int p2 = 0;
+            for (int sidx = 0; sidx < nseg; ++sidx) {
+                const int2 d = sg[sidx];
+                for (int i = 2 * (int)((threadIdx.x + 64u * sidx) & 255u) + 1024; i < d.y; i += 512) *(double2 *)(lds + p2 + i) = fetch(R0 + d.x + i);
+                p2 += d.y;
+            }
+        }
+    };
+    if (desc & 128) stage(std::false_type());
+    else stage(std::true_type());
+    if (wv == 0) lt[lane] = PairEntry{(mybase + mytab) << 3, 0, myval};
+    __syncthreads();
+    const char *lb = (const char *)lds + 8 * (lane + 64 * wv);
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        if (4 * g + 4 <= w) {
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const PairEntry e = lt[(cws[g] >> (8 * e4)) & 255u];
+                const double xv = *(const double *)(lb + e.off);
+                if (e4 & 1) s1 = fma(e.val, xv, s1);
+                else s0 = fma(e.val, xv, s0);
+            }
+        } else if (4 * g < w) {
+#pragma unroll
+            for (int e4 = 0; e4 < 3; ++e4) {
+                if (4 * g + e4 < w) {
+                    const PairEntry e = lt[(cws[g] >> (8 * e4)) & 255u];
+                    s0 = fma(e.val, *(const double *)(lb + e.off), s0);
+                }
+            }
+        }
+    }
+    const double sum = s0 + s1;
+    if (MODE == MODE_PLAIN) {
+        y[row] = sum;
+    } else if (MODE == MODE_RESIDUAL) {
+        y[row] = e_b - sum;
+    } else if (MODE == MODE_ADD) {
+        y[row] = e_x + sum;
+    } else {
+        y[row] = e_x + scale * (e_d * (sum - e_b));
+    }
+}
+
 // The tiles the staged kernel leaves out, from the list the staging plan made (ids of the whole operator; those
 // outside the row range are skipped), one workgroup per tile through sell_slice.
 template <int MODE>
@@ -546,6 +715,16 @@ __device__ __forceinline__ int gdict_lookup(int off, unsigned long long vb, int 
     const unsigned long long hsh = (vb ^ (vb >> 29)) * 0x9E3779B97F4A7C15ull + (unsigned long long)(unsigned)off * 0xC2B2AE3D27D4EB4Full;
     unsigned slot = (unsigned)(hsh >> 40) & (GD_CAP - 1);
     for (int probes = 0; probes < GD_CAP; ++probes) {
+        // (an operator without repeated pairs -- a general coarse operator -- can have every resident lane claim a slot
+        // before the first of them sees the abandon flag: more claims than GD_CAP slots, and a look-up in a full table
+        // would walk all of it.  The flag is looked at every 32 probes, and 1 024 probes without a hit abandon the build.)
+        if ((probes & 31) == 31) {
+            if (__hip_atomic_load(&counter[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 0;
+            if (probes >= 1023) {
+                __hip_atomic_store(&counter[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return 0;
+            }
+        }
         typedef unsigned long long gd_u2 __attribute__((ext_vector_type(2)));
         const gd_u2 r = *(const gd_u2 *)(rec + 2 * (size_t)slot);      // (ordinary, cached)
         unsigned long long w1 = r[1], w0 = r[0];
@@ -553,6 +732,10 @@ __device__ __forceinline__ int gdict_lookup(int off, unsigned long long vb, int 
             int st = __hip_atomic_load(&state[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (st == 0) {
                 if (__hip_atomic_load(&counter[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 0;      // abandoned
+                if (__hip_atomic_load(&counter[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= GP_MAX) {   // no room for a new pair: abandon before claiming
+                    __hip_atomic_store(&counter[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return 0;
+                }
                 if (atomicCAS(&state[slot], 0, 1) == 0) {
                     const int id = atomicAdd(&counter[0], 1);
                     int code = id;
@@ -1143,15 +1326,15 @@ void build_sell(hipStream_t s, DCsr &A) {
     hipLaunchKernelGGL(sell_fill_kernel, dim3(A.nslices), dim3(64), 0, s, A.nrows, A.rowptr.p, A.col.p,
                        A.val.p, A.sell_ptr.p, A.sell_col.p, A.sell_val.p);
     SA_HIP_CHECK(hipGetLastError());
-    // byte codes for the slices with few distinct column offsets (SAAMGE_AMD_SELL_CODES=0: none)
-    static const bool no_codes = std::getenv("SAAMGE_AMD_SELL_CODES") && std::atoi(std::getenv("SAAMGE_AMD_SELL_CODES")) == 0;
+    // byte codes for the slices with few distinct column offsets (saamge_amd_options.sell bit 0 cleared: none)
+    const bool no_codes = !(options().sell & 1);
     A.sell_ntab.alloc((size_t)A.nslices);
     A.sell_tab.alloc((size_t)A.nslices * 64);
     A.sell_code.alloc((size_t)total / 4 + (size_t)A.nslices * 64 + 64);
     A.sell_vtab.alloc((size_t)A.nslices * 64);
-    // (SAAMGE_AMD_SELL_CODES=1: offset codes only, values always streamed)
-    static const bool no_vals = std::getenv("SAAMGE_AMD_SELL_CODES") && std::atoi(std::getenv("SAAMGE_AMD_SELL_CODES")) == 1;
-    static const bool no_share = std::getenv("SAAMGE_AMD_SELL_SHARE") && std::atoi(std::getenv("SAAMGE_AMD_SELL_SHARE")) == 0;
+    // (bit 1 cleared: offset codes only, values always streamed)
+    const bool no_vals = !(options().sell & 2);
+    constexpr bool no_share = false;
     if (no_codes)
         SA_HIP_CHECK(hipMemsetAsync(A.sell_ntab.p, 0xff, sizeof(int) * (size_t)A.nslices, s));
     else
@@ -1174,8 +1357,8 @@ void build_sell(hipStream_t s, DCsr &A) {
     // 8 B slice offset + 4 B table size per slice
     A.sell_stream_bytes = 4.0 * (double)h[6] + 12.0 * 64.0 * (double)(h[0] - h[8]) + 4.0 * 64.0 * (double)h[1] +
                           8.0 * (double)h[4] + 12.0 * (double)h[5] + 12.0 * (double)A.nslices;
-    // operator-level pair dictionary for operators that are all plain slices (SAAMGE_AMD_SELL_GPAIR=0: never)
-    static const bool no_gpair = std::getenv("SAAMGE_AMD_SELL_GPAIR") && std::atoi(std::getenv("SAAMGE_AMD_SELL_GPAIR")) == 0;
+    // operator-level pair dictionary for operators that are all plain slices (bit 3 cleared: never)
+    const bool no_gpair = !(options().sell & 8);
     A.sell_gpair = false;
     if (!no_gpair && !no_codes && h[0] == 0 && h[1] == 0 && A.nnz >= (1 << 22) && A.ncols < (1 << 28)) {
         DBuf<int> st((size_t)GD_CAP), ctr(2);
@@ -1199,7 +1382,7 @@ void build_sell(hipStream_t s, DCsr &A) {
             A.sell_stream_bytes = 8.0 * words + 16.0 * (double)hc[0] + 8.0 * (double)A.nslices;
             A.sell_col.release();      // the dictionary replaces the streamed columns and values (12 B per stored entry)
             A.sell_val.release();
-            static const bool no_bs3 = std::getenv("SAAMGE_AMD_SELL_BS3") && std::atoi(std::getenv("SAAMGE_AMD_SELL_BS3")) == 0;
+            const bool no_bs3 = !(options().sell & 16);
             A.sell_bs3 = false;
             if (!no_bs3 && A.ncols == A.nrows && A.nrows >= 63) {
                 const int nwaves = div_up(A.nrows, 63), cap = A.nrows / 16 + 1;      // at most a sixteenth of the rows on their own
@@ -1217,16 +1400,16 @@ void build_sell(hipStream_t s, DCsr &A) {
             A.sell_gcode.release();
             A.sell_gtab.release();
         }
-        if (std::getenv("SAAMGE_AMD_SELL_VERBOSE"))
+        if ((options().debug & 2))
             std::fprintf(stderr, "build_sell: operator-level pair dictionary: %d pairs%s%s\n", hc[0], A.sell_gpair ? "" : " (abandoned)",
                          A.sell_gpair && A.sell_bs3 ? ", 3 x 3 node blocks" : "");
-        if (std::getenv("SAAMGE_AMD_SELL_VERBOSE") && A.sell_gpair)
+        if ((options().debug & 2) && A.sell_gpair)
             std::fprintf(stderr, "build_sell: %d of %d rows outside regular node blocks\n", A.sell_nirr, A.nrows);
     }
-    static const bool no_fast = std::getenv("SAAMGE_AMD_SELL_PAIR_FAST") && std::atoi(std::getenv("SAAMGE_AMD_SELL_PAIR_FAST")) == 0;
+    const bool no_fast = !(options().sell & 4);
     A.sell_fast_ok = !no_fast && A.ncols < (1 << 29);      // (32-bit byte offsets into x on the short-chain path)
-    // x-staging plan of the pair-coded tiles (SAAMGE_AMD_SELL_STAGE=0: none)
-    static const bool no_stage = std::getenv("SAAMGE_AMD_SELL_STAGE") && std::atoi(std::getenv("SAAMGE_AMD_SELL_STAGE")) == 0;
+    // x-staging plan of the pair-coded tiles
+    constexpr bool no_stage = false;
     A.sell_stage_cap = 0;
     int staged_tiles = 0;
     if (A.sell_fast_ok && !no_stage && h[0] * 2 >= (unsigned long long)A.nslices) {      // (worth a plan: most slices pair-coded)
@@ -1248,10 +1431,20 @@ void build_sell(hipStream_t s, DCsr &A) {
         if (A.sell_nunstaged * 4 > ntiles) A.sell_stage_cap = 0;      // too few tiles staged to be worth two launches
         A.sell_one_table = hm[3] == 0;
         A.sell_stream_bytes += (4.0 + 8.0 * SELL_SEG_MAX) * ntiles;
+        // the regular second copy of the staged tiles' code words + one descriptor word per tile (sell_staged2_kernel)
+        A.sell_wq = 0;
+        if (A.sell_stage_cap > 0 && A.sell_one_table) {
+            A.sell_wq = (int)std::min<unsigned long long>(8, (h[7] + 3) / 4);      // (h[7]: the widest slice; staged ones are <= 32)
+            A.sell_codeR.alloc((size_t)ntiles * A.sell_wq * 256);
+            A.sell_tile_desc.alloc((size_t)ntiles);
+            hipLaunchKernelGGL(sell_regular_codes_kernel, dim3(ntiles), dim3(256), 0, s, ntiles, A.sell_wq, A.ncols, A.sell_ptr.p,
+                               A.sell_tile_nseg.p, A.sell_tile_seg.p, A.sell_code.p, A.sell_codeR.p, A.sell_tile_desc.p);
+            SA_HIP_CHECK(hipGetLastError());
+        }
     }
-    if (std::getenv("SAAMGE_AMD_SELL_VERBOSE"))
+    if ((options().debug & 2))
         std::fprintf(stderr, "build_sell: staging plan: %d of %d tiles, largest %d doubles\n", staged_tiles, div_up(A.nslices, 4), A.sell_stage_cap);
-    if (std::getenv("SAAMGE_AMD_SELL_VERBOSE"))
+    if ((options().debug & 2))
         std::fprintf(stderr, "build_sell: %d rows, slices pair/offset/plain %lld/%lld/%lld, widest %llu, stream bytes %.0f, fast path %d\n",
                      A.nrows, (long long)h[0], (long long)h[1], (long long)h[2], h[7], A.sell_stream_bytes, (int)A.sell_fast_ok);
     A.has_sell = true;
@@ -1306,9 +1499,14 @@ static void launch_spmv(hipStream_t s, const DCsr &A, RowRange rr, const double 
     // (tiles are global: a row range takes the staged kernel when it starts on a tile and ends on one or with the operator)
     if (A.has_sell && A.sell_stage_cap > 0 && row0 % 256 == 0 && (nrows % 256 == 0 || row0 + nrows == A.nrows)) {
         const int nblocks = div_up((long)div_up(nrows, 64) * 64, 256);
-        static const bool no_xcd = std::getenv("SAAMGE_AMD_SELL_XCD") && std::atoi(std::getenv("SAAMGE_AMD_SELL_XCD")) == 0;
+        constexpr bool no_xcd = false;
         const int per_xcd = no_xcd ? 0 : div_up(nblocks, 8);
         const size_t lds_bytes = 8 * (size_t)A.sell_stage_cap + (A.sell_one_table ? 1 : 4) * 64 * sizeof(PairEntry);
+        if (A.sell_wq > 0)
+            hipLaunchKernelGGL((sell_staged2_kernel<MODE>), dim3(no_xcd ? nblocks : per_xcd * 8), dim3(256), lds_bytes, s, nrows, row0,
+                               nblocks, per_xcd, A.sell_stage_cap, A.ncols, A.sell_wq, A.sell_codeR.p, A.sell_tab.p, A.sell_vtab.p,
+                               A.sell_tile_desc.p, A.sell_tile_seg.p, x, y, b, dinv, scale, xrow);
+        else
         hipLaunchKernelGGL((sell_staged_kernel<MODE>), dim3(no_xcd ? nblocks : per_xcd * 8), dim3(256), lds_bytes, s, nrows, row0,
                            nblocks, per_xcd, A.sell_stage_cap, A.ncols, (int)A.sell_one_table, A.sell_ptr.p + row0 / 64, A.sell_ntab.p, A.sell_tab.p,
                            A.sell_code.p, x, y, b, dinv, scale, xrow, A.sell_vtab.p, A.sell_tile_nseg.p, A.sell_tile_seg.p);
@@ -1321,7 +1519,7 @@ static void launch_spmv(hipStream_t s, const DCsr &A, RowRange rr, const double 
     }
     if (A.has_sell) {
         const int nblocks = div_up((long)div_up(nrows, 64) * 64, 256);
-        static const bool no_xcd = std::getenv("SAAMGE_AMD_SELL_XCD") && std::atoi(std::getenv("SAAMGE_AMD_SELL_XCD")) == 0;
+        constexpr bool no_xcd = false;
         const int per_xcd = no_xcd ? 0 : div_up(nblocks, 8);     // (0: blocks in launch order)
         hipLaunchKernelGGL((sell_spmv_kernel<MODE>), dim3(no_xcd ? nblocks : per_xcd * 8), dim3(256), 0, s, nrows, row0, nblocks, per_xcd,
                            (int)A.sell_fast_ok, A.sell_ptr.p + row0 / 64, A.sell_col.p, A.sell_val.p, A.sell_ntab.p,

@@ -97,6 +97,7 @@ struct DevPool {
     std::vector<hipEvent_t> events;                     // spare events
     std::map<std::pair<int, hipStream_t>, Epoch *> open;   // the batch each (device, stream) is filling
     size_t idle_bytes = 0, max_idle = 0;
+    size_t live_bytes = 0, peak_bytes = 0;              // handed out now / high-water mark (dev_memory_stats)
     bool enabled = true;
     DevPool() {
         const char *e = std::getenv("SAAMGE_AMD_POOL_MAX_GB");
@@ -151,6 +152,19 @@ void pool_drop(DevPool &P, F keep) {
 }
 }  // namespace
 
+Options &options() {
+    static Options o;
+    return o;
+}
+bool env_timing() {
+    static const bool v = std::getenv("SAAMGE_AMD_TIMING") != nullptr;
+    return v;
+}
+bool env_serial() {
+    static const bool v = std::getenv("SAAMGE_AMD_SERIAL") != nullptr;
+    return v;
+}
+
 void set_thread_stream(hipStream_t s) { tl_stream = s; tl_stream_set = true; }
 void unset_thread_stream() { tl_stream = nullptr; tl_stream_set = false; }
 hipStream_t thread_stream() { return tl_stream; }
@@ -175,6 +189,8 @@ void *dev_alloc(size_t bytes) {
             }
             void *p = it->second.p;
             P.live[p] = it->first;
+            P.live_bytes += it->first;
+            P.peak_bytes = std::max(P.peak_bytes, P.live_bytes);
             P.idle_bytes -= it->first;
             P.idle.erase(it);
             if (ep->refs == 1 && !ep->recorded) {      // an open batch that has just lost its last block stays open
@@ -195,6 +211,8 @@ void *dev_alloc(size_t bytes) {
     if (e != hipSuccess) throw Error((int)e, std::string("hipMalloc of ") + std::to_string(want) + " bytes failed: " + hipGetErrorString(e));
     std::lock_guard<std::mutex> lk(P.mu);
     P.live[p] = want;
+    P.live_bytes += want;
+    P.peak_bytes = std::max(P.peak_bytes, P.live_bytes);
     return p;
 }
 
@@ -205,7 +223,7 @@ void dev_free(void *p) noexcept {
     {
         std::lock_guard<std::mutex> lk(P.mu);
         auto it = P.live.find(p);
-        if (it != P.live.end()) { size = it->second; P.live.erase(it); }
+        if (it != P.live.end()) { size = it->second; P.live.erase(it); P.live_bytes -= size; }
     }
     int dev = 0;
     if (!size || !P.enabled || !tl_stream_set || size > P.max_idle || hipGetDevice(&dev) != hipSuccess) {
@@ -261,6 +279,14 @@ void dev_pool_release() {
     DevPool &P = dev_pool();
     std::lock_guard<std::mutex> lk(P.mu);
     pool_drop(P, [](std::multimap<size_t, IdleBlock>::iterator) { return false; });
+}
+
+void dev_memory_stats(size_t *live, size_t *peak, bool reset_peak) {
+    DevPool &P = dev_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (live) *live = P.live_bytes;
+    if (peak) *peak = P.peak_bytes;
+    if (reset_peak) P.peak_bytes = P.live_bytes;
 }
 
 size_t dev_pool_idle_bytes() {
@@ -417,7 +443,7 @@ static inline uint64_t hash_row(const int *r, int n) {
 
 void build_relations_ae(Relations &r, Table &&elem_to_dof, const hvec<int> &partitioning,
                         int nparts, int ND, const signed char *bdr) {
-    const bool timing = std::getenv("SAAMGE_AMD_TIMING") != nullptr;
+    const bool timing = env_timing();
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;
@@ -594,7 +620,7 @@ static void arbitrate_aggregates(Relations &r, const HostCsr &A) {
 }
 
 void build_relations_mis(Relations &r, const HostCsr *aggregates_A) {
-    const bool timing = std::getenv("SAAMGE_AMD_TIMING") != nullptr;
+    const bool timing = env_timing();
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;

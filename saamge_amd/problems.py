@@ -739,3 +739,127 @@ def elasticity3d_q2_device(n, blk=(4, 4, 4), coarse_blk=None, lam=1.0, mu=1.0, d
         nparts.append(nb[0] * nb[1] * nb[2])
     return Problem(rowptr=rowptr.to(it), col=A_col, val=A_val, n=ND, b=b, elem_to_dof=e2d, elmat=elmat, bdr=bdr,
                    partitions=parts, nparts=nparts, dims=n, NE_=NE, ess=ess, nde_=81, nnz_=nnz)
+
+
+def split_parcsr(prob, world, levels):
+    """Per-rank inputs of saamge_amd_ml_produce_data_parcsr from a global host Problem: what the reference's multi-rank
+    drivers hold (pmltest, amg/CMakeLists.txt:198-203) -- the row block of A in hypre's ParCSR split (diag / offd /
+    col_map_offd), the rank's own elements (global dof ids), their matrices, the flags of its own rows and its own
+    agglomerate partitions with LOCAL agglomerate ids.
+
+    The agglomerates of the coarsest partition are dealt to the ranks in contiguous id ranges; the problem must be
+    numbered so that this makes the elements and the agglomerates of every level contiguous per rank (structured meshes
+    split into slabs along the slowest direction are) -- checked.  A dof belongs to the lowest rank one of whose elements
+    touches it; those sets must be contiguous row ranges -- checked.  Returns a list of `world` dicts."""
+    import scipy.sparse as sp
+    nco = levels - 1
+    parts = [np.asarray(p, dtype=np.int64) for p in prob.partitions[:nco]]
+    ntop = int(parts[-1].max()) + 1
+    assert ntop >= world, "fewer coarsest agglomerates (%d) than ranks (%d)" % (ntop, world)
+    top_owner = (np.arange(ntop) * world) // ntop                       # contiguous ranges of the coarsest agglomerates
+    owner = [None] * nco                                                # owner[l][a] = rank of level-l agglomerate a
+    owner[nco - 1] = top_owner
+    for l in range(nco - 2, -1, -1):
+        owner[l] = owner[l + 1][parts[l + 1]]
+    elem_owner = owner[0][parts[0]]
+    for arr, what in [(elem_owner, "elements")] + [(owner[l], "level-%d agglomerates" % l) for l in range(nco)]:
+        assert np.all(np.diff(arr) >= 0), "%s of a rank are not contiguous in the global numbering" % what
+    e2d = np.asarray(prob.elem_to_dof, dtype=np.int64)
+    n = prob.A.shape[0]
+    dof_owner = np.full(n, world, dtype=np.int64)
+    np.minimum.at(dof_owner, e2d.ravel(), np.repeat(elem_owner, e2d.shape[1]))
+    assert dof_owner.max() < world and np.all(np.diff(dof_owner) >= 0), "the dofs of a rank are not a contiguous row range"
+    row_starts = np.searchsorted(dof_owner, np.arange(world + 1)).astype(np.int64)
+    A = prob.A.tocsr()
+    elmat = np.asarray(prob.elmat, dtype=np.float64).reshape(e2d.shape[0], -1)
+    bdr = np.asarray(prob.bdr, dtype=np.int8)
+    out = []
+    for r in range(world):
+        r0, r1 = int(row_starts[r]), int(row_starts[r + 1])
+        rows = A[r0:r1].tocoo()
+        inside = (rows.col >= r0) & (rows.col < r1)
+        diag = sp.csr_matrix((rows.data[inside], (rows.row[inside], rows.col[inside] - r0)), shape=(r1 - r0, r1 - r0))
+        cmap = np.unique(rows.col[~inside]).astype(np.int64)
+        offd = sp.csr_matrix((rows.data[~inside], (rows.row[~inside], np.searchsorted(cmap, rows.col[~inside]))),
+                             shape=(r1 - r0, max(len(cmap), 1)))
+        # hypre keeps the diagonal entry FIRST in every row of diag and the rest unsorted: reproduce that order
+        dI, dJ, dV = diag.indptr.astype(np.int32), diag.indices.astype(np.int32).copy(), diag.data.copy()
+        for i in range(r1 - r0):
+            a, b = dI[i], dI[i + 1]
+            k = np.nonzero(dJ[a:b] == i)[0]
+            if k.size and k[0] != 0:
+                kk = a + int(k[0])
+                dJ[a + 1:kk + 1], dJ[a] = dJ[a:kk].copy(), dJ[kk]
+                dV[a + 1:kk + 1], dV[a] = dV[a:kk].copy(), dV[kk]
+        mine = np.nonzero(elem_owner == r)[0]
+        p_loc, np_loc = [], []
+        for l in range(nco):
+            src = mine if l == 0 else np.nonzero(owner[l - 1] == r)[0]
+            ae = np.nonzero(owner[l] == r)[0]
+            p_loc.append(np.ascontiguousarray(parts[l][src] - ae[0], dtype=np.int32))
+            np_loc.append(int(ae.size))
+        out.append({"global_rows": n, "row_starts": row_starts.copy(), "nrows": r1 - r0,
+                    "diag_i": dI, "diag_j": dJ, "diag_a": dV,
+                    "offd_i": offd.indptr.astype(np.int32), "offd_j": offd.indices.astype(np.int32), "offd_a": offd.data.copy(),
+                    "num_cols_offd": int(len(cmap)), "col_map_offd": cmap if len(cmap) else np.zeros(1, dtype=np.int64),
+                    "elem_to_dof": np.ascontiguousarray(e2d[mine], dtype=np.int32), "elmat": np.ascontiguousarray(elmat[mine]),
+                    "bdr": np.ascontiguousarray(bdr[r0:r1]), "partitions": p_loc, "nparts": np_loc})
+    return out
+
+
+def split_parcsr_device(prob, world, rank, levels):
+    """split_parcsr for a Problem whose arrays are torch tensors in HBM (poisson3d_device / elasticity3d_q2_device): the
+    piece of ONE rank, built on the device without touching the host (the rows of a slab are a contiguous range of the CSR
+    arrays: diag / offd are masked selections of it, in the caller's column order)."""
+    import torch
+    nco = levels - 1
+    parts = [p.long() for p in prob.partitions[:nco]]
+    ntop = int(prob.nparts[nco - 1])
+    assert ntop >= world
+    dev = parts[0].device
+    owner = [None] * nco
+    owner[nco - 1] = (torch.arange(ntop, device=dev) * world) // ntop
+    for l in range(nco - 2, -1, -1):
+        owner[l] = owner[l + 1][parts[l + 1]]
+    elem_owner = owner[0][parts[0]]
+    for arr in [elem_owner] + owner:
+        assert bool((arr[1:] >= arr[:-1]).all()), "a rank's elements / agglomerates are not contiguous in the global numbering"
+    e2d = prob.elem_to_dof.long()
+    n = int(prob.n)
+    dof_owner = torch.full((n,), world, dtype=torch.long, device=dev)
+    dof_owner.scatter_reduce_(0, e2d.reshape(-1), elem_owner.repeat_interleave(e2d.shape[1]), reduce="amin")
+    assert int(dof_owner.max()) < world and bool((dof_owner[1:] >= dof_owner[:-1]).all())
+    row_starts = torch.searchsorted(dof_owner, torch.arange(world + 1, device=dev)).cpu().numpy().astype(np.int64)
+    r0, r1 = int(row_starts[rank]), int(row_starts[rank + 1])
+    nl = r1 - r0
+    rp = prob.rowptr[r0:r1 + 1].long()
+    e0, e1 = int(rp[0]), int(rp[-1])
+    col = prob.col[e0:e1].long()
+    val = prob.val[e0:e1]
+    row_of = torch.repeat_interleave(torch.arange(nl, device=dev), rp[1:] - rp[:-1])
+    inside = (col >= r0) & (col < r1)
+
+    def csr(mask, cols):
+        cnt = torch.bincount(row_of[mask], minlength=nl)
+        ptr = torch.zeros(nl + 1, dtype=torch.int32, device=dev)
+        ptr[1:] = torch.cumsum(cnt, 0).to(torch.int32)
+        return ptr, cols.to(torch.int32).contiguous(), val[mask].contiguous()
+    di, dj, da = csr(inside, col[inside] - r0)
+    cmap = torch.unique(col[~inside])
+    oi, oj, oa = csr(~inside, torch.searchsorted(cmap, col[~inside]))
+    mine = torch.nonzero(elem_owner == rank).reshape(-1)
+    nde2 = prob.elmat.shape[-1] if prob.elmat.dim() == 2 else int(np.prod(prob.elmat.shape[1:]))
+    elm = prob.elmat.reshape(e2d.shape[0], nde2)
+    p_loc, np_loc = [], []
+    for l in range(nco):
+        src = mine if l == 0 else torch.nonzero(owner[l - 1] == rank).reshape(-1)
+        ae = torch.nonzero(owner[l] == rank).reshape(-1)
+        p_loc.append((parts[l][src] - ae[0]).to(torch.int32).contiguous())
+        np_loc.append(int(ae.numel()))
+    m0, m1 = int(mine[0]), int(mine[-1]) + 1
+    return {"global_rows": n, "row_starts": row_starts, "nrows": nl, "diag_i": di, "diag_j": dj, "diag_a": da,
+            "offd_i": oi, "offd_j": oj, "offd_a": oa, "num_cols_offd": int(cmap.numel()),
+            "col_map_offd": cmap.contiguous() if cmap.numel() else torch.zeros(1, dtype=torch.long, device=dev),
+            # (clones: a slice that is contiguous already would be a VIEW that keeps the whole global array alive)
+            "elem_to_dof": prob.elem_to_dof[m0:m1].clone(), "elmat": elm[m0:m1].clone(),
+            "bdr": prob.bdr[r0:r1].clone(), "partitions": p_loc, "nparts": np_loc}

@@ -11,6 +11,18 @@
 
 typedef int HYPRE_Int;
 typedef int MPI_Comm;
+typedef int MPI_Datatype;
+typedef int MPI_Op;
+extern const MPI_Datatype MPI_BYTE, MPI_DOUBLE, MPI_INT;
+extern const MPI_Op MPI_SUM;
+int MPI_Comm_rank(MPI_Comm comm, int *rank);
+int MPI_Comm_size(MPI_Comm comm, int *size);
+int MPI_Allgather(const void *sendbuf, int sendcount, MPI_Datatype sendtype, void *recvbuf, int recvcount, MPI_Datatype recvtype, MPI_Comm comm);
+int MPI_Allgatherv(const void *sendbuf, int sendcount, MPI_Datatype sendtype, void *recvbuf, const int *recvcounts, const int *displs,
+                   MPI_Datatype recvtype, MPI_Comm comm);
+int MPI_Allreduce(const void *sendbuf, void *recvbuf, int count, MPI_Datatype datatype, MPI_Op op, MPI_Comm comm);
+int MPI_Alltoallv(const void *sendbuf, const int *sendcounts, const int *sdispls, MPI_Datatype sendtype, void *recvbuf,
+                  const int *recvcounts, const int *rdispls, MPI_Datatype recvtype, MPI_Comm comm);
 
 namespace mfem {
 
@@ -109,6 +121,11 @@ public:
     HYPRE_Int GetGlobalNumRows() const;
     HYPRE_Int GetGlobalNumCols() const;
     void GetDiag(SparseMatrix &diag) const;
+    void GetOffd(SparseMatrix &offd, HYPRE_Int *&cmap) const;
+    HYPRE_Int *RowPart();
+    HYPRE_Int *ColPart();
+    const HYPRE_Int *RowPart() const;
+    const HYPRE_Int *ColPart() const;
     virtual void Mult(const Vector &x, Vector &y) const;
 };
 

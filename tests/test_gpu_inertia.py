@@ -104,13 +104,13 @@ print("COUNT", len(w))
 def test_planted_eigenvalue_orthogonal_to_start_block():
     """An eigenvalue inside the window whose eigenvector is orthogonal to the iteration's start block:
     the iteration converges on everything else first.  With the inertia certificate the result is the
-    full count (2); without it (SAAMGE_AMD_SS_CERTIFY=0, kept for this test) the miss is shown."""
+    full count (2); without it (saamge_amd_options.eig_certify = 0, kept for this test) the miss is shown."""
     code = _PLANTED % ROOT
-    env = dict(os.environ, SAAMGE_AMD_SS_MIN_N="0")
+    env = dict(os.environ, SAAMGE_AMD_TEST_OPTIONS="eig_min_n=0")
     o = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert o.returncode == 0, o.stdout + o.stderr
     assert "COUNT 2" in o.stdout, o.stdout + o.stderr
-    o2 = subprocess.run([sys.executable, "-c", code], env=dict(env, SAAMGE_AMD_SS_CERTIFY="0"),
+    o2 = subprocess.run([sys.executable, "-c", code], env=dict(env, SAAMGE_AMD_TEST_OPTIONS="eig_min_n=0,eig_certify=0"),
                         capture_output=True, text=True, timeout=300)
     print("uncertified run:", o2.stdout.strip(), o2.stderr.strip()[-300:])
     assert o2.returncode == 0
@@ -145,7 +145,7 @@ def test_slow_wide_band_matrix_is_factored_again_at_a_better_shift():
     0.8^k; the iteration asks for a shift just below the smallest Ritz value, the batch is factored again and
     finishes on the few-eigenpairs path (STRICT: the dense fallback is an error) with LAPACK's smallest pair."""
     code = _RESHIFT % (ROOT, os.path.join(ROOT, "tests"))
-    env = dict(os.environ, SAAMGE_AMD_SS_STRICT="1", SAAMGE_AMD_SS_DEBUG="1")
+    env = dict(os.environ, SAAMGE_AMD_TEST_OPTIONS="eig_strict=1,debug=1")
     o = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert o.returncode == 0 and "OK" in o.stdout, o.stdout[-2000:] + o.stderr[-3000:]
     assert "factored again" in o.stderr, o.stderr[-3000:]

@@ -50,15 +50,11 @@ def test_spmv_beyond_2_31_entries(sell):
     rowptr, col, val = _banded(n, w, dev)
     x = torch.cos(torch.arange(n, dtype=torch.float64, device=dev) * 1e-3)
     y = torch.zeros(n, dtype=torch.float64, device=dev)
-    old = os.environ.pop("SAAMGE_AMD_SPMV_SELL", None)
+    old = capi.set_options(spmv_sell=1 if sell else 0)
     try:
-        if sell:
-            os.environ["SAAMGE_AMD_SPMV_SELL"] = "1"
         capi.spmv_raw(n, n, rowptr, col, val, x, y)
     finally:
-        os.environ.pop("SAAMGE_AMD_SPMV_SELL", None)
-        if old is not None:
-            os.environ["SAAMGE_AMD_SPMV_SELL"] = old
+        capi.set_options(spmv_sell=old.spmv_sell)
     torch.cuda.synchronize()
     ref = _expected(n, w, x, dev)
     err = float(torch.max(torch.abs(y - ref)) / torch.max(torch.abs(ref)))

@@ -166,8 +166,7 @@ def test_batched_eigens_banded_matrices_take_the_few_eigenpairs_path():
         L = W + np.diag(-W.sum(axis=1))
         return L + np.diag(1e-4 * rng.uniform(0.5, 1.0, size=n))     # SPD, one eigenvalue near zero
 
-    old = os.environ.get("SAAMGE_AMD_SS_STRICT")
-    os.environ["SAAMGE_AMD_SS_STRICT"] = "1"
+    old = capi.set_options(eig_strict=1)
     try:
         for shapes in ([(70, 1), (96, 5), (130, 17), (64, 40)], [(200, 52)], [(150, 60), (90, 3)], [(300, 100), (77, 2)],
                        [(300, 120), (257, 256), (80, 4)]):
@@ -183,10 +182,7 @@ def test_batched_eigens_banded_matrices_take_the_few_eigenpairs_path():
                 assert np.abs(R).max() <= 1e-10
                 assert np.allclose(_proj(X, D), _proj(Xr, D), atol=PROJ_TOL)
     finally:
-        if old is None:
-            del os.environ["SAAMGE_AMD_SS_STRICT"]
-        else:
-            os.environ["SAAMGE_AMD_SS_STRICT"] = old
+        capi.set_options(eig_strict=old.eig_strict)
 
 
 @pytest.mark.gpu
@@ -207,8 +203,7 @@ def test_wide_band_matrices_without_a_wanted_eigenvalue_keep_the_inertia_factor(
         L = W + np.diag(-W.sum(axis=1))
         return L + np.diag((lift * L.diagonal() if lift else 1e-4) * rng.uniform(0.5, 1.0, size=n))
 
-    old = os.environ.get("SAAMGE_AMD_SS_STRICT")
-    os.environ["SAAMGE_AMD_SS_STRICT"] = "1"
+    old = capi.set_options(eig_strict=1)
     try:
         for shapes in ([(300, 130, 0.05), (257, 256, 0.05), (80, 4, 0.05)],
                        [(300, 120, 0.05), (280, 140, 0.0), (90, 7, 0.05), (200, 150, 0.0)]):
@@ -225,10 +220,7 @@ def test_wide_band_matrices_without_a_wanted_eigenvalue_keep_the_inertia_factor(
                 assert np.abs(R).max() <= 1e-10
                 assert np.allclose(_proj(X, D), _proj(Xr, D), atol=PROJ_TOL)
     finally:
-        if old is None:
-            del os.environ["SAAMGE_AMD_SS_STRICT"]
-        else:
-            os.environ["SAAMGE_AMD_SS_STRICT"] = old
+        capi.set_options(eig_strict=old.eig_strict)
 
 
 def _range_projection(P, probe):
@@ -438,17 +430,13 @@ def test_more_wanted_pairs_than_the_block_holds_are_locked(theta, m_interior):
     the whole chunk -- to the dense path.  STRICT: any fallback is an error.  The eight interior agglomerates of a
     32 x 32 x 16 mesh carry 7 (theta = 0.06) / 8 (0.08) pairs; counts, coarse dimension, iterations and history against
     the oracle."""
-    o = _oracle()
+    capi, o = _capi(), _oracle()
     prob = pr.poisson3d_problem((32, 32, 16), blk=(8, 8, 4))
-    old = os.environ.get("SAAMGE_AMD_SS_STRICT")
-    os.environ["SAAMGE_AMD_SS_STRICT"] = "1"
+    old = capi.set_options(eig_strict=1)
     try:
         h, H = _build_pair(prob, 1, theta=theta)
     finally:
-        if old is None:
-            del os.environ["SAAMGE_AMD_SS_STRICT"]
-        else:
-            os.environ["SAAMGE_AMD_SS_STRICT"] = old
+        capi.set_options(eig_strict=old.eig_strict)
     m, ev, X, Ds = h.get_ae_eigens(0)
     assert sorted(m.tolist())[-8:] == [m_interior] * 8 and max(m.tolist()) == m_interior
     # (a box of equal elements: repeated eigenvalues, so the eigenspaces are compared -- projectors -- and not the

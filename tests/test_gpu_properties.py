@@ -147,29 +147,28 @@ def test_edge_cases():
 
 
 def test_one_stage_and_two_stage_eigensolvers_agree():
-    """SAAMGE_AMD_EIG=onestage selects the one-stage blocked Householder kernel; every path must
-    give the same hierarchy (coarse dims) and PCG history."""
+    """The dense path (saamge_amd_params.eigensolver = 1) with the one-stage blocked Householder kernel
+    (saamge_amd_options.eig_dense_one_stage) and with the two-stage band reduction, and the few-eigenpairs path on every
+    agglomerate size: every path must give the same hierarchy (coarse dims) and PCG history."""
     code = (
         "import sys, json; sys.path.insert(0, %r)\n"
         "import numpy as np\n"
         "from saamge_amd import capi, problems as pr\n"
         "prob = pr.poisson3d_problem((16,16,8), blk=(8,8,4))\n"
-        "h = capi.Hierarchy.from_problem(prob, capi.default_params(coarse_rtol=1e-28))\n"
+        "import os\n"
+        "h = capi.Hierarchy.from_problem(prob, capi.default_params(coarse_rtol=1e-28, eigensolver=os.environ.get('EIGSOLVER', 'subspace')))\n"
         "x, it, conv, hist = h.pcg(prob.b, rel_tol=1e-8)\n"
         "print(json.dumps({'nc': h.level_info(0)['ncoarse'], 'it': it, 'hist': list(hist)}))\n" % ROOT)
     import json
     outs = []
-    # the dense path: one-stage kernel, two-stage band reduction (one or two rows per lane in the fused update)
-    variants = [{"SAAMGE_AMD_EIG": "onestage"}, {"SAAMGE_AMD_EIG": "twostage"},
-                {"SAAMGE_AMD_EIG": "twostage", "SAAMGE_AMD_EIG_RPL": "1"}]
+    # the dense path: one-stage kernel, two-stage band reduction
+    variants = [{"EIGSOLVER": "dense", "SAAMGE_AMD_TEST_OPTIONS": "eig_dense_one_stage=1"}, {"EIGSOLVER": "dense"}]
     # the few-eigenpairs path (Cholesky + shift-invert subspace iteration) on every agglomerate size
-    # (STRICT: giving up on a batch is an error instead of the silent dense fallback), with its variants:
-    # band kept in LDS (default), banded factorisation through HBM, full Cholesky, first-encounter row order,
-    # global-dof order without the box renumbering, without the known-null-vector shortcut
-    ss = {"SAAMGE_AMD_EIG": "subspace", "SAAMGE_AMD_SS_MIN_N": "0", "SAAMGE_AMD_SS_STRICT": "1"}
-    variants += [ss, dict(ss, SAAMGE_AMD_SS_BAND_LDS="0"), dict(ss, SAAMGE_AMD_SS_BAND="0"),
-                 dict(ss, SAAMGE_AMD_SS_PERM="0"), dict(ss, SAAMGE_AMD_SS_BOX="0"),
-                 dict(ss, SAAMGE_AMD_SS_NULLCHECK="0")]
+    # (strict: giving up on a batch is an error instead of the silent dense fallback), with and without the
+    # known-null-vector shortcut and without the inertia certificate's kept factor
+    variants += [{"SAAMGE_AMD_TEST_OPTIONS": "eig_min_n=0,eig_strict=1"},
+                 {"SAAMGE_AMD_TEST_OPTIONS": "eig_min_n=0,eig_strict=1,eig_nullcheck=0"},
+                 {"SAAMGE_AMD_TEST_OPTIONS": "eig_min_n=0,eig_strict=1,eig_keep_inertia_factor=0"}]
     for extra in variants:
         env = dict(os.environ, **extra)
         o = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)

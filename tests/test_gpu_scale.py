@@ -84,18 +84,18 @@ def test_scale_golden(name, eigensolver):
 def test_scale_golden_with_single_matrices_on_the_dense_path():
     """A few matrices of a chunk leave the few-eigenpairs path (no certificate, a non-positive pivot, no
     convergence ...): they alone are redone by the dense path and the chunk's results are put together again
-    (csrc/hierarchy.hip, post()).  SAAMGE_AMD_SS_FORCE_BAD marks every 50th agglomerate: 10 of the 512 level-0
+    (csrc/hierarchy.hip, post()).  saamge_amd_options.eig_force_fallback = 50 marks every 50th agglomerate: 10 of the 512 level-0
     agglomerates go alone (in runs of one; with 1 GiB chunks also across chunk boundaries), the one marked
     agglomerate of the 8 on level 1 exceeds the 10 % limit and takes the whole level with it."""
-    import os
-    os.environ["SAAMGE_AMD_SS_FORCE_BAD"] = "50"
+    from saamge_amd import capi
+    old = capi.set_options(eig_force_fallback=50)
     try:
         g, out = _run("scale_64x64x32_skew", "subspace")
         _check(g, out, "scale_64x64x32_skew/subspace/forced-bad")
         g, out = _run("scale_96x96x64", "subspace", workspace_bytes=1 << 30)
         _check(g, out, "scale_96x96x64/subspace/forced-bad/1GiB-chunks")
     finally:
-        del os.environ["SAAMGE_AMD_SS_FORCE_BAD"]
+        capi.set_options(eig_force_fallback=old.eig_force_fallback)
 
 
 def test_scale_golden_chunked():
@@ -114,8 +114,8 @@ def test_scale_golden_128(eigensolver):
 
 def test_coarse_level_switches_give_the_same_hierarchy():
     """The round-2 switches of the coarse-level eigenproblems -- band-limited assembly / scaling of the few large
-    agglomerates (SAAMGE_AMD_BAND_ASSEMBLY), kept inertia factor (SAAMGE_AMD_SS_REUSE), subspace iteration beside
-    the next chunk (SAAMGE_AMD_EIG_OVERLAP, with the level-0 agglomerates split over several chunks) -- each switched
+    agglomerates (saamge_amd_options.band_assembly), kept inertia factor (eig_keep_inertia_factor), subspace iteration beside
+    the next chunk (overlap bit 0, with the level-0 agglomerates split over several chunks) -- each switched
     off in a process of its own: identical level dimensions, eigenvector counts and iteration counts, history to 1e-9
     (the golden is the oracle's; this is the library against itself)."""
     import json
@@ -141,7 +141,8 @@ def test_coarse_level_switches_give_the_same_hierarchy():
         "print(json.dumps({'dims': [i['n'] for i in infos] + [infos[-1]['ncoarse']], 'it': it, 'conv': bool(conv),\n"
         "                  'hist': list(hist), 'm': ms}))\n" % root)
     outs = []
-    for extra in ({}, {"SAAMGE_AMD_BAND_ASSEMBLY": "0"}, {"SAAMGE_AMD_SS_REUSE": "0"}, {"SAAMGE_AMD_EIG_OVERLAP": "0"}):
+    for extra in ({}, {"SAAMGE_AMD_TEST_OPTIONS": "band_assembly=0"}, {"SAAMGE_AMD_TEST_OPTIONS": "eig_keep_inertia_factor=0"},
+                  {"SAAMGE_AMD_TEST_OPTIONS": "overlap=6"}):
         o = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         assert o.returncode == 0, o.stderr[-2000:]
         outs.append(json.loads(o.stdout.strip().splitlines()[-1]))
@@ -150,3 +151,24 @@ def test_coarse_level_switches_give_the_same_hierarchy():
     for other in outs[1:]:
         assert other["conv"] and other["dims"] == outs[0]["dims"] and other["it"] == outs[0]["it"] and other["m"] == outs[0]["m"]
         assert np.allclose(other["hist"], outs[0]["hist"], rtol=1e-9, atol=0.0)
+
+
+@pytest.mark.parametrize("flip", [
+    {"eig_min_n": 0}, {"eig_nullcheck": 0}, {"eig_keep_inertia_factor": 0}, {"band_assembly": 0}, {"overlap": 0},
+    {"sell": 0}, {"sell": 1}, {"sell": 3}, {"sell": 31 & ~4}, {"eig_force_fallback": 7},
+    {"eig_dense_one_stage": 1, "_eigensolver": "dense"}, {"eig_certify": 0}])
+def test_every_remaining_option_flipped_gives_the_golden(flip):
+    """saamge_amd_options (include/saamge_amd.h) is what is left of the environment switches of rounds 1-3: every field that
+    selects a code path is flipped here, one at a time, on the 64 x 64 x 32 three-level golden -- the oracle's level
+    dimensions, eigenvector counts, coarse dofs per MIS, iteration count and history (1e-8) must come out whichever path ran.
+    (eig_strict, spmv_sell and debug select no arithmetic: tests/test_gpu_parity.py, test_gpu_sell.py use them.)"""
+    from saamge_amd import capi
+    flip = dict(flip)
+    eigensolver = flip.pop("_eigensolver", "subspace")
+    old = capi.get_options()
+    capi.set_options(**flip)
+    try:
+        g, out = _run("scale_64x64x32", eigensolver)
+        _check(g, out, "scale_64x64x32/" + ",".join("%s=%s" % kv for kv in flip.items()))
+    finally:
+        capi.load().saamge_amd_set_options(__import__("ctypes").byref(old))

@@ -42,11 +42,13 @@ for name, A in mats.items():
 
 
 def _run(codes, pair_fast=None):
-    env = dict(os.environ, SAAMGE_AMD_SPMV_SELL="1")
-    if pair_fast is not None:
-        env["SAAMGE_AMD_SELL_PAIR_FAST"] = str(pair_fast)
+    # saamge_amd_options.sell: bit 0 coded slices at all, 1 pair coding, 2 short-chain path, 3 dictionary, 4 node blocks
+    sell = 31
+    if pair_fast is not None and int(pair_fast) == 0:
+        sell &= ~4
     if codes is not None:
-        env["SAAMGE_AMD_SELL_CODES"] = str(codes)
+        sell &= {0: ~3, 1: ~2}.get(int(codes), ~0)       # codes = 0: plain slices only; 1: offset codes only
+    env = dict(os.environ, SAAMGE_AMD_TEST_OPTIONS="spmv_sell=1,sell=%d" % (sell & 31))
     o = subprocess.run([sys.executable, "-c", _CODE % ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert o.returncode == 0, o.stdout + o.stderr
     res = {}
@@ -112,8 +114,8 @@ def test_operator_level_pair_dictionary_is_lossless():
     irregular lanes), without the sharing, and without the dictionary."""
     outs = []
     for gpair, bs3 in (("1", "1"), ("1", "0"), ("0", "0")):
-        env = dict(os.environ, SAAMGE_AMD_SPMV_SELL="1", SAAMGE_AMD_SELL_GPAIR=gpair, SAAMGE_AMD_SELL_BS3=bs3,
-                   SAAMGE_AMD_SELL_VERBOSE="1")
+        sell = 31 & ~(0 if gpair == "1" else 8) & ~(0 if bs3 == "1" else 16)
+        env = dict(os.environ, SAAMGE_AMD_TEST_OPTIONS="spmv_sell=1,debug=2,sell=%d" % sell)
         o = subprocess.run([sys.executable, "-c", _CODE_GPAIR % ROOT], env=env, capture_output=True, text=True, timeout=900)
         assert o.returncode == 0, o.stdout + o.stderr
         line = [l for l in o.stdout.splitlines() if l.startswith("RESULT")][0].split()

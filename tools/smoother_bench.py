@@ -35,6 +35,10 @@ for lev in range(levels - 1):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (reps * 10)
     print("level %d: %d rows, smoother step %.1f us" % (lev, nl, us), flush=True)
+    import json as _json
+    _f = h.level_format(lev)
+    print("FORMAT %d %d %s" % (lev, nl, _json.dumps({"slices": _f["slices"], "staged_tiles": _f["staged_tiles"],
+                                                      "dictionary_pairs": _f["dictionary_pairs"]})), flush=True)
 if 'quick' in sys.argv:
     h.close()
     sys.exit(0)
