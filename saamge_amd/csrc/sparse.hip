@@ -148,6 +148,8 @@ struct alignas(16) PairEntry {
     int off, pad;
     double val;
 };
+// (Measured, round 4: the whole 16-byte entry with ONE LDS instruction -- ds_read_b128 instead of the ds_read_b32 + ds_read_b64 a
+// member-wise read becomes -- 233 against 230 us per fine-level smoother step: the LDS data path, not its instruction count.)
 
 // ---- the SELL-64 kernels of the whole SpMV family: one wavefront per slice, one lane per row ----------------------
 // What bounds them (MI355X, 257^3 rows x 27 entries, counters + tools/spmv_lab, tools/vmem_rate): not HBM.  A

@@ -20,7 +20,7 @@ has() { [[ " $PARTS " == *" $1 "* ]]; }
 
 if has stats; then
   cd /tmp
-  timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-general --warmup 1 --steps 2 > $O/stats_bench.json 2> $O/stats_bench.err
+  timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-general --no-others --warmup 1 --steps 2 > $O/stats_bench.json 2> $O/stats_bench.err
   echo "stats rc=$?"
   cd $R
 fi
@@ -42,7 +42,7 @@ if has sq; then
            "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i+1))
     timeout -k 10 150 rocprofv3 --pmc $C --kernel-include-regex "chol_band_lds|ae_rows8|ae_build|rap_numeric|rap_symbolic|ss_trsolve|gj_panel|gj_apply|coarse_elmat|chol_panel|sbr_fused|mis_svd|ss_solve_lds|ss_rr" \
-        --kernel-trace --output-format csv -d $O/sq/p$i -o p -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-general --warmup 0 --steps 1 > $O/sq_p$i.log 2>&1
+        --kernel-trace --output-format csv -d $O/sq/p$i -o p -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-general --no-others --warmup 0 --steps 1 > $O/sq_p$i.log 2>&1
     echo "sq pass $i rc=$?"
   done
   unset SAAMGE_AMD_SERIAL
@@ -50,7 +50,7 @@ if has sq; then
   python3 tools/pmc_summary.py $O/sq | cut -c1-1200 > $O/sq_counters.txt
 fi
 if has timing; then
-  SAAMGE_AMD_TIMING=1 python3 bench.py --no-cpu-baseline --no-roofline --no-general --warmup 1 --steps 1 2> $O/phase_timing.err > /dev/null
+  SAAMGE_AMD_TIMING=1 python3 bench.py --no-cpu-baseline --no-roofline --no-general --no-others --warmup 1 --steps 1 2> $O/phase_timing.err > /dev/null
   grep TIMING $O/phase_timing.err | tail -31 > $O/phase_timing_256.txt
   echo "timing done"
 fi

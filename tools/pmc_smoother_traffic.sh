@@ -8,7 +8,7 @@ R=$PWD; O=$R/gpurun_out/$1; N=${2:-256}
 mkdir -p $O
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $C --kernel-include-regex "sell_staged_kernel|sell_tiles_kernel" --kernel-trace --output-format csv -d $O/$C -o p -- python3 $R/tools/smoother_bench.py $N 3 quick > $O/$C.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $C --kernel-include-regex "sell_staged|sell_tiles_kernel" --kernel-trace --output-format csv -d $O/$C -o p -- python3 $R/tools/smoother_bench.py $N 3 quick > $O/$C.log 2>&1
   echo "pass $C rc=$?"
 done
 cd $R
