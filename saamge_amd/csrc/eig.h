@@ -78,6 +78,8 @@ struct EigBatch {
     bool has_x0c = false;
     void set_window(double vu_) { has_window = true; window_vu = vu_; }
     bool subspace = false, dense_only = false, ss_failed = false;
+    int ss_nb = 8;                // vectors of the iteration's block: 8 (bands resident in LDS), 16 (wide bands: the solves' matrix-core tiles
+                                  // are 16 columns wide either way, the block converges at (lambda_i - sigma) / (lambda_17 - sigma))
     double ss_tol = 1e-12;        // acceptance bound of a Ritz pair's residual (saamge_amd_params.eig_tol)
     // few-eigenpairs path, per matrix: h_bad[i] = 1 -- this matrix has to be redone by the dense path (more wanted
     // pairs than the block holds, no certificate, a non-positive pivot, no or hopeless convergence, a count that

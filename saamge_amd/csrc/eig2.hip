@@ -1692,6 +1692,7 @@ __global__ __launch_bounds__(NC_NT) void ss_nullcheck_kernel(const int *__restri
 
 // accepted-before-the-iteration matrices: column 0 of X becomes the unit eigenvector, mu the Ritz value, the
 // state "converged, one pair inside the window, one pair returned"
+template <int NB = 8>
 __global__ __launch_bounds__(256) void ss_preaccept_kernel(const int *__restrict__ ns, const int64_t *__restrict__ voff,
                                                            const int *__restrict__ pre, const double *__restrict__ pre_val,
                                                            const double *__restrict__ sigmas, double *__restrict__ X,
@@ -1701,9 +1702,9 @@ __global__ __launch_bounds__(256) void ss_preaccept_kernel(const int *__restrict
     const int n = ns[b];
     double *Xb = X + voff[b] * SB;
     const double sc = pre_val[2 * b + 1];
-    for (int r = threadIdx.x; r < n; r += 256) Xb[(size_t)r * SS_B] *= sc;
+    for (int r = threadIdx.x; r < n; r += 256) Xb[(size_t)r * NB] *= sc;
     if (threadIdx.x == 0) {
-        mu[(size_t)b * SS_B] = pre_val[2 * b] - sigmas[b];
+        mu[(size_t)b * NB] = pre_val[2 * b] - sigmas[b];
         state[b] = 1 | (1 << 4) | (1 << 8);
     }
 }
@@ -1711,6 +1712,7 @@ __global__ __launch_bounds__(256) void ss_preaccept_kernel(const int *__restrict
 // Start block: column 0 = D^1/2 1 (the exact null vector of C for an agglomerate without essential
 // rows -- most of them -- and a smooth first guess otherwise), the rest pseudo-random.  No
 // dependence on the batch: the same vectors on any rank / chunking.
+template <int NB = 8>
 __global__ __launch_bounds__(256) void ss_init_kernel(const int *__restrict__ ns, const int64_t *__restrict__ voff,
                                                       const double *__restrict__ dis, const short *__restrict__ perm,
                                                       double *__restrict__ X, const double *__restrict__ x0c = nullptr) {
@@ -1720,32 +1722,33 @@ __global__ __launch_bounds__(256) void ss_init_kernel(const int *__restrict__ ns
     double *Xb = X + voff[b] * SB;
     const double *db = dis + voff[b];
     const short *pm = perm ? perm + voff[b] : nullptr;
-    for (int idx = threadIdx.x; idx < n * SS_B; idx += 256) {
-        const int r = idx >> 3, pr = pm ? pm[r] : r;       // (dis is in agglomerate order, the matrix in perm order)
-        Xb[pr * SS_B + (idx & 7)] = ((idx & 7) == 0) ? (x0c ? x0c[voff[b] + r] : 1.0) / db[r] : unit_rand_ss((unsigned)(pr * SS_B + (idx & 7)), (unsigned)n);
+    for (int idx = threadIdx.x; idx < n * NB; idx += 256) {
+        const int r = idx / NB, pr = pm ? pm[r] : r;       // (dis is in agglomerate order, the matrix in perm order)
+        Xb[pr * NB + (idx % NB)] = ((idx % NB) == 0) ? (x0c ? x0c[voff[b] + r] : 1.0) / db[r] : unit_rand_ss((unsigned)(pr * NB + (idx % NB)), (unsigned)n);
     }
 }
 
+template <int NB = 8>
 __global__ __launch_bounds__(256) void ss_copy_active_kernel(const int *__restrict__ ns, const int64_t *__restrict__ voff,
                                                              const int *__restrict__ active, const double *__restrict__ X,
                                                              double *__restrict__ Z) {
     const int b = active[blockIdx.x];
-    const size_t base = (size_t)voff[b] * SB, cnt = (size_t)ns[b] * SS_B;
+    const size_t base = (size_t)voff[b] * SB, cnt = (size_t)ns[b] * NB;
     for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < cnt; i += (size_t)256 * gridDim.y) Z[base + i] = X[base + i];
 }
 
 // X <- T^-1 X for the lower (UPPER = false: L y = x) or the upper (UPPER = true: L^T z = y) factor,
 // SS_B right-hand sides, rows x SS_B row-major.  Right-looking by blocks of SB: the solved block
 // is eliminated from the remaining rows with coalesced column reads (the upper triangle holds L^T).
-template <bool UPPER, int NT>
+template <bool UPPER, int NT, int NB = 8>
 __global__ __launch_bounds__(NT) void ss_trsolve_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
                                                          const int64_t *__restrict__ voff,
                                                          const double *__restrict__ W, double *__restrict__ X,
                                                          const int *__restrict__ state, const int *__restrict__ bws,
         const int *__restrict__ active = nullptr) {
     __shared__ double Td[SB][SB + 1];
-    __shared__ double ys[SB][SS_B];
-    __shared__ double xs[2][SB][SS_B];       // right-hand side rows of the current / next block
+    __shared__ double ys[SB][NB];
+    __shared__ double xs[2][SB][NB];       // right-hand side rows of the current / next block
     const int b = active ? active[blockIdx.x] : (int)blockIdx.x, n = ns[b];     // (active: the matrices still iterating)
     if (state[b] & 3) return;
     // the factor is zero beyond this distance from the diagonal (at least SB: the rows of the next
@@ -1765,9 +1768,9 @@ __global__ __launch_bounds__(NT) void ss_trsolve_kernel(const int *__restrict__ 
     {
         const int k0 = UPPER ? (nblk - 1) * SB : 0;
         const int nb = min(SB, n - k0);
-        if (tid < SB * SS_B) {
-            const int c = tid >> 3, jj = tid & 7;
-            xs[0][c][jj] = (c < nb) ? Xb[(size_t)(k0 + c) * SS_B + jj] : 0.0;
+        if (tid < SB * NB) {
+            const int c = tid / NB, jj = tid % NB;
+            xs[0][c][jj] = (c < nb) ? Xb[(size_t)(k0 + c) * NB + jj] : 0.0;
         }
     }
     double td_next = load_td(UPPER ? (nblk - 1) * SB : 0);
@@ -1777,13 +1780,13 @@ __global__ __launch_bounds__(NT) void ss_trsolve_kernel(const int *__restrict__ 
         const int cur = bb & 1;
         if (tid < SB * SB) Td[ti][tj] = td_next;
         __syncthreads();
-        if (tid < SB * SS_B) {      // y = T11^-1 x
-            const int c = tid >> 3, jj = tid & 7;
+        if (tid < SB * NB) {      // y = T11^-1 x
+            const int c = tid / NB, jj = tid % NB;
             double t = 0.0;
 #pragma unroll
             for (int i = 0; i < SB; ++i) t = fma(Td[c][i], xs[cur][i][jj], t);
             ys[c][jj] = (c < nb) ? t : 0.0;
-            if (c < nb) Xb[(size_t)(k0 + c) * SS_B + jj] = t;
+            if (c < nb) Xb[(size_t)(k0 + c) * NB + jj] = t;
         }
         // the next block's inverse is requested now; its rows of the right-hand side are caught in LDS by
         // the threads that update them below
@@ -1792,9 +1795,9 @@ __global__ __launch_bounds__(NT) void ss_trsolve_kernel(const int *__restrict__ 
         __syncthreads();
         const int r_lo = UPPER ? max(0, k0 - bw) : k0 + nb, r_hi = UPPER ? k0 : min(n, k0 + nb + bw);
         for (int r = r_lo + tid; r < r_hi; r += NT) {
-            double acc[SS_B];
+            double acc[NB];
 #pragma unroll
-            for (int j = 0; j < SS_B; ++j) acc[j] = Xb[(size_t)r * SS_B + j];
+            for (int j = 0; j < NB; ++j) acc[j] = Xb[(size_t)r * NB + j];
             const double *ap = A + (size_t)k0 * n + r;        // T(r, k0 + c): column k0 + c, row r
 #pragma unroll 1
             for (int c = 0; c < SB; c += 8) {     // eight factor entries in flight (ys is zero past the block)
@@ -1804,18 +1807,18 @@ __global__ __launch_bounds__(NT) void ss_trsolve_kernel(const int *__restrict__ 
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
 #pragma unroll
-                    for (int j = 0; j < SS_B; ++j) acc[j] = fma(-t[u], ys[c + u][j], acc[j]);
+                    for (int j = 0; j < NB; ++j) acc[j] = fma(-t[u], ys[c + u][j], acc[j]);
             }
             const bool in_next = (r >= kn && r < kn + SB);
 #pragma unroll
-            for (int j = 0; j < SS_B; ++j) {
-                Xb[(size_t)r * SS_B + j] = acc[j];
+            for (int j = 0; j < NB; ++j) {
+                Xb[(size_t)r * NB + j] = acc[j];
                 if (in_next) xs[cur ^ 1][r - kn][j] = acc[j];
             }
         }
         if (bb + 1 < nblk) {        // rows of the next block beyond the matrix (partial last block of the forward solve)
-            if (tid < SB * SS_B) {
-                const int c = tid >> 3, jj = tid & 7;
+            if (tid < SB * NB) {
+                const int c = tid / NB, jj = tid % NB;
                 if (kn + c >= n) xs[cur ^ 1][c][jj] = 0.0;
             }
         }
@@ -1842,15 +1845,15 @@ typedef double ss_v4d __attribute__((ext_vector_type(4)));
 constexpr int TW_NT = 1024;      // threads
 // TW_TPW: tiles of 16 rows per wavefront whose factor entries are requested a step ahead (4: one workgroup per CU;
 // 0: nothing ahead, few enough registers for two workgroups per CU -- chunks of more than 256 matrices)
-template <bool UPPER, int TW_TPW, int WGS>
+template <bool UPPER, int TW_TPW, int WGS, int NB = 8>
 __global__ __launch_bounds__(TW_NT) __attribute__((amdgpu_waves_per_eu(4 * WGS, 4 * WGS))) void ss_trsolve_win_kernel(int WR, const int *__restrict__ ns, const int64_t *__restrict__ moff,
                                                                 const int64_t *__restrict__ voff,
                                                                 const double *__restrict__ W, double *__restrict__ X,
                                                                 const int *__restrict__ state, const int *__restrict__ bws,
                                                                 const int *__restrict__ active) {
-    extern __shared__ __align__(16) double win[];      // [SS_B][WR]: WR is odd
+    extern __shared__ __align__(16) double win[];      // [NB][WR]: WR is odd
     __shared__ double Td[SB][SB + 1];
-    __shared__ double ys[SB][SS_B];
+    __shared__ double ys[SB][NB];
     const int b = active ? active[blockIdx.x] : (int)blockIdx.x, n = ns[b];
     if (state[b] & 3) return;
     const int bw = min(bws ? max(bws[b], SB) : n, WR - 2 * SB);
@@ -1888,9 +1891,9 @@ __global__ __launch_bounds__(TW_NT) __attribute__((amdgpu_waves_per_eu(4 * WGS, 
         for (int kk = 0; kk < 4; ++kk) a[kk] = (ok && 4 * kk + l4 < nb) ? a[kk] : 0.0;
     };
     const int kfirst = UPPER ? (nblk - 1) * SB : 0;
-    for (int idx = tid; idx < (bw + SB) * SS_B; idx += TW_NT) {      // the first window: positions 0 .. bw + SB - 1
-        const int p = idx >> 3, r = row_at(kfirst, p);
-        win[(idx & 7) * WR + p] = (r >= 0 && r < n) ? Xb[(size_t)r * SS_B + (idx & 7)] : 0.0;
+    for (int idx = tid; idx < (bw + SB) * NB; idx += TW_NT) {      // the first window: positions 0 .. bw + SB - 1
+        const int p = idx / NB, r = row_at(kfirst, p);
+        win[(idx % NB) * WR + p] = (r >= 0 && r < n) ? Xb[(size_t)r * NB + (idx % NB)] : 0.0;
     }
     double td_next = load_td(kfirst);
     double an[TW_TPW ? TW_TPW : 1][4];
@@ -1907,11 +1910,11 @@ __global__ __launch_bounds__(TW_NT) __attribute__((amdgpu_waves_per_eu(4 * WGS, 
         __syncthreads();
         if (more) td_next = load_td(kn);
         double enter = 0.0;
-        const int pe = bw + SB + (tid >> 3);              // position (relative to THIS block) of the rows that enter
+        const int pe = bw + SB + (tid / NB);              // position (relative to THIS block) of the rows that enter
         const int re = row_at(k0, pe);
-        if (more && tid < SB * SS_B) enter = Xb[(size_t)min(max(re, 0), n - 1) * SS_B + (tid & 7)];      // (raw)
-        if (tid < SB * SS_B) {      // y = T11^-1 x
-            const int c = tid >> 3, jj = tid & 7;
+        if (more && tid < SB * NB) enter = Xb[(size_t)min(max(re, 0), n - 1) * NB + (tid % NB)];      // (raw)
+        if (tid < SB * NB) {      // y = T11^-1 x
+            const int c = tid / NB, jj = tid % NB;
             double acc = 0.0;
 #pragma unroll
             for (int i = 0; i < SB; ++i) {
@@ -1921,12 +1924,12 @@ __global__ __launch_bounds__(TW_NT) __attribute__((amdgpu_waves_per_eu(4 * WGS, 
                 acc = fma(Td[c][i], win[jj * WR + sl], acc);
             }
             ys[c][jj] = (c < nb) ? acc : 0.0;
-            if (c < nb) Xb[(size_t)(k0 + c) * SS_B + jj] = acc;
+            if (c < nb) Xb[(size_t)(k0 + c) * NB + jj] = acc;
         }
         __syncthreads();
         double bq[4];      // B operand: -y(4 kk + l4, l15), zero in the eight unused columns
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) bq[kk] = l15 < SS_B ? -ys[4 * kk + l4][l15 & 7] : 0.0;
+        for (int kk = 0; kk < 4; ++kk) bq[kk] = l15 < NB ? -ys[4 * kk + l4][l15 % NB] : 0.0;
         auto do_tile = [&](int t, double (&a)[4]) {      // 16 rows after (before) the block
             mask_a(a, k0, t);
             ss_v4d c;
@@ -1935,16 +1938,16 @@ __global__ __launch_bounds__(TW_NT) __attribute__((amdgpu_waves_per_eu(4 * WGS, 
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int q = 16 * t + l4 + 4 * reg, r = row_at(k0, SB + q);
-                ok[reg] = l15 < SS_B && q < bw && r >= 0 && r < n;
+                ok[reg] = l15 < NB && q < bw && r >= 0 && r < n;
                 sl[reg] = wbase + SB + q;
                 if (sl[reg] >= WR) sl[reg] -= WR;
-                c[reg] = ok[reg] ? win[(l15 & 7) * WR + sl[reg]] : 0.0;
+                c[reg] = ok[reg] ? win[(l15 % NB) * WR + sl[reg]] : 0.0;
             }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], bq[kk], c, 0, 0, 0);
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg)
-                if (ok[reg]) win[(l15 & 7) * WR + sl[reg]] = c[reg];
+                if (ok[reg]) win[(l15 % NB) * WR + sl[reg]] = c[reg];
         };
 #pragma unroll
         for (int u = 0; u < TW_TPW; ++u)
@@ -1960,10 +1963,10 @@ __global__ __launch_bounds__(TW_NT) __attribute__((amdgpu_waves_per_eu(4 * WGS, 
             for (int u = 0; u < TW_TPW; ++u)
                 if (wv + 16 * u < ntile) load_a(an[u], kn, wv + 16 * u);
         }
-        if (more && tid < SB * SS_B) {
+        if (more && tid < SB * NB) {
             int se = wbase + pe;
             if (se >= WR) se -= WR;
-            win[(tid & 7) * WR + se] = (re >= 0 && re < n) ? enter : 0.0;
+            win[(tid % NB) * WR + se] = (re >= 0 && re < n) ? enter : 0.0;
         }
         wbase += SB;
         if (wbase >= WR) wbase -= WR;
@@ -2165,6 +2168,7 @@ __global__ __launch_bounds__(NT) void ss_solve_lds_pf_kernel(const int *__restri
 // Rayleigh-Ritz on span(Z) from M = Z^T X and G = Z^T Z, inverse residuals of the previous pairs,
 // X <- Z C.  state[b]: bit 0 = converged (the wanted pairs and the first unwanted one), count in
 // bits 8.., bit 1 = failure (too many wanted pairs / breakdown).  mu[b][SS_B] ascending.
+template <int NB = 8>
 __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, const int64_t *__restrict__ voff,
                                                     double *__restrict__ X, const double *__restrict__ Z,
                                                     double *__restrict__ mu, int *__restrict__ state, int iter,
@@ -2176,39 +2180,40 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
     // ndefl[b]: pairs of this matrix locked so far (the block is kept orthogonal to them); it0[b]: the iteration at which
     // its block was last started (0, or the lock): convergence is judged from the second iteration after that
     if (it0) iter -= it0[active ? active[blockIdx.x] : (int)blockIdx.x];
-    __shared__ double part[4][2 * SS_B + 1][SS_B];  // [wavefront][M rows | G rows | residual][column j]
-    __shared__ double Ms[SS_B][SS_B], Gs[SS_B][SS_B], Cs[SS_B][SS_B], res2[SS_B], mus[SS_B], mu_old[SS_B];
+    __shared__ double part[4][2 * NB + 1][NB];  // [wavefront][M rows | G rows | residual][column j]
+    __shared__ double Ms[NB][NB], Gs[NB][NB], Cs[NB][NB], res2[NB], mus[NB], mu_old[NB];
     const int b = active ? active[blockIdx.x] : (int)blockIdx.x, n = ns[b];     // (active: the matrices still iterating)
     if (state[b] & 3) return;                       // accepted earlier: X, mu stay as they are
     const double sigma = sigmas[b];
     double *Xb = X + voff[b] * SB;
     const double *Zb = Z + voff[b] * SB;
     const int tid = threadIdx.x;
-    const int j = tid & 7, grp = tid >> 3;          // column j, row group (32 of them)
-    if (tid < SS_B) mu_old[tid] = (iter > 0) ? mu[(size_t)b * SS_B + tid] : 1.0;
+    constexpr int NG = 256 / NB;                    // row groups
+    const int j = tid % NB, grp = tid / NB;         // column j, row group
+    if (tid < NB) mu_old[tid] = (iter > 0) ? mu[(size_t)b * NB + tid] : 1.0;
     __syncthreads();
     {
-        double am[SS_B], ag[SS_B], rs = 0.0;
+        double am[NB], ag[NB], rs = 0.0;
 #pragma unroll
-        for (int i = 0; i < SS_B; ++i) { am[i] = 0.0; ag[i] = 0.0; }
+        for (int i = 0; i < NB; ++i) { am[i] = 0.0; ag[i] = 0.0; }
         const double th = 1.0 / mu_old[j];
                 // two rows per trip: their loads are independent (four would cost a resident workgroup: 164 VGPRs)
-        for (int r0 = grp; r0 < n; r0 += 64) {
-            double xj[2], zjv[2], zr[2][SS_B];
+        for (int r0 = grp; r0 < n; r0 += 2 * NG) {
+            double xj[2], zjv[2], zr[2][NB];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int r = min(r0 + 32 * u, n - 1);
-                xj[u] = Xb[(size_t)r * SS_B + j];
-                zjv[u] = Zb[(size_t)r * SS_B + j];
+                const int r = min(r0 + NG * u, n - 1);
+                xj[u] = Xb[(size_t)r * NB + j];
+                zjv[u] = Zb[(size_t)r * NB + j];
 #pragma unroll
-                for (int i = 0; i < SS_B; ++i) zr[u][i] = Zb[(size_t)r * SS_B + i];
+                for (int i = 0; i < NB; ++i) zr[u][i] = Zb[(size_t)r * NB + i];
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                if (r0 + 32 * u < n) {
+                if (r0 + NG * u < n) {
                     const double zj = zjv[u];
 #pragma unroll
-                    for (int i = 0; i < SS_B; ++i) {
+                    for (int i = 0; i < NB; ++i) {
                         am[i] = fma(zr[u][i], xj[u], am[i]);
                         ag[i] = fma(zr[u][i], zj, ag[i]);
                     }
@@ -2220,40 +2225,40 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
         // the 8 row groups of a wavefront are summed in registers (lane bits 3..5), the 4 wavefronts in LDS:
         // a small footprint lets 8 workgroups share a CU, which is what hides the serial part below
 #pragma unroll
-        for (int o = 8; o < 64; o <<= 1) {
+        for (int o = NB; o < 64; o <<= 1) {
 #pragma unroll
-            for (int i = 0; i < SS_B; ++i) { am[i] += __shfl_xor(am[i], o, 64); ag[i] += __shfl_xor(ag[i], o, 64); }
+            for (int i = 0; i < NB; ++i) { am[i] += __shfl_xor(am[i], o, 64); ag[i] += __shfl_xor(ag[i], o, 64); }
             rs += __shfl_xor(rs, o, 64);
         }
-        if ((tid & 63) < SS_B) {
+        if ((tid & 63) < NB) {
             const int w = tid >> 6;
 #pragma unroll
-            for (int i = 0; i < SS_B; ++i) { part[w][i][j] = am[i]; part[w][SS_B + i][j] = ag[i]; }
-            part[w][2 * SS_B][j] = rs;
+            for (int i = 0; i < NB; ++i) { part[w][i][j] = am[i]; part[w][NB + i][j] = ag[i]; }
+            part[w][2 * NB][j] = rs;
         }
         __syncthreads();
-        if (tid < (2 * SS_B + 1) * SS_B) {
-            const int i = tid >> 3, jj = tid & 7;
+        for (int idx = tid; idx < (2 * NB + 1) * NB; idx += 256) {
+            const int i = idx / NB, jj = idx % NB;
             const double sum = (part[0][i][jj] + part[1][i][jj]) + (part[2][i][jj] + part[3][i][jj]);
-            if (i < SS_B) Ms[i][jj] = sum; else if (i < 2 * SS_B) Gs[i - SS_B][jj] = sum; else res2[jj] = sum;
+            if (i < NB) Ms[i][jj] = sum; else if (i < 2 * NB) Gs[i - NB][jj] = sum; else res2[jj] = sum;
         }
         __syncthreads();
     }
-    __shared__ double R[SS_B][SS_B + 1], S[SS_B][SS_B + 1], V[SS_B][SS_B + 1];
-    __shared__ double rot_c[4], rot_s[4], rdi[SS_B];     // (rdi: reciprocal diagonal of R)
+    __shared__ double R[NB][NB + 1], S[NB][NB + 1], V[NB][NB + 1];
+    __shared__ double rot_c[NB / 2], rot_s[NB / 2], rdi[NB];     // (rdi: reciprocal diagonal of R)
     __shared__ int sh_st, sh_ok;
     if (tid == 0) {
         int st = 0;
         // convergence of the PREVIOUS pairs (X, mu_old): || C x - lambda x || <= || C - sigma || mu || z - x / mu ||
         if (iter > 0) {
             int k = 0;
-            for (int q = 0; q < SS_B; ++q) if (sigma + mu_old[q] <= vu) ++k;
+            for (int q = 0; q < NB; ++q) if (sigma + mu_old[q] <= vu) ++k;
             if (dbg)        // (SAAMGE_AMD_SS_DEBUG: residual bounds and Ritz values of the previous pairs)
-                for (int q = 0; q < SS_B; ++q) { dbg[(size_t)b * 2 * SS_B + q] = 2.5 * mu_old[q] * sqrt(res2[q]); dbg[(size_t)b * 2 * SS_B + SS_B + q] = sigma + mu_old[q]; }
+                for (int q = 0; q < NB; ++q) { dbg[(size_t)b * 2 * NB + q] = 2.5 * mu_old[q] * sqrt(res2[q]); dbg[(size_t)b * 2 * NB + NB + q] = sigma + mu_old[q]; }
             const int nd = ndefl ? ndefl[b] : 0;
             const int cert0 = inertia ? inertia[b] : -2;     // certified #{lambda < vu}; -1: not certifiable, -2: none
             const int cert = cert0 > 0 ? cert0 - nd : cert0; // ... of which nd are locked already
-            const bool partial = cert > SS_B - 2;            // more wanted pairs than the block holds: lock the first six
+            const bool partial = cert > NB - 2;            // more wanted pairs than the block holds: lock the first six
             // hopeless convergence (the wanted pair far above the shift inside a cluster: rate ~ 1): the bound of
             // the slowest wanted pair four iterations ago predicts the iterations still needed; a matrix that
             // cannot make it within the budget gives up now instead of after max_iter iterations
@@ -2277,7 +2282,7 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
                 bool ok = k >= SS_LOCK;
                 for (int q = 0; q < SS_LOCK; ++q) ok = ok && (2.5 * mu_old[q] * sqrt(res2[q]) <= SS_TOL);
                 if (ok) st |= 8;
-            } else if (k > SS_B - 2 || cert > SS_B - 2 || cert == -1) st |= 2;
+            } else if (k > NB - 2 || cert > NB - 2 || cert == -1) st |= 2;
             else if (cert >= 0) {
                 // Ritz values approach the eigenvalues from above, so the number inside the window grows to the
                 // certified count: accept once it is reached and those pairs have converged (count 0: the
@@ -2298,16 +2303,16 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
         sh_ok = 1;
         if (!(st & 3)) {
             // G = R^T R (upper factor, row by row): the only serial piece (~100 flops)
-            for (int c = 0; c < SS_B; ++c)
-                for (int r2 = 0; r2 < SS_B; ++r2) R[r2][c] = 0.0;
-            for (int c = 0; c < SS_B; ++c) {
+            for (int c = 0; c < NB; ++c)
+                for (int r2 = 0; r2 < NB; ++r2) R[r2][c] = 0.0;
+            for (int c = 0; c < NB; ++c) {
                 double d = Gs[c][c];
                 for (int q = 0; q < c; ++q) d -= R[q][c] * R[q][c];
                 if (!(d > 0.0)) { sh_ok = 0; d = 1.0; }
                 const double ri = fast_rsqrt(d);      // (division and square-root chains: hardware seed + Newton)
                 R[c][c] = d * ri;
                 rdi[c] = ri;
-                for (int c2 = c + 1; c2 < SS_B; ++c2) {
+                for (int c2 = c + 1; c2 < NB; ++c2) {
                     double t = 0.5 * (Gs[c][c2] + Gs[c2][c]);
                     for (int q = 0; q < c; ++q) t -= R[q][c] * R[q][c2];
                     R[c][c2] = t * ri;
@@ -2316,23 +2321,123 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
         }
     }
     __syncthreads();
-    if (!(sh_st & 3) && tid < 64) {
+    if (NB != 8 && !(sh_st & 3)) {
+        // ---- NB = 16: the same with all 256 threads and workgroup barriers (16 x 16 entries: one per thread; eight disjoint
+        // rotations per step, fifteen steps per sweep) ----
+        const int lr = tid / NB, lc = tid % NB;
+        V[lr][lc] = (lr == lc) ? 1.0 : 0.0;
+        if (tid < NB) {                     // column c of T1 = R^-T Msym: forward substitution
+            const int c = tid;
+            for (int r2 = 0; r2 < NB; ++r2) {
+                double t = 0.5 * (Ms[r2][c] + Ms[c][r2]);
+                for (int q = 0; q < r2; ++q) t -= R[q][r2] * S[q][c];
+                S[r2][c] = t * rdi[r2];
+            }
+        }
+        __syncthreads();
+        if (tid < NB) {                     // row r of S = T1 R^-1
+            const int r2 = tid;
+            for (int c = 0; c < NB; ++c) {
+                double t = S[r2][c];
+                for (int q = 0; q < c; ++q) t -= S[r2][q] * R[q][c];
+                S[r2][c] = t * rdi[c];
+            }
+        }
+        __syncthreads();
+        {
+            const double t = 0.5 * (S[lr][lc] + S[lc][lr]);
+            __syncthreads();
+            S[lr][lc] = t;
+        }
+        __syncthreads();
+        for (int sweep = 0; sweep < 16; ++sweep) {
+            double off = (lr != lc) ? S[lr][lc] * S[lr][lc] : 0.0, dg = (lr == lc) ? S[lr][lc] * S[lr][lc] : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o, 64); dg += __shfl_xor(dg, o, 64); }
+            if ((tid & 63) == 0) { part[0][0][tid >> 6] = off; part[0][1][tid >> 6] = dg; }
+            __syncthreads();
+            off = (part[0][0][0] + part[0][0][1]) + (part[0][0][2] + part[0][0][3]);
+            dg = (part[0][1][0] + part[0][1][1]) + (part[0][1][2] + part[0][1][3]);
+            __syncthreads();
+            if (off <= 1e-34 * dg) break;      // (uniform)
+            for (int step = 0; step < NB - 1; ++step) {
+                // round-robin pairing of NB players: the last one fixed, the others rotate
+                auto player = [&](int slot) { return slot == NB - 1 ? NB - 1 : (slot + step) % (NB - 1); };
+                if (tid < NB / 2) {
+                    int p2 = player(tid), q2 = player(NB - 1 - tid);
+                    if (p2 > q2) { const int t = p2; p2 = q2; q2 = t; }
+                    double cc = 1.0, sn = 0.0;
+                    const double apq = S[p2][q2];
+                    if (apq != 0.0) {
+                        const double d = S[q2][q2] - S[p2][p2];
+                        const double den = fabs(d) + fast_sqrt(fma(d, d, 4.0 * apq * apq));
+                        const double t = ((d >= 0.0) == (apq >= 0.0) ? 2.0 : -2.0) * fabs(apq) * fast_rcp(den);
+                        cc = fast_rsqrt(fma(t, t, 1.0));
+                        sn = t * cc;
+                    }
+                    rot_c[tid] = cc;
+                    rot_s[tid] = sn;
+                }
+                __syncthreads();
+                const int m2 = tid % (NB / 2), k2 = (tid / (NB / 2)) % NB;      // pair m2, row / column k2; threads 0..127 S, 128..255 V
+                int p2 = player(m2), q2 = player(NB - 1 - m2);
+                if (p2 > q2) { const int t = p2; p2 = q2; q2 = t; }
+                const double cc = rot_c[m2], sn = rot_s[m2];
+                {   // columns p, q of S and of V (the entries (k2, p2), (k2, q2) belong to this thread alone)
+                    double (*Mx)[NB + 1] = (tid < NB * NB / 2) ? S : V;
+                    const double a = Mx[k2][p2], bq = Mx[k2][q2];
+                    Mx[k2][p2] = cc * a - sn * bq;
+                    Mx[k2][q2] = sn * a + cc * bq;
+                }
+                __syncthreads();
+                if (tid < NB * NB / 2) {   // rows p, q of S
+                    const double a = S[p2][k2], bq = S[q2][k2];
+                    S[p2][k2] = cc * a - sn * bq;
+                    S[q2][k2] = sn * a + cc * bq;
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int order[NB];
+            for (int q = 0; q < NB; ++q) order[q] = q;
+            for (int a2 = 0; a2 < NB; ++a2)
+                for (int b2 = a2 + 1; b2 < NB; ++b2)
+                    if (S[order[b2]][order[b2]] < S[order[a2]][order[a2]]) { const int t = order[a2]; order[a2] = order[b2]; order[b2] = t; }
+            for (int q = 0; q < NB; ++q) {
+                mus[q] = S[order[q]][order[q]];
+                if (!(mus[q] > 0.0)) sh_ok = 0;
+                res2[q] = (double)order[q];      // (res2 is free now: source column of output q)
+            }
+        }
+        __syncthreads();
+        if (tid < NB) {      // column q of C = R^-1 V(:, src)
+            const int q = tid, src = (int)res2[q];
+            for (int r2 = NB - 1; r2 >= 0; --r2) {
+                double t = V[r2][src];
+                for (int c2 = r2 + 1; c2 < NB; ++c2) t -= R[r2][c2] * Cs[c2][q];
+                Cs[r2][q] = t * rdi[r2];
+            }
+        }
+    }
+    if (NB == 8 && !(sh_st & 3) && tid < 64) {
         // ---- S = R^-T Msym R^-1 and its eigen-decomposition by parallel-order Jacobi, one wavefront ----
         const int lr = tid >> 3, lc = tid & 7;
         auto wsync = []() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
         V[lr][lc] = (lr == lc) ? 1.0 : 0.0;
-        if (tid < SS_B) {                     // column c of T1 = R^-T Msym: forward substitution
+        if (tid < NB) {                     // column c of T1 = R^-T Msym: forward substitution
             const int c = tid;
-            for (int r2 = 0; r2 < SS_B; ++r2) {
+            for (int r2 = 0; r2 < NB; ++r2) {
                 double t = 0.5 * (Ms[r2][c] + Ms[c][r2]);
                 for (int q = 0; q < r2; ++q) t -= R[q][r2] * S[q][c];
                 S[r2][c] = t * rdi[r2];
             }
         }
         wsync();
-        if (tid < SS_B) {                     // row r of S = T1 R^-1
+        if (tid < NB) {                     // row r of S = T1 R^-1
             const int r2 = tid;
-            for (int c = 0; c < SS_B; ++c) {
+            for (int c = 0; c < NB; ++c) {
                 double t = S[r2][c];
                 for (int q = 0; q < c; ++q) t -= S[r2][q] * R[q][c];
                 S[r2][c] = t * rdi[c];
@@ -2375,7 +2480,7 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
                 if (p2 > q2) { const int t = p2; p2 = q2; q2 = t; }
                 const double cc = rot_c[m2], sn = rot_s[m2];
                 {   // columns p, q of S (lanes < 32) and of V (lanes >= 32)
-                    double (*Mx)[SS_B + 1] = (tid < 32) ? S : V;
+                    double (*Mx)[NB + 1] = (tid < 32) ? S : V;
                     const double a = Mx[k2][p2], bq = Mx[k2][q2];
                     wsync();
                     Mx[k2][p2] = cc * a - sn * bq;
@@ -2392,12 +2497,12 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
         }
         wsync();
         if (tid == 0) {
-            int order[SS_B];
-            for (int q = 0; q < SS_B; ++q) order[q] = q;
-            for (int a2 = 0; a2 < SS_B; ++a2)
-                for (int b2 = a2 + 1; b2 < SS_B; ++b2)
+            int order[NB];
+            for (int q = 0; q < NB; ++q) order[q] = q;
+            for (int a2 = 0; a2 < NB; ++a2)
+                for (int b2 = a2 + 1; b2 < NB; ++b2)
                     if (S[order[b2]][order[b2]] < S[order[a2]][order[a2]]) { const int t = order[a2]; order[a2] = order[b2]; order[b2] = t; }
-            for (int q = 0; q < SS_B; ++q) {
+            for (int q = 0; q < NB; ++q) {
                 mus[q] = S[order[q]][order[q]];
                 if (!(mus[q] > 0.0)) sh_ok = 0;
                 rot_c[0] = 0.0;
@@ -2405,11 +2510,11 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
             }
         }
         wsync();
-        if (tid < SS_B) {      // column q of C = R^-1 V(:, src)
+        if (tid < NB) {      // column q of C = R^-1 V(:, src)
             const int q = tid, src = (int)res2[q];
-            for (int r2 = SS_B - 1; r2 >= 0; --r2) {
+            for (int r2 = NB - 1; r2 >= 0; --r2) {
                 double t = V[r2][src];
-                for (int c2 = r2 + 1; c2 < SS_B; ++c2) t -= R[r2][c2] * Cs[c2][q];
+                for (int c2 = r2 + 1; c2 < NB; ++c2) t -= R[r2][c2] * Cs[c2][q];
                 Cs[r2][q] = t * rdi[r2];
             }
         }
@@ -2424,17 +2529,17 @@ __global__ __launch_bounds__(256) void ss_rr_kernel(const int *__restrict__ ns, 
     __syncthreads();
     const int st = (int)Ms[0][0];
     if (st & 3) return;            // converged (X, mu stay the accepted pairs) or failed
-    if (tid < SS_B) mu[(size_t)b * SS_B + tid] = mus[tid];
-    {   // X = Z C: one output entry per thread and trip (its column of C in 8 registers, coalesced stores)
-        const int q = tid & 7;
-        double cq[SS_B];
+    if (tid < NB) mu[(size_t)b * NB + tid] = mus[tid];
+    {   // X = Z C: one output entry per thread and trip (its column of C in NB registers, coalesced stores)
+        const int q = tid % NB;
+        double cq[NB];
 #pragma unroll
-        for (int i = 0; i < SS_B; ++i) cq[i] = Cs[i][q];
-        for (int r = tid >> 3; r < n; r += 32) {
+        for (int i = 0; i < NB; ++i) cq[i] = Cs[i][q];
+        for (int r = tid / NB; r < n; r += NG) {
             double t = 0.0;
 #pragma unroll
-            for (int i = 0; i < SS_B; ++i) t = fma(Zb[(size_t)r * SS_B + i], cq[i], t);
-            Xb[(size_t)r * SS_B + q] = t;
+            for (int i = 0; i < NB; ++i) t = fma(Zb[(size_t)r * NB + i], cq[i], t);
+            Xb[(size_t)r * NB + q] = t;
         }
     }
 }
@@ -2511,6 +2616,7 @@ __global__ __launch_bounds__(256) void ss_lock_kernel(const int *__restrict__ li
     if (threadIdx.x == 0) { ndefl[b] = SS_LOCK; it0[b] = iter + 1; state[b] = 0; }
 }
 
+template <int NB = 8>
 __global__ __launch_bounds__(256) void ss_output_kernel(const int *__restrict__ ns, const int64_t *__restrict__ voff,
                                                         const double *__restrict__ X, const double *__restrict__ mu,
                                                         const double *__restrict__ dis, const short *__restrict__ perm,
@@ -2527,20 +2633,21 @@ __global__ __launch_bounds__(256) void ss_output_kernel(const int *__restrict__ 
     const double *Vb = Vl ? Vl + voff[b] * SS_LOCK_PITCH : nullptr;
     const short *pm = perm ? perm + voff[b] : nullptr;
     for (int q = threadIdx.x; q < m; q += 256)
-        evals[eoff[b] + q] = q < nd ? lock_mu[(size_t)b * SS_LOCK_PITCH + q] : sigma + mu[(size_t)b * SS_B + (q - nd)];
+        evals[eoff[b] + q] = q < nd ? lock_mu[(size_t)b * SS_LOCK_PITCH + q] : sigma + mu[(size_t)b * NB + (q - nd)];
     for (int idx = threadIdx.x; idx < n * m; idx += 256) {
         const int r = idx % n, q = idx / n, pr = pm ? pm[r] : r;
-        evecs[xoff[b] + (size_t)q * n + r] = dis[voff[b] + r] * (q < nd ? Vb[(size_t)pr * SS_LOCK_PITCH + q] : Xb[(size_t)pr * SS_B + (q - nd)]);
+        evecs[xoff[b] + (size_t)q * n + r] = dis[voff[b] + r] * (q < nd ? Vb[(size_t)pr * SS_LOCK_PITCH + q] : Xb[(size_t)pr * NB + (q - nd)]);
     }
 }
 
 // after a matrix has been factored again at a new shift: its Ritz values are kept as lambda - sigma
+template <int NB = 8>
 __global__ void ss_reshift_mu_kernel(int nreq, const int *__restrict__ req, const double *__restrict__ delta,
                                      double *__restrict__ mu, double *__restrict__ hist) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nreq * SS_B) return;
-    const int b = req[t / SS_B], q = t % SS_B;
-    mu[(size_t)b * SS_B + q] += delta[t / SS_B];
+    if (t >= nreq * NB) return;
+    const int b = req[t / NB], q = t % NB;
+    mu[(size_t)b * NB + q] += delta[t / NB];
     if (q < 4) hist[(size_t)b * 4 + q] = 0.0;
 }
 
@@ -2616,6 +2723,7 @@ static void ss_factor_generic(hipStream_t s, EigBatch &b, bool sgn, int *neg, in
 
 bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
     const int nmax = b.max_n;
+    b.ss_nb = 8;      // block of the iteration; 16 where more pairs are wanted than eight vectors reach (decided after the inertia pass)
     b.h_xpoff.clear();
     b.h_goff.assign((size_t)b.count + 1, 0);
     b.h_roff.assign((size_t)b.count + 1, 0);
@@ -2731,9 +2839,21 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
     b.nbad = 0;
     auto mark_bad = [&](int i) { if (!b.h_bad[(size_t)i]) { b.h_bad[(size_t)i] = 1; ++b.nbad; } };
     auto too_many_bad = [&]() { return (long)b.nbad * 10 > (long)b.count; };
-    constexpr bool lock_on = true;
+    // The block of SIXTEEN vectors (round 4): wide-band matrices -- their solves stream the factor through HBM and work on
+    // matrix-core tiles that are 16 columns wide whatever the block holds -- take it as soon as one of them wants more than the
+    // six pairs a block of eight converges without locking (config 4 with 8 x 8 x 4-AE coarse blocks: eight wanted pairs, 1 035 ->
+    // 799 ms per step); small matrices (right-hand sides in LDS beside the band: no room for sixteen) keep the block of eight and
+    // its lock up to twelve wanted pairs, and take the block of sixteen -- through the streaming solves -- for 13 and 14.
+    // With six pairs or fewer the block of eight stays: measured on the headline's level 1 (two wanted pairs), sixteen vectors
+    // need 13 instead of 16 iterations of 1.4 instead of 1.3 ms -- nothing --, and a different basis of a degenerate eigenspace
+    // (the six rigid-body modes of config 5) is a different member of the family of valid hierarchies.
+    {
+        int maxwant = 0;
+        for (int v : b.h_inertia) maxwant = std::max(maxwant, v);
+        if (maxwant <= 16 - 2 && ((nmax > 1280 && maxwant > SS_B - 2) || maxwant > SS_WANT_MAX)) b.ss_nb = 16;
+    }
     for (size_t i = 0; i < b.h_inertia.size(); ++i)
-        if (b.h_inertia[i] > (lock_on ? SS_WANT_MAX : SS_B - 2) || b.h_inertia[i] < 0) {
+        if (b.h_inertia[i] > (b.ss_nb == 16 ? 16 - 2 : SS_WANT_MAX) || b.h_inertia[i] < 0) {
             SA_REQUIRE(!options().eig_strict, "few-eigenpairs path: a matrix has more wanted pairs than the block holds, or no certificate (strict mode)");
             mark_bad((int)i);
         }
@@ -2881,7 +3001,10 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     auto mark_bad = [&](int i) { if (!b.h_bad[(size_t)i]) { b.h_bad[(size_t)i] = 1; ++b.nbad; } };
     auto too_many_bad = [&]() { return (long)b.nbad * 10 > (long)b.count; };
     double *X = b.Xbuf.p, *Z = b.Vpk2.p, *mu = b.d.p;     // d: rows >= SS_B per matrix is checked by the caller
-    DBuf<double> mubuf((size_t)b.count * SS_B);
+    const int NB = b.ss_nb;
+    // (kernels of the block are templates on its width)
+    auto with_nb = [&](auto f) { if (NB == 16) f(std::integral_constant<int, 16>()); else f(std::integral_constant<int, 8>()); };
+    DBuf<double> mubuf((size_t)b.count * NB);
     mu = mubuf.p;
     DBuf<double> slow_hist((size_t)b.count * 4);       // bound of the slowest wanted pair, last four iterations
     slow_hist.zero(s);
@@ -2899,7 +3022,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     // matrices with seven to twelve wanted pairs: the first six are locked when they have converged (ss_lock_kernel)
     std::vector<int> h_ndefl((size_t)b.count, 0);
     bool any_lock = false;
-    for (int i = 0; i < b.count && !b.h_inertia.empty(); ++i) any_lock = any_lock || (!b.h_bad[i] && b.h_inertia[i] > SS_B - 2);
+    for (int i = 0; i < b.count && !b.h_inertia.empty() && NB == 8; ++i) any_lock = any_lock || (!b.h_bad[i] && b.h_inertia[i] > SS_B - 2);
     DBuf<int> it0;
     b.ss_has_lock = false;
     if (any_lock) {
@@ -2917,8 +3040,10 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         std::fprintf(stderr, "\n");
     }
     if (!prof) profiler().begin(s);
-    hipLaunchKernelGGL(ss_init_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, b.dis.p,
-                       b.has_perm ? b.perm.p : nullptr, X, b.has_x0c ? b.x0c.p : (const double *)nullptr);
+    with_nb([&](auto nb) {
+        hipLaunchKernelGGL(ss_init_kernel<decltype(nb)::value>, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, b.dis.p,
+                           b.has_perm ? b.perm.p : nullptr, X, b.has_x0c ? b.x0c.p : (const double *)nullptr);
+    });
     bool done = false, failed = false;
     std::vector<int> hstate;
     // Only the matrices that are still iterating are launched, through a dense index list: accepted ones
@@ -2930,8 +3055,10 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
     for (int i = 0; i < b.count; ++i)
         if ((b.h_pre.empty() || !b.h_pre[i]) && !b.h_bad[i]) h_active.push_back(i);
     if (!b.h_pre.empty())       // finished before the factorisation (eig_subspace_factor): unit vector, Ritz value, state
-        hipLaunchKernelGGL(ss_preaccept_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, b.pre.p, b.pre_val.p,
-                           b.ss_sigma.p, X, mu, state.p);
+        with_nb([&](auto nb) {
+            hipLaunchKernelGGL(ss_preaccept_kernel<decltype(nb)::value>, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, b.pre.p, b.pre_val.p,
+                               b.ss_sigma.p, X, mu, state.p);
+        });
     DBuf<int> active((size_t)b.count);
     int nact = (int)h_active.size();
     if (nact) SA_HIP_CHECK(hipMemcpyAsync(active.p, h_active.data(), sizeof(int) * (size_t)nact, hipMemcpyHostToDevice, s));
@@ -2946,7 +3073,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         }
         if (prof) profiler().begin(s);
         const size_t xl_bytes = sizeof(double) * (size_t)b.max_n * XLP + 64;
-        if (b.max_n <= 1280) {
+        if (b.max_n <= 1280 && NB == 8) {
             // narrow bands: the deep-prefetch kernel; wider ones: the plain kernel, 256 or 512 threads by the band
             const int rows = std::min(b.max_n, b.ss_bwmax + SB);     // rows a block step updates
             auto go = [&](auto kern, int nt) {
@@ -2959,11 +3086,13 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
         } else {
         // Z <- X for the matrices still iterating (the whole buffer used to be copied every iteration: 0.6 s of
         // config 5's 23 s, where most matrices of a chunk are done long before the last one)
-        hipLaunchKernelGGL(ss_copy_active_kernel, dim3(nact, std::max(1, std::min(16, b.max_n / 256))), dim3(256), 0, s, b.n.p,
-                           b.voff.p, active.p, X, Z);
+        with_nb([&](auto nb) {
+            hipLaunchKernelGGL(ss_copy_active_kernel<decltype(nb)::value>, dim3(nact, std::max(1, std::min(16, b.max_n / 256))), dim3(256), 0, s, b.n.p,
+                               b.voff.p, active.p, X, Z);
+        });
         constexpr bool no_win = false;
         const int wr = (std::min(b.max_n, bws ? std::max(b.ss_bwmax, SB) : b.max_n) + 2 * SB) | 1;      // rows of the LDS window (odd)
-        const size_t win_bytes = sizeof(double) * SS_B * (size_t)wr;
+        const size_t win_bytes = sizeof(double) * (size_t)NB * (size_t)wr;
         if (b.max_n > 768 && !no_win && win_bytes <= 150 * 1024) {
             // more matrices than CUs: the variant without requests ahead, two workgroups per CU (config 5 at 64^3: solves 448 -> 397 ms
             // per step; SAAMGE_AMD_SS_TRSOLVE_TWO=0: one per CU always)
@@ -2974,34 +3103,45 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
                 hipLaunchKernelGGL(lo, dim3(nact), dim3(1024), win_bytes, s, wr, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
                 hipLaunchKernelGGL(up, dim3(nact), dim3(1024), win_bytes, s, wr, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
             };
-            if (two_env && nact > 256 && win_bytes <= 70 * 1024) go(ss_trsolve_win_kernel<false, 0, 2>, ss_trsolve_win_kernel<true, 0, 2>);
-            else go(ss_trsolve_win_kernel<false, 4, 1>, ss_trsolve_win_kernel<true, 4, 1>);
+            with_nb([&](auto nb) {
+                constexpr int B = decltype(nb)::value;
+                if (two_env && nact > 256 && win_bytes <= 70 * 1024) go(ss_trsolve_win_kernel<false, 0, 2, B>, ss_trsolve_win_kernel<true, 0, 2, B>);
+                else go(ss_trsolve_win_kernel<false, 4, 1, B>, ss_trsolve_win_kernel<true, 4, 1, B>);
+            });
         } else if (b.max_n > 768) {
-            hipLaunchKernelGGL((ss_trsolve_kernel<false, 1024>), dim3(nact), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
-            hipLaunchKernelGGL((ss_trsolve_kernel<true, 1024>), dim3(nact), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
+            with_nb([&](auto nb) {
+                constexpr int B = decltype(nb)::value;
+                hipLaunchKernelGGL((ss_trsolve_kernel<false, 1024, B>), dim3(nact), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
+                hipLaunchKernelGGL((ss_trsolve_kernel<true, 1024, B>), dim3(nact), dim3(1024), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
+            });
         } else {
-            hipLaunchKernelGGL((ss_trsolve_kernel<false, 256>), dim3(nact), dim3(256), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
-            hipLaunchKernelGGL((ss_trsolve_kernel<true, 256>), dim3(nact), dim3(256), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
+            with_nb([&](auto nb) {
+                constexpr int B = decltype(nb)::value;
+                hipLaunchKernelGGL((ss_trsolve_kernel<false, 256, B>), dim3(nact), dim3(256), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
+                hipLaunchKernelGGL((ss_trsolve_kernel<true, 256, B>), dim3(nact), dim3(256), 0, s, b.n.p, b.moff.p, b.voff.p, b.W.p, Z, state.p, bws, active.p);
+            });
         }
         }
         if (prof) {
             double ab = 0.0;      // the factor once per triangle + the right-hand sides, ACTIVE matrices only
             for (int i : h_active) {
                 const double n = b.h_n[i], w = b.h_bw.empty() ? n : std::min(n, (double)b.h_bw[i] + SB);
-                ab += 8.0 * n * (2.0 * w - w * w / n) + 2.0 * 8.0 * SS_B * n;
+                ab += 8.0 * n * (2.0 * w - w * w / n) + 2.0 * 8.0 * NB * n;
             }
             profiler().end(s, b.max_n <= 1280 ? "eig_ss_solve" : "eig_ss_solve_g", ab, 0.0);
             profiler().begin(s);
         }
         const bool dbg_on = (options().debug & 1) != 0;
         DBuf<double> dbgbuf;
-        if (dbg_on) dbgbuf.alloc((size_t)b.count * 2 * SS_B);
+        if (dbg_on) dbgbuf.alloc((size_t)b.count * 2 * NB);
         if (any_lock)
             hipLaunchKernelGGL(ss_deflate_kernel, dim3(nact), dim3(256), 0, s, b.n.p, b.voff.p, b.ss_Vlock.p, b.ss_ndefl.p, Z, state.p, active.p);
-        hipLaunchKernelGGL(ss_rr_kernel, dim3(nact), dim3(256), 0, s, b.n.p, b.voff.p, X, Z, mu, state.p, iter,
-                           b.ss_sigma.p, vu, b.h_inertia.empty() ? (const int *)nullptr : b.inertia.p, dbgbuf.p, active.p,
-                           slow_hist.p, max_iter, reshift_on ? reshift_ok.p : (const int *)nullptr,
-                           any_lock ? b.ss_ndefl.p : (const int *)nullptr, any_lock ? it0.p : (const int *)nullptr, b.ss_tol);
+        with_nb([&](auto nb) {
+            hipLaunchKernelGGL(ss_rr_kernel<decltype(nb)::value>, dim3(nact), dim3(256), 0, s, b.n.p, b.voff.p, X, Z, mu, state.p, iter,
+                               b.ss_sigma.p, vu, b.h_inertia.empty() ? (const int *)nullptr : b.inertia.p, dbgbuf.p, active.p,
+                               slow_hist.p, max_iter, reshift_on ? reshift_ok.p : (const int *)nullptr,
+                               any_lock ? b.ss_ndefl.p : (const int *)nullptr, any_lock ? it0.p : (const int *)nullptr, b.ss_tol);
+        });
         if (dbg_on && iter > 0) {
             auto hd = dbgbuf.to_host(s);
             const int show = std::min(b.count, 3);
@@ -3016,8 +3156,8 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
             for (int i = 0; i < show && dbg_one < 0; ++i) {
                 const int mi = (int)((int64_t)i * (b.count - 1) / std::max(1, show - 1));
                 std::fprintf(stderr, "  iter %d matrix %d (n %d): bounds %.2e %.2e %.2e | lambda %.6e %.6e %.6e | inertia %d\n", iter, mi, b.h_n[mi],
-                             hd[(size_t)mi * 16], hd[(size_t)mi * 16 + 1], hd[(size_t)mi * 16 + 2], hd[(size_t)mi * 16 + 8],
-                             hd[(size_t)mi * 16 + 9], hd[(size_t)mi * 16 + 10], b.h_inertia.empty() ? -2 : b.h_inertia[mi]);
+                             hd[(size_t)mi * 2 * NB], hd[(size_t)mi * 2 * NB + 1], hd[(size_t)mi * 2 * NB + 2], hd[(size_t)mi * 2 * NB + NB],
+                             hd[(size_t)mi * 2 * NB + NB + 1], hd[(size_t)mi * 2 * NB + NB + 2], b.h_inertia.empty() ? -2 : b.h_inertia[mi]);
             }
         }
         if (prof) profiler().end(s, "eig_ss_rr", 0.0, 0.0);
@@ -3073,7 +3213,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
                 // level-1 agglomerates of config 4 with 8 x 8 x 4-AE blocks the value of iteration 6 was still more
                 // than 2 % too high and the factorisation at the new shift met a negative pivot.
                 for (int i : cand) {
-                    const double gap = hmu[(size_t)i * SS_B];
+                    const double gap = hmu[(size_t)i * NB];
                     const double moved = reshift_prev[(size_t)i] > 0.0 ? reshift_prev[(size_t)i] - gap : 1e300;
                     reshift_prev[(size_t)i] = gap;
                     if (moved <= 0.005 * gap) { reshift_margin[(size_t)i] = std::max(0.02 * gap, 5.0 * std::max(moved, 0.0)); req.push_back(i); }
@@ -3082,7 +3222,7 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
                     std::vector<double> delta(req.size());
                     for (size_t t = 0; t < req.size(); ++t) {
                         const int i = req[t];
-                        const double gap = hmu[(size_t)i * SS_B];              // smallest Ritz value - sigma (> 0)
+                        const double gap = hmu[(size_t)i * NB];              // smallest Ritz value - sigma (> 0)
                         const double snew = b.h_sigma[i] + gap - reshift_margin[(size_t)i];
                         delta[t] = b.h_sigma[i] - snew;
                         b.h_sigma[i] = snew;
@@ -3113,8 +3253,10 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
                     DBuf<double> d_delta;
                     d_req.from_host(req, s);
                     d_delta.from_host(delta, s);
-                    hipLaunchKernelGGL(ss_reshift_mu_kernel, dim3(div_up((long)req.size() * SS_B, 256)), dim3(256), 0, s, (int)req.size(),
-                                       d_req.p, d_delta.p, mu, slow_hist.p);
+                    with_nb([&](auto nb) {
+                        hipLaunchKernelGGL(ss_reshift_mu_kernel<decltype(nb)::value>, dim3(div_up((long)req.size() * NB, 256)), dim3(256), 0, s, (int)req.size(),
+                                           d_req.p, d_delta.p, mu, slow_hist.p);
+                    });
                     SA_HIP_CHECK(hipGetLastError());
                     SA_HIP_CHECK(hipStreamSynchronize(s));
                     if ((options().debug & 1))
@@ -3179,10 +3321,13 @@ bool eig_subspace_iterate(hipStream_t s, EigBatch &b, double vu) {
 void eig_subspace_vectors(hipStream_t s, EigBatch &b, const int64_t *eoff, const int64_t *xoff, double *evals,
                           double *evecs) {
     profiler().begin(s);
-    hipLaunchKernelGGL(ss_output_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, b.Xbuf.p, b.ss_mu.p, b.dis.p,
-                       b.has_perm ? b.perm.p : nullptr, b.m.p, eoff, xoff, evals, evecs, b.ss_sigma.p,
-                       b.ss_has_lock ? b.ss_ndefl.p : (const int *)nullptr, b.ss_has_lock ? b.ss_Vlock.p : (const double *)nullptr,
-                       b.ss_has_lock ? b.ss_lock_mu.p : (const double *)nullptr);
+    auto launch = [&](auto nb) {
+        hipLaunchKernelGGL(ss_output_kernel<decltype(nb)::value>, dim3(b.count), dim3(256), 0, s, b.n.p, b.voff.p, b.Xbuf.p, b.ss_mu.p, b.dis.p,
+                           b.has_perm ? b.perm.p : nullptr, b.m.p, eoff, xoff, evals, evecs, b.ss_sigma.p,
+                           b.ss_has_lock ? b.ss_ndefl.p : (const int *)nullptr, b.ss_has_lock ? b.ss_Vlock.p : (const double *)nullptr,
+                           b.ss_has_lock ? b.ss_lock_mu.p : (const double *)nullptr);
+    };
+    if (b.ss_nb == 16) launch(std::integral_constant<int, 16>()); else launch(std::integral_constant<int, 8>());
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "eig_ss_output", 0.0, 0.0);
 }

@@ -466,9 +466,11 @@ __global__ __launch_bounds__(256) void sell_staged2_kernel(int nrows, int row0, 
 #pragma unroll
     for (int q = 0; q < 8; ++q) cws[q] = (q < wq) ? __builtin_nontemporal_load(wp + 256 * q) : 0u;
     double e_b = 0.0, e_d = 0.0, e_x = 0.0;
-    if (MODE == MODE_RESIDUAL) e_b = b[row];
+    // (b and D^-1 are read once per application: streamed past the caches like the code words, so that the L2 keeps x)
+    if (MODE == MODE_RESIDUAL) e_b = __builtin_nontemporal_load(b + row);
     if (MODE == MODE_ADD) e_x = y[row];
-    if (MODE == MODE_SMOOTH) { e_b = b[row]; e_d = dinv[row]; e_x = xrow[row]; }
+    // (the smoother's x-row is x itself at the tile's own rows: taken from the staged segment that holds them, below)
+    if (MODE == MODE_SMOOTH) { e_b = __builtin_nontemporal_load(b + row); e_d = __builtin_nontemporal_load(dinv + row); }
     int mytab = 0;
     double myval = 0.0;
     if (wv == 0) {          // the tile's one table sits at its first slice
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(256) void sell_staged2_kernel(int nrows, int row0, 
     const int w = __builtin_amdgcn_readfirstlane((desc >> (8 + 6 * wv)) & 63);
     const int2 *sg = tile_seg + (size_t)gtile * SELL_SEG_MAX;
     const int R0 = row0 + blk * 256;
-    int mybase = 0;
+    int mybase = 0, zbase = -1;      // zbase: LDS index of x[R0] when a segment holds the tile's own rows
     // the tile's segments x[R0 + lo .. R0 + lo + len) -> lds[pre ..), 16 bytes per lane, four segments per batch (their loads
     // first, then the LDS stores).  CHECK = false: the descriptor says that every segment lies inside x (bit 7)
     auto stage = [&](auto check_tag) {
@@ -513,7 +515,8 @@ __global__ __launch_bounds__(256) void sell_staged2_kernel(int nrows, int row0, 
                         if (i < d.y) st[2 * k] = fetch(R0 + d.x + i);
                         if (i + 512 < d.y) st[2 * k + 1] = fetch(R0 + d.x + i + 512);
                         longer = longer || d.y > 1024;
-                        if (mytab >= d.x) mybase = pre - d.x;
+                        if (wv == 0 && mytab >= d.x) mybase = pre - d.x;
+                        if (MODE == MODE_SMOOTH && d.x <= 0 && d.x + d.y >= 256) zbase = pre - d.x;
                         pre += d.y;
                     }
                 }
@@ -537,7 +540,9 @@ __global__ __launch_bounds__(256) void sell_staged2_kernel(int nrows, int row0, 
     if (desc & 128) stage(std::false_type());
     else stage(std::true_type());
     if (wv == 0) lt[lane] = PairEntry{(mybase + mytab) << 3, 0, myval};
+    if (MODE == MODE_SMOOTH && zbase < 0) e_x = xrow[row];      // (no segment holds the own rows: an operator without a diagonal run)
     __syncthreads();
+    if (MODE == MODE_SMOOTH && zbase >= 0) e_x = lds[zbase + threadIdx.x];
     const char *lb = (const char *)lds + 8 * (lane + 64 * wv);
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll

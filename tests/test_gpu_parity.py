@@ -422,6 +422,52 @@ def test_poisson3d_three_level_without_symmetry_matches_oracle_tightly(n, blk, c
     h.close()
 
 
+@pytest.mark.parametrize("nwant", [13, 14])
+def test_thirteen_and_fourteen_wanted_pairs_take_the_block_of_sixteen(nwant):
+    """More wanted pairs than a block of eight reaches with one lock (twelve): the batch takes the block of SIXTEEN vectors
+    (round 4: ss_rr_kernel<16> with its 16 x 16 Rayleigh-Ritz step, the triangular solves that stream the factor) instead of
+    the dense path.  STRICT: any fallback is an error.  Matrices with exactly 13 / 14 small eigenvalues and a gap above them
+    (weakly coupled band Laplacians, each with its own near-null vector), next to one with two and one with six wanted
+    pairs; eigenvalues, residuals and D-orthogonal projectors against LAPACK (the oracle's lower_eigens_dense)."""
+    capi, o = _capi(), _oracle()
+    rng = np.random.default_rng(100 + nwant)
+
+    def chain(ncomp, size, bw, lift, couple):
+        n = ncomp * size
+        L = np.zeros((n, n))
+        for c in range(ncomp):
+            W = np.zeros((size, size))
+            for d in range(1, bw + 1):
+                w = rng.uniform(0.5, 1.5, size=size - d)
+                W += np.diag(-w, d) + np.diag(-w, -d)
+            B = W + np.diag(-W.sum(axis=1))
+            L[c * size:(c + 1) * size, c * size:(c + 1) * size] = B
+        for c in range(ncomp - 1):          # a weak edge between neighbouring components (inside the band)
+            i, j = (c + 1) * size - 1, (c + 1) * size
+            L[i, i] += couple; L[j, j] += couple; L[i, j] -= couple; L[j, i] -= couple
+        return L + np.diag(lift * rng.uniform(0.5, 1.0, size=n))
+    mats = [chain(nwant, 40, 5, 1e-5, 1e-4), chain(2, 150, 7, 1e-5, 1e-4), chain(6, 60, 4, 1e-5, 1e-4)]
+    Ds = [o.snd_D_from_dense(L) for L in mats]
+    import scipy.linalg as sla
+    w_all = sla.eigh(mats[0], np.diag(Ds[0]), eigvals_only=True)
+    theta = float(np.sqrt(w_all[nwant - 1] * w_all[nwant]))          # inside the gap of the first matrix ...
+    for L, D, k in zip(mats[1:], Ds[1:], (2, 6)):                    # ... and of the others
+        w = sla.eigh(L, np.diag(D), eigvals_only=True)
+        assert w[k - 1] < theta < w[k], (w[:k + 1], theta)
+    old = capi.set_options(eig_strict=1, eig_min_n=0)
+    try:
+        res = capi.lower_eigens_batched(mats, Ds, -1.0, theta)
+    finally:
+        capi.set_options(eig_strict=old.eig_strict, eig_min_n=old.eig_min_n)
+    for L, D, (w, X), k in zip(mats, Ds, res, (nwant, 2, 6)):
+        wr, Xr = o.lower_eigens_dense(L, D, theta)
+        assert len(w) == len(wr) == k
+        assert np.allclose(w, wr, atol=EIG_TOL)
+        R = L @ X - (D[:, None] * X) * w[None, :]
+        assert np.abs(R).max() <= 1e-10
+        assert np.allclose(_proj(X, D), _proj(Xr, D), atol=PROJ_TOL)
+
+
 @pytest.mark.parametrize("theta,m_interior", [(0.06, 7), (0.08, 8)])
 def test_more_wanted_pairs_than_the_block_holds_are_locked(theta, m_interior):
     """Agglomerates with seven to twelve wanted pairs (the reference's dsygvx has no such limit, src/xpacks.cpp:222-314):
@@ -429,7 +475,9 @@ def test_more_wanted_pairs_than_the_block_holds_are_locked(theta, m_interior):
     (csrc/eig2.hip: ss_lock_kernel, ss_deflate_kernel) instead of sending the agglomerate -- or, beyond a tenth of them,
     the whole chunk -- to the dense path.  STRICT: any fallback is an error.  The eight interior agglomerates of a
     32 x 32 x 16 mesh carry 7 (theta = 0.06) / 8 (0.08) pairs; counts, coarse dimension, iterations and history against
-    the oracle."""
+    the oracle.  (With theta = 0.12 they carry 13, but the window's end then sits in a dense part of the spectrum -- the 13th pair
+    converges like 0.9^k even with sixteen vectors -- and the agglomerates rightly go to the dense path:
+    test_thirteen_and_fourteen_wanted_pairs_take_the_block_of_sixteen uses matrices with a gap there.)"""
     capi, o = _capi(), _oracle()
     prob = pr.poisson3d_problem((32, 32, 16), blk=(8, 8, 4))
     old = capi.set_options(eig_strict=1)
