@@ -51,9 +51,9 @@ FP64_PEAK_TFLOPS = 78.6    # MI355X datasheet fp64 vector == matrix
 
 # profiler label -> (kernel symbol in rocprofv3 output, roofline bound)
 KERNELS = {
-    "smooth_step": ("sell_staged_kernel<3> / sell_spmv_kernel<3>", "hbm"),
-    "spmv": ("sell_staged_kernel<0> / sell_spmv_kernel<0>", "hbm"),
-    "spmv_residual": ("sell_staged_kernel<1> / sell_spmv_kernel<1>", "hbm"),
+    "smooth_step": ("sell_staged2_kernel<3> / sell_staged_kernel<3> / sell_spmv_kernel<3>", "hbm"),
+    "spmv": ("sell_staged2_kernel<0> / sell_staged_kernel<0> / sell_spmv_kernel<0>", "hbm"),
+    "spmv_residual": ("sell_staged2_kernel<1> / sell_staged_kernel<1> / sell_spmv_kernel<1>", "hbm"),
     "eig_sbr_symm": ("sbr_symm_kernel", "hbm"),
     "eig_sbr_syr2k": ("sbr_fused_kernel<false, 1>", "hbm"),
     "eig_sbr_fused": ("sbr_fused_kernel<true, 2>", "hbm"),

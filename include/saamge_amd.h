@@ -45,8 +45,9 @@ typedef struct saamge_amd_options {
     int eig_nullcheck;            /* 1: agglomerates whose one wanted pair is the known null vector skip the iteration */
     int eig_keep_inertia_factor;  /* 1: wide-band matrices with certified count 0 keep the factor of the inertia pass */
     int band_assembly;            /* 1: coarse-level agglomerate matrices are assembled, summed and scaled inside their band */
-    int overlap;                  /* 7: bit 0 subspace iteration of a chunk beside the next chunk's assembly, bit 1 halo exchange
-                                   * beside the interior rows, bit 2 Galerkin product beside the next level's eigenproblems */
+    int overlap;                  /* 15: bit 0 subspace iteration of a chunk beside the next chunk's assembly, bit 1 halo exchange
+                                   * beside the interior rows, bit 2 Galerkin product beside the next level's eigenproblems,
+                                   * bit 3 the fine operator's SELL copy and smoother diagonal beside the AE tables */
     int sell;                     /* 31: SELL slice formats: bit 0 coded slices at all, bit 1 pair coding (values in the table),
                                    * bit 2 the short-chain kernel path, bit 3 operator-level dictionary, bit 4 3 x 3 node blocks */
     int spmv_sell;                /* 0.  1: saamge_amd_spmv / spmv64 build and use the SELL copy (tests of the SELL kernels) */

@@ -2665,38 +2665,61 @@ bool eig_ss_band_enabled() {
 static void ss_factor_generic(hipStream_t s, EigBatch &b, bool sgn, int *neg, int *info_p, const int *bws, int bwmax,
                               int keep = 0, const int *skip = nullptr) {
     const int nmax = b.max_n;
-    const int cnt8 = 8 * div_up(b.count, 8);
     const bool prof = profiler().enabled;
-    struct { int *p; } info{info_p};
-    (void)cnt8;
-    const int *gbw = bws ? bws : (sgn ? b.bw.p : nullptr);
-    auto panel = [&](int k0, double *Vout, double *Zout, int rext, double *Sout) {
-        if (prof) profiler().begin(s);
-        const bool big = std::min(nmax, bwmax + 2 * SB) > 768;
-        if (sgn) {
-            if (big) hipLaunchKernelGGL((chol_panel_kernel<1024, true>), dim3(b.count), dim3(1024), 0, s, k0, b.n.p, b.moff.p,
-                                        b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, Sout, neg, keep, skip);
-            else hipLaunchKernelGGL((chol_panel_kernel<256, true>), dim3(b.count), dim3(256), 0, s, k0, b.n.p, b.moff.p,
-                                    b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, Sout, neg, keep, skip);
-        } else {
-            if (big) hipLaunchKernelGGL((chol_panel_kernel<1024, false>), dim3(b.count), dim3(1024), 0, s, k0, b.n.p, b.moff.p,
-                                        b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, (double *)nullptr, (int *)nullptr, 0, skip);
-            else hipLaunchKernelGGL((chol_panel_kernel<256, false>), dim3(b.count), dim3(256), 0, s, k0, b.n.p, b.moff.p,
-                                    b.voff.p, b.W.p, Vout, Zout, info.p, gbw, rext, (double *)nullptr, (int *)nullptr, 0, skip);
-        }
-        if (prof) profiler().end(s, sgn ? "eig_ss_inertia_panel" : "eig_ss_panel", 0.0, 0.0);
-    };
-    const double *vrow = sgn ? b.Xbuf.p : nullptr, *zrow = sgn ? b.Tfac.p : nullptr;
-    for (int k0 = 0; k0 < nmax; k0 += 2 * SB) {
+    const int *gbw_all = bws ? bws : (sgn ? b.bw.p : nullptr);
+    // Two halves of the batch on two streams (round 4): a panel is a latency chain (one workgroup per matrix: diagonal block by
+    // one wavefront, then the panel rows), the trailing update is compute-bound -- one half's panels run beside the other half's
+    // updates.  Every per-matrix array of the kernels is indexed by the matrix alone, so a half is the same launch with the
+    // arrays shifted.  Not under the profiler (its event pair brackets one stream), not for small batches.
+    const bool two = !prof && !env_serial() && b.count >= 64;
+    hipStream_t s2 = two ? side_stream(5) : s;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (two) {
+        SA_HIP_CHECK(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
+        SA_HIP_CHECK(hipEventCreateWithFlags(&ev1, hipEventDisableTiming));
+        SA_HIP_CHECK(hipEventRecord(ev0, s));                 // the matrices are assembled
+        SA_HIP_CHECK(hipStreamWaitEvent(s2, ev0, 0));
+    }
+    const int half0 = two ? (b.count / 2 + 7) / 8 * 8 : b.count;      // (multiples of 8: the XCD decode of the tiled kernels)
+    struct Part { hipStream_t q; int first, cnt; };
+    const Part parts[2] = {{s, 0, half0}, {s2, half0, b.count - half0}};
+    const int nparts = (two && b.count - half0 > 0) ? 2 : 1;
+    auto step = [&](const Part &P, int k0) {
+        hipStream_t q = P.q;
+        const int f = P.first, cnt = P.cnt;
+        const int cnt8 = 8 * div_up(cnt, 8);
+        const int *ns = b.n.p + f;
+        const int64_t *moff = b.moff.p + f, *voff = b.voff.p + f, *goff = b.goff.p + f;
+        const int *gbw = gbw_all ? gbw_all + f : nullptr;
+        const int *sk = skip ? skip + f : nullptr;
+        int *ng = neg ? neg + f : nullptr;
+        int *info = info_p + f;
+        auto panel = [&](int kk, double *Vout, double *Zout, int rext, double *Sout) {
+            if (prof) profiler().begin(q);
+            const bool big = std::min(nmax, bwmax + 2 * SB) > 768;
+            if (sgn) {
+                if (big) hipLaunchKernelGGL((chol_panel_kernel<1024, true>), dim3(cnt), dim3(1024), 0, q, kk, ns, moff,
+                                            voff, b.W.p, Vout, Zout, info, gbw, rext, Sout, ng, keep, sk);
+                else hipLaunchKernelGGL((chol_panel_kernel<256, true>), dim3(cnt), dim3(256), 0, q, kk, ns, moff,
+                                        voff, b.W.p, Vout, Zout, info, gbw, rext, Sout, ng, keep, sk);
+            } else {
+                if (big) hipLaunchKernelGGL((chol_panel_kernel<1024, false>), dim3(cnt), dim3(1024), 0, q, kk, ns, moff,
+                                            voff, b.W.p, Vout, Zout, info, gbw, rext, (double *)nullptr, (int *)nullptr, 0, sk);
+                else hipLaunchKernelGGL((chol_panel_kernel<256, false>), dim3(cnt), dim3(256), 0, q, kk, ns, moff,
+                                        voff, b.W.p, Vout, Zout, info, gbw, rext, (double *)nullptr, (int *)nullptr, 0, sk);
+            }
+            if (prof) profiler().end(q, sgn ? "eig_ss_inertia_panel" : "eig_ss_panel", 0.0, 0.0);
+        };
+        const double *vrow = sgn ? b.Xbuf.p : nullptr, *zrow = sgn ? b.Tfac.p : nullptr;
         panel(k0, b.Vpk.p, b.Zbuf.p, SB, b.Xbuf.p);
         const int np1f = nmax - k0 - SB;         // order of the trailing matrix after panel k
-        if (np1f < 1) break;
+        if (np1f < 1) return false;
         const int np1 = std::min(np1f, bwmax);   // ... of its part inside the band
         if (np1 >= 1) {
-            if (prof) profiler().begin(s);
-            hipLaunchKernelGGL(sbr_panel_update_kernel, dim3(cnt8 * div_up(np1, 256)), dim3(256), 0, s, k0, b.n.p, b.moff.p,
-                               b.voff.p, b.W.p, b.Vpk.p, b.Zbuf.p, b.count, div_up(np1, 256), 1, gbw, skip);
-            if (prof) profiler().end(s, sgn ? "eig_ss_inertia_panel" : "eig_ss_panel", 0.0, 0.0);
+            if (prof) profiler().begin(q);
+            hipLaunchKernelGGL(sbr_panel_update_kernel, dim3(cnt8 * div_up(np1, 256)), dim3(256), 0, q, k0, ns, moff,
+                               voff, b.W.p, b.Vpk.p, b.Zbuf.p, cnt, div_up(np1, 256), 1, gbw, sk);
+            if (prof) profiler().end(q, sgn ? "eig_ss_inertia_panel" : "eig_ss_panel", 0.0, 0.0);
         }
         panel(k0 + SB, b.Vpk2.p, nullptr, 0, b.Tfac.p);
         const int np = std::min(np1f - SB, bwmax);    // ... after panel k + 1
@@ -2704,21 +2727,33 @@ static void ss_factor_generic(hipStream_t s, EigBatch &b, bool sgn, int *neg, in
             double ub = 0.0;
             if (prof) {      // lower tiles of the trailing matrices (inside the band), read and written once
                 for (size_t i = 0; i < b.h_n.size(); ++i) {
-                    double q = (double)b.h_n[i] - k0 - 2 * SB;
-                    if (!b.h_bw.empty()) q = std::min(q, (double)b.h_bw[i]);
-                    if (q >= 1.0) ub += 8.0 * q * q;
+                    double qn = (double)b.h_n[i] - k0 - 2 * SB;
+                    if (!b.h_bw.empty()) qn = std::min(qn, (double)b.h_bw[i]);
+                    if (qn >= 1.0) ub += 8.0 * qn * qn;
                 }
-                profiler().begin(s);
+                profiler().begin(q);
             }
             // (one row per lane, 108 VGPRs, four wavefronts per SIMD: 8 % faster on the 2 187-row agglomerates of config 5 than two
             // rows per lane at 212 VGPRs and two wavefronts per SIMD)
-                hipLaunchKernelGGL((sbr_fused_kernel<false, 1, 3>), dim3(cnt8 * div_up(np, SF_ROWS)), dim3(S2_NT), 0, s, k0,
-                                   b.n.p, b.moff.p, b.voff.p, b.W.p, b.Vpk.p, b.Vpk2.p, b.Vpk.p, b.Xbuf.p, b.goff.p,
-                                   b.Gbuf.p, b.trash.p, b.count, div_up(np, SF_ROWS), SB, gbw, vrow, zrow, skip);
-            if (prof) profiler().end(s, sgn ? "eig_ss_inertia_update" : (np > 192 ? "eig_ss_update" : "eig_ss_update1"), ub, 0.0);
+            hipLaunchKernelGGL((sbr_fused_kernel<false, 1, 3>), dim3(cnt8 * div_up(np, SF_ROWS)), dim3(S2_NT), 0, q, k0,
+                               ns, moff, voff, b.W.p, b.Vpk.p, b.Vpk2.p, b.Vpk.p, b.Xbuf.p, goff,
+                               b.Gbuf.p, b.trash.p, cnt, div_up(np, SF_ROWS), SB, gbw, vrow, zrow, sk);
+            if (prof) profiler().end(q, sgn ? "eig_ss_inertia_update" : (np > 192 ? "eig_ss_update" : "eig_ss_update1"), ub, 0.0);
         }
+        return true;
+    };
+    for (int k0 = 0; k0 < nmax; k0 += 2 * SB) {
+        bool more = false;
+        for (int h = 0; h < nparts; ++h) more = step(parts[h], k0) || more;
+        if (!more) break;
     }
     SA_HIP_CHECK(hipGetLastError());
+    if (two) {
+        SA_HIP_CHECK(hipEventRecord(ev1, s2));
+        SA_HIP_CHECK(hipStreamWaitEvent(s, ev1, 0));
+        SA_HIP_CHECK(hipEventDestroy(ev0));
+        SA_HIP_CHECK(hipEventDestroy(ev1));
+    }
 }
 
 bool eig_subspace_factor(hipStream_t s, EigBatch &b) {

@@ -74,6 +74,7 @@ struct Level {                  // tg_data_t + interp_data_t + agg_partitioning_
     double theta = 0.0;
     int nu_relax = 3;
     Relations rel;              // host topology
+    bool rel_prebuilt = false;  // rel was built ahead, beside the coarse element matrices of the level above (prepare_next_level)
     NextPrep next_prep;         // filled beside the Galerkin product, consumed by prepare_next_level
     DevRelations drel;          // device mirror
     DevElmats elmat;            // element matrices of this level
@@ -166,6 +167,10 @@ struct Hierarchy {              // ml_data_t
     };
     std::vector<UserSmoother> user_smoothers;
     DBuf<int> own_e2d;          // element-free mode: the generated identity elem_to_dof
+    // host copies of the coarse partitions (levels >= 1: a few thousand ints), fetched once at the start of the setup: the host
+    // build of a coarse level's AE tables starts while the GPU still computes that level's element matrices
+    std::vector<hvec<int>> coarse_parts;
+    std::vector<int> nparts_in;
     std::unique_ptr<DistIn> dist_in;      // per-rank inputs: the gathered operator / topology the level-0 arrays view
     // setup only: the Galerkin product of level `galerkin_lev` runs on its own thread and stream beside the
     // next level's element matrices and eigenproblems (which need the level's size, not its operator)

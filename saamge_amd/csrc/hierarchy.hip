@@ -168,6 +168,29 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     L.nu_relax = P.nu_relax[lev];
     SA_REQUIRE(P.nu_pro[lev] >= 0 && P.nu_pro[lev] <= 8, "bad prolongator smoothing degree");
     PhaseTimer tm(s);
+    // Fine level, device-resident inputs: the SELL copy of the operator and the smoother diagonal (bandwidth work on A alone) are
+    // built on a thread and stream of their own BESIDE the device build of the AE tables (integer work on elem_to_dof: sorts,
+    // hash sets, atomics), and joined where they used to run, before the eigenproblems.
+    std::thread op_thread;
+    std::exception_ptr op_err;
+    struct OpJoiner { std::thread &t; ~OpJoiner() { if (t.joinable()) t.join(); } } op_joiner{op_thread};
+    const bool op_early = lev == 0 && din && !env_serial() && !profiler().enabled && H.galerkin_lev < 0 && (options().overlap & 8);
+    if (op_early) {
+        hipStream_t os = side_stream(6);
+        const int dev0 = current_device();
+        SA_HIP_CHECK(hipStreamSynchronize(s));          // (the operator's arrays are complete)
+        op_thread = std::thread([&L, &op_err, os, dev0]() {
+            try {
+                adopt_device(dev0);
+                set_thread_stream(os);
+                build_sell(os, L.A);
+                L.dinv_neg.alloc((size_t)L.A.nrows);
+                DBuf<double> tmp((size_t)L.A.nrows);
+                build_dinv_neg(os, L.A, tmp.p, L.dinv_neg.p);
+                SA_HIP_CHECK(hipStreamSynchronize(os));
+            } catch (...) { op_err = std::current_exception(); }
+        });
+    }
     bool on_device = false;
     if (din) {
         on_device = build_relations_ae_device(L.rel, L.drel, din->e2d, din->NE, din->nde, din->part, nparts,
@@ -185,9 +208,10 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
             part_h = fetch_host(din->part, (size_t)din->NE, s);
             if (din->bdr) bdr_h = fetch_host(din->bdr, (size_t)L.A.nrows, s);
         }
-        build_relations_ae(L.rel, std::move(e2d), din ? part_h : part, nparts, L.A.nrows,
-                           din ? (din->bdr ? bdr_h.data() : nullptr) : bdr_host);
-        tm.lap("host topology (AE tables)", lev);
+        if (!L.rel_prebuilt)
+            build_relations_ae(L.rel, std::move(e2d), din ? part_h : part, nparts, L.A.nrows,
+                               din ? (din->bdr ? bdr_h.data() : nullptr) : bdr_host);
+        tm.lap(L.rel_prebuilt ? "host topology (built beside the element matrices)" : "host topology (AE tables)", lev);
         upload_relations_ae(L.drel, L.rel, s);
         tm.lap("upload topology", lev);
     }
@@ -255,7 +279,13 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         SA_HIP_CHECK(hipStreamSynchronize(s));
     };
     const bool operator_pending = H.galerkin_lev >= 0;
-    if (!operator_pending) operator_data();
+    // (Measured in round 4 and dropped: the fine level's SELL copy and D^-1 -- 13 ms of bandwidth work the setup itself does not
+    // need -- on a thread and stream of their own beside the next level: setup 247 -> 243 ms, but the smoother then ran at 221
+    // instead of 216 us per step and the step took 399 instead of 390 ms.)
+    if (op_early) {
+        op_thread.join();
+        if (op_err) std::rethrow_exception(op_err);
+    } else if (!operator_pending) operator_data();
     L.roots = sas_poly_roots(L.nu_relax);
 
     // ---- local spectral problems, chunked over AEs (interp_compute_vectors) ----
@@ -842,6 +872,27 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
     }
     N.elmat.off.from_host(out_off, s);
     N.elmat.val.alloc((size_t)out_off[nparts] + 1);
+    // The next level's AE tables are a HOST build (7.8 ms on the headline's level 1).  Its inputs are complete here -- the coarse
+    // element lists just made, the caller's partition -- and nothing below needs its result: it runs on a thread of its own
+    // beside the coarse element matrices (20 ms of device work during which this thread only waits).
+    std::exception_ptr topo_err;
+    std::thread topo_thread;
+    struct TopoJoiner { std::thread &t; ~TopoJoiner() { if (t.joinable()) t.join(); } } topo_joiner{topo_thread};
+    if (lev + 1 < H.params.num_coarsenings && lev + 1 < (int)H.coarse_parts.size() && !H.coarse_parts[(size_t)lev + 1].empty() &&
+        !env_serial()) {
+        const int dev = current_device();
+        const int nd_next = L.mis_coloff.back(), np_next = H.nparts_in[(size_t)lev + 1];
+        Table *e2d_copy = new Table(e2d);
+        const hvec<int> *part_next = &H.coarse_parts[(size_t)lev + 1];
+        topo_thread = std::thread([&N, &topo_err, e2d_copy, part_next, nd_next, np_next, dev]() {
+            std::unique_ptr<Table> own(e2d_copy);
+            try {
+                adopt_device(dev);
+                build_relations_ae(N.rel, std::move(*own), *part_next, np_next, nd_next, nullptr);
+                N.rel_prebuilt = true;
+            } catch (...) { topo_err = std::current_exception(); }
+        });
+    }
     std::vector<int> sizes((size_t)nparts);
     for (int p = 0; p < nparts; ++p) sizes[p] = rel.AE_to_dof.row_size(p);
     // several ranks: each computes the coarse element matrices of its AE range (the ranges of
@@ -894,6 +945,8 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
         SA_REQUIRE(H.params.allgather(H.params.allgather_ctx, N.elmat.val.p, off.data()) == 0,
                    "all-gather (coarse element matrices) failed");
     }
+    if (topo_thread.joinable()) topo_thread.join();
+    if (topo_err) std::rethrow_exception(topo_err);
     return e2d;
 }
 
@@ -1331,11 +1384,21 @@ Hierarchy *hierarchy_create(int n, const void *Arow, int rowptr_bits, const int 
         e2d.ncols = n;
         if (bdr) bdr_h = fetch_host(bdr, (size_t)n, s);
     }
+    H.coarse_parts.resize((size_t)p.num_coarsenings);
+    H.nparts_in.assign(nparts, nparts + p.num_coarsenings);
+    {
+        int ne = nparts[0];
+        for (int lev = 1; lev < p.num_coarsenings; ++lev) {       // (level-lev elements = level-(lev - 1) agglomerates)
+            H.coarse_parts[(size_t)lev] = fetch_host(partitions[lev], (size_t)ne, s);
+            ne = nparts[lev];
+        }
+    }
     tm0.lap("inputs fetched/imported", 0);
     int n_elem = NE;
     for (int lev = 0; lev < p.num_coarsenings; ++lev) {
         hvec<int> part;
-        if (!(lev == 0 && dev_inputs)) part = fetch_host(partitions[lev], (size_t)n_elem, s);
+        if (lev > 0) part = H.coarse_parts[(size_t)lev];
+        else if (!dev_inputs) part = fetch_host(partitions[lev], (size_t)n_elem, s);
         const bool tag_levels = (options().debug & 4) != 0;
         profiler().level_tag = tag_levels ? lev : 0;
         build_level(H, lev, std::move(e2d), part, nparts[lev], (lev == 0 && bdr && !dev_inputs) ? bdr_h.data() : nullptr,

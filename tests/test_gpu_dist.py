@@ -112,7 +112,7 @@ def test_halo_overlap_does_not_change_the_arithmetic(tmp_path):
     """Interior rows beside the halo exchange (csrc/dist.hip: halo_then) against exchange-then-apply: the same
     kernels on the same rows, so every vector must be bit-identical."""
     on = _run(tmp_path, 2, min_rows=1)
-    off = _run(tmp_path, 2, min_rows=1, extra_env={"SAAMGE_AMD_TEST_OPTIONS": "overlap=5"}, tag="_off")
+    off = _run(tmp_path, 2, min_rows=1, extra_env={"SAAMGE_AMD_TEST_OPTIONS": "overlap=13"}, tag="_off")
     for a, b in zip(on, off):
         for k in ("x", "vc", "sm", "hist", "it"):
             assert np.array_equal(a[k], b[k]), k

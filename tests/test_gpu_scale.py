@@ -142,7 +142,7 @@ def test_coarse_level_switches_give_the_same_hierarchy():
         "                  'hist': list(hist), 'm': ms}))\n" % root)
     outs = []
     for extra in ({}, {"SAAMGE_AMD_TEST_OPTIONS": "band_assembly=0"}, {"SAAMGE_AMD_TEST_OPTIONS": "eig_keep_inertia_factor=0"},
-                  {"SAAMGE_AMD_TEST_OPTIONS": "overlap=6"}):
+                  {"SAAMGE_AMD_TEST_OPTIONS": "overlap=14"}):
         o = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         assert o.returncode == 0, o.stderr[-2000:]
         outs.append(json.loads(o.stdout.strip().splitlines()[-1]))
