@@ -121,6 +121,7 @@ void eig_subspace_vectors(hipStream_t s, EigBatch &b, const int64_t *eoff, const
                           double *evecs);
 void eig_arena_release();   // frees the persistent workspace
 double *eig_arena_bandsave(const EigBatch &b, size_t doubles);   // persistent scratch of the inertia pass
+double *eig_arena_subpanels(const EigBatch &b, size_t doubles); // packed sub-panels of the outer blocks of the wide-band factorisations
 // bytes of device workspace one matrix of size n needs (for chunk sizing)
 size_t eig_workspace_bytes(int n);
 // Phase 2: count eigenvalues in (vl, vu] (Sturm); fills b.m / b.j0 and the host copy b.h_m

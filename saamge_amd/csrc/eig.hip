@@ -750,7 +750,7 @@ static bool use_one_stage() { return options().eig_dense_one_stage != 0; }
 // multi-GB buffers costs 0.1-0.4 s each on this platform; the arena is allocated once per
 // process and reused by every chunk / level / hierarchy).  Single stream, sequential use.
 struct EigArena {
-    DBuf<double> W, panel, d, e, tau, dis, Tfac, Xbuf, Zbuf, Vpk, Vpk2, trash, rv, rtau, bandg, Gbuf, Xpart, bandsave;
+    DBuf<double> W, panel, d, e, tau, dis, Tfac, Xbuf, Zbuf, Vpk, Vpk2, trash, rv, rtau, bandg, Gbuf, Xpart, bandsave, subpanels;
     DBuf<int> n, m, j0;
     DBuf<int64_t> moff, voff, roff, goff, xpoff;
 };
@@ -779,6 +779,13 @@ double *eig_arena_bandsave(const EigBatch &b, size_t doubles) {
     EigArena &a = arena();
     if (a.bandsave.n < doubles) a.bandsave.alloc(doubles + doubles / 8 + 64);
     return a.bandsave.p;
+}
+
+double *eig_arena_subpanels(const EigBatch &b, size_t doubles) {
+    g_slot = b.slot;
+    EigArena &a = arena();
+    if (a.subpanels.n < doubles) a.subpanels.alloc(doubles + doubles / 8 + 64);
+    return a.subpanels.p;
 }
 
 void eig_batch_alloc(EigBatch &b, const std::vector<int> &sizes, hipStream_t s, int slot) {
@@ -852,7 +859,7 @@ constexpr size_t LDS_MAX = 160 * 1024;
 
 size_t eig_workspace_bytes(int n) {
     const size_t nn = (size_t)n;
-    return 8 * (nn * nn + nn * (EIG_NB + 8) + nn * nn / 2 + nn * (3 * EIG_SB + 2 * EIG_SB) + 64);
+    return 8 * (nn * nn + nn * (EIG_NB + 8) + nn * nn / 2 + nn * (3 * EIG_SB + 2 * EIG_SB + 16 * EIG_SB) + 64);
 }
 
 // The few-eigenpairs path (eig2.hip) is the default for batches whose largest agglomerate has at

@@ -2651,6 +2651,348 @@ __global__ void ss_reshift_mu_kernel(int nreq, const int *__restrict__ req, cons
     if (q < 4) hist[(size_t)b * 4 + q] = 0.0;
 }
 
+// ---------------------------------------------------------------------------------------
+// Wide-band factorisations by OUTER BLOCKS of G 16-column sub-panels (round 4)
+// ---------------------------------------------------------------------------------------
+// The two-panel walk below passes over the trailing window (bw x bw / 2 entries per matrix, read and written) once per
+// 32 columns: 4 flop per byte, 3 TB/s and 12 TFLOP/s on config 5's 2 187-row agglomerates (half bandwidth ~580), and
+// three launches per 32 columns whose panel kernels are latency chains.  Here an outer block of G sub-panels is
+// factored LEFT-LOOKING -- sub-panel g first receives the updates of sub-panels 0 .. g - 1 of its block (their packed
+// copies are a few hundred KB per matrix: L2), then is factored; one launch per 16 columns, the panel's columns read
+// once and written once -- and the trailing window takes ONE rank-16 G update per outer block on the matrix cores
+// (v_mfma_f64_16x16x4): 8 (G = 4) or 16 (G = 8) flop per byte of window traffic.
+// Packed sub-panels: Pc = column operands (L21), Pr = row operands (L21 again, or L21 S of the signed walk
+// C - theta I = L S L^T), sub-panel g at g * pstride, row r of the matrix at packed row r - (k0 + SB (g + 1)),
+// rows up to k0 + SB G + bw (zeros past the band: the trailing update reads them with the sub-panel's row shift).
+// MFMA lane roles (16 x 16 x 4, f64): lane = (l15, l4); A operand A[row l15][k l4], B operand B[k l4][col l15], C / D
+// element [row l4 + 4 reg][col l15].  Everywhere below the MFMA "col" is a matrix ROW (16 consecutive rows of a
+// column-major column: 128 contiguous bytes per quarter wavefront) and the MFMA "row" a matrix COLUMN.
+template <int NT, int G, bool SIGNED>
+__global__ __launch_bounds__(NT) void chol_panel_ll_kernel(int k0, int g, const int *__restrict__ ns,
+                                                            const int64_t *__restrict__ moff, const int64_t *__restrict__ voff,
+                                                            double *__restrict__ W, double *__restrict__ Pc, double *__restrict__ Pr,
+                                                            size_t pstride, int *__restrict__ info, const int *__restrict__ bws,
+                                                            int *__restrict__ neg, int keep, const int *__restrict__ skip) {
+    __shared__ double Ld[SB][SB + 1];
+    __shared__ double Li[SB][SB + 1];
+    __shared__ double sg[SB];
+    __shared__ __align__(16) double Cb[G - 1][SB][18];      // column operands of the earlier sub-panels on the rows of this one
+    __shared__ int bad;
+    const int b = blockIdx.x, n = ns[b];
+    const int kk = k0 + SB * g;
+    if (kk >= n) return;
+    if (skip && skip[b]) return;
+    const int bw = bws ? bws[b] : n;
+    const int rin = min(n, kk + SB + bw);                        // rows from here on are zero in these columns
+    const int rend = min(n, kk + SB + bw + SB * (G - 1 - g));    // ... and still written (as zeros) to the packed copies
+    double *A = W + moff[b];
+    const int nb = min(SB, n - kk);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    constexpr int NW = NT / 64;
+    const size_t vo = (size_t)voff[b] * SB;
+    for (int idx = tid; idx < g * SB * SB; idx += NT) {
+        const int gp = idx >> 8, i = (idx >> 4) & 15, k = idx & 15;
+        const int pr = kk + i - (k0 + SB * (gp + 1));
+        Cb[gp][i][k] = (kk + i < n) ? Pc[gp * pstride + vo + (size_t)pr * SB + k] : 0.0;
+    }
+    __syncthreads();
+    double ca[G - 1][4];      // A operands: Cb[gp][column l15][k = 4 l4 + s]
+#pragma unroll
+    for (int gp = 0; gp < G - 1; ++gp)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ca[gp][s] = (gp < g) ? Cb[gp][l15][4 * l4 + s] : 0.0;
+    // the 16 rows from r0 on of the panel's columns with the block's earlier sub-panels applied: element
+    // (row r0 + l15, column kk + l4 + 4 reg); rows past the band / the matrix come out as exact zeros
+    auto updated = [&](int r0) {
+        const int r = r0 + l15;
+        const int rc = min(r, rin - 1);
+        ss_v4d x;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) x[reg] = A[(size_t)min(kk + l4 + 4 * reg, n - 1) * n + rc];
+#pragma unroll
+        for (int gp = 0; gp < G - 1; ++gp) {
+            if (gp < g) {      // (block-uniform)
+                const double *p = Pr + gp * pstride + vo + (size_t)(rc - (k0 + SB * (gp + 1))) * SB + 4 * l4;
+                const double2 p0 = *(const double2 *)p, p1 = *(const double2 *)(p + 2);
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[gp][0], -p0.x, x, 0, 0, 0);
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[gp][1], -p0.y, x, 0, 0, 0);
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[gp][2], -p1.x, x, 0, 0, 0);
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[gp][3], -p1.y, x, 0, 0, 0);
+            }
+        }
+        if (r >= rin) x = ss_v4d{0.0, 0.0, 0.0, 0.0};
+        return x;
+    };
+    // rows below the diagonal block, 16 per wavefront and trip; the first tile's loads and products do not wait for the block
+    const int ntile = (rend - kk - SB + 15) >> 4;
+    ss_v4d xfirst = ss_v4d{0.0, 0.0, 0.0, 0.0};
+    if (nb == SB && wv < ntile) xfirst = updated(kk + SB + 16 * wv);
+    if (wv == 0) {
+        const ss_v4d x = updated(kk);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int c = l4 + 4 * reg;
+            Ld[l15][c] = (l15 < nb && c <= l15) ? x[reg] : ((l15 == c) ? 1.0 : 0.0);
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int r = chol16_inverse_wave<SIGNED>(Ld, Li, tid, sg);
+        if (tid == 0) bad = r;
+    }
+    __syncthreads();
+    if (SIGNED) {
+        if (tid == 0) { if (bad < 0) info[b] = 1; else neg[b] += bad; }
+    } else {
+        if (tid == 0 && bad) info[b] = 1;
+    }
+    if (!SIGNED || keep) {      // the diagonal block is kept INVERTED (both triangles), as the solves expect it
+        if (tid < SB * SB) {
+            const int i = tid >> 4, j = tid & 15;
+            if (i < nb && j <= i) {
+                A[(size_t)(kk + j) * n + (kk + i)] = Li[i][j];
+                A[(size_t)(kk + i) * n + (kk + j)] = Li[i][j];
+            }
+        }
+    }
+    if (nb < SB) return;
+    double la[4], sgc[4];     // A operand of the solve: L11^-1[row l15][k = l4 + 4 s] (the k slots of the C layout)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { la[s] = Li[l15][l4 + 4 * s]; sgc[s] = SIGNED ? sg[l4 + 4 * s] : 1.0; }
+    double *Pcg = Pc + g * pstride + vo, *Prg = Pr + g * pstride + vo;
+    for (int t = wv; t < ntile; t += NW) {
+        const int r0 = kk + SB + 16 * t;
+        const ss_v4d x = (t == wv) ? xfirst : updated(r0);
+        ss_v4d y = ss_v4d{0.0, 0.0, 0.0, 0.0};      // row of L21 (S) = x L11^-T: element (row r0 + l15, column l4 + 4 reg)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) y = __builtin_amdgcn_mfma_f64_16x16x4f64(la[s], x[s], y, 0, 0, 0);
+        const int r = r0 + l15;
+        const bool live = r < rend;      // (stores under the mask: no divergent branch around the matrix-core instructions)
+        const size_t pr = (size_t)(r - kk - SB) * SB;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int c = l4 + 4 * reg;
+            const double ts = y[reg], tv = SIGNED ? ts * sgc[reg] : ts;
+            if (live) Pcg[pr + c] = tv;
+            if (SIGNED && live) Prg[pr + c] = ts;
+            if (r < rin) {
+                if (!SIGNED) {
+                    A[(size_t)(kk + c) * n + r] = tv;
+                    A[(size_t)r * n + (kk + c)] = tv;
+                } else if (keep) {
+                    A[(size_t)(kk + c) * n + r] = tv;      // (L only; L^T: ss_keep_transpose_kernel, kept matrices only)
+                }
+            }
+        }
+    }
+}
+
+// A22 -= sum over the G sub-panels of (row operands) (column operands)^T on the lower tiles of the trailing window of the
+// outer block at k0.  One workgroup per strip of 128 rows (four wavefronts, 32 rows each: their row operands stay in
+// registers, negated), walking the column blocks of 16 up to the strip's diagonal; the column operands of a block are
+// staged through LDS once per workgroup (double-buffered, one barrier per column block), the window tiles are requested
+// one column block ahead.  Tiles that cross the diagonal are updated whole (the factorisations read the lower triangle).
+template <int G, bool SIGNED>
+__global__ __launch_bounds__(256) void band_trail_mfma_kernel(int k0, const int *__restrict__ ns, const int64_t *__restrict__ moff,
+                                                              const int64_t *__restrict__ voff, double *__restrict__ W,
+                                                              const double *__restrict__ Pc, const double *__restrict__ Pr,
+                                                              size_t pstride, int count, int tiles, const int *__restrict__ bws,
+                                                              const int *__restrict__ skip) {
+    __shared__ __align__(16) double As[2][G][SB][18];
+    int b, blk;
+    xcd_decode(tiles, b, blk);
+    if (b >= count) return;
+    if (skip && skip[b]) return;
+    const int n = ns[b], base = k0 + SB * G;
+    int np = n - base;
+    if (bws) np = min(np, bws[b]);
+    if (np < 1) return;
+    blk = tiles - 1 - blk;                 // (the long strips first)
+    const int i0 = blk * 128;
+    if (i0 >= np) return;
+    double *A22 = W + moff[b] + (size_t)base * n + base;
+    const size_t vo = (size_t)voff[b] * SB;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int iw = i0 + 32 * wv;
+    double br[2][G][4];      // row operands, negated: [tile][sub-panel][k = 4 l4 + s]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int r = min(iw + 16 * t + l15, np - 1);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const double *p = Pr + g * pstride + vo + (size_t)(r + SB * (G - 1 - g)) * SB + 4 * l4;
+            const double2 p0 = *(const double2 *)p, p1 = *(const double2 *)(p + 2);
+            br[t][g][0] = -p0.x; br[t][g][1] = -p0.y; br[t][g][2] = -p1.x; br[t][g][3] = -p1.y;
+        }
+    }
+    const int jend = min(np, i0 + 128);
+    const int nj = (jend + 15) >> 4;
+    constexpr int CH = G / 4;              // 32-byte pieces of a column block's operands per thread
+    double2 sv[CH][2];
+    auto stage_load = [&](int jb) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int ch = tid + 256 * u, g = ch >> 6, j = (ch >> 2) & 15, q = ch & 3;
+            const double *p = Pc + g * pstride + vo + (size_t)(min(16 * jb + j, np - 1) + SB * (G - 1 - g)) * SB + 4 * q;
+            sv[u][0] = *(const double2 *)p;
+            sv[u][1] = *(const double2 *)(p + 2);
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int ch = tid + 256 * u, g = ch >> 6, j = (ch >> 2) & 15, q = ch & 3;
+            *(double2 *)&As[buf][g][j][4 * q] = sv[u][0];
+            *(double2 *)&As[buf][g][j][4 * q + 2] = sv[u][1];
+        }
+    };
+    // window tile (rows iw + 16 t + l15, columns 16 jb + l4 + 4 reg): always loaded from clamped addresses, stored under the mask
+    const int rowc[2] = {min(iw + l15, np - 1), min(iw + 16 + l15, np - 1)};
+    auto tile_load = [&](int jb, ss_v4d (&c)[2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) c[t][reg] = A22[(size_t)min(16 * jb + l4 + 4 * reg, np - 1) * n + rowc[t]];
+    };
+    stage_load(0);
+    ss_v4d cn[2];
+    tile_load(0, cn);
+    stage_store(0);
+    __syncthreads();
+    for (int jb = 0; jb < nj; ++jb) {
+        const int cur = jb & 1;
+        const bool more = jb + 1 < nj;
+        ss_v4d c[2] = {cn[0], cn[1]};
+        if (more) {
+            stage_load(jb + 1);
+            tile_load(jb + 1, cn);
+        }
+        // (wave-uniform) tile t takes part when some column of the block is not beyond its last row and it has rows at all
+        const bool on0 = iw < np && 16 * jb <= iw + 15, on1 = iw + 16 < np && 16 * jb <= iw + 31;
+        if (on1) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const double2 a0 = *(const double2 *)&As[cur][g][l15][4 * l4], a1 = *(const double2 *)&As[cur][g][l15][4 * l4 + 2];
+                if (on0) {
+                    c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, br[0][g][0], c[0], 0, 0, 0);
+                    c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, br[0][g][1], c[0], 0, 0, 0);
+                    c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, br[0][g][2], c[0], 0, 0, 0);
+                    c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, br[0][g][3], c[0], 0, 0, 0);
+                }
+                c[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, br[1][g][0], c[1], 0, 0, 0);
+                c[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, br[1][g][1], c[1], 0, 0, 0);
+                c[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, br[1][g][2], c[1], 0, 0, 0);
+                c[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, br[1][g][3], c[1], 0, 0, 0);
+            }
+        } else if (on0) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const double2 a0 = *(const double2 *)&As[cur][g][l15][4 * l4], a1 = *(const double2 *)&As[cur][g][l15][4 * l4 + 2];
+                c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, br[0][g][0], c[0], 0, 0, 0);
+                c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, br[0][g][1], c[0], 0, 0, 0);
+                c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, br[0][g][2], c[0], 0, 0, 0);
+                c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, br[0][g][3], c[0], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (!(t ? on1 : on0)) continue;
+            const int r = iw + 16 * t + l15;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int col = 16 * jb + l4 + 4 * reg;
+                if (r < np && col < np) A22[(size_t)col * n + r] = c[t][reg];
+            }
+        }
+        if (more) stage_store(cur ^ 1);
+        __syncthreads();
+    }
+}
+
+
+template <int G>
+static void ss_factor_blocked(hipStream_t s, EigBatch &b, bool sgn, int *neg, int *info_p, const int *gbw_all, int bwmax, int keep,
+                              const int *skip) {
+    const int nmax = b.max_n;
+    const bool prof = profiler().enabled;
+    const size_t rows = (size_t)b.h_voff[b.count];
+    const size_t pstride = (rows * SB + 15) / 16 * 16;
+    double *Pc = eig_arena_subpanels(b, pstride * G * (sgn ? 2 : 1));
+    double *Pr = sgn ? Pc + pstride * G : Pc;
+    // two halves of the batch on two streams, as in the two-panel walk below: one half's panels (latency chains) beside the
+    // other half's window updates
+    const bool two = !prof && !env_serial() && b.count >= 64;
+    hipStream_t s2 = two ? side_stream(5) : s;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (two) {
+        SA_HIP_CHECK(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
+        SA_HIP_CHECK(hipEventCreateWithFlags(&ev1, hipEventDisableTiming));
+        SA_HIP_CHECK(hipEventRecord(ev0, s));
+        SA_HIP_CHECK(hipStreamWaitEvent(s2, ev0, 0));
+    }
+    const int half0 = two ? (b.count / 2 + 7) / 8 * 8 : b.count;
+    struct Part { hipStream_t q; int first, cnt; };
+    const Part parts[2] = {{s, 0, half0}, {s2, half0, b.count - half0}};
+    const int nparts = (two && b.count - half0 > 0) ? 2 : 1;
+    auto step = [&](const Part &P, int k0) {
+        hipStream_t q = P.q;
+        const int f = P.first, cnt = P.cnt;
+        const int cnt8 = 8 * div_up(cnt, 8);
+        const int *ns = b.n.p + f;
+        const int64_t *moff = b.moff.p + f, *voff = b.voff.p + f;
+        const int *gbw = gbw_all ? gbw_all + f : nullptr;
+        const int *sk = skip ? skip + f : nullptr;
+        int *ng = neg ? neg + f : nullptr;
+        int *info = info_p + f;
+        const bool big = std::min(nmax - k0, bwmax + SB * G) > 448;
+        if (prof) profiler().begin(q);
+        for (int g = 0; g < G && k0 + SB * g < nmax; ++g) {
+            if (sgn) {
+                if (big) hipLaunchKernelGGL((chol_panel_ll_kernel<512, G, true>), dim3(cnt), dim3(512), 0, q, k0, g, ns, moff, voff, b.W.p, Pc, Pr,
+                                            pstride, info, gbw, ng, keep, sk);
+                else hipLaunchKernelGGL((chol_panel_ll_kernel<256, G, true>), dim3(cnt), dim3(256), 0, q, k0, g, ns, moff, voff, b.W.p, Pc, Pr,
+                                        pstride, info, gbw, ng, keep, sk);
+            } else {
+                if (big) hipLaunchKernelGGL((chol_panel_ll_kernel<512, G, false>), dim3(cnt), dim3(512), 0, q, k0, g, ns, moff, voff, b.W.p, Pc, Pr,
+                                            pstride, info, gbw, (int *)nullptr, 0, sk);
+                else hipLaunchKernelGGL((chol_panel_ll_kernel<256, G, false>), dim3(cnt), dim3(256), 0, q, k0, g, ns, moff, voff, b.W.p, Pc, Pr,
+                                        pstride, info, gbw, (int *)nullptr, 0, sk);
+            }
+        }
+        if (prof) profiler().end(q, sgn ? "eig_ss_inertia_panel" : "eig_ss_panel", 0.0, 0.0);
+        const int npmax = std::min(nmax - k0 - SB * G, bwmax);
+        if (npmax < 1) return false;
+        double ub = 0.0;
+        if (prof) {      // lower tiles of the trailing windows, read and written once
+            for (size_t i = 0; i < b.h_n.size(); ++i) {
+                double qn = (double)b.h_n[i] - k0 - SB * G;
+                if (!b.h_bw.empty()) qn = std::min(qn, (double)b.h_bw[i]);
+                if (qn >= 1.0) ub += 8.0 * qn * qn;
+            }
+            profiler().begin(q);
+        }
+        const int tiles = div_up(npmax, 128);
+        if (sgn) hipLaunchKernelGGL((band_trail_mfma_kernel<G, true>), dim3(cnt8 * tiles), dim3(256), 0, q, k0, ns, moff, voff, b.W.p, Pc, Pr,
+                                    pstride, cnt, tiles, gbw, sk);
+        else hipLaunchKernelGGL((band_trail_mfma_kernel<G, false>), dim3(cnt8 * tiles), dim3(256), 0, q, k0, ns, moff, voff, b.W.p, Pc, Pr,
+                                pstride, cnt, tiles, gbw, sk);
+        if (prof) profiler().end(q, sgn ? "eig_ss_inertia_update" : (npmax > 192 ? "eig_ss_update" : "eig_ss_update1"), ub, 0.0);
+        return true;
+    };
+    for (int k0 = 0; k0 < nmax; k0 += SB * G) {
+        bool more = false;
+        for (int h = 0; h < nparts; ++h) more = step(parts[h], k0) || more;
+        if (!more) break;
+    }
+    SA_HIP_CHECK(hipGetLastError());
+    if (two) {
+        SA_HIP_CHECK(hipEventRecord(ev1, s2));
+        SA_HIP_CHECK(hipStreamWaitEvent(s, ev1, 0));
+        SA_HIP_CHECK(hipEventDestroy(ev0));
+        SA_HIP_CHECK(hipEventDestroy(ev1));
+    }
+}
+
 bool eig_ss_band_enabled() {
     static const bool v = true;
     return v;
@@ -2667,6 +3009,8 @@ static void ss_factor_generic(hipStream_t s, EigBatch &b, bool sgn, int *neg, in
     const int nmax = b.max_n;
     const bool prof = profiler().enabled;
     const int *gbw_all = bws ? bws : (sgn ? b.bw.p : nullptr);
+    if (options().eig_outer_panels >= 8) return ss_factor_blocked<8>(s, b, sgn, neg, info_p, gbw_all, bwmax, keep, skip);
+    if (options().eig_outer_panels >= 4) return ss_factor_blocked<4>(s, b, sgn, neg, info_p, gbw_all, bwmax, keep, skip);
     // Two halves of the batch on two streams (round 4): a panel is a latency chain (one workgroup per matrix: diagonal block by
     // one wavefront, then the panel rows), the trailing update is compute-bound -- one half's panels run beside the other half's
     // updates.  Every per-matrix array of the kernels is indexed by the matrix alone, so a half is the same launch with the
