@@ -357,10 +357,14 @@ def main():
     grp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks = [t0]
     for i in range(args.steps):
         h, x, its, conv, hist = one_step(capi, prob, params, group=grp)
         if i < args.steps - 1:
             h.close()
+        marks.append(time.perf_counter())      # (a step ends with the iteration count on the host: no extra synchronisation)
+    if rank == 0:
+        sys.stderr.write("bench: wall ms of the timed steps: %s\n" % " ".join("%.1f" % (1e3 * (b - a)) for a, b in zip(marks, marks[1:])))
     grp.barrier()
     torch.cuda.synchronize()
     dt = grp.max_time(time.perf_counter() - t0)

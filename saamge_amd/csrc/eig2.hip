@@ -2696,11 +2696,6 @@ __global__ __launch_bounds__(NT) void chol_panel_ll_kernel(int k0, int g, const 
         Cb[gp][i][k] = (kk + i < n) ? Pc[gp * pstride + vo + (size_t)pr * SB + k] : 0.0;
     }
     __syncthreads();
-    double ca[G - 1][4];      // A operands: Cb[gp][column l15][k = 4 l4 + s]
-#pragma unroll
-    for (int gp = 0; gp < G - 1; ++gp)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) ca[gp][s] = (gp < g) ? Cb[gp][l15][4 * l4 + s] : 0.0;
     // the 16 rows from r0 on of the panel's columns with the block's earlier sub-panels applied: element
     // (row r0 + l15, column kk + l4 + 4 reg); rows past the band / the matrix come out as exact zeros
     auto updated = [&](int r0) {
@@ -2714,10 +2709,13 @@ __global__ __launch_bounds__(NT) void chol_panel_ll_kernel(int k0, int g, const 
             if (gp < g) {      // (block-uniform)
                 const double *p = Pr + gp * pstride + vo + (size_t)(rc - (k0 + SB * (gp + 1))) * SB + 4 * l4;
                 const double2 p0 = *(const double2 *)p, p1 = *(const double2 *)(p + 2);
-                x = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[gp][0], -p0.x, x, 0, 0, 0);
-                x = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[gp][1], -p0.y, x, 0, 0, 0);
-                x = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[gp][2], -p1.x, x, 0, 0, 0);
-                x = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[gp][3], -p1.y, x, 0, 0, 0);
+                // (A operands Cb[gp][column l15][k = 4 l4 + s] read where they are used: 56 VGPRs less at G = 8, two
+                // workgroups of 512 per CU instead of one)
+                const double2 a0 = *(const double2 *)&Cb[gp][l15][4 * l4], a1 = *(const double2 *)&Cb[gp][l15][4 * l4 + 2];
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, -p0.x, x, 0, 0, 0);
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, -p0.y, x, 0, 0, 0);
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, -p1.x, x, 0, 0, 0);
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, -p1.y, x, 0, 0, 0);
             }
         }
         if (r >= rin) x = ss_v4d{0.0, 0.0, 0.0, 0.0};
@@ -2788,12 +2786,12 @@ __global__ __launch_bounds__(NT) void chol_panel_ll_kernel(int k0, int g, const 
 }
 
 // A22 -= sum over the G sub-panels of (row operands) (column operands)^T on the lower tiles of the trailing window of the
-// outer block at k0.  One workgroup per strip of 128 rows (four wavefronts, 32 rows each: their row operands stay in
+// outer block at k0.  One workgroup per strip of 32 WV rows (WV wavefronts, 32 rows each: their row operands stay in
 // registers, negated), walking the column blocks of 16 up to the strip's diagonal; the column operands of a block are
 // staged through LDS once per workgroup (double-buffered, one barrier per column block), the window tiles are requested
 // one column block ahead.  Tiles that cross the diagonal are updated whole (the factorisations read the lower triangle).
-template <int G, bool SIGNED>
-__global__ __launch_bounds__(256) void band_trail_mfma_kernel(int k0, const int *__restrict__ ns, const int64_t *__restrict__ moff,
+template <int G, bool SIGNED, int WV>
+__global__ __launch_bounds__(64 * WV) void band_trail_mfma_kernel(int k0, const int *__restrict__ ns, const int64_t *__restrict__ moff,
                                                               const int64_t *__restrict__ voff, double *__restrict__ W,
                                                               const double *__restrict__ Pc, const double *__restrict__ Pr,
                                                               size_t pstride, int count, int tiles, const int *__restrict__ bws,
@@ -2808,7 +2806,7 @@ __global__ __launch_bounds__(256) void band_trail_mfma_kernel(int k0, const int 
     if (bws) np = min(np, bws[b]);
     if (np < 1) return;
     blk = tiles - 1 - blk;                 // (the long strips first)
-    const int i0 = blk * 128;
+    const int i0 = blk * (32 * WV);
     if (i0 >= np) return;
     double *A22 = W + moff[b] + (size_t)base * n + base;
     const size_t vo = (size_t)voff[b] * SB;
@@ -2825,14 +2823,14 @@ __global__ __launch_bounds__(256) void band_trail_mfma_kernel(int k0, const int 
             br[t][g][0] = -p0.x; br[t][g][1] = -p0.y; br[t][g][2] = -p1.x; br[t][g][3] = -p1.y;
         }
     }
-    const int jend = min(np, i0 + 128);
+    const int jend = min(np, i0 + 32 * WV);
     const int nj = (jend + 15) >> 4;
-    constexpr int CH = G / 4;              // 32-byte pieces of a column block's operands per thread
+    constexpr int CH = (G + WV - 1) / WV;  // 32-byte pieces of a column block's operands per thread
     double2 sv[CH][2];
     auto stage_load = [&](int jb) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-            const int ch = tid + 256 * u, g = ch >> 6, j = (ch >> 2) & 15, q = ch & 3;
+            const int ch = min(tid + 64 * WV * u, 64 * G - 1), g = ch >> 6, j = (ch >> 2) & 15, q = ch & 3;
             const double *p = Pc + g * pstride + vo + (size_t)(min(16 * jb + j, np - 1) + SB * (G - 1 - g)) * SB + 4 * q;
             sv[u][0] = *(const double2 *)p;
             sv[u][1] = *(const double2 *)(p + 2);
@@ -2841,7 +2839,7 @@ __global__ __launch_bounds__(256) void band_trail_mfma_kernel(int k0, const int 
     auto stage_store = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-            const int ch = tid + 256 * u, g = ch >> 6, j = (ch >> 2) & 15, q = ch & 3;
+            const int ch = min(tid + 64 * WV * u, 64 * G - 1), g = ch >> 6, j = (ch >> 2) & 15, q = ch & 3;      // (duplicates store the same values)
             *(double2 *)&As[buf][g][j][4 * q] = sv[u][0];
             *(double2 *)&As[buf][g][j][4 * q + 2] = sv[u][1];
         }
@@ -2919,21 +2917,12 @@ static void ss_factor_blocked(hipStream_t s, EigBatch &b, bool sgn, int *neg, in
     const size_t pstride = (rows * SB + 15) / 16 * 16;
     double *Pc = eig_arena_subpanels(b, pstride * G * (sgn ? 2 : 1));
     double *Pr = sgn ? Pc + pstride * G : Pc;
-    // two halves of the batch on two streams, as in the two-panel walk below: one half's panels (latency chains) beside the
-    // other half's window updates
-    const bool two = !prof && !env_serial() && b.count >= 64;
-    hipStream_t s2 = two ? side_stream(5) : s;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (two) {
-        SA_HIP_CHECK(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
-        SA_HIP_CHECK(hipEventCreateWithFlags(&ev1, hipEventDisableTiming));
-        SA_HIP_CHECK(hipEventRecord(ev0, s));
-        SA_HIP_CHECK(hipStreamWaitEvent(s2, ev0, 0));
-    }
-    const int half0 = two ? (b.count / 2 + 7) / 8 * 8 : b.count;
+    // ONE stream: the two halves on two streams that help the two-panel walk below (panels = latency chains beside the
+    // other half's updates) cost these kernels a tenth (config 5: 8.44 against 7.98 s per step) -- a whole chunk's panels
+    // fill the card two workgroups deep, and two windows' worth of tiles thrash what one leaves in the caches
     struct Part { hipStream_t q; int first, cnt; };
-    const Part parts[2] = {{s, 0, half0}, {s2, half0, b.count - half0}};
-    const int nparts = (two && b.count - half0 > 0) ? 2 : 1;
+    const Part parts[1] = {{s, 0, b.count}};
+    const int nparts = 1;
     auto step = [&](const Part &P, int k0) {
         hipStream_t q = P.q;
         const int f = P.first, cnt = P.cnt;
@@ -2971,10 +2960,15 @@ static void ss_factor_blocked(hipStream_t s, EigBatch &b, bool sgn, int *neg, in
             }
             profiler().begin(q);
         }
-        const int tiles = div_up(npmax, 128);
-        if (sgn) hipLaunchKernelGGL((band_trail_mfma_kernel<G, true>), dim3(cnt8 * tiles), dim3(256), 0, q, k0, ns, moff, voff, b.W.p, Pc, Pr,
+        // (two wavefronts per workgroup: a strip's wavefronts stop at their own diagonal and wait for the last one at the
+        // barriers, and the last strip of a window is partial -- with four, a third of the wavefront-steps were idle)
+        // (four wavefronts per workgroup: with two, fewer wavefront-steps idle at a strip's diagonal but twice the staging
+        // traffic -- 8.10 instead of 7.98 s per step on config 5; with eight 8.5)
+        constexpr int WV = 4;
+        const int tiles = div_up(npmax, 32 * WV);
+        if (sgn) hipLaunchKernelGGL((band_trail_mfma_kernel<G, true, WV>), dim3(cnt8 * tiles), dim3(64 * WV), 0, q, k0, ns, moff, voff, b.W.p, Pc, Pr,
                                     pstride, cnt, tiles, gbw, sk);
-        else hipLaunchKernelGGL((band_trail_mfma_kernel<G, false>), dim3(cnt8 * tiles), dim3(256), 0, q, k0, ns, moff, voff, b.W.p, Pc, Pr,
+        else hipLaunchKernelGGL((band_trail_mfma_kernel<G, false, WV>), dim3(cnt8 * tiles), dim3(64 * WV), 0, q, k0, ns, moff, voff, b.W.p, Pc, Pr,
                                 pstride, cnt, tiles, gbw, sk);
         if (prof) profiler().end(q, sgn ? "eig_ss_inertia_update" : (npmax > 192 ? "eig_ss_update" : "eig_ss_update1"), ub, 0.0);
         return true;
@@ -2985,12 +2979,6 @@ static void ss_factor_blocked(hipStream_t s, EigBatch &b, bool sgn, int *neg, in
         if (!more) break;
     }
     SA_HIP_CHECK(hipGetLastError());
-    if (two) {
-        SA_HIP_CHECK(hipEventRecord(ev1, s2));
-        SA_HIP_CHECK(hipStreamWaitEvent(s, ev1, 0));
-        SA_HIP_CHECK(hipEventDestroy(ev0));
-        SA_HIP_CHECK(hipEventDestroy(ev1));
-    }
 }
 
 bool eig_ss_band_enabled() {
