@@ -59,8 +59,8 @@ KERNELS = {
     "eig_sbr_fused": ("sbr_fused_kernel<true, 2>", "hbm"),
     "eig_sbr_fused1": ("sbr_fused_kernel<true, 1>", "hbm"),
     "eig_ss_solve": ("ss_solve_lds_pf_kernel<128>", "hbm"),
-    "eig_ss_chol_lds": ("chol_band_lds_kernel<68, false>", "hbm"),
-    "eig_ss_inertia_lds": ("chol_band_lds_kernel<68, true>", "hbm"),
+    "eig_ss_chol_lds": ("chol_band_lds2_kernel<67, false>", "hbm"),
+    "eig_ss_inertia_lds": ("chol_band_lds2_kernel<67, true>", "hbm"),
     "coarse_inverse": ("gj_update_kernel", "mfma"),
     "eig_ss_solve_g": ("ss_trsolve_kernel<false, 1024>", "hbm"),
     "eig_ss_update": ("sbr_fused_kernel<false, 2, 3>", "hbm"),

@@ -29,7 +29,7 @@ __device__ inline double readlane_f64(double v, int src) {       // src: wave-un
 // theta sits on an eigenvalue of a leading block to within round-off growth: the caller falls
 // back to the dense path, whose Sturm count has no such restriction).
 template <bool SIGNED>
-__device__ inline int chol16_inverse_wave(double (*Ld)[SB + 1], double (*Li)[SB + 1], int lane, double *sg = nullptr) {
+__device__ __forceinline__ int chol16_inverse_wave(double (*Ld)[SB + 1], double (*Li)[SB + 1], int lane, double *sg = nullptr) {
     const int li = lane & (SB - 1);
     double a[SB];
 #pragma unroll

@@ -1475,153 +1475,13 @@ constexpr int BC_NT = 256;
 // double per row would cost the fourth workgroup of a CU by 512 bytes); bands up to 51 -- the 8 x 8 x 4-element agglomerates
 // of the Q1 problems have exactly 51 -- take the window of 67 rows, pitch 52.
 constexpr int bc_pitch(int win) { return win == 68 ? win - SB + 1 : ((win - SB + 1) + 1) / 2 * 2; }
-constexpr int bc_pitch_t(int win) { return ((win - SB + 4) + 1) / 2 * 2; }      // transposed panel: rows stay 16-byte aligned
-constexpr size_t bc_lds_bytes(int win) {      // window rows x pitch, L21^T, the two block buffers, signs
-    return sizeof(double) * ((size_t)win * bc_pitch(win) + (size_t)SB * bc_pitch_t(win) + 2 * SB * (SB + 1) + SB) + 64;
-}
 // INERTIA = true: nothing is written back.  The same window walk factors C - shift I = L S L^T
 // (S = diag(+-1), no pivoting) and info[b] receives the number of negative pivots = the number of
 // eigenvalues of C below `shift` (Sylvester), or -1 when a pivot was too small to trust the count.
 // This is what makes the few-eigenpairs path's count as rigorous as dsygvx's bisection
 // (dstebz Sturm counts, amg/src/xpacks.cpp:226-268).
-template <int BC_WIN, bool INERTIA = false>
-__global__ __launch_bounds__(BC_NT) void chol_band_lds_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
-                                                              double *__restrict__ W, const int *__restrict__ bws,
-                                                              int *__restrict__ info, double shift = 0.0,
-                                                              const int *__restrict__ active = nullptr) {
-    // the window is kept band-packed: row i holds columns i - BC_MAXBW .. i (only the lower band is ever
-    // touched), 53 instead of 69 doubles per row at BC_WIN = 68 -- four workgroups per CU instead of three
-    constexpr int BC_MAXBW = BC_WIN - SB, BC_P = bc_pitch(BC_WIN);
-    constexpr int BC_PT = bc_pitch_t(BC_WIN);      // pitch of the transposed panel (rows padded to the 4-row tiles)
-    extern __shared__ __align__(16) double bc_lds[];
-    double *S = bc_lds;                                  // [BC_WIN][BC_P]
-    double *Lp = S + BC_WIN * BC_P;                      // [SB][BC_PT]: L21^T of the current block (16-byte aligned rows)
-    double (*Ld)[SB + 1] = (double (*)[SB + 1])(Lp + SB * BC_PT);
-    double (*Li)[SB + 1] = Ld + SB;
-    int *bad = (int *)(Li + SB);
-    double *sg = (double *)(bad + 2);                    // INERTIA: signs of the current block's pivots
-    const int b = active ? active[blockIdx.x] : (int)blockIdx.x, n = ns[b], bw = bws[b];     // (active: dense list of the matrices to factor)
-    if (bw > BC_MAXBW) return;                           // (the host only launches this when every matrix fits)
-    double *A = W + moff[b];
-    // (The serial stages -- diagonal block: one wavefront; panel: <= 52 threads; update: <= 2 wavefronts -- run on the first
-    // wavefronts of the workgroup.  tools/simd_map.hip: the hardware already puts wavefront 0 of the four workgroups resident
-    // on a CU on four DIFFERENT SIMDs; rotating the roles by the block index lined them up instead: 25.4 -> 32 ms, round 4.)
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
-    auto sl = [&](int i, int j) -> double & { return S[(i % BC_WIN) * BC_P + (j - i + BC_MAXBW)]; };     // (0 <= i - j <= BC_MAXBW)
-    auto fetch_rows = [&](int i0, int i1) {              // rows [i0, i1) of the band, from the upper triangle
-        for (int i = i0 + w; i < min(i1, n); i += BC_NT / 64)
-            for (int jj = lane; jj <= bw; jj += 64) {
-                const int j = i - bw + jj;
-                if (j >= 0) sl(i, j) = A[(size_t)i * n + j] - ((INERTIA && j == i) ? shift : 0.0);
-            }
-    };
-    if (tid == 0) { bad[0] = 0; bad[1] = 0; }
-    fetch_rows(0, SB + bw);
-    __syncthreads();
-    for (int k0 = 0; k0 < n; k0 += SB) {
-        const int nb = min(SB, n - k0);
-        if (tid < SB * SB) {
-            const int i = tid >> 4, j = tid & 15;
-            Ld[i][j] = (i < nb && j <= i && i - j <= bw) ? sl(k0 + i, k0 + j) : ((i == j) ? 1.0 : 0.0);
-        }
-        __syncthreads();
-        if (tid < 64) {        // Cholesky of the block and its inverse by one wavefront
-            const int r = chol16_inverse_wave<INERTIA>(Ld, Li, tid, sg);
-            if (INERTIA) { if (tid == 0) { if (r < 0) *bad = 1; else bad[1] += r; } }
-            else if (tid == 0 && r) *bad = 1;
-        }
-        __syncthreads();
-        if (!INERTIA && tid < SB * SB) {
-            const int i = tid >> 4, j = tid & 15;
-            if (i < nb && j <= i) {
-                A[(size_t)(k0 + j) * n + (k0 + i)] = Li[i][j];
-                A[(size_t)(k0 + i) * n + (k0 + j)] = Li[i][j];
-            }
-        }
-        if (nb < SB) break;                              // (block-uniform: the last, partial block has nothing below it)
-        const int rend = min(n, k0 + SB + bw), m = rend - (k0 + SB);     // rows below the block inside the band
-        // the next SB rows of the band are requested now and land in the window after the update
-        constexpr int NPF = (SB * (BC_MAXBW + 1) + BC_NT - 1) / BC_NT;
-        double pf[NPF];
-        const int f0 = k0 + SB + bw, bw1 = bw + 1;
-#pragma unroll
-        for (int u = 0; u < NPF; ++u) {
-            const int idx = tid + u * BC_NT, ii = idx / bw1, jj = idx - ii * bw1;
-            const int i = f0 + ii, j = i - bw + jj;
-            pf[u] = (ii < SB && i < n && j >= 0) ? A[(size_t)i * n + j] - ((INERTIA && j == i) ? shift : 0.0) : 0.0;
-        }
-        if (tid >= m && tid < m + 4) {               // the 4-row tiles read up to 3 rows past the panel
-#pragma unroll
-            for (int c = 0; c < SB; ++c) Lp[c * BC_PT + tid] = 0.0;
-        }
-        if (tid < m) {
-            const int r = k0 + SB + tid;
-            double x[SB];
-#pragma unroll
-            for (int c = 0; c < SB; ++c) x[c] = (r - (k0 + c) <= bw) ? sl(r, k0 + c) : 0.0;
-#pragma unroll
-            for (int c = 0; c < SB; ++c) {
-                double t = 0.0;
-#pragma unroll
-                for (int j = 0; j <= c; ++j) t = fma(x[j], Li[c][j], t);
-                if (INERTIA) t *= sg[c];              // L21 = A21 L11^-T S
-                Lp[c * BC_PT + tid] = t;
-                if (!INERTIA) {
-                    A[(size_t)(k0 + c) * n + r] = t;
-                    A[(size_t)r * n + (k0 + c)] = t;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __syncthreads();
-        // window(i, j) -= L21(i, :) . L21(j, :) on the tiles on and below the diagonal
-        const int T = (m + 3) >> 2, ntile = T * (T + 1) / 2;
-        for (int tl = tid; tl < ntile; tl += BC_NT) {
-            int ti = (int)((sqrtf(8.0f * (float)tl + 1.0f) - 1.0f) * 0.5f);
-            while (ti * (ti + 1) / 2 > tl) --ti;
-            while ((ti + 1) * (ti + 2) / 2 <= tl) ++ti;
-            const int tj = tl - ti * (ti + 1) / 2;
-            double acc[4][4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[a][c] = 0.0;
-            const double *pi = Lp + 4 * ti, *pj = Lp + 4 * tj;
-#pragma unroll 2
-            for (int c = 0; c < SB; ++c) {        // (not fully unrolled: the scheduler would hoist all 64 operand loads, 300 VGPRs)
-                const double2 i01 = *(const double2 *)(pi + c * BC_PT), i23 = *(const double2 *)(pi + c * BC_PT + 2);
-                const double2 j01 = *(const double2 *)(pj + c * BC_PT), j23 = *(const double2 *)(pj + c * BC_PT + 2);
-                double ai[4] = {i01.x, i01.y, i23.x, i23.y};
-                const double aj[4] = {j01.x, j01.y, j23.x, j23.y};
-                if (INERTIA) {                         // window -= L21 S L21^T
-                    const double sc = sg[c];
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) ai[a] *= sc;
-                }
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[a][e] = fma(ai[a], aj[e], acc[a][e]);
-            }
-            const int gi = k0 + SB + 4 * ti, gj = k0 + SB + 4 * tj;
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (gi + a < rend && gj + e <= gi + a) sl(gi + a, gj + e) -= acc[a][e];
-        }
-#pragma unroll
-        for (int u = 0; u < NPF; ++u) {
-            const int idx = tid + u * BC_NT, ii = idx / bw1, jj = idx - ii * bw1;
-            const int i = f0 + ii, j = i - bw + jj;
-            if (ii < SB && i < n && j >= 0) sl(i, j) = pf[u];
-        }
-        __syncthreads();
-    }
-    if (INERTIA) { if (tid == 0) info[b] = *bad ? -1 : bad[1]; }
-    else if (tid == 0 && *bad) info[b] = 1;
-}
+// (The kernel of rounds 2-3 ran the four stages of a block step one after the other; the pipelined kernel that replaced
+// it -- chol_band_lds2_kernel -- follows the matrix-core helpers below.)
 
 // Is the start vector x0 = D^1/2 1 / |.| already the one wanted eigenvector?  C x0 over the band of the
 // (unshifted, unfactored) matrix, one workgroup per matrix, thread = row: pre[b] = 1 when the certified count
@@ -2652,6 +2512,207 @@ __global__ void ss_reshift_mu_kernel(int nreq, const int *__restrict__ req, cons
 }
 
 // ---------------------------------------------------------------------------------------
+// The same factorisation with the block steps PIPELINED (round 4)
+// ---------------------------------------------------------------------------------------
+// The kernel of rounds 2-3 (chol_band_lds_kernel, git history) ran four stages per block step one after the other, each behind a barrier: block fill,
+// Cholesky + inverse of the 16 x 16 block by one wavefront (3.3 us), the panel rows by <= 52 threads (136 dependent
+// multiply-adds with LDS operands each), the rank-16 update of the window by <= 91 threads -- 17 us per step with four
+// workgroups on a CU, 26 steps per 405-row agglomerate, 34 ms per setup of the 256^3 problem for the inertia pass alone.
+// Here the panel and the update run on the matrix cores (v_mfma_f64_16x16x4: a tile of 16 rows per wavefront, lane roles as
+// in chol_panel_ll_kernel), and the step is split so that only the block factorisation is left on the critical path:
+//   phase A  every wavefront: its tiles of L21 = A21 L11^-T (S) -> LDS (+ the factor, to memory)
+//   phase B  wavefront 0: the update of the NEXT diagonal block alone, then its Cholesky + inverse;
+//            wavefronts 1-3: the other tiles of the update and the 16 rows that enter the window
+// with two barriers per step.
+constexpr int BC2_LP = 18;      // pitch of a row of L21 in LDS (16-byte aligned rows, conflict-free 16-byte reads)
+constexpr size_t bc2_lds_bytes(int win) {      // window, L21 (band rows x 18), the two block buffers, two sets of signs
+    return sizeof(double) * ((size_t)win * bc_pitch(win) + (size_t)(win - SB) * BC2_LP + 2 * SB * (SB + 1) + 2 * SB) + 16;
+}
+template <int BC_WIN, bool INERTIA>
+__global__ __launch_bounds__(BC_NT) void chol_band_lds2_kernel(const int *__restrict__ ns, const int64_t *__restrict__ moff,
+                                                               double *__restrict__ W, const int *__restrict__ bws,
+                                                               int *__restrict__ info, double shift = 0.0,
+                                                               const int *__restrict__ active = nullptr) {
+    constexpr int BC_MAXBW = BC_WIN - SB, BC_P = bc_pitch(BC_WIN), LPR = BC_MAXBW;
+    extern __shared__ __align__(16) double bc_lds[];
+    double *S = bc_lds;                                  // [BC_WIN][BC_P]
+    double *Lp = S + BC_WIN * BC_P;                      // [LPR][BC2_LP]: L21 of the current block, row-major
+    double (*Ld)[SB + 1] = (double (*)[SB + 1])(Lp + LPR * BC2_LP);
+    double (*Li)[SB + 1] = Ld + SB;
+    double *sg = (double *)(Li + SB);                    // [2][SB]: signs of the pivots of the current / the next block
+    int *bad = (int *)(sg + 2 * SB);
+    const int b = active ? active[blockIdx.x] : (int)blockIdx.x, n = ns[b], bw = bws[b];
+    if (bw > BC_MAXBW) return;
+    double *A = W + moff[b];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    auto sl = [&](int i, int j) -> double & { return S[(i % BC_WIN) * BC_P + (j - i + BC_MAXBW)]; };     // (0 <= i - j <= BC_MAXBW)
+    auto fetch_rows = [&](int i0, int i1) {
+        for (int i = i0 + w; i < min(i1, n); i += BC_NT / 64)
+            for (int jj = lane; jj <= bw; jj += 64) {
+                const int j = i - bw + jj;
+                if (j >= 0) sl(i, j) = A[(size_t)i * n + j] - ((INERTIA && j == i) ? shift : 0.0);
+            }
+    };
+    // Cholesky + inverse of the block in Ld (wavefront 0), its signs to sg[which], its inverse to the matrix
+    auto factor_block = [&](int k0, int which) {
+        const int r = chol16_inverse_wave<INERTIA>(Ld, Li, lane, sg + SB * which);
+        if (INERTIA) { if (lane == 0) { if (r < 0) bad[0] = 1; else bad[1] += r; } }
+        else if (lane == 0 && r) bad[0] = 1;
+        if (!INERTIA) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int nbk = min(SB, n - k0);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = l15, j = l4 + 4 * reg;
+                if (i < nbk && j <= i) {
+                    const double v = Li[i][j];
+                    A[(size_t)(k0 + j) * n + (k0 + i)] = v;
+                    A[(size_t)(k0 + i) * n + (k0 + j)] = v;
+                }
+            }
+        }
+    };
+    if (tid == 0) { bad[0] = 0; bad[1] = 0; }
+    fetch_rows(0, SB + bw);
+    __syncthreads();
+    {
+        const int nb0 = min(SB, n);
+        if (tid < SB * SB) {
+            const int i = tid >> 4, j = tid & 15;
+            Ld[i][j] = (i < nb0 && j <= i && i - j <= bw) ? sl(i, j) : ((i == j) ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        if (w == 0) factor_block(0, 0);
+        __syncthreads();
+    }
+    int pb = 0;
+    for (int k0 = 0; k0 + SB < n; k0 += SB, pb ^= 1) {      // (a last, partial block has nothing below it)
+        const int rend = min(n, k0 + SB + bw), m = rend - (k0 + SB);     // rows below the block inside the band (>= 1)
+        const int T16 = (m + 15) >> 4;
+        const int f0 = k0 + SB + bw, bw1 = bw + 1;      // the 16 rows that enter the window in this step
+        const double *sgk = sg + SB * pb;
+        // ---- phase A: tiles w, w + 4, ... of the panel ----
+        for (int t = w; t < T16; t += BC_NT / 64) {
+            const int q = 16 * t + l15;                   // row of the panel
+            const int r = k0 + SB + q;
+            const bool live = q < m;
+            ss_v4d x;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int c = l4 + 4 * reg;
+                x[reg] = (live && r - (k0 + c) <= bw) ? sl(r, k0 + c) : 0.0;
+            }
+            ss_v4d y = ss_v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[l15][l4 + 4 * s], x[s], y, 0, 0, 0);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int c = l4 + 4 * reg;
+                const double v = INERTIA ? y[reg] * sgk[c] : y[reg];      // L21 = A21 L11^-T (S)
+                if (live) {
+                    Lp[q * BC2_LP + c] = v;
+                    if (!INERTIA) {
+                        A[(size_t)(k0 + c) * n + r] = v;
+                        A[(size_t)r * n + (k0 + c)] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase B ----
+        // window tile (ti, tj) -= (L21 S)(rows of ti) L21(rows of tj)^T: element (row 16 ti + l15, column 16 tj + l4 + 4 reg)
+        auto operand = [&](int t, bool signedrow, double (&o)[4]) {
+            const int q = 16 * t + l15;
+            const double *p = Lp + min(q, LPR - 1) * BC2_LP + 4 * l4;
+            const double2 p0 = *(const double2 *)p, p1 = *(const double2 *)(p + 2);
+            o[0] = p0.x; o[1] = p0.y; o[2] = p1.x; o[3] = p1.y;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (q >= m) o[s] = 0.0;
+                else if (INERTIA && signedrow) o[s] *= -sgk[4 * l4 + s];
+                else if (signedrow) o[s] = -o[s];
+            }
+        };
+        auto update_tile = [&](int ti, int tj, ss_v4d &c, bool load) {
+            double ob[4], oa[4];
+            operand(ti, true, ob);
+            operand(tj, false, oa);
+            const int i = k0 + SB + 16 * ti + l15;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int j = k0 + SB + 16 * tj + l4 + 4 * reg;
+                c[reg] = (load && i < rend && j <= i) ? sl(i, j) : 0.0;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(oa[s], ob[s], c, 0, 0, 0);
+        };
+        // (bands narrower than a block: some rows of the next block enter the window only in this step -- its factorisation
+        // then follows the step instead of running beside the update)
+        const bool ahead = bw >= SB;
+        if (w == 0 && !ahead) {
+            ss_v4d c;
+            update_tile(0, 0, c, true);
+            const int i = k0 + SB + l15;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int j = k0 + SB + l4 + 4 * reg;
+                if (i < rend && j <= i) sl(i, j) = c[reg];
+            }
+        } else if (w == 0) {
+            ss_v4d c;
+            update_tile(0, 0, c, true);
+            const int nb1 = min(SB, n - (k0 + SB));
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = l15, j = l4 + 4 * reg;
+                Ld[i][j] = (i < nb1 && j <= i && i - j <= bw) ? c[reg] : ((i == j) ? 1.0 : 0.0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+                factor_block(k0 + SB, pb ^ 1);
+            } else {
+            // the next SB rows of the band (wavefronts 1-3 have the time: the block factorisation is what the step waits for);
+            // they take the slots of the rows k0 .. k0 + SB - 1, whose block was consumed in the step before
+            constexpr int NPF = (SB * (BC_MAXBW + 1) + 191) / 192;
+#pragma unroll
+            for (int u = 0; u < NPF; ++u) {
+                const int idx = (tid - 64) + u * 192, ii = idx / bw1, jj = idx - ii * bw1;
+                const int i = f0 + ii, j = i - bw + jj;
+                if (ii < SB && i < n && j >= 0) sl(i, j) = A[(size_t)i * n + j] - ((INERTIA && j == i) ? shift : 0.0);
+            }
+            int cnt = 0;
+            for (int ti = 1; ti < T16; ++ti)
+                for (int tj = 0; tj <= ti; ++tj, ++cnt) {
+                    if (cnt % 3 != w - 1) continue;      // (wave-uniform)
+                    ss_v4d c;
+                    update_tile(ti, tj, c, true);
+                    const int i = k0 + SB + 16 * ti + l15;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int j = k0 + SB + 16 * tj + l4 + 4 * reg;
+                        if (i < rend && j <= i) sl(i, j) = c[reg];
+                    }
+                }
+        }
+        __syncthreads();
+        if (!ahead) {      // (workgroup-uniform)
+            const int nb1 = min(SB, n - (k0 + SB));
+            if (tid < SB * SB) {
+                const int i = tid >> 4, j = tid & 15;
+                Ld[i][j] = (i < nb1 && j <= i && i - j <= bw) ? sl(k0 + SB + i, k0 + SB + j) : ((i == j) ? 1.0 : 0.0);
+            }
+            __syncthreads();
+            if (w == 0) factor_block(k0 + SB, pb ^ 1);
+            __syncthreads();
+        }
+    }
+    if (INERTIA) { if (tid == 0) info[b] = bad[0] ? -1 : bad[1]; }
+    else if (tid == 0 && bad[0]) info[b] = 1;
+}
+
+// ---------------------------------------------------------------------------------------
 // Wide-band factorisations by OUTER BLOCKS of G 16-column sub-panels (round 4)
 // ---------------------------------------------------------------------------------------
 // The two-panel walk below passes over the trailing window (bw x bw / 2 entries per matrix, read and written) once per
@@ -3153,15 +3214,15 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
         neg.zero(s);
         if (lds_path) {
             profiler().begin(s);
-            auto go = [&](auto kern, int win) {
-                SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bc_lds_bytes(win)));
-                hipLaunchKernelGGL(kern, dim3(b.count), dim3(BC_NT), bc_lds_bytes(win), s, b.n.p, b.moff.p, b.W.p, bws, neg.p,
+            auto go2 = [&](auto kern, int win) {
+                SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bc2_lds_bytes(win)));
+                hipLaunchKernelGGL(kern, dim3(b.count), dim3(BC_NT), bc2_lds_bytes(win), s, b.n.p, b.moff.p, b.W.p, bws, neg.p,
                                    b.window_vu, (const int *)nullptr);
             };
-            if (bwmax <= 67 - SB) go(chol_band_lds_kernel<67, true>, 67);
-            else if (bwmax <= 68 - SB) go(chol_band_lds_kernel<68, true>, 68);
-            else if (bwmax <= 80 - SB) go(chol_band_lds_kernel<80, true>, 80);
-            else go(chol_band_lds_kernel<128, true>, 128);
+            if (bwmax <= 67 - SB) go2(chol_band_lds2_kernel<67, true>, 67);
+            else if (bwmax <= 68 - SB) go2(chol_band_lds2_kernel<68, true>, 68);
+            else if (bwmax <= 80 - SB) go2(chol_band_lds2_kernel<80, true>, 80);
+            else go2(chol_band_lds2_kernel<128, true>, 128);
             SA_HIP_CHECK(hipGetLastError());
             profiler().end(s, "eig_ss_inertia_lds", cb, 0.0);
             auto h = neg.to_host(s);
@@ -3326,16 +3387,16 @@ bool eig_subspace_factor(hipStream_t s, EigBatch &b) {
     hipLaunchKernelGGL(ss_shift_kernel, dim3(b.count), dim3(256), 0, s, b.n.p, b.moff.p, b.W.p, 0.0, b.ss_sigma.p);
     if (lds_path) {
         profiler().begin(s);
-        auto go = [&](auto kern, int win) {
+        auto go2 = [&](auto kern, int win) {
             if (!nchol) return;
-            SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bc_lds_bytes(win)));
-            hipLaunchKernelGGL(kern, dim3(nchol), dim3(BC_NT), bc_lds_bytes(win), s, b.n.p, b.moff.p, b.W.p, bws, info.p, 0.0,
+            SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bc2_lds_bytes(win)));
+            hipLaunchKernelGGL(kern, dim3(nchol), dim3(BC_NT), bc2_lds_bytes(win), s, b.n.p, b.moff.p, b.W.p, bws, info.p, 0.0,
                                use_chol_list ? chol_active.p : (const int *)nullptr);
         };
-        if (bwmax <= 67 - SB) go(chol_band_lds_kernel<67, false>, 67);
-        else if (bwmax <= 68 - SB) go(chol_band_lds_kernel<68, false>, 68);
-        else if (bwmax <= 80 - SB) go(chol_band_lds_kernel<80, false>, 80);
-        else go(chol_band_lds_kernel<128, false>, 128);
+        if (bwmax <= 67 - SB) go2(chol_band_lds2_kernel<67, false>, 67);
+        else if (bwmax <= 68 - SB) go2(chol_band_lds2_kernel<68, false>, 68);
+        else if (bwmax <= 80 - SB) go2(chol_band_lds2_kernel<80, false>, 80);
+        else go2(chol_band_lds2_kernel<128, false>, 128);
         SA_HIP_CHECK(hipGetLastError());
         profiler().end(s, "eig_ss_chol_lds", 3.0 * cb, 0.0);
     } else {

@@ -41,7 +41,7 @@ if has sq; then
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
            "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i+1))
-    timeout -k 10 150 rocprofv3 --pmc $C --kernel-include-regex "chol_band_lds|ae_rows8|ae_build|rap_numeric|rap_symbolic|ss_trsolve|gj_panel|gj_apply|coarse_elmat|chol_panel|sbr_fused|mis_svd|ss_solve_lds|ss_rr" \
+    timeout -k 10 150 rocprofv3 --pmc $C --kernel-include-regex "chol_band_lds2|ae_rows8|ae_build|rap_numeric|rap_symbolic|ss_trsolve|gj_panel|gj_apply|coarse_elmat|chol_panel|band_trail_mfma|sbr_fused|mis_svd|ss_solve_lds|ss_rr" \
         --kernel-trace --output-format csv -d $O/sq/p$i -o p -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-general --no-others --warmup 0 --steps 1 > $O/sq_p$i.log 2>&1
     echo "sq pass $i rc=$?"
   done
