@@ -45,6 +45,8 @@ typedef struct saamge_amd_options {
     int eig_nullcheck;            /* 1: agglomerates whose one wanted pair is the known null vector skip the iteration */
     int eig_keep_inertia_factor;  /* 1: wide-band matrices with certified count 0 keep the factor of the inertia pass */
     int band_assembly;            /* 1: coarse-level agglomerate matrices are assembled, summed and scaled inside their band */
+    int eig_dedupe;               /* 1: bitwise identical agglomerate matrices of a batch (structured meshes, piecewise constant
+                                   * coefficients) are solved once, their eigenpairs copied to the other members of the class */
     int eig_outer_panels;         /* 8: 16-column panels per outer block of the wide-band factorisations (left-looking panels,
                                    * one rank-128 update of the trailing window on the matrix cores); 4: rank-64; 2: the
                                    * right-looking two-panel walk of rounds 2-3 */

@@ -44,8 +44,14 @@ struct RowsSpan {
     int64_t first = 0, total = 0;
 };
 void ae_rows_new_build();
+// classes (optional, in/out): where the assembly can tell identical agglomerates apart before it builds their matrices
+// (the fused fine-level path), it builds the first member of every class only and reports the classes here (reps empty:
+// every matrix of the batch was built).
+struct AeClasses {
+    std::vector<int> reps, rep_of;
+};
 void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevElmats &el, int ae0,
-              EigBatch &batch, bool scale, double *Dout, const RowsSpan *rows = nullptr);
+              EigBatch &batch, bool scale, double *Dout, const RowsSpan *rows = nullptr, AeClasses *classes = nullptr);
 
 // Fine level, 8-dof elements: the sparse rows of the AE matrices of a chunk (RW slots per row at
 // rv / rc[(batch.voff[b] + row) * RW + slot], column -1 = empty).  false: not applicable.

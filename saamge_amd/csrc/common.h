@@ -97,6 +97,7 @@ struct Options {
     int eig_nullcheck = 1;            // known-null-vector shortcut (ss_nullcheck_kernel)
     int eig_keep_inertia_factor = 1;  // wide-band matrices with certified count 0 keep the factor of the inertia pass
     int band_assembly = 1;            // coarse-level agglomerate matrices assembled inside their band
+    int eig_dedupe = 1;               // bitwise identical agglomerate matrices of a batch are solved once
     int eig_outer_panels = 8;         // 16-column panels per outer block of the wide-band factorisations (2: the right-looking two-panel walk)
     int overlap = 15;                 // bit 0 subspace iteration beside the next chunk, 1 halo exchange beside the interior rows, 2 Galerkin product beside the next level, 3 fine operator data beside the AE tables
     int sell = 31;                    // bit 0 coded slices at all, 1 pair coding, 2 short-chain kernel path, 3 operator-level dictionary, 4 node blocks

@@ -122,6 +122,15 @@ void eig_subspace_vectors(hipStream_t s, EigBatch &b, const int64_t *eoff, const
 void eig_arena_release();   // frees the persistent workspace
 double *eig_arena_bandsave(const EigBatch &b, size_t doubles);   // persistent scratch of the inertia pass
 double *eig_arena_subpanels(const EigBatch &b, size_t doubles); // packed sub-panels of the outer blocks of the wide-band factorisations
+// duplicate matrices of a batch (eig.hip): reps = the first matrix of every class of bitwise identical matrices, rep_of[i] =
+// the position in reps of matrix i's class; false: not worth it (few duplicates) or not applicable.  eig_batch_compact
+// makes the batch of the representatives in the same workspace; eig_dedupe_expand copies their results to every member.
+bool eig_batch_find_duplicates(hipStream_t s, const EigBatch &b, std::vector<int> &reps, std::vector<int> &rep_of);
+int eig_dedupe_group(const unsigned long long *hh, int count, std::vector<int> &rep);
+void eig_dedupe_classes(const std::vector<int> &rep, std::vector<int> &reps, std::vector<int> &rep_of);
+void eig_batch_compact(hipStream_t s, EigBatch &cb, EigBatch &full, const std::vector<int> &reps);
+void eig_dedupe_expand(hipStream_t s, int count, int max_n, const int *rep, const int64_t *ceoff, const int64_t *cxoff, const double *cevals,
+                       const double *cevecs, const int64_t *eoff, const int64_t *xoff, double *evals, double *evecs);
 // bytes of device workspace one matrix of size n needs (for chunk sizing)
 size_t eig_workspace_bytes(int n);
 // Phase 2: count eigenvalues in (vl, vu] (Sturm); fills b.m / b.j0 and the host copy b.h_m

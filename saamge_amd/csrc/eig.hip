@@ -14,6 +14,8 @@
 // fallback to the single smallest pair), amg/src/spectral.cpp:124-237.
 #include "eig.h"
 
+#include <unordered_map>
+
 #include <cfloat>
 #include <cstdlib>
 #include <string>
@@ -857,9 +859,218 @@ static size_t vec_lds_bytes(int n) {
 }
 constexpr size_t LDS_MAX = 160 * 1024;
 
+// ---------------------------------------------------------------------------------------
+// Duplicate agglomerate matrices (round 4)
+// ---------------------------------------------------------------------------------------
+// On a structured mesh with piecewise constant coefficients most agglomerates are translates of one another: their
+// scaled matrices C, scalings D and row orders are IDENTICAL bit for bit (the 256^3 Poisson problem: 65 536 agglomerates
+// on the fine level, a few hundred distinct ones; the same on the coarse levels, whose element matrices are built from
+// identical eigenvectors by order-preserving sums).  The eigenpairs of a matrix are a function of those bits alone -- no
+// kernel of the few-eigenpairs or the dense path looks at a matrix's position in its batch, the start vectors are seeded
+// by (row, n) -- so one member of every class is solved and the others receive copies: the hierarchy is the one the
+// per-agglomerate computation builds.  Classes are found by a 128-bit hash of everything the eigensolvers read (n, the
+// half bandwidth, the band of C in both triangles, D^-1/2, the row order, the coarse start vector) and CONFIRMED by a
+// word-by-word comparison with the class representative; a batch with fewer than a quarter of duplicates is left alone
+// (variable coefficients, unstructured meshes: the cost is the hash, one pass over the bands).
+// saamge_amd_options.eig_dedupe = 0 switches it off.
+__device__ inline unsigned long long dd_mix(unsigned long long x) {      // splitmix64 finaliser
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+struct DdView {      // what a matrix of the batch consists of, as far as the eigensolvers are concerned
+    const int *ns;
+    const int64_t *moff, *voff;
+    const double *W;
+    const int *bws;
+    const double *dis;
+    const short *perm;      // or null
+    const double *x0c;      // or null
+};
+__global__ __launch_bounds__(256) void batch_hash_kernel(DdView v, unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long red[2][4];
+    const int b = blockIdx.x, n = v.ns[b], bw = min(v.bws[b], n - 1), w2 = 2 * bw + 1, tid = threadIdx.x;
+    const double *A = v.W + v.moff[b];
+    const int64_t vo = v.voff[b];
+    unsigned long long h1 = 0, h2 = 0;
+    auto take = [&](unsigned long long bits, unsigned long long pos, unsigned long long salt) {
+        const unsigned long long k = dd_mix(bits + 0x9E3779B97F4A7C15ull * (pos + 1) + salt);
+        h1 += k;      // (sums: independent of the order the threads visit the words in)
+        h2 += dd_mix(k ^ 0xD6E8FEB86659FD93ull);
+    };
+    for (long idx = tid; idx < (long)n * w2; idx += 256) {
+        const int j = (int)(idx / w2), i = j - bw + (int)(idx - (long)j * w2);
+        if (i >= 0 && i < n) take((unsigned long long)__double_as_longlong(A[(size_t)j * n + i]), (unsigned long long)idx, 0);
+    }
+    for (int r = tid; r < n; r += 256) {
+        take((unsigned long long)__double_as_longlong(v.dis[vo + r]), (unsigned long long)r, 0x1111111111111111ull);
+        if (v.perm) take((unsigned long long)(unsigned short)v.perm[vo + r], (unsigned long long)r, 0x2222222222222222ull);
+        if (v.x0c) take((unsigned long long)__double_as_longlong(v.x0c[vo + r]), (unsigned long long)r, 0x3333333333333333ull);
+    }
+    if (tid == 0) take((unsigned long long)n, 0, 0x4444444444444444ull), take((unsigned long long)bw, 1, 0x4444444444444444ull);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = h1; red[1][tid >> 6] = h2; }
+    __syncthreads();
+    if (tid == 0) {
+        out[2 * (size_t)b] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        out[2 * (size_t)b + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+// every matrix against the first of its class (rep[b] = that matrix): differ[b] = 1 unless every word is the same
+__global__ __launch_bounds__(256) void batch_verify_kernel(DdView v, const int *__restrict__ rep, int *__restrict__ differ) {
+    const int b = blockIdx.x, r0 = rep[b], tid = threadIdx.x;
+    if (r0 == b) return;
+    const int n = v.ns[b], bw = min(v.bws[b], n - 1), w2 = 2 * bw + 1;
+    if (n != v.ns[r0] || bw != min(v.bws[r0], n - 1)) { if (tid == 0) differ[b] = 1; return; }
+    const long long *A = (const long long *)(v.W + v.moff[b]), *B = (const long long *)(v.W + v.moff[r0]);
+    const int64_t va = v.voff[b], vb = v.voff[r0];
+    int bad = 0;
+    for (long idx = tid; idx < (long)n * w2; idx += 256) {
+        const int j = (int)(idx / w2), i = j - bw + (int)(idx - (long)j * w2);
+        if (i >= 0 && i < n) bad |= A[(size_t)j * n + i] != B[(size_t)j * n + i];
+    }
+    for (int r = tid; r < n; r += 256) {
+        bad |= __double_as_longlong(v.dis[va + r]) != __double_as_longlong(v.dis[vb + r]);
+        if (v.perm) bad |= v.perm[va + r] != v.perm[vb + r];
+        if (v.x0c) bad |= __double_as_longlong(v.x0c[va + r]) != __double_as_longlong(v.x0c[vb + r]);
+    }
+    if (bad) differ[b] = 1;
+}
+__global__ void gather_int_kernel(int n, const int *__restrict__ idx, const int *__restrict__ src, int *__restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+// results of the class representatives to every member: block i copies eigenvalues and eigenvectors of matrix rep[i]
+__global__ __launch_bounds__(256) void dedupe_expand_kernel(const int *__restrict__ rep, const int64_t *__restrict__ ceoff,
+                                                            const int64_t *__restrict__ cxoff, const double *__restrict__ cevals,
+                                                            const double *__restrict__ cevecs, const int64_t *__restrict__ eoff,
+                                                            const int64_t *__restrict__ xoff, double *__restrict__ evals,
+                                                            double *__restrict__ evecs) {
+    const int i = blockIdx.x, r = rep[i];
+    const int64_t ne = ceoff[r + 1] - ceoff[r], nx = cxoff[r + 1] - cxoff[r];
+    for (int64_t t = threadIdx.x; t < ne; t += 256) evals[eoff[i] + t] = cevals[ceoff[r] + t];
+    for (int64_t t = blockIdx.y * 256 + threadIdx.x; t < nx; t += 256 * (int64_t)gridDim.y) evecs[xoff[i] + t] = cevecs[cxoff[r] + t];
+}
+void eig_dedupe_expand(hipStream_t s, int count, int max_n, const int *rep, const int64_t *ceoff, const int64_t *cxoff, const double *cevals,
+                       const double *cevecs, const int64_t *eoff, const int64_t *xoff, double *evals, double *evecs) {
+    if (!count) return;
+    const int ny = std::max(1, std::min(64, std::min(max_n / 128, 65536 / std::max(1, count))));
+    hipLaunchKernelGGL(dedupe_expand_kernel, dim3(count, ny), dim3(256), 0, s, rep, ceoff, cxoff, cevals, cevecs, eoff, xoff, evals, evecs);
+    SA_HIP_CHECK(hipGetLastError());
+}
+
+// rep[i] = the first matrix with matrix i's 128-bit hash (hashes: two words per matrix); returns the number of classes
+int eig_dedupe_group(const unsigned long long *hh, int count, std::vector<int> &rep) {
+    struct Key { unsigned long long a, b; bool operator==(const Key &o) const { return a == o.a && b == o.b; } };
+    struct KeyHash { size_t operator()(const Key &k) const { return (size_t)(k.a ^ (k.b * 0x9E3779B97F4A7C15ull)); } };
+    std::unordered_map<Key, int, KeyHash> first;
+    first.reserve((size_t)count / 8 + 16);
+    rep.resize((size_t)count);
+    int nuniq = 0;
+    for (int i = 0; i < count; ++i) {
+        auto it = first.emplace(Key{hh[2 * (size_t)i], hh[2 * (size_t)i + 1]}, i);
+        rep[i] = it.first->second;
+        nuniq += it.second ? 1 : 0;
+    }
+    return nuniq;
+}
+// rep (first member per matrix) -> the list of first members and, per matrix, the position of its class in that list
+void eig_dedupe_classes(const std::vector<int> &rep, std::vector<int> &reps, std::vector<int> &rep_of) {
+    const int count = (int)rep.size();
+    reps.clear();
+    std::vector<int> pos((size_t)count, -1);
+    for (int i = 0; i < count; ++i)
+        if (rep[i] == i) { pos[i] = (int)reps.size(); reps.push_back(i); }
+    rep_of.resize((size_t)count);
+    for (int i = 0; i < count; ++i) rep_of[i] = pos[rep[i]];
+}
+
+bool eig_batch_find_duplicates(hipStream_t s, const EigBatch &b, std::vector<int> &reps, std::vector<int> &rep_of) {
+    reps.clear();
+    rep_of.clear();
+    if (!b.has_bw || b.count < 32 || b.bw.n < (size_t)b.count) return false;
+    profiler().begin(s);
+    DdView v{b.n.p, b.moff.p, b.voff.p, b.W.p, b.bw.p, b.dis.p, b.has_perm ? b.perm.p : nullptr, b.has_x0c ? b.x0c.p : nullptr};
+    DBuf<unsigned long long> hash(2 * (size_t)b.count);
+    hipLaunchKernelGGL(batch_hash_kernel, dim3(b.count), dim3(256), 0, s, v, hash.p);
+    SA_HIP_CHECK(hipGetLastError());
+    auto hh = hash.to_host(s);
+    std::vector<int> rep;
+    const int nuniq = eig_dedupe_group(hh.data(), b.count, rep);
+    if ((long)nuniq * 4 > (long)b.count * 3) { profiler().end(s, "eig_dedupe", 0.0, 0.0); return false; }
+    DBuf<int> d_rep, differ((size_t)b.count);
+    d_rep.from_host(rep, s);
+    differ.zero(s);
+    hipLaunchKernelGGL(batch_verify_kernel, dim3(b.count), dim3(256), 0, s, v, d_rep.p, differ.p);
+    SA_HIP_CHECK(hipGetLastError());
+    auto hd = differ.to_host(s);
+    for (int i = 0; i < b.count; ++i)
+        if (hd[i]) rep[i] = i;      // (a collision of the hash: the matrix stands for itself)
+    eig_dedupe_classes(rep, reps, rep_of);
+    double bytes = 0.0;
+    for (int i = 0; i < b.count; ++i) bytes += 16.0 * (double)b.h_n[i] * (2.0 * std::min(b.h_n[i] - 1, 64) + 1.0);
+    profiler().end(s, "eig_dedupe", bytes, 0.0);
+    if ((options().debug & 1)) std::fprintf(stderr, "duplicate agglomerates: %d distinct of %d\n", (int)reps.size(), b.count);
+    return true;
+}
+
+// the batch of the class representatives: the same workspace, per-matrix tables of its own
+void eig_batch_compact(hipStream_t s, EigBatch &cb, EigBatch &full, const std::vector<int> &reps) {
+    cb = EigBatch();
+    cb.slot = g_slot = full.slot;
+    cb.count = (int)reps.size();
+    cb.h_n.resize(reps.size());
+    cb.h_moff.assign(reps.size() + 1, 0);
+    cb.h_voff.assign(reps.size() + 1, 0);
+    cb.max_n = 0;
+    for (size_t i = 0; i < reps.size(); ++i) {
+        cb.h_n[i] = full.h_n[reps[i]];
+        cb.h_moff[i] = full.h_moff[reps[i]];
+        cb.h_voff[i] = full.h_voff[reps[i]];
+        cb.max_n = std::max(cb.max_n, cb.h_n[i]);
+    }
+    cb.h_moff[reps.size()] = full.h_moff[full.count];      // (the totals size the shared buffers)
+    cb.h_voff[reps.size()] = full.h_voff[full.count];
+    cb.n.from_host(cb.h_n, s);
+    cb.moff.from_host(cb.h_moff, s);
+    cb.voff.from_host(cb.h_voff, s);
+    cb.W.view(full.W.p, full.W.n);
+    cb.d.view(full.d.p, full.d.n);
+    cb.e.view(full.e.p, full.e.n);
+    cb.tau.view(full.tau.p, full.tau.n);
+    cb.dis.view(full.dis.p, full.dis.n);
+    if (full.panel.n) cb.panel.view(full.panel.p, full.panel.n);
+    cb.m.alloc((size_t)cb.count);
+    cb.j0.alloc((size_t)cb.count);
+    cb.has_perm = full.has_perm;
+    if (full.perm.n) cb.perm.view(full.perm.p, full.perm.n);
+    if (full.iperm.n) cb.iperm.view(full.iperm.p, full.iperm.n);
+    cb.has_bw = full.has_bw;
+    if (full.has_bw) {
+        DBuf<int> idx;
+        idx.from_host(reps, s);
+        cb.bw.alloc((size_t)cb.count);
+        hipLaunchKernelGGL(gather_int_kernel, dim3(div_up(cb.count, 256)), dim3(256), 0, s, cb.count, idx.p, full.bw.p, cb.bw.p);
+        SA_HIP_CHECK(hipGetLastError());
+        SA_HIP_CHECK(hipStreamSynchronize(s));      // (idx is freed on return)
+    }
+    cb.has_x0c = full.has_x0c;
+    if (full.has_x0c) cb.x0c.view(full.x0c.p, full.x0c.n);
+    cb.has_window = full.has_window;
+    cb.window_vu = full.window_vu;
+    cb.vl = full.vl;
+    cb.vu = full.vu;
+    cb.ss_tol = full.ss_tol;
+    cb.dense_only = full.dense_only;
+}
+
 size_t eig_workspace_bytes(int n) {
     const size_t nn = (size_t)n;
-    return 8 * (nn * nn + nn * (EIG_NB + 8) + nn * nn / 2 + nn * (3 * EIG_SB + 2 * EIG_SB + 16 * EIG_SB) + 64);
+    // (the packed sub-panels of the blocked wide-band factorisation: only matrices that can have a band beyond the LDS window)
+    const size_t sub = nn > 512 ? 16 * EIG_SB : 0;
+    return 8 * (nn * nn + nn * (EIG_NB + 8) + nn * nn / 2 + nn * (3 * EIG_SB + 2 * EIG_SB + sub) + 64);
 }
 
 // The few-eigenpairs path (eig2.hip) is the default for batches whose largest agglomerate has at

@@ -333,7 +333,11 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     hipStream_t qa = s, qb = s;
     SA_HIP_CHECK(hipStreamSynchronize(s));
     const size_t chunk_bytes = P.workspace_bytes;
-    EigBatch batches[2];
+    // (batches: what the eigensolvers run on -- the assembled batch itself, or the batch of the representatives of its
+    // classes of bitwise identical matrices, eig.hip "Duplicate agglomerate matrices"; rep_of: empty = no classes)
+    EigBatch batches[2], assembled[2];
+    std::vector<int> rep_of[2];
+    const bool dedupe = options().eig_dedupe != 0 && !(P.testmesh && lev == 0);
     int pend_ae0[2] = {0, 0}, pend_cnt[2] = {0, 0};
     int64_t pend_row0[2] = {0, 0};
     // The subspace iteration of a chunk (a few hundred to a few thousand small matrices still active: launches that
@@ -373,6 +377,11 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
             eig_tridiagonalize(qb, batch, 2);
             eig_count(qb, batch, -1.0, L.theta);
         }
+        if (batch.ss_failed && !rep_of[slot].empty()) {      // ... on ALL matrices of the chunk (the assembled batch is still there)
+            batch = std::move(assembled[slot]);
+            rep_of[slot].clear();
+            batch.ss_failed = true;
+        }
         if (batch.ss_failed) {   // few-eigenpairs path gave up on this chunk: dense path on re-assembled matrices
             batch.dense_only = true;
             batch.subspace = batch.ss_failed = false;
@@ -388,27 +397,55 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         c.count = cnt;
         c.eoff.assign((size_t)cnt + 1, 0);
         c.xoff.assign((size_t)cnt + 1, 0);
+        // per agglomerate of the chunk: eigenvector count and "redo by the dense path" -- its own, or its class's
+        const std::vector<int> &ro = rep_of[slot];
+        std::vector<int> hm((size_t)cnt);
+        std::vector<char> hbad((size_t)cnt, 0);
+        const bool some_bad = batch.subspace && batch.nbad > 0;
         for (int i = 0; i < cnt; ++i) {
-            L.ae_m[ae0 + i] = batch.h_m[i];
-            c.eoff[i + 1] = c.eoff[i] + batch.h_m[i];
-            c.xoff[i + 1] = c.xoff[i] + (int64_t)batch.h_m[i] * sizes[ae0 + i];
+            const int r = ro.empty() ? i : ro[i];
+            hm[i] = batch.h_m[r];
+            if (some_bad) hbad[i] = batch.h_bad[r];
+        }
+        for (int i = 0; i < cnt; ++i) {
+            L.ae_m[ae0 + i] = hm[i];
+            c.eoff[i + 1] = c.eoff[i] + hm[i];
+            c.xoff[i + 1] = c.xoff[i] + (int64_t)hm[i] * sizes[ae0 + i];
         }
         c.evals.alloc((size_t)c.eoff[cnt]);
         c.evecs.alloc((size_t)c.xoff[cnt]);
         c.d_eoff.from_host(c.eoff, qb);
         c.d_xoff.from_host(c.xoff, qb);
-        eig_vectors(qb, batch, c.d_eoff.p, c.d_xoff.p, c.evals.p, c.evecs.p);
+        if (ro.empty()) {
+            eig_vectors(qb, batch, c.d_eoff.p, c.d_xoff.p, c.evals.p, c.evecs.p);
+        } else {      // the representatives' eigenpairs, packed, then a copy to every member of their classes
+            const int nr = batch.count;
+            std::vector<int64_t> re((size_t)nr + 1, 0), rx((size_t)nr + 1, 0);
+            for (int r = 0; r < nr; ++r) {
+                re[r + 1] = re[r] + batch.h_m[r];
+                rx[r + 1] = rx[r] + (int64_t)batch.h_m[r] * batch.h_n[r];
+            }
+            DBuf<double> revals((size_t)re[nr] + 1), revecs((size_t)rx[nr] + 1);
+            DBuf<int64_t> d_re, d_rx;
+            DBuf<int> d_ro;
+            d_re.from_host(re, qb);
+            d_rx.from_host(rx, qb);
+            d_ro.from_host(ro, qb);
+            eig_vectors(qb, batch, d_re.p, d_rx.p, revals.p, revecs.p);
+            eig_dedupe_expand(qb, cnt, batch.max_n, d_ro.p, d_re.p, d_rx.p, revals.p, revecs.p, c.d_eoff.p, c.d_xoff.p, c.evals.p, c.evecs.p);
+            SA_HIP_CHECK(hipStreamSynchronize(qb));      // (the packed results are freed here)
+        }
         SA_HIP_CHECK(hipStreamSynchronize(qb));
-        if (!(batch.subspace && batch.nbad > 0)) return;
+        if (!some_bad) return;
         // ---- the few-eigenpairs path finished all but a few matrices of the chunk (h_bad): those are redone by
         // the dense path, as contiguous runs of agglomerates (runs closer than three apart are joined), in the
         // workspace the chunk has just left; then the chunk's packed results are put together ----
-        std::vector<char> bad(batch.h_bad.begin(), batch.h_bad.end());
+        std::vector<char> bad(hbad.begin(), hbad.end());
         for (int i = 0; i < cnt; ++i)
             if (bad[i])
                 for (int j = i + 1; j < std::min(cnt, i + 4); ++j)
                     if (bad[j]) { for (int q = i + 1; q < j; ++q) bad[q] = 1; break; }
-        std::vector<int> m_all(batch.h_m.begin(), batch.h_m.end());
+        std::vector<int> m_all(hm.begin(), hm.end());
         struct Redo { int a, b; DBuf<double> evals, evecs; std::vector<int64_t> eoff, xoff; };
         std::vector<Redo> redo;
         for (int a = 0; a < cnt;) {
@@ -507,8 +544,21 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
             batch.has_x0c = true;
         }
         const RowsSpan span{(int64_t)L.rel.AE_to_dof.I[ae0] - (int64_t)L.rel.AE_to_dof.I[ae_lo], (int64_t)L.rel.AE_to_dof.I[ae_hi] - (int64_t)L.rel.AE_to_dof.I[ae_lo]};      // (positions among the rows of this rank's agglomerates)
+        AeClasses classes;
         ae_build(qa, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch, true,
-                 P.keep_debug ? L.ae_D.p + row0 : nullptr, keep_rows ? &span : nullptr);
+                 P.keep_debug ? L.ae_D.p + row0 : nullptr, keep_rows ? &span : nullptr,
+                 dedupe && !batch.dense_only ? &classes : nullptr);
+        const int64_t rows_chunk = batch.h_voff[cnt];
+        rep_of[slot].clear();
+        if (dedupe && !batch.dense_only) {
+            // (classes known before the matrices were built -- the fused fine-level assembly --, or found on the matrices)
+            if (!classes.reps.empty()) rep_of[slot] = classes.rep_of;
+            else if (!eig_batch_find_duplicates(qa, batch, classes.reps, rep_of[slot])) rep_of[slot].clear();
+            if (!rep_of[slot].empty()) {
+                assembled[slot] = std::move(batch);
+                eig_batch_compact(qa, batch, assembled[slot], classes.reps);
+            }
+        }
         eig_tridiagonalize(qa, batch, 1);
         pend_ae0[slot] = ae0;
         pend_cnt[slot] = cnt;
@@ -516,7 +566,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         if (prev >= 0) { join_iterate(); post(prev); }
         start_iterate(slot);
         prev = slot;
-        row0 += batch.h_voff[cnt];
+        row0 += rows_chunk;
         ae0 += cnt;
     }
     if (prev >= 0) { join_iterate(); post(prev); }
