@@ -45,10 +45,12 @@ struct RowsSpan {
 };
 void ae_rows_new_build();
 // classes (optional, in/out): where the assembly can tell identical agglomerates apart before it builds their matrices
-// (the fused fine-level path), it builds the first member of every class only and reports the classes here (reps empty:
+// (the fused fine-level path), it builds the first member of every class only and reports the classes here (early = false:
 // every matrix of the batch was built).
 struct AeClasses {
-    std::vector<int> reps, rep_of;
+    bool early = false;     // the classes below were found on the sparse rows and only cls.reps were built
+    DdSource src;           // ... where those rows are (valid until the next ae_build)
+    DdClasses cls;
 };
 void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevElmats &el, int ae0,
               EigBatch &batch, bool scale, double *Dout, const RowsSpan *rows = nullptr, AeClasses *classes = nullptr);

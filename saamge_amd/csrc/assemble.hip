@@ -951,85 +951,7 @@ __global__ __launch_bounds__(256) void ae_perm_kernel(int ae0, const int *__rest
 // Classes of identical agglomerates BEFORE their matrices are built (eig.hip, "Duplicate agglomerate matrices"): the fused
 // kernel below makes the scaled matrix, its scaling and its band from the agglomerate's sparse rows (RW slots of column +
 // value per row) and its row order alone, so agglomerates whose rows and order agree bit for bit get identical matrices --
-// only one member of a class is built (and factored, and iterated).  Same scheme as there: 128-bit hash, then a word-by-
-// word comparison with the first member of the class.
-__device__ inline unsigned long long rd_mix(unsigned long long x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-__global__ __launch_bounds__(256) void rows_hash_kernel(int RW, const int *__restrict__ ns, const int64_t *__restrict__ voff,
-                                                        const double *__restrict__ rvals, const short *__restrict__ rcols,
-                                                        const short *__restrict__ perm, unsigned long long *__restrict__ out) {
-    __shared__ unsigned long long red[2][4];
-    const int b = blockIdx.x, n = ns[b], tid = threadIdx.x;
-    const size_t base = (size_t)voff[b] * RW;
-    unsigned long long h1 = 0, h2 = 0;
-    auto take = [&](unsigned long long bits, unsigned long long pos, unsigned long long salt) {
-        const unsigned long long k = rd_mix(bits + 0x9E3779B97F4A7C15ull * (pos + 1) + salt);
-        h1 += k;
-        h2 += rd_mix(k ^ 0xD6E8FEB86659FD93ull);
-    };
-    for (int it = tid; it < n * RW; it += 256) {
-        take((unsigned long long)__double_as_longlong(rvals[base + it]), (unsigned long long)it, 0);
-        take((unsigned long long)(unsigned short)rcols[base + it], (unsigned long long)it, 0x5555555555555555ull);
-    }
-    if (perm)
-        for (int r = tid; r < n; r += 256) take((unsigned long long)(unsigned short)perm[voff[b] + r], (unsigned long long)r, 0x2222222222222222ull);
-    if (tid == 0) take((unsigned long long)n, 0, 0x4444444444444444ull);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64); }
-    if ((tid & 63) == 0) { red[0][tid >> 6] = h1; red[1][tid >> 6] = h2; }
-    __syncthreads();
-    if (tid == 0) {
-        out[2 * (size_t)b] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        out[2 * (size_t)b + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    }
-}
-__global__ __launch_bounds__(256) void rows_verify_kernel(int RW, const int *__restrict__ ns, const int64_t *__restrict__ voff,
-                                                          const double *__restrict__ rvals, const short *__restrict__ rcols,
-                                                          const short *__restrict__ perm, const int *__restrict__ rep,
-                                                          int *__restrict__ differ) {
-    const int b = blockIdx.x, r0 = rep[b], tid = threadIdx.x;
-    if (r0 == b) return;
-    const int n = ns[b];
-    if (n != ns[r0]) { if (tid == 0) differ[b] = 1; return; }
-    const size_t ba = (size_t)voff[b] * RW, bb = (size_t)voff[r0] * RW;
-    const long long *va = (const long long *)rvals;
-    int bad = 0;
-    for (int it = tid; it < n * RW; it += 256) bad |= (va[ba + it] != va[bb + it]) | (rcols[ba + it] != rcols[bb + it]);
-    if (perm)
-        for (int r = tid; r < n; r += 256) bad |= perm[voff[b] + r] != perm[voff[r0] + r];
-    if (bad) differ[b] = 1;
-}
-static bool rows_find_duplicates(hipStream_t s, const EigBatch &batch, int RW, const double *rv, const short *rc, const short *pm,
-                                 AeClasses &cls) {
-    cls.reps.clear();
-    cls.rep_of.clear();
-    if (batch.count < 32) return false;
-    profiler().begin(s);
-    DBuf<unsigned long long> hash(2 * (size_t)batch.count);
-    hipLaunchKernelGGL(rows_hash_kernel, dim3(batch.count), dim3(256), 0, s, RW, batch.n.p, batch.voff.p, rv, rc, pm, hash.p);
-    SA_HIP_CHECK(hipGetLastError());
-    auto hh = hash.to_host(s);
-    std::vector<int> rep;
-    const int nuniq = eig_dedupe_group(hh.data(), batch.count, rep);
-    if ((long)nuniq * 4 > (long)batch.count * 3) { profiler().end(s, "eig_dedupe", 0.0, 0.0); return false; }
-    DBuf<int> d_rep, differ((size_t)batch.count);
-    d_rep.from_host(rep, s);
-    differ.zero(s);
-    hipLaunchKernelGGL(rows_verify_kernel, dim3(batch.count), dim3(256), 0, s, RW, batch.n.p, batch.voff.p, rv, rc, pm, d_rep.p, differ.p);
-    SA_HIP_CHECK(hipGetLastError());
-    auto hd = differ.to_host(s);
-    for (int i = 0; i < batch.count; ++i)
-        if (hd[i]) rep[i] = i;
-    eig_dedupe_classes(rep, cls.reps, cls.rep_of);
-    profiler().end(s, "eig_dedupe", 20.0 * (double)batch.h_voff[batch.count] * RW, 0.0);
-    if ((options().debug & 1)) std::fprintf(stderr, "duplicate agglomerates (sparse rows): %d distinct of %d\n", (int)cls.reps.size(), batch.count);
-    return true;
-}
-
+// only one member of a class is built (and factored, and iterated): DdSource kind 0.
 void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevElmats &el, int ae0,
               EigBatch &batch, bool scale, double *Dout, const RowsSpan *rows, AeClasses *classes) {
     if (!batch.count) return;
@@ -1097,9 +1019,17 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
     // not when D is wanted for every agglomerate (keep_debug)
     DBuf<int> only;
     int nbuild = batch.count;
-    if (classes && nde8 && bwp && !Dout && !batch.has_x0c && rows_find_duplicates(s, batch, RW, rv, rc, pm, *classes)) {
-        only.from_host(classes->reps, s);
-        nbuild = (int)classes->reps.size();
+    if (classes && nde8 && bwp && !Dout && !batch.has_x0c) {
+        DdSource &src = classes->src;
+        src = DdSource();
+        src.kind = 0;
+        src.ns = batch.n.p; src.voff = batch.voff.p; src.moff = batch.moff.p;
+        src.perm = pm; src.rvals = rv; src.rcols = rc; src.RW = RW;
+        classes->early = eig_dedupe_find(s, src, batch.count, batch.max_n, classes->cls);
+        if (classes->early) {
+            only.from_host(classes->cls.reps, s);
+            nbuild = (int)classes->cls.reps.size();
+        }
     }
     auto launch = [&](auto kern) {
         SA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));

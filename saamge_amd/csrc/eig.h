@@ -122,15 +122,40 @@ void eig_subspace_vectors(hipStream_t s, EigBatch &b, const int64_t *eoff, const
 void eig_arena_release();   // frees the persistent workspace
 double *eig_arena_bandsave(const EigBatch &b, size_t doubles);   // persistent scratch of the inertia pass
 double *eig_arena_subpanels(const EigBatch &b, size_t doubles); // packed sub-panels of the outer blocks of the wide-band factorisations
-// duplicate matrices of a batch (eig.hip): reps = the first matrix of every class of bitwise identical matrices, rep_of[i] =
-// the position in reps of matrix i's class; false: not worth it (few duplicates) or not applicable.  eig_batch_compact
-// makes the batch of the representatives in the same workspace; eig_dedupe_expand copies their results to every member.
-bool eig_batch_find_duplicates(hipStream_t s, const EigBatch &b, std::vector<int> &reps, std::vector<int> &rep_of);
-int eig_dedupe_group(const unsigned long long *hh, int count, std::vector<int> &rep);
-void eig_dedupe_classes(const std::vector<int> &rep, std::vector<int> &reps, std::vector<int> &rep_of);
+// Duplicate matrices (eig.hip, "Duplicate agglomerate matrices").  DdSource: where the words of the matrices of a batch are
+// (kind 1: the assembled matrices; kind 0: the sparse rows the fused fine-level assembly builds them from).
+struct DdSource {
+    int kind = 1;
+    const int *ns = nullptr;
+    const int64_t *moff = nullptr, *voff = nullptr;
+    const double *W = nullptr;
+    const int *bws = nullptr;
+    const double *dis = nullptr;
+    const short *perm = nullptr;      // or null
+    const double *x0c = nullptr;      // or null
+    const double *rvals = nullptr;    // kind 0
+    const short *rcols = nullptr;
+    int RW = 0;
+};
+struct DdKey { unsigned long long a, b; bool operator==(const DdKey &o) const { return a == o.a && b == o.b; } };
+struct DdKeyHash { size_t operator()(const DdKey &k) const { return (size_t)(k.a ^ (k.b * 0x9E3779B97F4A7C15ull)); } };
+// classes of a batch: reps = the first matrix of every class of bitwise identical matrices (confirmed word by word),
+// rep_of[i] = the position in reps of matrix i's class, rep_hash = the 128-bit hash of every class (two words each)
+struct DdClasses {
+    std::vector<int> reps, rep_of;
+    std::vector<unsigned long long> rep_hash;
+};
+DdSource eig_dedupe_source(const EigBatch &b);
+bool eig_dedupe_find(hipStream_t s, const DdSource &src, int count, int max_n, DdClasses &out);      // false: fewer than a quarter duplicates
+std::vector<long> eig_dedupe_words(hipStream_t s, const DdSource &src, const std::vector<int> &h_n, const std::vector<int> &list);
+void eig_dedupe_pack(hipStream_t s, const DdSource &src, int max_n, const std::vector<int> &list, const std::vector<long> &words,
+                     std::vector<DBuf<unsigned long long>> &blobs);
+void eig_dedupe_compare(hipStream_t s, const DdSource &src, int max_n, const std::vector<int> &list,
+                        const std::vector<const unsigned long long *> &blobs, const std::vector<long> &blob_words, std::vector<char> &same);
+// the batch of some matrices of `full` (class representatives) in the same workspace; results to every member of the classes
 void eig_batch_compact(hipStream_t s, EigBatch &cb, EigBatch &full, const std::vector<int> &reps);
-void eig_dedupe_expand(hipStream_t s, int count, int max_n, const int *rep, const int64_t *ceoff, const int64_t *cxoff, const double *cevals,
-                       const double *cevecs, const int64_t *eoff, const int64_t *xoff, double *evals, double *evecs);
+void eig_dedupe_expand(hipStream_t s, int count, int max_n, const double *const *src_evals, const double *const *src_evecs,
+                       const int64_t *eoff, const int64_t *xoff, double *evals, double *evecs);
 // bytes of device workspace one matrix of size n needs (for chunk sizing)
 size_t eig_workspace_bytes(int n);
 // Phase 2: count eigenvalues in (vl, vu] (Sturm); fills b.m / b.j0 and the host copy b.h_m

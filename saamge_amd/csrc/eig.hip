@@ -879,141 +879,215 @@ __device__ inline unsigned long long dd_mix(unsigned long long x) {      // spli
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
 }
-struct DdView {      // what a matrix of the batch consists of, as far as the eigensolvers are concerned
-    const int *ns;
-    const int64_t *moff, *voff;
-    const double *W;
-    const int *bws;
-    const double *dis;
-    const short *perm;      // or null
-    const double *x0c;      // or null
-};
-__global__ __launch_bounds__(256) void batch_hash_kernel(DdView v, unsigned long long *__restrict__ out) {
-    __shared__ unsigned long long red[2][4];
-    const int b = blockIdx.x, n = v.ns[b], bw = min(v.bws[b], n - 1), w2 = 2 * bw + 1, tid = threadIdx.x;
-    const double *A = v.W + v.moff[b];
+// The words a matrix consists of, in a fixed order (DdSource, eig.h).  kind 1, the assembled matrix: the band of C in both
+// triangles (column by column, 2 bw + 1 slots per column, slots outside the matrix = 0), D^-1/2, the row order, the coarse
+// start vector, n and bw.  kind 0, the sparse rows the fused fine-level assembly builds the matrix from: values, columns,
+// the row order, n.
+__device__ inline long dd_count(const DdSource &v, int b) {
+    const long n = v.ns[b];
+    if (v.kind == 0) return 2 * n * v.RW + n + 1;
+    const long bw = min(v.bws[b], (int)n - 1);
+    return n * (2 * bw + 1) + 3 * n + 2;
+}
+__device__ inline unsigned long long dd_word(const DdSource &v, int b, long idx) {
+    const long n = v.ns[b];
     const int64_t vo = v.voff[b];
+    if (v.kind == 0) {
+        const long nr = n * v.RW;
+        if (idx < nr) return (unsigned long long)__double_as_longlong(v.rvals[(size_t)vo * v.RW + idx]);
+        if (idx < 2 * nr) return (unsigned long long)(unsigned short)v.rcols[(size_t)vo * v.RW + (idx - nr)];
+        if (idx < 2 * nr + n) return v.perm ? (unsigned long long)(unsigned short)v.perm[vo + (idx - 2 * nr)] : 0ull;
+        return (unsigned long long)n;
+    }
+    const long bw = min(v.bws[b], (int)n - 1), w2 = 2 * bw + 1, nb = n * w2;
+    if (idx < nb) {
+        const long j = idx / w2, i = j - bw + (idx - j * w2);
+        return (i >= 0 && i < n) ? (unsigned long long)__double_as_longlong(v.W[v.moff[b] + (size_t)j * n + i]) : 0ull;
+    }
+    idx -= nb;
+    if (idx < n) return (unsigned long long)__double_as_longlong(v.dis[vo + idx]);
+    if (idx < 2 * n) return v.perm ? (unsigned long long)(unsigned short)v.perm[vo + (idx - n)] : 0ull;
+    if (idx < 3 * n) return v.x0c ? (unsigned long long)__double_as_longlong(v.x0c[vo + (idx - 2 * n)]) : 0ull;
+    return idx == 3 * n ? (unsigned long long)n : (unsigned long long)bw;
+}
+// grid (matrices, y): partial 128-bit sums of the mixed (word, position) pairs, added into out[2 b], out[2 b + 1] (zeroed)
+__global__ __launch_bounds__(256) void dd_hash_kernel(DdSource v, unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long red[2][4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const long cnt = dd_count(v, b);
     unsigned long long h1 = 0, h2 = 0;
-    auto take = [&](unsigned long long bits, unsigned long long pos, unsigned long long salt) {
-        const unsigned long long k = dd_mix(bits + 0x9E3779B97F4A7C15ull * (pos + 1) + salt);
-        h1 += k;      // (sums: independent of the order the threads visit the words in)
+    for (long idx = (long)blockIdx.y * 256 + tid; idx < cnt; idx += 256l * gridDim.y) {
+        const unsigned long long k = dd_mix(dd_word(v, b, idx) + 0x9E3779B97F4A7C15ull * (unsigned long long)(idx + 1));
+        h1 += k;      // (sums: independent of the order the words are visited in)
         h2 += dd_mix(k ^ 0xD6E8FEB86659FD93ull);
-    };
-    for (long idx = tid; idx < (long)n * w2; idx += 256) {
-        const int j = (int)(idx / w2), i = j - bw + (int)(idx - (long)j * w2);
-        if (i >= 0 && i < n) take((unsigned long long)__double_as_longlong(A[(size_t)j * n + i]), (unsigned long long)idx, 0);
     }
-    for (int r = tid; r < n; r += 256) {
-        take((unsigned long long)__double_as_longlong(v.dis[vo + r]), (unsigned long long)r, 0x1111111111111111ull);
-        if (v.perm) take((unsigned long long)(unsigned short)v.perm[vo + r], (unsigned long long)r, 0x2222222222222222ull);
-        if (v.x0c) take((unsigned long long)__double_as_longlong(v.x0c[vo + r]), (unsigned long long)r, 0x3333333333333333ull);
-    }
-    if (tid == 0) take((unsigned long long)n, 0, 0x4444444444444444ull), take((unsigned long long)bw, 1, 0x4444444444444444ull);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64); }
     if ((tid & 63) == 0) { red[0][tid >> 6] = h1; red[1][tid >> 6] = h2; }
     __syncthreads();
     if (tid == 0) {
-        out[2 * (size_t)b] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        out[2 * (size_t)b + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        atomicAdd(out + 2 * (size_t)b, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(out + 2 * (size_t)b + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
     }
 }
 // every matrix against the first of its class (rep[b] = that matrix): differ[b] = 1 unless every word is the same
-__global__ __launch_bounds__(256) void batch_verify_kernel(DdView v, const int *__restrict__ rep, int *__restrict__ differ) {
+__global__ __launch_bounds__(256) void dd_verify_kernel(DdSource v, const int *__restrict__ rep, int *__restrict__ differ) {
     const int b = blockIdx.x, r0 = rep[b], tid = threadIdx.x;
     if (r0 == b) return;
-    const int n = v.ns[b], bw = min(v.bws[b], n - 1), w2 = 2 * bw + 1;
-    if (n != v.ns[r0] || bw != min(v.bws[r0], n - 1)) { if (tid == 0) differ[b] = 1; return; }
-    const long long *A = (const long long *)(v.W + v.moff[b]), *B = (const long long *)(v.W + v.moff[r0]);
-    const int64_t va = v.voff[b], vb = v.voff[r0];
+    const long cnt = dd_count(v, b);
+    if (cnt != dd_count(v, r0)) { if (tid == 0) differ[b] = 1; return; }
     int bad = 0;
-    for (long idx = tid; idx < (long)n * w2; idx += 256) {
-        const int j = (int)(idx / w2), i = j - bw + (int)(idx - (long)j * w2);
-        if (i >= 0 && i < n) bad |= A[(size_t)j * n + i] != B[(size_t)j * n + i];
-    }
-    for (int r = tid; r < n; r += 256) {
-        bad |= __double_as_longlong(v.dis[va + r]) != __double_as_longlong(v.dis[vb + r]);
-        if (v.perm) bad |= v.perm[va + r] != v.perm[vb + r];
-        if (v.x0c) bad |= __double_as_longlong(v.x0c[va + r]) != __double_as_longlong(v.x0c[vb + r]);
-    }
+    for (long idx = (long)blockIdx.y * 256 + tid; idx < cnt; idx += 256l * gridDim.y) bad |= dd_word(v, b, idx) != dd_word(v, r0, idx);
     if (bad) differ[b] = 1;
+}
+// list[q] = a matrix of the batch, blobs[q] = where its words go / what they are compared with (differ[q] = 1: not the same)
+__global__ __launch_bounds__(256) void dd_pack_kernel(DdSource v, const int *__restrict__ list, unsigned long long *const *__restrict__ blobs) {
+    const int b = list[blockIdx.x];
+    const long cnt = dd_count(v, b);
+    unsigned long long *out = blobs[blockIdx.x];
+    for (long idx = (long)blockIdx.y * 256 + threadIdx.x; idx < cnt; idx += 256l * gridDim.y) out[idx] = dd_word(v, b, idx);
+}
+__global__ __launch_bounds__(256) void dd_compare_kernel(DdSource v, const int *__restrict__ list, const unsigned long long *const *__restrict__ blobs,
+                                                         const long *__restrict__ blob_words, int *__restrict__ differ) {
+    const int b = list[blockIdx.x];
+    const long cnt = dd_count(v, b);
+    if (cnt != blob_words[blockIdx.x]) { if (threadIdx.x == 0) differ[blockIdx.x] = 1; return; }
+    const unsigned long long *ref = blobs[blockIdx.x];
+    int bad = 0;
+    for (long idx = (long)blockIdx.y * 256 + threadIdx.x; idx < cnt; idx += 256l * gridDim.y) bad |= dd_word(v, b, idx) != ref[idx];
+    if (bad) differ[blockIdx.x] = 1;
 }
 __global__ void gather_int_kernel(int n, const int *__restrict__ idx, const int *__restrict__ src, int *__restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[idx[i]];
 }
-// results of the class representatives to every member: block i copies eigenvalues and eigenvectors of matrix rep[i]
-__global__ __launch_bounds__(256) void dedupe_expand_kernel(const int *__restrict__ rep, const int64_t *__restrict__ ceoff,
-                                                            const int64_t *__restrict__ cxoff, const double *__restrict__ cevals,
-                                                            const double *__restrict__ cevecs, const int64_t *__restrict__ eoff,
-                                                            const int64_t *__restrict__ xoff, double *__restrict__ evals,
-                                                            double *__restrict__ evecs) {
-    const int i = blockIdx.x, r = rep[i];
-    const int64_t ne = ceoff[r + 1] - ceoff[r], nx = cxoff[r + 1] - cxoff[r];
-    for (int64_t t = threadIdx.x; t < ne; t += 256) evals[eoff[i] + t] = cevals[ceoff[r] + t];
-    for (int64_t t = blockIdx.y * 256 + threadIdx.x; t < nx; t += 256 * (int64_t)gridDim.y) evecs[xoff[i] + t] = cevecs[cxoff[r] + t];
+// results to every member of the classes: block i copies the eigenvalues and eigenvectors its class was given
+__global__ __launch_bounds__(256) void dedupe_expand_kernel(const double *const *__restrict__ src_evals, const double *const *__restrict__ src_evecs,
+                                                            const int64_t *__restrict__ eoff, const int64_t *__restrict__ xoff,
+                                                            double *__restrict__ evals, double *__restrict__ evecs) {
+    const int i = blockIdx.x;
+    const int64_t ne = eoff[i + 1] - eoff[i], nx = xoff[i + 1] - xoff[i];
+    const double *se = src_evals[i], *sx = src_evecs[i];
+    if (blockIdx.y == 0)
+        for (int64_t t = threadIdx.x; t < ne; t += 256) evals[eoff[i] + t] = se[t];
+    for (int64_t t = blockIdx.y * 256 + threadIdx.x; t < nx; t += 256 * (int64_t)gridDim.y) evecs[xoff[i] + t] = sx[t];
 }
-void eig_dedupe_expand(hipStream_t s, int count, int max_n, const int *rep, const int64_t *ceoff, const int64_t *cxoff, const double *cevals,
-                       const double *cevecs, const int64_t *eoff, const int64_t *xoff, double *evals, double *evecs) {
+void eig_dedupe_expand(hipStream_t s, int count, int max_n, const double *const *src_evals, const double *const *src_evecs,
+                       const int64_t *eoff, const int64_t *xoff, double *evals, double *evecs) {
     if (!count) return;
     const int ny = std::max(1, std::min(64, std::min(max_n / 128, 65536 / std::max(1, count))));
-    hipLaunchKernelGGL(dedupe_expand_kernel, dim3(count, ny), dim3(256), 0, s, rep, ceoff, cxoff, cevals, cevecs, eoff, xoff, evals, evecs);
+    hipLaunchKernelGGL(dedupe_expand_kernel, dim3(count, ny), dim3(256), 0, s, src_evals, src_evecs, eoff, xoff, evals, evecs);
     SA_HIP_CHECK(hipGetLastError());
 }
 
 // rep[i] = the first matrix with matrix i's 128-bit hash (hashes: two words per matrix); returns the number of classes
-int eig_dedupe_group(const unsigned long long *hh, int count, std::vector<int> &rep) {
-    struct Key { unsigned long long a, b; bool operator==(const Key &o) const { return a == o.a && b == o.b; } };
-    struct KeyHash { size_t operator()(const Key &k) const { return (size_t)(k.a ^ (k.b * 0x9E3779B97F4A7C15ull)); } };
-    std::unordered_map<Key, int, KeyHash> first;
+static int dd_group(const unsigned long long *hh, int count, std::vector<int> &rep) {
+    std::unordered_map<DdKey, int, DdKeyHash> first;
     first.reserve((size_t)count / 8 + 16);
     rep.resize((size_t)count);
     int nuniq = 0;
     for (int i = 0; i < count; ++i) {
-        auto it = first.emplace(Key{hh[2 * (size_t)i], hh[2 * (size_t)i + 1]}, i);
+        auto it = first.emplace(DdKey{hh[2 * (size_t)i], hh[2 * (size_t)i + 1]}, i);
         rep[i] = it.first->second;
         nuniq += it.second ? 1 : 0;
     }
     return nuniq;
 }
-// rep (first member per matrix) -> the list of first members and, per matrix, the position of its class in that list
-void eig_dedupe_classes(const std::vector<int> &rep, std::vector<int> &reps, std::vector<int> &rep_of) {
-    const int count = (int)rep.size();
-    reps.clear();
-    std::vector<int> pos((size_t)count, -1);
-    for (int i = 0; i < count; ++i)
-        if (rep[i] == i) { pos[i] = (int)reps.size(); reps.push_back(i); }
-    rep_of.resize((size_t)count);
-    for (int i = 0; i < count; ++i) rep_of[i] = pos[rep[i]];
+static int dd_grid_y(const DdSource &src, int count, int max_n) {      // workgroups per matrix: few large matrices need several
+    const long words = src.kind == 0 ? 2l * max_n * src.RW : (long)max_n * std::min(2 * max_n, 2048);
+    return (int)std::max(1l, std::min(std::min(64l, words / 65536), 4096l / std::max(1, count)));
 }
 
-bool eig_batch_find_duplicates(hipStream_t s, const EigBatch &b, std::vector<int> &reps, std::vector<int> &rep_of) {
-    reps.clear();
-    rep_of.clear();
-    if (!b.has_bw || b.count < 32 || b.bw.n < (size_t)b.count) return false;
+bool eig_dedupe_find(hipStream_t s, const DdSource &src, int count, int max_n, DdClasses &out) {
+    out.reps.clear();
+    out.rep_of.clear();
+    out.rep_hash.clear();
+    if (count < 16) return false;
     profiler().begin(s);
-    DdView v{b.n.p, b.moff.p, b.voff.p, b.W.p, b.bw.p, b.dis.p, b.has_perm ? b.perm.p : nullptr, b.has_x0c ? b.x0c.p : nullptr};
-    DBuf<unsigned long long> hash(2 * (size_t)b.count);
-    hipLaunchKernelGGL(batch_hash_kernel, dim3(b.count), dim3(256), 0, s, v, hash.p);
+    const int ny = dd_grid_y(src, count, max_n);
+    DBuf<unsigned long long> hash(2 * (size_t)count);
+    hash.zero(s);
+    hipLaunchKernelGGL(dd_hash_kernel, dim3(count, ny), dim3(256), 0, s, src, hash.p);
     SA_HIP_CHECK(hipGetLastError());
     auto hh = hash.to_host(s);
     std::vector<int> rep;
-    const int nuniq = eig_dedupe_group(hh.data(), b.count, rep);
-    if ((long)nuniq * 4 > (long)b.count * 3) { profiler().end(s, "eig_dedupe", 0.0, 0.0); return false; }
-    DBuf<int> d_rep, differ((size_t)b.count);
+    const int nuniq = dd_group(hh.data(), count, rep);
+    if ((long)nuniq * 4 > (long)count * 3) { profiler().end(s, "eig_dedupe", 0.0, 0.0); return false; }
+    DBuf<int> d_rep, differ((size_t)count);
     d_rep.from_host(rep, s);
     differ.zero(s);
-    hipLaunchKernelGGL(batch_verify_kernel, dim3(b.count), dim3(256), 0, s, v, d_rep.p, differ.p);
+    hipLaunchKernelGGL(dd_verify_kernel, dim3(count, ny), dim3(256), 0, s, src, d_rep.p, differ.p);
     SA_HIP_CHECK(hipGetLastError());
     auto hd = differ.to_host(s);
-    for (int i = 0; i < b.count; ++i)
+    for (int i = 0; i < count; ++i)
         if (hd[i]) rep[i] = i;      // (a collision of the hash: the matrix stands for itself)
-    eig_dedupe_classes(rep, reps, rep_of);
-    double bytes = 0.0;
-    for (int i = 0; i < b.count; ++i) bytes += 16.0 * (double)b.h_n[i] * (2.0 * std::min(b.h_n[i] - 1, 64) + 1.0);
-    profiler().end(s, "eig_dedupe", bytes, 0.0);
-    if ((options().debug & 1)) std::fprintf(stderr, "duplicate agglomerates: %d distinct of %d\n", (int)reps.size(), b.count);
+    std::vector<int> pos((size_t)count, -1);
+    for (int i = 0; i < count; ++i)
+        if (rep[i] == i) {
+            pos[i] = (int)out.reps.size();
+            out.reps.push_back(i);
+            out.rep_hash.push_back(hh[2 * (size_t)i]);
+            out.rep_hash.push_back(hh[2 * (size_t)i + 1]);
+        }
+    out.rep_of.resize((size_t)count);
+    for (int i = 0; i < count; ++i) out.rep_of[i] = pos[rep[i]];
+    profiler().end(s, "eig_dedupe", 0.0, 0.0);
+    if ((options().debug & 1)) std::fprintf(stderr, "duplicate agglomerates (%s): %d distinct of %d\n", src.kind ? "bands" : "sparse rows", (int)out.reps.size(), count);
     return true;
+}
+// the words of some matrices of the batch, kept for comparisons with matrices of later batches
+void eig_dedupe_pack(hipStream_t s, const DdSource &src, int max_n, const std::vector<int> &list, const std::vector<long> &words,
+                     std::vector<DBuf<unsigned long long>> &blobs) {
+    blobs.clear();
+    blobs.resize(list.size());
+    if (list.empty()) return;
+    std::vector<unsigned long long *> ptrs(list.size());
+    for (size_t q = 0; q < list.size(); ++q) { blobs[q].alloc((size_t)words[q]); ptrs[q] = blobs[q].p; }
+    DBuf<int> d_list;
+    DBuf<unsigned long long *> d_ptrs;
+    d_list.from_host(list, s);
+    d_ptrs.from_host(ptrs, s);
+    hipLaunchKernelGGL(dd_pack_kernel, dim3((unsigned)list.size(), dd_grid_y(src, (int)list.size(), max_n)), dim3(256), 0, s, src, d_list.p, d_ptrs.p);
+    SA_HIP_CHECK(hipGetLastError());
+    SA_HIP_CHECK(hipStreamSynchronize(s));
+}
+// same[q] = matrix list[q] of the batch consists of exactly the words blobs[q]
+void eig_dedupe_compare(hipStream_t s, const DdSource &src, int max_n, const std::vector<int> &list,
+                        const std::vector<const unsigned long long *> &blobs, const std::vector<long> &blob_words, std::vector<char> &same) {
+    same.assign(list.size(), 0);
+    if (list.empty()) return;
+    DBuf<int> d_list, differ(list.size());
+    DBuf<const unsigned long long *> d_ptrs;
+    DBuf<long> d_words;
+    d_list.from_host(list, s);
+    d_ptrs.from_host(blobs, s);
+    d_words.from_host(blob_words, s);
+    differ.zero(s);
+    hipLaunchKernelGGL(dd_compare_kernel, dim3((unsigned)list.size(), dd_grid_y(src, (int)list.size(), max_n)), dim3(256), 0, s, src, d_list.p, d_ptrs.p,
+                       d_words.p, differ.p);
+    SA_HIP_CHECK(hipGetLastError());
+    auto hd = differ.to_host(s);
+    for (size_t q = 0; q < list.size(); ++q) same[q] = hd[q] ? 0 : 1;
+}
+// word counts of some matrices (host): the half bandwidths come from the device
+std::vector<long> eig_dedupe_words(hipStream_t s, const DdSource &src, const std::vector<int> &h_n, const std::vector<int> &list) {
+    std::vector<long> w(list.size());
+    hvec<int> hb;
+    if (src.kind == 1) { DBuf<int> tmp; tmp.view(const_cast<int *>(src.bws), h_n.size()); hb = tmp.to_host(s); }
+    for (size_t q = 0; q < list.size(); ++q) {
+        const long n = h_n[list[q]];
+        if (src.kind == 0) w[q] = 2 * n * src.RW + n + 1;
+        else { const long bw = std::min((long)hb[list[q]], n - 1); w[q] = n * (2 * bw + 1) + 3 * n + 2; }
+    }
+    return w;
+}
+DdSource eig_dedupe_source(const EigBatch &b) {
+    DdSource v{};
+    v.kind = 1;
+    v.ns = b.n.p; v.moff = b.moff.p; v.voff = b.voff.p; v.W = b.W.p; v.bws = b.bw.p; v.dis = b.dis.p;
+    v.perm = b.has_perm ? b.perm.p : nullptr;
+    v.x0c = b.has_x0c ? b.x0c.p : nullptr;
+    return v;
 }
 
 // the batch of the class representatives: the same workspace, per-matrix tables of its own
@@ -1048,7 +1122,7 @@ void eig_batch_compact(hipStream_t s, EigBatch &cb, EigBatch &full, const std::v
     if (full.perm.n) cb.perm.view(full.perm.p, full.perm.n);
     if (full.iperm.n) cb.iperm.view(full.iperm.p, full.iperm.n);
     cb.has_bw = full.has_bw;
-    if (full.has_bw) {
+    if (full.has_bw && cb.count) {
         DBuf<int> idx;
         idx.from_host(reps, s);
         cb.bw.alloc((size_t)cb.count);

@@ -336,7 +336,22 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     // (batches: what the eigensolvers run on -- the assembled batch itself, or the batch of the representatives of its
     // classes of bitwise identical matrices, eig.hip "Duplicate agglomerate matrices"; rep_of: empty = no classes)
     EigBatch batches[2], assembled[2];
-    std::vector<int> rep_of[2];
+    // Classes of bitwise identical agglomerates of this level (a rank's part of it): the first member met is solved, in
+    // the chunk it sits in; every later member -- of that chunk or a later one -- receives a copy.  A class keeps the words
+    // it consists of (the first member's: sparse rows or band, eig.h DdSource), against which the candidates of later
+    // chunks are compared word by word, and where its eigenpairs are.
+    struct SolvedClass {
+        int n = 0, m = 0, kind = 0;
+        bool bad = false;           // the few-eigenpairs path gave up on it: every member is redone by the dense path
+        long words = 0;
+        DBuf<unsigned long long> blob;
+        const double *evals = nullptr, *evecs = nullptr;
+    };
+    std::vector<SolvedClass> lvl_classes;
+    std::unordered_map<DdKey, std::vector<int>, DdKeyHash> lvl_by_hash;
+    std::vector<DBuf<double>> kept;          // packed eigenpairs of the chunks' representatives
+    std::vector<int> cls_of[2];              // per slot: class of every agglomerate of the chunk (empty: no classes)
+    std::vector<int> solve_cls[2];           // per slot: classes of the matrices of the batch that is solved, in its order
     const bool dedupe = options().eig_dedupe != 0 && !(P.testmesh && lev == 0);
     int pend_ae0[2] = {0, 0}, pend_cnt[2] = {0, 0};
     int64_t pend_row0[2] = {0, 0};
@@ -373,16 +388,17 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     auto post = [&](int slot) {   // band -> tridiagonal, counts, eigenvectors of the chunk in `slot`
         EigBatch &batch = batches[slot];
         const int ae0 = pend_ae0[slot], cnt = pend_cnt[slot];
-        if (!counted[slot]) {
+        const std::vector<int> &co = cls_of[slot];
+        bool have = batch.count > 0;      // (with classes: the batch of the NEW classes' representatives, possibly empty)
+        if (have && !counted[slot]) {
             eig_tridiagonalize(qb, batch, 2);
             eig_count(qb, batch, -1.0, L.theta);
         }
-        if (batch.ss_failed && !rep_of[slot].empty()) {      // ... on ALL matrices of the chunk (the assembled batch is still there)
-            batch = std::move(assembled[slot]);
-            rep_of[slot].clear();
-            batch.ss_failed = true;
+        if (have && batch.ss_failed && !co.empty()) {      // the new classes go to the dense path, member by member (below)
+            for (int id : solve_cls[slot]) lvl_classes[id].bad = true;
+            have = false;
         }
-        if (batch.ss_failed) {   // few-eigenpairs path gave up on this chunk: dense path on re-assembled matrices
+        if (have && batch.ss_failed) {   // few-eigenpairs path gave up on this chunk: dense path on re-assembled matrices
             batch.dense_only = true;
             batch.subspace = batch.ss_failed = false;
             const RowsSpan span{(int64_t)L.rel.AE_to_dof.I[ae0] - (int64_t)L.rel.AE_to_dof.I[ae_lo], (int64_t)L.rel.AE_to_dof.I[ae_hi] - (int64_t)L.rel.AE_to_dof.I[ae_lo]};      // (positions among the rows of this rank's agglomerates)
@@ -398,14 +414,44 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         c.eoff.assign((size_t)cnt + 1, 0);
         c.xoff.assign((size_t)cnt + 1, 0);
         // per agglomerate of the chunk: eigenvector count and "redo by the dense path" -- its own, or its class's
-        const std::vector<int> &ro = rep_of[slot];
         std::vector<int> hm((size_t)cnt);
         std::vector<char> hbad((size_t)cnt, 0);
-        const bool some_bad = batch.subspace && batch.nbad > 0;
+        bool some_bad = have && batch.subspace && batch.nbad > 0;
+        if (!co.empty() && have) {      // the eigenpairs of the classes solved in this chunk, packed; kept for the later members
+            const int nr = batch.count;
+            std::vector<int64_t> re((size_t)nr + 1, 0), rx((size_t)nr + 1, 0);
+            for (int r = 0; r < nr; ++r) {
+                re[r + 1] = re[r] + batch.h_m[r];
+                rx[r + 1] = rx[r] + (int64_t)batch.h_m[r] * batch.h_n[r];
+            }
+            kept.emplace_back((size_t)re[nr] + 1);
+            double *revals = kept.back().p;
+            kept.emplace_back((size_t)rx[nr] + 1);
+            double *revecs = kept.back().p;
+            DBuf<int64_t> d_re, d_rx;
+            d_re.from_host(re, qb);
+            d_rx.from_host(rx, qb);
+            eig_vectors(qb, batch, d_re.p, d_rx.p, revals, revecs);
+            SA_HIP_CHECK(hipStreamSynchronize(qb));
+            for (int r = 0; r < nr; ++r) {
+                SolvedClass &sc = lvl_classes[solve_cls[slot][r]];
+                sc.m = batch.h_m[r];
+                sc.bad = some_bad && batch.h_bad[r];
+                sc.evals = revals + re[r];
+                sc.evecs = revecs + rx[r];
+            }
+        }
+        some_bad = co.empty() ? some_bad : false;
         for (int i = 0; i < cnt; ++i) {
-            const int r = ro.empty() ? i : ro[i];
-            hm[i] = batch.h_m[r];
-            if (some_bad) hbad[i] = batch.h_bad[r];
+            if (co.empty()) {
+                hm[i] = batch.h_m[i];
+                if (some_bad) hbad[i] = batch.h_bad[i];
+            } else {
+                const SolvedClass &sc = lvl_classes[co[i]];
+                hm[i] = sc.bad ? 0 : sc.m;
+                hbad[i] = sc.bad ? 1 : 0;
+                some_bad = some_bad || sc.bad;
+            }
         }
         for (int i = 0; i < cnt; ++i) {
             L.ae_m[ae0 + i] = hm[i];
@@ -416,24 +462,16 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         c.evecs.alloc((size_t)c.xoff[cnt]);
         c.d_eoff.from_host(c.eoff, qb);
         c.d_xoff.from_host(c.xoff, qb);
-        if (ro.empty()) {
+        if (co.empty()) {
             eig_vectors(qb, batch, c.d_eoff.p, c.d_xoff.p, c.evals.p, c.evecs.p);
-        } else {      // the representatives' eigenpairs, packed, then a copy to every member of their classes
-            const int nr = batch.count;
-            std::vector<int64_t> re((size_t)nr + 1, 0), rx((size_t)nr + 1, 0);
-            for (int r = 0; r < nr; ++r) {
-                re[r + 1] = re[r] + batch.h_m[r];
-                rx[r + 1] = rx[r] + (int64_t)batch.h_m[r] * batch.h_n[r];
-            }
-            DBuf<double> revals((size_t)re[nr] + 1), revecs((size_t)rx[nr] + 1);
-            DBuf<int64_t> d_re, d_rx;
-            DBuf<int> d_ro;
-            d_re.from_host(re, qb);
-            d_rx.from_host(rx, qb);
-            d_ro.from_host(ro, qb);
-            eig_vectors(qb, batch, d_re.p, d_rx.p, revals.p, revecs.p);
-            eig_dedupe_expand(qb, cnt, batch.max_n, d_ro.p, d_re.p, d_rx.p, revals.p, revecs.p, c.d_eoff.p, c.d_xoff.p, c.evals.p, c.evecs.p);
-            SA_HIP_CHECK(hipStreamSynchronize(qb));      // (the packed results are freed here)
+        } else {      // a copy of its class's eigenpairs to every agglomerate
+            std::vector<const double *> pe((size_t)cnt), px((size_t)cnt);
+            for (int i = 0; i < cnt; ++i) { pe[i] = lvl_classes[co[i]].evals; px[i] = lvl_classes[co[i]].evecs; }
+            DBuf<const double *> d_pe, d_px;
+            d_pe.from_host(pe, qb);
+            d_px.from_host(px, qb);
+            eig_dedupe_expand(qb, cnt, sizes.empty() ? 1 : *std::max_element(sizes.begin() + ae0, sizes.begin() + ae0 + cnt), d_pe.p, d_px.p,
+                              c.d_eoff.p, c.d_xoff.p, c.evals.p, c.evecs.p);
         }
         SA_HIP_CHECK(hipStreamSynchronize(qb));
         if (!some_bad) return;
@@ -549,17 +587,63 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
                  P.keep_debug ? L.ae_D.p + row0 : nullptr, keep_rows ? &span : nullptr,
                  dedupe && !batch.dense_only ? &classes : nullptr);
         const int64_t rows_chunk = batch.h_voff[cnt];
-        rep_of[slot].clear();
+        cls_of[slot].clear();
+        solve_cls[slot].clear();
         if (dedupe && !batch.dense_only) {
-            // (classes known before the matrices were built -- the fused fine-level assembly --, or found on the matrices)
-            if (!classes.reps.empty()) rep_of[slot] = classes.rep_of;
-            else if (!eig_batch_find_duplicates(qa, batch, classes.reps, rep_of[slot])) rep_of[slot].clear();
-            if (!rep_of[slot].empty()) {
+            // classes within the chunk: known before its matrices were built (the fused fine-level assembly) or found on them
+            DdSource src = classes.src;
+            bool found = classes.early;
+            if (!found && batch.has_bw) {
+                src = eig_dedupe_source(batch);
+                found = eig_dedupe_find(qa, src, cnt, batch.max_n, classes.cls);
+            }
+            if (found) {
+                const DdClasses &cl = classes.cls;
+                const int nl = (int)cl.reps.size();
+                std::vector<int> l2g((size_t)nl, -1);
+                // ... against the classes of the earlier chunks: same hash, then word by word against the class's first member
+                std::vector<int> list, qidx, cand;
+                std::vector<const unsigned long long *> blobs;
+                std::vector<long> bwords;
+                for (int q = 0; q < nl; ++q) {
+                    auto it = lvl_by_hash.find(DdKey{cl.rep_hash[2 * (size_t)q], cl.rep_hash[2 * (size_t)q + 1]});
+                    if (it == lvl_by_hash.end()) continue;
+                    for (int id : it->second)
+                        if (lvl_classes[id].kind == src.kind) {
+                            list.push_back(cl.reps[q]); qidx.push_back(q); cand.push_back(id);
+                            blobs.push_back(lvl_classes[id].blob.p); bwords.push_back(lvl_classes[id].words);
+                        }
+                }
+                std::vector<char> same;
+                eig_dedupe_compare(qa, src, batch.max_n, list, blobs, bwords, same);
+                for (size_t t = 0; t < list.size(); ++t)
+                    if (same[t] && l2g[qidx[t]] < 0) l2g[qidx[t]] = cand[t];
+                // the new classes: their words are kept, their first members are what this chunk solves
+                std::vector<int> newq, newlist;
+                for (int q = 0; q < nl; ++q)
+                    if (l2g[q] < 0) { newq.push_back(q); newlist.push_back(cl.reps[q]); }
+                const std::vector<long> nwords = eig_dedupe_words(qa, src, batch.h_n, newlist);
+                std::vector<DBuf<unsigned long long>> nblobs;
+                eig_dedupe_pack(qa, src, batch.max_n, newlist, nwords, nblobs);
+                for (size_t t = 0; t < newq.size(); ++t) {
+                    const int id = (int)lvl_classes.size();
+                    lvl_classes.emplace_back();
+                    SolvedClass &sc = lvl_classes.back();
+                    sc.n = batch.h_n[newlist[t]];
+                    sc.kind = src.kind;
+                    sc.words = nwords[t];
+                    sc.blob = std::move(nblobs[t]);
+                    lvl_by_hash[DdKey{cl.rep_hash[2 * (size_t)newq[t]], cl.rep_hash[2 * (size_t)newq[t] + 1]}].push_back(id);
+                    l2g[newq[t]] = id;
+                    solve_cls[slot].push_back(id);
+                }
+                cls_of[slot].resize((size_t)cnt);
+                for (int i = 0; i < cnt; ++i) cls_of[slot][i] = l2g[cl.rep_of[i]];
                 assembled[slot] = std::move(batch);
-                eig_batch_compact(qa, batch, assembled[slot], classes.reps);
+                eig_batch_compact(qa, batch, assembled[slot], newlist);
             }
         }
-        eig_tridiagonalize(qa, batch, 1);
+        if (batch.count) eig_tridiagonalize(qa, batch, 1);
         pend_ae0[slot] = ae0;
         pend_cnt[slot] = cnt;
         pend_row0[slot] = row0;
