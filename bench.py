@@ -417,6 +417,10 @@ def main():
                    "true_relative_residual": relres,
                    "level_dims": [i["n"] for i in infos] + [infos[-1]["ncoarse"]],
                    "operator_formats": op_formats,
+                   # local eigenproblems solved / agglomerates per level (rank 0's share): the agglomerates of a structured mesh with
+                   # piecewise constant coefficients fall into a few classes of bitwise identical matrices, each solved once
+                   # (saamge_amd_options.eig_dedupe; general_coefficient below has no such classes)
+                   "eigenproblems_solved": [[h.level_format(l)["eigenproblems_solved"], infos[l]["nparts"]] for l in range(args.levels - 1)],
                    "collectives": ("RCCL inside the library (csrc/comm.hip)" if native else "torch.distributed callbacks (%s)" % backend)
                    if world > 1 else None,
                    "parallelism": ("%d ranks: per-AE spectral problems, RAP and coarse element matrices sharded + "

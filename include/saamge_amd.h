@@ -286,7 +286,8 @@ int saamge_amd_level_info(const saamge_amd_hierarchy *h, int level, long long in
  * that are pair-coded / offset-coded / plain, [3..5] = their stored entries, [6] = 256-row tiles whose x-segments are
  * staged through LDS, [7] = bytes of matrix data one application streams in these formats, [8] = pairs of the operator-level
  * (offset, value) dictionary that replaces the plain slices' columns and values by 16-bit codes (0: none), [9] = 1 if the
- * lanes of a 3 x 3 node block share their gathers of x, [10] = rows outside regular node blocks, [11] reserved. */
+ * lanes of a 3 x 3 node block share their gathers of x, [10] = rows outside regular node blocks, [11] = local eigenproblems this rank SOLVED on the level (its other
+ * agglomerates are bitwise identical to one of those and received a copy: saamge_amd_options.eig_dedupe). */
 int saamge_amd_level_format(const saamge_amd_hierarchy *h, int level, long long info[12]);
 /* which: 0 A_l, 1 interp, 2 restr, 3 Ac (host output buffers sized from level_info) */
 int saamge_amd_get_csr(const saamge_amd_hierarchy *h, int level, int which, int *rowptr, int *col,

@@ -405,7 +405,8 @@ class Hierarchy(object):
         return {"slices": {"pair_coded": v[0], "offset_coded": v[1], "plain": v[2]},
                 "entries": {"pair_coded": v[3], "offset_coded": v[4], "plain": v[5]},
                 "staged_tiles": v[6], "stream_bytes": v[7],
-                "dictionary_pairs": v[8], "node_blocks": bool(v[9]), "irregular_rows": v[10]}
+                "dictionary_pairs": v[8], "node_blocks": bool(v[9]), "irregular_rows": v[10],
+                "eigenproblems_solved": v[11]}
 
     def get_csr(self, level, which):
         import scipy.sparse as sp

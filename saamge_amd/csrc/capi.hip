@@ -403,6 +403,7 @@ int saamge_amd_level_format(const saamge_amd_hierarchy *h, int level, long long 
     if (A.sell_gpair) { info[8] = A.sell_ng; info[9] = A.sell_bs3 ? 1 : 0; info[10] = A.sell_bs3 ? A.sell_nirr : 0; }
     info[6] = A.sell_stage_cap > 0 ? (long long)div_up(A.nslices, 4) - A.sell_nunstaged : 0;
     info[7] = (long long)A.sell_stream_bytes;
+    info[11] = H.levels.at(level)->ae_solved;
     SA_API_END
 }
 

@@ -296,6 +296,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     std::vector<int> sizes((size_t)nparts);
     for (int p = 0; p < nparts; ++p) sizes[p] = rel.AE_to_dof.row_size(p);
     L.ae_m.assign((size_t)nparts, 0);
+    L.ae_solved = 0;
     struct Chunk { int ae0, count; DBuf<double> evals, evecs; std::vector<int64_t> eoff, xoff; DBuf<int64_t> d_eoff, d_xoff; };
     std::vector<Chunk> chunks;
     if (P.keep_debug) L.ae_D.alloc((size_t)rel.AE_to_dof.I[nparts]);
@@ -644,6 +645,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
             }
         }
         if (batch.count) eig_tridiagonalize(qa, batch, 1);
+        L.ae_solved += batch.count;      // (eigenproblems that are solved, not copied)
         pend_ae0[slot] = ae0;
         pend_cnt[slot] = cnt;
         pend_row0[slot] = row0;

@@ -173,3 +173,48 @@ def test_every_remaining_option_flipped_gives_the_golden(flip):
         _check(g, out, "scale_64x64x32/" + ",".join("%s=%s" % kv for kv in flip.items()))
     finally:
         capi.load().saamge_amd_set_options(__import__("ctypes").byref(old))
+
+
+def test_identical_agglomerates_solved_once_give_the_bitwise_same_hierarchy():
+    """saamge_amd_options.eig_dedupe (csrc/eig.hip "Duplicate agglomerate matrices"): on a structured mesh most agglomerates
+    are translates of one another, their local matrices identical bit for bit; one member per class is solved, the others get
+    copies.  Required: the prolongators and the coarse operators of BOTH levels are bitwise those of the per-agglomerate
+    computation (eig_dedupe = 0), with the level-0 agglomerates in several chunks (classes are carried from chunk to chunk),
+    and far fewer eigenproblems are solved; with a coefficient without symmetry nothing is a duplicate and every agglomerate
+    is solved on its own.  Reference semantics: every AE's eigenproblem is the reference's (src/spectral.cpp:124-237) --
+    which ones share a solve is not observable in the result."""
+    import hashlib
+    import torch
+    from saamge_amd import capi
+
+    def build(dedupe, coef):
+        capi.set_options(eig_dedupe=dedupe)
+        try:
+            prob = pr.poisson3d_device((64, 64, 32), blk=(8, 8, 4), coarse_blk=[(8, 8, 4)], device="cuda:0", coef=coef)
+            params = capi.default_params(num_coarsenings=2, theta=0.003, nu_relax=3, workspace_bytes=1 << 28)
+            h = capi.Hierarchy(prob.rowptr, prob.col, prob.val, prob.n, prob.elem_to_dof, prob.elmat, prob.bdr,
+                               prob.partitions, prob.nparts, params, prob.NE_, 8)
+            dig = []
+            for l in range(2):
+                for which in ("P", "Ac"):
+                    M = h.get_csr(l, which).tocsr()
+                    M.sort_indices()
+                    dig.append(hashlib.sha256(M.indptr.tobytes() + M.indices.tobytes() + M.data.tobytes()).hexdigest())
+            solved = [h.level_format(l)["eigenproblems_solved"] for l in range(2)]
+            nparts = [h.level_info(l)["nparts"] for l in range(2)]
+            x = torch.zeros_like(prob.b)
+            _, it, conv, _ = h.pcg(prob.b, x, rel_tol=1e-8, max_iter=100)
+            h.close()
+            return dig, solved, nparts, it, bool(conv)
+        finally:
+            capi.reset_options()
+
+    on, off = build(1, None), build(0, None)
+    print("constant coefficient: eigenproblems solved", on[1], "of", on[2], "(without classes:", off[1], ")")
+    assert on[0] == off[0] and on[3] == off[3] and on[4] and off[4]
+    assert off[1] == off[2]                                   # every agglomerate on its own
+    assert on[1][0] * 4 < on[2][0]                            # (512 fine agglomerates: a few dozen classes)
+    assert on[1][1] <= on[2][1]
+    gen_on, gen_off = build(1, "skew"), build(0, "skew")
+    print("general coefficient: eigenproblems solved", gen_on[1], "of", gen_on[2])
+    assert gen_on[0] == gen_off[0] and gen_on[1] == gen_on[2]
