@@ -386,6 +386,7 @@ def main():
         r0 = r1
     relres = float(res2 ** 0.5 / torch.linalg.norm(prob.b))
     op_formats = [dict(h.level_format(l)["slices"], dictionary_pairs=h.level_format(l)["dictionary_pairs"]) for l in range(args.levels - 1)]
+    eig_solved = [[h.level_format(l)["eigenproblems_solved"], infos[l]["nparts"]] for l in range(args.levels - 1)]
     h.close()
 
     res = {
@@ -420,7 +421,7 @@ def main():
                    # local eigenproblems solved / agglomerates per level (rank 0's share): the agglomerates of a structured mesh with
                    # piecewise constant coefficients fall into a few classes of bitwise identical matrices, each solved once
                    # (saamge_amd_options.eig_dedupe; general_coefficient below has no such classes)
-                   "eigenproblems_solved": [[h.level_format(l)["eigenproblems_solved"], infos[l]["nparts"]] for l in range(args.levels - 1)],
+                   "eigenproblems_solved": eig_solved,
                    "collectives": ("RCCL inside the library (csrc/comm.hip)" if native else "torch.distributed callbacks (%s)" % backend)
                    if world > 1 else None,
                    "parallelism": ("%d ranks: per-AE spectral problems, RAP and coarse element matrices sharded + "
