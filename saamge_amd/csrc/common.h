@@ -280,6 +280,11 @@ struct DCsr {
     // of tile T at (T sell_wq + q) 256 + t) and one descriptor word per tile (segments | the four slice widths)
     int sell_wq = 0;
     DBuf<unsigned> sell_codeR;
+    // the smoother's diagonal factor as byte codes into a table of <= 256 values (operators whose rows repeat: a 256-row tile
+    // then reads 256 bytes of it instead of 2 KB); sell_dsrc: the array the codes were made from (build_dinv_codes)
+    DBuf<unsigned char> sell_dcode;
+    DBuf<unsigned long long> sell_dtab;
+    const double *sell_dsrc = nullptr;
     DBuf<int> sell_tile_desc;
     DBuf<int> sell_unstaged;       // tiles left to the gather kernel (sell_nunstaged of them)
     int sell_nunstaged = 0;

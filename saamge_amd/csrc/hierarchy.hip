@@ -187,6 +187,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
                 L.dinv_neg.alloc((size_t)L.A.nrows);
                 DBuf<double> tmp((size_t)L.A.nrows);
                 build_dinv_neg(os, L.A, tmp.p, L.dinv_neg.p);
+                build_dinv_codes(os, L.A, L.dinv_neg.p);
                 SA_HIP_CHECK(hipStreamSynchronize(os));
             } catch (...) { op_err = std::current_exception(); }
         });
@@ -276,6 +277,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         L.dinv_neg.alloc((size_t)L.A.nrows);
         DBuf<double> tmp((size_t)L.A.nrows);
         build_dinv_neg(s, L.A, tmp.p, L.dinv_neg.p);
+        build_dinv_codes(s, L.A, L.dinv_neg.p);
         SA_HIP_CHECK(hipStreamSynchronize(s));
     };
     const bool operator_pending = H.galerkin_lev >= 0;
@@ -1601,6 +1603,7 @@ void hierarchy_update_operators(Hierarchy &H, const double *new_val) {
         {
             DBuf<double> tmp((size_t)L.A.nrows);
             build_dinv_neg(s, L.A, tmp.p, L.dinv_neg.p);
+            build_dinv_codes(s, L.A, L.dinv_neg.p);
             SA_HIP_CHECK(hipStreamSynchronize(s));
         }
         L.Ac = DCsr();

@@ -28,6 +28,8 @@ void smooth_first(hipStream_t s, int n, const double *dinv_neg, const double *b,
 // dinv_neg_i = -1 / ( sqrt|a_ii| * sum_j |a_ij| / sqrt|a_jj| )
 //                                               (reference: amg/src/mbox.cpp:1839-1861)
 void build_dinv_neg(hipStream_t s, const DCsr &A, double *sqrt_diag_tmp, double *dinv_neg);
+// byte codes of the smoother's diagonal factor (operators with <= 256 distinct values of it and the staged coded format)
+void build_dinv_codes(hipStream_t s, DCsr &A, const double *dinv_neg);
 
 // deterministic dot product: out[0] = sum a_i b_i ; `partials` holds >= 1024 doubles
 void dot(hipStream_t s, int n, const double *a, const double *b, double *partials, double *out);

@@ -452,7 +452,9 @@ __global__ __launch_bounds__(256) void sell_staged2_kernel(int nrows, int row0, 
                                                            const int *__restrict__ tile_desc, const int2 *__restrict__ tile_seg,
                                                            const double *__restrict__ x, double *__restrict__ y,
                                                            const double *__restrict__ b, const double *__restrict__ dinv,
-                                                           double scale, const double *__restrict__ xrow) {
+                                                           double scale, const double *__restrict__ xrow,
+                                                           const unsigned char *__restrict__ dcode = nullptr,
+                                                           const double *__restrict__ dtab = nullptr) {
     extern __shared__ __align__(16) double lds[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     PairEntry *lt = (PairEntry *)(lds + stage_cap);
@@ -470,7 +472,8 @@ __global__ __launch_bounds__(256) void sell_staged2_kernel(int nrows, int row0, 
     if (MODE == MODE_RESIDUAL) e_b = __builtin_nontemporal_load(b + row);
     if (MODE == MODE_ADD) e_x = y[row];
     // (the smoother's x-row is x itself at the tile's own rows: taken from the staged segment that holds them, below)
-    if (MODE == MODE_SMOOTH) { e_b = __builtin_nontemporal_load(b + row); e_d = __builtin_nontemporal_load(dinv + row); }
+    // (D^-1 as a byte code into a small table where the operator's rows repeat: 1 instead of 8 bytes per row)
+    if (MODE == MODE_SMOOTH) { e_b = __builtin_nontemporal_load(b + row); e_d = dcode ? dtab[__builtin_nontemporal_load(dcode + row)] : __builtin_nontemporal_load(dinv + row); }
     int mytab = 0;
     double myval = 0.0;
     if (wv == 0) {          // the tile's one table sits at its first slice
@@ -1317,6 +1320,8 @@ void export_rowptr32(int *dst_host, const DBuf<roff_t> &src, size_t n, hipStream
 
 void build_sell(hipStream_t s, DCsr &A) {
     A.has_sell = false;
+    A.sell_dcode.release();      // (codes of the smoother's diagonal belong to the operator they were made for: build_dinv_codes)
+    A.sell_dsrc = nullptr;
     if (A.nrows == 0) return;
     A.nslices = div_up(A.nrows, 64);
     DBuf<int> w64((size_t)A.nslices);
@@ -1468,6 +1473,7 @@ static void launch_spmv(hipStream_t s, const DCsr &A, RowRange rr, const double 
     SA_REQUIRE(row0 % 64 == 0 && row0 + nrows <= A.nrows, "bad row range");
     y += row0;
     if (b) b += row0;
+    const unsigned char *dcode = (dinv && A.sell_dcode.n == (size_t)A.nrows && dinv == A.sell_dsrc) ? A.sell_dcode.p + row0 : nullptr;
     if (dinv) dinv += row0;
     const double *xrow = x + row0;
     // (y += A x with irregular rows: the wave kernel's result for them would be added before the fix kernel adds the right
@@ -1512,7 +1518,7 @@ static void launch_spmv(hipStream_t s, const DCsr &A, RowRange rr, const double 
         if (A.sell_wq > 0)
             hipLaunchKernelGGL((sell_staged2_kernel<MODE>), dim3(no_xcd ? nblocks : per_xcd * 8), dim3(256), lds_bytes, s, nrows, row0,
                                nblocks, per_xcd, A.sell_stage_cap, A.ncols, A.sell_wq, A.sell_codeR.p, A.sell_tab.p, A.sell_vtab.p,
-                               A.sell_tile_desc.p, A.sell_tile_seg.p, x, y, b, dinv, scale, xrow);
+                               A.sell_tile_desc.p, A.sell_tile_seg.p, x, y, b, dinv, scale, xrow, dcode, (const double *)A.sell_dtab.p);
         else
         hipLaunchKernelGGL((sell_staged_kernel<MODE>), dim3(no_xcd ? nblocks : per_xcd * 8), dim3(256), lds_bytes, s, nrows, row0,
                            nblocks, per_xcd, A.sell_stage_cap, A.ncols, (int)A.sell_one_table, A.sell_ptr.p + row0 / 64, A.sell_ntab.p, A.sell_tab.p,
@@ -1588,8 +1594,10 @@ void smooth_step(hipStream_t s, const DCsr &A, const double *dinv_neg, const dou
                  const double *xin, double *xout, double scale, RowRange rr) {
     profiler().begin(s);
     launch_spmv<MODE_SMOOTH>(s, A, rr, xin, xout, b, dinv_neg, scale);
+    // (b, and D^-1 as it is read: 8 bytes per row, or its byte code where the operator carries one -- build_dinv_codes)
+    const bool coded_d = A.sell_dcode.n == (size_t)A.nrows && dinv_neg == A.sell_dsrc && A.sell_wq > 0 && A.sell_stage_cap > 0;
     profiler().end(s, spmv_label("smooth_step", A).c_str(), spmv_bytes(A, rr) + 24.0 * spmv_rows(A, rr), spmv_flops(A, rr),
-                   spmv_fmt_bytes(A, rr) + (A.has_sell ? 16.0 * spmv_rows(A, rr) : 0.0));
+                   spmv_fmt_bytes(A, rr) + (A.has_sell ? (coded_d ? 9.0 : 16.0) * spmv_rows(A, rr) : 0.0));
 }
 
 __global__ __launch_bounds__(256) void smooth_first_kernel(int n, const double *__restrict__ dinv,
@@ -1651,6 +1659,58 @@ void build_dinv_neg(hipStream_t s, const DCsr &A, double *sd, double *out) {
     hipLaunchKernelGGL((dinv_neg_kernel<8>), dim3(grid), dim3(256), 0, s, A.nrows, A.rowptr.p,
                        A.col.p, A.val.p, sd, out);
     SA_HIP_CHECK(hipGetLastError());
+}
+
+// The smoother's diagonal factor as byte codes (DCsr::sell_dcode): every value goes into an open-addressing table of 256
+// slots (key = its bits); more than 256 distinct values (variable coefficients) -- no codes.  The code of a row is the
+// slot of its value, the table is read as doubles.
+constexpr unsigned long long DINV_EMPTY = 0x7FF8DEADBEEF0001ull;      // (a NaN payload no diagonal produces)
+__device__ inline unsigned dinv_slot0(unsigned long long bits) {
+    bits ^= bits >> 33; bits *= 0xFF51AFD7ED558CCDull; bits ^= bits >> 29;
+    return (unsigned)bits & 255u;
+}
+__global__ __launch_bounds__(256) void dinv_tab_kernel(int n, const double *__restrict__ dinv, unsigned long long *__restrict__ tab,
+                                                       int *__restrict__ overflow) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || *overflow) return;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(dinv[i]);
+    unsigned h = dinv_slot0(bits);
+    for (int probe = 0; probe < 256; ++probe, h = (h + 1) & 255u) {
+        unsigned long long cur = tab[h];
+        if (cur == bits) return;
+        if (cur == DINV_EMPTY) {
+            cur = atomicCAS(tab + h, DINV_EMPTY, bits);
+            if (cur == DINV_EMPTY || cur == bits) return;
+        }
+    }
+    *overflow = 1;
+}
+__global__ __launch_bounds__(256) void dinv_code_kernel(int n, const double *__restrict__ dinv, const unsigned long long *__restrict__ tab,
+                                                        unsigned char *__restrict__ code) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(dinv[i]);
+    unsigned h = dinv_slot0(bits);
+    for (int probe = 0; probe < 256 && tab[h] != bits; ++probe) h = (h + 1) & 255u;
+    code[i] = (unsigned char)h;
+}
+void build_dinv_codes(hipStream_t s, DCsr &A, const double *dinv) {
+    A.sell_dcode.release();
+    A.sell_dsrc = nullptr;
+    if (!A.nrows || !A.has_sell || A.sell_wq <= 0) return;      // (only the staged kernel of the coded formats reads them)
+    A.sell_dtab.alloc(256);
+    std::vector<unsigned long long> empty(256, DINV_EMPTY);
+    SA_HIP_CHECK(hipMemcpyAsync(A.sell_dtab.p, empty.data(), 256 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+    DBuf<int> overflow(1);
+    overflow.zero(s);
+    SA_HIP_CHECK(hipStreamSynchronize(s));      // (empty is a local)
+    hipLaunchKernelGGL(dinv_tab_kernel, dim3(div_up(A.nrows, 256)), dim3(256), 0, s, A.nrows, dinv, A.sell_dtab.p, overflow.p);
+    SA_HIP_CHECK(hipGetLastError());
+    if (overflow.to_host(s)[0]) return;
+    A.sell_dcode.alloc((size_t)A.nrows);
+    hipLaunchKernelGGL(dinv_code_kernel, dim3(div_up(A.nrows, 256)), dim3(256), 0, s, A.nrows, dinv, A.sell_dtab.p, A.sell_dcode.p);
+    SA_HIP_CHECK(hipGetLastError());
+    A.sell_dsrc = dinv;
 }
 
 // ---- deterministic dot product -----------------------------------------------------------
