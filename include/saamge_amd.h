@@ -54,7 +54,8 @@ typedef struct saamge_amd_options {
                                    * beside the interior rows, bit 2 Galerkin product beside the next level's eigenproblems,
                                    * bit 3 the fine operator's SELL copy and smoother diagonal beside the AE tables */
     int sell;                     /* 31: SELL slice formats: bit 0 coded slices at all, bit 1 pair coding (values in the table),
-                                   * bit 2 the short-chain kernel path, bit 3 operator-level dictionary, bit 4 3 x 3 node blocks */
+                                   * bit 2 the short-chain kernel path, bit 3 operator-level dictionary, bit 4 3 x 3 node blocks,
+                                   * bit 5 (off) the smoother's diagonal as byte codes where the rows of the operator repeat */
     int spmv_sell;                /* 0.  1: saamge_amd_spmv / spmv64 build and use the SELL copy (tests of the SELL kernels) */
     int debug;                    /* 0: bit 0 iteration traces of the few-eigenpairs path, bit 1 operator format census on stderr,
                                    * bit 2 level tags in the kernel profile */

@@ -100,7 +100,7 @@ struct Options {
     int eig_dedupe = 1;               // bitwise identical agglomerate matrices of a batch are solved once
     int eig_outer_panels = 8;         // 16-column panels per outer block of the wide-band factorisations (2: the right-looking two-panel walk)
     int overlap = 15;                 // bit 0 subspace iteration beside the next chunk, 1 halo exchange beside the interior rows, 2 Galerkin product beside the next level, 3 fine operator data beside the AE tables
-    int sell = 31;                    // bit 0 coded slices at all, 1 pair coding, 2 short-chain kernel path, 3 operator-level dictionary, 4 node blocks
+    int sell = 31;                    // bit 0 coded slices at all, 1 pair coding, 2 short-chain kernel path, 3 operator-level dictionary, 4 node blocks, 5 (off) coded smoother diagonal
     int spmv_sell = 0;                // saamge_amd_spmv / spmv64 build and use the SELL copy
     int debug = 0;                    // bit 0 iteration traces of the few-eigenpairs path, 1 operator format census, 2 level tags in the kernel profile
 };

@@ -1697,7 +1697,10 @@ __global__ __launch_bounds__(256) void dinv_code_kernel(int n, const double *__r
 void build_dinv_codes(hipStream_t s, DCsr &A, const double *dinv) {
     A.sell_dcode.release();
     A.sell_dsrc = nullptr;
-    if (!A.nrows || !A.has_sell || A.sell_wq <= 0) return;      // (only the staged kernel of the coded formats reads them)
+    // (only the staged kernel of the coded formats reads them.  options().sell bit 5, off by default: measured on the 256^3
+    // problem, 960 instead of 1 079 MB per application (PMC: 967 / 1 086) and 205.1 instead of 210.5 us -- the kernel is not
+    // bound by its bytes alone, 2.3 % for 11 % of them)
+    if (!A.nrows || !A.has_sell || A.sell_wq <= 0 || !(options().sell & 32)) return;
     A.sell_dtab.alloc(256);
     std::vector<unsigned long long> empty(256, DINV_EMPTY);
     SA_HIP_CHECK(hipMemcpyAsync(A.sell_dtab.p, empty.data(), 256 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
