@@ -49,6 +49,7 @@ void ae_rows_new_build();
 // every matrix of the batch was built).
 struct AeClasses {
     bool early = false;     // the classes below were found on the sparse rows and only cls.reps were built
+    bool searched = false;  // the sparse rows were searched (early = false then: too few identical agglomerates to bother)
     DdSource src;           // ... where those rows are (valid until the next ae_build)
     DdClasses cls;
 };

@@ -1025,6 +1025,7 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
         src.kind = 0;
         src.ns = batch.n.p; src.voff = batch.voff.p; src.moff = batch.moff.p;
         src.perm = pm; src.rvals = rv; src.rcols = rc; src.RW = RW;
+        classes->searched = true;
         classes->early = eig_dedupe_find(s, src, batch.count, batch.max_n, classes->cls);
         if (classes->early) {
             only.from_host(classes->cls.reps, s);

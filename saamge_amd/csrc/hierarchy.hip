@@ -356,6 +356,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     std::vector<int> cls_of[2];              // per slot: class of every agglomerate of the chunk (empty: no classes)
     std::vector<int> solve_cls[2];           // per slot: classes of the matrices of the batch that is solved, in its order
     const bool dedupe = options().eig_dedupe != 0 && !(P.testmesh && lev == 0);
+    bool dedupe_level = true;
     int pend_ae0[2] = {0, 0}, pend_cnt[2] = {0, 0};
     int64_t pend_row0[2] = {0, 0};
     // The subspace iteration of a chunk (a few hundred to a few thousand small matrices still active: launches that
@@ -588,18 +589,20 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
         AeClasses classes;
         ae_build(qa, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch, true,
                  P.keep_debug ? L.ae_D.p + row0 : nullptr, keep_rows ? &span : nullptr,
-                 dedupe && !batch.dense_only ? &classes : nullptr);
+                 dedupe && dedupe_level && !batch.dense_only ? &classes : nullptr);
         const int64_t rows_chunk = batch.h_voff[cnt];
         cls_of[slot].clear();
         solve_cls[slot].clear();
-        if (dedupe && !batch.dense_only) {
+        if (dedupe && dedupe_level && !batch.dense_only) {
             // classes within the chunk: known before its matrices were built (the fused fine-level assembly) or found on them
             DdSource src = classes.src;
             bool found = classes.early;
-            if (!found && batch.has_bw) {
+            if (!found && !classes.searched && batch.has_bw) {      // (distinct sparse rows: distinct matrices)
                 src = eig_dedupe_source(batch);
                 found = eig_dedupe_find(qa, src, cnt, batch.max_n, classes.cls);
             }
+            // a level whose first chunk has (almost) no identical agglomerates is not searched further: variable coefficients
+            if (!found && lvl_classes.empty()) dedupe_level = false;
             if (found) {
                 const DdClasses &cl = classes.cls;
                 const int nl = (int)cl.reps.size();
