@@ -26,11 +26,12 @@ struct DevElmats {
 // `banded` (few large agglomerates in permuted order, coarse levels): the half bandwidths come from the topology
 // (batch.bw, has_bw) and only the band the eigensolver reads is cleared
 void ae_assemble(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevElmats &el,
-                 int ae0, EigBatch &batch, bool banded = false);
+                 int ae0, EigBatch &batch, bool banded = false, const int *ae_ids = nullptr);
 
 // D_ii = sum_j |a_ij| sqrt(a_ii/a_jj)  (amg/src/mbox.cpp:913-949);  batch.dis = D^-1/2 and
 // W <- D^-1/2 W D^-1/2 in place.  Dout (optional, packed like batch.d) receives D.
-void ae_scale(hipStream_t s, EigBatch &batch, double *Dout);
+// split: -1 = chosen by the batch's shape (few large agglomerates: row sums and scaling spread over several kernels), 0 / 1 forced
+void ae_scale(hipStream_t s, EigBatch &batch, double *Dout, int split = -1);
 
 // longest row of a CSR operator (one small kernel + a read-back; callers cache it in A.max_row)
 int csr_max_row(hipStream_t s, const DCsr &A);

@@ -19,8 +19,10 @@ __global__ __launch_bounds__(ASM_NT) void ae_assemble_kernel(
     const int *__restrict__ e2d_J, const int *__restrict__ elem_ldof,
     const int64_t *__restrict__ eloff, const double *__restrict__ elval, int has_A,
     const roff_t *__restrict__ Arow, const int *__restrict__ Acol, const double *__restrict__ Aval,
-    const int64_t *__restrict__ voff, const short *__restrict__ perm, int do_zero) {
-    const int b = blockIdx.x, p = ae0 + b, n = ns[b];
+    const int64_t *__restrict__ voff, const short *__restrict__ perm, int do_zero, const int *__restrict__ ae_ids = nullptr) {
+    // (ae_ids: the agglomerate behind matrix b of the batch when the batch is not a contiguous range -- the representatives
+    // of the classes of identical agglomerates)
+    const int b = blockIdx.x, p = ae_ids ? ae_ids[b] : ae0 + b, n = ns[b];
     double *Wm = W + moff[b];
     const int tid = threadIdx.x;
     const size_t nn = (size_t)n * n;
@@ -84,11 +86,11 @@ __global__ __launch_bounds__(ASM_NT) void ae_band_topo_kernel(
     const int *__restrict__ ae2d_I, const int *__restrict__ ae2d_J, const int *__restrict__ d2e_I,
     const int *__restrict__ d2e_J, const int *__restrict__ part, const int *__restrict__ e2d_I,
     const int *__restrict__ e2d_J, const int *__restrict__ elem_ldof, const int64_t *__restrict__ eloff,
-    const double *__restrict__ elval, int *__restrict__ bws) {
+    const double *__restrict__ elval, int *__restrict__ bws, const int *__restrict__ ae_ids = nullptr) {
     // (exact zeros of the element matrices do not count: dofs on opposite faces of a coarse element share the
     // element but no entry -- the band of the numbers is half the band of the lists)
     __shared__ int wmax[ASM_NT / 64];
-    const int b = blockIdx.x, p = ae0 + b, n = ns[b], tid = threadIdx.x;
+    const int b = blockIdx.x, p = ae_ids ? ae_ids[b] : ae0 + b, n = ns[b], tid = threadIdx.x;
     const int *aedofs = ae2d_J + ae2d_I[p];
     const short *pm = perm + voff[b];
     int bw = 0;
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void ae_zero_band_kernel(const int *__restrict
 }
 
 void ae_assemble(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevElmats &el,
-                 int ae0, EigBatch &batch, bool banded) {
+                 int ae0, EigBatch &batch, bool banded, const int *ae_ids) {
     if (!batch.count) return;
     double bytes = 0.0;
     for (int n : batch.h_n) bytes += 8.0 * (double)n * n;
@@ -137,7 +139,7 @@ void ae_assemble(hipStream_t s, const DevRelations &rel, const DCsr *A, const De
         const int ny_t = std::max(1, std::min(div_up(batch.max_n, ASM_NT), 4096 / std::max(1, batch.count)));
         hipLaunchKernelGGL(ae_band_topo_kernel, dim3(batch.count, ny_t), dim3(ASM_NT), 0, s, ae0, batch.n.p, batch.voff.p,
                            batch.perm.p, rel.ae2d_I.p, rel.ae2d_J.p, rel.d2e_I.p, rel.d2e_J.p, rel.part.p, rel.e2d_I.p,
-                           rel.e2d_J.p, rel.elem_ldof.p, el.off.p, el.val.p, batch.bw.p);
+                           rel.e2d_J.p, rel.elem_ldof.p, el.off.p, el.val.p, batch.bw.p, ae_ids);
         const int ny = std::max(1, std::min(256, 65536 / std::max(1, batch.count)));
         hipLaunchKernelGGL(ae_zero_band_kernel, dim3(batch.count, ny), dim3(256), 0, s, batch.n.p, batch.moff.p, batch.W.p,
                            batch.bw.p);
@@ -152,7 +154,7 @@ void ae_assemble(hipStream_t s, const DevRelations &rel, const DCsr *A, const De
                        rel.d2ae_J.p, rel.dof_id_inAE.p, rel.flags.p, rel.d2e_I.p, rel.d2e_J.p,
                        rel.part.p, rel.e2d_I.p, rel.e2d_J.p, rel.elem_ldof.p, el.off.p, el.val.p,
                        A ? 1 : 0, A ? A->rowptr.p : nullptr, A ? A->col.p : nullptr,
-                       A ? A->val.p : nullptr, batch.voff.p, batch.has_perm ? batch.perm.p : nullptr, 0);
+                       A ? A->val.p : nullptr, batch.voff.p, batch.has_perm ? batch.perm.p : nullptr, 0, ae_ids);
     SA_HIP_CHECK(hipGetLastError());
     profiler().end(s, "ae_assemble", bytes, 0.0);
 }
@@ -272,11 +274,11 @@ __global__ __launch_bounds__(256) void ae_apply_scale_kernel(const int *__restri
     for (int r = lo + threadIdx.x; r < hi; r += 256) col[r] = d[ip ? ip[r] : r] * col[r] * dj;
 }
 
-void ae_scale(hipStream_t s, EigBatch &batch, double *Dout) {
+void ae_scale(hipStream_t s, EigBatch &batch, double *Dout, int split) {
     if (!batch.count) return;
     double bytes = 0.0;
     for (int n : batch.h_n) bytes += 24.0 * (double)n * n;
-    if (batch.count <= 2048 && batch.max_n >= 1024) {
+    if (split < 0 ? (batch.count <= 2048 && batch.max_n >= 1024) : split != 0) {
         profiler().begin(s);
         const short *ip = batch.has_perm ? batch.iperm.p : nullptr;
         const int *bws = batch.has_bw ? batch.bw.p : nullptr;      // (band-limited assembly: ae_assemble)
@@ -948,6 +950,216 @@ __global__ __launch_bounds__(256) void ae_perm_kernel(int ae0, const int *__rest
     }
 }
 
+// The same for the GENERIC assembly (ae_assemble_kernel + the scaling: coarse levels, elements that are not 8-dof hexes): the
+// matrix, its scaling and its band are functions of what that kernel reads -- per row of the agglomerate (in agglomerate
+// order): its position in the matrix, its flag, the coarse start vector; per entry of its row of the global matrix whose column
+// lies in the agglomerate: the column's local number, its flag, the value; per element of the row's dof inside the agglomerate:
+// the dof's slot in the element, and per dof of the element its local number, its flag, the entry of the element matrix.
+// ai_row_walk visits exactly those words for one row, a wavefront per row; asm_hash_kernel sums mixed (word, position, row) triples
+// into a 128-bit hash per agglomerate, asm_verify_kernel walks an agglomerate and the first member of its class in lockstep and
+// compares them position by position.
+struct AeInputs {
+    const int *ns;
+    const int64_t *voff;
+    const short *perm;          // or null
+    const double *x0c;          // or null
+    const int *ae2d_I, *ae2d_J, *d2ae_I, *d2ae_J, *dof_id_inAE;
+    const signed char *flags;
+    const int *d2e_I, *d2e_J, *part, *e2d_I, *e2d_J, *elem_ldof;
+    const int64_t *eloff;
+    const double *elval;
+    int has_A;
+    const roff_t *Arow;
+    const int *Acol;
+    const double *Aval;
+    int ae0;
+};
+// local number of a global dof in an agglomerate, or -1: an LDS hash table of the agglomerate's dofs (open addressing, hsize a
+// power of two >= 2 n; the list search through dof -> AE of the assembly kernel costs six dependent global loads per entry of a
+// 375-entry row)
+struct AiTable {
+    int *key;
+    short *val;
+    unsigned mask;
+    __device__ inline void build(const AeInputs &v, int p, int n, int tid, int nt) {
+        for (int i = tid; i <= (int)mask; i += nt) key[i] = -1;
+        __syncthreads();
+        const int *dofs = v.ae2d_J + v.ae2d_I[p];
+        for (int i = tid; i < n; i += nt) {
+            const int g = dofs[i];
+            unsigned h = ((unsigned)g * 2654435761u) & mask;
+            while (atomicCAS(&key[h], -1, g) != -1) h = (h + 1) & mask;
+            val[h] = (short)i;
+        }
+        __syncthreads();
+    }
+    __device__ inline int operator()(int c) const {
+        unsigned h = ((unsigned)c * 2654435761u) & mask;
+        for (;;) {
+            const int k = key[h];
+            if (k == c) return val[h];
+            if (k == -1) return -1;
+            h = (h + 1) & mask;
+        }
+    }
+};
+// The words of row lr0 of agglomerate p (matrix b), visited by a WAVEFRONT: lanes take the entries of the row of the global
+// matrix, then, element by element of the row's dof, the dofs of the element (coalesced reads of the element-matrix row).
+// F(word, position): every word carries a position that does not depend on the lane that visits it (entry index in the row of
+// A / element ordinal and dof slot), so sums over (word, position) are order-independent and two agglomerates can be compared
+// position by position.  `other` (verification): the same walk over a second agglomerate in lockstep; returns false at the
+// first difference.
+__device__ inline unsigned long long ai_mix(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+struct AiRow {      // what identifies one side of a walk
+    int b, p;
+    const AiTable *loc;
+};
+template <bool PAIR, class F>
+__device__ inline bool ai_row_walk(const AeInputs &v, const AiRow &x, const AiRow &y, int lr0, int lane, F &&f) {
+    const int gx = v.ae2d_J[v.ae2d_I[x.p] + lr0], gy = PAIR ? v.ae2d_J[v.ae2d_I[y.p] + lr0] : 0;
+    bool ok = true;
+    if (lane == 0) {
+        const int64_t vx = v.voff[x.b];
+        const unsigned long long w0 = (unsigned long long)(unsigned short)(v.perm ? v.perm[vx + lr0] : (short)lr0);
+        const unsigned long long w1 = v.x0c ? (unsigned long long)__double_as_longlong(v.x0c[vx + lr0]) : 0ull;
+        const unsigned long long w2 = v.has_A ? (unsigned long long)(unsigned char)v.flags[gx] : 0ull;
+        if (PAIR) {
+            const int64_t vy = v.voff[y.b];
+            ok = w0 == (unsigned long long)(unsigned short)(v.perm ? v.perm[vy + lr0] : (short)lr0) &&
+                 w1 == (v.x0c ? (unsigned long long)__double_as_longlong(v.x0c[vy + lr0]) : 0ull) &&
+                 w2 == (v.has_A ? (unsigned long long)(unsigned char)v.flags[gy] : 0ull);
+        } else {
+            f(w0, 1ull); f(w1, 2ull); f(w2, 3ull);
+        }
+    }
+    if (v.has_A) {
+        const roff_t ax = v.Arow[gx], nx = v.Arow[gx + 1] - ax;
+        const roff_t ay = PAIR ? v.Arow[gy] : 0, ny = PAIR ? v.Arow[gy + 1] - ay : 0;
+        if (PAIR && nx != ny) return false;
+        for (roff_t k = lane; k < nx; k += 64) {
+            const int c = v.Acol[ax + k];
+            const int lc = (*x.loc)(c);
+            // (an entry whose column is outside the agglomerate is skipped by the assembly: only its being outside counts)
+            const unsigned long long w = lc < 0 ? ~0ull : (((unsigned long long)(unsigned)lc << 8) | (unsigned long long)(unsigned char)v.flags[c] | (c == gx ? 1ull << 40 : 0ull));
+            const unsigned long long a = lc < 0 ? 0ull : (unsigned long long)__double_as_longlong(v.Aval[ax + k]);
+            if (PAIR) {
+                const int c2 = v.Acol[ay + k];
+                const int l2 = (*y.loc)(c2);
+                const unsigned long long w2 = l2 < 0 ? ~0ull : (((unsigned long long)(unsigned)l2 << 8) | (unsigned long long)(unsigned char)v.flags[c2] | (c2 == gy ? 1ull << 40 : 0ull));
+                const unsigned long long a2 = l2 < 0 ? 0ull : (unsigned long long)__double_as_longlong(v.Aval[ay + k]);
+                ok = ok && w == w2 && a == a2;
+            } else {
+                f(w, (1ull << 40) + 2 * (unsigned long long)k);
+                f(a, (1ull << 40) + 2 * (unsigned long long)k + 1);
+            }
+        }
+    }
+    const int qx = v.d2e_I[gx], cx = v.d2e_I[gx + 1] - qx;
+    const int qy = PAIR ? v.d2e_I[gy] : 0;
+    if (PAIR && cx != v.d2e_I[gy + 1] - qy) return false;
+    for (int q = 0; q < cx; ++q) {      // (wave-uniform)
+        const int e = v.d2e_J[qx + q];
+        const bool in = v.part[e] == x.p;
+        int e2 = 0;
+        if (PAIR) {
+            e2 = v.d2e_J[qy + q];
+            if (in != (v.part[e2] == y.p)) return false;
+        }
+        if (!in) continue;
+        const int eb = v.e2d_I[e], nd = v.e2d_I[e + 1] - eb;
+        const int eb2 = PAIR ? v.e2d_I[e2] : 0;
+        if (PAIR && nd != v.e2d_I[e2 + 1] - eb2) return false;
+        // the dof's slot in the element: found by the lanes
+        int kk = nd, kk2 = nd;
+        for (int j0 = 0; j0 < nd && kk == nd; j0 += 64) {
+            const unsigned long long m = __ballot(j0 + lane < nd && v.e2d_J[eb + j0 + lane] == gx);
+            if (m) kk = j0 + __builtin_ctzll(m);
+        }
+        if (PAIR) {
+            for (int j0 = 0; j0 < nd && kk2 == nd; j0 += 64) {
+                const unsigned long long m = __ballot(j0 + lane < nd && v.e2d_J[eb2 + j0 + lane] == gy);
+                if (m) kk2 = j0 + __builtin_ctzll(m);
+            }
+            if (kk != kk2) return false;
+        } else if (lane == 0) {
+            f(((unsigned long long)(unsigned)nd << 32) | (unsigned)kk, (2ull << 40) + ((unsigned long long)q << 20));
+        }
+        const double *M = v.elval + v.eloff[e] + (size_t)kk * nd;
+        const double *M2 = PAIR ? v.elval + v.eloff[e2] + (size_t)kk * nd : nullptr;
+        for (int jj = lane; jj < nd; jj += 64) {
+            const int d = v.e2d_J[eb + jj];
+            const unsigned long long w = ((unsigned long long)(unsigned)v.elem_ldof[eb + jj] << 8) |
+                                         (v.has_A ? (unsigned long long)(unsigned char)v.flags[d] | (d == gx ? 1ull << 40 : 0ull) : 0ull);
+            const unsigned long long a = (unsigned long long)__double_as_longlong(M[jj]);
+            if (PAIR) {
+                const int d2 = v.e2d_J[eb2 + jj];
+                const unsigned long long w2 = ((unsigned long long)(unsigned)v.elem_ldof[eb2 + jj] << 8) |
+                                              (v.has_A ? (unsigned long long)(unsigned char)v.flags[d2] | (d2 == gy ? 1ull << 40 : 0ull) : 0ull);
+                ok = ok && w == w2 && a == (unsigned long long)__double_as_longlong(M2[jj]);
+            } else {
+                const unsigned long long pos = (3ull << 40) + ((unsigned long long)q << 20) + 2 * (unsigned long long)jj;
+                f(w, pos);
+                f(a, pos + 1);
+            }
+        }
+    }
+    return ok;
+}
+constexpr int AI_NT = 256;
+__global__ __launch_bounds__(AI_NT) void asm_hash_kernel(AeInputs v, int hsize, unsigned long long *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char ai_lds[];
+    __shared__ unsigned long long red[2][AI_NT / 64];
+    const int b = blockIdx.x, p = v.ae0 + b, n = v.ns[b], tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    AiTable loc{(int *)ai_lds, (short *)(ai_lds + 4 * (size_t)hsize), (unsigned)(hsize - 1)};
+    if (v.has_A) loc.build(v, p, n, tid, AI_NT);
+    const AiRow x{b, p, &loc};
+    unsigned long long h1 = 0, h2 = 0;
+    for (int lr0 = blockIdx.y * (AI_NT / 64) + wv; lr0 < n; lr0 += (AI_NT / 64) * gridDim.y) {
+        const unsigned long long rowtag = (unsigned long long)(lr0 + 1) * 0xC2B2AE3D27D4EB4Full;
+        ai_row_walk<false>(v, x, x, lr0, lane, [&](unsigned long long w, unsigned long long pos) {
+            const unsigned long long k = ai_mix(w + 0x9E3779B97F4A7C15ull * (pos + 1) + rowtag);
+            h1 += k;
+            h2 += ai_mix(k ^ 0xD6E8FEB86659FD93ull);
+        });
+    }
+    if (tid == 0 && blockIdx.y == 0) { h1 += ai_mix((unsigned long long)n + 0x4444444444444444ull); h2 += ai_mix((unsigned long long)n ^ 0x7777777777777777ull); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64); }
+    if (lane == 0) { red[0][wv] = h1; red[1][wv] = h2; }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long s1 = 0, s2 = 0;
+        for (int q = 0; q < AI_NT / 64; ++q) { s1 += red[0][q]; s2 += red[1][q]; }
+        atomicAdd(out + 2 * (size_t)b, s1);
+        atomicAdd(out + 2 * (size_t)b + 1, s2);
+    }
+}
+__global__ void scatter_int_kernel(int n, const int *__restrict__ idx, const int *__restrict__ src, int *__restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[idx[i]] = src[i];
+}
+__global__ __launch_bounds__(AI_NT) void asm_verify_kernel(AeInputs v, int hsize, const int *__restrict__ rep, int *__restrict__ differ) {
+    extern __shared__ __align__(16) unsigned char ai_lds[];
+    const int b = blockIdx.x, r0 = rep[b], tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (r0 == b) return;
+    const int n = v.ns[b];
+    if (n != v.ns[r0]) { if (tid == 0) differ[b] = 1; return; }
+    const size_t tb = 6 * (size_t)hsize;      // bytes of one table (keys + values), a multiple of 8
+    AiTable locb{(int *)ai_lds, (short *)(ai_lds + 4 * (size_t)hsize), (unsigned)(hsize - 1)};
+    AiTable locr{(int *)(ai_lds + tb), (short *)(ai_lds + tb + 4 * (size_t)hsize), (unsigned)(hsize - 1)};
+    if (v.has_A) { locb.build(v, v.ae0 + b, n, tid, AI_NT); locr.build(v, v.ae0 + r0, n, tid, AI_NT); }
+    const AiRow x{b, v.ae0 + b, &locb}, y{r0, v.ae0 + r0, &locr};
+    bool ok = true;
+    for (int lr0 = blockIdx.y * (AI_NT / 64) + wv; lr0 < n; lr0 += (AI_NT / 64) * gridDim.y)
+        ok = ai_row_walk<true>(v, x, y, lr0, lane, [](unsigned long long, unsigned long long) {}) && ok;
+    if (!ok) differ[b] = 1;
+}
+
 // Classes of identical agglomerates BEFORE their matrices are built (eig.hip, "Duplicate agglomerate matrices"): the fused
 // kernel below makes the scaled matrix, its scaling and its band from the agglomerate's sparse rows (RW slots of column +
 // value per row) and its row order alone, so agglomerates whose rows and order agree bit for bit get identical matrices --
@@ -997,6 +1209,79 @@ void ae_build(hipStream_t s, const DevRelations &rel, const DCsr *A, const DevEl
         // kernel's LDS: an entry copied from A couples two dofs of an element of this agglomerate, so the band of the
         // element matrices holds it)
         const bool banded = band_asm && batch.has_perm && split_scale && scale && eig_ss_band_enabled();
+        // classes of identical agglomerates on the INPUTS of the assembly (AeInputs above): only their first members are assembled
+        // and scaled -- as the batch of the representatives over the same workspace, through the same kernels the whole batch
+        // would take (the choice between the one-kernel and the spread scaling is the whole batch's)
+        if (classes && scale && banded && !Dout && batch.count >= 16) {
+            classes->searched = true;
+            AeInputs v{batch.n.p, batch.voff.p, batch.has_perm ? batch.perm.p : nullptr, batch.has_x0c ? batch.x0c.p : nullptr,
+                       rel.ae2d_I.p, rel.ae2d_J.p, rel.d2ae_I.p, rel.d2ae_J.p, rel.dof_id_inAE.p, rel.flags.p, rel.d2e_I.p, rel.d2e_J.p,
+                       rel.part.p, rel.e2d_I.p, rel.e2d_J.p, rel.elem_ldof.p, el.off.p, el.val.p, A ? 1 : 0,
+                       A ? A->rowptr.p : nullptr, A ? A->col.p : nullptr, A ? A->val.p : nullptr, ae0};
+            profiler().begin(s);
+            const int ny = std::max(1, std::min(div_up(batch.max_n, 256), 4096 / std::max(1, batch.count)));
+            DBuf<unsigned long long> hash(2 * (size_t)batch.count);
+            hash.zero(s);
+            int hsize = 64;
+            while (hsize < batch.max_n + batch.max_n / 2) hsize <<= 1;
+            const size_t tbytes = A ? 6 * (size_t)hsize : 0;      // (the tables are needed for the rows of the global matrix only)
+            SA_REQUIRE(2 * tbytes <= 150 * 1024, "agglomerate too large for the class search");
+            static bool attr_ai = false;
+            if (!attr_ai) {
+                SA_HIP_CHECK(hipFuncSetAttribute((const void *)asm_hash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                SA_HIP_CHECK(hipFuncSetAttribute((const void *)asm_verify_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                attr_ai = true;
+            }
+            hipLaunchKernelGGL(asm_hash_kernel, dim3(batch.count, ny), dim3(256), tbytes, s, v, hsize, hash.p);
+            SA_HIP_CHECK(hipGetLastError());
+            auto hh = hash.to_host(s);
+            std::vector<int> rep;
+            const int nuniq = eig_dedupe_group(hh.data(), batch.count, rep);
+            bool found = (long)nuniq * 4 <= (long)batch.count * 3;
+            if (found) {
+                DBuf<int> d_rep, differ((size_t)batch.count);
+                d_rep.from_host(rep, s);
+                differ.zero(s);
+                hipLaunchKernelGGL(asm_verify_kernel, dim3(batch.count, ny), dim3(256), 2 * tbytes, s, v, hsize, d_rep.p, differ.p);
+                SA_HIP_CHECK(hipGetLastError());
+                auto hd = differ.to_host(s);
+                for (int i = 0; i < batch.count; ++i)
+                    if (hd[i]) rep[i] = i;
+            }
+            profiler().end(s, "eig_dedupe", 0.0, 0.0);
+            if (found) {
+                DdClasses &cl = classes->cls;
+                cl.reps.clear();
+                std::vector<int> pos((size_t)batch.count, -1);
+                for (int i = 0; i < batch.count; ++i)
+                    if (rep[i] == i) { pos[i] = (int)cl.reps.size(); cl.reps.push_back(i); }
+                cl.rep_of.resize((size_t)batch.count);
+                for (int i = 0; i < batch.count; ++i) cl.rep_of[i] = pos[rep[i]];
+                if ((options().debug & 1)) std::fprintf(stderr, "duplicate agglomerates (assembly inputs): %d distinct of %d\n", (int)cl.reps.size(), batch.count);
+                EigBatch cb;
+                eig_batch_compact(s, cb, batch, cl.reps);
+                std::vector<int> ids(cl.reps.size());
+                for (size_t q = 0; q < ids.size(); ++q) ids[q] = ae0 + cl.reps[q];
+                DBuf<int> d_ids, d_reps;
+                d_ids.from_host(ids, s);
+                d_reps.from_host(cl.reps, s);
+                ae_assemble(s, rel, A, el, ae0, cb, banded, d_ids.p);
+                ae_scale(s, cb, nullptr, split_scale ? 1 : 0);
+                // the representatives' half bandwidths at their places in the batch; what the matrices consist of from here on --
+                // for the comparison with the classes of other chunks -- is their assembled form (DdSource kind 1)
+                if (batch.bw.n < (size_t)batch.count) batch.bw.alloc((size_t)batch.count);
+                SA_HIP_CHECK(hipMemsetAsync(batch.bw.p, 0, sizeof(int) * (size_t)batch.count, s));
+                hipLaunchKernelGGL(scatter_int_kernel, dim3(div_up(cb.count, 256)), dim3(256), 0, s, cb.count, d_reps.p, cb.bw.p, batch.bw.p);
+                SA_HIP_CHECK(hipGetLastError());
+                batch.has_bw = cb.has_bw;
+                batch.has_perm = cb.has_perm;
+                classes->src = eig_dedupe_source(batch);
+                cl.rep_hash = eig_dedupe_hash_list(s, classes->src, batch.max_n, cl.reps);
+                classes->early = true;
+                SA_HIP_CHECK(hipStreamSynchronize(s));      // (the lists are freed here)
+                return;
+            }
+        }
         ae_assemble(s, rel, A, el, ae0, batch, banded);
         if (scale) ae_scale(s, batch, Dout);
         return;

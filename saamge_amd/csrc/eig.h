@@ -147,6 +147,8 @@ struct DdClasses {
 };
 DdSource eig_dedupe_source(const EigBatch &b);
 bool eig_dedupe_find(hipStream_t s, const DdSource &src, int count, int max_n, DdClasses &out);      // false: fewer than a quarter duplicates
+int eig_dedupe_group(const unsigned long long *hh, int count, std::vector<int> &rep);      // rep[i] = first matrix with i's hash; returns the classes
+std::vector<unsigned long long> eig_dedupe_hash_list(hipStream_t s, const DdSource &src, int max_n, const std::vector<int> &list);
 std::vector<long> eig_dedupe_words(hipStream_t s, const DdSource &src, const std::vector<int> &h_n, const std::vector<int> &list);
 void eig_dedupe_pack(hipStream_t s, const DdSource &src, int max_n, const std::vector<int> &list, const std::vector<long> &words,
                      std::vector<DBuf<unsigned long long>> &blobs);

@@ -981,7 +981,7 @@ void eig_dedupe_expand(hipStream_t s, int count, int max_n, const double *const 
 }
 
 // rep[i] = the first matrix with matrix i's 128-bit hash (hashes: two words per matrix); returns the number of classes
-static int dd_group(const unsigned long long *hh, int count, std::vector<int> &rep) {
+int eig_dedupe_group(const unsigned long long *hh, int count, std::vector<int> &rep) {
     std::unordered_map<DdKey, int, DdKeyHash> first;
     first.reserve((size_t)count / 8 + 16);
     rep.resize((size_t)count);
@@ -1011,7 +1011,7 @@ bool eig_dedupe_find(hipStream_t s, const DdSource &src, int count, int max_n, D
     SA_HIP_CHECK(hipGetLastError());
     auto hh = hash.to_host(s);
     std::vector<int> rep;
-    const int nuniq = dd_group(hh.data(), count, rep);
+    const int nuniq = eig_dedupe_group(hh.data(), count, rep);
     if ((long)nuniq * 4 > (long)count * 3) { profiler().end(s, "eig_dedupe", 0.0, 0.0); return false; }
     DBuf<int> d_rep, differ((size_t)count);
     d_rep.from_host(rep, s);
@@ -1034,6 +1034,39 @@ bool eig_dedupe_find(hipStream_t s, const DdSource &src, int count, int max_n, D
     profiler().end(s, "eig_dedupe", 0.0, 0.0);
     if ((options().debug & 1)) std::fprintf(stderr, "duplicate agglomerates (%s): %d distinct of %d\n", src.kind ? "bands" : "sparse rows", (int)out.reps.size(), count);
     return true;
+}
+// the hashes of SOME matrices of the batch (two words each, in the order of the list)
+__global__ __launch_bounds__(256) void dd_hash_list_kernel(DdSource v, const int *__restrict__ list, unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long red[2][4];
+    const int b = list[blockIdx.x], tid = threadIdx.x;
+    const long cnt = dd_count(v, b);
+    unsigned long long h1 = 0, h2 = 0;
+    for (long idx = (long)blockIdx.y * 256 + tid; idx < cnt; idx += 256l * gridDim.y) {
+        const unsigned long long k = dd_mix(dd_word(v, b, idx) + 0x9E3779B97F4A7C15ull * (unsigned long long)(idx + 1));
+        h1 += k;
+        h2 += dd_mix(k ^ 0xD6E8FEB86659FD93ull);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = h1; red[1][tid >> 6] = h2; }
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(out + 2 * (size_t)blockIdx.x, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(out + 2 * (size_t)blockIdx.x + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+std::vector<unsigned long long> eig_dedupe_hash_list(hipStream_t s, const DdSource &src, int max_n, const std::vector<int> &list) {
+    std::vector<unsigned long long> out(2 * list.size(), 0);
+    if (list.empty()) return out;
+    DBuf<int> d_list;
+    d_list.from_host(list, s);
+    DBuf<unsigned long long> hash(2 * list.size());
+    hash.zero(s);
+    hipLaunchKernelGGL(dd_hash_list_kernel, dim3((unsigned)list.size(), dd_grid_y(src, (int)list.size(), max_n)), dim3(256), 0, s, src, d_list.p, hash.p);
+    SA_HIP_CHECK(hipGetLastError());
+    auto hh = hash.to_host(s);
+    std::copy(hh.begin(), hh.end(), out.begin());
+    return out;
 }
 // the words of some matrices of the batch, kept for comparisons with matrices of later batches
 void eig_dedupe_pack(hipStream_t s, const DdSource &src, int max_n, const std::vector<int> &list, const std::vector<long> &words,

@@ -631,8 +631,32 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
                 const std::vector<long> nwords = eig_dedupe_words(qa, src, batch.h_n, newlist);
                 std::vector<DBuf<unsigned long long>> nblobs;
                 eig_dedupe_pack(qa, src, batch.max_n, newlist, nwords, nblobs);
+                // (local classes found on the INPUTS of the assembly can share their assembled matrix -- agglomerates that differ
+                // in the flags of their surface dofs only: candidates with the hash of an earlier candidate are compared with it)
+                std::vector<int> alias(newq.size(), -1);
+                {
+                    std::unordered_map<DdKey, int, DdKeyHash> firstc;
+                    std::vector<int> clist, cwho;
+                    std::vector<const unsigned long long *> cblobs;
+                    std::vector<long> cwords;
+                    for (size_t t = 0; t < newq.size(); ++t) {
+                        auto it = firstc.emplace(DdKey{cl.rep_hash[2 * (size_t)newq[t]], cl.rep_hash[2 * (size_t)newq[t] + 1]}, (int)t);
+                        if (it.second) continue;
+                        clist.push_back(newlist[t]); cwho.push_back((int)t);
+                        cblobs.push_back(nblobs[it.first->second].p); cwords.push_back(nwords[it.first->second]);
+                    }
+                    std::vector<char> csame;
+                    eig_dedupe_compare(qa, src, batch.max_n, clist, cblobs, cwords, csame);
+                    for (size_t u = 0; u < clist.size(); ++u)
+                        if (csame[u]) alias[cwho[u]] = firstc[DdKey{cl.rep_hash[2 * (size_t)newq[cwho[u]]], cl.rep_hash[2 * (size_t)newq[cwho[u]] + 1]}];
+                }
+                std::vector<int> solve_list;
+                std::vector<int> id_of(newq.size(), -1);
                 for (size_t t = 0; t < newq.size(); ++t) {
+                    if (alias[t] >= 0) { id_of[t] = id_of[alias[t]]; l2g[newq[t]] = id_of[t]; continue; }
+                    solve_list.push_back(newlist[t]);
                     const int id = (int)lvl_classes.size();
+                    id_of[t] = id;
                     lvl_classes.emplace_back();
                     SolvedClass &sc = lvl_classes.back();
                     sc.n = batch.h_n[newlist[t]];
@@ -646,7 +670,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
                 cls_of[slot].resize((size_t)cnt);
                 for (int i = 0; i < cnt; ++i) cls_of[slot][i] = l2g[cl.rep_of[i]];
                 assembled[slot] = std::move(batch);
-                eig_batch_compact(qa, batch, assembled[slot], newlist);
+                eig_batch_compact(qa, batch, assembled[slot], solve_list);
             }
         }
         if (batch.count) eig_tridiagonalize(qa, batch, 1);

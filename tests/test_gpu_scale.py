@@ -190,10 +190,17 @@ def test_identical_agglomerates_solved_once_give_the_bitwise_same_hierarchy():
     def build(dedupe, coef):
         capi.set_options(eig_dedupe=dedupe)
         try:
-            prob = pr.poisson3d_device((64, 64, 32), blk=(8, 8, 4), coarse_blk=[(8, 8, 4)], device="cuda:0", coef=coef)
-            params = capi.default_params(num_coarsenings=2, theta=0.003, nu_relax=3, workspace_bytes=1 << 28)
+            if coef == "q2":      # Q2 elasticity 16^3, 4x4x4-element agglomerates of 2 187 rows: the GENERIC assembly, whose classes
+                # are found on its inputs (element matrices, local numbering, rows of the global matrix), in two chunks
+                prob = pr.elasticity3d_q2_device(16, blk=(4, 4, 4), coarse_blk=[(2, 2, 2)], device="cuda:0")
+                params = capi.default_params(num_coarsenings=2, theta=0.003, nu_relax=3, workspace_bytes=2 << 30)
+                nde = 81
+            else:
+                prob = pr.poisson3d_device((64, 64, 32), blk=(8, 8, 4), coarse_blk=[(8, 8, 4)], device="cuda:0", coef=coef)
+                params = capi.default_params(num_coarsenings=2, theta=0.003, nu_relax=3, workspace_bytes=1 << 28)
+                nde = 8
             h = capi.Hierarchy(prob.rowptr, prob.col, prob.val, prob.n, prob.elem_to_dof, prob.elmat, prob.bdr,
-                               prob.partitions, prob.nparts, params, prob.NE_, 8)
+                               prob.partitions, prob.nparts, params, prob.NE_, nde)
             dig = []
             for l in range(2):
                 for which in ("P", "Ac"):
@@ -218,3 +225,7 @@ def test_identical_agglomerates_solved_once_give_the_bitwise_same_hierarchy():
     gen_on, gen_off = build(1, "skew"), build(0, "skew")
     print("general coefficient: eigenproblems solved", gen_on[1], "of", gen_on[2])
     assert gen_on[0] == gen_off[0] and gen_on[1] == gen_on[2]
+    q2_on, q2_off = build(1, "q2"), build(0, "q2")
+    print("Q2 elasticity: eigenproblems solved", q2_on[1], "of", q2_on[2])
+    assert q2_on[0] == q2_off[0] and q2_on[3] == q2_off[3] and q2_on[4]
+    assert q2_on[1][0] <= 4 and q2_on[2][0] == 64            # (clamped on one face: two classes)
