@@ -66,7 +66,7 @@ bool ae_sparse_rows(hipStream_t s, const DevRelations &rel, const DCsr &A, const
 void coarse_elmats_sparse(hipStream_t s, const DevRelations &rel, int ae0, const EigBatch &batch, int RW,
                           const double *rv, const short *rc, const int *mis_k, const int64_t *mis_u_off,
                           const double *mis_u, const int *colpos_ptr, const int *colpos, const int64_t *out_off,
-                          double *out, double *scratch, const int64_t *scratch_off, int kmax);
+                          double *out, double *scratch, const int64_t *scratch_off, int kmax, const int *ae_class = nullptr);
 
 // Coarse element matrices E_e = P_loc^T A_e P_loc for AEs [ae0, ae0+count)
 // (ElementMatrixParallelCoarse::GetMatrix, amg/src/elmat.cpp:105-195).  batch.W must hold

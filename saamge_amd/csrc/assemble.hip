@@ -1541,14 +1541,16 @@ __global__ __launch_bounds__(ASM_NT) void coarse_elmat_rows_kernel(
     const int *__restrict__ mis2d_I, const int *__restrict__ mis_k,
     const int64_t *__restrict__ mis_u_off, const double *__restrict__ mis_u,
     const int *__restrict__ colpos_ptr, const int *__restrict__ colpos,
-    const int64_t *__restrict__ out_off, double *__restrict__ out, int *__restrict__ flagged) {
+    const int64_t *__restrict__ out_off, double *__restrict__ out, int *__restrict__ flagged,
+    const int *__restrict__ list = nullptr) {
     extern __shared__ __align__(16) unsigned char ce_lds[];
     constexpr int MAXT = 64, MAXKE = 256;
     __shared__ int tk[MAXT], tr[MAXT];
     __shared__ long long tu[MAXT];
     __shared__ unsigned char col_t[MAXKE], col_w[MAXKE];
     __shared__ int bad, wsum[ASM_NT / 64], total_s;
-    const int b = blockIdx.x, e = ae0 + b, n = ns[b];
+    // (list: the agglomerates of the batch to compute -- the first members of its classes of identical inputs)
+    const int b = list ? list[blockIdx.x] : (int)blockIdx.x, e = ae0 + b, n = ns[b];
     double *E = out + out_off[e];
     const int ke = (int)(sqrt((double)(out_off[e + 1] - out_off[e])) + 0.5);
     const int tid = threadIdx.x;
@@ -1716,11 +1718,128 @@ __global__ __launch_bounds__(ASM_NT) void coarse_elmat_rows_kernel(
     }
 }
 
+// Classes of agglomerates with identical coarse element matrices (eig.hip, "Duplicate agglomerate matrices", one stage further
+// down the setup): E_e = P_loc^T A_e P_loc is a function of the agglomerate's sparse rows -- whose class the eigenproblem stage
+// has established, ae_class -- and of its MISes in their order: per MIS the number of basis vectors, the row list in the
+// agglomerate's numbering, the basis itself and the positions of its coarse dofs in the element.  CeIn names those arrays;
+// ce_walk visits the words of one agglomerate (a workgroup per agglomerate, threads over the entries of each MIS) either summing
+// mixed (word, position) pairs (the 128-bit hash) or comparing them with the first member of the class in lockstep.
+struct CeIn {
+    const int *ae_class, *ae2mis_I, *ae2mis_J, *ae_pair;
+    const int64_t *pair_loc_off;
+    const int *pair_loc, *mis2d_I, *mis_k;
+    const int64_t *mis_u_off;
+    const double *mis_u;
+    const int *colpos_ptr, *colpos;
+    const int64_t *out_off;
+    int ae0;
+};
+template <bool PAIR, class F>
+__device__ inline bool ce_walk(const CeIn &v, int e, int e2, int tid, int nt_, F &&f) {
+    const int mb = v.ae2mis_I[e], nm = v.ae2mis_I[e + 1] - mb;
+    const int mb2 = PAIR ? v.ae2mis_I[e2] : 0;
+    if (PAIR && (nm != v.ae2mis_I[e2 + 1] - mb2 || v.ae_class[e] != v.ae_class[e2] ||
+                 v.out_off[e + 1] - v.out_off[e] != v.out_off[e2 + 1] - v.out_off[e2])) return false;
+    bool ok = true;
+    if (!PAIR && tid == 0) { f((unsigned long long)(unsigned)v.ae_class[e], 1ull); f((unsigned long long)nm, 2ull); f((unsigned long long)(v.out_off[e + 1] - v.out_off[e]), 3ull); }
+    for (int t = 0; t < nm; ++t) {      // (workgroup-uniform)
+        const int mis = v.ae2mis_J[mb + t], k = v.mis_k[mis], r = v.mis2d_I[mis + 1] - v.mis2d_I[mis];
+        const int *loc = v.pair_loc + v.pair_loc_off[v.ae_pair[mb + t]];
+        const int *cp = v.colpos + v.colpos_ptr[mb + t];
+        const double *U = v.mis_u + v.mis_u_off[mis];
+        const unsigned long long tag = (unsigned long long)(t + 1) << 40;
+        if (PAIR) {
+            const int mis2 = v.ae2mis_J[mb2 + t];
+            if (k != v.mis_k[mis2] || r != v.mis2d_I[mis2 + 1] - v.mis2d_I[mis2]) return false;
+            const int *loc2 = v.pair_loc + v.pair_loc_off[v.ae_pair[mb2 + t]];
+            const int *cp2 = v.colpos + v.colpos_ptr[mb2 + t];
+            const long long *U1 = (const long long *)U, *U2 = (const long long *)(v.mis_u + v.mis_u_off[mis2]);
+            for (int i = tid; i < k; i += nt_) ok = ok && cp[i] == cp2[i];
+            for (int i = tid; i < r; i += nt_) ok = ok && loc[i] == loc2[i];
+            for (int i = tid; i < r * k; i += nt_) ok = ok && U1[i] == U2[i];
+        } else {
+            if (tid == 0) f(((unsigned long long)(unsigned)k << 32) | (unsigned)r, tag);
+            for (int i = tid; i < k; i += nt_) f((unsigned long long)(unsigned)cp[i], tag + (1ull << 36) + (unsigned long long)i);
+            for (int i = tid; i < r; i += nt_) f((unsigned long long)(unsigned)loc[i], tag + (2ull << 36) + (unsigned long long)i);
+            for (int i = tid; i < r * k; i += nt_) f((unsigned long long)__double_as_longlong(U[i]), tag + (3ull << 36) + (unsigned long long)i);
+        }
+    }
+    return ok;
+}
+__global__ __launch_bounds__(256) void ce_hash_kernel(CeIn v, unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long red[2][4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    unsigned long long h1 = 0, h2 = 0;
+    ce_walk<false>(v, v.ae0 + b, 0, tid, 256, [&](unsigned long long w, unsigned long long pos) {
+        const unsigned long long k = ai_mix(w + 0x9E3779B97F4A7C15ull * (pos + 1));
+        h1 += k;
+        h2 += ai_mix(k ^ 0xD6E8FEB86659FD93ull);
+    });
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = h1; red[1][tid >> 6] = h2; }
+    __syncthreads();
+    if (tid == 0) {
+        out[2 * (size_t)b] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        out[2 * (size_t)b + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+__global__ __launch_bounds__(256) void ce_verify_kernel(CeIn v, const int *__restrict__ rep, int *__restrict__ differ) {
+    const int b = blockIdx.x, r0 = rep[b];
+    if (r0 == b) return;
+    if (!ce_walk<true>(v, v.ae0 + b, v.ae0 + r0, threadIdx.x, 256, [](unsigned long long, unsigned long long) {})) differ[b] = 1;
+}
+// E of every member of a class from the class's first member
+__global__ __launch_bounds__(256) void ce_copy_kernel(int ae0, const int *__restrict__ rep, const int64_t *__restrict__ out_off,
+                                                      double *__restrict__ out) {
+    const int b = blockIdx.x, r0 = rep[b];
+    if (r0 == b) return;
+    const int64_t n = out_off[ae0 + b + 1] - out_off[ae0 + b];
+    const double *src = out + out_off[ae0 + r0];
+    double *dst = out + out_off[ae0 + b];
+    for (int64_t i = blockIdx.y * 256 + threadIdx.x; i < n; i += 256 * (int64_t)gridDim.y) dst[i] = src[i];
+}
+
 void coarse_elmats_sparse(hipStream_t s, const DevRelations &rel, int ae0, const EigBatch &batch, int RW,
                           const double *rv, const short *rc, const int *mis_k, const int64_t *mis_u_off,
                           const double *mis_u, const int *colpos_ptr, const int *colpos, const int64_t *out_off,
-                          double *out, double *scratch, const int64_t *scratch_off, int kmax) {
+                          double *out, double *scratch, const int64_t *scratch_off, int kmax, const int *ae_class) {
     if (!batch.count) return;
+    // classes of identical inputs: only their first members are computed, the others copied (ae_class: the classes of the
+    // agglomerates' sparse rows from the eigenproblem stage, per agglomerate of the level; null: every agglomerate on its own)
+    std::vector<int> rep;
+    DBuf<int> d_rep, d_list;
+    int ncompute = batch.count;
+    if (ae_class && batch.count >= 16) {
+        profiler().begin(s);
+        CeIn v{ae_class, rel.ae2mis_I.p, rel.ae2mis_J.p, rel.ae_pair.p, rel.pair_loc_off.p, rel.pair_loc.p, rel.mis2d_I.p, mis_k,
+               mis_u_off, mis_u, colpos_ptr, colpos, out_off, ae0};
+        DBuf<unsigned long long> hash(2 * (size_t)batch.count);
+        hipLaunchKernelGGL(ce_hash_kernel, dim3(batch.count), dim3(256), 0, s, v, hash.p);
+        SA_HIP_CHECK(hipGetLastError());
+        auto hh = hash.to_host(s);
+        const int nuniq = eig_dedupe_group(hh.data(), batch.count, rep);
+        if ((long)nuniq * 4 <= (long)batch.count * 3) {
+            DBuf<int> differ((size_t)batch.count);
+            d_rep.from_host(rep, s);
+            differ.zero(s);
+            hipLaunchKernelGGL(ce_verify_kernel, dim3(batch.count), dim3(256), 0, s, v, d_rep.p, differ.p);
+            SA_HIP_CHECK(hipGetLastError());
+            auto hd = differ.to_host(s);
+            std::vector<int> list;
+            for (int i = 0; i < batch.count; ++i) {
+                if (hd[i]) rep[i] = i;
+                if (rep[i] == i) list.push_back(i);
+            }
+            d_rep.from_host(rep, s);
+            d_list.from_host(list, s);
+            ncompute = (int)list.size();
+            if (options().debug & 1) std::fprintf(stderr, "coarse element matrices: %d distinct of %d\n", ncompute, batch.count);
+        } else {
+            rep.clear();
+        }
+        profiler().end(s, "eig_dedupe", 0.0, 0.0);
+    }
     profiler().begin(s);
     // the packed rows of T of one agglomerate in LDS: a pool of 6 doubles per row on average (+ keys, column starts, offsets
     // and dof maps: 24 bytes per row); an agglomerate that needs more is redone by the dense-T kernel
@@ -1734,10 +1853,10 @@ void coarse_elmats_sparse(hipStream_t s, const DevRelations &rel, int ae0, const
     if (!old_only && kmax >= 1 && kmax < 256 && lds <= 64 * 1024) {
         flagged.alloc((size_t)batch.count);
         flagged.zero(s);
-        hipLaunchKernelGGL(coarse_elmat_rows_kernel, dim3(batch.count), dim3(ASM_NT), lds, s, ae0, RW, pool_cap, u_cap, batch.n.p,
+        hipLaunchKernelGGL(coarse_elmat_rows_kernel, dim3(ncompute), dim3(ASM_NT), lds, s, ae0, RW, pool_cap, u_cap, batch.n.p,
                            batch.voff.p, rv, rc, rel.ae2mis_I.p, rel.ae2mis_J.p, rel.ae_pair.p, rel.pair_loc_off.p,
                            rel.pair_loc.p, rel.mis2d_I.p, mis_k, mis_u_off, mis_u, colpos_ptr, colpos, out_off, out,
-                           flagged.p);
+                           flagged.p, rep.empty() ? (const int *)nullptr : d_list.p);
         SA_HIP_CHECK(hipGetLastError());
         only = flagged.p;
         profiler().end(s, "coarse_elmats_rows", 0.0, 0.0);
@@ -1748,6 +1867,12 @@ void coarse_elmats_sparse(hipStream_t s, const DevRelations &rel, int ae0, const
                        rel.pair_loc_off.p, rel.pair_loc.p, rel.mis2d_I.p, mis_k, mis_u_off, mis_u, colpos_ptr,
                        colpos, out_off, out, scratch, scratch_off, only);
     SA_HIP_CHECK(hipGetLastError());
+    if (!rep.empty() && only) {      // (classes: the fallback kernel above ran for the flagged first members only)
+        const int ny = std::max(1, std::min(16, 65536 / std::max(1, batch.count)));
+        hipLaunchKernelGGL(ce_copy_kernel, dim3(batch.count, ny), dim3(256), 0, s, ae0, d_rep.p, out_off, out);
+        SA_HIP_CHECK(hipGetLastError());
+        SA_HIP_CHECK(hipStreamSynchronize(s));      // (the lists are freed here)
+    }
     profiler().end(s, "coarse_elmats", 0.0, 0.0);
 }
 

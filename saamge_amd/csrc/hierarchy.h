@@ -81,6 +81,7 @@ struct Level {                  // tg_data_t + interp_data_t + agg_partitioning_
     // interp_data_t
     std::vector<int> ae_begin;          // [world+1] AE ownership ranges of the ranks (eigenproblems, coarse element matrices)
     std::vector<int> ae_m;              // eigenvectors per AE
+    std::vector<int> ae_class;          // per agglomerate: its class of identical SPARSE ROWS (the eigenproblem stage's, fused fine-level assembly), or -1
     long long ae_solved = 0;            // local eigenproblems actually solved on this level by this rank (the others: copies of a class)
     std::vector<int64_t> ae_xoff, ae_eoff;
     DBuf<double> evals, evecs;          // cut_evects_arr (packed)

@@ -299,6 +299,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     for (int p = 0; p < nparts; ++p) sizes[p] = rel.AE_to_dof.row_size(p);
     L.ae_m.assign((size_t)nparts, 0);
     L.ae_solved = 0;
+    L.ae_class.assign((size_t)nparts, -1);
     struct Chunk { int ae0, count; DBuf<double> evals, evecs; std::vector<int64_t> eoff, xoff; DBuf<int64_t> d_eoff, d_xoff; };
     std::vector<Chunk> chunks;
     if (P.keep_debug) L.ae_D.alloc((size_t)rel.AE_to_dof.I[nparts]);
@@ -452,6 +453,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
                 if (some_bad) hbad[i] = batch.h_bad[i];
             } else {
                 const SolvedClass &sc = lvl_classes[co[i]];
+                if (sc.kind == 0) L.ae_class[ae0 + i] = co[i];
                 hm[i] = sc.bad ? 0 : sc.m;
                 hbad[i] = sc.bad ? 1 : 0;
                 some_bad = some_bad || sc.bad;
@@ -1065,6 +1067,7 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
     const int world = H.params.world > 1 ? H.params.world : 1;
     const int ae_lo = world > 1 ? L.ae_begin[H.params.rank] : 0;
     const int ae_hi = world > 1 ? L.ae_begin[H.params.rank + 1] : nparts;
+    DBuf<int> d_ae_class;
     for (int ae0 = ae_lo; ae0 < ae_hi;) {
         size_t bytes = 0;
         int cnt = 0;
@@ -1091,8 +1094,13 @@ static Table prepare_next_level(Hierarchy &H, int lev) {
             // fine level: straight from the sparse rows of the AE matrices
             int kmax = 0;
             for (int km : L.mis_k) kmax = std::max(kmax, km);
+            // (classes of the agglomerates' sparse rows, where the eigenproblem stage found them for every agglomerate of the range)
+            bool have_classes = options().eig_dedupe != 0 && (int)L.ae_class.size() == nparts;
+            for (int i = ae0; have_classes && i < ae0 + cnt; ++i) have_classes = L.ae_class[i] >= 0;
+            if (have_classes && !d_ae_class.n) d_ae_class.from_host(L.ae_class, s);
             coarse_elmats_sparse(s, L.drel, ae0, batch, RW, rv, rc, L.d_mis_k.p, L.d_mis_u_off.p, L.mis_U.p,
-                                 d_colpos_ptr.p, d_colpos.p, N.elmat.off.p, N.elmat.val.p, scratch, d_soff.p, kmax);
+                                 d_colpos_ptr.p, d_colpos.p, N.elmat.off.p, N.elmat.val.p, scratch, d_soff.p, kmax,
+                                 have_classes ? d_ae_class.p : nullptr);
         } else {
             ae_build(s, L.drel, lev == 0 ? &L.A : nullptr, L.elmat, ae0, batch, false, nullptr);
             coarse_elmats(s, L.drel, ae0, batch, L.d_mis_k.p, L.d_mis_u_off.p, L.mis_U.p, d_colpos_ptr.p,
