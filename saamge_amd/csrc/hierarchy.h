@@ -82,6 +82,7 @@ struct Level {                  // tg_data_t + interp_data_t + agg_partitioning_
     std::vector<int> ae_begin;          // [world+1] AE ownership ranges of the ranks (eigenproblems, coarse element matrices)
     std::vector<int> ae_m;              // eigenvectors per AE
     std::vector<int> ae_class;          // per agglomerate: its class of identical SPARSE ROWS (the eigenproblem stage's, fused fine-level assembly), or -1
+    std::vector<int> ae_evclass;        // per agglomerate: the class whose eigenpairs it holds a copy of (any kind of class), or -1
     long long ae_solved = 0;            // local eigenproblems actually solved on this level by this rank (the others: copies of a class)
     std::vector<int64_t> ae_xoff, ae_eoff;
     DBuf<double> evals, evecs;          // cut_evects_arr (packed)

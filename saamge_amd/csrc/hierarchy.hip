@@ -300,6 +300,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
     L.ae_m.assign((size_t)nparts, 0);
     L.ae_solved = 0;
     L.ae_class.assign((size_t)nparts, -1);
+    L.ae_evclass.assign((size_t)nparts, -1);
     struct Chunk { int ae0, count; DBuf<double> evals, evecs; std::vector<int64_t> eoff, xoff; DBuf<int64_t> d_eoff, d_xoff; };
     std::vector<Chunk> chunks;
     if (P.keep_debug) L.ae_D.alloc((size_t)rel.AE_to_dof.I[nparts]);
@@ -454,6 +455,7 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
             } else {
                 const SolvedClass &sc = lvl_classes[co[i]];
                 if (sc.kind == 0) L.ae_class[ae0 + i] = co[i];
+                if (!sc.bad) L.ae_evclass[ae0 + i] = co[i];
                 hm[i] = sc.bad ? 0 : sc.m;
                 hbad[i] = sc.bad ? 1 : 0;
                 some_bad = some_bad || sc.bad;
@@ -830,7 +832,12 @@ static void build_level(Hierarchy &H, int lev, Table &&e2d, const hvec<int> &par
             SA_REQUIRE(P.allgather(P.allgather_ctx, L.d_mis_k.p, off.data()) == 0, "all-gather (MIS counts) failed");
             SA_REQUIRE(P.allgather(P.allgather_ctx, d_ncols.p, off.data()) == 0, "all-gather (MIS columns) failed");
         } else {
-            mis_svd(s, L.drel, nm, max_ctot, io);
+            // (agglomerates that hold copies of one class's eigenpairs: MISes with identical inputs are decomposed once)
+            DBuf<int> d_ev;
+            bool any = false;
+            for (int v_ : L.ae_evclass) any = any || v_ >= 0;
+            if (any && options().eig_dedupe != 0 && !(P.testmesh && lev == 0)) d_ev.from_host(L.ae_evclass, s);
+            mis_svd(s, L.drel, nm, max_ctot, io, 0, d_ev.n ? d_ev.p : nullptr);
         }
         { auto t_ = L.d_mis_k.to_host(s); L.mis_k.assign(t_.begin(), t_.end()); }
         { auto t_ = d_ncols.to_host(s); L.mis_ncols.assign(t_.begin(), t_.end()); }

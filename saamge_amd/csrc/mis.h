@@ -31,7 +31,10 @@ struct MisSvdIO {
 // Jacobi instead of dgesvd), cut at sigma > 1e-10 sigma_max (:591-620).
 // `m0`: first MIS of the range [m0, m0 + num_mises) this call works on (ranks of a multi-GPU setup take
 // contiguous ranges and all-gather the bases).
-void mis_svd(hipStream_t s, const DevRelations &rel, int num_mises, int max_ctot, const MisSvdIO &io, int m0 = 0);
+// ae_ev (optional, single rank, the whole level in one call): per agglomerate the class whose eigenpairs it received a copy of
+// (-1: computed on its own) -- MISes with identical inputs are then decomposed once (mis.hip, "Classes of identical MISes").
+void mis_svd(hipStream_t s, const DevRelations &rel, int num_mises, int max_ctot, const MisSvdIO &io, int m0 = 0,
+             const int *ae_ev = nullptr);
 
 // P (ND x nc) and R = P^T from the MIS blocks (contrib_tent_insert_simple,
 // amg/src/contrib.cpp:170-194; explicit zeros are kept in the block pattern).

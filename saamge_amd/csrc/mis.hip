@@ -19,9 +19,10 @@ __global__ __launch_bounds__(64) void mis_svd_kernel(
     const int *__restrict__ mis2d_I, const int *__restrict__ mis2d_J,
     const int *__restrict__ mis2ae_I, const int *__restrict__ mis2ae_J,
     const int *__restrict__ ae2d_I, const int64_t *__restrict__ pair_loc_off,
-    const int *__restrict__ pair_loc, const signed char *__restrict__ flags, MisSvdIO io, int m0) {
+    const int *__restrict__ pair_loc, const signed char *__restrict__ flags, MisSvdIO io, int m0,
+    const int *__restrict__ list = nullptr) {
     extern __shared__ __align__(16) double lds[];  // sig[ctot], then perm[ctot] (ints)
-    const int m = m0 + blockIdx.x;
+    const int m = list ? list[blockIdx.x] : m0 + (int)blockIdx.x;      // (list: the first members of the classes of identical MISes)
     const int lane = threadIdx.x;
     const int r = mis2d_I[m + 1] - mis2d_I[m];
     const int *dofs = mis2d_J + mis2d_I[m];
@@ -191,9 +192,179 @@ __global__ __launch_bounds__(64) void mis_svd_kernel(
     if (lane == 0) io.k[m] = k;
 }
 
-void mis_svd(hipStream_t s, const DevRelations &rel, int num_mises, int max_ctot, const MisSvdIO &io, int m0) {
+// Classes of identical MISes (eig.hip, "Duplicate agglomerate matrices", carried to the MIS stage): what the kernel above
+// gathers is a function of the MIS's size, the essential-boundary bits of its dofs, and per agglomerate it belongs to the
+// agglomerate's eigenvector block -- identical, bit for bit, for the members of one class of agglomerates (they received
+// copies of the class's eigenpairs: ae_ev = the class per agglomerate, -1 = on its own) -- its size and the MIS's rows in the
+// agglomerate's numbering; plus the appended modes on its dofs.  mis_walk visits those words for one MIS (a wavefront per
+// MIS), summing mixed (word, position) pairs or comparing with the first member of the class in lockstep.
+struct MisIn {
+    const int *mis2d_I, *mis2d_J, *mis2ae_I, *mis2ae_J, *ae2d_I;
+    const int64_t *pair_loc_off;
+    const int *pair_loc;
+    const signed char *flags;
+    MisSvdIO io;
+    const int *ae_ev;
+};
+__device__ inline unsigned long long mi_mix(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+template <bool PAIR, class F>
+__device__ inline bool mis_walk(const MisIn &v, int m, int m2, int lane, F &&f) {
+    const int r = v.mis2d_I[m + 1] - v.mis2d_I[m], qb = v.mis2ae_I[m], nq = v.mis2ae_I[m + 1] - qb;
+    const int ctot = (int)(v.io.s_off[m + 1] - v.io.s_off[m]);
+    const int *dofs = v.mis2d_J + v.mis2d_I[m];
+    const int qb2 = PAIR ? v.mis2ae_I[m2] : 0;
+    const int *dofs2 = PAIR ? v.mis2d_J + v.mis2d_I[m2] : nullptr;
+    if (PAIR && (r != v.mis2d_I[m2 + 1] - v.mis2d_I[m2] || nq != v.mis2ae_I[m2 + 1] - qb2 ||
+                 ctot != (int)(v.io.s_off[m2 + 1] - v.io.s_off[m2]))) return false;
+    bool ok = true;
+    if (!PAIR && lane == 0) { f(((unsigned long long)(unsigned)r << 32) | (unsigned)nq, 1ull); f((unsigned long long)(unsigned)ctot, 2ull); }
+    if (v.io.avoid_ess || v.io.nextra) {
+        for (int i = lane; i < r; i += 64) {
+            const unsigned long long w = v.io.avoid_ess ? (unsigned long long)(v.flags[dofs[i]] & FLAG_ON_ESS_BORDER) : 0ull;
+            if (PAIR) ok = ok && w == (v.io.avoid_ess ? (unsigned long long)(v.flags[dofs2[i]] & FLAG_ON_ESS_BORDER) : 0ull);
+            else f(w, (1ull << 40) + (unsigned long long)i);
+            for (int q = 0; q < v.io.nextra; ++q) {
+                const unsigned long long x = (unsigned long long)__double_as_longlong(v.io.extra[(size_t)q * v.io.ND + dofs[i]]);
+                if (PAIR) ok = ok && x == (unsigned long long)__double_as_longlong(v.io.extra[(size_t)q * v.io.ND + dofs2[i]]);
+                else f(x, (2ull << 40) + ((unsigned long long)q << 24) + (unsigned long long)i);
+            }
+        }
+    }
+    for (int t = 0; t < nq; ++t) {      // (wave-uniform)
+        const int ae = v.mis2ae_J[qb + t], na = v.ae2d_I[ae + 1] - v.ae2d_I[ae], ma = v.io.ae_m[ae];
+        const int id = v.ae_ev[ae];
+        const int *loc = v.pair_loc + v.pair_loc_off[qb + t];
+        const unsigned long long tag = (unsigned long long)(t + 3) << 40;
+        if (PAIR) {
+            const int ae2 = v.mis2ae_J[qb2 + t];
+            // (the same eigenvector block: the same class, or the same agglomerate)
+            if (!(ae == ae2 || (id >= 0 && id == v.ae_ev[ae2])) || na != v.ae2d_I[ae2 + 1] - v.ae2d_I[ae2] || ma != v.io.ae_m[ae2]) return false;
+            const int *loc2 = v.pair_loc + v.pair_loc_off[qb2 + t];
+            for (int i = lane; i < r; i += 64) ok = ok && loc[i] == loc2[i];
+        } else {
+            if (lane == 0) {
+                f(id >= 0 ? (unsigned long long)(unsigned)id : 0x8000000000000000ull + (unsigned long long)(unsigned)ae, tag);
+                f(((unsigned long long)(unsigned)na << 32) | (unsigned)ma, tag + 1);
+            }
+            for (int i = lane; i < r; i += 64) f((unsigned long long)(unsigned)loc[i], tag + 2 + (unsigned long long)i);
+        }
+    }
+    return ok;
+}
+// a wavefront per MIS: its 64-bit hash (two of them: the second is checked before the walk of the verification)
+__global__ __launch_bounds__(256) void mis_hash_kernel(MisIn v, int nm, unsigned long long *__restrict__ h) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= nm) return;
+    unsigned long long h1 = 0, h2 = 0;
+    mis_walk<false>(v, m, 0, lane, [&](unsigned long long w, unsigned long long pos) {
+        const unsigned long long k = mi_mix(w + 0x9E3779B97F4A7C15ull * (pos + 1));
+        h1 += k;
+        h2 += mi_mix(k ^ 0xD6E8FEB86659FD93ull);
+    });
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64); }
+    if (lane == 0) { h[2 * (size_t)m] = h1; h[2 * (size_t)m + 1] = h2; }
+}
+// open-addressing table keyed by the first hash: the smallest MIS of every key
+constexpr unsigned long long MI_EMPTY = ~0ull;
+__global__ __launch_bounds__(256) void mis_group_kernel(int nm, const unsigned long long *__restrict__ h, unsigned long long *__restrict__ keys,
+                                                        int *__restrict__ first, unsigned mask, int *__restrict__ slot) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= nm) return;
+    unsigned long long key = h[2 * (size_t)m];
+    if (key == MI_EMPTY) key = 0;
+    unsigned pos = (unsigned)(key ^ (key >> 32)) & mask;
+    for (;;) {
+        const unsigned long long cur = atomicCAS(keys + pos, MI_EMPTY, key);
+        if (cur == MI_EMPTY || cur == key) break;
+        pos = (pos + 1) & mask;
+    }
+    atomicMin(first + pos, m);
+    slot[m] = (int)pos;
+}
+__global__ __launch_bounds__(256) void mis_rep_kernel2(int nm, const int *__restrict__ slot, const int *__restrict__ first, int *__restrict__ rep) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m < nm) rep[m] = first[slot[m]];
+}
+// every MIS against the first of its key, word by word; a MIS that differs stands for itself
+__global__ __launch_bounds__(256) void mis_verify_kernel(MisIn v, int nm, const unsigned long long *__restrict__ h, int *__restrict__ rep,
+                                                         int *__restrict__ isrep) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= nm) return;
+    const int r0 = rep[m];
+    bool same = true;
+    if (r0 != m) {
+        same = h[2 * (size_t)m + 1] == h[2 * (size_t)r0 + 1];
+        if (same) same = mis_walk<true>(v, m, r0, lane, [](unsigned long long, unsigned long long) {});
+        same = __ballot(!same) == 0ull;
+    }
+    if (lane == 0) {
+        if (!same) rep[m] = m;
+        isrep[m] = (r0 == m || !same) ? 1 : 0;
+    }
+}
+__global__ __launch_bounds__(256) void mis_list_kernel(int nm, const int *__restrict__ isrep, const int *__restrict__ pos, int *__restrict__ list) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m < nm && isrep[m]) list[pos[m]] = m;
+}
+// results of the first members to the other members of their classes (a wavefront per MIS)
+__global__ __launch_bounds__(256) void mis_copy_kernel(MisIn v, int nm, const int *__restrict__ rep) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= nm) return;
+    const int r0 = rep[m];
+    if (r0 == m) return;
+    const int r = v.mis2d_I[m + 1] - v.mis2d_I[m], k = v.io.k[r0], ctot = (int)(v.io.s_off[m + 1] - v.io.s_off[m]);
+    if (lane == 0) { v.io.k[m] = k; v.io.ncols[m] = v.io.ncols[r0]; }
+    const double *su = v.io.U + v.io.u_off[r0], *ss = v.io.sig + v.io.s_off[r0];
+    double *du = v.io.U + v.io.u_off[m], *ds = v.io.sig + v.io.s_off[m];
+    for (int i = lane; i < r * k; i += 64) du[i] = su[i];
+    for (int i = lane; i < ctot; i += 64) ds[i] = ss[i];
+}
+
+void mis_svd(hipStream_t s, const DevRelations &rel, int num_mises, int max_ctot, const MisSvdIO &io, int m0, const int *ae_ev) {
     if (!num_mises) return;
     const size_t lds = (sizeof(double) + sizeof(int)) * (size_t)(max_ctot + 2);
+    // classes of identical MISes (single rank, the whole level at once): only their first members go through the SVD
+    if (ae_ev && m0 == 0 && num_mises >= 4096) {
+        const int nm = num_mises;
+        profiler().begin(s);
+        MisIn v{rel.mis2d_I.p, rel.mis2d_J.p, rel.mis2ae_I.p, rel.mis2ae_J.p, rel.ae2d_I.p, rel.pair_loc_off.p, rel.pair_loc.p, rel.flags.p, io, ae_ev};
+        unsigned tsize = 1024;
+        while (tsize < 4u * (unsigned)nm) tsize <<= 1;
+        DBuf<unsigned long long> h(2 * (size_t)nm), keys((size_t)tsize);
+        DBuf<int> first((size_t)tsize), slot((size_t)nm), rep((size_t)nm), isrep((size_t)nm), pos((size_t)nm + 1), list((size_t)nm);
+        SA_HIP_CHECK(hipMemsetAsync(keys.p, 0xff, sizeof(unsigned long long) * (size_t)tsize, s));
+        SA_HIP_CHECK(hipMemsetAsync(first.p, 0x7f, sizeof(int) * (size_t)tsize, s));
+        hipLaunchKernelGGL(mis_hash_kernel, dim3(div_up(nm, 4)), dim3(256), 0, s, v, nm, h.p);
+        hipLaunchKernelGGL(mis_group_kernel, dim3(div_up(nm, 256)), dim3(256), 0, s, nm, h.p, keys.p, first.p, tsize - 1, slot.p);
+        hipLaunchKernelGGL(mis_rep_kernel2, dim3(div_up(nm, 256)), dim3(256), 0, s, nm, slot.p, first.p, rep.p);
+        hipLaunchKernelGGL(mis_verify_kernel, dim3(div_up(nm, 4)), dim3(256), 0, s, v, nm, h.p, rep.p, isrep.p);
+        SA_HIP_CHECK(hipGetLastError());
+        exclusive_scan_int(s, nm, isrep.p, pos.p);
+        hipLaunchKernelGGL(mis_list_kernel, dim3(div_up(nm, 256)), dim3(256), 0, s, nm, isrep.p, pos.p, list.p);
+        SA_HIP_CHECK(hipGetLastError());
+        int last[2] = {0, 0};
+        SA_HIP_CHECK(hipMemcpyAsync(&last[0], pos.p + (nm - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+        SA_HIP_CHECK(hipMemcpyAsync(&last[1], isrep.p + (nm - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+        SA_HIP_CHECK(hipStreamSynchronize(s));
+        const int nrep = last[0] + last[1];
+        profiler().end(s, "eig_dedupe", 0.0, 0.0);
+        if (options().debug & 1) std::fprintf(stderr, "MISes: %d distinct of %d\n", nrep, nm);
+        profiler().begin(s);
+        hipLaunchKernelGGL(mis_svd_kernel, dim3(nrep), dim3(64), lds, s, rel.mis2d_I.p,
+                           rel.mis2d_J.p, rel.mis2ae_I.p, rel.mis2ae_J.p, rel.ae2d_I.p,
+                           rel.pair_loc_off.p, rel.pair_loc.p, rel.flags.p, io, 0, list.p);
+        hipLaunchKernelGGL(mis_copy_kernel, dim3(div_up(nm, 4)), dim3(256), 0, s, v, nm, rep.p);
+        SA_HIP_CHECK(hipGetLastError());
+        SA_HIP_CHECK(hipStreamSynchronize(s));      // (the lists are freed here)
+        profiler().end(s, "mis_svd", 0.0, 0.0);
+        return;
+    }
     profiler().begin(s);
     hipLaunchKernelGGL(mis_svd_kernel, dim3(num_mises), dim3(64), lds, s, rel.mis2d_I.p,
                        rel.mis2d_J.p, rel.mis2ae_I.p, rel.mis2ae_J.p, rel.ae2d_I.p,
