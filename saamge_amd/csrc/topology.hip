@@ -925,6 +925,13 @@ __global__ __launch_bounds__(256) void row_sort_kernel(const int *__restrict__ I
 
 // mode 0: rowcnt[p] = number of distinct dofs; mode 1: write them at out[outI[p] ...] in
 // first-encounter order
+__global__ __launch_bounds__(256) void ae_pack_lists_kernel(int nde, const int *__restrict__ ae2e_I, const int *__restrict__ outI,
+                                                            const int *__restrict__ padded, int *__restrict__ out) {
+    const int p = blockIdx.x, n = outI[p + 1] - outI[p];
+    const int *src = padded + (size_t)ae2e_I[p] * nde;
+    int *dst = out + outI[p];
+    for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+}
 __global__ __launch_bounds__(256) void ae_to_dof_kernel(int mode, int nde, int HS,
                                                         const int *__restrict__ ae2e_I,
                                                         const int *__restrict__ ae2e_J,
@@ -976,8 +983,11 @@ __global__ __launch_bounds__(256) void ae_to_dof_kernel(int mode, int nde, int H
         if (tid == 0) rowcnt[p] = total;
         return;
     }
+    // mode 2: the count AND the list, the list into a padded buffer (K slots per AE at eb * nde: the offsets of the packed
+    // lists are not known yet) -- one pass over the elements instead of a counting pass and a filling pass
+    if (mode == 2 && tid == 0) rowcnt[p] = total;
     int pos = wsum[tid >> 6] + incl - run;
-    int *o = out + outI[p];
+    int *o = mode == 2 ? out + (size_t)eb * nde : out + outI[p];
     for (int u = 0; u < per; ++u) {
         const int idx = tid * per + u;
         if (first[idx]) {
@@ -1068,15 +1078,16 @@ bool build_relations_ae_device(Relations &r, DevRelations &d, const int *e2d_dev
     const size_t lds = sizeof(int) * ((size_t)2 * HS + ((K + 255) & ~255));
     DBuf<int> rowcnt((size_t)nparts);
     d.ae2d_I.alloc((size_t)nparts + 1);
-    hipLaunchKernelGGL(ae_to_dof_kernel, dim3(nparts), dim3(256), lds, s, 0, nde, HS, ae2e_I.p, ae2e_J.p, e2d_dev,
-                       rowcnt.p, nullptr, nullptr);
+    // (one pass: counts + lists into a padded buffer of NE * nde slots, then the packed copy)
+    DBuf<int> padded((size_t)NE * nde);
+    hipLaunchKernelGGL(ae_to_dof_kernel, dim3(nparts), dim3(256), lds, s, 2, nde, HS, ae2e_I.p, ae2e_J.p, e2d_dev,
+                       rowcnt.p, nullptr, padded.p);
     exclusive_scan_int(s, nparts, rowcnt.p, d.ae2d_I.p);
     download(r.AE_to_dof.I, d.ae2d_I, (size_t)nparts + 1, s);
     SA_HIP_CHECK(hipStreamSynchronize(s));
     const long nae2d = r.AE_to_dof.I[nparts];
     d.ae2d_J.alloc((size_t)nae2d);
-    hipLaunchKernelGGL(ae_to_dof_kernel, dim3(nparts), dim3(256), lds, s, 1, nde, HS, ae2e_I.p, ae2e_J.p, e2d_dev,
-                       rowcnt.p, d.ae2d_I.p, d.ae2d_J.p);
+    hipLaunchKernelGGL(ae_pack_lists_kernel, dim3(nparts), dim3(256), 0, s, nde, ae2e_I.p, d.ae2d_I.p, padded.p, d.ae2d_J.p);
     // ---- dof_to_AE, dof_id_inAE, flags ----
     d.d2ae_I.alloc((size_t)ND + 1);
     d.d2ae_J.alloc((size_t)nae2d);
