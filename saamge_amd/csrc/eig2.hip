@@ -2719,7 +2719,7 @@ __global__ __launch_bounds__(BC_NT) void chol_band_lds2_kernel(const int *__rest
 // 32 columns: 4 flop per byte, 3 TB/s and 12 TFLOP/s on config 5's 2 187-row agglomerates (half bandwidth ~580), and
 // three launches per 32 columns whose panel kernels are latency chains.  Here an outer block of G sub-panels is
 // factored LEFT-LOOKING -- sub-panel g first receives the updates of sub-panels 0 .. g - 1 of its block (their packed
-// copies are a few hundred KB per matrix: L2), then is factored; one launch per 16 columns, the panel's columns read
+// copies are a few hundred KB per matrix: L2), then is factored; one launch per outer block, the panel's columns read
 // once and written once -- and the trailing window takes ONE rank-16 G update per outer block on the matrix cores
 // (v_mfma_f64_16x16x4): 8 (G = 4) or 16 (G = 8) flop per byte of window traffic.
 // Packed sub-panels: Pc = column operands (L21), Pr = row operands (L21 again, or L21 S of the signed walk
@@ -2729,7 +2729,7 @@ __global__ __launch_bounds__(BC_NT) void chol_band_lds2_kernel(const int *__rest
 // element [row l4 + 4 reg][col l15].  Everywhere below the MFMA "col" is a matrix ROW (16 consecutive rows of a
 // column-major column: 128 contiguous bytes per quarter wavefront) and the MFMA "row" a matrix COLUMN.
 template <int NT, int G, bool SIGNED>
-__global__ __launch_bounds__(NT) void chol_panel_ll_kernel(int k0, int g, const int *__restrict__ ns,
+__global__ __launch_bounds__(NT) void chol_panel_ll_kernel(int k0, int g0, int g1, const int *__restrict__ ns,
                                                             const int64_t *__restrict__ moff, const int64_t *__restrict__ voff,
                                                             double *__restrict__ W, double *__restrict__ Pc, double *__restrict__ Pr,
                                                             size_t pstride, int *__restrict__ info, const int *__restrict__ bws,
@@ -2740,9 +2740,12 @@ __global__ __launch_bounds__(NT) void chol_panel_ll_kernel(int k0, int g, const 
     __shared__ __align__(16) double Cb[G - 1][SB][18];      // column operands of the earlier sub-panels on the rows of this one
     __shared__ int bad;
     const int b = blockIdx.x, n = ns[b];
-    const int kk = k0 + SB * g;
-    if (kk >= n) return;
     if (skip && skip[b]) return;
+    // (the sub-panels g0 .. g1 - 1 of the outer block in ONE launch: a matrix is one workgroup's from the first to the last, the
+    // packed copies a sub-panel leaves are read back by the same workgroup behind a barrier -- seven launches less per block)
+    for (int g = g0; g < g1; ++g) {
+    const int kk = k0 + SB * g;
+    if (kk >= n) break;
     const int bw = bws ? bws[b] : n;
     const int rin = min(n, kk + SB + bw);                        // rows from here on are zero in these columns
     const int rend = min(n, kk + SB + bw + SB * (G - 1 - g));    // ... and still written (as zeros) to the packed copies
@@ -2814,7 +2817,7 @@ __global__ __launch_bounds__(NT) void chol_panel_ll_kernel(int k0, int g, const 
             }
         }
     }
-    if (nb < SB) return;
+    if (nb < SB) break;
     double la[4], sgc[4];     // A operand of the solve: L11^-1[row l15][k = l4 + 4 s] (the k slots of the C layout)
 #pragma unroll
     for (int s = 0; s < 4; ++s) { la[s] = Li[l15][l4 + 4 * s]; sgc[s] = SIGNED ? sg[l4 + 4 * s] : 1.0; }
@@ -2843,6 +2846,9 @@ __global__ __launch_bounds__(NT) void chol_panel_ll_kernel(int k0, int g, const 
                 }
             }
         }
+    }
+    __threadfence_block();      // (the next sub-panel reads this one's packed copies and reuses the LDS buffers)
+    __syncthreads();
     }
 }
 
@@ -2996,16 +3002,17 @@ static void ss_factor_blocked(hipStream_t s, EigBatch &b, bool sgn, int *neg, in
         int *info = info_p + f;
         const bool big = std::min(nmax - k0, bwmax + SB * G) > 448;
         if (prof) profiler().begin(q);
-        for (int g = 0; g < G && k0 + SB * g < nmax; ++g) {
+        {
+            const int g1 = std::min(G, div_up(nmax - k0, SB));
             if (sgn) {
-                if (big) hipLaunchKernelGGL((chol_panel_ll_kernel<512, G, true>), dim3(cnt), dim3(512), 0, q, k0, g, ns, moff, voff, b.W.p, Pc, Pr,
+                if (big) hipLaunchKernelGGL((chol_panel_ll_kernel<512, G, true>), dim3(cnt), dim3(512), 0, q, k0, 0, g1, ns, moff, voff, b.W.p, Pc, Pr,
                                             pstride, info, gbw, ng, keep, sk);
-                else hipLaunchKernelGGL((chol_panel_ll_kernel<256, G, true>), dim3(cnt), dim3(256), 0, q, k0, g, ns, moff, voff, b.W.p, Pc, Pr,
+                else hipLaunchKernelGGL((chol_panel_ll_kernel<256, G, true>), dim3(cnt), dim3(256), 0, q, k0, 0, g1, ns, moff, voff, b.W.p, Pc, Pr,
                                         pstride, info, gbw, ng, keep, sk);
             } else {
-                if (big) hipLaunchKernelGGL((chol_panel_ll_kernel<512, G, false>), dim3(cnt), dim3(512), 0, q, k0, g, ns, moff, voff, b.W.p, Pc, Pr,
+                if (big) hipLaunchKernelGGL((chol_panel_ll_kernel<512, G, false>), dim3(cnt), dim3(512), 0, q, k0, 0, g1, ns, moff, voff, b.W.p, Pc, Pr,
                                             pstride, info, gbw, (int *)nullptr, 0, sk);
-                else hipLaunchKernelGGL((chol_panel_ll_kernel<256, G, false>), dim3(cnt), dim3(256), 0, q, k0, g, ns, moff, voff, b.W.p, Pc, Pr,
+                else hipLaunchKernelGGL((chol_panel_ll_kernel<256, G, false>), dim3(cnt), dim3(256), 0, q, k0, 0, g1, ns, moff, voff, b.W.p, Pc, Pr,
                                         pstride, info, gbw, (int *)nullptr, 0, sk);
             }
         }
