@@ -91,6 +91,11 @@ struct EigBatch {
     // buffer + offsets): a matrix whose convergence rate is hopeless at its first shift is restored from it and
     // factored again at a shift just below its smallest Ritz value (eig_subspace_iterate)
     double *ss_save = nullptr;
+    // packed sub-panels of the blocked wide-band factorisations (arena buffer): taken from the arena by the FIRST factorisation of
+    // the batch -- on the thread that owns the workspace -- and kept here, so that a later factorisation from the iteration's own
+    // thread (a matrix factored again at a better shift) does not touch the arena
+    double *ss_sub = nullptr;
+    size_t ss_sub_n = 0;
     DBuf<int64_t> ss_soff;
     std::vector<double> h_sigma;
     std::vector<int> h_n, h_m;

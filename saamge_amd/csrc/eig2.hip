@@ -2982,7 +2982,11 @@ static void ss_factor_blocked(hipStream_t s, EigBatch &b, bool sgn, int *neg, in
     const bool prof = profiler().enabled;
     const size_t rows = (size_t)b.h_voff[b.count];
     const size_t pstride = (rows * SB + 15) / 16 * 16;
-    double *Pc = eig_arena_subpanels(b, pstride * G * (sgn ? 2 : 1));
+    if (b.ss_sub_n < pstride * G * 2) {      // (both operand sets, whichever factorisation comes first)
+        b.ss_sub = eig_arena_subpanels(b, pstride * G * 2);
+        b.ss_sub_n = pstride * G * 2;
+    }
+    double *Pc = b.ss_sub;
     double *Pr = sgn ? Pc + pstride * G : Pc;
     // ONE stream: the two halves on two streams that help the two-panel walk below (panels = latency chains beside the
     // other half's updates) cost these kernels a tenth (config 5: 8.44 against 7.98 s per step) -- a whole chunk's panels
