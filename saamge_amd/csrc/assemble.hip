@@ -419,6 +419,13 @@ __global__ __launch_bounds__(256) void ae_rows8_lds_kernel(
     int *hkey = llen + n;                           // [hsize] dof or -1
     short *hval = (short *)(hkey + hsize);          // [hsize] local index
     signed char *lflag = (signed char *)(hval + hsize);   // [n]
+    // per dof of the agglomerate: its elements INSIDE the agglomerate, in the order of the dof -> element list, and the dof's
+    // slot in each (round 4).  An assembled entry (row g, column c) used to walk g's element list in global memory -- per
+    // element its partition and two 16-byte loads of its dofs -- for every one of the row's ~27 entries; now the lists are
+    // made once per dof, and an entry matches the row's list against the column's in LDS: one global load (the element-matrix
+    // entry) per common element, the same products in the same order.
+    int *del = (int *)(((uintptr_t)(lflag + n) + 3) & ~(uintptr_t)3);      // [n][8] element or -1
+    unsigned char *dkk = (unsigned char *)(del + 8 * (size_t)n);          // [n][8] slot of the dof in it
     const int tid = threadIdx.x;
     for (int i = tid; i < hsize; i += 256) hkey[i] = -1;
     __syncthreads();
@@ -434,7 +441,26 @@ __global__ __launch_bounds__(256) void ae_rows8_lds_kernel(
         while (atomicCAS(&hkey[hpos], -1, g) != -1) hpos = (hpos + 1) & (unsigned)(hsize - 1);
         hval[hpos] = (short)i;
     }
-    __syncthreads();
+    bool many = false;      // (a dof with more than 8 elements: the agglomerate takes the walk through global memory)
+    for (int it = tid; it < n * 8; it += 256) {
+        const int i = it >> 3, q = it & 7;
+        const int g = dofs[i];
+        const int qb = d2e_I[g], cnt = d2e_I[g + 1] - qb;
+        many = many || cnt > 8;
+        int e = -1, kk = 0;
+        if (q < cnt) {
+            e = d2e_J[qb + q];
+            if (part[e] != p) e = -1;
+            else {
+                const int4 lo = *(const int4 *)(e2d_J + (size_t)e * 8), hi = *(const int4 *)(e2d_J + (size_t)e * 8 + 4);
+                kk = (lo.x == g) ? 0 : (lo.y == g) ? 1 : (lo.z == g) ? 2 : (lo.w == g) ? 3 :
+                     (hi.x == g) ? 4 : (hi.y == g) ? 5 : (hi.z == g) ? 6 : 7;
+            }
+        }
+        del[it] = e;
+        dkk[it] = (unsigned char)kk;
+    }
+    const bool walk = __syncthreads_or(many ? 1 : 0) != 0;
     const size_t obase = (size_t)voff[b] * RW;
     // four entries per thread and trip: their columns and values are requested together (one entry at a time, a thread
     // walked its ~43 entries through 43 x two dependent global latencies)
@@ -481,7 +507,19 @@ __global__ __launch_bounds__(256) void ae_rows8_lds_kernel(
                 const bool assembled = (fg & 1) && (fc & 1) && (!((fg | fc) & 2) || c == g);
                 if (!assembled) {
                     v = vs[u];                      // copied from the global matrix (aggregates.cpp:930-934)
-                } else {                            // agg_assemble_value, aggregates.cpp:68-184
+                } else if (!walk) {                 // agg_assemble_value, aggregates.cpp:68-184: the elements of g inside the agglomerate
+                    // that also hold c, ascending in g's list (the order of the walk below)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int e = del[lr * 8 + q];
+                        if (e < 0) continue;
+                        int jj = -1;
+#pragma unroll
+                        for (int q2 = 0; q2 < 8; ++q2)
+                            if (del[lc * 8 + q2] == e) jj = dkk[lc * 8 + q2];
+                        if (jj >= 0) v += elval[((size_t)e * 8 + dkk[lr * 8 + q]) * 8 + jj];
+                    }
+                } else {
                     const int qb = d2e_I[g], cnt = d2e_I[g + 1] - qb;
                     for (int q = 0; q < cnt; ++q) {      // ascending element id: the order of the kernel above
                         const int e = d2e_J[qb + q];
@@ -849,7 +887,7 @@ static void launch_rows8(hipStream_t s, const DevRelations &rel, const DCsr &A, 
     constexpr bool old_rows = false;      // (the kernel without the LDS hash of the agglomerate's dofs: larger agglomerates only)
     int hsize = 64;
     while (hsize < 2 * batch.max_n) hsize <<= 1;
-    const size_t lds = (size_t)batch.max_n * (8 + 4 + 4 + 1) + (size_t)hsize * 6 + 16;
+    const size_t lds = (size_t)batch.max_n * (8 + 4 + 4 + 1) + (size_t)hsize * 6 + 16 + (size_t)batch.max_n * 40 + 8;      // (+ the per-dof element lists)
     if (!old_rows && lds <= 64 * 1024)
         hipLaunchKernelGGL(ae_rows8_lds_kernel, dim3(batch.count), dim3(256), lds, s, ae0, RW, hsize, batch.n.p, batch.voff.p,
                            rel.ae2d_I.p, rel.ae2d_J.p, rel.flags.p, rel.d2e_I.p, rel.d2e_J.p, rel.part.p, rel.e2d_J.p,
