@@ -113,11 +113,14 @@ def build_problem(n, levels, dev, aniso=1.0, blk=(8, 8, 4), coarse_blk=(8, 8, 4)
 def one_step(capi, prob, params, rel_tol=1e-8, group=None):
     import torch
     # the library works on torch's current stream
+    t0 = time.perf_counter()
     h = capi.Hierarchy(prob.rowptr, prob.col, prob.val, prob.n, prob.elem_to_dof, prob.elmat,
                        prob.bdr, prob.partitions, prob.nparts, params, prob.NE_, getattr(prob, "nde_", 8),
                        stream=torch.cuda.current_stream().cuda_stream, group=group)
+    t1 = time.perf_counter()
     x = torch.zeros_like(prob.b)
     _, it, conv, hist = h.pcg(prob.b, x, rel_tol=rel_tol, max_iter=200)
+    one_step.last_split = (1e3 * (t1 - t0), 1e3 * (time.perf_counter() - t1))      # (host wall: the setup call, the solve call)
     return h, x, it, conv, hist
 
 
@@ -358,13 +361,16 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     marks = [t0]
+    splits = []
     for i in range(args.steps):
         h, x, its, conv, hist = one_step(capi, prob, params, group=grp)
         if i < args.steps - 1:
             h.close()
         marks.append(time.perf_counter())      # (a step ends with the iteration count on the host: no extra synchronisation)
+        splits.append(getattr(one_step, "last_split", (0.0, 0.0)))
     if rank == 0:
         sys.stderr.write("bench: wall ms of the timed steps: %s\n" % " ".join("%.1f" % (1e3 * (b - a)) for a, b in zip(marks, marks[1:])))
+        sys.stderr.write("bench: setup / solve calls of those steps: %s\n" % " ".join("%.0f/%.0f" % sp for sp in splits))
     grp.barrier()
     torch.cuda.synchronize()
     dt = grp.max_time(time.perf_counter() - t0)

@@ -126,6 +126,8 @@ void dev_pool_release();
 size_t dev_pool_idle_bytes();
 // device bytes the library holds in DBufs right now and their high-water mark since the last reset
 void dev_memory_stats(size_t *live, size_t *peak, bool reset_peak);
+// requests of the pool that went to the driver since the last reset (hipMalloc calls and their bytes, hipFree of cached blocks)
+void dev_pool_counts(long *n_malloc, long *n_free, size_t *malloc_bytes, bool reset);
 struct ThreadStreamScope {       // the calling thread's stream for a scope (restored at its end)
     hipStream_t prev;
     bool had;

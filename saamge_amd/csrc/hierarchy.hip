@@ -1618,6 +1618,13 @@ Hierarchy *hierarchy_create(int n, const void *Arow, int rowptr_bits, const int 
         tm0.lap("row-partitioned solve: halo lists", 0);
     }
     tm_all.lap("TOTAL ml_produce_data", 0);
+    if (env_timing()) {
+        long nm_ = 0, nf_ = 0;
+        size_t mb_ = 0;
+        dev_pool_counts(&nm_, &nf_, &mb_, true);
+        std::fprintf(stderr, "TIMING: device pool: %ld hipMalloc (%.1f MB), %ld hipFree of cached blocks, %.1f GB idle\n", nm_, mb_ / 1048576.0, nf_,
+                     dev_pool_idle_bytes() / 1073741824.0);
+    }
     return Hp.release();
 }
 

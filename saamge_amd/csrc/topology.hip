@@ -98,6 +98,8 @@ struct DevPool {
     std::map<std::pair<int, hipStream_t>, Epoch *> open;   // the batch each (device, stream) is filling
     size_t idle_bytes = 0, max_idle = 0;
     size_t live_bytes = 0, peak_bytes = 0;              // handed out now / high-water mark (dev_memory_stats)
+    long n_malloc = 0, n_free = 0;                      // requests that went to the driver (dev_pool_counts)
+    size_t malloc_bytes = 0;
     bool enabled = true;
     DevPool() {
         const char *e = std::getenv("SAAMGE_AMD_POOL_MAX_GB");
@@ -131,6 +133,7 @@ bool epoch_record(DevPool &P, Epoch *ep) {
 // pool lock held: hipFree one idle block (hipFree waits for the device: whatever used the block is done)
 std::multimap<size_t, IdleBlock>::iterator pool_drop_block(DevPool &P, std::multimap<size_t, IdleBlock>::iterator it) {
     (void)hipFree(it->second.p);
+    ++P.n_free;
     Epoch *ep = it->second.ep;
     P.idle_bytes -= it->first;
     it = P.idle.erase(it);
@@ -213,7 +216,17 @@ void *dev_alloc(size_t bytes) {
     P.live[p] = want;
     P.live_bytes += want;
     P.peak_bytes = std::max(P.peak_bytes, P.live_bytes);
+    ++P.n_malloc;
+    P.malloc_bytes += want;
     return p;
+}
+void dev_pool_counts(long *n_malloc, long *n_free, size_t *malloc_bytes, bool reset) {
+    DevPool &P = dev_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (n_malloc) *n_malloc = P.n_malloc;
+    if (n_free) *n_free = P.n_free;
+    if (malloc_bytes) *malloc_bytes = P.malloc_bytes;
+    if (reset) { P.n_malloc = P.n_free = 0; P.malloc_bytes = 0; }
 }
 
 void dev_free(void *p) noexcept {
