@@ -367,10 +367,11 @@ def main():
         if i < args.steps - 1:
             h.close()
         marks.append(time.perf_counter())      # (a step ends with the iteration count on the host: no extra synchronisation)
-        splits.append(getattr(one_step, "last_split", (0.0, 0.0)))
+        splits.append(getattr(one_step, "last_split", (0.0, 0.0)) + capi.pool_counts(reset=True)[:3:2])
     if rank == 0:
         sys.stderr.write("bench: wall ms of the timed steps: %s\n" % " ".join("%.1f" % (1e3 * (b - a)) for a, b in zip(marks, marks[1:])))
-        sys.stderr.write("bench: setup / solve calls of those steps: %s\n" % " ".join("%.0f/%.0f" % sp for sp in splits))
+        sys.stderr.write("bench: setup / solve calls of those steps (ms; + hipMalloc / hipFree calls of the block cache): %s\n"
+                         % " ".join("%.0f/%.0f+%d/%d" % sp for sp in splits))
     grp.barrier()
     torch.cuda.synchronize()
     dt = grp.max_time(time.perf_counter() - t0)

@@ -343,6 +343,9 @@ long long saamge_amd_cached_memory_bytes(void);
 /* device bytes the library holds right now (hierarchies, workspace in use; the caller's own arrays and the idle cache
  * are not counted) and their high-water mark since the last call with reset_peak != 0 */
 void saamge_amd_memory_stats(long long *live_bytes, long long *peak_bytes, int reset_peak);
+/* Requests of the library's cache of device blocks that went to the driver since the last reset: counts[0] = hipMalloc calls,
+ * [1] = their bytes, [2] = hipFree of cached blocks, [3] = bytes idle in the cache now.  A steady-state setup makes none. */
+void saamge_amd_pool_counts(long long counts[4], int reset);
 
 /* ---- per-kernel timing for bench.py's roofline leg (HIP events around every launch) ---- */
 void saamge_amd_profile_enable(int on);

@@ -27,7 +27,7 @@ SYMBOLS = [
     "saamge_amd_params_set_comm", "saamge_amd_comm_selftest", "saamge_amd_comm_last_error",
     "saamge_amd_release_cached_memory", "saamge_amd_cached_memory_bytes",
     "saamge_amd_ml_produce_data64", "saamge_amd_get_csr64", "saamge_amd_spmv64", "saamge_amd_set_smoother", "saamge_amd_profile_get2", "saamge_amd_level_format", "saamge_amd_update_operators2",
-    "saamge_amd_ml_produce_data_parcsr", "saamge_amd_memory_stats",
+    "saamge_amd_ml_produce_data_parcsr", "saamge_amd_memory_stats", "saamge_amd_pool_counts",
     "saamge_amd_options_default", "saamge_amd_set_options", "saamge_amd_get_options",
 ]
 
@@ -570,6 +570,13 @@ def reset_options():
     o = Options()
     load().saamge_amd_options_default(C.byref(o))
     load().saamge_amd_set_options(C.byref(o))
+
+
+def pool_counts(reset=False):
+    """(hipMalloc calls, their bytes, hipFree of cached blocks, idle bytes) of the library's cache of device blocks since the last reset."""
+    c = (C.c_longlong * 4)()
+    load().saamge_amd_pool_counts(c, C.c_int(int(reset)))
+    return tuple(int(v) for v in c)
 
 
 def memory_stats(reset_peak=False):

@@ -653,6 +653,12 @@ void saamge_amd_memory_stats(long long *live_bytes, long long *peak_bytes, int r
     if (live_bytes) *live_bytes = (long long)l;
     if (peak_bytes) *peak_bytes = (long long)pk;
 }
+void saamge_amd_pool_counts(long long counts[4], int reset) {
+    long nm = 0, nf = 0;
+    size_t mb = 0;
+    dev_pool_counts(&nm, &nf, &mb, reset != 0);
+    if (counts) { counts[0] = nm; counts[1] = (long long)mb; counts[2] = nf; counts[3] = (long long)dev_pool_idle_bytes(); }
+}
 
 void saamge_amd_profile_enable(int on) { profiler().enabled = on != 0; }
 void saamge_amd_profile_reset(void) { profiler().stats.clear(); }
