@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void ae_rows8_lds_kernel(
         la0[i] = a0;
         llen[i] = (int)(Arow[g + 1] - a0);
         lflag[i] = flags[g];
-        unsigned hpos = ((unsigned)g * 2654435761u) & (unsigned)(hsize - 1);
+        unsigned hpos = hash_home((unsigned)g, (unsigned)hsize);
         while (atomicCAS(&hkey[hpos], -1, g) != -1) hpos = (hpos + 1) & (unsigned)(hsize - 1);
         hval[hpos] = (short)i;
     }
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void ae_rows8_lds_kernel(
             lcs[u] = -1;
             if (on[u]) {
                 const int c = cs[u];
-                unsigned hpos = ((unsigned)c * 2654435761u) & (unsigned)(hsize - 1);
+                unsigned hpos = hash_home((unsigned)c, (unsigned)hsize);
                 for (;;) {
                     const int key = hkey[hpos];
                     if (key == c) { lcs[u] = hval[hpos]; break; }
@@ -1025,14 +1025,14 @@ struct AiTable {
         const int *dofs = v.ae2d_J + v.ae2d_I[p];
         for (int i = tid; i < n; i += nt) {
             const int g = dofs[i];
-            unsigned h = ((unsigned)g * 2654435761u) & mask;
+            unsigned h = hash_home((unsigned)g, mask + 1u);
             while (atomicCAS(&key[h], -1, g) != -1) h = (h + 1) & mask;
             val[h] = (short)i;
         }
         __syncthreads();
     }
     __device__ inline int operator()(int c) const {
-        unsigned h = ((unsigned)c * 2654435761u) & mask;
+        unsigned h = hash_home((unsigned)c, mask + 1u);
         for (;;) {
             const int k = key[h];
             if (k == c) return val[h];

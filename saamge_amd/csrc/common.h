@@ -294,6 +294,8 @@ struct DCsr {
 
 // exclusive scans (mis.hip); out has n + 1 entries
 void exclusive_scan_int(hipStream_t s, int n, const int *in, int *out);
+// the same without the host synchronisation: `tile_sums` is the caller's scratch of div_up(n, 1024) + 1 ints
+void exclusive_scan_int_async(hipStream_t s, int n, const int *in, int *out, int *tile_sums);
 void exclusive_scan_off(hipStream_t s, int n, const int *in, roff_t *out);
 
 // Row offsets crossing the C ABI (sparse.hip).  In: int32 (the reference's HYPRE_Int; widened on the device)
@@ -310,6 +312,13 @@ inline int pick_lanes_per_row(int64_t nnz, int nrows) {
 }
 
 inline int div_up(int64_t a, int64_t b) { return int((a + b - 1) / b); }
+// Home slot of `key` in an open-addressing table of `size` slots (a power of two >= 2): the HIGH bits of the multiplicative
+// hash.  (Until round 4 the tables took the low bits, which are a permutation of the key's own low bits: the dofs of a box
+// of a lexicographically numbered grid -- x + 257 y + 66049 z -- collide in lattices, 4.2 probes per look-up instead of 1.0
+// for the 405 dofs of the headline's agglomerates in 1 024 slots.)
+__host__ __device__ inline unsigned hash_home(unsigned key, unsigned size) {
+    return (key * 2654435761u) >> (__builtin_clz(size) + 1);
+}
 
 // ---- optional per-kernel timing (bench.py's roofline leg) -------------------------
 struct KernelStat {

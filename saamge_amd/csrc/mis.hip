@@ -457,6 +457,13 @@ static void exclusive_scan_t(hipStream_t s, int n, const int *in, OUT *out) {
     SA_HIP_CHECK(hipStreamSynchronize(s));  // tsum is freed on return
 }
 void exclusive_scan_int(hipStream_t s, int n, const int *in, int *out) { exclusive_scan_t<int>(s, n, in, out); }
+void exclusive_scan_int_async(hipStream_t s, int n, const int *in, int *out, int *tsum) {
+    const int nt = div_up(n, 1024);
+    hipLaunchKernelGGL(scan_tile_kernel<int>, dim3(nt), dim3(256), 0, s, n, in, out, tsum);
+    hipLaunchKernelGGL(scan_sums_kernel<int>, dim3(1), dim3(256), 0, s, nt, tsum, tsum + nt);
+    hipLaunchKernelGGL(scan_add_kernel<int>, dim3(div_up(n, 256)), dim3(256), 0, s, n, out, (const int *)tsum, (const int *)(tsum + nt));
+    SA_HIP_CHECK(hipGetLastError());
+}
 void exclusive_scan_off(hipStream_t s, int n, const int *in, roff_t *out) { exclusive_scan_t<roff_t>(s, n, in, out); }
 
 __global__ __launch_bounds__(256) void p_fill_kernel(int ND, const int *__restrict__ mises,
@@ -698,7 +705,7 @@ __global__ __launch_bounds__(RAP_NT) void rap_symbolic_kernel(
             for (roff_t q = Arow[g]; q < Arow[g + 1]; ++q) {
                 const int m2 = mises[Acol[q]];
                 if (k[m2] == 0) continue;
-                unsigned h = ((unsigned)m2 * 2654435761u) & (HS - 1);
+                unsigned h = hash_home((unsigned)m2, (unsigned)HS);
                 for (int probe = 0; probe < HS; ++probe) {
                     const int old = atomicCAS(&table[h], -1, m2);
                     if (old == -1) { atomicAdd(&nfound, 1); break; }

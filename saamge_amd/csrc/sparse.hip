@@ -1191,23 +1191,28 @@ __global__ __launch_bounds__(256) void sell_code_kernel(int nslices, const roff_
         for (int k = 0; k < w && ok; ++k) {
             const int delta = scol[beg + 64 * k + lane] - row;
             const long long vb = pairs ? __double_as_longlong(sval[beg + 64 * k + lane]) : 0;
+            // One trip per DISTINCT pair among the 64 entries of this column of the slice (one to three on a stencil operator):
+            // the first lane without a code broadcasts its pair, the table -- entry t in lane t -- answers with one ballot, and a
+            // pair that is not in it is appended.  (Until round 4 every lane first walked the whole table through two shuffles
+            // per entry -- 27 x 27 x 3 cross-lane reads per slice of a 27-point operator, the kernel's bound -- before this loop
+            // added what was missing.  Same tables, same codes: the pairs are appended in the order of the lanes that bring them.)
             int code = -1;
-            for (int t = 0; t < nt; ++t) {
-                // (both shuffles outside the condition: a cross-lane read under a divergent branch returns
-                // nothing from the lanes that did not take it)
-                const int tt = __shfl(mytab, t);
-                const long long tv = __shfl(myval, t);
-                if (tt == delta && tv == vb) code = t;
-            }
-            unsigned long long pending = __ballot(code < 0);
+            unsigned long long pending = ~0ull;
             while (pending) {
                 const int leader = __ffsll((long long)pending) - 1;
+                // (both shuffles outside any condition: a cross-lane read under a divergent branch returns nothing from
+                // the lanes that did not take it)
                 const int d = __shfl(delta, leader);
                 const long long dv = __shfl(vb, leader);
-                if (nt == 64) { ok = false; break; }
-                if (lane == nt) { mytab = d; myval = dv; }
-                if (code < 0 && delta == d && vb == dv) code = nt;
-                ++nt;
+                const unsigned long long hit = __ballot(lane < nt && mytab == d && myval == dv);
+                int c;
+                if (hit) c = __ffsll((long long)hit) - 1;
+                else {
+                    if (nt == 64) { ok = false; break; }
+                    if (lane == nt) { mytab = d; myval = dv; }
+                    c = nt++;
+                }
+                if (code < 0 && delta == d && vb == dv) code = c;
                 pending = __ballot(code < 0);
             }
             cw |= (unsigned)(code & 255) << (8 * (k & 3));

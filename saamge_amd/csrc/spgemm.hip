@@ -20,7 +20,7 @@ __device__ inline void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL
 // slot of `key` in the open-addressing table (inserted if absent); -1 when the table is full
 template <int T>
 __device__ inline int hash_slot(int *keys, int key) {
-    unsigned h = ((unsigned)key * 2654435761u) & (unsigned)(T - 1);
+    unsigned h = hash_home((unsigned)key, (unsigned)T);
     for (int probe = 0; probe < T; ++probe) {
         const int prev = atomicCAS(&keys[h], SPG_EMPTY, key);
         if (prev == SPG_EMPTY || prev == key) return (int)h;

@@ -511,7 +511,7 @@ void build_relations_ae(Relations &r, Table &&elem_to_dof, const hvec<int> &part
                 const int el = r.AE_to_elem.J[k];
                 for (int q = e2d.I[el]; q < e2d.I[el + 1]; ++q) {
                     const int d = e2d.J[q];
-                    size_t h = ((size_t)(uint32_t)d * 2654435761u) & (cap - 1);
+                    size_t h = hash_home((unsigned)d, (unsigned)cap);
                     while (table[h] != -1 && table[h] != d) h = (h + 1) & (cap - 1);
                     if (table[h] == -1) {
                         table[h] = d;
@@ -904,11 +904,36 @@ __global__ __launch_bounds__(256) void key_count_kernel(long n, const int *__res
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) atomicAdd(&cnt[key[i]], 1);
 }
-__global__ __launch_bounds__(256) void key_fill_kernel(long n, const int *__restrict__ key,
-                                                       const int *__restrict__ rowI, int *__restrict__ cursor,
-                                                       int *__restrict__ J) {
+// Count and fill for keys that come in runs (the partition of lexicographically numbered elements: eight neighbours share an
+// agglomerate): one atomic per run of equal keys in a wavefront instead of one per element -- the 64 atomics of a wavefront fell
+// on eight counters.  The order inside a row is whatever the atomics give, as before (row_sort_kernel follows).
+__device__ inline void run_of_lane(int k, int lane, int &head, int &len) {
+    const int prev = __shfl_up(k, 1, 64);
+    const unsigned long long heads = __ballot(lane == 0 || k != prev);
+    head = 63 - __clzll(heads & (~0ull >> (63 - lane)));
+    const unsigned long long after = head == 63 ? 0ull : heads >> (head + 1);
+    len = after ? __ffsll((long long)after) : 64 - head;
+}
+__global__ __launch_bounds__(256) void key_count_runs_kernel(long n, const int *__restrict__ key, int *__restrict__ cnt) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) J[rowI[key[i]] + atomicAdd(&cursor[key[i]], 1)] = (int)i;
+    const int lane = threadIdx.x & 63;
+    const int k = i < n ? key[i] : -1 - lane;
+    int head, len;
+    run_of_lane(k, lane, head, len);
+    if (lane == head && i < n) atomicAdd(&cnt[k], len);
+}
+__global__ __launch_bounds__(256) void key_fill_runs_kernel(long n, const int *__restrict__ key,
+                                                            const int *__restrict__ rowI, int *__restrict__ cursor,
+                                                            int *__restrict__ J) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int k = i < n ? key[i] : -1 - lane;
+    int head, len;
+    run_of_lane(k, lane, head, len);
+    int base = 0;
+    if (lane == head && i < n) base = rowI[k] + atomicAdd(&cursor[k], len);
+    base = __shfl(base, head, 64);
+    if (i < n) J[base + (lane - head)] = (int)i;
 }
 __global__ __launch_bounds__(256) void any_zero_kernel(long n, const int *__restrict__ cnt, int bit, int *__restrict__ err) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -952,18 +977,23 @@ __global__ __launch_bounds__(256) void ae_to_dof_kernel(int mode, int nde, int H
                                                         const int *__restrict__ outI, int *__restrict__ out) {
     extern __shared__ int sh[];
     __shared__ int wsum[4], total;
-    int *keys = sh, *ranks = sh + HS, *first = sh + 2 * HS;
     const int p = blockIdx.x, tid = threadIdx.x;
     const int eb = ae2e_I[p], ne = ae2e_I[p + 1] - eb;
     const int K = ne * nde;
-    for (int i = tid; i < HS; i += 256) { keys[i] = -1; ranks[i] = 0x7fffffff; }
     const int Kpad = (K + 255) & ~255;
+    int *keys = sh, *ranks = sh + HS, *first = sh + 2 * HS, *vals = first + Kpad;
+    for (int i = tid; i < HS; i += 256) { keys[i] = -1; ranks[i] = 0x7fffffff; }
     for (int i = tid; i < Kpad; i += 256) first[i] = 0;
-    __syncthreads();
+    // (the dofs first, into LDS: the loads of a thread's entries are independent of the table and go out together; with the
+    // inserts in the same loop every entry waited for two dependent global loads behind the previous entry's atomics)
     for (int idx = tid; idx < K; idx += 256) {
         const int q = idx / nde, t = idx - q * nde;
-        const int d = e2d_J[(size_t)ae2e_J[eb + q] * nde + t];
-        unsigned h = ((unsigned)d * 2654435761u) & (unsigned)(HS - 1);
+        vals[idx] = e2d_J[(size_t)ae2e_J[eb + q] * nde + t];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < K; idx += 256) {
+        const int d = vals[idx];
+        unsigned h = hash_home((unsigned)d, (unsigned)HS);
         for (;;) {
             const int prev = atomicCAS(&keys[h], -1, d);
             if (prev == -1 || prev == d) { atomicMin(&ranks[h], idx); break; }
@@ -1003,10 +1033,7 @@ __global__ __launch_bounds__(256) void ae_to_dof_kernel(int mode, int nde, int H
     int *o = mode == 2 ? out + (size_t)eb * nde : out + outI[p];
     for (int u = 0; u < per; ++u) {
         const int idx = tid * per + u;
-        if (first[idx]) {
-            const int q = idx / nde, t = idx - q * nde;
-            o[pos++] = e2d_J[(size_t)ae2e_J[eb + q] * nde + t];
-        }
+        if (first[idx]) o[pos++] = vals[idx];
     }
 }
 
@@ -1067,10 +1094,41 @@ bool build_relations_ae_device(Relations &r, DevRelations &d, const int *e2d_dev
         SA_REQUIRE(!(h[0] & 1), "partition id out of range");
         SA_REQUIRE(!(h[0] & 2), "elem_to_dof entry out of range");
     }
+    // dof_to_elem (for the assembly kernels, as in upload_relations_ae) depends on the elements alone: its five kernels --
+    // counters and cursors of global atomics, latency-bound -- run on a side stream beside the agglomerate tables
+    hipStream_t s2 = side_stream(7);
+    DBuf<int> cnt2((size_t)ND + 1), sums2((size_t)div_up(ND, 1024) + 1);
+    d.d2e_I.alloc((size_t)ND + 1);
+    d.d2e_J.alloc((size_t)nconn);
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    SA_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    SA_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    {
+        SA_HIP_CHECK(hipEventRecord(ev_fork, s));
+        SA_HIP_CHECK(hipStreamWaitEvent(s2, ev_fork, 0));
+        SA_HIP_CHECK(hipMemsetAsync(cnt2.p, 0, sizeof(int) * (size_t)ND, s2));
+        hipLaunchKernelGGL(d2e_count_kernel, dim3(div_up(nconn, 256)), dim3(256), 0, s2, nconn, d.e2d_J.p, cnt2.p);
+        exclusive_scan_int_async(s2, ND, cnt2.p, d.d2e_I.p, sums2.p);
+        SA_HIP_CHECK(hipMemsetAsync(cnt2.p, 0, sizeof(int) * (size_t)ND, s2));
+        hipLaunchKernelGGL(d2e_fill_kernel, dim3(div_up(NE, 256)), dim3(256), 0, s2, NE, d.e2d_I.p, d.e2d_J.p, d.d2e_I.p,
+                           cnt2.p, d.d2e_J.p);
+        hipLaunchKernelGGL(d2e_sort_kernel, dim3(div_up(ND, 256)), dim3(256), 0, s2, ND, d.d2e_I.p, d.d2e_J.p);
+        SA_HIP_CHECK(hipGetLastError());
+        SA_HIP_CHECK(hipEventRecord(ev_join, s2));
+    }
+    struct JoinSide {      // (every way out of this function waits for the side stream: its buffers are released here)
+        hipStream_t s2;
+        hipEvent_t a, b;
+        ~JoinSide() {
+            (void)hipStreamSynchronize(s2);
+            (void)hipEventDestroy(a);
+            (void)hipEventDestroy(b);
+        }
+    } join_side{s2, ev_fork, ev_join};
     // ---- AE_to_elem ----
     DBuf<int> ae2e_I((size_t)nparts + 1), ae2e_J((size_t)NE);
     SA_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(int) * (size_t)nparts, s));
-    hipLaunchKernelGGL(key_count_kernel, dim3(div_up(NE, 256)), dim3(256), 0, s, (long)NE, part_dev, cnt.p);
+    hipLaunchKernelGGL(key_count_runs_kernel, dim3(div_up(NE, 256)), dim3(256), 0, s, (long)NE, part_dev, cnt.p);
     hipLaunchKernelGGL(any_zero_kernel, dim3(div_up(nparts, 256)), dim3(256), 0, s, (long)nparts, cnt.p, 4, err.p);
     exclusive_scan_int(s, nparts, cnt.p, ae2e_I.p);
     auto h_ae2e_I = ae2e_I.to_host(s);
@@ -1079,7 +1137,7 @@ bool build_relations_ae_device(Relations &r, DevRelations &d, const int *e2d_dev
     for (int p = 0; p < nparts; ++p) max_ne = std::max(max_ne, h_ae2e_I[p + 1] - h_ae2e_I[p]);
     if ((long)max_ne * nde > TOPO_MAXK || max_ne > 4096) return false;   // host path handles it
     SA_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(int) * (size_t)nparts, s));
-    hipLaunchKernelGGL(key_fill_kernel, dim3(div_up(NE, 256)), dim3(256), 0, s, (long)NE, part_dev, ae2e_I.p, cnt.p,
+    hipLaunchKernelGGL(key_fill_runs_kernel, dim3(div_up(NE, 256)), dim3(256), 0, s, (long)NE, part_dev, ae2e_I.p, cnt.p,
                        ae2e_J.p);
     int cap = 2;
     while (cap < max_ne) cap <<= 1;
@@ -1088,11 +1146,13 @@ bool build_relations_ae_device(Relations &r, DevRelations &d, const int *e2d_dev
     const int K = max_ne * nde;
     int HS = 64;
     while (HS < 2 * K) HS <<= 1;
-    const size_t lds = sizeof(int) * ((size_t)2 * HS + ((K + 255) & ~255));
+    const size_t lds = sizeof(int) * ((size_t)2 * HS + 2 * (size_t)((K + 255) & ~255));
     DBuf<int> rowcnt((size_t)nparts);
     d.ae2d_I.alloc((size_t)nparts + 1);
     // (one pass: counts + lists into a padded buffer of NE * nde slots, then the packed copy)
     DBuf<int> padded((size_t)NE * nde);
+    if (lds > 64 * 1024)
+        SA_HIP_CHECK(hipFuncSetAttribute((const void *)ae_to_dof_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     hipLaunchKernelGGL(ae_to_dof_kernel, dim3(nparts), dim3(256), lds, s, 2, nde, HS, ae2e_I.p, ae2e_J.p, e2d_dev,
                        rowcnt.p, nullptr, padded.p);
     exclusive_scan_int(s, nparts, rowcnt.p, d.ae2d_I.p);
@@ -1120,17 +1180,9 @@ bool build_relations_ae_device(Relations &r, DevRelations &d, const int *e2d_dev
     r.ae_host_pending = true;
     r.AE_to_dof.ncols = ND;
     r.dof_to_AE.ncols = nparts;
-    // dof_to_elem / elem_ldof for the assembly kernels (as in upload_relations_ae)
-    d.d2e_I.alloc((size_t)ND + 1);
-    d.d2e_J.alloc((size_t)nconn);
+    // elem_ldof for the assembly kernels
     d.elem_ldof.alloc((size_t)nconn);
-    SA_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(int) * (size_t)ND, s));
-    hipLaunchKernelGGL(d2e_count_kernel, dim3(div_up(nconn, 256)), dim3(256), 0, s, nconn, d.e2d_J.p, cnt.p);
-    exclusive_scan_int(s, ND, cnt.p, d.d2e_I.p);
-    SA_HIP_CHECK(hipMemsetAsync(cnt.p, 0, sizeof(int) * (size_t)ND, s));
-    hipLaunchKernelGGL(d2e_fill_kernel, dim3(div_up(NE, 256)), dim3(256), 0, s, NE, d.e2d_I.p, d.e2d_J.p, d.d2e_I.p,
-                       cnt.p, d.d2e_J.p);
-    hipLaunchKernelGGL(d2e_sort_kernel, dim3(div_up(ND, 256)), dim3(256), 0, s, ND, d.d2e_I.p, d.d2e_J.p);
+    SA_HIP_CHECK(hipStreamWaitEvent(s, ev_join, 0));
     hipLaunchKernelGGL(elem_ldof_kernel, dim3(div_up(NE, 256)), dim3(256), 0, s, NE, d.e2d_I.p, d.e2d_J.p, d.part.p,
                        d.d2ae_I.p, d.d2ae_J.p, d.dof_id_inAE.p, d.elem_ldof.p);
     SA_HIP_CHECK(hipGetLastError());
