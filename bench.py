@@ -114,13 +114,16 @@ def one_step(capi, prob, params, rel_tol=1e-8, group=None):
     import torch
     # the library works on torch's current stream
     t0 = time.perf_counter()
+    c0 = time.process_time()
     h = capi.Hierarchy(prob.rowptr, prob.col, prob.val, prob.n, prob.elem_to_dof, prob.elmat,
                        prob.bdr, prob.partitions, prob.nparts, params, prob.NE_, getattr(prob, "nde_", 8),
                        stream=torch.cuda.current_stream().cuda_stream, group=group)
     t1 = time.perf_counter()
+    c1 = time.process_time()
     x = torch.zeros_like(prob.b)
     _, it, conv, hist = h.pcg(prob.b, x, rel_tol=rel_tol, max_iter=200)
-    one_step.last_split = (1e3 * (t1 - t0), 1e3 * (time.perf_counter() - t1))      # (host wall: the setup call, the solve call)
+    # (host wall: the setup call, the solve call; CPU time of all threads of the process in the setup call)
+    one_step.last_split = (1e3 * (t1 - t0), 1e3 * (time.perf_counter() - t1), 1e3 * (c1 - c0))
     return h, x, it, conv, hist
 
 
@@ -367,11 +370,11 @@ def main():
         if i < args.steps - 1:
             h.close()
         marks.append(time.perf_counter())      # (a step ends with the iteration count on the host: no extra synchronisation)
-        splits.append(getattr(one_step, "last_split", (0.0, 0.0)) + capi.pool_counts(reset=True)[:3:2])
+        splits.append(getattr(one_step, "last_split", (0.0, 0.0, 0.0)) + capi.pool_counts(reset=True)[:3:2])
     if rank == 0:
         sys.stderr.write("bench: wall ms of the timed steps: %s\n" % " ".join("%.1f" % (1e3 * (b - a)) for a, b in zip(marks, marks[1:])))
-        sys.stderr.write("bench: setup / solve calls of those steps (ms; + hipMalloc / hipFree calls of the block cache): %s\n"
-                         % " ".join("%.0f/%.0f+%d/%d" % sp for sp in splits))
+        sys.stderr.write("bench: setup / solve calls of those steps (ms; (CPU ms of the process in the setup call) + hipMalloc / hipFree calls "
+                         "of the block cache): %s\n" % " ".join("%.0f/%.0f(%.0f)+%d/%d" % sp for sp in splits))
     grp.barrier()
     torch.cuda.synchronize()
     dt = grp.max_time(time.perf_counter() - t0)

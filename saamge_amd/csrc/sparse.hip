@@ -1122,6 +1122,28 @@ __global__ __launch_bounds__(256) void sell_width_kernel(int nrows, const roff_t
 // cache lines per load instruction (measured: 110 GB fetched to convert 5.5 GB).  Slices with more than
 // SF_CAP entries (dense coarse-level rows) take that slow walk.
 constexpr int SF_CAP = 2048;
+// the contiguous CSR range [r0, r0 + len) of a slice into LDS, one wavefront: eight entries per lane and trip are requested
+// before the first is stored (one entry per trip waited for a global round trip 27 times per slice of a 27-point operator)
+__device__ __forceinline__ void stage_slice(const int *__restrict__ col, const double *__restrict__ val, roff_t r0, int len, int lane,
+                                            int *lc, double *lv) {
+    constexpr int U = 8;
+    for (int t0 = lane; t0 < len; t0 += 64 * U) {
+        int c[U];
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = min(t0 + 64 * u, len - 1);
+            c[u] = col[r0 + t];
+            v[u] = val[r0 + t];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (t0 + 64 * u < len) {
+                lc[t0 + 64 * u] = c[u];
+                lv[t0 + 64 * u] = v[u];
+            }
+    }
+}
 __global__ __launch_bounds__(64) void sell_fill_kernel(int nrows, const roff_t *__restrict__ rowptr,
                                                        const int *__restrict__ col,
                                                        const double *__restrict__ val,
@@ -1138,10 +1160,7 @@ __global__ __launch_bounds__(64) void sell_fill_kernel(int nrows, const roff_t *
     const int pad = (row < nrows) ? (int)row : nrows - 1;
     const roff_t r0 = rowptr[(long)slice * 64], r1 = rowptr[min((long)slice * 64 + 64, (long)nrows)];
     if (r1 - r0 <= SF_CAP) {
-        for (int t = lane; t < (int)(r1 - r0); t += 64) {
-            lc[t] = col[r0 + t];
-            lv[t] = val[r0 + t];
-        }
+        stage_slice(col, val, r0, (int)(r1 - r0), lane, lc, lv);
         __syncthreads();
         for (int k = 0; k < w; ++k) {
             const bool in = rb + k < re;

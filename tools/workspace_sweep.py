@@ -21,7 +21,7 @@ for gib in [int(v) for v in sys.argv[1:]] or [32, 64]:
         t0 = time.perf_counter()
         h, x, it, conv, hist = bench.one_step(capi, prob, params)
         torch.cuda.synchronize()
-        out.append((1e3 * (time.perf_counter() - t0),) + bench.one_step.last_split)
+        out.append((1e3 * (time.perf_counter() - t0),) + bench.one_step.last_split[:2])
         h.close()
     live, peak = capi.memory_stats()
     print("workspace %4d GiB: steps %s  its %d  peak %.1f GB" % (gib, " ".join("%.0f=%.0f+%.0f" % o for o in out[2:]), it, peak / 1e9), flush=True)
