@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(AI_NT) void asm_hash_kernel(AeInputs v, int hsize, 
         ai_row_walk<false>(v, x, x, lr0, lane, [&](unsigned long long w, unsigned long long pos) {
             const unsigned long long k = ai_mix(w + 0x9E3779B97F4A7C15ull * (pos + 1) + rowtag);
             h1 += k;
-            h2 += ai_mix(k ^ 0xD6E8FEB86659FD93ull);
+            h2 += (k >> 32) * (k & 0xffffffffull);      // (second sum: the product of the halves of the mixed word; a full second mix was half of the kernel)
         });
     }
     if (tid == 0 && blockIdx.y == 0) { h1 += ai_mix((unsigned long long)n + 0x4444444444444444ull); h2 += ai_mix((unsigned long long)n ^ 0x7777777777777777ull); }
@@ -1811,7 +1811,7 @@ __global__ __launch_bounds__(256) void ce_hash_kernel(CeIn v, unsigned long long
     ce_walk<false>(v, v.ae0 + b, 0, tid, 256, [&](unsigned long long w, unsigned long long pos) {
         const unsigned long long k = ai_mix(w + 0x9E3779B97F4A7C15ull * (pos + 1));
         h1 += k;
-        h2 += ai_mix(k ^ 0xD6E8FEB86659FD93ull);
+        h2 += (k >> 32) * (k & 0xffffffffull);      // (second sum: the product of the halves of the mixed word; a full second mix was half of the kernel)
     });
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64); }

@@ -910,17 +910,47 @@ __device__ inline unsigned long long dd_word(const DdSource &v, int b, long idx)
     if (idx < 3 * n) return v.x0c ? (unsigned long long)__double_as_longlong(v.x0c[vo + (idx - 2 * n)]) : 0ull;
     return idx == 3 * n ? (unsigned long long)n : (unsigned long long)bw;
 }
+// kind 0, the two long arrays of a matrix (values, then columns): four words per thread and trip, their loads requested
+// together (dd_word's chain of branches kept one load in flight per thread).  fn(word, idx) sees every word of [0, 2 nr).
+template <class F>
+__device__ inline void dd_rows_words(const DdSource &v, int b, long start, long stride, F fn) {
+    const long nr = (long)v.ns[b] * v.RW;
+    const double *rv = v.rvals + (size_t)v.voff[b] * v.RW;
+    const short *rc = v.rcols + (size_t)v.voff[b] * v.RW;
+    for (long i0 = start; i0 < nr; i0 += 4 * stride) {
+        double x[4];
+        short c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i = min(i0 + u * stride, nr - 1);
+            x[u] = rv[i];
+            c[u] = rc[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * stride < nr) {
+                fn((unsigned long long)__double_as_longlong(x[u]), i0 + u * stride);
+                fn((unsigned long long)(unsigned short)c[u], nr + i0 + u * stride);
+            }
+    }
+}
 // grid (matrices, y): partial 128-bit sums of the mixed (word, position) pairs, added into out[2 b], out[2 b + 1] (zeroed)
 __global__ __launch_bounds__(256) void dd_hash_kernel(DdSource v, unsigned long long *__restrict__ out) {
     __shared__ unsigned long long red[2][4];
     const int b = blockIdx.x, tid = threadIdx.x;
     const long cnt = dd_count(v, b);
     unsigned long long h1 = 0, h2 = 0;
-    for (long idx = (long)blockIdx.y * 256 + tid; idx < cnt; idx += 256l * gridDim.y) {
-        const unsigned long long k = dd_mix(dd_word(v, b, idx) + 0x9E3779B97F4A7C15ull * (unsigned long long)(idx + 1));
+    auto add = [&](unsigned long long w, long idx) {
+        const unsigned long long k = dd_mix(w + 0x9E3779B97F4A7C15ull * (unsigned long long)(idx + 1));
         h1 += k;      // (sums: independent of the order the words are visited in)
-        h2 += dd_mix(k ^ 0xD6E8FEB86659FD93ull);
+        h2 += (k >> 32) * (k & 0xffffffffull);      // (second sum: the product of the halves of the mixed word; a full second mix was half of the kernel)
+    };
+    long first = 0;
+    if (v.kind == 0) {
+        dd_rows_words(v, b, (long)blockIdx.y * 256 + tid, 256l * gridDim.y, add);
+        first = 2l * v.ns[b] * v.RW;      // (the short tail -- row order, n -- through dd_word)
     }
+    for (long idx = first + (long)blockIdx.y * 256 + tid; idx < cnt; idx += 256l * gridDim.y) add(dd_word(v, b, idx), idx);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64); }
     if ((tid & 63) == 0) { red[0][tid >> 6] = h1; red[1][tid >> 6] = h2; }
@@ -937,7 +967,28 @@ __global__ __launch_bounds__(256) void dd_verify_kernel(DdSource v, const int *_
     const long cnt = dd_count(v, b);
     if (cnt != dd_count(v, r0)) { if (tid == 0) differ[b] = 1; return; }
     int bad = 0;
-    for (long idx = (long)blockIdx.y * 256 + tid; idx < cnt; idx += 256l * gridDim.y) bad |= dd_word(v, b, idx) != dd_word(v, r0, idx);
+    long first = 0;
+    if (v.kind == 0) {      // (the two long arrays four words at a time, both matrices' loads in flight together)
+        const long nr = (long)v.ns[b] * v.RW, stride = 256l * gridDim.y;
+        const double *rv = v.rvals + (size_t)v.voff[b] * v.RW, *rv0 = v.rvals + (size_t)v.voff[r0] * v.RW;
+        const short *rc = v.rcols + (size_t)v.voff[b] * v.RW, *rc0 = v.rcols + (size_t)v.voff[r0] * v.RW;
+        for (long i0 = (long)blockIdx.y * 256 + tid; i0 < nr; i0 += 4 * stride) {
+            long long x[4], y[4];
+            short c[4], d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long i = min(i0 + u * stride, nr - 1);
+                x[u] = __double_as_longlong(rv[i]);
+                y[u] = __double_as_longlong(rv0[i]);
+                c[u] = rc[i];
+                d[u] = rc0[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bad |= (x[u] != y[u]) | (c[u] != d[u]);
+        }
+        first = 2 * nr;
+    }
+    for (long idx = first + (long)blockIdx.y * 256 + tid; idx < cnt; idx += 256l * gridDim.y) bad |= dd_word(v, b, idx) != dd_word(v, r0, idx);
     if (bad) differ[b] = 1;
 }
 // list[q] = a matrix of the batch, blobs[q] = where its words go / what they are compared with (differ[q] = 1: not the same)
@@ -1044,7 +1095,7 @@ __global__ __launch_bounds__(256) void dd_hash_list_kernel(DdSource v, const int
     for (long idx = (long)blockIdx.y * 256 + tid; idx < cnt; idx += 256l * gridDim.y) {
         const unsigned long long k = dd_mix(dd_word(v, b, idx) + 0x9E3779B97F4A7C15ull * (unsigned long long)(idx + 1));
         h1 += k;
-        h2 += dd_mix(k ^ 0xD6E8FEB86659FD93ull);
+        h2 += (k >> 32) * (k & 0xffffffffull);      // (second sum: the product of the halves of the mixed word; a full second mix was half of the kernel)
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64); }

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void mis_hash_kernel(MisIn v, int nm, unsigned
     mis_walk<false>(v, m, 0, lane, [&](unsigned long long w, unsigned long long pos) {
         const unsigned long long k = mi_mix(w + 0x9E3779B97F4A7C15ull * (pos + 1));
         h1 += k;
-        h2 += mi_mix(k ^ 0xD6E8FEB86659FD93ull);
+        h2 += (k >> 32) * (k & 0xffffffffull);      // (second sum: the product of the halves of the mixed word; a full second mix was half of the kernel)
     });
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64); }
