@@ -382,6 +382,14 @@ __global__ __launch_bounds__(256) void p_count_kernel(int ND, const int *__restr
     if (i < ND) cnt[i] = k[mises[i]];
 }
 
+__global__ __launch_bounds__(256) void r_len_kernel(int nm, const int *__restrict__ mis2d_I, const int *__restrict__ k,
+                                                    const int *__restrict__ coloff, int *__restrict__ len) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= nm) return;
+    const int r = mis2d_I[m + 1] - mis2d_I[m], c0 = coloff[m];
+    for (int v = 0; v < k[m]; ++v) len[c0 + v] = r;
+}
+
 // exclusive scan of ints, three small kernels (tile = 1024); OUT = int, or roff_t for the row offsets of an
 // operator (counts are int, their running sum may pass 2^31)
 template <class OUT>
@@ -517,13 +525,9 @@ void build_P_R(hipStream_t s, const DevRelations &rel, const Relations &hrel,
     const int ND = hrel.ND;
     int nc = 0;
     int64_t nnz = 0;
-    std::vector<roff_t> r_rowptr;
-    r_rowptr.push_back(0);
     for (int m = 0; m < hrel.num_mises; ++m) {
-        const int r = hrel.mis_to_dof.row_size(m);
         nc += h_k[m];
-        nnz += (int64_t)h_k[m] * r;
-        for (int v = 0; v < h_k[m]; ++v) r_rowptr.push_back(r_rowptr.back() + r);
+        nnz += (int64_t)h_k[m] * hrel.mis_to_dof.row_size(m);
     }
     P.nrows = ND; P.ncols = nc; P.nnz = nnz;
     P.rowptr.alloc((size_t)ND + 1);
@@ -539,7 +543,16 @@ void build_P_R(hipStream_t s, const DevRelations &rel, const Relations &hrel,
                        P.col.p, P.val.p);
     P.lanes_per_row = pick_lanes_per_row(nnz, ND);
     R.nrows = nc; R.ncols = ND; R.nnz = nnz;
-    R.rowptr.from_host(r_rowptr, s);
+    {   // row (m, v) of R has the dofs of MIS m: lengths and their running sum on the device (the host loop appended half a
+        // million offsets to a vector and uploaded it between the SVDs and the fill kernels)
+        DBuf<int> len((size_t)std::max(nc, 1));
+        R.rowptr.alloc((size_t)nc + 1);
+        if (hrel.num_mises)
+            hipLaunchKernelGGL(r_len_kernel, dim3(div_up(hrel.num_mises, 256)), dim3(256), 0, s, hrel.num_mises, rel.mis2d_I.p, d_k,
+                               d_coloff, len.p);
+        if (nc > 0) exclusive_scan_off(s, nc, len.p, R.rowptr.p);
+        else SA_HIP_CHECK(hipMemsetAsync(R.rowptr.p, 0, sizeof(roff_t), s));
+    }
     R.col.alloc((size_t)nnz);
     R.val.alloc((size_t)nnz);
     if (hrel.num_mises)
