@@ -365,14 +365,18 @@ def main():
     t0 = time.perf_counter()
     marks = [t0]
     splits = []
+    closes = []
     for i in range(args.steps):
         h, x, its, conv, hist = one_step(capi, prob, params, group=grp)
+        tc = time.perf_counter()
         if i < args.steps - 1:
             h.close()
+        closes.append(1e3 * (time.perf_counter() - tc))
         marks.append(time.perf_counter())      # (a step ends with the iteration count on the host: no extra synchronisation)
         splits.append(getattr(one_step, "last_split", (0.0, 0.0, 0.0)) + capi.pool_counts(reset=True)[:3:2])
     if rank == 0:
         sys.stderr.write("bench: wall ms of the timed steps: %s\n" % " ".join("%.1f" % (1e3 * (b - a)) for a, b in zip(marks, marks[1:])))
+        sys.stderr.write("bench: release of the hierarchy after those steps (ms): %s\n" % " ".join("%.1f" % c for c in closes))
         sys.stderr.write("bench: setup / solve calls of those steps (ms; (CPU ms of the process in the setup call) + hipMalloc / hipFree calls "
                          "of the block cache): %s\n" % " ".join("%.0f/%.0f(%.0f)+%d/%d" % sp for sp in splits))
     grp.barrier()

@@ -42,7 +42,7 @@ ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlo
 class Options(C.Structure):      # saamge_amd_options
     _fields_ = [(k, C.c_int) for k in ("eig_strict", "eig_certify", "eig_min_n", "eig_force_fallback", "eig_dense_only",
                                        "eig_dense_one_stage", "eig_nullcheck", "eig_keep_inertia_factor", "band_assembly",
-                                       "eig_dedupe", "eig_outer_panels", "overlap", "sell", "spmv_sell", "debug")]
+                                       "eig_dedupe", "eig_outer_panels", "overlap", "sell", "spmv_sell", "debug", "host_heap_pad_mb")]
 
 
 class Params(C.Structure):

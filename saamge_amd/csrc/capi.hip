@@ -45,6 +45,7 @@ static void options_to_c(const Options &o, saamge_amd_options *c) {
     c->eig_force_fallback = o.eig_force_fallback; c->eig_dense_only = o.eig_dense_only; c->eig_dense_one_stage = o.eig_dense_one_stage;
     c->eig_nullcheck = o.eig_nullcheck; c->eig_keep_inertia_factor = o.eig_keep_inertia_factor; c->band_assembly = o.band_assembly;
     c->eig_dedupe = o.eig_dedupe; c->eig_outer_panels = o.eig_outer_panels; c->overlap = o.overlap; c->sell = o.sell; c->spmv_sell = o.spmv_sell; c->debug = o.debug;
+    c->host_heap_pad_mb = o.host_heap_pad_mb;
 }
 void saamge_amd_options_default(saamge_amd_options *o) { options_to_c(Options(), o); }
 void saamge_amd_get_options(saamge_amd_options *o) { options_to_c(options(), o); }
@@ -54,6 +55,7 @@ void saamge_amd_set_options(const saamge_amd_options *c) {
     o.eig_force_fallback = c->eig_force_fallback; o.eig_dense_only = c->eig_dense_only; o.eig_dense_one_stage = c->eig_dense_one_stage;
     o.eig_nullcheck = c->eig_nullcheck; o.eig_keep_inertia_factor = c->eig_keep_inertia_factor; o.band_assembly = c->band_assembly;
     o.eig_dedupe = c->eig_dedupe; o.eig_outer_panels = c->eig_outer_panels; o.overlap = c->overlap; o.sell = c->sell; o.spmv_sell = c->spmv_sell; o.debug = c->debug;
+    o.host_heap_pad_mb = c->host_heap_pad_mb;
 }
 
 void saamge_amd_params_default(saamge_amd_params *p) {
@@ -102,6 +104,7 @@ int saamge_amd_memcpy(void *dst, const void *src, long long bytes) {
 
 static Params convert_params(const saamge_amd_params *params, void *stream) {
     saamge_amd_set_options(&params->options);
+    host_heap_policy();
     Params p;
     p.num_coarsenings = params->num_coarsenings;
     SA_REQUIRE(p.num_coarsenings >= 1 && p.num_coarsenings < MAX_LEVELS, "bad num_coarsenings");

@@ -103,9 +103,13 @@ struct Options {
     int sell = 31;                    // bit 0 coded slices at all, 1 pair coding, 2 short-chain kernel path, 3 operator-level dictionary, 4 node blocks, 5 (off) coded smoother diagonal
     int spmv_sell = 0;                // saamge_amd_spmv / spmv64 build and use the SELL copy
     int debug = 0;                    // bit 0 iteration traces of the few-eigenpairs path, 1 operator format census, 2 level tags in the kernel profile
+    int host_heap_pad_mb = 1024;      // glibc keeps this much freed heap instead of trimming it after every hierarchy (0: allocator left alone)
 };
+// Applied once, by the first hierarchy of the process (capi.hip): see Options::host_heap_pad_mb and DESIGN.md section 7.0.
+void host_heap_policy();
 Options &options();
 bool env_timing();      // SAAMGE_AMD_TIMING
+bool env_timing_host(); // SAAMGE_AMD_TIMING=host
 bool env_serial();      // SAAMGE_AMD_SERIAL: no worker threads in the setup (counter passes)
 
 // ---- device memory: caching allocator behind every DBuf -----------------------------------

@@ -37,15 +37,15 @@ static std::vector<double> sas_poly_roots(int nu) {
 
 // SAAMGE_AMD_TIMING=1 prints host-side phase times (the reference's "TIMING:" lines)
 struct PhaseTimer {
-    bool on;
+    bool on, host;
     hipStream_t s;
     std::chrono::steady_clock::time_point t0;
-    explicit PhaseTimer(hipStream_t st) : on(env_timing()), s(st) {
+    explicit PhaseTimer(hipStream_t st) : on(env_timing() || env_timing_host()), host(env_timing_host()), s(st) {
         t0 = std::chrono::steady_clock::now();
     }
     void lap(const char *what, int lev) {
         if (!on) return;
-        (void)hipStreamSynchronize(s);
+        if (!host) (void)hipStreamSynchronize(s);
         auto t1 = std::chrono::steady_clock::now();
         std::fprintf(stderr, "TIMING: level %d %-28s %9.3f ms\n", lev, what,
                      std::chrono::duration<double, std::milli>(t1 - t0).count());

@@ -10,6 +10,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
+#include <malloc.h>
 #include <functional>
 #include <thread>
 #include <unordered_map>
@@ -160,8 +161,26 @@ Options &options() {
     return o;
 }
 bool env_timing() {
-    static const bool v = std::getenv("SAAMGE_AMD_TIMING") != nullptr;
+    static const bool v = std::getenv("SAAMGE_AMD_TIMING") != nullptr && std::getenv("SAAMGE_AMD_TIMING")[0] != 'h';
     return v;
+}
+bool env_timing_host() {      // SAAMGE_AMD_TIMING=host: the phases' host times WITHOUT synchronising the stream at their ends
+    static const bool v = std::getenv("SAAMGE_AMD_TIMING") != nullptr && std::getenv("SAAMGE_AMD_TIMING")[0] == 'h';
+    return v;
+}
+// The setup builds some tens of MB of host tables per hierarchy in std::vectors and releases them with the hierarchy.  glibc
+// serves such blocks from anonymous mappings at first, but every mapped block that is freed raises its mmap threshold (up
+// to 32 MB), after which they come from the heap -- whose top is then returned to the kernel at every release and grown
+// again by the next hierarchy.  On MI355X boxes that trimming costs far more than its system calls: the first kernel of
+// the next setup starts ~20 ms late (the GPU trace shows the queue idle with the kernel submitted; tools/ and DESIGN.md
+// section 7.0: 127 -> 150-160 ms per setup in three of four processes, gone with MALLOC_TOP_PAD_ set).  Any mallopt call
+// also freezes the sliding threshold, so the big tables keep their own mappings.
+void host_heap_policy() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const int mb = options().host_heap_pad_mb;
+        if (mb > 0) (void)mallopt(M_TOP_PAD, (int)std::min<long>((long)mb << 20, 0x7ff00000l));
+    });
 }
 bool env_serial() {
     static const bool v = std::getenv("SAAMGE_AMD_SERIAL") != nullptr;

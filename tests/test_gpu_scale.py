@@ -155,7 +155,7 @@ def test_coarse_level_switches_give_the_same_hierarchy():
 
 @pytest.mark.parametrize("flip", [
     {"eig_min_n": 0}, {"eig_nullcheck": 0}, {"eig_keep_inertia_factor": 0}, {"band_assembly": 0}, {"overlap": 0},
-    {"eig_outer_panels": 2}, {"eig_outer_panels": 4}, {"eig_dedupe": 0},
+    {"eig_outer_panels": 2}, {"eig_outer_panels": 4}, {"eig_dedupe": 0}, {"host_heap_pad_mb": 0},
     {"sell": 0}, {"sell": 1}, {"sell": 3}, {"sell": 31 & ~4}, {"sell": 63}, {"eig_force_fallback": 7},
     {"eig_dense_one_stage": 1, "_eigensolver": "dense"}, {"eig_certify": 0}])
 def test_every_remaining_option_flipped_gives_the_golden(flip):
