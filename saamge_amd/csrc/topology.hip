@@ -160,14 +160,16 @@ Options &options() {
     static Options o;
     return o;
 }
-bool env_timing() {
-    static const bool v = std::getenv("SAAMGE_AMD_TIMING") != nullptr && std::getenv("SAAMGE_AMD_TIMING")[0] != 'h';
+static int timing_mode() {      // 0 off, 1 SAAMGE_AMD_TIMING set, 2 SAAMGE_AMD_TIMING=host
+    static const int v = [] {
+        const char *e = std::getenv("SAAMGE_AMD_TIMING");
+        return !e ? 0 : (e[0] == 'h' ? 2 : 1);
+    }();
     return v;
 }
-bool env_timing_host() {      // SAAMGE_AMD_TIMING=host: the phases' host times WITHOUT synchronising the stream at their ends
-    static const bool v = std::getenv("SAAMGE_AMD_TIMING") != nullptr && std::getenv("SAAMGE_AMD_TIMING")[0] == 'h';
-    return v;
-}
+bool env_timing() { return timing_mode() == 1; }
+// SAAMGE_AMD_TIMING=host: the phases' host times WITHOUT synchronising the stream at their ends
+bool env_timing_host() { return timing_mode() == 2; }
 // The setup builds some tens of MB of host tables per hierarchy in std::vectors and releases them with the hierarchy.  glibc
 // serves such blocks from anonymous mappings at first, but every mapped block that is freed raises its mmap threshold (up
 // to 32 MB), after which they come from the heap -- whose top is then returned to the kernel at every release and grown
