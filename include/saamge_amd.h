@@ -59,12 +59,12 @@ typedef struct saamge_amd_options {
     int spmv_sell;                /* 0.  1: saamge_amd_spmv / spmv64 build and use the SELL copy (tests of the SELL kernels) */
     int debug;                    /* 0: bit 0 iteration traces of the few-eigenpairs path, bit 1 operator format census on stderr,
                                    * bit 2 level tags in the kernel profile */
-    int host_heap_pad_mb;         /* 1024: the first hierarchy of the process asks glibc (mallopt M_TOP_PAD) to keep this many MiB
-                                   * of freed heap instead of returning the top of the heap to the kernel after every hierarchy and
-                                   * growing it again for the next.  Where glibc's sliding mmap threshold had moved the setup's
-                                   * host tables (some tens of MB per hierarchy) onto the heap, that trimming stalled the GPU's
-                                   * queues for ~20 ms at the start of the next setup (measured: DESIGN.md section 7.0).
-                                   * 0: the allocator is left alone. */
+    int host_heap_pad_mb;         /* 256: the first hierarchy of the process asks glibc (mallopt) never to trim its heap, to serve
+                                   * blocks up to 32 MB from it and to grow it in steps of this many MiB.  The setup's host tables
+                                   * (some tens of MB per hierarchy, some of them copied to and from the device as pageable
+                                   * memory) otherwise go back to the kernel with every hierarchy; unmapping pages the GPU driver
+                                   * has registered stalled the process's queues for ~20 ms at the start of the next setup in
+                                   * half of the processes (measured: DESIGN.md section 7.0).  0: the allocator is left alone. */
 } saamge_amd_options;
 void saamge_amd_options_default(saamge_amd_options *o);
 void saamge_amd_set_options(const saamge_amd_options *o);

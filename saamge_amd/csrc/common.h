@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -103,7 +104,7 @@ struct Options {
     int sell = 31;                    // bit 0 coded slices at all, 1 pair coding, 2 short-chain kernel path, 3 operator-level dictionary, 4 node blocks, 5 (off) coded smoother diagonal
     int spmv_sell = 0;                // saamge_amd_spmv / spmv64 build and use the SELL copy
     int debug = 0;                    // bit 0 iteration traces of the few-eigenpairs path, 1 operator format census, 2 level tags in the kernel profile
-    int host_heap_pad_mb = 1024;      // glibc keeps this much freed heap instead of trimming it after every hierarchy (0: allocator left alone)
+    int host_heap_pad_mb = 256;       // > 0: glibc never trims its heap, serves blocks up to 32 MB from it and grows it in steps of this size (0: allocator left alone)
 };
 // Applied once, by the first hierarchy of the process (capi.hip): see Options::host_heap_pad_mb and DESIGN.md section 7.0.
 void host_heap_policy();
@@ -184,10 +185,24 @@ struct DBuf {
     template <class V>
     void from_host(const V &v, hipStream_t s = 0) {
         alloc(v.size());
-        if (n) {
-            SA_HIP_CHECK(hipMemcpyAsync(p, v.data(), n * sizeof(T), hipMemcpyHostToDevice, s));
-            SA_HIP_CHECK(hipStreamSynchronize(s));  // v may be a temporary
+        if (!n) return;
+        const size_t bytes = n * sizeof(T);
+        // A large pageable vector goes through a page-locked block of the library's own (never returned to the system): handed
+        // over as it is, the runtime registers the caller's pages with the GPU for the transfer and keeps the registration
+        // cached -- pages that go back to the kernel when the vector dies (host_heap_policy, topology.hip).
+        const bool pinned = std::is_same<typename V::allocator_type, PinnedAlloc<typename V::value_type>>::value;
+        if (!pinned && bytes >= (256u << 10)) {
+            void *stage = pinned_alloc(bytes);
+            std::memcpy(stage, v.data(), bytes);
+            const hipError_t e = hipMemcpyAsync(p, stage, bytes, hipMemcpyHostToDevice, s);
+            const hipError_t e2 = hipStreamSynchronize(s);
+            pinned_free(stage, bytes);
+            SA_HIP_CHECK(e);
+            SA_HIP_CHECK(e2);
+            return;
         }
+        SA_HIP_CHECK(hipMemcpyAsync(p, v.data(), bytes, hipMemcpyHostToDevice, s));
+        SA_HIP_CHECK(hipStreamSynchronize(s));  // v may be a temporary
     }
     hvec<T> to_host(hipStream_t s = 0) const {
         hvec<T> v(n);

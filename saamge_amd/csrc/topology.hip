@@ -170,18 +170,27 @@ static int timing_mode() {      // 0 off, 1 SAAMGE_AMD_TIMING set, 2 SAAMGE_AMD_
 bool env_timing() { return timing_mode() == 1; }
 // SAAMGE_AMD_TIMING=host: the phases' host times WITHOUT synchronising the stream at their ends
 bool env_timing_host() { return timing_mode() == 2; }
-// The setup builds some tens of MB of host tables per hierarchy in std::vectors and releases them with the hierarchy.  glibc
-// serves such blocks from anonymous mappings at first, but every mapped block that is freed raises its mmap threshold (up
-// to 32 MB), after which they come from the heap -- whose top is then returned to the kernel at every release and grown
-// again by the next hierarchy.  On MI355X boxes that trimming costs far more than its system calls: the first kernel of
-// the next setup starts ~20 ms late (the GPU trace shows the queue idle with the kernel submitted; tools/ and DESIGN.md
-// section 7.0: 127 -> 150-160 ms per setup in three of four processes, gone with MALLOC_TOP_PAD_ set).  Any mallopt call
-// also freezes the sliding threshold, so the big tables keep their own mappings.
+// The setup builds some tens of MB of host tables per hierarchy in std::vectors, copies some of them to and from the device
+// (pageable memory: the runtime registers the pages with the GPU for the transfer and keeps such registrations cached) and
+// releases them with the hierarchy.  What glibc then does with the memory decides how the NEXT setup starts:
+//  * from the heap, with the default trimming: the top of the heap goes back to the kernel at every release and is grown
+//    again by the next hierarchy.  Unmapping pages the GPU driver still knows invalidates its registration, and the
+//    process's queues are stopped and restored: the first kernel of the next setup starts ~20 ms late (GPU trace: the queue
+//    idle with the kernel submitted; 127 -> 150-160 ms per setup in half of the processes -- those in which glibc's sliding
+//    mmap threshold had moved the tables onto the heap);
+//  * from anonymous mappings of their own (the threshold frozen at its initial 128 KB): mapped and unmapped at recurring
+//    addresses under the runtime's registration cache -- measured once: GPU memory access faults;
+//  * from a heap that is never trimmed: neither.  That is what this asks for, once per process: blocks up to glibc's
+//    maximum of 32 MB from the heap, no trimming, the heap grown in steps of host_heap_pad_mb.
+// MPI libraries with registration caches set the same three parameters for the same reason.  DESIGN.md section 7.0.
 void host_heap_policy() {
     static std::once_flag once;
     std::call_once(once, [] {
         const int mb = options().host_heap_pad_mb;
-        if (mb > 0) (void)mallopt(M_TOP_PAD, (int)std::min<long>((long)mb << 20, 0x7ff00000l));
+        if (mb <= 0) return;
+        (void)mallopt(M_MMAP_THRESHOLD, 32 << 20);
+        (void)mallopt(M_TRIM_THRESHOLD, 0x7ff00000);
+        (void)mallopt(M_TOP_PAD, (int)std::min<long>((long)mb << 20, 0x7ff00000l));
     });
 }
 bool env_serial() {
