@@ -27,6 +27,23 @@ def test_params_struct_matches_header_defaults():
     assert p.world == 1 and p.rank == 0
 
 
+def test_options_struct_matches_the_header_field_by_field():
+    """saamge_amd_options: the ctypes mirror lists the header's fields in the header's order, and the library's defaults are the
+    documented ones (the struct is embedded in saamge_amd_params: a field out of place shifts everything behind it)."""
+    import ctypes as C
+    from saamge_amd import capi
+    hdr = open(os.path.join(ROOT, "include", "saamge_amd.h")).read()
+    body = hdr[hdr.index("typedef struct saamge_amd_options {"):hdr.index("} saamge_amd_options;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\bint\s+([a-z_0-9]+)\s*;", body)
+    assert fields == [f for f, _ in capi.Options._fields_]
+    o = capi.Options()
+    capi.load().saamge_amd_options_default(C.byref(o))
+    got = {f: getattr(o, f) for f in fields}
+    assert got["eig_dedupe"] == 1 and got["eig_outer_panels"] == 8 and got["overlap"] == 15 and got["sell"] == 31
+    assert got["host_heap_pad_mb"] == 256 and got["eig_min_n"] == 64 and got["debug"] == 0 and got["eig_strict"] == 0
+
+
 def test_product_has_no_oracle_dependency():
     """The shipped package must not import the oracle (test infrastructure only)."""
     pkg = os.path.join(ROOT, "saamge_amd")
