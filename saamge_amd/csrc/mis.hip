@@ -678,6 +678,7 @@ bool coarse_e2d_device(hipStream_t s, const DevRelations &rel, const Relations &
 // ---------------------------------------------------------------------------------------
 constexpr int RAP_NT = 256;
 constexpr int RAP_HASH = 2048;
+constexpr int RAP_SMALL_ROWS = 64;     // MISes of at most this many dofs take a one-wavefront workgroup in the numeric kernel
 
 // symbolic: neighbour MISes (with k > 0) of every MIS; pass 0 counts, pass 1 writes the
 // ascending list.
@@ -768,15 +769,21 @@ __global__ __launch_bounds__(256) void rap_unstage_kernel(int nm, int cap, const
     if (m < nm && t < nbr_ptr[m + 1] - nbr_ptr[m]) nbr[nbr_ptr[m] + t] = stage[i];
 }
 
-__global__ __launch_bounds__(RAP_NT) void rap_numeric_kernel(
-    int m_first, const int *__restrict__ mis2d_I, const int *__restrict__ mis2d_J, const roff_t *__restrict__ Arow,
+// NT threads per workgroup; list != nullptr: the workgroups take the MISes list[0 .. grid) instead of m_first + block.
+// (A workgroup costs tens of microseconds whatever its MIS holds -- a dozen rounds of dependent gathers and as many
+// barriers -- and a CU has room for eight workgroups of four wavefronts: the MISes of at most RAP_SMALL_ROWS dofs, seven
+// eighths of the MISes of a hexahedral mesh (vertices, edges and faces of the agglomerates), take one wavefront each instead,
+// with 8 KB of LDS: more of them resident, and a face's 49 rows on 64 lanes instead of 256.  Same code, same order of every sum.)
+template <int NT>
+__global__ __launch_bounds__(NT) void rap_numeric_kernel(
+    const int *__restrict__ list, int m_first, const int *__restrict__ mis2d_I, const int *__restrict__ mis2d_J, const roff_t *__restrict__ Arow,
     const int *__restrict__ Acol, const double *__restrict__ Aval, const int *__restrict__ mises,
     const int *__restrict__ row_in_mis, const int *__restrict__ k, const int *__restrict__ coloff,
     const int64_t *__restrict__ u_off, const double *__restrict__ U,
     const int *__restrict__ nbr_ptr, const int *__restrict__ nbr, const roff_t *__restrict__ crowptr,
     int *__restrict__ ccol, double *__restrict__ cval, int lds_doubles) {
     extern __shared__ __align__(16) double lds[];
-    const int m1 = m_first + blockIdx.x;
+    const int m1 = list ? list[blockIdx.x] : m_first + (int)blockIdx.x;
     const int k1 = k[m1];
     if (k1 == 0) return;
     const int tid = threadIdx.x;
@@ -794,7 +801,7 @@ __global__ __launch_bounds__(RAP_NT) void rap_numeric_kernel(
     int *nbl = pos + nn + 1;                  // [nn]
     int *kk = nbl + nn;                       // [nn]
     int *rr = kk + nn;                        // [nn]
-    for (int t = tid; t < nn; t += RAP_NT) {
+    for (int t = tid; t < nn; t += NT) {
         const int m2 = nb[t];
         nbl[t] = m2;
         kk[t] = k[m2];
@@ -818,7 +825,7 @@ __global__ __launch_bounds__(RAP_NT) void rap_numeric_kernel(
     const int RC = rows_total - KC;
     double *T = acc + (size_t)KC * ncol;
     // column indices of the k1 output rows
-    for (int idx = tid; idx < k1 * ncol; idx += RAP_NT) {
+    for (int idx = tid; idx < k1 * ncol; idx += NT) {
         const int v1 = idx / ncol, cc = idx % ncol;
         int lo = 0, hi = nn;  // neighbour owning local column cc
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pos[mid] <= cc) lo = mid; else hi = mid; }
@@ -827,13 +834,13 @@ __global__ __launch_bounds__(RAP_NT) void rap_numeric_kernel(
     for (int v0 = 0; v0 < k1; v0 += KC) {
         const int kc = min(KC, k1 - v0);
         __syncthreads();
-        for (int i = tid; i < kc * ncol; i += RAP_NT) acc[i] = 0.0;
+        for (int i = tid; i < kc * ncol; i += NT) acc[i] = 0.0;
         for (int c0 = 0; c0 < r1; c0 += RC) {
             const int rc = min(RC, r1 - c0);
             __syncthreads();
-            for (int i = tid; i < rc * ncol; i += RAP_NT) T[i] = 0.0;
+            for (int i = tid; i < rc * ncol; i += NT) T[i] = 0.0;
             __syncthreads();
-            for (int il = tid; il < rc; il += RAP_NT) {
+            for (int il = tid; il < rc; il += NT) {
                 const int g = dofs[c0 + il];
                 double *Trow = T + (size_t)il * ncol;
                 // four entries of the row at a time: their gather chains (column -> MIS -> slot -> row in the MIS ->
@@ -875,7 +882,7 @@ __global__ __launch_bounds__(RAP_NT) void rap_numeric_kernel(
                 }
             }
             __syncthreads();
-            for (int idx = tid; idx < kc * ncol; idx += RAP_NT) {
+            for (int idx = tid; idx < kc * ncol; idx += NT) {
                 const int v1 = idx / ncol, cc = idx % ncol;
                 double sum = acc[idx];
                 const double *u = U1 + (size_t)(v0 + v1) * r1 + c0;
@@ -884,7 +891,7 @@ __global__ __launch_bounds__(RAP_NT) void rap_numeric_kernel(
             }
         }
         __syncthreads();
-        for (int idx = tid; idx < kc * ncol; idx += RAP_NT) {
+        for (int idx = tid; idx < kc * ncol; idx += NT) {
             const int v1 = idx / ncol, cc = idx % ncol;
             cval[crowptr[coloff[m1] + v0 + v1] + cc] = acc[idx];
         }
@@ -935,6 +942,9 @@ void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, cons
     std::vector<roff_t> crow((size_t)nc + 1, 0);
     int64_t nnz = 0;
     size_t need_max = 0, small_max = 0;
+    // doubles of LDS a MIS wants in a one-wavefront workgroup: tables + its k output rows + all its rows of T, but no more than
+    // 8 KB unless k + 8 rows need it (the kernel walks the MIS's rows in chunks of what fits)
+    std::vector<int> small_need((size_t)nm, 0);
     for (int m = 0; m < nm; ++m) {
         if (h_k[m] == 0) continue;
         int ncol = 0;
@@ -949,6 +959,11 @@ void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, cons
         if (need > cap) need = std::max((size_t)(3 * h_cnt[m] + 2) + 2 * (size_t)ncol, std::min(need, cap));
         if (need > need_max) need_max = need;
         small_max = std::max(small_max, (size_t)(3 * h_cnt[m] + 2) + (size_t)(h_k[m] + 8) * ncol);
+        {
+            const size_t tables = (size_t)(3 * h_cnt[m] + 2);
+            const size_t all = tables + (size_t)(h_k[m] + hrel.mis_to_dof.row_size(m)) * ncol, floor8 = tables + (size_t)(h_k[m] + 8) * ncol;
+            small_need[m] = (int)std::min<size_t>(std::min(all, std::max((size_t)1024, floor8)), 1u << 30);
+        }
     }
     for (int i = 0; i < nc; ++i) crow[i + 1] += crow[i];
     // Blocks that fit 64 KiB in one pass get by with the k output rows + >= 8 rows of T per chunk of
@@ -957,12 +972,8 @@ void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, cons
     size_t lds_doubles = std::max((size_t)2048, small_max);
     if (need_max > 8192) lds_doubles = need_max;
     SA_REQUIRE(lds_doubles * 8 <= 160 * 1024, "RAP: MIS block too wide for LDS");
-    static bool attr = false;
-    if (!attr) {
-        SA_HIP_CHECK(hipFuncSetAttribute((const void *)rap_numeric_kernel,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
+    SA_HIP_CHECK(hipFuncSetAttribute((const void *)rap_numeric_kernel<RAP_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SA_HIP_CHECK(hipFuncSetAttribute((const void *)rap_numeric_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     Ac.nnz = nnz;
     Ac.rowptr.from_host(crow, s);
     Ac.col.alloc((size_t)nnz);
@@ -984,11 +995,31 @@ void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, cons
         m_lo = mb[rank];
         m_hi = mb[rank + 1];
     }
-    if (m_hi > m_lo)
-        hipLaunchKernelGGL(rap_numeric_kernel, dim3(m_hi - m_lo), dim3(RAP_NT), lds_doubles * 8, s, m_lo,
+    // the MISes of this rank's range in two lists: few dofs (one wavefront per MIS, the LDS those need), the others
+    std::vector<int> small_list, big_list;
+    size_t small_lds = 0;
+    for (int m = m_lo; m < m_hi; ++m) {
+        if (h_k[m] == 0) continue;
+        if (hrel.mis_to_dof.row_size(m) <= RAP_SMALL_ROWS && small_need[m] <= 2048) {
+            small_list.push_back(m);
+            small_lds = std::max(small_lds, (size_t)small_need[m]);
+        } else big_list.push_back(m);
+    }
+    DBuf<int> d_small, d_big;
+    d_small.from_host(small_list, s);
+    d_big.from_host(big_list, s);
+    if (!big_list.empty())
+        hipLaunchKernelGGL(rap_numeric_kernel<RAP_NT>, dim3((unsigned)big_list.size()), dim3(RAP_NT), lds_doubles * 8, s, d_big.p, 0,
                            rel.mis2d_I.p, rel.mis2d_J.p, A.rowptr.p, A.col.p, A.val.p, rel.mises.p,
                            rel.dof_row_in_mis.p, d_k, d_coloff, d_u_off, U, nbr_ptr.p, nbr.p, Ac.rowptr.p,
                            Ac.col.p, Ac.val.p, (int)lds_doubles);
+    if (!small_list.empty()) {
+        const size_t sl = std::max((size_t)256, small_lds);
+        hipLaunchKernelGGL(rap_numeric_kernel<64>, dim3((unsigned)small_list.size()), dim3(64), sl * 8, s, d_small.p, 0,
+                           rel.mis2d_I.p, rel.mis2d_J.p, A.rowptr.p, A.col.p, A.val.p, rel.mises.p,
+                           rel.dof_row_in_mis.p, d_k, d_coloff, d_u_off, U, nbr_ptr.p, nbr.p, Ac.rowptr.p,
+                           Ac.col.p, Ac.val.p, (int)sl);
+    }
     SA_HIP_CHECK(hipGetLastError());
     SA_HIP_CHECK(hipStreamSynchronize(s));  // nbr buffers are freed on return
     profiler().end(s, "rap", 12.0 * (double)(A.nnz + nnz) + 4.0 * A.nrows, 0.0);
