@@ -682,15 +682,20 @@ constexpr int RAP_SMALL_ROWS = 64;     // MISes of at most this many dofs take a
 
 // symbolic: neighbour MISes (with k > 0) of every MIS; pass 0 counts, pass 1 writes the
 // ascending list.
-__global__ __launch_bounds__(RAP_NT) void rap_symbolic_kernel(
-    int pass, const int *__restrict__ mis2d_I, const int *__restrict__ mis2d_J,
+// NT threads, tables of CAP slots; mlist != nullptr: the workgroups take the MISes mlist[0 .. grid).  The MISes of at most
+// RAP_SMALL_ROWS dofs take <64, 256>: one wavefront and 2 KB of tables instead of four and 16 KB (as in rap_numeric_kernel: a
+// workgroup costs tens of microseconds whatever its MIS holds, so what counts is how many are resident); one whose neighbours
+// do not fit 128 of those 256 slots reports cnt = -1 and is done again by <RAP_NT, RAP_HASH>.
+template <int NT, int CAP>
+__global__ __launch_bounds__(NT) void rap_symbolic_kernel(
+    const int *__restrict__ mlist, int pass, const int *__restrict__ mis2d_I, const int *__restrict__ mis2d_J,
     const roff_t *__restrict__ Arow, const int *__restrict__ Acol, const int *__restrict__ mises,
     const int *__restrict__ k, int *__restrict__ cnt, const int *__restrict__ nbr_ptr,
     int *__restrict__ nbr, int *__restrict__ err, int *__restrict__ stage = nullptr, int stage_cap = 0,
     int maxrow = 0) {
-    __shared__ int table[RAP_HASH];
+    __shared__ int table[CAP];
     __shared__ int nfound;
-    const int m1 = blockIdx.x;
+    const int m1 = mlist ? mlist[blockIdx.x] : (int)blockIdx.x;
     if (k[m1] == 0) {
         if (pass == 0 && threadIdx.x == 0) cnt[m1] = 0;
         return;
@@ -703,7 +708,7 @@ __global__ __launch_bounds__(RAP_NT) void rap_symbolic_kernel(
     // A larger MIS (a face or the interior of an agglomerate) could have many neighbours but on a mesh has a few
     // dozen: it starts with 256 slots and walks its rows again with the full table only if those fill up.
     __shared__ int overflow;
-    int HS = RAP_HASH;
+    int HS = CAP;
     if (maxrow > 0) {
         const long bound = 2l * r1 * maxrow;
         HS = 64;
@@ -711,10 +716,10 @@ __global__ __launch_bounds__(RAP_NT) void rap_symbolic_kernel(
     }
     const bool certain = maxrow > 0 && 2l * r1 * maxrow <= HS;     // the table cannot fill up
     for (;;) {
-        for (int i = threadIdx.x; i < HS; i += RAP_NT) table[i] = -1;
+        for (int i = threadIdx.x; i < HS; i += NT) table[i] = -1;
         if (threadIdx.x == 0) { nfound = 0; overflow = 0; }
         __syncthreads();
-        for (int il = threadIdx.x; il < r1; il += RAP_NT) {
+        for (int il = threadIdx.x; il < r1; il += NT) {
             const int g = dofs[il];
             for (roff_t q = Arow[g]; q < Arow[g + 1]; ++q) {
                 const int m2 = mises[Acol[q]];
@@ -731,10 +736,15 @@ __global__ __launch_bounds__(RAP_NT) void rap_symbolic_kernel(
         }
         __syncthreads();
         // (more than half full counts as full: the probe sequences get long, and the rank pass below is quadratic)
-        const bool again = HS < RAP_HASH && !certain && (overflow || 2 * nfound > HS);
+        const bool full = !certain && (overflow || 2 * nfound > HS);
+        const bool again = HS < CAP && full;
         __syncthreads();
+        if (CAP < RAP_HASH && full && !again) {      // (the small tables are not enough: left to the full-size kernel)
+            if (threadIdx.x == 0) cnt[m1] = -1;
+            return;
+        }
         if (!again) break;
-        HS = RAP_HASH;
+        HS = CAP;
     }
     if (pass == 0) {
         if (threadIdx.x == 0) cnt[m1] = nfound;
@@ -743,18 +753,18 @@ __global__ __launch_bounds__(RAP_NT) void rap_symbolic_kernel(
         if (!stage || nfound > stage_cap) return;
     }
     // compact the table into a short list, then rank inside the list and write in order
-    __shared__ int list[RAP_HASH];
+    __shared__ int list[CAP];
     __shared__ int nlist;
     if (threadIdx.x == 0) nlist = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < HS; i += RAP_NT) {
+    for (int i = threadIdx.x; i < HS; i += NT) {
         const int v = table[i];
         if (v >= 0) list[atomicAdd(&nlist, 1)] = v;
     }
     __syncthreads();
     const int nl = nlist;
     int *out = (pass == 0) ? stage + (size_t)m1 * stage_cap : nbr + nbr_ptr[m1];
-    for (int i = threadIdx.x; i < nl; i += RAP_NT) {
+    for (int i = threadIdx.x; i < nl; i += NT) {
         const int v = list[i];
         int rank = 0;
         for (int j = 0; j < nl; ++j) rank += (list[j] < v);
@@ -918,11 +928,38 @@ void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, cons
     profiler().begin(s);
     constexpr int STAGE_CAP = 64;
     DBuf<int> stage((size_t)nm * STAGE_CAP);
-    hipLaunchKernelGGL(rap_symbolic_kernel, dim3(nm), dim3(RAP_NT), 0, s, 0, rel.mis2d_I.p,
-                       rel.mis2d_J.p, A.rowptr.p, A.col.p, rel.mises.p, d_k, cnt.p, nullptr, nullptr, err.p, stage.p, STAGE_CAP,
-                       maxrow);
-    SA_HIP_CHECK(hipGetLastError());
+    {   // (two lists by the number of dofs, as for the numeric kernel below)
+        std::vector<int> sym_small, sym_big;
+        for (int m = 0; m < nm; ++m) (hrel.mis_to_dof.row_size(m) <= RAP_SMALL_ROWS ? sym_small : sym_big).push_back(m);
+        DBuf<int> d_sym_small, d_sym_big;
+        d_sym_small.from_host(sym_small, s);
+        d_sym_big.from_host(sym_big, s);
+        if (!sym_big.empty())
+            hipLaunchKernelGGL((rap_symbolic_kernel<RAP_NT, RAP_HASH>), dim3((unsigned)sym_big.size()), dim3(RAP_NT), 0, s, d_sym_big.p, 0,
+                               rel.mis2d_I.p, rel.mis2d_J.p, A.rowptr.p, A.col.p, rel.mises.p, d_k, cnt.p, nullptr, nullptr, err.p, stage.p,
+                               STAGE_CAP, maxrow);
+        if (!sym_small.empty())
+            hipLaunchKernelGGL((rap_symbolic_kernel<64, 256>), dim3((unsigned)sym_small.size()), dim3(64), 0, s, d_sym_small.p, 0,
+                               rel.mis2d_I.p, rel.mis2d_J.p, A.rowptr.p, A.col.p, rel.mises.p, d_k, cnt.p, nullptr, nullptr, err.p, stage.p,
+                               STAGE_CAP, maxrow);
+        SA_HIP_CHECK(hipGetLastError());
+        SA_HIP_CHECK(hipStreamSynchronize(s));      // (the lists are freed here)
+    }
     auto h_cnt = cnt.to_host(s);
+    {   // small MISes whose neighbours did not fit the small tables: once more, full size
+        std::vector<int> again;
+        for (int m = 0; m < nm; ++m)
+            if (h_cnt[m] < 0) again.push_back(m);
+        if (!again.empty()) {
+            DBuf<int> d_again;
+            d_again.from_host(again, s);
+            hipLaunchKernelGGL((rap_symbolic_kernel<RAP_NT, RAP_HASH>), dim3((unsigned)again.size()), dim3(RAP_NT), 0, s, d_again.p, 0,
+                               rel.mis2d_I.p, rel.mis2d_J.p, A.rowptr.p, A.col.p, rel.mises.p, d_k, cnt.p, nullptr, nullptr, err.p, stage.p,
+                               STAGE_CAP, maxrow);
+            SA_HIP_CHECK(hipGetLastError());
+            h_cnt = cnt.to_host(s);
+        }
+    }
     SA_REQUIRE(err.to_host(s)[0] == 0, "RAP: MIS neighbour table overflow");
     std::vector<int> h_nbr_ptr((size_t)nm + 1, 0);
     int cnt_max = 0;
@@ -933,7 +970,7 @@ void rap_mis(hipStream_t s, const DevRelations &rel, const Relations &hrel, cons
         hipLaunchKernelGGL(rap_unstage_kernel, dim3(div_up((long)nm * STAGE_CAP, 256)), dim3(256), 0, s, nm, STAGE_CAP, stage.p,
                            nbr_ptr.p, nbr.p);
     else
-        hipLaunchKernelGGL(rap_symbolic_kernel, dim3(nm), dim3(RAP_NT), 0, s, 1, rel.mis2d_I.p,
+        hipLaunchKernelGGL((rap_symbolic_kernel<RAP_NT, RAP_HASH>), dim3(nm), dim3(RAP_NT), 0, s, (const int *)nullptr, 1, rel.mis2d_I.p,
                            rel.mis2d_J.p, A.rowptr.p, A.col.p, rel.mises.p, d_k, cnt.p, nbr_ptr.p, nbr.p, err.p, (int *)nullptr, 0,
                            maxrow);
     SA_HIP_CHECK(hipGetLastError());
