@@ -445,8 +445,22 @@ __global__ __launch_bounds__(256) void sell_regular_codes_kernel(int ntiles, int
     }
 }
 
+// The few tiles the staging plan leaves out (an operator whose row count is not a multiple of 256: its last tile), done by the
+// trailing workgroups of sell_staged2_kernel -- what sell_tiles_kernel does in a launch of its own, 5 us behind every one of
+// the 456 smoother steps of the headline's solve for a single row.  Through sell_slice's general path (fast_ok = 0: the same
+// sums in the same order; its sixteen gathers in flight would take the kernel from 63 to 84 registers and from eight to six
+// workgroups per CU).
+struct SellLeftover {
+    int grid_main, n;            // workgroups of the staged tiles; tiles left over (0: none are done here)
+    const int *tiles;
+    const roff_t *sptr;
+    const int *col;
+    const double *val;
+    const int *ntab;
+    const unsigned *codes;
+};
 template <int MODE>
-__global__ __launch_bounds__(256) void sell_staged2_kernel(int nrows, int row0, int nblocks, int per_xcd, int stage_cap,
+__global__ __launch_bounds__(256) void sell_staged2_kernel(SellLeftover left, int nrows, int row0, int nblocks, int per_xcd, int stage_cap,
                                                            int ncols, int wq, const unsigned *__restrict__ codesR,
                                                            const int *__restrict__ tab, const double *__restrict__ vtab,
                                                            const int *__restrict__ tile_desc, const int2 *__restrict__ tile_seg,
@@ -457,6 +471,15 @@ __global__ __launch_bounds__(256) void sell_staged2_kernel(int nrows, int row0, 
                                                            const double *__restrict__ dtab = nullptr) {
     extern __shared__ __align__(16) double lds[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((int)blockIdx.x >= left.grid_main) {      // (a trailing workgroup: one of the tiles that are not staged)
+        const long lrow0 = (long)left.tiles[blockIdx.x - left.grid_main] * 256 - row0;      // the tile's first row, local to the range
+        if (lrow0 < 0 || lrow0 >= nrows) return;
+        const long trow = lrow0 + threadIdx.x;
+        const int slice = __builtin_amdgcn_readfirstlane((int)(trow >> 6));
+        sell_slice<MODE>((PairEntry *)lds + 64 * wv, nrows, row0, trow, slice, 0, left.sptr, left.col, left.val, left.ntab, tab, left.codes, x, y,
+                         b, dinv, scale, xrow, vtab);
+        return;
+    }
     PairEntry *lt = (PairEntry *)(lds + stage_cap);
     const int blk = per_xcd > 0 ? (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (blk >= nblocks || (long)blk * 256 + 256 > nrows) return;
@@ -1539,15 +1562,20 @@ static void launch_spmv(hipStream_t s, const DCsr &A, RowRange rr, const double 
         constexpr bool no_xcd = false;
         const int per_xcd = no_xcd ? 0 : div_up(nblocks, 8);
         const size_t lds_bytes = 8 * (size_t)A.sell_stage_cap + (A.sell_one_table ? 1 : 4) * 64 * sizeof(PairEntry);
-        if (A.sell_wq > 0)
-            hipLaunchKernelGGL((sell_staged2_kernel<MODE>), dim3(no_xcd ? nblocks : per_xcd * 8), dim3(256), lds_bytes, s, nrows, row0,
+        // (up to eight tiles that are not staged ride at the end of the staged kernel's grid instead of a launch of their own)
+        const int grid_main = no_xcd ? nblocks : per_xcd * 8;
+        const bool fold = A.sell_wq > 0 && A.sell_nunstaged > 0 && A.sell_nunstaged <= 8 && 8 * (size_t)A.sell_stage_cap >= 4 * 64 * sizeof(PairEntry);
+        if (A.sell_wq > 0) {
+            const SellLeftover left{grid_main, fold ? A.sell_nunstaged : 0, A.sell_unstaged.p, A.sell_ptr.p + row0 / 64, A.sell_col.p, A.sell_val.p,
+                                    A.sell_ntab.p, A.sell_code.p};
+            hipLaunchKernelGGL((sell_staged2_kernel<MODE>), dim3(grid_main + left.n), dim3(256), lds_bytes, s, left, nrows, row0,
                                nblocks, per_xcd, A.sell_stage_cap, A.ncols, A.sell_wq, A.sell_codeR.p, A.sell_tab.p, A.sell_vtab.p,
                                A.sell_tile_desc.p, A.sell_tile_seg.p, x, y, b, dinv, scale, xrow, dcode, (const double *)A.sell_dtab.p);
-        else
+        } else
         hipLaunchKernelGGL((sell_staged_kernel<MODE>), dim3(no_xcd ? nblocks : per_xcd * 8), dim3(256), lds_bytes, s, nrows, row0,
                            nblocks, per_xcd, A.sell_stage_cap, A.ncols, (int)A.sell_one_table, A.sell_ptr.p + row0 / 64, A.sell_ntab.p, A.sell_tab.p,
                            A.sell_code.p, x, y, b, dinv, scale, xrow, A.sell_vtab.p, A.sell_tile_nseg.p, A.sell_tile_seg.p);
-        if (A.sell_nunstaged > 0)
+        if (A.sell_nunstaged > 0 && !fold)
             hipLaunchKernelGGL((sell_tiles_kernel<MODE>), dim3(A.sell_nunstaged), dim3(256), 0, s, A.sell_nunstaged, A.sell_unstaged.p,
                                nrows, row0, A.sell_ptr.p + row0 / 64, A.sell_col.p, A.sell_val.p, A.sell_ntab.p, A.sell_tab.p,
                                A.sell_code.p, x, y, b, dinv, scale, xrow, A.sell_vtab.p);
